@@ -1,0 +1,193 @@
+/*
+ * qmpc.h -- C ABI of the MI355X-native batched quaternion-MPC inner loop.
+ *
+ * This is the drop-in boundary for ONE hot path of zixinz990/quaternion-mpc:
+ * the per-tick solve inside `legged::QuatMpc::grf_update`
+ * (reference legged_ctrl/src/mpc/QuatMpc.cpp:217-265: ALTRO set-up, Solve(),
+ * GetInput(0)).  The reference has no FFI layer; its seam is the C++ virtual
+ * class `legged::LeggedMpc` (legged_ctrl/include/mpc/LeggedMpc.h:21-28).  The
+ * host-side C++ class `legged::QuatMpcHip` (quaternion-mpc_amd/host/QuatMpcHip.h)
+ * keeps that virtual surface and calls the functions below instead of
+ * constructing an `altro::ALTROSolver`.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in any signature (streams are void*)
+ *   - all reals are IEEE double (the reference's a_float, QuatMpc.cpp:196)
+ *     except the knot spacing, which the reference's dynamics callbacks receive
+ *     as `float h` (legged_ctrl/src/utils/AltroUtils.cpp:10,79) -- kept here
+ *   - quaternions are (w, x, y, z)       (QuaternionUtils.cpp:8)
+ *   - 3x3 matrices are row-major; foot_pos_body is 3x4 COLUMN-major, i.e.
+ *     foot_pos_body[3*leg + axis], the memory layout of the reference's
+ *     Eigen::Matrix<double,3,4> (LeggedState.h:60)
+ *   - leg order FL, FR, RL, RR                     (BaseInterface.cpp:11)
+ *   - forces are BODY-frame, 3 per leg, as `optimized_input[0:12]`
+ *     (QuatMpc.cpp:269)
+ *   - nothing throws or aborts across this boundary; every entry point returns
+ *     a qmpc_status and every instance gets its own status word.
+ */
+#ifndef QMPC_H_
+#define QMPC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QMPC_NX 13      /* full state  [p(3) q(4) v(3) w(3)]      QuatMpc.cpp:28  */
+#define QMPC_NE 12      /* error state [dp(3) phi(3) dv(3) dw(3)] QuatMpc.cpp:212 */
+#define QMPC_NU 12      /* 4 legs x (fx,fy,fz) body frame         QuatMpc.cpp:29  */
+#define QMPC_NLEG 4     /* LeggedParams.h:9 */
+#define QMPC_NC 24      /* friction-cone rows per knot            QuatMpc.cpp:229 */
+#define QMPC_MAX_HORIZON 32
+
+/* ---- status codes (call-level and per-instance) -------------------------- */
+typedef enum qmpc_status {
+  QMPC_OK = 0,              /* converged to the stated tolerances              */
+  QMPC_MAX_ITER = 1,        /* iteration cap hit; forces are the last iterate
+                               (this is what the reference silently returns:
+                               SolveStatus ignored at QuatMpc.cpp:256)          */
+  QMPC_NO_CONTACT = 2,      /* no stance leg: reference computes 0/0 at
+                               QuatMpc.cpp:122; we return zero forces          */
+  QMPC_NAN_INPUT = 3,       /* non-finite input record; zero forces            */
+  QMPC_LINESEARCH_FAIL = 4, /* no step length reduced the merit function       */
+  QMPC_NOT_PD = 5,          /* Quu lost positive definiteness                  */
+  /* call-level only */
+  QMPC_BAD_ARGUMENT = 16,
+  QMPC_NO_DEVICE = 17,      /* HIP runtime / device missing: fail loudly       */
+  QMPC_HIP_ERROR = 18,
+  QMPC_BATCH_TOO_LARGE = 19
+} qmpc_status;
+
+/* ---- solver mode --------------------------------------------------------- */
+typedef enum qmpc_mode {
+  /* Converged KKT point of the NLP the reference poses (default): primal-dual
+     interior point on the iLQR/Riccati core, run to tol_step / ipm_mu_final.   */
+  QMPC_MODE_CONVERGED = 0,
+  /* Reference-style truncated AL-iLQR: iterations_max=10, penalty_scaling=20
+     (QuatMpc.cpp:22,26) and the upstream ALTRO tolerances (1e-4).             */
+  QMPC_MODE_REFERENCE = 1
+} qmpc_mode;
+
+/* ---- shared, read-only problem parameters -------------------------------- */
+/* Sources: legged_ctrl/config/gazebo_go1_quat_mpc.yaml:36-75,115-122 and
+ * LeggedState.h:160-244 (LeggedParam). */
+typedef struct qmpc_params {
+  int32_t horizon;          /* N knots; param.mpc_horizon (yaml: 20)           */
+  float   h;                /* knot spacing [s] AS FLOAT = (float)(mpc_update_period/1000) */
+  double  h_ref;            /* knot spacing used by the reference trajectory,
+                               double: i*h/1000.0 at QuatMpc.cpp:156-157       */
+  double  mass;             /* param.robot_mass                                */
+  double  inertia[9];       /* row-major; QuatMpc passes 1.2*trunk_inertia (QuatMpc.cpp:182) */
+  double  q_weights[13];    /* diag Q on the FULL state                        */
+  double  r_weights[12];    /* diag R                                          */
+  double  w;                /* quaternion cost weight  w*(1-|qref'q|)          */
+  double  mu;               /* friction coefficient                            */
+  double  fz_max;
+  int32_t mode;             /* qmpc_mode                                       */
+  int32_t iterations_max;   /* both modes (reference: 10, QuatMpc.cpp:22)      */
+  /* reference mode: AL-iLQR options (AltroOptions at QuatMpc.cpp:21-26 +
+     upstream ALTRO defaults)                                                  */
+  double  penalty_initial;
+  double  penalty_scaling;
+  double  penalty_max;
+  double  tol_stationarity;
+  double  tol_feasibility;        /* both modes (cone violation / |c+s|)       */
+  double  tol_cost_intermediate;  /* dual update trigger                       */
+  /* converged mode: interior-point options                                    */
+  double  tol_step;               /* stop when |dU|_inf <= tol_step [N] ...     */
+  double  ipm_mu_final;           /* ... and the barrier is <= ipm_mu_final    */
+  double  ipm_sigma;              /* centering parameter                       */
+  double  ipm_sigma_fast;         /* centering once full steps are taken       */
+  double  ipm_tau;                /* fraction to the boundary                  */
+  int32_t linesearch_max;         /* reference mode: max halvings              */
+  /* parity switches for the reference's quirks */
+  int32_t drop_ang_vel;     /* 1: x_init[10:13]=0 (comma-initialiser bug at
+                               QuatMpc.cpp:242-245); 0: use ang_vel_body       */
+  int32_t reserved_;
+} qmpc_params;
+
+/* Fill *p with the Go1 values of gazebo_go1_quat_mpc.yaml and the solver
+ * defaults for `mode`.  horizon: 10 or 20 in BASELINE.json. */
+void qmpc_default_params(qmpc_params* p, int32_t horizon, int32_t mode);
+
+/* ---- one MPC instance ----------------------------------------------------
+ * Exactly the LeggedState fields grf_update reads, 48
+ * doubles = 384 B, so one wavefront fetches one record with one coalesced
+ * 8-byte-per-lane load. */
+typedef struct qmpc_input {
+  double quat[4];           /* fbk.torso_quat (w,x,y,z)       QuatMpc.cpp:236-239 */
+  double rot[9];            /* fbk.torso_rot_mat, body->world :184-186,203,213   */
+  double lin_vel_body[3];   /* R' * fbk.torso_lin_vel_world   :231               */
+  double ang_vel_body[3];   /* fbk.torso_ang_vel_body (dropped when drop_ang_vel) */
+  double foot_pos_body[12]; /* fbk.foot_pos_body, 3x4 col-major                  */
+  double contacts[4];       /* ctrl.plan_contacts as 0.0 / 1.0 :118-125          */
+  double pos_ref_body[3];   /* torso_pos_d_body_filtered      :156-158           */
+  double vel_ref_body[3];   /* torso_lin_vel_d_body_filtered  :156-157,169       */
+  double acc_ref_body[3];   /* 0 in QuatMpc; lets the accelerating reference of
+                               TestAltroTrotQuatMpc.cpp:67-70 be expressed       */
+  double quat_d[4];         /* ctrl.torso_quat_d AFTER the :128-137 update       */
+} qmpc_input;
+
+/* ---- per-instance result ------------------------------------------------- */
+typedef struct qmpc_info {
+  int32_t status;           /* qmpc_status                                     */
+  int32_t iterations;       /* AL-iLQR iterations taken                        */
+  double  cost;             /* final (un-augmented) objective                  */
+  double  max_violation;    /* max(c,0) over all cone rows                     */
+  double  last_step;        /* |dU|_inf of the final iteration [N]             */
+  double  penalty;          /* final AL penalty                                */
+} qmpc_info;
+
+typedef struct qmpc_handle qmpc_handle;
+
+/* ---- lifetime ------------------------------------------------------------ */
+/* Creates a solver bound to HIP device `device` with capacity for `max_batch`
+ * instances.  Fails with QMPC_NO_DEVICE when there is no GPU: there is NO CPU
+ * fallback behind this library. */
+qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t device,
+                        qmpc_handle** out);
+qmpc_status qmpc_set_params(qmpc_handle* h, const qmpc_params* params);
+void        qmpc_destroy(qmpc_handle* h);
+
+/* ---- solve --------------------------------------------------------------- */
+/* Synchronous, host buffers (replaces QuatMpc.cpp:217-265 for `batch`
+ * independent LeggedStates).  forces_body: [batch][12]; info may be NULL;
+ * traj_u ([batch][N][12]) and traj_x ([batch][N+1][13]) may be NULL.
+ * batch == 1 keeps the blocking semantics of the reference's mpc_thread
+ * (Main.cpp:106-108). */
+qmpc_status qmpc_solve(qmpc_handle* h, int32_t batch, const qmpc_input* in,
+                       double* forces_body, qmpc_info* info);
+qmpc_status qmpc_solve_traj(qmpc_handle* h, int32_t batch, const qmpc_input* in,
+                            double* forces_body, qmpc_info* info,
+                            double* traj_u, double* traj_x);
+
+/* Stream-ordered, DEVICE buffers (inputs already resident in HBM).  `stream`
+ * is a hipStream_t passed as void* (NULL = the handle's own stream).  Nothing
+ * is synchronised; pair with qmpc_wait or your own stream sync. */
+qmpc_status qmpc_solve_device(qmpc_handle* h, int32_t batch, const qmpc_input* d_in,
+                              double* d_forces_body, qmpc_info* d_info, void* stream);
+qmpc_status qmpc_wait(qmpc_handle* h);
+
+/* Time (ms, HIP events on the launch stream) of the most recent
+ * qmpc_solve_device / qmpc_solve kernel, after it completed. */
+qmpc_status qmpc_last_kernel_ms(qmpc_handle* h, float* ms);
+
+/* Batched linearisation only: for every instance and knot
+ * k<N, roll out x from the reference's initial guess U=u_ref and return the
+ * error-state Jacobians  Abar [batch][N][12][12], Bbar [batch][N][12][12]
+ * (row-major) and the rollout X [batch][N+1][13].  Host buffers. */
+qmpc_status qmpc_linearize(qmpc_handle* h, int32_t batch, const qmpc_input* in,
+                           double* Abar, double* Bbar, double* X);
+
+/* ---- introspection -------------------------------------------------------- */
+const char* qmpc_status_string(int32_t status);
+const char* qmpc_version(void);
+int32_t     qmpc_sizeof_input(void);   /* ABI guards for foreign-language bindings */
+int32_t     qmpc_sizeof_params(void);
+int32_t     qmpc_sizeof_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QMPC_H_ */

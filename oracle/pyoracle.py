@@ -1,0 +1,129 @@
+"""ctypes loader for the CPU oracle (oracle/libqmpc_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: import this from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import importlib.util
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ORACLE_DIR = Path(__file__).resolve().parent
+REPO_DIR = ORACLE_DIR.parent
+LIB_PATH = ORACLE_DIR / "libqmpc_oracle.so"
+
+
+def _load_pkg():
+    name = "quaternion_mpc_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(
+        name, REPO_DIR / "quaternion-mpc_amd" / "__init__.py",
+        submodule_search_locations=[str(REPO_DIR / "quaternion-mpc_amd")])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+pkg = _load_pkg()
+Params, INPUT_DTYPE, INFO_DTYPE = pkg.Params, pkg.INPUT_DTYPE, pkg.INFO_DTYPE
+
+
+def build(force: bool = False) -> Path:
+    srcs = [ORACLE_DIR / f for f in ("qo_srbd.c", "qo_altro.c", "qo_quatmpc.c", "qo_kat.c",
+                                     "qo_linalg.h", "qo_srbd.h", "qo_altro.h", "qo_quatmpc.h")]
+    srcs.append(REPO_DIR / "include" / "qmpc.h")
+    if force or not LIB_PATH.exists() or any(
+            s.exists() and s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs):
+        if all(s.exists() for s in srcs):
+            subprocess.run(["make", "-C", str(ORACLE_DIR), "-B"], check=True, capture_output=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(str(LIB_PATH))
+        vp, i32, dp = C.c_void_p, C.c_int32, C.POINTER(C.c_double)
+        _lib.qo_default_params.argtypes = [C.POINTER(Params), i32, i32]
+        _lib.qo_default_params.restype = None
+        _lib.qo_solve_batch.argtypes = [C.POINTER(Params), i32, vp, vp, vp, vp, vp, i32]
+        _lib.qo_solve_batch.restype = i32
+        _lib.qo_solve_one.argtypes = [C.POINTER(Params), vp, vp, vp, vp, vp, i32]
+        _lib.qo_solve_one.restype = i32
+        _lib.qo_linearize.argtypes = [C.POINTER(Params), i32, vp, vp, vp, vp]
+        _lib.qo_linearize.restype = i32
+        _lib.qo_build_reference.argtypes = [C.POINTER(Params), vp, vp, vp]
+        _lib.qo_kat_double_integrator.argtypes = [i32, dp, i32]
+        _lib.qo_kat_double_integrator.restype = i32
+        _lib.qo_kat_pendulum_midpoint.argtypes = [dp, dp]
+        _lib.qo_kat_pendulum_swingup.argtypes = [dp, i32]
+        _lib.qo_kat_pendulum_swingup.restype = i32
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_params(horizon: int = 10, mode: int = 0) -> Params:
+    p = Params()
+    lib().qo_default_params(C.byref(p), horizon, mode)
+    return p
+
+
+def solve(params: Params, inputs: np.ndarray, threads: int = 1, want_traj: bool = False):
+    inputs = np.ascontiguousarray(inputs, dtype=INPUT_DTYPE)
+    B, N = inputs.shape[0], params.horizon
+    forces = np.zeros((B, 12))
+    info = np.zeros(B, dtype=INFO_DTYPE)
+    tu = np.zeros((B, N, 12)) if want_traj else None
+    tx = np.zeros((B, N + 1, 13)) if want_traj else None
+    lib().qo_solve_batch(C.byref(params), B, _ptr(inputs), _ptr(forces), _ptr(info), _ptr(tu), _ptr(tx), threads)
+    if want_traj:
+        return forces, info, tu, tx
+    return forces, info
+
+
+def solve_verbose(params: Params, inp: np.ndarray):
+    inp = np.ascontiguousarray(inp, dtype=INPUT_DTYPE)
+    f = np.zeros(12)
+    info = np.zeros(1, dtype=INFO_DTYPE)
+    lib().qo_solve_one(C.byref(params), _ptr(inp), _ptr(f), _ptr(info), None, None, 1)
+    return f, info
+
+
+def linearize(params: Params, inputs: np.ndarray):
+    inputs = np.ascontiguousarray(inputs, dtype=INPUT_DTYPE)
+    B, N = inputs.shape[0], params.horizon
+    A = np.zeros((B, N, 12, 12)); Bm = np.zeros((B, N, 12, 12)); X = np.zeros((B, N + 1, 13))
+    lib().qo_linearize(C.byref(params), B, _ptr(inputs), _ptr(A), _ptr(Bm), _ptr(X))
+    return A, Bm, X
+
+
+def kat_double_integrator(which: int, verbose: int = 0):
+    out = (C.c_double * 8)()
+    lib().qo_kat_double_integrator(which, out, verbose)
+    return list(out)
+
+
+def kat_pendulum_midpoint():
+    xn = (C.c_double * 2)(); J = (C.c_double * 6)()
+    lib().qo_kat_pendulum_midpoint(xn, J)
+    return np.array(xn), np.array(J).reshape(3, 2).T  # col-major 2x3
+
+
+def kat_pendulum_swingup(verbose: int = 0):
+    out = (C.c_double * 8)()
+    lib().qo_kat_pendulum_swingup(out, verbose)
+    return list(out)

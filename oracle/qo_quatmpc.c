@@ -1,0 +1,295 @@
+/*
+ * qo_quatmpc.c -- CPU restatement of legged::QuatMpc::grf_update's problem
+ * construction and solve (legged_ctrl/src/mpc/QuatMpc.cpp:109-276) on top of
+ * the restated model (qo_srbd.c) and solver scheme (qo_altro.c).
+ * TEST INFRASTRUCTURE ONLY: it checks the HIP path and is timed as the
+ * cpu_baseline ("port") in bench.py; the product never calls it.
+ */
+#include "qo_quatmpc.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "qo_altro.h"
+#include "qo_linalg.h"
+#include "qo_srbd.h"
+
+/* legged_ctrl/config/gazebo_go1_quat_mpc.yaml:36-75,115-122; QuatMpc.cpp:21-26,182 */
+void qo_default_params(qmpc_params* p, int32_t horizon, int32_t mode) {
+  memset(p, 0, sizeof *p);
+  p->horizon = horizon;
+  p->h = (float)(10.0 / 1000.0);  /* mpc_update_period: 10.0 [ms] -> float seconds */
+  p->h_ref = 10.0 / 1000.0;
+  p->mass = 12.84;
+  const double trunk[3] = {0.0168128557, 0.063009565, 0.0716547275};
+  for (int a = 0; a < 3; ++a) p->inertia[4 * a] = 1.2 * trunk[a]; /* QuatMpc.cpp:182 */
+  const double q[13] = {2.5, 2.5, 10.0, 0, 0, 0, 0, 0.1, 0.1, 0.1, 0.15, 0.15, 0.15};
+  memcpy(p->q_weights, q, sizeof q);
+  for (int j = 0; j < 12; ++j) p->r_weights[j] = 0.000001;
+  p->w = 50.0;
+  p->mu = 0.7;
+  p->fz_max = 100.0;
+  p->mode = mode;
+  p->linesearch_max = 10;
+  p->drop_ang_vel = 1;
+  qo_options o;
+  qo_default_options(&o, mode);
+  p->iterations_max = o.iterations_max;
+  p->penalty_initial = o.penalty_initial;
+  p->penalty_scaling = o.penalty_scaling;
+  p->penalty_max = o.penalty_max;
+  p->tol_stationarity = o.tol_stationarity;
+  p->tol_feasibility = o.tol_feasibility;
+  p->tol_cost_intermediate = o.tol_cost_intermediate;
+  p->tol_step = o.tol_step;
+  p->ipm_mu_final = o.ipm_mu_final;
+  p->ipm_sigma = o.ipm_sigma;
+  p->ipm_sigma_fast = o.ipm_sigma_fast;
+  p->ipm_tau = o.ipm_tau;
+  if (mode == QMPC_MODE_REFERENCE) {
+    p->iterations_max = 10;    /* QuatMpc.cpp:22 */
+    p->penalty_scaling = 20.0; /* QuatMpc.cpp:26 */
+  }
+}
+
+typedef struct mpc_ctx {
+  qo_srbd_model model;
+  double mu, fz_max;
+  double CR[18];
+  double row_enable[24];
+} mpc_ctx;
+
+static void dyn_cb(void* ctx, int k, double* xn, const double* x, const double* u, float h) {
+  (void)k;
+  qo_srbd_discrete_dynamics(&((mpc_ctx*)ctx)->model, xn, x, u, h);
+}
+static void jac_cb(void* ctx, int k, double* jac, const double* x, const double* u, float h) {
+  (void)k;
+  qo_srbd_discrete_jacobian(&((mpc_ctx*)ctx)->model, jac, x, u, h);
+}
+/* QuatMpc.cpp:194-205 */
+static void cone_con(void* ctx, int k, double* c, const double* x, const double* u) {
+  (void)k; (void)x;
+  const mpc_ctx* m = (const mpc_ctx*)ctx;
+  qo_cone_eval(m->mu, m->fz_max, m->model.rot, m->model.contacts, u, c);
+}
+/* QuatMpc.cpp:207-215: 24 x 24 col-major, block C_mat*R at rows 6i, cols 12+3i.
+ * Swing-leg blocks are left zero (their forces are pinned to 0). */
+static void cone_jac(void* ctx, int k, double* jac, const double* x, const double* u) {
+  (void)k; (void)x; (void)u;
+  const mpc_ctx* m = (const mpc_ctx*)ctx;
+  for (int i = 0; i < 4; ++i) {
+    if (m->model.contacts[i] == 0.0) continue;
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 3; ++c) jac[(6 * i + r) + 24 * (12 + 3 * i + c)] = m->CR[3 * r + c];
+  }
+}
+
+void qo_build_reference(const qmpc_params* p, const qmpc_input* in, double* xref, double* uref) {
+  /* QuatMpc.cpp:118-125 */
+  int nc = 0;
+  for (int i = 0; i < 4; ++i) if (in->contacts[i] != 0.0) nc++;
+  memset(uref, 0, sizeof(double) * 12);
+  for (int i = 0; i < 4; ++i)
+    uref[3 * i + 2] = in->contacts[i] * p->mass * 9.81 / (double)nc;
+  /* QuatMpc.cpp:148-176 (h there is in ms: i*h/1000.0, left-to-right) */
+  const double h_ms = p->h_ref * 1000.0;
+  for (int k = 0; k <= p->horizon; ++k) {
+    double* xr = &xref[13 * k];
+    memset(xr, 0, sizeof(double) * 13);
+    const double t = (double)k * p->h_ref;
+    xr[0] = in->pos_ref_body[0] + in->vel_ref_body[0] * k * h_ms / 1000.0 +
+            0.5 * in->acc_ref_body[0] * t * t;
+    xr[1] = in->pos_ref_body[1] + in->vel_ref_body[1] * k * h_ms / 1000.0 +
+            0.5 * in->acc_ref_body[1] * t * t;
+    xr[2] = in->pos_ref_body[2] + 0.5 * in->acc_ref_body[2] * t * t;
+    for (int a = 0; a < 4; ++a) xr[3 + a] = in->quat_d[a];
+    for (int a = 0; a < 3; ++a) xr[7 + a] = in->vel_ref_body[a] + in->acc_ref_body[a] * t;
+  }
+}
+
+static int input_is_finite(const qmpc_input* in) {
+  const double* v = (const double*)in;
+  for (size_t i = 0; i < sizeof(qmpc_input) / sizeof(double); ++i)
+    if (!isfinite(v[i])) return 0;
+  return 1;
+}
+
+static void setup_problem(const qmpc_params* p, const qmpc_input* in, mpc_ctx* ctx,
+                          qo_problem* prob) {
+  const int N = p->horizon;
+  memset(ctx, 0, sizeof *ctx);
+  memcpy(ctx->model.foot_pos_body, in->foot_pos_body, sizeof in->foot_pos_body);
+  memcpy(ctx->model.inertia, p->inertia, sizeof p->inertia);
+  ctx->model.mass = p->mass;
+  memcpy(ctx->model.rot, in->rot, sizeof in->rot);
+  for (int i = 0; i < 4; ++i) ctx->model.contacts[i] = (in->contacts[i] != 0.0) ? 1.0 : 0.0;
+  qo_srbd_prepare(&ctx->model);
+  ctx->mu = p->mu;
+  ctx->fz_max = p->fz_max;
+  qo_cone_block(p->mu, in->rot, ctx->CR);
+
+  memset(prob, 0, sizeof *prob);
+  prob->n = 13; prob->m = 12; prob->N = N;
+  prob->use_quaternion = 1;       /* QuatMpc.cpp:24 */
+  prob->quat_start_index = 3;     /* QuatMpc.cpp:25 */
+  prob->h = p->h;
+  prob->dyn = dyn_cb; prob->jac = jac_cb; prob->dyn_ctx = ctx;
+  double xref[(QMPC_MAX_HORIZON + 1) * 13], uref[12];
+  qo_build_reference(p, in, xref, uref);
+  for (int k = 0; k <= N; ++k) {
+    memcpy(prob->Q[k], p->q_weights, sizeof(double) * 13);
+    memcpy(prob->R[k], p->r_weights, sizeof(double) * 12);
+    memcpy(prob->xref[k], &xref[13 * k], sizeof(double) * 13);
+    memcpy(prob->uref[k], uref, sizeof(double) * 12);
+    prob->w[k] = p->w;
+  }
+  /* SetConstraint(..., 24, INEQUALITY, "friction cone", 0, horizon): knots 0..N-1 */
+  prob->ncon = 1;
+  prob->con[0].type = QO_INEQUALITY;
+  prob->con[0].p = 24;
+  prob->con[0].k_start = 0;
+  prob->con[0].k_stop = N;
+  prob->con[0].con = cone_con;
+  prob->con[0].jac = cone_jac;
+  prob->con[0].ctx = ctx;
+  for (int i = 0; i < 24; ++i) ctx->row_enable[i] = ctx->model.contacts[i / 6];
+  prob->con[0].row_enable = ctx->row_enable;
+  /* x_init, QuatMpc.cpp:231-246 (angular velocity dropped by the ';' at :242) */
+  prob->x0[3] = in->quat[0]; prob->x0[4] = in->quat[1];
+  prob->x0[5] = in->quat[2]; prob->x0[6] = in->quat[3];
+  for (int a = 0; a < 3; ++a) {
+    prob->x0[7 + a] = in->lin_vel_body[a];
+    prob->x0[10 + a] = p->drop_ang_vel ? 0.0 : in->ang_vel_body[a];
+  }
+}
+
+static void options_from_params(const qmpc_params* p, qo_options* o, int verbose) {
+  memset(o, 0, sizeof *o);
+  o->mode = p->mode;
+  o->iterations_max = p->iterations_max;
+  o->penalty_initial = p->penalty_initial;
+  o->penalty_scaling = p->penalty_scaling;
+  o->penalty_max = p->penalty_max;
+  o->tol_stationarity = p->tol_stationarity;
+  o->tol_feasibility = p->tol_feasibility;
+  o->tol_cost_intermediate = p->tol_cost_intermediate;
+  o->tol_step = p->tol_step;
+  o->linesearch_max = p->linesearch_max;
+  o->verbose = verbose;
+  o->ipm_iterations_max = (p->mode == QMPC_MODE_CONVERGED) ? p->iterations_max : 0;
+  o->ipm_mu_final = p->ipm_mu_final;
+  o->ipm_sigma = p->ipm_sigma;
+  o->ipm_sigma_fast = p->ipm_sigma_fast;
+  o->ipm_tau = p->ipm_tau;
+}
+
+int qo_solve_one(const qmpc_params* p, const qmpc_input* in, double* forces, qmpc_info* info,
+                 double* traj_u, double* traj_x, int verbose) {
+  const int N = p->horizon;
+  qmpc_info inf;
+  memset(&inf, 0, sizeof inf);
+  memset(forces, 0, sizeof(double) * 12);
+  int nc = 0;
+  for (int i = 0; i < 4; ++i) if (in->contacts[i] != 0.0) nc++;
+  if (!input_is_finite(in)) inf.status = QMPC_NAN_INPUT;
+  else if (nc == 0) inf.status = QMPC_NO_CONTACT;
+  if (inf.status != QMPC_OK) {
+    if (info) *info = inf;
+    if (traj_u) memset(traj_u, 0, sizeof(double) * N * 12);
+    if (traj_x) memset(traj_x, 0, sizeof(double) * (N + 1) * 13);
+    return inf.status;
+  }
+  mpc_ctx* ctx = (mpc_ctx*)malloc(sizeof(mpc_ctx));
+  qo_problem* prob = (qo_problem*)malloc(sizeof(qo_problem));
+  setup_problem(p, in, ctx, prob);
+  qo_options o;
+  options_from_params(p, &o, verbose);
+  double X[(QMPC_MAX_HORIZON + 1) * 13], U[QMPC_MAX_HORIZON * 12];
+  /* initial guess: SetInput(u_ref) on all knots (QuatMpc.cpp:253); the state
+   * guess x_ref (:250-252) is overwritten by the solver's initial rollout */
+  for (int k = 0; k < N; ++k) memcpy(&U[12 * k], prob->uref[0], sizeof(double) * 12);
+  qo_result r;
+  qo_altro_solve(prob, &o, X, U, &r);
+  memcpy(forces, U, sizeof(double) * 12); /* GetInput(u, 0), QuatMpc.cpp:264-265 */
+  inf.status = r.status;
+  inf.iterations = r.iterations;
+  inf.cost = r.cost;
+  inf.max_violation = r.max_violation;
+  inf.last_step = r.last_step;
+  inf.penalty = r.penalty;
+  if (info) *info = inf;
+  if (traj_u) memcpy(traj_u, U, sizeof(double) * N * 12);
+  if (traj_x) memcpy(traj_x, X, sizeof(double) * (N + 1) * 13);
+  free(ctx);
+  free(prob);
+  return inf.status;
+}
+
+typedef struct batch_job {
+  const qmpc_params* p;
+  const qmpc_input* in;
+  double* forces;
+  qmpc_info* info;
+  double* traj_u;
+  double* traj_x;
+  int begin, end;
+} batch_job;
+
+static void* batch_worker(void* arg) {
+  batch_job* j = (batch_job*)arg;
+  const int N = j->p->horizon;
+  for (int b = j->begin; b < j->end; ++b)
+    qo_solve_one(j->p, &j->in[b], &j->forces[12 * b], j->info ? &j->info[b] : NULL,
+                 j->traj_u ? &j->traj_u[(size_t)b * N * 12] : NULL,
+                 j->traj_x ? &j->traj_x[(size_t)b * (N + 1) * 13] : NULL, 0);
+  return NULL;
+}
+
+int qo_solve_batch(const qmpc_params* p, int32_t batch, const qmpc_input* in, double* forces,
+                   qmpc_info* info, double* traj_u, double* traj_x, int32_t threads) {
+  if (threads < 1) threads = 1;
+  if (threads > batch) threads = batch > 0 ? batch : 1;
+  batch_job* jobs = (batch_job*)calloc((size_t)threads, sizeof(batch_job));
+  pthread_t* tid = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+  for (int t = 0; t < threads; ++t) {
+    jobs[t].p = p; jobs[t].in = in; jobs[t].forces = forces; jobs[t].info = info;
+    jobs[t].traj_u = traj_u; jobs[t].traj_x = traj_x;
+    jobs[t].begin = (int)((long long)batch * t / threads);
+    jobs[t].end = (int)((long long)batch * (t + 1) / threads);
+  }
+  if (threads == 1) {
+    batch_worker(&jobs[0]);
+  } else {
+    for (int t = 0; t < threads; ++t) pthread_create(&tid[t], NULL, batch_worker, &jobs[t]);
+    for (int t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
+  }
+  free(jobs);
+  free(tid);
+  return 0;
+}
+
+int qo_linearize(const qmpc_params* p, int32_t batch, const qmpc_input* in, double* Abar,
+                 double* Bbar, double* X) {
+  const int N = p->horizon;
+  mpc_ctx* ctx = (mpc_ctx*)malloc(sizeof(mpc_ctx));
+  qo_problem* prob = (qo_problem*)malloc(sizeof(qo_problem));
+  for (int b = 0; b < batch; ++b) {
+    setup_problem(p, &in[b], ctx, prob);
+    double* Xb = &X[(size_t)b * (N + 1) * 13];
+    memcpy(Xb, prob->x0, sizeof(double) * 13);
+    double jac[13 * 25];
+    for (int k = 0; k < N; ++k)
+      qo_srbd_discrete_dynamics(&ctx->model, &Xb[13 * (k + 1)], &Xb[13 * k], prob->uref[0], p->h);
+    for (int k = 0; k < N; ++k) {
+      qo_srbd_discrete_jacobian(&ctx->model, jac, &Xb[13 * k], prob->uref[0], p->h);
+      qo_srbd_project(jac, &Xb[13 * k], &Xb[13 * (k + 1)],
+                      &Abar[((size_t)b * N + k) * 144], &Bbar[((size_t)b * N + k) * 144]);
+    }
+  }
+  free(ctx);
+  free(prob);
+  return 0;
+}

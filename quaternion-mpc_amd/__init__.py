@@ -1,0 +1,262 @@
+"""quaternion-mpc_amd -- MI355X-native batched quaternion-MPC inner loop.
+
+Python is plumbing only (tests, bench, multi-GPU launch): the product is the
+C-ABI shared library ``csrc/libqmpc_hip.so`` declared in ``include/qmpc.h`` and
+the C++ host class in ``host/``.  This module mirrors the C records with ctypes
+and loads the library.  There is NO CPU fallback: if the HIP library is
+missing or no GPU is visible, calls fail loudly.
+
+The directory name contains a hyphen, so load it with
+``importlib`` (see ``tests/conftest.py`` / ``__graft_entry__.py``) under the
+module name ``quaternion_mpc_amd``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+REPO_DIR = PKG_DIR.parent
+LIB_PATH = PKG_DIR / "csrc" / "libqmpc_hip.so"
+
+NX, NE, NU, NLEG, NC = 13, 12, 12, 4, 24
+
+# status codes (include/qmpc.h)
+OK, MAX_ITER, NO_CONTACT, NAN_INPUT, LINESEARCH_FAIL, NOT_PD = 0, 1, 2, 3, 4, 5
+BAD_ARGUMENT, NO_DEVICE, HIP_ERROR, BATCH_TOO_LARGE = 16, 17, 18, 19
+MODE_CONVERGED, MODE_REFERENCE = 0, 1
+
+
+class Params(C.Structure):
+    """struct qmpc_params (include/qmpc.h)."""
+
+    _fields_ = [
+        ("horizon", C.c_int32),
+        ("h", C.c_float),
+        ("h_ref", C.c_double),
+        ("mass", C.c_double),
+        ("inertia", C.c_double * 9),
+        ("q_weights", C.c_double * 13),
+        ("r_weights", C.c_double * 12),
+        ("w", C.c_double),
+        ("mu", C.c_double),
+        ("fz_max", C.c_double),
+        ("mode", C.c_int32),
+        ("iterations_max", C.c_int32),
+        ("penalty_initial", C.c_double),
+        ("penalty_scaling", C.c_double),
+        ("penalty_max", C.c_double),
+        ("tol_stationarity", C.c_double),
+        ("tol_feasibility", C.c_double),
+        ("tol_cost_intermediate", C.c_double),
+        ("tol_step", C.c_double),
+        ("ipm_mu_final", C.c_double),
+        ("ipm_sigma", C.c_double),
+        ("ipm_sigma_fast", C.c_double),
+        ("ipm_tau", C.c_double),
+        ("linesearch_max", C.c_int32),
+        ("drop_ang_vel", C.c_int32),
+        ("reserved_", C.c_int32),
+    ]
+
+    def copy(self) -> "Params":
+        out = Params()
+        C.memmove(C.byref(out), C.byref(self), C.sizeof(Params))
+        return out
+
+
+# struct qmpc_input as a numpy structured dtype: 48 doubles, 384 B
+INPUT_DTYPE = np.dtype(
+    [
+        ("quat", "<f8", (4,)),
+        ("rot", "<f8", (9,)),
+        ("lin_vel_body", "<f8", (3,)),
+        ("ang_vel_body", "<f8", (3,)),
+        ("foot_pos_body", "<f8", (12,)),
+        ("contacts", "<f8", (4,)),
+        ("pos_ref_body", "<f8", (3,)),
+        ("vel_ref_body", "<f8", (3,)),
+        ("acc_ref_body", "<f8", (3,)),
+        ("quat_d", "<f8", (4,)),
+    ],
+    align=False,
+)
+assert INPUT_DTYPE.itemsize == 48 * 8
+
+# struct qmpc_info: 2 x int32 + 4 doubles = 40 B
+INFO_DTYPE = np.dtype(
+    [
+        ("status", "<i4"),
+        ("iterations", "<i4"),
+        ("cost", "<f8"),
+        ("max_violation", "<f8"),
+        ("last_step", "<f8"),
+        ("penalty", "<f8"),
+    ],
+    align=False,
+)
+assert INFO_DTYPE.itemsize == 40
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class QmpcError(RuntimeError):
+    def __init__(self, code: int, what: str):
+        super().__init__(f"{what}: qmpc_status {code}")
+        self.code = code
+
+
+def load_library(path: os.PathLike | None = None) -> C.CDLL:
+    """dlopen the HIP library.  Raises (never falls back) when it is absent."""
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise FileNotFoundError(
+            f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+        )
+    lib = C.CDLL(str(p))
+    vp, i32 = C.c_void_p, C.c_int32
+    lib.qmpc_default_params.argtypes = [C.POINTER(Params), i32, i32]
+    lib.qmpc_default_params.restype = None
+    lib.qmpc_create.argtypes = [C.POINTER(Params), i32, i32, C.POINTER(vp)]
+    lib.qmpc_create.restype = i32
+    lib.qmpc_set_params.argtypes = [vp, C.POINTER(Params)]
+    lib.qmpc_set_params.restype = i32
+    lib.qmpc_destroy.argtypes = [vp]
+    lib.qmpc_destroy.restype = None
+    lib.qmpc_solve.argtypes = [vp, i32, vp, vp, vp]
+    lib.qmpc_solve.restype = i32
+    lib.qmpc_solve_traj.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    lib.qmpc_solve_traj.restype = i32
+    lib.qmpc_solve_device.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.qmpc_solve_device.restype = i32
+    lib.qmpc_wait.argtypes = [vp]
+    lib.qmpc_wait.restype = i32
+    lib.qmpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.qmpc_last_kernel_ms.restype = i32
+    lib.qmpc_linearize.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.qmpc_linearize.restype = i32
+    lib.qmpc_status_string.argtypes = [i32]
+    lib.qmpc_status_string.restype = C.c_char_p
+    lib.qmpc_version.argtypes = []
+    lib.qmpc_version.restype = C.c_char_p
+    for name in ("qmpc_sizeof_input", "qmpc_sizeof_params", "qmpc_sizeof_info"):
+        getattr(lib, name).argtypes = []
+        getattr(lib, name).restype = i32
+    if lib.qmpc_sizeof_input() != INPUT_DTYPE.itemsize:
+        raise RuntimeError("qmpc_input ABI size mismatch")
+    if lib.qmpc_sizeof_params() != C.sizeof(Params):
+        raise RuntimeError("qmpc_params ABI size mismatch")
+    if lib.qmpc_sizeof_info() != INFO_DTYPE.itemsize:
+        raise RuntimeError("qmpc_info ABI size mismatch")
+    return lib
+
+
+EXPORTED_SYMBOLS = (
+    "qmpc_default_params",
+    "qmpc_create",
+    "qmpc_set_params",
+    "qmpc_destroy",
+    "qmpc_solve",
+    "qmpc_solve_traj",
+    "qmpc_solve_device",
+    "qmpc_wait",
+    "qmpc_last_kernel_ms",
+    "qmpc_linearize",
+    "qmpc_status_string",
+    "qmpc_version",
+    "qmpc_sizeof_input",
+    "qmpc_sizeof_params",
+    "qmpc_sizeof_info",
+)
+
+
+def default_params(horizon: int = 10, mode: int = MODE_CONVERGED, lib: C.CDLL | None = None) -> Params:
+    lib = lib or load_library()
+    p = Params()
+    lib.qmpc_default_params(C.byref(p), horizon, mode)
+    return p
+
+
+class Solver:
+    """Thin RAII wrapper over a qmpc_handle (one per GPU, single caller)."""
+
+    def __init__(self, params: Params, max_batch: int, device: int = 0, lib: C.CDLL | None = None):
+        self.lib = lib or load_library()
+        self.params = params.copy()
+        self.max_batch = int(max_batch)
+        self._h = C.c_void_p()
+        st = self.lib.qmpc_create(C.byref(self.params), self.max_batch, device, C.byref(self._h))
+        if st != OK:
+            self._h = C.c_void_p()
+            raise QmpcError(st, "qmpc_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.qmpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def set_params(self, params: Params):
+        self.params = params.copy()
+        st = self.lib.qmpc_set_params(self._h, C.byref(self.params))
+        if st != OK:
+            raise QmpcError(st, "qmpc_set_params")
+
+    def solve(self, inputs: np.ndarray, want_traj: bool = False):
+        """Host buffers in, host buffers out (H2D + kernel + D2H, synchronous)."""
+        inputs = np.ascontiguousarray(inputs, dtype=INPUT_DTYPE)
+        B, N = inputs.shape[0], self.params.horizon
+        forces = np.zeros((B, NU), dtype=np.float64)
+        info = np.zeros(B, dtype=INFO_DTYPE)
+        if want_traj:
+            tu = np.zeros((B, N, NU))
+            tx = np.zeros((B, N + 1, NX))
+            st = self.lib.qmpc_solve_traj(self._h, B, _ptr(inputs), _ptr(forces), _ptr(info), _ptr(tu), _ptr(tx))
+            if st != OK:
+                raise QmpcError(st, "qmpc_solve_traj")
+            return forces, info, tu, tx
+        st = self.lib.qmpc_solve(self._h, B, _ptr(inputs), _ptr(forces), _ptr(info))
+        if st != OK:
+            raise QmpcError(st, "qmpc_solve")
+        return forces, info
+
+    def solve_device(self, batch: int, d_in: int, d_forces: int, d_info: int, stream: int = 0):
+        """Device pointers (ints), stream-ordered, no synchronisation."""
+        st = self.lib.qmpc_solve_device(self._h, int(batch), C.c_void_p(d_in), C.c_void_p(d_forces),
+                                        C.c_void_p(d_info) if d_info else None,
+                                        C.c_void_p(stream) if stream else None)
+        if st != OK:
+            raise QmpcError(st, "qmpc_solve_device")
+
+    def wait(self):
+        st = self.lib.qmpc_wait(self._h)
+        if st != OK:
+            raise QmpcError(st, "qmpc_wait")
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        st = self.lib.qmpc_last_kernel_ms(self._h, C.byref(ms))
+        if st != OK:
+            raise QmpcError(st, "qmpc_last_kernel_ms")
+        return float(ms.value)
+
+    def linearize(self, inputs: np.ndarray):
+        inputs = np.ascontiguousarray(inputs, dtype=INPUT_DTYPE)
+        B, N = inputs.shape[0], self.params.horizon
+        A = np.zeros((B, N, NE, NE))
+        Bm = np.zeros((B, N, NE, NU))
+        X = np.zeros((B, N + 1, NX))
+        st = self.lib.qmpc_linearize(self._h, B, _ptr(inputs), _ptr(A), _ptr(Bm), _ptr(X))
+        if st != OK:
+            raise QmpcError(st, "qmpc_linearize")
+        return A, Bm, X
+
+
+from .scenarios import go1_stand_input, quat_to_rot, random_go1_trot_states  # noqa: E402,F401
