@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- quaternion-MPC solves/s on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic LeggedState
+records: `batch` independent MPC problems (Go1, 12 contact forces, horizon N),
+inputs already resident in HBM, one kernel launch per step per GPU.  With
+--gpus N > 1 the driver launches one rank per GPU (torch.distributed, RCCL);
+instances shard embarrassingly (rank r solves its own `batch` records: weak
+scaling) and ONE all_gather of the [batch,12] force block per step returns the
+results to every rank.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector = matrix peak
+W_ALG_KFLOP_PER_KNOT = 159.0     # W_alg(N) = 159 N kFLOP per solve
+
+
+def load_pkg():
+    name = "quaternion_mpc_amd"
+    spec = importlib.util.spec_from_file_location(name, REPO / "quaternion-mpc_amd" / "__init__.py",
+                                                  submodule_search_locations=[str(REPO / "quaternion-mpc_amd")])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def cpu_baseline(pkg, horizon: int, config_id: int, seconds: float = 12.0):
+    """Time the CPU oracle ("port") on a bounded sample of the same workload."""
+    from oracle import pyoracle  # checker / baseline only
+
+    cores = os.cpu_count() or 1
+    p = pyoracle.default_params(horizon, 0)
+    probe = pkg.random_go1_trot_states(4 * cores, config_id=config_id)
+    t0 = time.perf_counter()
+    pyoracle.solve(p, probe, threads=cores)
+    rate = len(probe) / max(time.perf_counter() - t0, 1e-9)
+    n = int(min(max(rate * seconds, 4 * cores), 65536))
+    rec = pkg.random_go1_trot_states(n, config_id=config_id)
+    t0 = time.perf_counter()
+    _, info = pyoracle.solve(p, rec, threads=cores)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+        "sample": f"first {n} instances of the same synthetic workload (N={horizon}), all {cores} host threads, "
+                  f"instance-parallel; oracle/ C restatement, {dt:.1f} s; mean {float(info['iterations'].mean()):.1f} iterations",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="instances per GPU per step (BASELINE config 1)")
+    ap.add_argument("--horizon", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="also compare a sample against the oracle")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: WORLD_SIZE={world} != --gpus {args.gpus}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the product path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    pkg = load_pkg()
+    lib = pkg.load_library()
+    N, B = args.horizon, args.batch
+    config_id = 2 if N == 10 else 3
+    params = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
+    solver = pkg.Solver(params, B, device=local, lib=lib)
+
+    # synthetic Go1 trot states; rank r owns instances [r*B, (r+1)*B)
+    rec = pkg.random_go1_trot_states(B, config_id=config_id, first=rank * B)
+    d_in = torch.from_numpy(rec.view(np.uint8).reshape(B, -1).copy()).cuda()
+    d_f = torch.zeros(B, 12, dtype=torch.float64, device="cuda")
+    d_info = torch.zeros(B, pkg.INFO_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    gathered = torch.zeros(world * B, 12, dtype=torch.float64, device="cuda") if world > 1 else None
+    stream = torch.cuda.current_stream()
+
+    def step():
+        solver.solve_device(B, d_in.data_ptr(), d_f.data_ptr(), d_info.data_ptr(), stream.cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, d_f)   # the single RCCL collective of the path
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ev_ms = ev0.elapsed_time(ev1)                     # HIP events on the launch stream
+    kernel_ms = ev_ms / args.steps                    # average launch duration (back-to-back launches)
+
+    info = d_info.cpu().numpy().view(pkg.INFO_DTYPE).reshape(-1)
+    n_ok = int((info["status"] == 0).sum())
+    mean_iters = float(info["iterations"].mean())
+
+    if rank == 0:
+        total = world * B * args.steps
+        value = total / elapsed
+        w_alg = W_ALG_KFLOP_PER_KNOT * 1e3 * N          # algorithmic FP64 flops per solve
+        achieved = w_alg * B / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "MPC QP solves/sec (Go1, 12 forces, N=%d)" % N,
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"Batch={B} random Go1 trot states per GPU, N={N}, converged mode "
+                                   f"(interior point to |dU|<=1e-8 N), generator seed 0x5EED000{config_id}",
+                       "batch_per_gpu": B, "horizon": N, "parallelism": f"instance-sharded x{world}",
+                       "converged": n_ok, "mean_iterations": mean_iters},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "qmpc_solve_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_flops_per_launch": w_alg * B,
+                         "note": "FP64 MFMA/vector roof (78.6 TF); algorithmic work W_alg=159*N kFLOP/solve (SURVEY 8d); "
+                                 "compulsory HBM traffic is 460 B/solve, i.e. not the binding roof"},
+        }
+        if args.check:
+            from oracle import pyoracle
+            idx = np.arange(0, B, max(B // 64, 1))
+            fo, _ = pyoracle.solve(pyoracle.default_params(N, 0), rec[idx], threads=os.cpu_count() or 1)
+            out["config"]["force_linf_vs_cpu"] = float(np.abs(d_f.cpu().numpy()[idx] - fo).max())
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, N, config_id)
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -180,6 +180,12 @@ qmpc_status qmpc_last_kernel_ms(qmpc_handle* h, float* ms);
 qmpc_status qmpc_linearize(qmpc_handle* h, int32_t batch, const qmpc_input* in,
                            double* Abar, double* Bbar, double* X);
 
+/* ---- diagnostics ----------------------------------------------------------- */
+/* C = X' * Y on [12][16] row-major tiles through the FP64 MFMA path the solver
+ * uses (host buffers of 192 doubles each).  Lets the GPU tests pin the
+ * fragment layout independently of the solver. */
+qmpc_status qmpc_selftest_mtm(int32_t device, const double* X, const double* Y, double* C);
+
 /* ---- introspection -------------------------------------------------------- */
 const char* qmpc_status_string(int32_t status);
 const char* qmpc_version(void);

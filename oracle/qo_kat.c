@@ -84,13 +84,13 @@ int qo_kat_double_integrator(int which, double* out, int verbose) {
   if (which == 0) {
     di_problem(&p, 1.0, 2.0);
     p.ncon = 1;
-    p.con[0] = (qo_constraint){QO_EQUALITY, 4, 10, 11, goal_con, goal_jac, NULL};
+    p.con[0] = (qo_constraint){QO_EQUALITY, 4, 10, 11, goal_con, goal_jac, NULL, NULL};
   } else {
     di_problem(&p, 2.0, 2.0);
     o.penalty_initial = 100.0;
     p.ncon = 2;
-    p.con[0] = (qo_constraint){QO_EQUALITY, 4, 10, 11, goal_con, goal_jac, NULL};
-    p.con[1] = (qo_constraint){QO_INEQUALITY, 4, 0, 10, ubnd_con, ubnd_jac, NULL};
+    p.con[0] = (qo_constraint){QO_EQUALITY, 4, 10, 11, goal_con, goal_jac, NULL, NULL};
+    p.con[1] = (qo_constraint){QO_INEQUALITY, 4, 0, 10, ubnd_con, ubnd_jac, NULL, NULL};
   }
   double X[11 * 4], U[10 * 2];
   memset(U, 0, sizeof U);

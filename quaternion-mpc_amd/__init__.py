@@ -141,6 +141,8 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.qmpc_last_kernel_ms.restype = i32
     lib.qmpc_linearize.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.qmpc_linearize.restype = i32
+    lib.qmpc_selftest_mtm.argtypes = [i32, vp, vp, vp]
+    lib.qmpc_selftest_mtm.restype = i32
     lib.qmpc_status_string.argtypes = [i32]
     lib.qmpc_status_string.restype = C.c_char_p
     lib.qmpc_version.argtypes = []
@@ -168,6 +170,7 @@ EXPORTED_SYMBOLS = (
     "qmpc_wait",
     "qmpc_last_kernel_ms",
     "qmpc_linearize",
+    "qmpc_selftest_mtm",
     "qmpc_status_string",
     "qmpc_version",
     "qmpc_sizeof_input",

@@ -1,0 +1,345 @@
+// qmpc_device.h -- device-side building blocks of the batched quaternion-MPC
+// solver for gfx950 (MI355X).  One 64-lane wavefront owns one MPC instance; the
+// whole per-instance working set lives in LDS.
+//
+// Reference arithmetic being accelerated (zixinz990/quaternion-mpc, legged_ctrl/):
+//   src/utils/AltroUtils.cpp:363-439   ct_srb_quat_dynamics / _jacobian
+//   src/utils/AltroUtils.cpp:9-22,78-110 explicit midpoint + chain rule (float h)
+//   src/utils/QuaternionUtils.cpp:30-52 L(q), G(q)
+//   src/mpc/QuatMpc.cpp:109-276        problem construction, cone rows, output
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/qmpc.h"
+
+namespace qmpc {
+
+constexpr int kWave = 64;
+constexpr int LD = 16;          // leading dimension of every LDS matrix: [12][16]
+constexpr int MAT = 12 * LD;    // 192 doubles = 3 MFMA fragments of 64 lanes
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// Device copy of qmpc_params plus derived constants (host fills it).
+struct DevParams {
+  int N;
+  int mode;
+  int iterations_max;
+  int drop_ang_vel;
+  double h;        // (double)(float h)
+  double hh;       // (double)(h/2) with h float
+  double h_ref;
+  double mass;
+  double Iinv[9];
+  double Q[13];
+  double R[12];
+  double w;
+  double mu;
+  double fz_max;
+  double tol_feas, tol_step, mu_final, sigma, sigma_fast, tau;
+};
+
+// ---- per-instance LDS layout (offsets in doubles) ---------------------------
+struct Layout {
+  int cst, bw0, refp, uref, X, U, S, LAM, DS, DLAM, CV, AB, LX, LXX, KD;
+  int Pm, Am, Bm, Tm, Sm, rot, at, wts, gw, misc, dx, du, total;
+};
+
+__host__ __device__ inline Layout make_layout(int N) {
+  Layout L;
+  int o = 0;
+  auto take = [&](int n) { int r = o; o += n; return r; };
+  L.cst = take(64);
+  L.bw0 = take(36);
+  L.refp = take(13);
+  L.uref = take(12);
+  L.X = take((N + 1) * 13);
+  L.U = take(N * 12);
+  L.S = take(N * 24);
+  L.LAM = take(N * 24);
+  L.DS = take(N * 24);
+  L.DLAM = take(N * 24);
+  L.CV = take(N * 24);
+  L.AB = take(N * 27);
+  L.LX = take((N + 1) * 12);
+  L.LXX = take((N + 1) * 9);
+  L.KD = take(N * 12 * 13);
+  o = (o + 1) & ~1;  // 16-byte alignment of the MFMA tiles
+  L.Pm = take(MAT);
+  L.Am = take(MAT);
+  L.Bm = take(MAT);
+  L.Tm = take(MAT);
+  L.Sm = take(MAT);
+  L.rot = take(36);
+  L.at = take(72);
+  L.wts = take(24);
+  L.gw = take(24);
+  L.misc = take(32);
+  L.dx = take(24);
+  L.du = take(12);
+  L.total = (o + 1) & ~1;
+  return L;
+}
+
+// cst[] slots
+enum {
+  C_FOOT = 0,    // 12: foot_pos_body[3*leg+axis]
+  C_GB = 12,     // 3 : R' (0,0,-9.81)
+  C_WD0 = 15,    // 3 : Iinv * (c x 5.204 g_body)
+  C_CR = 18,     // 18: C_mat * R   (6x3 row-major)
+  C_CON = 36,    // 4 : contacts (0/1)
+  C_X0 = 40,     // 13: initial state
+};
+
+#define QSYNC() __syncthreads()
+
+// ---- FP64 MFMA on [12][16] LDS tiles ----------------------------------------
+// v_mfma_f64_16x16x4_f64: A operand lane l = A[i=l&15][k=l>>4], B operand lane l
+// = B[k=l>>4][j=l&15], D reg r lane l = D[row=4r+(l>>4)][col=l&15].  With tiles
+// stored row-major [12][16], fragment kk of a tile is simply tile[64*kk + lane],
+// for the B operand AND (meaning the transpose) for the A operand.
+//   C = X' * Y  (12x16 result rows 0..11; rows 12..15 of the MFMA output dropped)
+__device__ __forceinline__ void mtm_load(const double* X, const double* Y, int lane, d4& acc) {
+  const double x0 = X[lane], x1 = X[64 + lane], x2 = X[128 + lane];
+  const double y0 = Y[lane], y1 = Y[64 + lane], y2 = Y[128 + lane];
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, y2, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mtm(double* C, const double* X, const double* Y, int lane) {
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+  mtm_load(X, Y, lane, acc);
+  C[lane] = acc[0];
+  C[64 + lane] = acc[1];
+  C[128 + lane] = acc[2];
+}
+
+// ---- wave reductions (64 lanes) ----------------------------------------------
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// ---- quaternion helpers (QuaternionUtils.cpp:30-52) --------------------------
+// G(q) (4x3): rows (-x,-y,-z), (s,-z,y), (z,s,-x), (-y,x,s)
+__device__ __forceinline__ void quat_G(const double* q, double G[12]) {
+  const double s = q[0], x = q[1], y = q[2], z = q[3];
+  G[0] = -x; G[1] = -y;  G[2] = -z;
+  G[3] = s;  G[4] = -z;  G[5] = y;
+  G[6] = z;  G[7] = s;   G[8] = -x;
+  G[9] = -y; G[10] = x;  G[11] = s;
+}
+// Omega(w) (4x4) = [[0,-w'],[w,-skew(w)]]  (AltroUtils.cpp:408-410, without the 0.5)
+__device__ __forceinline__ void quat_Omega(const double* w, double O[16]) {
+  const double x = w[0], y = w[1], z = w[2];
+  O[0] = 0;  O[1] = -x; O[2] = -y;  O[3] = -z;
+  O[4] = x;  O[5] = 0;  O[6] = z;   O[7] = -y;
+  O[8] = y;  O[9] = -z; O[10] = 0;  O[11] = x;
+  O[12] = z; O[13] = y; O[14] = -x; O[15] = 0;
+}
+
+// Explicit-midpoint step of the quaternion SRBD (AltroUtils.cpp:9-22 applied to
+// :363-392).  vdot and wdot do not depend on the state, so both midpoint
+// evaluations share them.  x, xn: 13 doubles in registers.
+__device__ __forceinline__ void srbd_step(const DevParams& P, const double* cst, const double* bw0,
+                                          const double* x, const double* u, double* xn) {
+  double F[3] = {0, 0, 0};
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const double c = cst[C_CON + l];
+    F[0] += c * u[3 * l]; F[1] += c * u[3 * l + 1]; F[2] += c * u[3 * l + 2];
+  }
+  double vd[3], wd[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    vd[a] = F[a] / P.mass + cst[C_GB + a];
+    double s = cst[C_WD0 + a];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) s += bw0[12 * a + j] * u[j];
+    wd[a] = s;
+  }
+  // midpoint state
+  double G[12];
+  quat_G(&x[3], G);
+  double qm[4], wm[3];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    qm[r] = x[3 + r] + P.hh * (0.5 * (G[3 * r] * x[10] + G[3 * r + 1] * x[11] + G[3 * r + 2] * x[12]));
+#pragma unroll
+  for (int a = 0; a < 3; ++a) wm[a] = x[10 + a] + P.hh * wd[a];
+  quat_G(qm, G);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    xn[a] = x[a] + P.h * (x[7 + a] + P.hh * vd[a]);
+    xn[7 + a] = x[7 + a] + P.h * vd[a];
+    xn[10 + a] = x[10 + a] + P.h * wd[a];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    xn[3 + r] = x[3 + r] + P.h * (0.5 * (G[3 * r] * wm[0] + G[3 * r + 1] * wm[1] + G[3 * r + 2] * wm[2]));
+}
+
+// Reference state of knot k (QuatMpc.cpp:148-176), from refp = pos(3) vel(3) acc(3) quat_d(4)
+__device__ __forceinline__ void xref_at(const DevParams& P, const double* refp, int k, double* xr) {
+  const double t = (double)k * P.h_ref;
+  const double h_ms = P.h_ref * 1000.0;
+  xr[0] = refp[0] + refp[3] * k * h_ms / 1000.0 + 0.5 * refp[6] * t * t;
+  xr[1] = refp[1] + refp[4] * k * h_ms / 1000.0 + 0.5 * refp[7] * t * t;
+  xr[2] = refp[2] + 0.5 * refp[8] * t * t;
+  xr[3] = refp[9]; xr[4] = refp[10]; xr[5] = refp[11]; xr[6] = refp[12];
+  xr[7] = refp[3] + refp[6] * t; xr[8] = refp[4] + refp[7] * t; xr[9] = refp[5] + refp[8] * t;
+  xr[10] = 0.0; xr[11] = 0.0; xr[12] = 0.0;
+}
+
+// Per-knot expansion, executed by ONE lane per knot (knots are independent):
+//  - compact error-state Jacobian blocks AB[27] = {Aphiphi(9), Aphiw(9), W(9)}
+//    of Abar = E(x+)' A E(x), Bbar = E(x+)' B   (AltroUtils.cpp:78-110,153-168):
+//      Abar = [[I,0,hI,0],[0,Aphiphi,0,Aphiw],[0,0,I,0],[0,0,0,I]]
+//      Bbar = [ (h^2/2m) c_i I ; (h/4) W (h Bw0) ; (h/m) c_i I ; h Bw0 ]
+//  - cost gradient lx(12) and attitude Hessian block lxx(9) in error coordinates
+//    (w (1 - |qref'q|) term)
+__device__ inline void expand_knot(const DevParams& P, const double* cst, const double* bw0,
+                                   const double* refp, int k, const double* x, const double* u,
+                                   const double* xn, double* AB, double* lx, double* lxx) {
+  const int N = P.N;
+  if (k < N) {
+    double wd[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      double s = cst[C_WD0 + a];
+      for (int j = 0; j < 12; ++j) s += bw0[12 * a + j] * u[j];
+      wd[a] = s;
+    }
+    double G0[12], Gm[12], Gn[12], O0[16], Om[16];
+    quat_G(&x[3], G0);
+    double qm[4], wm[3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      qm[r] = x[3 + r] + P.hh * (0.5 * (G0[3 * r] * x[10] + G0[3 * r + 1] * x[11] + G0[3 * r + 2] * x[12]));
+#pragma unroll
+    for (int a = 0; a < 3; ++a) wm[a] = x[10 + a] + P.hh * wd[a];
+    quat_G(qm, Gm);
+    quat_G(&xn[3], Gn);
+    quat_Omega(&x[10], O0);
+    quat_Omega(wm, Om);
+    // Aqq = I + (h/2) Om (I + (h/4) O0)   (4x4)
+    double M1[16], Aqq[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) M1[i] = ((i % 5 == 0) ? 1.0 : 0.0) + 0.5 * P.hh * O0[i];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s += Om[4 * r + t] * M1[4 * t + c];
+        Aqq[4 * r + c] = ((r == c) ? 1.0 : 0.0) + P.hh * s;
+      }
+    // Aqw = (h/2) (Om (h/4) G0 + Gm)   (4x3)
+    double Aqw[12];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s += Om[4 * r + t] * (0.5 * P.hh * G0[3 * t + c]);
+        Aqw[3 * r + c] = P.hh * (s + Gm[3 * r + c]);
+      }
+    // Aphiphi = Gn' Aqq G0 ; Aphiw = Gn' Aqw ; W = Gn' Gm
+    double AG[12];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s += Aqq[4 * r + t] * G0[3 * t + c];
+        AG[3 * r + c] = s;
+      }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          s1 += Gn[3 * t + r] * AG[3 * t + c];
+          s2 += Gn[3 * t + r] * Aqw[3 * t + c];
+          s3 += Gn[3 * t + r] * Gm[3 * t + c];
+        }
+        AB[3 * r + c] = s1;
+        AB[9 + 3 * r + c] = s2;
+        AB[18 + 3 * r + c] = s3;
+      }
+  }
+  // ---- cost expansion at knot k (k = 0..N) ----
+  double xr[13];
+  xref_at(P, refp, k, xr);
+  double lxf[13];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) lxf[i] = P.Q[i] * (x[i] - xr[i]);
+  const double dq = xr[3] * x[3] + xr[4] * x[4] + xr[5] * x[5] + xr[6] * x[6];
+  const double sg = (dq >= 0.0) ? 1.0 : -1.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) lxf[3 + r] += -sg * P.w * xr[3 + r];
+  const double qh = -(x[3] * lxf[3] + x[4] * lxf[4] + x[5] * lxf[5] + x[6] * lxf[6]);
+  double G[12];
+  quat_G(&x[3], G);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lx[a] = lxf[a];
+    lx[6 + a] = lxf[7 + a];
+    lx[9 + a] = lxf[10 + a];
+    lx[3 + a] = G[a] * lxf[3] + G[3 + a] * lxf[4] + G[6 + a] * lxf[5] + G[9 + a] * lxf[6];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      double s = (a == b) ? qh : 0.0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s += G[3 * t + a] * P.Q[3 + t] * G[3 * t + b];
+      lxx[3 * a + b] = s;
+    }
+}
+
+// Element (r,c) of the dense 12x12 Abar from the compact blocks.
+__device__ __forceinline__ double abar_elem(const DevParams& P, const double* AB, int r, int c) {
+  if (r < 3) return ((r == c) ? 1.0 : 0.0) + ((c == r + 6) ? P.h : 0.0);
+  if (r < 6) {
+    if (c >= 3 && c < 6) return AB[3 * (r - 3) + (c - 3)];
+    if (c >= 9) return AB[9 + 3 * (r - 3) + (c - 9)];
+    return 0.0;
+  }
+  return (r == c) ? 1.0 : 0.0;
+}
+// Element (r, 3l+a) of the dense 12x12 Bbar (unrotated).
+__device__ __forceinline__ double bbar_elem(const DevParams& P, const double* cst, const double* bw0,
+                                            const double* AB, int r, int col) {
+  const int l = col / 3, a = col - 3 * l;
+  const double cl = cst[C_CON + l];
+  if (r < 3) return (r == a) ? cl * (P.h * (P.hh * (1.0 / P.mass))) : 0.0;
+  if (r < 6) {
+    const double* W = AB + 18 + 3 * (r - 3);
+    return (0.5 * P.hh) * (W[0] * (P.h * bw0[col]) + W[1] * (P.h * bw0[12 + col]) +
+                            W[2] * (P.h * bw0[24 + col]));
+  }
+  if (r < 9) return (r - 6 == a) ? cl * (P.h * (1.0 / P.mass)) : 0.0;
+  return P.h * bw0[12 * (r - 9) + col];
+}
+
+}  // namespace qmpc

@@ -1,0 +1,305 @@
+// qmpc_hip.hip -- C ABI (include/qmpc.h) over the gfx950 kernels.
+//
+// Drop-in boundary: replaces the ALTRO set-up / Solve() / GetInput(0) block of
+// legged::QuatMpc::grf_update (legged_ctrl/src/mpc/QuatMpc.cpp:217-265) for a
+// batch of independent LeggedState records.  No CPU fallback exists here: with
+// no HIP device every entry point returns QMPC_NO_DEVICE.
+#include "qmpc_kernels.hip"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+using namespace qmpc;
+
+struct qmpc_handle {
+  qmpc_params params;
+  DevParams dev;
+  int device;
+  int max_batch;
+  hipStream_t stream;
+  hipEvent_t ev0, ev1;
+  bool timed;
+  qmpc_input* d_in;
+  double* d_forces;
+  qmpc_info* d_info;
+  double* d_traj_u;
+  double* d_traj_x;
+  double* d_A;
+  double* d_B;
+  size_t lds_bytes;
+};
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      std::fprintf(stderr, "qmpc: %s failed: %s\n", #expr, hipGetErrorString(e_));         \
+      return QMPC_HIP_ERROR;                                                               \
+    }                                                                                      \
+  } while (0)
+
+extern "C" {
+
+const char* qmpc_version(void) { return "qmpc-hip 0.1 (gfx950, wave-per-instance IPM/Riccati, fp64 MFMA)"; }
+int32_t qmpc_sizeof_input(void) { return (int32_t)sizeof(qmpc_input); }
+int32_t qmpc_sizeof_params(void) { return (int32_t)sizeof(qmpc_params); }
+int32_t qmpc_sizeof_info(void) { return (int32_t)sizeof(qmpc_info); }
+
+const char* qmpc_status_string(int32_t s) {
+  switch (s) {
+    case QMPC_OK: return "ok";
+    case QMPC_MAX_ITER: return "iteration cap reached";
+    case QMPC_NO_CONTACT: return "no stance leg";
+    case QMPC_NAN_INPUT: return "non-finite input";
+    case QMPC_LINESEARCH_FAIL: return "line search failed";
+    case QMPC_NOT_PD: return "Quu not positive definite";
+    case QMPC_BAD_ARGUMENT: return "bad argument";
+    case QMPC_NO_DEVICE: return "no HIP device (there is no CPU fallback)";
+    case QMPC_HIP_ERROR: return "HIP runtime error";
+    case QMPC_BATCH_TOO_LARGE: return "batch exceeds the handle's capacity";
+    default: return "unknown status";
+  }
+}
+
+// legged_ctrl/config/gazebo_go1_quat_mpc.yaml:36-75,115-122; QuatMpc.cpp:21-26,182
+void qmpc_default_params(qmpc_params* p, int32_t horizon, int32_t mode) {
+  std::memset(p, 0, sizeof *p);
+  p->horizon = horizon;
+  p->h = (float)(10.0 / 1000.0);
+  p->h_ref = 10.0 / 1000.0;
+  p->mass = 12.84;
+  const double trunk[3] = {0.0168128557, 0.063009565, 0.0716547275};
+  for (int a = 0; a < 3; ++a) p->inertia[4 * a] = 1.2 * trunk[a];
+  const double q[13] = {2.5, 2.5, 10.0, 0, 0, 0, 0, 0.1, 0.1, 0.1, 0.15, 0.15, 0.15};
+  std::memcpy(p->q_weights, q, sizeof q);
+  for (int j = 0; j < 12; ++j) p->r_weights[j] = 0.000001;
+  p->w = 50.0;
+  p->mu = 0.7;
+  p->fz_max = 100.0;
+  p->mode = mode;
+  p->penalty_initial = 1.0;
+  p->penalty_max = 1e8;
+  p->tol_stationarity = 1e-4;
+  p->tol_cost_intermediate = 1e-4;
+  p->linesearch_max = 10;
+  p->drop_ang_vel = 1;
+  if (mode == QMPC_MODE_REFERENCE) {
+    p->iterations_max = 10;     // QuatMpc.cpp:22
+    p->penalty_scaling = 20.0;  // QuatMpc.cpp:26
+    p->tol_feasibility = 1e-4;
+  } else {
+    p->iterations_max = 40;
+    p->penalty_scaling = 10.0;
+    p->tol_feasibility = 1e-8;
+    p->tol_step = 1e-8;
+    p->ipm_mu_final = 1e-12;
+    p->ipm_sigma = 0.2;
+    p->ipm_sigma_fast = 0.05;
+    p->ipm_tau = 0.995;
+  }
+}
+
+static int fill_dev_params(const qmpc_params* p, DevParams* d) {
+  if (!p || p->horizon < 1 || p->horizon > QMPC_MAX_HORIZON) return QMPC_BAD_ARGUMENT;
+  if (p->mode != QMPC_MODE_CONVERGED) return QMPC_BAD_ARGUMENT;  // device path: converged mode
+  if (!(p->mass > 0.0) || !(p->h > 0.0f)) return QMPC_BAD_ARGUMENT;
+  std::memset(d, 0, sizeof *d);
+  d->N = p->horizon;
+  d->mode = p->mode;
+  d->iterations_max = p->iterations_max;
+  d->drop_ang_vel = p->drop_ang_vel;
+  d->h = (double)p->h;
+  d->hh = (double)(p->h / 2);  // float division, as `h / 2` in AltroUtils.cpp:16,94
+  d->h_ref = p->h_ref;
+  d->mass = p->mass;
+  // cofactor inverse of the 3x3 inertia (Eigen's fixed-size inverse(), AltroUtils.cpp:391)
+  const double* A = p->inertia;
+  const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+  const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+  if (!(std::fabs(det) > 0.0)) return QMPC_BAD_ARGUMENT;
+  const double id = 1.0 / det;
+  d->Iinv[0] = c00 * id; d->Iinv[1] = (A[2] * A[7] - A[1] * A[8]) * id; d->Iinv[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+  d->Iinv[3] = c01 * id; d->Iinv[4] = (A[0] * A[8] - A[2] * A[6]) * id; d->Iinv[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+  d->Iinv[6] = c02 * id; d->Iinv[7] = (A[1] * A[6] - A[0] * A[7]) * id; d->Iinv[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+  std::memcpy(d->Q, p->q_weights, sizeof d->Q);
+  std::memcpy(d->R, p->r_weights, sizeof d->R);
+  for (int j = 0; j < 12; ++j) if (!(d->R[j] > 0.0)) return QMPC_BAD_ARGUMENT;
+  d->w = p->w;
+  d->mu = p->mu;
+  d->fz_max = p->fz_max;
+  d->tol_feas = p->tol_feasibility;
+  d->tol_step = p->tol_step;
+  d->mu_final = p->ipm_mu_final;
+  d->sigma = p->ipm_sigma;
+  d->sigma_fast = p->ipm_sigma_fast;
+  d->tau = p->ipm_tau;
+  return QMPC_OK;
+}
+
+qmpc_status qmpc_set_params(qmpc_handle* h, const qmpc_params* params) {
+  if (!h || !params) return QMPC_BAD_ARGUMENT;
+  DevParams d;
+  const int st = fill_dev_params(params, &d);
+  if (st != QMPC_OK) return (qmpc_status)st;
+  if (params->horizon != h->params.horizon) return QMPC_BAD_ARGUMENT;  // buffers are sized by N
+  h->params = *params;
+  h->dev = d;
+  return QMPC_OK;
+}
+
+qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t device, qmpc_handle** out) {
+  if (!out) return QMPC_BAD_ARGUMENT;
+  *out = nullptr;
+  if (!params || max_batch < 1) return QMPC_BAD_ARGUMENT;
+  DevParams d;
+  const int st = fill_dev_params(params, &d);
+  if (st != QMPC_OK) return (qmpc_status)st;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) {
+    std::fprintf(stderr, "qmpc_create: no HIP device %d (found %d); there is no CPU fallback\n", device, ndev);
+    return QMPC_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(device));
+  qmpc_handle* h = new (std::nothrow) qmpc_handle();
+  if (!h) return QMPC_HIP_ERROR;
+  std::memset(h, 0, sizeof *h);
+  h->params = *params;
+  h->dev = d;
+  h->device = device;
+  h->max_batch = max_batch;
+  const int N = params->horizon;
+  const Layout L = make_layout(N);
+  h->lds_bytes = (size_t)L.total * sizeof(double);
+  if (h->lds_bytes > 160 * 1024) { delete h; return QMPC_BAD_ARGUMENT; }
+  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&h->ev0));
+  HIP_TRY(hipEventCreate(&h->ev1));
+  HIP_TRY(hipMalloc(&h->d_in, sizeof(qmpc_input) * (size_t)max_batch));
+  HIP_TRY(hipMalloc(&h->d_forces, sizeof(double) * 12 * (size_t)max_batch));
+  HIP_TRY(hipMalloc(&h->d_info, sizeof(qmpc_info) * (size_t)max_batch));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_linearize_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+  *out = h;
+  return QMPC_OK;
+}
+
+void qmpc_destroy(qmpc_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->d_in) (void)hipFree(h->d_in);
+  if (h->d_forces) (void)hipFree(h->d_forces);
+  if (h->d_info) (void)hipFree(h->d_info);
+  if (h->d_traj_u) (void)hipFree(h->d_traj_u);
+  if (h->d_traj_x) (void)hipFree(h->d_traj_x);
+  if (h->d_A) (void)hipFree(h->d_A);
+  if (h->d_B) (void)hipFree(h->d_B);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces,
+                                qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s) {
+  HIP_TRY(hipEventRecord(h->ev0, s));
+  hipLaunchKernelGGL(qmpc_solve_kernel, dim3((unsigned)batch), dim3(kWave), h->lds_bytes, s, h->dev, d_in,
+                     d_forces, d_info, d_tu, d_tx, (int)batch);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->ev1, s));
+  h->timed = true;
+  return QMPC_OK;
+}
+
+qmpc_status qmpc_solve_device(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces_body,
+                              qmpc_info* d_info, void* stream) {
+  if (!h || batch < 0 || (batch > 0 && (!d_in || !d_forces_body))) return QMPC_BAD_ARGUMENT;
+  if (batch == 0) return QMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  return launch_solve(h, batch, d_in, d_forces_body, d_info, nullptr, nullptr, s);
+}
+
+qmpc_status qmpc_wait(qmpc_handle* h) {
+  if (!h) return QMPC_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  if (h->timed) HIP_TRY(hipEventSynchronize(h->ev1));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return QMPC_OK;
+}
+
+qmpc_status qmpc_last_kernel_ms(qmpc_handle* h, float* ms) {
+  if (!h || !ms) return QMPC_BAD_ARGUMENT;
+  if (!h->timed) { *ms = 0.0f; return QMPC_OK; }
+  HIP_TRY(hipEventSynchronize(h->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return QMPC_OK;
+}
+
+qmpc_status qmpc_solve_traj(qmpc_handle* h, int32_t batch, const qmpc_input* in, double* forces_body,
+                            qmpc_info* info, double* traj_u, double* traj_x) {
+  if (!h || batch < 0 || (batch > 0 && (!in || !forces_body))) return QMPC_BAD_ARGUMENT;
+  if (batch == 0) return QMPC_OK;
+  if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
+  HIP_TRY(hipSetDevice(h->device));
+  const int N = h->params.horizon;
+  if (traj_u && !h->d_traj_u) HIP_TRY(hipMalloc(&h->d_traj_u, sizeof(double) * 12 * N * (size_t)h->max_batch));
+  if (traj_x && !h->d_traj_x) HIP_TRY(hipMalloc(&h->d_traj_x, sizeof(double) * 13 * (N + 1) * (size_t)h->max_batch));
+  HIP_TRY(hipMemcpyAsync(h->d_in, in, sizeof(qmpc_input) * (size_t)batch, hipMemcpyHostToDevice, h->stream));
+  const qmpc_status st = launch_solve(h, batch, h->d_in, h->d_forces, h->d_info, traj_u ? h->d_traj_u : nullptr,
+                                      traj_x ? h->d_traj_x : nullptr, h->stream);
+  if (st != QMPC_OK) return st;
+  HIP_TRY(hipMemcpyAsync(forces_body, h->d_forces, sizeof(double) * 12 * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+  if (info) HIP_TRY(hipMemcpyAsync(info, h->d_info, sizeof(qmpc_info) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+  if (traj_u) HIP_TRY(hipMemcpyAsync(traj_u, h->d_traj_u, sizeof(double) * 12 * N * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+  if (traj_x) HIP_TRY(hipMemcpyAsync(traj_x, h->d_traj_x, sizeof(double) * 13 * (N + 1) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return QMPC_OK;
+}
+
+qmpc_status qmpc_solve(qmpc_handle* h, int32_t batch, const qmpc_input* in, double* forces_body, qmpc_info* info) {
+  return qmpc_solve_traj(h, batch, in, forces_body, info, nullptr, nullptr);
+}
+
+qmpc_status qmpc_linearize(qmpc_handle* h, int32_t batch, const qmpc_input* in, double* Abar, double* Bbar, double* X) {
+  if (!h || batch < 0 || (batch > 0 && (!in || !Abar || !Bbar || !X))) return QMPC_BAD_ARGUMENT;
+  if (batch == 0) return QMPC_OK;
+  if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
+  HIP_TRY(hipSetDevice(h->device));
+  const int N = h->params.horizon;
+  const size_t nA = sizeof(double) * 144 * N * (size_t)h->max_batch;
+  if (!h->d_A) HIP_TRY(hipMalloc(&h->d_A, nA));
+  if (!h->d_B) HIP_TRY(hipMalloc(&h->d_B, nA));
+  if (!h->d_traj_x) HIP_TRY(hipMalloc(&h->d_traj_x, sizeof(double) * 13 * (N + 1) * (size_t)h->max_batch));
+  HIP_TRY(hipMemcpyAsync(h->d_in, in, sizeof(qmpc_input) * (size_t)batch, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(qmpc_linearize_kernel, dim3((unsigned)batch), dim3(kWave), h->lds_bytes, h->stream, h->dev,
+                     h->d_in, h->d_A, h->d_B, h->d_traj_x, (int)batch);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(Abar, h->d_A, sizeof(double) * 144 * N * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(Bbar, h->d_B, sizeof(double) * 144 * N * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(X, h->d_traj_x, sizeof(double) * 13 * (N + 1) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return QMPC_OK;
+}
+
+// Diagnostic (not part of the drop-in surface): C = X' * Y on [12][16] tiles via
+// the FP64 MFMA path; host buffers of 192 doubles each.
+qmpc_status qmpc_selftest_mtm(int32_t device, const double* X, const double* Y, double* Cout) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device >= ndev) return QMPC_NO_DEVICE;
+  HIP_TRY(hipSetDevice(device));
+  double* d = nullptr;
+  HIP_TRY(hipMalloc(&d, sizeof(double) * 3 * MAT));
+  HIP_TRY(hipMemcpy(d, X, sizeof(double) * MAT, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d + MAT, Y, sizeof(double) * MAT, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(qmpc_selftest_kernel, dim3(1), dim3(kWave), 0, 0, d, d + MAT, d + 2 * MAT);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(Cout, d + 2 * MAT, sizeof(double) * MAT, hipMemcpyDeviceToHost));
+  HIP_TRY(hipFree(d));
+  return QMPC_OK;
+}
+
+}  // extern "C"

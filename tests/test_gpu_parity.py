@@ -1,0 +1,172 @@
+"""GPU suite (-m gpu): the HIP path against the CPU oracle, through the C ABI.
+
+Tolerances (forces in newtons):
+  * linearisation (Abar, Bbar, rollout X)          : 1e-12 abs
+  * GPU vs oracle, converged mode, same inputs       : 1e-6 N  L_inf
+  * GPU vs the reference's golden trajectories       : 1e-5 N  L_inf (what the
+    oracle itself achieves; the JSON is a tolerance-terminated iterate)
+  * contact flags / swing-leg forces                 : exact (0.0)
+"""
+import ctypes as C
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import golden_problem
+
+pytestmark = pytest.mark.gpu
+GOLDEN = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    return pkg.load_library()   # raises if the HIP extension is missing: no fallback
+
+
+def _solver(pkg, lib, N, cap=4096, **over):
+    p = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p, pkg.Solver(p, cap, device=0, lib=lib)
+
+
+def test_mfma_fragment_layout(lib):
+    """C = X'Y through v_mfma_f64_16x16x4_f64 with ASYMMETRIC operands."""
+    rng = np.random.default_rng(1)
+    X = np.zeros((12, 16)); Y = np.zeros((12, 16))
+    X[:, :13] = rng.standard_normal((12, 13)); Y[:, :13] = rng.standard_normal((12, 13))
+    Cc = np.zeros((12, 16))
+    st = lib.qmpc_selftest_mtm(0, X.ctypes.data, Y.ctypes.data, Cc.ctypes.data)
+    assert st == 0
+    ref = (X.T @ Y)[:12]
+    assert np.abs(Cc - ref).max() < 1e-13
+
+
+@pytest.mark.parametrize("N", [10, 20])
+def test_linearisation_matches_oracle(pkg, lib, oracle, N):
+    p, s = _solver(pkg, lib, N)
+    rec = pkg.random_go1_trot_states(64, config_id=2)
+    rec["ang_vel_body"] *= 1.0
+    for drop in (1, 0):
+        p.drop_ang_vel = drop
+        s.set_params(p)
+        A, B, X = s.linearize(rec)
+        Ao, Bo, Xo = oracle.linearize(p, rec)
+        assert np.abs(X - Xo).max() < 1e-12
+        assert np.abs(A - Ao).max() < 1e-12
+        assert np.abs(B - Bo).max() < 1e-12
+    s.close()
+
+
+@pytest.mark.parametrize("N,cfg", [(10, 2), (20, 3)])
+def test_forces_match_oracle_random_trot(pkg, lib, oracle, N, cfg):
+    p, s = _solver(pkg, lib, N)
+    rec = pkg.random_go1_trot_states(256, config_id=cfg)
+    f, info, tu, tx = s.solve(rec, want_traj=True)
+    fo, io, tuo, txo = oracle.solve(p, rec, threads=8, want_traj=True)
+    assert (info["status"] == 0).all(), np.unique(info["status"], return_counts=True)
+    assert (io["status"] == 0).all()
+    err = np.abs(f - fo).max(axis=1)
+    assert err.max() < 1e-6, (err.max(), int(err.argmax()))
+    assert np.abs(tu - tuo).max() < 1e-5            # whole horizon, looser: later knots are flatter
+    assert np.abs(tx - txo).max() < 1e-8
+    assert np.abs(info["iterations"] - io["iterations"]).max() <= 2
+    # contact schedule exact: swing legs carry exactly zero force
+    assert (f.reshape(-1, 4, 3)[rec["contacts"] == 0] == 0).all()
+    s.close()
+
+
+@pytest.mark.parametrize("which,name", [("stand", "quat_mpc_test.json"), ("trot", "trot_quat_mpc_test.json")])
+def test_golden_trajectories_on_gpu(pkg, lib, which, name):
+    d = json.loads((GOLDEN / name).read_text())
+    Xg, Ug = np.array(d["state_trajectory"]), np.array(d["input_trajectory"])
+    p, rec, cols = golden_problem(pkg, pkg.default_params(20, 0, lib), which)
+    s = pkg.Solver(p, 4, device=0, lib=lib)
+    f, info, tu, tx = s.solve(rec, want_traj=True)
+    assert info["status"][0] == 0
+    assert np.abs(tu[0][:, cols] - Ug).max() < 1e-5
+    assert np.abs(tx[0] - Xg).max() < 1e-5
+    s.close()
+
+
+def test_stand_pose_single_instance(pkg, lib, oracle):
+    """BASELINE config 0: one stand-pose LeggedState, blocking B = 1 call."""
+    for N in (10, 20):
+        p, s = _solver(pkg, lib, N, cap=1)
+        rec = pkg.go1_stand_input()
+        f, info = s.solve(rec)
+        fo, _ = oracle.solve(p, rec)
+        assert info["status"][0] == 0 and np.abs(f - fo).max() < 1e-6
+        assert abs(f[0].reshape(4, 3)[:, 2].sum() - 12.84 * 9.81) < 0.5   # carries the weight
+        s.close()
+
+
+def test_edge_cases(pkg, lib, oracle):
+    p, s = _solver(pkg, lib, 10)
+    rec = pkg.random_go1_trot_states(5, config_id=2)
+    rec["contacts"][0] = 0
+    rec["rot"][1][4] = np.inf
+    rec["contacts"][2] = [1, 1, 1, 0]      # three stance legs
+    rec["contacts"][3] = [0, 0, 1, 0]      # a single stance leg
+    f, info = s.solve(rec)
+    fo, io = oracle.solve(p, rec)
+    assert info["status"].tolist() == io["status"].tolist()
+    assert info["status"][0] == pkg.NO_CONTACT and info["status"][1] == pkg.NAN_INPUT
+    assert (f[:2] == 0).all()
+    ok = info["status"] == 0
+    assert np.abs(f[ok] - fo[ok]).max() < 1e-6
+    # empty batch and over-capacity batch
+    f0, i0 = s.solve(rec[:0])
+    assert f0.shape == (0, 12)
+    with pytest.raises(pkg.QmpcError) as e:
+        s.solve(pkg.random_go1_trot_states(5000, config_id=2))
+    assert e.value.code == pkg.BATCH_TOO_LARGE
+    s.close()
+
+
+def test_full_size_properties(pkg, lib, oracle):
+    """BASELINE config 1 at full size (B=1024, N=10): properties that need no oracle
+    run, plus an oracle spot check on a bounded sample."""
+    p, s = _solver(pkg, lib, 10)
+    rec = pkg.random_go1_trot_states(1024, config_id=2)
+    f, info = s.solve(rec)
+    assert (info["status"] == 0).all()
+    # feasibility in the world frame (QuatMpc.cpp:47-52,194-205)
+    fw = np.einsum("bij,blj->bli", rec["rot"].reshape(-1, 3, 3), f.reshape(-1, 4, 3))
+    st = rec["contacts"] != 0
+    assert (f.reshape(-1, 4, 3)[~st] == 0).all()
+    assert (fw[st][:, 2] <= 100 + 1e-7).all() and (fw[st][:, 2] >= -1e-7).all()
+    assert (np.abs(fw[st][:, 0]) <= 0.7 * fw[st][:, 2] + 1e-7).all()
+    assert (np.abs(fw[st][:, 1]) <= 0.7 * fw[st][:, 2] + 1e-7).all()
+    # instances are independent: a permuted batch gives the permuted answer, bit for bit
+    perm = np.random.default_rng(0).permutation(1024)
+    f2, _ = s.solve(rec[perm])
+    assert np.array_equal(f2, f[perm])
+    # determinism
+    f3, _ = s.solve(rec)
+    assert np.array_equal(f3, f)
+    # spot check
+    idx = np.arange(0, 1024, 16)
+    fo, _ = oracle.solve(p, rec[idx], threads=8)
+    assert np.abs(f[idx] - fo).max() < 1e-6
+    s.close()
+
+
+def test_device_pointer_entry_point(pkg, lib):
+    """qmpc_solve_device on torch-owned HBM buffers and torch's stream."""
+    import torch
+
+    p, s = _solver(pkg, lib, 10)
+    rec = pkg.random_go1_trot_states(512, config_id=2)
+    f_host, _ = s.solve(rec)
+    d_in = torch.from_numpy(rec.view(np.uint8).reshape(512, -1)).cuda()
+    d_f = torch.zeros(512, 12, dtype=torch.float64, device="cuda")
+    d_info = torch.zeros(512, 40, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    s.solve_device(512, d_in.data_ptr(), d_f.data_ptr(), d_info.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_f.cpu().numpy(), f_host)
+    assert s.last_kernel_ms() > 0
+    s.close()
