@@ -105,7 +105,9 @@ def main():
     d_f = torch.zeros(B, 12, dtype=torch.float64, device="cuda")
     d_info = torch.zeros(B, pkg.INFO_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
     gathered = torch.zeros(world * B, 12, dtype=torch.float64, device="cuda") if world > 1 else None
-    stream = torch.cuda.current_stream()
+    # a real (non-null) stream: the C ABI treats NULL as "the handle's own stream"
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
 
     def step():
         solver.solve_device(B, d_in.data_ptr(), d_f.data_ptr(), d_info.data_ptr(), stream.cuda_stream)

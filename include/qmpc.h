@@ -185,6 +185,11 @@ qmpc_status qmpc_linearize(qmpc_handle* h, int32_t batch, const qmpc_input* in,
  * uses (host buffers of 192 doubles each).  Lets the GPU tests pin the
  * fragment layout independently of the solver. */
 qmpc_status qmpc_selftest_mtm(int32_t device, const double* X, const double* Y, double* C);
+/* Per-instance phase cycle counts (s_memtime) of one instrumented solve launch:
+ * cycles_out [batch][16] int64 (host); slots 0..8 = set-up, expansions, operand
+ * build, MFMA + stage terms, stage solve, cost-to-go update, IPM directions,
+ * rollout, misc; slot 15 = iterations.  Used by tools/phase_profile.py. */
+qmpc_status qmpc_debug_profile(qmpc_handle* h, int32_t batch, const qmpc_input* in, int64_t* cycles_out);
 
 /* ---- introspection -------------------------------------------------------- */
 const char* qmpc_status_string(int32_t status);

@@ -114,6 +114,16 @@ class QmpcError(RuntimeError):
 def load_library(path: os.PathLike | None = None) -> C.CDLL:
     """dlopen the HIP library.  Raises (never falls back) when it is absent."""
     p = Path(path) if path else LIB_PATH
+    # torch bundles its own libamdhip64.so.7; whichever HIP runtime is loaded
+    # first serves the whole process.  Let torch (our device-memory / stream /
+    # RCCL plumbing) load its runtime first so both sides share one.
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     if not p.exists():
         raise FileNotFoundError(
             f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -141,6 +151,8 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.qmpc_last_kernel_ms.restype = i32
     lib.qmpc_linearize.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.qmpc_linearize.restype = i32
+    lib.qmpc_debug_profile.argtypes = [vp, i32, vp, vp]
+    lib.qmpc_debug_profile.restype = i32
     lib.qmpc_selftest_mtm.argtypes = [i32, vp, vp, vp]
     lib.qmpc_selftest_mtm.restype = i32
     lib.qmpc_status_string.argtypes = [i32]
@@ -171,6 +183,7 @@ EXPORTED_SYMBOLS = (
     "qmpc_last_kernel_ms",
     "qmpc_linearize",
     "qmpc_selftest_mtm",
+    "qmpc_debug_profile",
     "qmpc_status_string",
     "qmpc_version",
     "qmpc_sizeof_input",
@@ -249,6 +262,14 @@ class Solver:
         if st != OK:
             raise QmpcError(st, "qmpc_last_kernel_ms")
         return float(ms.value)
+
+    def phase_profile(self, inputs: np.ndarray) -> np.ndarray:
+        inputs = np.ascontiguousarray(inputs, dtype=INPUT_DTYPE)
+        out = np.zeros((inputs.shape[0], 16), dtype=np.int64)
+        st = self.lib.qmpc_debug_profile(self._h, inputs.shape[0], _ptr(inputs), _ptr(out))
+        if st != OK:
+            raise QmpcError(st, "qmpc_debug_profile")
+        return out
 
     def linearize(self, inputs: np.ndarray):
         inputs = np.ascontiguousarray(inputs, dtype=INPUT_DTYPE)

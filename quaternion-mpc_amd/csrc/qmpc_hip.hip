@@ -179,7 +179,9 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
   HIP_TRY(hipMalloc(&h->d_in, sizeof(qmpc_input) * (size_t)max_batch));
   HIP_TRY(hipMalloc(&h->d_forces, sizeof(double) * 12 * (size_t)max_batch));
   HIP_TRY(hipMalloc(&h->d_info, sizeof(qmpc_info) * (size_t)max_batch));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_kernel),
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_linearize_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
@@ -206,8 +208,8 @@ void qmpc_destroy(qmpc_handle* h) {
 static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces,
                                 qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s) {
   HIP_TRY(hipEventRecord(h->ev0, s));
-  hipLaunchKernelGGL(qmpc_solve_kernel, dim3((unsigned)batch), dim3(kWave), h->lds_bytes, s, h->dev, d_in,
-                     d_forces, d_info, d_tu, d_tx, (int)batch);
+  hipLaunchKernelGGL(qmpc_solve_kernel<false>, dim3((unsigned)batch), dim3(kWave), h->lds_bytes, s, h->dev, d_in,
+                     d_forces, d_info, d_tu, d_tx, (int)batch, (long long*)nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev1, s));
   h->timed = true;
@@ -282,6 +284,27 @@ qmpc_status qmpc_linearize(qmpc_handle* h, int32_t batch, const qmpc_input* in, 
   HIP_TRY(hipMemcpyAsync(Bbar, h->d_B, sizeof(double) * 144 * N * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(X, h->d_traj_x, sizeof(double) * 13 * (N + 1) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return QMPC_OK;
+}
+
+// Diagnostic: per-instance phase cycle counts (s_memtime) of one solve launch.
+// cycles_out: [batch][16] int64 on the host; slots 0..8 = setup, expansions,
+// operand build, MFMA + stage terms, stage solve, cost-to-go update, IPM
+// directions, rollout, misc; slot 15 = iterations.
+qmpc_status qmpc_debug_profile(qmpc_handle* h, int32_t batch, const qmpc_input* in, int64_t* cycles_out) {
+  if (!h || batch < 1 || !in || !cycles_out) return QMPC_BAD_ARGUMENT;
+  if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
+  HIP_TRY(hipSetDevice(h->device));
+  long long* d_prof = nullptr;
+  HIP_TRY(hipMalloc(&d_prof, sizeof(long long) * 16 * (size_t)batch));
+  HIP_TRY(hipMemsetAsync(d_prof, 0, sizeof(long long) * 16 * (size_t)batch, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_in, in, sizeof(qmpc_input) * (size_t)batch, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(qmpc_solve_kernel<true>, dim3((unsigned)batch), dim3(kWave), h->lds_bytes, h->stream, h->dev,
+                     h->d_in, h->d_forces, h->d_info, (double*)nullptr, (double*)nullptr, (int)batch, d_prof);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(cycles_out, d_prof, sizeof(long long) * 16 * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipFree(d_prof));
   return QMPC_OK;
 }
 

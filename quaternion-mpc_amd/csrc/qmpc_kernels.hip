@@ -12,6 +12,29 @@
 
 namespace qmpc {
 
+// Optional phase-level cycle accounting (s_memtime), compiled in only for the
+// diagnostic instantiation qmpc_solve_kernel<true>.
+enum { PH_SETUP = 0, PH_EXPAND, PH_BUILD, PH_MFMA, PH_SOLVE, PH_PUPD, PH_DIRS, PH_ROLL, PH_MISC, PH_COUNT };
+template <bool PROF>
+struct Prof {
+  long long t[PH_COUNT];
+  long long last;
+  __device__ __forceinline__ void start() {
+    if (PROF) {
+#pragma unroll
+      for (int i = 0; i < PH_COUNT; ++i) t[i] = 0;
+      last = clock64();
+    }
+  }
+  __device__ __forceinline__ void tick(int ph) {
+    if (PROF) {
+      const long long now = clock64();
+      t[ph] += now - last;
+      last = now;
+    }
+  }
+};
+
 // ---- instance set-up: record -> LDS constants, reference, initial guess -----
 __device__ inline void setup_instance(const DevParams& P, const Layout& L, double* sm,
                                       const qmpc_input* in, int lane, int* status) {
@@ -243,8 +266,9 @@ __device__ inline int stage_solve(double* Sm, double* Tm, double* Bm, int lane) 
 
 // Riccati backward pass with interior-point weights; writes KD (unrotated gains
 // [K | d], 12 x 13 per knot).  Returns nonzero when a pivot is not positive.
+template <bool PROF>
 __device__ inline int backward_pass(const DevParams& P, const Layout& L, double* sm, double target,
-                                    int lane) {
+                                    int lane, Prof<PROF>& prof) {
   const int N = P.N;
   double* Pm = sm + L.Pm; double* Am = sm + L.Am; double* Bm = sm + L.Bm;
   double* Tm = sm + L.Tm; double* Sm = sm + L.Sm;
@@ -284,6 +308,7 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
       Bm[idx] = b;
     }
     QSYNC();
+    prof.tick(PH_BUILD);
     // T = P'A (col 12 <- p), S = P'B
     {
       d4 accT = {0, 0, 0, 0}, accS = {0, 0, 0, 0};
@@ -350,7 +375,10 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
     QSYNC();
     // keep Qux_aug for the cost-to-go update (the solve destroys Tm): copy to Pm
     Pm[lane] = Tm[lane]; Pm[64 + lane] = Tm[64 + lane]; Pm[128 + lane] = Tm[128 + lane];
+    QSYNC();
+    prof.tick(PH_MFMA);
     notpd |= stage_solve(Sm, Tm, Bm, lane);   // Bm <- [Kt | dt] (rotated)
+    prof.tick(PH_SOLVE);
     // unrotate and store the gains: KD[3l+a][c] = sum_b T_l[a][b] * Bm[3l+b][c]
     for (int idx = lane; idx < 12 * 13; idx += kWave) {
       const int r = idx / 13, c = idx - 13 * r, l = r / 3, a = r - 3 * l;
@@ -366,6 +394,7 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
       Pm[lane] = acc[0]; Pm[64 + lane] = acc[1]; Pm[128 + lane] = acc[2];
     }
     QSYNC();
+    prof.tick(PH_PUPD);
   }
   return notpd;
 }
@@ -506,11 +535,13 @@ __device__ inline double cost_plain(const DevParams& P, const Layout& L, double*
 }
 
 // ---- the solve kernel ---------------------------------------------------------
+template <bool PROF>
 __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_input* __restrict__ in,
                                                         double* __restrict__ forces,
                                                         qmpc_info* __restrict__ info,
                                                         double* __restrict__ traj_u,
-                                                        double* __restrict__ traj_x, int batch) {
+                                                        double* __restrict__ traj_x, int batch,
+                                                        long long* __restrict__ prof_out) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int b = blockIdx.x;
   if (b >= batch) return;
@@ -518,6 +549,8 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
   const int N = P.N;
   const Layout L = make_layout(N);
   int status = QMPC_OK;
+  Prof<PROF> prof;
+  prof.start();
   setup_instance(P, L, sm, in + b, lane, &status);
   if (status != QMPC_OK) {
     if (lane < 12) forces[12 * (size_t)b + lane] = 0.0;
@@ -540,6 +573,7 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
     sm[L.LAM + i] = 1.0 / s0;
   }
   QSYNC();
+  prof.tick(PH_SETUP);
   int it = 0, iters = 0;
   double mu = 0.0, resid = 0.0, last_step = 1e300, last_ap = 0.0, last_ad = 0.0;
   status = QMPC_MAX_ITER;
@@ -561,17 +595,22 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
     double sg = P.sigma;
     if (it > 1 && last_ap >= 0.999 && last_ad >= 0.999) sg = P.sigma_fast;
     const double target = sg * mu;
-    if (backward_pass(P, L, sm, target, lane)) { status = QMPC_NOT_PD; break; }
+    prof.tick(PH_MISC);
+    if (backward_pass<PROF>(P, L, sm, target, lane, prof)) { status = QMPC_NOT_PD; break; }
     double ap, ad;
     ipm_directions(P, L, sm, target, lane, &ap, &ad);
     last_ap = ap; last_ad = ad;
+    prof.tick(PH_DIRS);
     last_step = rollout_closed(P, L, sm, ap, lane);
+    prof.tick(PH_ROLL);
     for (int i = lane; i < N * 24; i += kWave) {
       sm[L.S + i] += ap * sm[L.DS + i];
       sm[L.LAM + i] += ad * sm[L.DLAM + i];
     }
     QSYNC();
+    prof.tick(PH_MISC);
     expansions(P, L, sm, lane);
+    prof.tick(PH_EXPAND);
     iters = it;
   }
   // outputs: GetInput(u, 0) (QuatMpc.cpp:264-265)
@@ -590,6 +629,12 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
       qmpc_info r = {status, iters, J, viol, last_step, mu};
       info[b] = r;
     }
+  }
+  if (PROF && prof_out && lane == 0) {
+    prof.tick(PH_MISC);
+#pragma unroll
+    for (int i = 0; i < PH_COUNT; ++i) prof_out[16 * (size_t)b + i] = prof.t[i];
+    prof_out[16 * (size_t)b + 15] = iters;
   }
 }
 

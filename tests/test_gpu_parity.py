@@ -164,9 +164,10 @@ def test_device_pointer_entry_point(pkg, lib):
     d_in = torch.from_numpy(rec.view(np.uint8).reshape(512, -1)).cuda()
     d_f = torch.zeros(512, 12, dtype=torch.float64, device="cuda")
     d_info = torch.zeros(512, 40, dtype=torch.uint8, device="cuda")
-    st = torch.cuda.current_stream().cuda_stream
-    s.solve_device(512, d_in.data_ptr(), d_f.data_ptr(), d_info.data_ptr(), st)
-    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    s.solve_device(512, d_in.data_ptr(), d_f.data_ptr(), d_info.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
     assert np.array_equal(d_f.cpu().numpy(), f_host)
     assert s.last_kernel_ms() > 0
     s.close()
