@@ -573,51 +573,33 @@ static double ipm_mu(const solver_ws* ws, double* resid) {
   return rows ? sum / rows : 0.0;
 }
 
-/* linear forward sweep: du_k = d_k + K_k dx_k, dx_{k+1} = A dx_k + B du_k;
- * ds = -(J [dx;du] + c + s),  dlam = (target - s lam - lam ds) / s;
- * fraction-to-the-boundary step lengths. */
+/* Slack / multiplier directions from the TRIAL closed-loop rollout at alpha = 1
+ * (Xc, Uc): the cone rows are linear in u, so c(Uc) = c(U) + J (Uc - U) exactly:
+ *   ds = -(c(Uc) + s),  dlam = (target - s lam - lam ds) / s,
+ * followed by the fraction-to-the-boundary step lengths. */
 static void ipm_directions(solver_ws* ws, double tau, double* alpha_p, double* alpha_d) {
   const qo_problem* p = ws->prob;
-  const int ne = ws->ne, m = ws->m, N = ws->N;
-  double dx[NE_MAX], dxn[NE_MAX], du[M_MAX];
-  memset(dx, 0, sizeof dx);
+  const int n = ws->n, m = ws->m, N = ws->N;
+  double cc[QO_MAXP];
   double ap = 1.0, ad = 1.0;
   for (int k = 0; k <= N; ++k) {
     knot_ws* kw = &ws->kn[k];
-    if (k < N) {
-      for (int j = 0; j < m; ++j) {
-        double sacc = kw->d[j];
-        for (int b = 0; b < ne; ++b) sacc += kw->K[j * ne + b] * dx[b];
-        du[j] = sacc;
-      }
-    } else {
-      memset(du, 0, sizeof du);
-    }
+    const double* x = &ws->Xc[k * n];
+    const double* u = (k < N) ? &ws->Uc[k * m] : NULL;
     for (int ci = 0; ci < p->ncon; ++ci) {
       const qo_constraint* cn = &p->con[ci];
       if (!con_active_at(cn, k) || cn->type != QO_INEQUALITY) continue;
+      cn->con(cn->ctx, k, cc, x, u);
       for (int i = 0; i < cn->p; ++i) {
         if (!row_on(cn, i)) continue;
-        double jd = 0.0;
-        for (int b = 0; b < ne; ++b) jd += kw->Jx[ci][i * ne + b] * dx[b];
-        for (int j = 0; j < m; ++j) jd += kw->Ju[ci][i * m + j] * du[j];
         const double sv = kw->s[ci][i], lv = kw->lam[ci][i];
-        const double dsv = -(jd + kw->c[ci][i] + sv);
+        const double dsv = -(cc[i] + sv);
         const double dlv = (ws->ipm_target - sv * lv - lv * dsv) / sv;
         kw->ds[ci][i] = dsv;
         kw->dlam[ci][i] = dlv;
         if (dsv < 0.0) ap = fmin(ap, -tau * sv / dsv);
         if (dlv < 0.0) ad = fmin(ad, -tau * lv / dlv);
       }
-    }
-    if (k < N) {
-      for (int a = 0; a < ne; ++a) {
-        double sacc = 0.0;
-        for (int b = 0; b < ne; ++b) sacc += kw->A[a * ne + b] * dx[b];
-        for (int j = 0; j < m; ++j) sacc += kw->B[a * m + j] * du[j];
-        dxn[a] = sacc;
-      }
-      memcpy(dx, dxn, sizeof(double) * ne);
     }
   }
   *alpha_p = ap;
@@ -661,10 +643,11 @@ static int ipm_phase(solver_ws* ws, const qo_options* o, qo_result* r) {
     const int bp = backward_pass(ws);
     if (bp != QO_STATUS_OK) { ws->ipm = 0; return bp; }
     double ap, ad;
+    rollout_closed_loop(ws, 1.0);               /* trial step */
     ipm_directions(ws, o->ipm_tau, &ap, &ad);
     last_ap = ap; last_ad = ad;
     ws->ipm = 0;
-    rollout_closed_loop(ws, ap);
+    if (ap < 1.0) rollout_closed_loop(ws, ap);  /* shortened primal step */
     ipm_apply(ws, ap, ad);
     double step = 0.0;
     for (int i = 0; i < N * m; ++i) step = fmax(step, fabs(ws->Uc[i] - ws->U[i]));
