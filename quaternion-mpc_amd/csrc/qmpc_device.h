@@ -43,9 +43,14 @@ struct DevParams {
 
 // ---- per-instance LDS layout (offsets in doubles) ---------------------------
 struct Layout {
-  int cst, bw0, refp, uref, X, U, S, LAM, DS, DLAM, CV, AB, LX, LXX, KD;
-  int Pm, Am, Bm, Tm, Sm, rot, at, wts, gw, misc, dx, du, total;
+  int cst, bw0, refp, uref, X, U, Xc, Uc, S, LAM, DS, DLAM, CV, AB, XT, KD, ROT, tile, total;
 };
+
+// Per-knot record sizes
+constexpr int kAB = 27;    // Aphiphi(9) Aphiw(9) W(9)
+constexpr int kXT = 21;    // lxx attitude block (9), lx (12)
+constexpr int kKD = 156;   // gains [K | d], 12 x 13 row-major
+constexpr int kROT = 84;   // per leg: T(9), Dblk(9), gq(3)
 
 __host__ __device__ inline Layout make_layout(int N) {
   Layout L;
@@ -57,28 +62,19 @@ __host__ __device__ inline Layout make_layout(int N) {
   L.uref = take(12);
   L.X = take((N + 1) * 13);
   L.U = take(N * 12);
+  L.Xc = take((N + 1) * 13);
+  L.Uc = take(N * 12);
   L.S = take(N * 24);
   L.LAM = take(N * 24);
   L.DS = take(N * 24);
   L.DLAM = take(N * 24);
   L.CV = take(N * 24);
-  L.AB = take(N * 27);
-  L.LX = take((N + 1) * 12);
-  L.LXX = take((N + 1) * 9);
-  L.KD = take(N * 12 * 13);
-  o = (o + 1) & ~1;  // 16-byte alignment of the MFMA tiles
-  L.Pm = take(MAT);
-  L.Am = take(MAT);
-  L.Bm = take(MAT);
-  L.Tm = take(MAT);
-  L.Sm = take(MAT);
-  L.rot = take(36);
-  L.at = take(72);
-  L.wts = take(24);
-  L.gw = take(24);
-  L.misc = take(32);
-  L.dx = take(24);
-  L.du = take(12);
+  L.AB = take(N * kAB);
+  L.XT = take((N + 1) * kXT);
+  L.KD = take(N * kKD);
+  L.ROT = take(N * kROT);
+  o = (o + 1) & ~1;  // 16-byte alignment of the tile
+  L.tile = take(MAT);
   L.total = (o + 1) & ~1;
   return L;
 }
@@ -108,6 +104,13 @@ __device__ __forceinline__ void mtm_load(const double* X, const double* Y, int l
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y1, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, y2, acc, 0, 0, 0);
 }
+// register-resident fragments: acc += X' * Y
+__device__ __forceinline__ d4 mtm3(const double X[3], const double Y[3], d4 acc) {
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[0], Y[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[1], Y[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[2], Y[2], acc, 0, 0, 0);
+  return acc;
+}
 __device__ __forceinline__ void mtm(double* C, const double* X, const double* Y, int lane) {
   d4 acc = {0.0, 0.0, 0.0, 0.0};
   mtm_load(X, Y, lane, acc);
@@ -131,6 +134,23 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   return v;
+}
+
+// ---- cross-lane moves inside the MFMA fragment layout --------------------------
+// lane = 16*g + c holds rows {g, 4+g, 8+g} of column c.
+// value of lane (g, J) of the same 16-lane row (DPP row_newbcast, no LDS)
+template <int J>
+__device__ __forceinline__ double row_bcast(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + J, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + J, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// wave-uniform copy of lane l's value (v_readlane -> SGPRs)
+__device__ __forceinline__ double read_lane(double x, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
 }
 
 // ---- quaternion helpers (QuaternionUtils.cpp:30-52) --------------------------

@@ -1,4 +1,4 @@
-// qmpc_kernels.hip -- gfx950 kernels of the batched quaternion-MPC solve.
+// qmpc_kernels.hip -- gfx950 kernels of the batched quaternion-MPC solve (v2).
 //
 // One wavefront (64 lanes, one workgroup) owns one MPC instance.  The solve is
 // the converged mode of include/qmpc.h: a primal-dual interior-point iteration
@@ -6,8 +6,14 @@
 // horizon (12-dim error state, 12 inputs), i.e. the same backward/forward pass
 // structure as the reference's external AL-iLQR solver (QuatMpc.cpp:218-256),
 // with the cone rows (QuatMpc.cpp:194-215) handled by barrier weights instead of
-// penalties.  All 12x12 products run on the FP64 matrix core
-// (v_mfma_f64_16x16x4_f64) from [12][16] LDS tiles.
+// penalties.
+//
+// v2 data flow of the backward pass: every 12x12 (+1 gradient column) matrix is
+// held in REGISTERS in the FP64 MFMA fragment layout (lane 16g+c holds rows
+// {g,4+g,8+g} of column c), so the 18 v_mfma_f64_16x16x4_f64 per knot chain
+// without any LDS round trip; per-lane index patterns are computed once; the
+// stage solve is a Gauss-Jordan elimination done with cross-lane moves (DPP
+// row broadcast + ds_bpermute) in the same layout.
 #include "qmpc_device.h"
 
 namespace qmpc {
@@ -43,7 +49,7 @@ __device__ inline void setup_instance(const DevParams& P, const Layout& L, doubl
   // one coalesced 8-byte-per-lane read of the 48-double record
   const double v = (lane < 48) ? rec[lane] : 0.0;
   const unsigned long long bad = __ballot(lane < 48 && !isfinite(v));
-  double* raw = sm + L.Pm;  // scratch
+  double* raw = sm + L.tile;  // scratch
   if (lane < 48) raw[lane] = v;
   QSYNC();
   // raw: quat 0..3, rot 4..12, linvel 13..15, angvel 16..18, foot 19..30,
@@ -144,11 +150,11 @@ __device__ inline void expansions(const DevParams& P, const Layout& L, double* s
     expand_knot(P, sm + L.cst, sm + L.bw0, sm + L.refp, lane, x, u, xn, AB, lx, lxx);
     if (lane < N)
 #pragma unroll
-      for (int i = 0; i < 27; ++i) sm[L.AB + 27 * lane + i] = AB[i];
+      for (int i = 0; i < 27; ++i) sm[L.AB + kAB * lane + i] = AB[i];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) sm[L.LX + 12 * lane + i] = lx[i];
+    for (int i = 0; i < 9; ++i) sm[L.XT + kXT * lane + i] = lxx[i];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) sm[L.LXX + 9 * lane + i] = lxx[i];
+    for (int i = 0; i < 12; ++i) sm[L.XT + kXT * lane + 9 + i] = lx[i];
   }
   // cone values c = C R u_l + b  (QuatMpc.cpp:194-205), N*24 rows
   const double* cr = sm + L.cst + C_CR;
@@ -162,311 +168,279 @@ __device__ inline void expansions(const DevParams& P, const Layout& L, double* s
   QSYNC();
 }
 
-// Per-leg rotation of the input coordinates for knot k (see DESIGN.md "rotated
-// stage solve"): T_l = [q1 q2 q3] with q1 along the heaviest cone row, q2 the
-// Gram-Schmidt complement of the second heaviest non-parallel row.  Lanes 0..3
-// (one per leg) write rot[9*l + 3*a + b] = T_l[a][b], at[18*l + 3*i + b] =
-// (T_l' a_i)[b], and lanes 0..23 write wts (Hessian weight) / gw (gradient weight).
-__device__ inline void leg_rotations(const DevParams& P, const Layout& L, double* sm, int k,
-                                     double target, int lane) {
+// Pre-pass over all (knot, leg) pairs, one lane each: rotation T_l of the leg's
+// input coordinates (q1 along the heaviest cone row, q2 the Gram-Schmidt
+// complement of the second heaviest non-parallel row, q3 = q1 x q2; see
+// DESIGN.md "rotated stage solve") and the blocks the backward pass adds in the
+// rotated coordinates:
+//   Dblk = T' R_l T + sum_i w_i (T'a_i)(T'a_i)',   w_i = lam_i / s_i
+//   gq   = T' (R_l (u_l - uref_l)) + sum_i g_i (T'a_i),  g_i = target/s_i + w_i (c_i + s_i)
+// ROT record per leg: T (9, row-major [a][b]), Dblk (9), gq (3).
+__device__ inline void rotation_prepass(const DevParams& P, const Layout& L, double* sm, double target,
+                                        int lane) {
+  const int N = P.N;
   const double* cst = sm + L.cst;
-  if (lane < 24) {
-    const int l = lane / 6;
-    const double on = cst[C_CON + l];
-    const double s = sm[L.S + 24 * k + lane], lam = sm[L.LAM + 24 * k + lane];
-    const double c = sm[L.CV + 24 * k + lane];
-    const double w = (on != 0.0) ? lam / s : 0.0;
-    sm[L.wts + lane] = w;
-    sm[L.gw + lane] = (on != 0.0) ? (target / s + w * (c + s)) : 0.0;
-  }
-  QSYNC();
-  if (lane < 4) {
-    const int l = lane;
-    double T[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    const double* cr = cst + C_CR;
-    if (cst[C_CON + l] != 0.0) {
-      const double* w = sm + L.wts + 6 * l;
-      int i1 = 0;
-      for (int i = 1; i < 6; ++i) if (w[i] > w[i1]) i1 = i;
-      int i2 = -1;
-      for (int i = 0; i < 6; ++i) {
-        if (i == i1) continue;
-        if ((i1 >= 4) && (i >= 4)) continue;  // rows 4,5 are antiparallel
-        if (i2 < 0 || w[i] > w[i2]) i2 = i;
-      }
-      double q1[3], q2[3], q3[3];
-      double n1 = sqrt(cr[3 * i1] * cr[3 * i1] + cr[3 * i1 + 1] * cr[3 * i1 + 1] + cr[3 * i1 + 2] * cr[3 * i1 + 2]);
-      for (int a = 0; a < 3; ++a) q1[a] = cr[3 * i1 + a] / n1;
-      double v[3] = {cr[3 * i2], cr[3 * i2 + 1], cr[3 * i2 + 2]};
-      for (int pass = 0; pass < 2; ++pass) {
-        const double dp = v[0] * q1[0] + v[1] * q1[1] + v[2] * q1[2];
-        for (int a = 0; a < 3; ++a) v[a] -= dp * q1[a];
-      }
-      const double n2 = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-      for (int a = 0; a < 3; ++a) q2[a] = v[a] / n2;
-      q3[0] = q1[1] * q2[2] - q1[2] * q2[1];
-      q3[1] = q1[2] * q2[0] - q1[0] * q2[2];
-      q3[2] = q1[0] * q2[1] - q1[1] * q2[0];
-      for (int a = 0; a < 3; ++a) { T[3 * a] = q1[a]; T[3 * a + 1] = q2[a]; T[3 * a + 2] = q3[a]; }
+  double cr[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) cr[i] = cst[C_CR + i];
+  for (int q = lane; q < 4 * N; q += kWave) {
+    const int k = q >> 2, l = q & 3;
+    double* out = sm + L.ROT + kROT * k + 21 * l;
+    const double R0 = P.R[3 * l], R1 = P.R[3 * l + 1], R2 = P.R[3 * l + 2];
+    if (cst[C_CON + l] == 0.0) {
+      // swing leg: identity frame, block = R, zero gradient (forces pinned to 0)
+      out[0] = 1; out[1] = 0; out[2] = 0; out[3] = 0; out[4] = 1; out[5] = 0; out[6] = 0; out[7] = 0; out[8] = 1;
+      out[9] = R0; out[10] = 0; out[11] = 0; out[12] = 0; out[13] = R1; out[14] = 0; out[15] = 0; out[16] = 0; out[17] = R2;
+      out[18] = 0; out[19] = 0; out[20] = 0;
+      continue;
     }
-    for (int i = 0; i < 9; ++i) sm[L.rot + 9 * l + i] = T[i];
+    double w[6], gi[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double s = sm[L.S + 24 * k + 6 * l + i], lam = sm[L.LAM + 24 * k + 6 * l + i];
+      const double c = sm[L.CV + 24 * k + 6 * l + i];
+      w[i] = lam / s;
+      gi[i] = target / s + w[i] * (c + s);
+    }
+    // heaviest row i1, second heaviest non-(anti)parallel row i2 (rows 4,5 are antiparallel)
+    int i1 = 0;
+    double w1 = w[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) if (w[i] > w1) { w1 = w[i]; i1 = i; }
+    int i2 = -1;
+    double w2 = -1.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const bool skip = (i == i1) || ((i1 >= 4) && (i >= 4));
+      if (!skip && w[i] > w2) { w2 = w[i]; i2 = i; }
+    }
+    double a1[3] = {0, 0, 0}, a2[3] = {0, 0, 0};
+#pragma unroll
     for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        a1[a] = (i == i1) ? cr[3 * i + a] : a1[a];
+        a2[a] = (i == i2) ? cr[3 * i + a] : a2[a];
+      }
+    const double n1 = sqrt(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
+    double q1[3], q2[3], q3[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) q1[a] = a1[a] / n1;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const double dp = a2[0] * q1[0] + a2[1] * q1[1] + a2[2] * q1[2];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) a2[a] -= dp * q1[a];
+    }
+    const double n2 = sqrt(a2[0] * a2[0] + a2[1] * a2[1] + a2[2] * a2[2]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) q2[a] = a2[a] / n2;
+    q3[0] = q1[1] * q2[2] - q1[2] * q2[1];
+    q3[1] = q1[2] * q2[0] - q1[0] * q2[2];
+    q3[2] = q1[0] * q2[1] - q1[1] * q2[0];
+    double T[9];  // T[3a+b] = (q_b)_a
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { T[3 * a] = q1[a]; T[3 * a + 1] = q2[a]; T[3 * a + 2] = q3[a]; }
+    double D[9], gq[3];
+    const double Rl[3] = {R0, R1, R2};
+    const double* u = sm + L.U + 12 * k + 3 * l;
+    const double* ur = sm + L.uref + 3 * l;
+    const double ru[3] = {R0 * (u[0] - ur[0]), R1 * (u[1] - ur[1]), R2 * (u[2] - ur[2])};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      gq[a] = T[a] * ru[0] + T[3 + a] * ru[1] + T[6 + a] * ru[2];
+#pragma unroll
       for (int b = 0; b < 3; ++b)
-        sm[L.at + 18 * l + 3 * i + b] = T[b] * cr[3 * i] + T[3 + b] * cr[3 * i + 1] + T[6 + b] * cr[3 * i + 2];
+        D[3 * a + b] = T[a] * Rl[0] * T[b] + T[3 + a] * Rl[1] * T[3 + b] + T[6 + a] * Rl[2] * T[6 + b];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      double at[3];  // rotated row: at[b] = sum_a T[a][b] a_i[a]
+#pragma unroll
+      for (int b = 0; b < 3; ++b) at[b] = T[b] * cr[3 * i] + T[3 + b] * cr[3 * i + 1] + T[6 + b] * cr[3 * i + 2];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        gq[a] += gi[i] * at[a];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) D[3 * a + b] += w[i] * at[a] * at[b];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { out[i] = T[i]; out[9 + i] = D[i]; }
+    out[18] = gq[0]; out[19] = gq[1]; out[20] = gq[2];
   }
   QSYNC();
 }
 
-// Solve  Sm * X = -Tm  for the 13 columns of Tm by Gaussian elimination without
-// pivoting (Sm is SPD and, in the rotated coordinates, scaled-diagonally
-// dominant); X -> Bm.  All three are [12][16] tiles.
-__device__ inline int stage_solve(double* Sm, double* Tm, double* Bm, int lane) {
-  int bad = 0;
+// One Gauss-Jordan step on pivot J of the pair (M | Rr) held in the fragment
+// layout: the pivot row is normalised and eliminated from every other row.
+template <int J>
+__device__ __forceinline__ void gj_step(double M[3], double Rr[3], int c, int g, int& bad) {
+  constexpr int ej = J >> 2, gj = J & 3;
+  const int src = (gj << 4) | c;
+  double mrow = __shfl(M[ej], src);
+  double rrow = __shfl(Rr[ej], src);
+  const double piv = read_lane(M[ej], (gj << 4) | J);
+  bad |= !(piv > 0.0);
+  const double inv = 1.0 / piv;
+  mrow *= inv;
+  rrow *= inv;
 #pragma unroll
-  for (int j = 0; j < 11; ++j) {
-    const int nr = 11 - j;         // rows below the pivot
-    const int ncols = nr + 13;     // trailing matrix columns + 13 right-hand sides
-    const double piv = Sm[j * LD + j];
-    bad |= !(piv > 0.0);
-    const double inv = 1.0 / piv;
-    for (int idx = lane; idx < nr * ncols; idx += kWave) {
-      const int i = j + 1 + idx / ncols;
-      const int cc = idx - (i - j - 1) * ncols;
-      const double f = Sm[i * LD + j] * inv;
-      if (cc < nr) {
-        const int c = j + 1 + cc;
-        Sm[i * LD + c] -= f * Sm[j * LD + c];
-      } else {
-        const int c = cc - nr;
-        Tm[i * LD + c] -= f * Tm[j * LD + c];
-      }
-    }
-    QSYNC();
+  for (int e = 0; e < 3; ++e) {
+    const double col = row_bcast<J>(M[e]);
+    const bool isp = (e == ej) && (g == gj);
+    M[e] = isp ? mrow : (M[e] - col * mrow);
+    Rr[e] = isp ? rrow : (Rr[e] - col * rrow);
   }
-  // back substitution, one lane per right-hand side
-  if (lane < 13) {
-    double xs[12];
-#pragma unroll
-    for (int i = 11; i >= 0; --i) {
-      double s = Tm[i * LD + lane];
-#pragma unroll
-      for (int t = i + 1; t < 12; ++t) s -= Sm[i * LD + t] * xs[t];
-      xs[i] = s / Sm[i * LD + i];
-    }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) Bm[i * LD + lane] = -xs[i];
-  } else if (lane < 16) {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) Bm[i * LD + lane] = 0.0;
-  }
-  bad |= !(Sm[11 * LD + 11] > 0.0);
-  QSYNC();
-  return bad;
 }
 
 // Riccati backward pass with interior-point weights; writes KD (unrotated gains
 // [K | d], 12 x 13 per knot).  Returns nonzero when a pivot is not positive.
 template <bool PROF>
-__device__ inline int backward_pass(const DevParams& P, const Layout& L, double* sm, double target,
-                                    int lane, Prof<PROF>& prof) {
+__device__ inline int backward_pass(const DevParams& P, const Layout& L, double* sm, int lane,
+                                    unsigned conmask, Prof<PROF>& prof) {
   const int N = P.N;
-  double* Pm = sm + L.Pm; double* Am = sm + L.Am; double* Bm = sm + L.Bm;
-  double* Tm = sm + L.Tm; double* Sm = sm + L.Sm;
   const double* cst = sm + L.cst;
   const double* bw0 = sm + L.bw0;
-  int notpd = 0;
-  // terminal cost-to-go: P = lxx_N, p = lx_N (column 12)
-  for (int idx = lane; idx < MAT; idx += kWave) {
-    const int r = idx / LD, c = idx - LD * r;
-    double v = 0.0;
-    if (c < 12) {
-      if (r >= 3 && r < 6 && c >= 3 && c < 6) v = sm[L.LXX + 9 * N + 3 * (r - 3) + (c - 3)];
-      else if (r == c) v = P.Q[(r < 3) ? r : r + 1];
-    } else if (c == 12) {
-      v = sm[L.LX + 12 * N + r];
+  const int c = lane & 15, g = lane >> 4;
+  const bool cval = c < 12;
+  const int lc = cval ? c / 3 : 0, bc = cval ? c - 3 * lc : 0;
+  // ---- per-lane, per-fragment patterns (row r_e = 4e + g) ----
+  double Ac[3], qadd[3], Bc[3][3], hbw[3][3];
+  int aoff[3], xoff[3], doff[3], goff[3], koff[3];
+  bool phi[3];
+  const double conl = cval ? cst[C_CON + lc] : 0.0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) hbw[j][a] = cval ? P.h * bw0[12 * j + 3 * lc + a] : 0.0;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const int r = 4 * e + g;
+    const int lr = r / 3, ar = r - 3 * lr;
+    phi[e] = (r >= 3 && r < 6);
+    Ac[e] = cval ? ((((r == c) && !phi[e]) ? 1.0 : 0.0) + ((r < 3 && c == r + 6) ? P.h : 0.0)) : 0.0;
+    aoff[e] = -1;
+    if (phi[e] && c >= 3 && c < 6) aoff[e] = 3 * (r - 3) + (c - 3);
+    if (phi[e] && c >= 9 && c < 12) aoff[e] = 9 + 3 * (r - 3) + (c - 9);
+    qadd[e] = (cval && r == c && !phi[e]) ? P.Q[(r < 3) ? r : r + 1] : 0.0;
+    xoff[e] = -1;
+    if (phi[e] && c >= 3 && c < 6) xoff[e] = 3 * (r - 3) + (c - 3);
+    if (c == 12) xoff[e] = 9 + r;
+    doff[e] = (cval && lc == lr) ? 21 * lr + 9 + 3 * ar + bc : -1;
+    goff[e] = (c == 12) ? 21 * lr + 18 + ar : -1;
+    koff[e] = (c < 13) ? 13 * r + c : -1;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      double v = 0.0;
+      if (cval) {
+        if (r < 3) v = (r == a) ? conl * (P.h * (P.hh * (1.0 / P.mass))) : 0.0;
+        else if (r >= 6 && r < 9) v = (r - 6 == a) ? conl * (P.h * (1.0 / P.mass)) : 0.0;
+        else if (r >= 9) v = P.h * bw0[12 * (r - 9) + 3 * lc + a];
+      }
+      Bc[e][a] = v;
     }
-    Pm[idx] = v;
   }
-  QSYNC();
+  // ---- terminal cost-to-go  P_aug = [lxx_N | lx_N] ----
+  double Pf[3];
+  {
+    const double* XTk = sm + L.XT + kXT * N;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) Pf[e] = qadd[e] + ((xoff[e] >= 0) ? XTk[xoff[e]] : 0.0);
+  }
+  int bad = 0;
+  double* tile = sm + L.tile;
   for (int k = N - 1; k >= 0; --k) {
-    const double* AB = sm + L.AB + 27 * k;
-    leg_rotations(P, L, sm, k, target, lane);
-    const double* rot = sm + L.rot;
-    // dense Abar and rotated Bbar*T tiles
-    for (int idx = lane; idx < MAT; idx += kWave) {
-      const int r = idx / LD, c = idx - LD * r;
-      double a = 0.0, b = 0.0;
-      if (c < 12) {
-        a = abar_elem(P, AB, r, c);
-        const int l = c / 3, bb = c - 3 * l;
-        const double* T = rot + 9 * l;
-        b = bbar_elem(P, cst, bw0, AB, r, 3 * l) * T[bb] +
-            bbar_elem(P, cst, bw0, AB, r, 3 * l + 1) * T[3 + bb] +
-            bbar_elem(P, cst, bw0, AB, r, 3 * l + 2) * T[6 + bb];
+    const double* AB = sm + L.AB + kAB * k;
+    const double* ROTk = sm + L.ROT + kROT * k;
+    const double* XTk = sm + L.XT + kXT * k;
+    // ---- operands: Abar and rotated Bbar * T, straight into fragments ----
+    double Af[3], Bf[3];
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    if (cval) { t0 = ROTk[21 * lc + bc]; t1 = ROTk[21 * lc + 3 + bc]; t2 = ROTk[21 * lc + 6 + bc]; }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      Af[e] = (aoff[e] >= 0) ? AB[aoff[e]] : Ac[e];
+      double b0 = Bc[e][0], b1 = Bc[e][1], b2 = Bc[e][2];
+      if (phi[e]) {
+        const double* W = AB + 18 + 3 * (4 * e + g - 3);
+        const double w0 = W[0], w1 = W[1], w2 = W[2];
+        b0 = (0.5 * P.hh) * (w0 * hbw[0][0] + w1 * hbw[1][0] + w2 * hbw[2][0]);
+        b1 = (0.5 * P.hh) * (w0 * hbw[0][1] + w1 * hbw[1][1] + w2 * hbw[2][1]);
+        b2 = (0.5 * P.hh) * (w0 * hbw[0][2] + w1 * hbw[1][2] + w2 * hbw[2][2]);
       }
-      Am[idx] = a;
-      Bm[idx] = b;
+      Bf[e] = b0 * t0 + b1 * t1 + b2 * t2;
     }
-    QSYNC();
     prof.tick(PH_BUILD);
-    // T = P'A (col 12 <- p), S = P'B
-    {
-      d4 accT = {0, 0, 0, 0}, accS = {0, 0, 0, 0};
-      mtm_load(Pm, Am, lane, accT);
-      mtm_load(Pm, Bm, lane, accS);
-      const bool c12 = (lane & 15) == 12;
-      Tm[lane] = c12 ? Pm[lane] : accT[0];
-      Tm[64 + lane] = c12 ? Pm[64 + lane] : accT[1];
-      Tm[128 + lane] = c12 ? Pm[128 + lane] : accT[2];
-      Sm[lane] = accS[0]; Sm[64 + lane] = accS[1]; Sm[128 + lane] = accS[2];
-    }
-    QSYNC();
-    // Qxx_aug = A'T_aug -> Am ; Qux_aug = B'T_aug -> Tm ; Quu = B'S -> Sm
-    {
-      d4 a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
-      mtm_load(Am, Tm, lane, a1);
-      mtm_load(Bm, Tm, lane, a2);
-      mtm_load(Bm, Sm, lane, a3);
-      QSYNC();
-      Am[lane] = a1[0]; Am[64 + lane] = a1[1]; Am[128 + lane] = a1[2];
-      Tm[lane] = a2[0]; Tm[64 + lane] = a2[1]; Tm[128 + lane] = a2[2];
-      Sm[lane] = a3[0]; Sm[64 + lane] = a3[1]; Sm[128 + lane] = a3[2];
-    }
-    QSYNC();
-    // stage cost + barrier terms
-    for (int idx = lane; idx < MAT; idx += kWave) {
-      const int r = idx / LD, c = idx - LD * r;
-      if (c < 12) {
-        // Qxx += lxx
-        double v = 0.0;
-        if (r >= 3 && r < 6 && c >= 3 && c < 6) v = sm[L.LXX + 9 * k + 3 * (r - 3) + (c - 3)];
-        else if (r == c) v = P.Q[(r < 3) ? r : r + 1];
-        Am[idx] += v;
-        // Quu leg block += T' R T + sum_i w_i at_i at_i'
-        const int l = r / 3, a = r - 3 * l;
-        if (c / 3 == l) {
-          const int b = c - 3 * l;
-          const double* T = rot + 9 * l;
-          double q = T[a] * P.R[3 * l] * T[b] + T[3 + a] * P.R[3 * l + 1] * T[3 + b] +
-                     T[6 + a] * P.R[3 * l + 2] * T[6 + b];
-          const double* at = sm + L.at + 18 * l;
-          const double* w = sm + L.wts + 6 * l;
+    // ---- T = P'A (col 12 <- p), S = P'B ; Qxx = A'T, Qux = B'T, Quu = B'S ----
+    const d4 z4 = {0.0, 0.0, 0.0, 0.0};
+    const d4 aT = mtm3(Pf, Af, z4);
+    const d4 aS = mtm3(Pf, Bf, z4);
+    double Tf[3], Sf[3];
 #pragma unroll
-          for (int i = 0; i < 6; ++i) q += w[i] * at[3 * i + a] * at[3 * i + b];
-          Sm[idx] += q;
-        }
-      } else if (c == 12) {
-        // Qx += lx
-        Am[idx] += sm[L.LX + 12 * k + r];
-        // Qu (rotated) += T'(R (u - uref)) + sum_i g_i at_i
-        const int l = r / 3, a = r - 3 * l;
-        const double* T = rot + 9 * l;
-        const double* u = sm + L.U + 12 * k + 3 * l;
-        const double* ur = sm + L.uref + 3 * l;
-        double q = T[a] * P.R[3 * l] * (u[0] - ur[0]) + T[3 + a] * P.R[3 * l + 1] * (u[1] - ur[1]) +
-                   T[6 + a] * P.R[3 * l + 2] * (u[2] - ur[2]);
-        const double* at = sm + L.at + 18 * l;
-        const double* g = sm + L.gw + 6 * l;
+    for (int e = 0; e < 3; ++e) { Tf[e] = (c == 12) ? Pf[e] : aT[e]; Sf[e] = aS[e]; }
+    const d4 aXX = mtm3(Af, Tf, z4);
+    const d4 aUX = mtm3(Bf, Tf, z4);
+    const d4 aUU = mtm3(Bf, Sf, z4);
+    double Qxx[3], Qux[3], Quu[3], Rr[3];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) q += g[i] * at[3 * i + a];
-        Tm[idx] += q;
-      }
+    for (int e = 0; e < 3; ++e) {
+      Qxx[e] = aXX[e] + qadd[e] + ((xoff[e] >= 0) ? XTk[xoff[e]] : 0.0);
+      Qux[e] = aUX[e] + ((goff[e] >= 0) ? ROTk[goff[e]] : 0.0);
+      Quu[e] = aUU[e] + ((doff[e] >= 0) ? ROTk[doff[e]] : 0.0);
+      Rr[e] = Qux[e];
     }
-    QSYNC();
-    // keep Qux_aug for the cost-to-go update (the solve destroys Tm): copy to Pm
-    Pm[lane] = Tm[lane]; Pm[64 + lane] = Tm[64 + lane]; Pm[128 + lane] = Tm[128 + lane];
-    QSYNC();
     prof.tick(PH_MFMA);
-    notpd |= stage_solve(Sm, Tm, Bm, lane);   // Bm <- [Kt | dt] (rotated)
+    // ---- stage solve: [Kt | dt] = -Quu^-1 [Qux | Qu]; swing-leg pivots are decoupled ----
+    if (conmask & 1u) { gj_step<0>(Quu, Rr, c, g, bad); gj_step<1>(Quu, Rr, c, g, bad); gj_step<2>(Quu, Rr, c, g, bad); }
+    if (conmask & 2u) { gj_step<3>(Quu, Rr, c, g, bad); gj_step<4>(Quu, Rr, c, g, bad); gj_step<5>(Quu, Rr, c, g, bad); }
+    if (conmask & 4u) { gj_step<6>(Quu, Rr, c, g, bad); gj_step<7>(Quu, Rr, c, g, bad); gj_step<8>(Quu, Rr, c, g, bad); }
+    if (conmask & 8u) { gj_step<9>(Quu, Rr, c, g, bad); gj_step<10>(Quu, Rr, c, g, bad); gj_step<11>(Quu, Rr, c, g, bad); }
+    double Kf[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) Kf[e] = -Rr[e];
     prof.tick(PH_SOLVE);
-    // unrotate and store the gains: KD[3l+a][c] = sum_b T_l[a][b] * Bm[3l+b][c]
-    for (int idx = lane; idx < 12 * 13; idx += kWave) {
-      const int r = idx / 13, c = idx - 13 * r, l = r / 3, a = r - 3 * l;
-      const double* T = rot + 9 * l;
-      sm[L.KD + 156 * k + idx] = T[3 * a] * Bm[(3 * l) * LD + c] + T[3 * a + 1] * Bm[(3 * l + 1) * LD + c] +
-                                  T[3 * a + 2] * Bm[(3 * l + 2) * LD + c];
-    }
-    // P_aug <- Qxx_aug + Qux_aug' [Kt | dt]
+    // ---- cost-to-go: P_aug <- Qxx_aug + Qux_aug' [Kt | dt] ----
     {
-      d4 acc = {Am[lane], Am[64 + lane], Am[128 + lane], 0.0};
-      mtm_load(Pm, Bm, lane, acc);
-      QSYNC();
-      Pm[lane] = acc[0]; Pm[64 + lane] = acc[1]; Pm[128 + lane] = acc[2];
+      d4 acc = {Qxx[0], Qxx[1], Qxx[2], 0.0};
+      acc = mtm3(Qux, Kf, acc);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) Pf[e] = acc[e];
+    }
+    // ---- un-rotate and store the gains: KD[3l+a][c] = sum_b T_l[a][b] Kt[3l+b][c] ----
+    tile[lane] = Kf[0]; tile[64 + lane] = Kf[1]; tile[128 + lane] = Kf[2];
+    QSYNC();
+    {
+      double* KDk = sm + L.KD + kKD * k;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        if (koff[e] >= 0) {
+          const int r = 4 * e + g, lr = r / 3, ar = r - 3 * lr;
+          const double* T = ROTk + 21 * lr + 3 * ar;
+          const double* col = tile + (3 * lr) * LD + c;
+          KDk[koff[e]] = T[0] * col[0] + T[1] * col[LD] + T[2] * col[2 * LD];
+        }
+      }
     }
     QSYNC();
     prof.tick(PH_PUPD);
   }
-  return notpd;
+  return bad;
 }
 
-// linear forward sweep: du, ds, dlam and the fraction-to-the-boundary lengths
-__device__ inline void ipm_directions(const DevParams& P, const Layout& L, double* sm, double target,
-                                      int lane, double* alpha_p, double* alpha_d) {
+// nonlinear closed-loop rollout with step alpha from (X,U) into the candidate
+// (Xc,Uc): u' = u + alpha d + K (x' (-) x)
+__device__ inline void rollout_closed(const DevParams& P, const Layout& L, double* sm, double alpha,
+                                      int lane) {
   const int N = P.N;
   const double* cst = sm + L.cst;
   const double* bw0 = sm + L.bw0;
-  double* dx = sm + L.dx;
-  double* du = sm + L.du;
-  if (lane < 12) dx[lane] = 0.0;
-  QSYNC();
-  double ap = 1.0, ad = 1.0;
-  int cur = 0;
-  for (int k = 0; k < N; ++k) {
-    const double* dxc = dx + 12 * cur;
-    double* dxn = dx + 12 * (cur ^ 1);
-    if (lane < 12) {
-      const double* kd = sm + L.KD + 156 * k + 13 * lane;
-      double s = kd[12];
-#pragma unroll
-      for (int b = 0; b < 12; ++b) s += kd[b] * dxc[b];
-      du[lane] = s;
-    }
-    QSYNC();
-    if (lane < 24) {
-      const int l = lane / 6, i = lane - 6 * l;
-      if (cst[C_CON + l] != 0.0) {
-        const double* cr = cst + C_CR + 3 * i;
-        const double jd = cr[0] * du[3 * l] + cr[1] * du[3 * l + 1] + cr[2] * du[3 * l + 2];
-        const double sv = sm[L.S + 24 * k + lane], lv = sm[L.LAM + 24 * k + lane];
-        const double dsv = -(jd + sm[L.CV + 24 * k + lane] + sv);
-        const double dlv = (target - sv * lv - lv * dsv) / sv;
-        sm[L.DS + 24 * k + lane] = dsv;
-        sm[L.DLAM + 24 * k + lane] = dlv;
-        if (dsv < 0.0) ap = fmin(ap, -P.tau * sv / dsv);
-        if (dlv < 0.0) ad = fmin(ad, -P.tau * lv / dlv);
-      } else {
-        sm[L.DS + 24 * k + lane] = 0.0;
-        sm[L.DLAM + 24 * k + lane] = 0.0;
-      }
-    } else if (lane >= 32 && lane < 44) {
-      // dx+ = Abar dx + Bbar du
-      const int r = lane - 32;
-      const double* AB = sm + L.AB + 27 * k;
-      double s = 0.0;
-#pragma unroll
-      for (int c = 0; c < 12; ++c) s += abar_elem(P, AB, r, c) * dxc[c];
-#pragma unroll
-      for (int c = 0; c < 12; ++c) s += bbar_elem(P, cst, bw0, AB, r, c) * du[c];
-      dxn[r] = s;
-    }
-    QSYNC();
-    cur ^= 1;
-  }
-  *alpha_p = wave_min(ap);
-  *alpha_d = wave_min(ad);
-}
-
-// nonlinear closed-loop rollout with step alpha, in place; returns |dU|_inf
-__device__ inline double rollout_closed(const DevParams& P, const Layout& L, double* sm, double alpha,
-                                        int lane) {
-  const int N = P.N;
-  const double* cst = sm + L.cst;
-  const double* bw0 = sm + L.bw0;
-  double* du = sm + L.du;  // holds the new input of the current knot
   double xc[13], xn[13];
 #pragma unroll
   for (int i = 0; i < 13; ++i) xc[i] = cst[C_X0 + i];
-  double step = 0.0;
+  if (lane == 0)
+#pragma unroll
+    for (int i = 0; i < 13; ++i) sm[L.Xc + i] = xc[i];
   for (int k = 0; k < N; ++k) {
     // dx = xc (-) X_k : inverse Cayley map of q_k^-1 * qc (QuaternionUtils.cpp:16-18)
     double xo[13];
@@ -488,33 +462,53 @@ __device__ inline double rollout_closed(const DevParams& P, const Layout& L, dou
         dx[3 + a] = (G[a] * xc[3] + G[3 + a] * xc[4] + G[6 + a] * xc[5] + G[9 + a] * xc[6]) / sc;
     }
     if (lane < 12) {
-      const double* kd = sm + L.KD + 156 * k + 13 * lane;
-      const double uo = sm[L.U + 12 * k + lane];
-      double s = uo + alpha * kd[12];
+      const double* kd = sm + L.KD + kKD * k + 13 * lane;
+      double s = sm[L.U + 12 * k + lane] + alpha * kd[12];
 #pragma unroll
       for (int b = 0; b < 12; ++b) s += kd[b] * dx[b];
-      du[lane] = s;
-      step = fmax(step, fabs(s - uo));
+      sm[L.Uc + 12 * k + lane] = s;
     }
     QSYNC();
     double un[12];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) un[j] = du[j];
+    for (int j = 0; j < 12; ++j) un[j] = sm[L.Uc + 12 * k + j];
     srbd_step(P, cst, bw0, xc, un, xn);
-    // publish the new knot (old x_k, u_k are no longer needed)
-    if (lane == 0)
-#pragma unroll
-      for (int i = 0; i < 13; ++i) sm[L.X + 13 * k + i] = xc[i];
-    if (lane < 12) sm[L.U + 12 * k + lane] = du[lane];
 #pragma unroll
     for (int i = 0; i < 13; ++i) xc[i] = xn[i];
-    QSYNC();
-  }
-  if (lane == 0)
+    if (lane == 0)
 #pragma unroll
-    for (int i = 0; i < 13; ++i) sm[L.X + 13 * N + i] = xc[i];
+      for (int i = 0; i < 13; ++i) sm[L.Xc + 13 * (k + 1) + i] = xn[i];
+  }
   QSYNC();
-  return wave_max(step);
+}
+
+// slack / multiplier directions from the trial rollout (cone rows are linear in
+// u):  ds = -(c(Uc) + s), dlam = (target - s lam - lam ds)/s, and the
+// fraction-to-the-boundary step lengths
+__device__ inline void ipm_directions(const DevParams& P, const Layout& L, double* sm, double target,
+                                      int lane, double* alpha_p, double* alpha_d) {
+  const int N = P.N;
+  const double* cst = sm + L.cst;
+  const double* cr = cst + C_CR;
+  double ap = 1.0, ad = 1.0;
+  for (int idx = lane; idx < N * 24; idx += kWave) {
+    const int k = idx / 24, row = idx - 24 * k, l = row / 6, i = row - 6 * l;
+    double dsv = 0.0, dlv = 0.0;
+    if (cst[C_CON + l] != 0.0) {
+      const double* u = sm + L.Uc + 12 * k + 3 * l;
+      double cc = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
+      if (i == 4) cc += -P.fz_max;
+      const double sv = sm[L.S + idx], lv = sm[L.LAM + idx];
+      dsv = -(cc + sv);
+      dlv = (target - sv * lv - lv * dsv) / sv;
+      if (dsv < 0.0) ap = fmin(ap, -P.tau * sv / dsv);
+      if (dlv < 0.0) ad = fmin(ad, -P.tau * lv / dlv);
+    }
+    sm[L.DS + idx] = dsv;
+    sm[L.DLAM + idx] = dlv;
+  }
+  *alpha_p = wave_min(ap);
+  *alpha_d = wave_min(ad);
 }
 
 __device__ inline double cost_plain(const DevParams& P, const Layout& L, double* sm, int lane) {
@@ -562,6 +556,9 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
     if (traj_x) for (int i = lane; i < (N + 1) * 13; i += kWave) traj_x[(size_t)b * (N + 1) * 13 + i] = 0.0;
     return;
   }
+  unsigned conmask = 0;
+  for (int l = 0; l < 4; ++l) conmask |= (sm[L.cst + C_CON + l] != 0.0) ? (1u << l) : 0u;
+  conmask = __builtin_amdgcn_readfirstlane(conmask);
   // initial guess U = u_ref (QuatMpc.cpp:253), slacks and multipliers
   for (int i = lane; i < N * 12; i += kWave) sm[L.U + i] = sm[L.uref + (i % 12)];
   QSYNC();
@@ -582,7 +579,7 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
     double sl = 0.0, rs = 0.0, cnt = 0.0;
     for (int i = lane; i < N * 24; i += kWave) {
       const int l = (i % 24) / 6;
-      if (sm[L.cst + C_CON + l] != 0.0) {
+      if (conmask & (1u << l)) {
         sl += sm[L.S + i] * sm[L.LAM + i];
         rs = fmax(rs, fabs(sm[L.CV + i] + sm[L.S + i]));
         cnt += 1.0;
@@ -595,18 +592,30 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
     double sg = P.sigma;
     if (it > 1 && last_ap >= 0.999 && last_ad >= 0.999) sg = P.sigma_fast;
     const double target = sg * mu;
+    rotation_prepass(P, L, sm, target, lane);
     prof.tick(PH_MISC);
-    if (backward_pass<PROF>(P, L, sm, target, lane, prof)) { status = QMPC_NOT_PD; break; }
+    if (backward_pass<PROF>(P, L, sm, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
     double ap, ad;
+    rollout_closed(P, L, sm, 1.0, lane);                 // trial step
+    prof.tick(PH_ROLL);
     ipm_directions(P, L, sm, target, lane, &ap, &ad);
     last_ap = ap; last_ad = ad;
     prof.tick(PH_DIRS);
-    last_step = rollout_closed(P, L, sm, ap, lane);
+    if (ap < 1.0) rollout_closed(P, L, sm, ap, lane);    // shortened primal step
     prof.tick(PH_ROLL);
+    // accept the candidate
+    double step = 0.0;
+    for (int i = lane; i < N * 12; i += kWave) {
+      const double un = sm[L.Uc + i];
+      step = fmax(step, fabs(un - sm[L.U + i]));
+      sm[L.U + i] = un;
+    }
+    for (int i = lane; i < (N + 1) * 13; i += kWave) sm[L.X + i] = sm[L.Xc + i];
     for (int i = lane; i < N * 24; i += kWave) {
       sm[L.S + i] += ap * sm[L.DS + i];
       sm[L.LAM + i] += ad * sm[L.DLAM + i];
     }
+    last_step = wave_max(step);
     QSYNC();
     prof.tick(PH_MISC);
     expansions(P, L, sm, lane);
@@ -622,7 +631,7 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
     double viol = 0.0;
     for (int i = lane; i < N * 24; i += kWave) {
       const int l = (i % 24) / 6;
-      if (sm[L.cst + C_CON + l] != 0.0) viol = fmax(viol, fmax(sm[L.CV + i], 0.0));
+      if (conmask & (1u << l)) viol = fmax(viol, fmax(sm[L.CV + i], 0.0));
     }
     viol = wave_max(viol);
     if (lane == 0) {
@@ -662,7 +671,7 @@ __global__ __launch_bounds__(64) void qmpc_linearize_kernel(DevParams P, const q
   expansions(P, L, sm, lane);
   for (int i = lane; i < N * 144; i += kWave) {
     const int k = i / 144, e = i - 144 * k, r = e / 12, c = e - 12 * r;
-    const double* AB = sm + L.AB + 27 * k;
+    const double* AB = sm + L.AB + kAB * k;
     Abar[(size_t)b * N * 144 + i] = abar_elem(P, AB, r, c);
     Bbar[(size_t)b * N * 144 + i] = bbar_elem(P, sm + L.cst, sm + L.bw0, AB, r, c);
   }
