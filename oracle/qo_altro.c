@@ -41,7 +41,8 @@ typedef struct knot_ws {
   double Jx[QO_MAXCON][QO_MAXP * NE_MAX];  /* p x ne row-major */
   double Ju[QO_MAXCON][QO_MAXP * M_MAX];   /* p x m  row-major */
   double lam[QO_MAXCON][QO_MAXP];
-  double s[QO_MAXCON][QO_MAXP];    /* interior-point slacks (phase 1)   */
+  double s[QO_MAXCON][QO_MAXP];    /* interior-point slacks             */
+  double rc[QO_MAXCON][QO_MAXP];   /* slack residual c(u) + s, tracked analytically */
   double ds[QO_MAXCON][QO_MAXP];
   double dlam[QO_MAXCON][QO_MAXP];
 } knot_ws;
@@ -54,6 +55,7 @@ typedef struct solver_ws {
   double* U;          /* N x m              */
   double* Xc;         /* candidate          */
   double* Uc;
+  double* dU;         /* candidate input increment alpha d + K dx, kept as computed */
   double rho;
   double dV1, dV2;
   int ipm;            /* 1: phase-1 interior-point weights, 0: AL weights */
@@ -247,7 +249,7 @@ static void al_multiplier(const solver_ws* ws, int k, int ci, double* zp, double
     if (!row_on(cn, i)) { zp[i] = 0.0; act[i] = 0.0; continue; }
     if (ws->ipm && cn->type == QO_INEQUALITY) {
       const double sig = kw->lam[ci][i] / kw->s[ci][i];
-      zp[i] = ws->ipm_target / kw->s[ci][i] + sig * (kw->c[ci][i] + kw->s[ci][i]);
+      zp[i] = ws->ipm_target / kw->s[ci][i] + sig * kw->rc[ci][i];
       act[i] = sig;
       continue;
     }
@@ -467,9 +469,10 @@ static void rollout_closed_loop(solver_ws* ws, double alpha) {
     const knot_ws* kw = &ws->kn[k];
     state_diff(p, &ws->Xc[k * n], &ws->X[k * n], dx);
     for (int j = 0; j < m; ++j) {
-      double s = ws->U[k * m + j] + alpha * kw->d[j];
+      double s = alpha * kw->d[j];
       for (int b = 0; b < ne; ++b) s += kw->K[j * ne + b] * dx[b];
-      ws->Uc[k * m + j] = s;
+      ws->dU[k * m + j] = s;
+      ws->Uc[k * m + j] = ws->U[k * m + j] + s;
     }
     p->dyn(p->dyn_ctx, k, &ws->Xc[(k + 1) * n], &ws->Xc[k * n], &ws->Uc[k * m], p->h);
   }
@@ -530,11 +533,19 @@ static double dual_update(solver_ws* ws) {
 }
 
 
-/* ---- phase 1 of the converged mode: primal-dual interior point ------------
- * Globalisation only (the reference has no such phase): Newton steps on the
- * perturbed KKT system of the SAME NLP, reusing the Riccati backward pass with
- * the interior-point weights of al_multiplier().  The iterate it hands to the
- * AL polish has the right active cone rows and multipliers. */
+/* ---- converged mode: primal-dual interior point on the Riccati core ----------
+ * (The reference has no such mode: its AL-iLQR scheme, restated above, stalls on
+ * states whose optimum sits on many cone faces.)  Newton steps on the perturbed
+ * KKT system of the SAME NLP, reusing the backward pass with the interior-point
+ * weights of al_multiplier().
+ *
+ * Slack bookkeeping.  The cone rows are linear in u, so with the input
+ * increment dU of a rollout  c(U + dU) = c(U) + Ju dU exactly.  The slack
+ * residual rc = c(u) + s is carried as its own variable and updated with the
+ * (small, accurately known) increments, rc <- rc + Ju dU + ds, never
+ * recomputed from c(u) (~100 N, rounding ~1e-14 N): that keeps the RELATIVE
+ * accuracy of slacks far below 1e-14 N, which the multipliers of weakly
+ * active rows need. */
 static int ipm_init(solver_ws* ws, double mu0) {
   const qo_problem* p = ws->prob;
   int rows = 0;
@@ -546,6 +557,7 @@ static int ipm_init(solver_ws* ws, double mu0) {
       for (int i = 0; i < cn->p; ++i) {
         if (!row_on(cn, i)) continue;
         kw->s[ci][i] = fmax(-kw->c[ci][i], 1.0);
+        kw->rc[ci][i] = kw->c[ci][i] + kw->s[ci][i];
         kw->lam[ci][i] = mu0 / kw->s[ci][i];
         rows++;
       }
@@ -565,7 +577,7 @@ static double ipm_mu(const solver_ws* ws, double* resid) {
       for (int i = 0; i < cn->p; ++i) {
         if (!row_on(cn, i)) continue;
         sum += kw->s[ci][i] * kw->lam[ci][i];
-        r = fmax(r, fabs(kw->c[ci][i] + kw->s[ci][i]));
+        r = fmax(r, fabs(kw->rc[ci][i]));
         rows++;
       }
     }
@@ -573,40 +585,45 @@ static double ipm_mu(const solver_ws* ws, double* resid) {
   return rows ? sum / rows : 0.0;
 }
 
-/* Slack / multiplier directions from the TRIAL closed-loop rollout at alpha = 1
- * (Xc, Uc): the cone rows are linear in u, so c(Uc) = c(U) + J (Uc - U) exactly:
- *   ds = -(c(Uc) + s),  dlam = (target - s lam - lam ds) / s,
- * followed by the fraction-to-the-boundary step lengths. */
-static void ipm_directions(solver_ws* ws, double tau, double* alpha_p, double* alpha_d) {
+/* ds = -(Ju dU + frac rc) for the rollout increment dU; with trial != 0 also
+ * dlam = (target - s lam - lam ds)/s and the fraction-to-the-boundary lengths. */
+static void ipm_directions(solver_ws* ws, double tau, double frac, int trial, double* alpha_p,
+                           double* alpha_d) {
   const qo_problem* p = ws->prob;
-  const int n = ws->n, m = ws->m, N = ws->N;
-  double cc[QO_MAXP];
+  const int m = ws->m, N = ws->N;
   double ap = 1.0, ad = 1.0;
-  for (int k = 0; k <= N; ++k) {
+  for (int k = 0; k < N; ++k) {
     knot_ws* kw = &ws->kn[k];
-    const double* x = &ws->Xc[k * n];
-    const double* u = (k < N) ? &ws->Uc[k * m] : NULL;
+    const double* du = &ws->dU[k * m];
     for (int ci = 0; ci < p->ncon; ++ci) {
       const qo_constraint* cn = &p->con[ci];
       if (!con_active_at(cn, k) || cn->type != QO_INEQUALITY) continue;
-      cn->con(cn->ctx, k, cc, x, u);
       for (int i = 0; i < cn->p; ++i) {
         if (!row_on(cn, i)) continue;
+        double jd = 0.0;
+        for (int j = 0; j < m; ++j) jd += kw->Ju[ci][i * m + j] * du[j];
         const double sv = kw->s[ci][i], lv = kw->lam[ci][i];
-        const double dsv = -(cc[i] + sv);
-        const double dlv = (ws->ipm_target - sv * lv - lv * dsv) / sv;
+        double dsv = -(jd + frac * kw->rc[ci][i]);
+        if (trial) {
+          const double dlv = (ws->ipm_target - sv * lv - lv * dsv) / sv;
+          kw->dlam[ci][i] = dlv;
+          if (dsv < 0.0) ap = fmin(ap, -tau * sv / dsv);
+          if (dlv < 0.0) ad = fmin(ad, -tau * lv / dlv);
+        } else {
+          /* re-rolled (shortened) step: the nonlinear rollout may differ from
+           * alpha * trial in second order; never leave the interior */
+          dsv = fmax(dsv, -(1.0 - 0.1 * (1.0 - tau)) * sv);
+        }
         kw->ds[ci][i] = dsv;
-        kw->dlam[ci][i] = dlv;
-        if (dsv < 0.0) ap = fmin(ap, -tau * sv / dsv);
-        if (dlv < 0.0) ad = fmin(ad, -tau * lv / dlv);
+        kw->c[ci][i] = jd; /* scratch: Ju dU of the accepted increment */
       }
     }
   }
-  *alpha_p = ap;
-  *alpha_d = ad;
+  if (alpha_p) *alpha_p = ap;
+  if (alpha_d) *alpha_d = ad;
 }
 
-static void ipm_apply(solver_ws* ws, double alpha_p, double alpha_d) {
+static void ipm_apply(solver_ws* ws, double alpha_d, int full_primal) {
   const qo_problem* p = ws->prob;
   for (int k = 0; k <= ws->N; ++k)
     for (int ci = 0; ci < p->ncon; ++ci) {
@@ -615,7 +632,9 @@ static void ipm_apply(solver_ws* ws, double alpha_p, double alpha_d) {
       knot_ws* kw = &ws->kn[k];
       for (int i = 0; i < cn->p; ++i) {
         if (!row_on(cn, i)) continue;
-        kw->s[ci][i] += alpha_p * kw->ds[ci][i];
+        kw->s[ci][i] += kw->ds[ci][i];
+        /* full step: ds = -(Ju dU + rc), hence rc + Ju dU + ds = 0 exactly */
+        kw->rc[ci][i] = full_primal ? 0.0 : kw->rc[ci][i] + kw->c[ci][i] + kw->ds[ci][i];
         kw->lam[ci][i] += alpha_d * kw->dlam[ci][i];
       }
     }
@@ -623,16 +642,18 @@ static void ipm_apply(solver_ws* ws, double alpha_p, double alpha_d) {
 
 static int ipm_phase(solver_ws* ws, const qo_options* o, qo_result* r) {
   const int n = ws->n, m = ws->m, N = ws->N;
-  ipm_init(ws, 1.0);
+  ipm_init(ws, o->ipm_mu0);
   int it;
   r->last_step = 1e300;
   double last_ap = 0.0, last_ad = 0.0;
-  for (it = 1; it <= o->ipm_iterations_max; ++it) {
+  int prev_full = 0, status = QO_STATUS_MAX_ITER;
+  for (it = 1; it <= o->ipm_iterations_max + 1; ++it) {
     double resid;
     const double mu = ipm_mu(ws, &resid);
     r->ipm_mu = mu;
-    if (mu <= o->ipm_mu_final && resid <= o->tol_feasibility && r->last_step <= o->tol_step)
-      return QO_STATUS_OK;
+    if (mu <= o->ipm_mu_final && resid <= o->tol_feasibility && r->last_step <= o->tol_step &&
+        prev_full) { status = QO_STATUS_OK; break; }
+    if (it > o->ipm_iterations_max) break;
     ws->ipm = 1;
     {
       /* centering: sigma until full steps are taken, then the fast value */
@@ -641,18 +662,23 @@ static int ipm_phase(solver_ws* ws, const qo_options* o, qo_result* r) {
       ws->ipm_target = sg * mu;
     }
     const int bp = backward_pass(ws);
-    if (bp != QO_STATUS_OK) { ws->ipm = 0; return bp; }
+    if (bp != QO_STATUS_OK) { ws->ipm = 0; status = bp; break; }
     double ap, ad;
-    rollout_closed_loop(ws, 1.0);               /* trial step */
-    ipm_directions(ws, o->ipm_tau, &ap, &ad);
+    rollout_closed_loop(ws, 1.0);                        /* trial step */
+    ipm_directions(ws, o->ipm_tau, 1.0, 1, &ap, &ad);
     last_ap = ap; last_ad = ad;
     ws->ipm = 0;
-    if (ap < 1.0) rollout_closed_loop(ws, ap);  /* shortened primal step */
-    ipm_apply(ws, ap, ad);
+    if (ap < 1.0) {                                      /* shortened primal step */
+      rollout_closed_loop(ws, ap);
+      ipm_directions(ws, o->ipm_tau, ap, 0, NULL, NULL);
+    }
+    ipm_apply(ws, ad, ap >= 1.0);
     double step = 0.0;
-    for (int i = 0; i < N * m; ++i) step = fmax(step, fabs(ws->Uc[i] - ws->U[i]));
-    memcpy(ws->X, ws->Xc, sizeof(double) * (N + 1) * n);
+    for (int i = 0; i < N * m; ++i) step = fmax(step, fabs(ws->dU[i]));
+    const int full = (ap >= 0.999 && ad >= 0.999);
+    prev_full = full;
     memcpy(ws->U, ws->Uc, sizeof(double) * N * m);
+    memcpy(ws->X, ws->Xc, sizeof(double) * (N + 1) * n);
     expansions(ws);
     r->ipm_iterations = it;
     r->last_step = step;
@@ -660,14 +686,7 @@ static int ipm_phase(solver_ws* ws, const qo_options* o, qo_result* r) {
       fprintf(stderr, "ipm %2d  mu=%.3e  resid=%.3e  ap=%.4f ad=%.4f  step=%.3e\n", it, mu, resid,
               ap, ad, step);
   }
-  {
-    double resid;
-    const double mu = ipm_mu(ws, &resid);
-    r->ipm_mu = mu;
-    if (mu <= o->ipm_mu_final && resid <= o->tol_feasibility && r->last_step <= o->tol_step)
-      return QO_STATUS_OK;
-  }
-  return QO_STATUS_MAX_ITER;
+  return status;
 }
 
 void qo_default_options(qo_options* o, int mode) {
@@ -692,7 +711,8 @@ void qo_default_options(qo_options* o, int mode) {
     o->ipm_iterations_max = 40;
     o->ipm_mu_final = 1e-12;
     o->ipm_sigma = 0.2;
-    o->ipm_sigma_fast = 0.05;
+    o->ipm_sigma_fast = 0.01;
+    o->ipm_mu0 = 0.01;
     o->ipm_tau = 0.995;
   }
 }
@@ -712,6 +732,7 @@ int qo_altro_solve(const qo_problem* prob, const qo_options* opts, double* X, do
   ws.U = U;
   ws.Xc = (double*)calloc((size_t)(N + 1) * n, sizeof(double));
   ws.Uc = (double*)calloc((size_t)N * m + 1, sizeof(double));
+  ws.dU = (double*)calloc((size_t)N * m + 1, sizeof(double));
   ws.rho = opts->penalty_initial;
 
   qo_result r;
@@ -733,7 +754,7 @@ int qo_altro_solve(const qo_problem* prob, const qo_options* opts, double* X, do
       r.status = st;
       r.penalty = r.ipm_mu;
       if (res) *res = r;
-      free(ws.kn); free(ws.Xc); free(ws.Uc);
+      free(ws.kn); free(ws.Xc); free(ws.Uc); free(ws.dU);
       return r.status;
     }
   }
@@ -794,5 +815,6 @@ int qo_altro_solve(const qo_problem* prob, const qo_options* opts, double* X, do
   free(ws.kn);
   free(ws.Xc);
   free(ws.Uc);
+  free(ws.dU);
   return r.status;
 }

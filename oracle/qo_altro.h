@@ -70,6 +70,7 @@ typedef struct qo_options {
    * input step <= tol_step (the reference's own AL scheme stalls on states
    * whose optimum sits on many cone faces)                     */
   int ipm_iterations_max;
+  double ipm_mu0;          /* initial barrier: s0 = max(-c,1), lambda0 = mu0/s0   */
   double ipm_mu_final;     /* hand over to the AL polish below this barrier   */
   double ipm_sigma;        /* centering parameter                              */
   double ipm_sigma_fast;   /* centering once full steps are being taken        */

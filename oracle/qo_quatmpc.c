@@ -44,6 +44,7 @@ void qo_default_params(qmpc_params* p, int32_t horizon, int32_t mode) {
   p->tol_feasibility = o.tol_feasibility;
   p->tol_cost_intermediate = o.tol_cost_intermediate;
   p->tol_step = o.tol_step;
+  p->ipm_mu0 = o.ipm_mu0;
   p->ipm_mu_final = o.ipm_mu_final;
   p->ipm_sigma = o.ipm_sigma;
   p->ipm_sigma_fast = o.ipm_sigma_fast;
@@ -180,6 +181,7 @@ static void options_from_params(const qmpc_params* p, qo_options* o, int verbose
   o->linesearch_max = p->linesearch_max;
   o->verbose = verbose;
   o->ipm_iterations_max = (p->mode == QMPC_MODE_CONVERGED) ? p->iterations_max : 0;
+  o->ipm_mu0 = p->ipm_mu0;
   o->ipm_mu_final = p->ipm_mu_final;
   o->ipm_sigma = p->ipm_sigma;
   o->ipm_sigma_fast = p->ipm_sigma_fast;

@@ -53,6 +53,7 @@ class Params(C.Structure):
         ("tol_feasibility", C.c_double),
         ("tol_cost_intermediate", C.c_double),
         ("tol_step", C.c_double),
+        ("ipm_mu0", C.c_double),
         ("ipm_mu_final", C.c_double),
         ("ipm_sigma", C.c_double),
         ("ipm_sigma_fast", C.c_double),

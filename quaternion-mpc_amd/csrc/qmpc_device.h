@@ -38,12 +38,12 @@ struct DevParams {
   double w;
   double mu;
   double fz_max;
-  double tol_feas, tol_step, mu_final, sigma, sigma_fast, tau;
+  double tol_feas, tol_step, mu0, mu_final, sigma, sigma_fast, tau;
 };
 
 // ---- per-instance LDS layout (offsets in doubles) ---------------------------
 struct Layout {
-  int cst, bw0, refp, uref, X, U, Xc, Uc, S, LAM, DS, DLAM, CV, AB, XT, KD, ROT, tile, total;
+  int cst, bw0, refp, uref, ub, X, U, Xc, dU, S, LAM, DS, DLAM, RC, AB, XT, KD, ROT, tile, total;
 };
 
 // Per-knot record sizes
@@ -60,15 +60,16 @@ __host__ __device__ inline Layout make_layout(int N) {
   L.bw0 = take(36);
   L.refp = take(13);
   L.uref = take(12);
+  L.ub = take(12);       // broadcast slot: candidate input of the current knot
   L.X = take((N + 1) * 13);
   L.U = take(N * 12);
   L.Xc = take((N + 1) * 13);
-  L.Uc = take(N * 12);
+  L.dU = take(N * 12);   // candidate input increment alpha d + K dx (kept as computed)
   L.S = take(N * 24);
   L.LAM = take(N * 24);
   L.DS = take(N * 24);
   L.DLAM = take(N * 24);
-  L.CV = take(N * 24);
+  L.RC = take(N * 24);   // slack residual c(u) + s, tracked analytically
   L.AB = take(N * kAB);
   L.XT = take((N + 1) * kXT);
   L.KD = take(N * kKD);
@@ -171,24 +172,37 @@ __device__ __forceinline__ void quat_Omega(const double* w, double O[16]) {
   O[12] = z; O[13] = y; O[14] = -x; O[15] = 0;
 }
 
+// Model constants of one instance held in registers by the rollouts.
+struct ModelRegs {
+  double con[4], gb[3], wd0[3], bw[36];
+  __device__ __forceinline__ void load(const double* cst, const double* bw0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) con[i] = cst[C_CON + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { gb[i] = cst[C_GB + i]; wd0[i] = cst[C_WD0 + i]; }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) bw[i] = bw0[i];
+  }
+};
+
 // Explicit-midpoint step of the quaternion SRBD (AltroUtils.cpp:9-22 applied to
 // :363-392).  vdot and wdot do not depend on the state, so both midpoint
 // evaluations share them.  x, xn: 13 doubles in registers.
-__device__ __forceinline__ void srbd_step(const DevParams& P, const double* cst, const double* bw0,
-                                          const double* x, const double* u, double* xn) {
+__device__ __forceinline__ void srbd_step(const DevParams& P, const ModelRegs& M, const double* x,
+                                          const double* u, double* xn) {
   double F[3] = {0, 0, 0};
 #pragma unroll
   for (int l = 0; l < 4; ++l) {
-    const double c = cst[C_CON + l];
+    const double c = M.con[l];
     F[0] += c * u[3 * l]; F[1] += c * u[3 * l + 1]; F[2] += c * u[3 * l + 2];
   }
   double vd[3], wd[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    vd[a] = F[a] / P.mass + cst[C_GB + a];
-    double s = cst[C_WD0 + a];
+    vd[a] = F[a] / P.mass + M.gb[a];
+    double s = M.wd0[a];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) s += bw0[12 * a + j] * u[j];
+    for (int j = 0; j < 12; ++j) s += M.bw[12 * a + j] * u[j];
     wd[a] = s;
   }
   // midpoint state

