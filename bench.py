@@ -104,15 +104,17 @@ def main():
     d_in = torch.from_numpy(rec.view(np.uint8).reshape(B, -1).copy()).cuda()
     d_f = torch.zeros(B, 12, dtype=torch.float64, device="cuda")
     d_info = torch.zeros(B, pkg.INFO_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
-    gathered = torch.zeros(world * B, 12, dtype=torch.float64, device="cuda") if world > 1 else None
     # a real (non-null) stream: the C ABI treats NULL as "the handle's own stream"
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
 
+    counts = [B] * world
+
     def step():
         solver.solve_device(B, d_in.data_ptr(), d_f.data_ptr(), d_info.data_ptr(), stream.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, d_f)   # the single RCCL collective of the path
+            return pkg.gather_forces(d_f, world, counts)   # the single RCCL collective of the path
+        return d_f
 
     for _ in range(args.warmup):
         step()

@@ -1,0 +1,147 @@
+// host_shim.cpp -- C entry points over the C++ host classes so the Python test
+// suite (ctypes) can drive QuatMpcHipT<LeggedStateLite>, LeggedContactFSMHip and
+// MovingWindowFilterHip.  Builds to host/libqmpc_host.so with plain g++; the HIP
+// library is dlopen'ed at run time, so this file has no HIP dependency.
+#include <dlfcn.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "LeggedStateLite.h"
+#include "QuatMpcHip.h"
+
+using legged::LeggedStateLite;
+using Mpc = legged::QuatMpcHipT<LeggedStateLite>;
+
+namespace {
+struct Harness {
+  LeggedStateLite state;
+  Mpc* mpc = nullptr;
+  void* dl = nullptr;
+};
+
+// a stub that records that no device library was given (host-logic tests on CPU)
+void stub_default_params(qmpc_params* p, int32_t horizon, int32_t mode) {
+  std::memset(p, 0, sizeof *p);
+  p->horizon = horizon;
+  p->mode = mode;
+}
+}  // namespace
+
+extern "C" {
+
+// lib_path: path of libqmpc_hip.so, or NULL/"" for a harness without a device
+void* qh_create(const char* lib_path, int horizon) {
+  Harness* h = new Harness();
+  h->state.param.mpc_horizon = horizon;
+  legged::QmpcApi api;
+  api.default_params = stub_default_params;
+  if (lib_path && lib_path[0]) {
+    h->dl = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
+    if (!h->dl) {
+      std::fprintf(stderr, "qh_create: dlopen(%s) failed: %s\n", lib_path, dlerror());
+      delete h;
+      return nullptr;
+    }
+    api.default_params = reinterpret_cast<decltype(api.default_params)>(dlsym(h->dl, "qmpc_default_params"));
+    api.create = reinterpret_cast<decltype(api.create)>(dlsym(h->dl, "qmpc_create"));
+    api.solve = reinterpret_cast<decltype(api.solve)>(dlsym(h->dl, "qmpc_solve"));
+    api.destroy = reinterpret_cast<decltype(api.destroy)>(dlsym(h->dl, "qmpc_destroy"));
+    if (!api.default_params || !api.create || !api.solve || !api.destroy) {
+      std::fprintf(stderr, "qh_create: missing qmpc_* symbols in %s\n", lib_path);
+      delete h;
+      return nullptr;
+    }
+  }
+  h->state.fbk.torso_rot_mat(0, 0) = h->state.fbk.torso_rot_mat(1, 1) = h->state.fbk.torso_rot_mat(2, 2) = 1.0;
+  h->state.fbk.torso_rot_mat_z = h->state.fbk.torso_rot_mat;
+  h->mpc = new Mpc(h->state, api, 0);
+  return h;
+}
+
+void qh_destroy(void* p) {
+  Harness* h = static_cast<Harness*>(p);
+  if (!h) return;
+  delete h->mpc;
+  // the HIP library stays loaded: unloading a library with live device code objects is not safe
+  delete h;
+}
+
+int qh_device_status(void* p) { return (int)static_cast<Harness*>(p)->mpc->last_status(); }
+
+// fbk: quat(4) rot(9, row-major) pos_world(3) lin_vel_world(3) ang_vel_body(3)
+//      foot_pos_body(12, [3*leg+axis]) foot_contact_flag(4)            = 38 doubles
+void qh_set_feedback(void* p, const double* f) {
+  LeggedStateLite& s = static_cast<Harness*>(p)->state;
+  s.fbk.torso_quat.w() = f[0]; s.fbk.torso_quat.x() = f[1]; s.fbk.torso_quat.y() = f[2]; s.fbk.torso_quat.z() = f[3];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) s.fbk.torso_rot_mat(r, c) = f[4 + 3 * r + c];
+  // yaw-only rotation (BaseInterface.cpp keeps torso_rot_mat_z next to torso_rot_mat)
+  const double yaw = std::atan2(s.fbk.torso_rot_mat(1, 0), s.fbk.torso_rot_mat(0, 0));
+  s.fbk.torso_rot_mat_z.setZero();
+  s.fbk.torso_rot_mat_z(0, 0) = std::cos(yaw); s.fbk.torso_rot_mat_z(0, 1) = -std::sin(yaw);
+  s.fbk.torso_rot_mat_z(1, 0) = std::sin(yaw); s.fbk.torso_rot_mat_z(1, 1) = std::cos(yaw);
+  s.fbk.torso_rot_mat_z(2, 2) = 1.0;
+  for (int i = 0; i < 3; ++i) {
+    s.fbk.torso_pos_world[i] = f[13 + i];
+    s.fbk.torso_lin_vel_world[i] = f[16 + i];
+    s.fbk.torso_ang_vel_body[i] = f[19 + i];
+  }
+  for (int l = 0; l < 4; ++l) {
+    for (int a = 0; a < 3; ++a) s.fbk.foot_pos_body(a, l) = f[22 + 3 * l + a];
+    s.fbk.foot_contact_flag[l] = f[34 + l];
+  }
+  s.estimator_init = true;
+}
+
+// joy: velx vely body_height roll_rate pitch_rate yaw_rate ; movement_mode
+void qh_set_command(void* p, const double* j, double movement_mode) {
+  LeggedStateLite& s = static_cast<Harness*>(p)->state;
+  s.joy.velx = j[0]; s.joy.vely = j[1]; s.joy.body_height = j[2];
+  s.joy.roll_rate = j[3]; s.joy.pitch_rate = j[4]; s.joy.yaw_rate = j[5];
+  s.ctrl.movement_mode = movement_mode;
+}
+
+void qh_goal_update(void* p) { Harness* h = static_cast<Harness*>(p); h->mpc->goal_update(h->state); }
+void qh_foot_update(void* p) { Harness* h = static_cast<Harness*>(p); h->mpc->foot_update(h->state); }
+int qh_grf_update(void* p) { Harness* h = static_cast<Harness*>(p); return h->mpc->grf_update(h->state) ? 1 : 0; }
+int qh_update(void* p) { Harness* h = static_cast<Harness*>(p); return h->mpc->update(h->state) ? 1 : 0; }
+
+// the record grf_update would hand to the C ABI (includes the quat_d in/out update)
+void qh_pack_input(void* p, qmpc_input* out) { Harness* h = static_cast<Harness*>(p); h->mpc->pack_input(h->state, out); }
+
+// out: plan_contacts(4) gait_counter(4) optimized_input[0:12] mpc_grf_world(12) quat_d(4)
+//      pos_d_world(3) mpc_time(1)                                        = 40 doubles
+void qh_get_outputs(void* p, double* o) {
+  LeggedStateLite& s = static_cast<Harness*>(p)->state;
+  for (int i = 0; i < 4; ++i) { o[i] = s.ctrl.plan_contacts[i] ? 1.0 : 0.0; o[4 + i] = s.ctrl.gait_counter[i]; }
+  for (int i = 0; i < 12; ++i) { o[8 + i] = s.ctrl.optimized_input[i]; o[20 + i] = s.ctrl.mpc_grf_world[i]; }
+  o[32] = s.ctrl.torso_quat_d.w(); o[33] = s.ctrl.torso_quat_d.x(); o[34] = s.ctrl.torso_quat_d.y(); o[35] = s.ctrl.torso_quat_d.z();
+  for (int i = 0; i < 3; ++i) o[36 + i] = s.ctrl.torso_pos_d_world[i];
+  o[39] = s.fbk.mpc_time;
+}
+
+// ---- stand-alone pieces ---------------------------------------------------------
+// contact schedule: ticks x 4 flags in (any non-zero = contact), ticks x 4 contacts
+// and phases out.  mode[t] is ctrl.movement_mode at tick t.
+void qh_fsm_run(double gait_freq, int ticks, const double* mode, const double* flags, int32_t* contacts, double* phases) {
+  legged::LeggedContactFSMHip fsm[4];
+  for (int i = 0; i < 4; ++i) fsm[i].reset_params(gait_freq, i);
+  for (int t = 0; t < ticks; ++t) {
+    if (mode[t] == 0) {
+      for (int i = 0; i < 4; ++i) { fsm[i].reset(); contacts[4 * t + i] = 1; phases[4 * t + i] = fsm[i].phase(); }
+    } else {
+      for (int i = 0; i < 4; ++i)
+        phases[4 * t + i] = fsm[i].update(5.0 / 1000.0, gait_freq, static_cast<bool>(flags[4 * t + i]));
+      for (int i = 0; i < 4; ++i) contacts[4 * t + i] = (int32_t)fsm[i].get_contact_state();
+    }
+  }
+}
+
+void qh_filter_run(int window, int n, const double* in, double* out) {
+  legged::MovingWindowFilterHip f(window);
+  for (int i = 0; i < n; ++i) out[i] = f.CalculateAverage(in[i]);
+}
+
+}  // extern "C"
