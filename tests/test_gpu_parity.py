@@ -192,6 +192,12 @@ def test_host_class_drives_the_gpu(pkg, lib, oracle):
     h = host.qh_create(str(pkg.LIB_PATH).encode(), 20)
     assert h and host.qh_device_status(h) == 0
     rec = pkg.random_go1_trot_states(3, config_id=3)
+    # the harness starts with torso_quat_d = identity: keep the yaw error small (tilt-only attitudes)
+    from quaternion_mpc_amd import scenarios as sc
+    for i, (ax, ang) in enumerate([((1.0, 0, 0), 0.2), ((0, 1.0, 0), -0.25), ((0.6, 0.8, 0), 0.3)]):
+        q = sc._axis_angle(np.array([ax]), np.array([ang]))[0]
+        rec["quat"][i] = q
+        rec["rot"][i] = sc.quat_to_rot(q)
     joy = np.array([0.3, 0.05, 0.28, 0.0, 0.0, 0.2])
     for i in range(3):
         r = rec[i]
