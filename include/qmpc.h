@@ -188,6 +188,9 @@ qmpc_status qmpc_linearize(qmpc_handle* h, int32_t batch, const qmpc_input* in,
  * uses (host buffers of 192 doubles each).  Lets the GPU tests pin the
  * fragment layout independently of the solver. */
 qmpc_status qmpc_selftest_mtm(int32_t device, const double* X, const double* Y, double* C);
+/* Cross-lane primitives of the stage solve on 64 doubles: out = 9 x 64 doubles
+ * (row-group broadcasts 0..3, wave sum / max / min, row_newbcast:5, quad_perm[1,1,1,1]). */
+qmpc_status qmpc_selftest_lanes(int32_t device, const double* in, double* out);
 /* Per-instance phase cycle counts (s_memtime) of one instrumented solve launch:
  * cycles_out [batch][16] int64 (host); slots 0..8 = set-up, expansions, operand
  * build, MFMA + stage terms, stage solve, cost-to-go update, IPM directions,

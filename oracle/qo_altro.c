@@ -585,10 +585,10 @@ static double ipm_mu(const solver_ws* ws, double* resid) {
   return rows ? sum / rows : 0.0;
 }
 
-/* ds = -(Ju dU + frac rc) for the rollout increment dU; with trial != 0 also
- * dlam = (target - s lam - lam ds)/s and the fraction-to-the-boundary lengths. */
-static void ipm_directions(solver_ws* ws, double tau, double frac, int trial, double* alpha_p,
-                           double* alpha_d) {
+/* Trial directions from the closed-loop rollout at alpha = 1 (increment dU):
+ *   ds = -(Ju dU + rc),  dlam = (target - s lam - lam ds)/s,
+ * and the fraction-to-the-boundary step lengths. */
+static void ipm_directions(solver_ws* ws, double tau, double* alpha_p, double* alpha_d) {
   const qo_problem* p = ws->prob;
   const int m = ws->m, N = ws->N;
   double ap = 1.0, ad = 1.0;
@@ -603,27 +603,23 @@ static void ipm_directions(solver_ws* ws, double tau, double frac, int trial, do
         double jd = 0.0;
         for (int j = 0; j < m; ++j) jd += kw->Ju[ci][i * m + j] * du[j];
         const double sv = kw->s[ci][i], lv = kw->lam[ci][i];
-        double dsv = -(jd + frac * kw->rc[ci][i]);
-        if (trial) {
-          const double dlv = (ws->ipm_target - sv * lv - lv * dsv) / sv;
-          kw->dlam[ci][i] = dlv;
-          if (dsv < 0.0) ap = fmin(ap, -tau * sv / dsv);
-          if (dlv < 0.0) ad = fmin(ad, -tau * lv / dlv);
-        } else {
-          /* re-rolled (shortened) step: the nonlinear rollout may differ from
-           * alpha * trial in second order; never leave the interior */
-          dsv = fmax(dsv, -(1.0 - 0.1 * (1.0 - tau)) * sv);
-        }
+        const double dsv = -(jd + kw->rc[ci][i]);
+        const double dlv = (ws->ipm_target - sv * lv - lv * dsv) / sv;
         kw->ds[ci][i] = dsv;
-        kw->c[ci][i] = jd; /* scratch: Ju dU of the accepted increment */
+        kw->dlam[ci][i] = dlv;
+        if (dsv < 0.0) ap = fmin(ap, -tau * sv / dsv);
+        if (dlv < 0.0) ad = fmin(ad, -tau * lv / dlv);
       }
     }
   }
-  if (alpha_p) *alpha_p = ap;
-  if (alpha_d) *alpha_d = ad;
+  *alpha_p = ap;
+  *alpha_d = ad;
 }
 
-static void ipm_apply(solver_ws* ws, double alpha_d, int full_primal) {
+/* Apply the step.  A shortened primal step scales the trial increment,
+ * dU <- alpha_p dU (the cone rows are linear in u, so s + alpha_p ds stays in the
+ * interior exactly and rc <- (1 - alpha_p) rc); a full step zeroes rc exactly. */
+static void ipm_apply(solver_ws* ws, double alpha_p, double alpha_d) {
   const qo_problem* p = ws->prob;
   for (int k = 0; k <= ws->N; ++k)
     for (int ci = 0; ci < p->ncon; ++ci) {
@@ -632,13 +628,14 @@ static void ipm_apply(solver_ws* ws, double alpha_d, int full_primal) {
       knot_ws* kw = &ws->kn[k];
       for (int i = 0; i < cn->p; ++i) {
         if (!row_on(cn, i)) continue;
-        kw->s[ci][i] += kw->ds[ci][i];
-        /* full step: ds = -(Ju dU + rc), hence rc + Ju dU + ds = 0 exactly */
-        kw->rc[ci][i] = full_primal ? 0.0 : kw->rc[ci][i] + kw->c[ci][i] + kw->ds[ci][i];
+        kw->s[ci][i] += alpha_p * kw->ds[ci][i];
+        kw->rc[ci][i] = (alpha_p >= 1.0) ? 0.0 : (1.0 - alpha_p) * kw->rc[ci][i];
         kw->lam[ci][i] += alpha_d * kw->dlam[ci][i];
       }
     }
 }
+
+static const double* p_x0(const solver_ws* ws) { return ws->prob->x0; }
 
 static int ipm_phase(solver_ws* ws, const qo_options* o, qo_result* r) {
   const int n = ws->n, m = ws->m, N = ws->N;
@@ -665,15 +662,20 @@ static int ipm_phase(solver_ws* ws, const qo_options* o, qo_result* r) {
     if (bp != QO_STATUS_OK) { ws->ipm = 0; status = bp; break; }
     double ap, ad;
     rollout_closed_loop(ws, 1.0);                        /* trial step */
-    ipm_directions(ws, o->ipm_tau, 1.0, 1, &ap, &ad);
+    ipm_directions(ws, o->ipm_tau, &ap, &ad);
     last_ap = ap; last_ad = ad;
     ws->ipm = 0;
-    if (ap < 1.0) {                                      /* shortened primal step */
-      rollout_closed_loop(ws, ap);
-      ipm_directions(ws, o->ipm_tau, ap, 0, NULL, NULL);
-    }
-    ipm_apply(ws, ad, ap >= 1.0);
+    ipm_apply(ws, ap, ad);
     double step = 0.0;
+    if (ap < 1.0) {   /* shortened primal step: scaled increment, open-loop states */
+      for (int i = 0; i < N * m; ++i) {
+        ws->dU[i] *= ap;
+        ws->Uc[i] = ws->U[i] + ws->dU[i];
+      }
+      memcpy(ws->Xc, p_x0(ws), sizeof(double) * n);
+      for (int k = 0; k < N; ++k)
+        ws->prob->dyn(ws->prob->dyn_ctx, k, &ws->Xc[(k + 1) * n], &ws->Xc[k * n], &ws->Uc[k * m], ws->prob->h);
+    }
     for (int i = 0; i < N * m; ++i) step = fmax(step, fabs(ws->dU[i]));
     const int full = (ap >= 0.999 && ad >= 0.999);
     prev_full = full;

@@ -154,6 +154,8 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.qmpc_linearize.restype = i32
     lib.qmpc_debug_profile.argtypes = [vp, i32, vp, vp]
     lib.qmpc_debug_profile.restype = i32
+    lib.qmpc_selftest_lanes.argtypes = [i32, vp, vp]
+    lib.qmpc_selftest_lanes.restype = i32
     lib.qmpc_selftest_mtm.argtypes = [i32, vp, vp, vp]
     lib.qmpc_selftest_mtm.restype = i32
     lib.qmpc_status_string.argtypes = [i32]
@@ -184,6 +186,7 @@ EXPORTED_SYMBOLS = (
     "qmpc_last_kernel_ms",
     "qmpc_linearize",
     "qmpc_selftest_mtm",
+    "qmpc_selftest_lanes",
     "qmpc_debug_profile",
     "qmpc_status_string",
     "qmpc_version",

@@ -32,6 +32,7 @@ struct DevParams {
   double hh;       // (double)(h/2) with h float
   double h_ref;
   double mass;
+  double inv_mass;
   double Iinv[9];
   double Q[13];
   double R[12];
@@ -60,7 +61,7 @@ __host__ __device__ inline Layout make_layout(int N) {
   L.bw0 = take(36);
   L.refp = take(13);
   L.uref = take(12);
-  L.ub = take(12);       // broadcast slot: candidate input of the current knot
+  L.ub = take(24);       // 2 broadcast slots (ping-pong): candidate input of the current knot
   L.X = take((N + 1) * 13);
   L.U = take(N * 12);
   L.Xc = take((N + 1) * 13);
@@ -120,21 +121,67 @@ __device__ __forceinline__ void mtm(double* C, const double* X, const double* Y,
   C[128 + lane] = acc[2];
 }
 
-// ---- wave reductions (64 lanes) ----------------------------------------------
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
-  return v;
+// ---- cross-lane primitives (no LDS): DPP inside a 16-lane row, gfx950
+// v_permlane16_swap / v_permlane32_swap across rows -----------------------------
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-  return v;
+// v_permlane16_swap(x,x): [0] = rows (r0,r0,r2,r2), [1] = rows (r1,r1,r3,r3)
+__device__ __forceinline__ void swap16(double x, double& even, double& odd) {
+  const u2v lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+  const u2v hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+  even = __hiloint2double((int)hi[0], (int)lo[0]);
+  odd = __hiloint2double((int)hi[1], (int)lo[1]);
 }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+// v_permlane32_swap(x,x): [0] = (lower half, lower half), [1] = (upper half, upper half)
+__device__ __forceinline__ void swap32(double x, double& lower, double& upper) {
+  const u2v lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+  const u2v hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+  lower = __hiloint2double((int)hi[0], (int)lo[0]);
+  upper = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// value of 16-lane row G, same column, in all four rows
+template <int G>
+__device__ __forceinline__ double rowgroup_bcast(double x) {
+  double ev, od, lo, up;
+  swap16(x, ev, od);
+  swap32((G & 1) ? od : ev, lo, up);
+  return (G & 2) ? up : lo;
+}
+
+// ---- wave reductions (64 lanes): butterfly with quad_perm / row mirrors, then
+// the two permlane swaps; every lane ends with the result -----------------------
+struct OpMin { __device__ __forceinline__ double operator()(double a, double b) const { return fmin(a, b); } };
+struct OpMax { __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); } };
+struct OpSum { __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
+template <class Op>
+__device__ __forceinline__ double wave_reduce(double v, Op op) {
+  v = op(v, dpp_mov<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = op(v, dpp_mov<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = op(v, dpp_mov<0x141>(v));   // row_half_mirror
+  v = op(v, dpp_mov<0x140>(v));   // row_mirror
+  double a, b;
+  swap16(v, a, b);
+  v = op(a, b);
+  swap32(v, a, b);
+  return op(a, b);
+}
+__device__ __forceinline__ double wave_min(double v) { return wave_reduce(v, OpMin()); }
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce(v, OpMax()); }
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce(v, OpSum()); }
+
+// 1/x: v_rcp_f64 + two Newton steps (instead of the ~12-instruction IEEE sequence)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
 }
 
 // ---- cross-lane moves inside the MFMA fragment layout --------------------------
@@ -199,11 +246,14 @@ __device__ __forceinline__ void srbd_step(const DevParams& P, const ModelRegs& M
   double vd[3], wd[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    vd[a] = F[a] / P.mass + M.gb[a];
-    double s = M.wd0[a];
-#pragma unroll
-    for (int j = 0; j < 12; ++j) s += M.bw[12 * a + j] * u[j];
-    wd[a] = s;
+    vd[a] = F[a] * P.inv_mass + M.gb[a];
+    // four independent partial sums: the wave has no other work to hide a 12-deep FMA chain
+    const double* b = &M.bw[12 * a];
+    const double s0 = M.wd0[a] + b[0] * u[0] + b[1] * u[1] + b[2] * u[2];
+    const double s1 = b[3] * u[3] + b[4] * u[4] + b[5] * u[5];
+    const double s2 = b[6] * u[6] + b[7] * u[7] + b[8] * u[8];
+    const double s3 = b[9] * u[9] + b[10] * u[10] + b[11] * u[11];
+    wd[a] = (s0 + s1) + (s2 + s3);
   }
   // midpoint state
   double G[12];

@@ -115,6 +115,7 @@ static int fill_dev_params(const qmpc_params* p, DevParams* d) {
   d->hh = (double)(p->h / 2);  // float division, as `h / 2` in AltroUtils.cpp:16,94
   d->h_ref = p->h_ref;
   d->mass = p->mass;
+  d->inv_mass = 1.0 / p->mass;
   // cofactor inverse of the 3x3 inertia (Eigen's fixed-size inverse(), AltroUtils.cpp:391)
   const double* A = p->inertia;
   const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
@@ -323,6 +324,22 @@ qmpc_status qmpc_selftest_mtm(int32_t device, const double* X, const double* Y, 
   hipLaunchKernelGGL(qmpc_selftest_kernel, dim3(1), dim3(kWave), 0, 0, d, d + MAT, d + 2 * MAT);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(Cout, d + 2 * MAT, sizeof(double) * MAT, hipMemcpyDeviceToHost));
+  HIP_TRY(hipFree(d));
+  return QMPC_OK;
+}
+
+// Diagnostic: cross-lane primitives on 64 doubles; out holds 9 x 64 doubles
+// (row-group broadcasts 0..3, wave sum/max/min, row_newbcast:5, quad_perm[1,1,1,1]).
+qmpc_status qmpc_selftest_lanes(int32_t device, const double* in, double* out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device >= ndev) return QMPC_NO_DEVICE;
+  HIP_TRY(hipSetDevice(device));
+  double* d = nullptr;
+  HIP_TRY(hipMalloc(&d, sizeof(double) * 64 * 10));
+  HIP_TRY(hipMemcpy(d, in, sizeof(double) * 64, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(qmpc_selftest_lanes_kernel, dim3(1), dim3(kWave), 0, 0, d, d + 64);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, d + 64, sizeof(double) * 64 * 9, hipMemcpyDeviceToHost));
   HIP_TRY(hipFree(d));
   return QMPC_OK;
 }

@@ -202,8 +202,9 @@ __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, dou
     for (int i = 0; i < 6; ++i) {
       const double s = sm[L.S + 24 * k + 6 * l + i], lam = sm[L.LAM + 24 * k + 6 * l + i];
       const double rc = sm[L.RC + 24 * k + 6 * l + i];
-      w[i] = lam / s;
-      gi[i] = target / s + w[i] * rc;
+      const double is = fast_rcp(s);
+      w[i] = lam * is;
+      gi[i] = (target + lam * rc) * is;
     }
     // heaviest row i1, second heaviest non-(anti)parallel row i2 (rows 4,5 are antiparallel)
     int i1 = 0;
@@ -276,27 +277,32 @@ __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, dou
 }
 
 // One Gauss-Jordan step on pivot J of the pair (M | Rr) held in the fragment
-// layout: the pivot row is normalised and eliminated from every other row.
+// layout: row J is eliminated from every OTHER row (the pivot row is left as it
+// is; gj_finish divides by the diagonal at the end).
 template <int J>
 __device__ __forceinline__ void gj_step(double M[3], double Rr[3], int c, int g, int& bad) {
   constexpr int ej = J >> 2, gj = J & 3;
   const int src = (gj << 4) | c;
-  double mrow = __shfl(M[ej], src);
-  double rrow = __shfl(Rr[ej], src);
+  const double mrow = __shfl(M[ej], src);      // row J of M / Rr, same column, all row groups
+  const double rrow = __shfl(Rr[ej], src);
   const double piv = read_lane(M[ej], (gj << 4) | J);
   bad |= !(piv > 0.0);
-  // v_rcp_f64 + two Newton steps instead of the IEEE division sequence
-  double inv = __builtin_amdgcn_rcp(piv);
-  inv = fma(fma(-piv, inv, 1.0), inv, inv);
-  inv = fma(fma(-piv, inv, 1.0), inv, inv);
-  mrow *= inv;
-  rrow *= inv;
+  const double ninv = -fast_rcp(piv);
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
     const double col = row_bcast<J>(M[e]);
-    const bool isp = (e == ej) && (g == gj);
-    M[e] = isp ? mrow : (M[e] - col * mrow);
-    Rr[e] = isp ? rrow : (Rr[e] - col * rrow);
+    const double f = ((e == ej) && (g == gj)) ? 0.0 : col * ninv;
+    M[e] = fma(f, mrow, M[e]);
+    Rr[e] = fma(f, rrow, Rr[e]);
+  }
+}
+// X = diag(M)^-1 Rr after all pivots (rows of skipped swing-leg pivots keep their
+// own positive diagonal R and a zero right-hand side)
+__device__ __forceinline__ void gj_finish(const double M[3], double Rr[3], int g) {
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const double dg = __shfl(M[e], (g << 4) | (4 * e + g));   // M[r][r] lives in lane (g, r)
+    Rr[e] *= fast_rcp(dg);
   }
 }
 
@@ -355,7 +361,6 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
     for (int e = 0; e < 3; ++e) Pf[e] = qadd[e] + ((xoff[e] >= 0) ? XTk[xoff[e]] : 0.0);
   }
   int bad = 0;
-  double* tile = sm + L.tile;
   for (int k = N - 1; k >= 0; --k) {
     const double* AB = sm + L.AB + kAB * k;
     const double* ROTk = sm + L.ROT + kROT * k;
@@ -402,6 +407,7 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
     if (conmask & 2u) { gj_step<3>(Quu, Rr, c, g, bad); gj_step<4>(Quu, Rr, c, g, bad); gj_step<5>(Quu, Rr, c, g, bad); }
     if (conmask & 4u) { gj_step<6>(Quu, Rr, c, g, bad); gj_step<7>(Quu, Rr, c, g, bad); gj_step<8>(Quu, Rr, c, g, bad); }
     if (conmask & 8u) { gj_step<9>(Quu, Rr, c, g, bad); gj_step<10>(Quu, Rr, c, g, bad); gj_step<11>(Quu, Rr, c, g, bad); }
+    gj_finish(Quu, Rr, g);
     double Kf[3];
 #pragma unroll
     for (int e = 0; e < 3; ++e) Kf[e] = -Rr[e];
@@ -413,35 +419,33 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
 #pragma unroll
       for (int e = 0; e < 3; ++e) Pf[e] = acc[e];
     }
-    // ---- un-rotate and store the gains: KD[3l+a][c] = sum_b T_l[a][b] Kt[3l+b][c] ----
-    tile[lane] = Kf[0]; tile[64 + lane] = Kf[1]; tile[128 + lane] = Kf[2];
-    QSYNC();
+    // ---- store the ROTATED gains [Kt | dt] straight from the fragments; the rollouts
+    //      apply T_l (3x3 per leg) to the 12 input increments ----
     {
       double* KDk = sm + L.KD + kKD * k;
 #pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        if (koff[e] >= 0) {
-          const int r = 4 * e + g, lr = r / 3, ar = r - 3 * lr;
-          const double* T = ROTk + 21 * lr + 3 * ar;
-          const double* col = tile + (3 * lr) * LD + c;
-          KDk[koff[e]] = T[0] * col[0] + T[1] * col[LD] + T[2] * col[2 * LD];
-        }
-      }
+      for (int e = 0; e < 3; ++e)
+        if (koff[e] >= 0) KDk[koff[e]] = Kf[e];
     }
-    QSYNC();
     prof.tick(PH_PUPD);
   }
   return bad;
 }
 
 // nonlinear closed-loop rollout with step alpha from (X,U) into the candidate
-// Xc and the input increment dU = alpha d + K (x' (-) x)
+// Xc and the input increment dU = T (alpha dt + Kt (x' (-) x)).  The gains are
+// stored in the rotated input coordinates of the backward pass; lane 4l+a (a<3)
+// owns input 3l+a, so the 3x3 rotation T_l is applied inside a lane quad with
+// DPP quad_perm broadcasts.
 __device__ inline void rollout_closed(const DevParams& P, const Layout& L, double* sm, double alpha,
                                       int lane) {
   const int N = P.N;
   const double* cst = sm + L.cst;
   ModelRegs M;
   M.load(cst, sm + L.bw0);
+  const int ql = lane >> 2, qa = lane & 3;             // leg, axis of this lane (lanes 0..15)
+  const bool ulane = (lane < 16) && (qa < 3);
+  const int uj = ulane ? 3 * ql + qa : 0;
   double xc[13], xn[13];
 #pragma unroll
   for (int i = 0; i < 13; ++i) xc[i] = cst[C_X0 + i];
@@ -449,6 +453,7 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
 #pragma unroll
     for (int i = 0; i < 13; ++i) sm[L.Xc + i] = xc[i];
   for (int k = 0; k < N; ++k) {
+    double* ub = sm + L.ub + 12 * (k & 1);
     // dx = xc (-) X_k : inverse Cayley map of q_k^-1 * qc (QuaternionUtils.cpp:16-18)
     double xo[13];
 #pragma unroll
@@ -463,31 +468,39 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
     {
       double G[12];
       quat_G(&xo[3], G);
-      const double sc = xo[3] * xc[3] + xo[4] * xc[4] + xo[5] * xc[5] + xo[6] * xc[6];
+      const double isc = fast_rcp(xo[3] * xc[3] + xo[4] * xc[4] + xo[5] * xc[5] + xo[6] * xc[6]);
 #pragma unroll
       for (int a = 0; a < 3; ++a)
-        dx[3 + a] = (G[a] * xc[3] + G[3 + a] * xc[4] + G[6 + a] * xc[5] + G[9 + a] * xc[6]) / sc;
+        dx[3 + a] = (G[a] * xc[3] + G[3 + a] * xc[4] + G[6 + a] * xc[5] + G[9 + a] * xc[6]) * isc;
     }
-    if (lane < 12) {
-      const double* kd = sm + L.KD + kKD * k + 13 * lane;
-      double s = alpha * kd[12];
-#pragma unroll
-      for (int b = 0; b < 12; ++b) s += kd[b] * dx[b];
-      sm[L.dU + 12 * k + lane] = s;                           // the increment, as computed
-      sm[L.ub + lane] = sm[L.U + 12 * k + lane] + s;
+    {
+      // rotated increment of input uj, then u-space increment through T_l
+      const double* kd = sm + L.KD + kKD * k + 13 * uj;
+      const double p0 = alpha * kd[12] + kd[0] * dx[0] + kd[1] * dx[1] + kd[2] * dx[2];
+      const double p1 = kd[3] * dx[3] + kd[4] * dx[4] + kd[5] * dx[5];
+      const double p2 = kd[6] * dx[6] + kd[7] * dx[7] + kd[8] * dx[8];
+      const double p3 = kd[9] * dx[9] + kd[10] * dx[10] + kd[11] * dx[11];
+      const double s = (p0 + p1) + (p2 + p3);
+      const double s0 = dpp_mov<0x00>(s), s1 = dpp_mov<0x55>(s), s2 = dpp_mov<0xAA>(s);   // quad_perm broadcasts
+      if (ulane) {
+        const double* T = sm + L.ROT + kROT * k + 21 * ql + 3 * qa;
+        const double inc = T[0] * s0 + T[1] * s1 + T[2] * s2;
+        sm[L.dU + 12 * k + uj] = inc;                         // the increment, as computed
+        ub[uj] = sm[L.U + 12 * k + uj] + inc;
+      }
     }
     QSYNC();
     double un[12];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) un[j] = sm[L.ub + j];
+    for (int j = 0; j < 12; ++j) un[j] = ub[j];
     srbd_step(P, M, xc, un, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) xc[i] = xn[i];
     if (lane == 0)
 #pragma unroll
       for (int i = 0; i < 13; ++i) sm[L.Xc + 13 * (k + 1) + i] = xn[i];
-    QSYNC();   // ub is rewritten at the next knot
   }
+  QSYNC();
 }
 
 // Slack / multiplier directions from the TRIAL rollout (alpha = 1).  The cone
@@ -509,9 +522,9 @@ __device__ inline void ipm_directions(const DevParams& P, const Layout& L, doubl
       const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
       const double sv = sm[L.S + idx], lv = sm[L.LAM + idx];
       dsv = -(jd + sm[L.RC + idx]);
-      dlv = (target - sv * lv - lv * dsv) / sv;
-      if (dsv < 0.0) ap = fmin(ap, -P.tau * sv / dsv);
-      if (dlv < 0.0) ad = fmin(ad, -P.tau * lv / dlv);
+      dlv = (target - sv * lv - lv * dsv) * fast_rcp(sv);
+      if (dsv < 0.0) ap = fmin(ap, -P.tau * sv * fast_rcp(dsv));
+      if (dlv < 0.0) ad = fmin(ad, -P.tau * lv * fast_rcp(dlv));
     }
     sm[L.DS + idx] = dsv;
     sm[L.DLAM + idx] = dlv;
@@ -521,34 +534,45 @@ __device__ inline void ipm_directions(const DevParams& P, const Layout& L, doubl
 }
 
 // Apply the step to (s, rc, lam).  The slack residual rc = c(u) + s is carried
-// as its own variable and updated with the small, accurately known increments
-// (rc <- rc + a.dU + ds), never recomputed from c(u) ~ 100 N: slacks keep their
-// RELATIVE accuracy far below 1e-14 N, which weakly active rows need.
-//   full primal step : ds = DS (trial), rc <- 0 exactly
-//   shortened step   : dU is the re-rolled increment; ds = -(a.dU + alpha rc),
-//                      kept inside the interior
+// as its own variable, never recomputed from c(u) ~ 100 N, so slacks keep their
+// RELATIVE accuracy far below 1e-14 N (weakly active rows need it).  The cone
+// rows are linear in u: a shortened primal step scales the trial increment
+// (dU <- alpha_p dU), hence s + alpha_p ds stays inside the interior exactly and
+// rc <- (1 - alpha_p) rc; a full step zeroes rc exactly.
 __device__ inline void ipm_apply(const DevParams& P, const Layout& L, double* sm, double ap, double ad,
                                  unsigned conmask, int lane) {
   const int N = P.N;
-  const double* cr = sm + L.cst + C_CR;
   for (int idx = lane; idx < N * 24; idx += kWave) {
-    const int k = idx / 24, row = idx - 24 * k, l = row / 6, i = row - 6 * l;
+    const int l = (idx % 24) / 6;
     if (!(conmask & (1u << l))) continue;
-    const double sv = sm[L.S + idx];
-    if (ap >= 1.0) {
-      sm[L.S + idx] = sv + sm[L.DS + idx];
-      sm[L.RC + idx] = 0.0;
-    } else {
-      const double* du = sm + L.dU + 12 * k + 3 * l;
-      const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
-      const double rc = sm[L.RC + idx];
-      double dsv = -(jd + ap * rc);
-      dsv = fmax(dsv, -(1.0 - 0.1 * (1.0 - P.tau)) * sv);
-      sm[L.S + idx] = sv + dsv;
-      sm[L.RC + idx] = rc + jd + dsv;
-    }
+    sm[L.S + idx] += ap * sm[L.DS + idx];
+    sm[L.RC + idx] = (ap >= 1.0) ? 0.0 : (1.0 - ap) * sm[L.RC + idx];
     sm[L.LAM + idx] += ad * sm[L.DLAM + idx];
   }
+}
+
+// shortened primal step: scale the trial increment and re-roll the states open loop
+__device__ inline void rollout_scaled(const DevParams& P, const Layout& L, double* sm, double ap, int lane) {
+  const int N = P.N;
+  const double* cst = sm + L.cst;
+  for (int i = lane; i < N * 12; i += kWave) sm[L.dU + i] *= ap;
+  QSYNC();
+  ModelRegs M;
+  M.load(cst, sm + L.bw0);
+  double x[13], xn[13], u[12];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) x[i] = cst[C_X0 + i];
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) u[j] = sm[L.U + 12 * k + j] + sm[L.dU + 12 * k + j];
+    srbd_step(P, M, x, u, xn);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) x[i] = xn[i];
+    if (lane == 0)
+#pragma unroll
+      for (int i = 0; i < 13; ++i) sm[L.Xc + 13 * (k + 1) + i] = xn[i];
+  }
+  QSYNC();
 }
 
 __device__ inline double cost_plain(const DevParams& P, const Layout& L, double* sm, int lane) {
@@ -613,21 +637,21 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
   }
   QSYNC();
   prof.tick(PH_SETUP);
+  const double inv_rows = 1.0 / (double)(6 * N * __popc(conmask));
   int it = 0, iters = 0, prev_full = 0;
   double mu = 0.0, resid = 0.0, last_step = 1e300, last_ap = 0.0, last_ad = 0.0;
   status = QMPC_MAX_ITER;
   for (it = 1; it <= P.iterations_max + 1; ++it) {
     // barrier parameter and slack residual over the enabled rows
-    double sl = 0.0, rs = 0.0, cnt = 0.0;
+    double sl = 0.0, rs = 0.0;
     for (int i = lane; i < N * 24; i += kWave) {
       const int l = (i % 24) / 6;
       if (conmask & (1u << l)) {
         sl += sm[L.S + i] * sm[L.LAM + i];
         rs = fmax(rs, fabs(sm[L.RC + i]));
-        cnt += 1.0;
       }
     }
-    mu = wave_sum(sl) / wave_sum(cnt);
+    mu = wave_sum(sl) * inv_rows;
     resid = wave_max(rs);
     if (mu <= P.mu_final && resid <= P.tol_feas && last_step <= P.tol_step && prev_full) { status = QMPC_OK; break; }
     if (it > P.iterations_max) break;
@@ -643,7 +667,7 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
     ipm_directions(P, L, sm, target, lane, &ap, &ad);
     last_ap = ap; last_ad = ad;
     prof.tick(PH_DIRS);
-    if (ap < 1.0) rollout_closed(P, L, sm, ap, lane);    // shortened primal step
+    if (ap < 1.0) rollout_scaled(P, L, sm, ap, lane);    // shortened primal step
     prof.tick(PH_ROLL);
     ipm_apply(P, L, sm, ap, ad, conmask, lane);
     prev_full = (ap >= 0.999 && ad >= 0.999);
@@ -729,6 +753,22 @@ __global__ __launch_bounds__(64) void qmpc_selftest_kernel(const double* __restr
   mtm(t + 2 * MAT, t, t + MAT, lane);
   QSYNC();
   for (int i = lane; i < MAT; i += kWave) C[i] = t[2 * MAT + i];
+}
+
+// ---- cross-lane primitive self-test: row-group broadcasts, wave reductions, quad broadcasts
+__global__ __launch_bounds__(64) void qmpc_selftest_lanes_kernel(const double* __restrict__ in,
+                                                                 double* __restrict__ out) {
+  const int lane = threadIdx.x;
+  const double x = in[lane];
+  out[lane] = rowgroup_bcast<0>(x);
+  out[64 + lane] = rowgroup_bcast<1>(x);
+  out[128 + lane] = rowgroup_bcast<2>(x);
+  out[192 + lane] = rowgroup_bcast<3>(x);
+  out[256 + lane] = wave_sum(x);
+  out[320 + lane] = wave_max(x);
+  out[384 + lane] = wave_min(x);
+  out[448 + lane] = row_bcast<5>(x);
+  out[512 + lane] = dpp_mov<0x55>(x);   // quad_perm [1,1,1,1]
 }
 
 }  // namespace qmpc

@@ -44,6 +44,20 @@ def test_mfma_fragment_layout(lib):
     assert np.abs(Cc - ref).max() < 1e-13
 
 
+def test_cross_lane_primitives(lib):
+    """DPP / v_permlane16_swap / v_permlane32_swap helpers of the stage solve."""
+    x = np.random.default_rng(5).standard_normal(64)
+    out = np.zeros((9, 64))
+    assert lib.qmpc_selftest_lanes(0, x.ctypes.data, out.ctypes.data) == 0
+    lanes = np.arange(64)
+    for G in range(4):
+        assert np.array_equal(out[G], x[16 * G + (lanes & 15)]), G
+    assert np.allclose(out[4], x.sum(), rtol=0, atol=1e-13) and np.ptp(out[4]) == 0
+    assert (out[5] == x.max()).all() and (out[6] == x.min()).all()
+    assert np.array_equal(out[7], x[(lanes & ~15) + 5])
+    assert np.array_equal(out[8], x[(lanes & ~3) + 1])
+
+
 @pytest.mark.parametrize("N", [10, 20])
 def test_linearisation_matches_oracle(pkg, lib, oracle, N):
     p, s = _solver(pkg, lib, N)
