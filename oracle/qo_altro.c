@@ -43,6 +43,7 @@ typedef struct knot_ws {
   double lam[QO_MAXCON][QO_MAXP];
   double s[QO_MAXCON][QO_MAXP];    /* interior-point slacks             */
   double rc[QO_MAXCON][QO_MAXP];   /* slack residual c(u) + s, tracked analytically */
+  double kap[QO_MAXCON][QO_MAXP];  /* 1 on rows showing the weakly-active signature       */
   double ds[QO_MAXCON][QO_MAXP];
   double dlam[QO_MAXCON][QO_MAXP];
 } knot_ws;
@@ -249,7 +250,7 @@ static void al_multiplier(const solver_ws* ws, int k, int ci, double* zp, double
     if (!row_on(cn, i)) { zp[i] = 0.0; act[i] = 0.0; continue; }
     if (ws->ipm && cn->type == QO_INEQUALITY) {
       const double sig = kw->lam[ci][i] / kw->s[ci][i];
-      zp[i] = ws->ipm_target / kw->s[ci][i] + sig * kw->rc[ci][i];
+      zp[i] = ws->ipm_target / kw->s[ci][i] - kw->kap[ci][i] * kw->lam[ci][i] + sig * kw->rc[ci][i];
       act[i] = sig;
       continue;
     }
@@ -604,7 +605,7 @@ static void ipm_directions(solver_ws* ws, double tau, double* alpha_p, double* a
         for (int j = 0; j < m; ++j) jd += kw->Ju[ci][i * m + j] * du[j];
         const double sv = kw->s[ci][i], lv = kw->lam[ci][i];
         const double dsv = -(jd + kw->rc[ci][i]);
-        const double dlv = (ws->ipm_target - sv * lv - lv * dsv) / sv;
+        const double dlv = (ws->ipm_target - (1.0 + kw->kap[ci][i]) * sv * lv - lv * dsv) / sv;
         kw->ds[ci][i] = dsv;
         kw->dlam[ci][i] = dlv;
         if (dsv < 0.0) ap = fmin(ap, -tau * sv / dsv);
@@ -628,9 +629,16 @@ static void ipm_apply(solver_ws* ws, double alpha_p, double alpha_d) {
       knot_ws* kw = &ws->kn[k];
       for (int i = 0; i < cn->p; ++i) {
         if (!row_on(cn, i)) continue;
+        const double s0 = kw->s[ci][i], l0 = kw->lam[ci][i];
         kw->s[ci][i] += alpha_p * kw->ds[ci][i];
         kw->rc[ci][i] = (alpha_p >= 1.0) ? 0.0 : (1.0 - alpha_p) * kw->rc[ci][i];
         kw->lam[ci][i] += alpha_d * kw->dlam[ci][i];
+        /* Tapia indicators: a weakly active row halves BOTH s and lambda on a full
+         * Newton step (regular rows send one of the two ratios to ~1, the other to ~sigma) */
+        const double rs = kw->s[ci][i] / s0, rl = kw->lam[ci][i] / l0;
+        const int sig = (alpha_p >= 0.99 && alpha_d >= 0.99 && rs < 0.6 && rl < 0.6 &&
+                         (kw->kap[ci][i] != 0.0 || (rs > 0.4 && rl > 0.4)));
+        kw->kap[ci][i] = sig ? 1.0 : 0.0;
       }
     }
 }
@@ -643,19 +651,21 @@ static int ipm_phase(solver_ws* ws, const qo_options* o, qo_result* r) {
   int it;
   r->last_step = 1e300;
   double last_ap = 0.0, last_ad = 0.0;
-  int prev_full = 0, status = QO_STATUS_MAX_ITER;
+  int status = QO_STATUS_MAX_ITER;
   for (it = 1; it <= o->ipm_iterations_max + 1; ++it) {
     double resid;
     const double mu = ipm_mu(ws, &resid);
     r->ipm_mu = mu;
-    if (mu <= o->ipm_mu_final && resid <= o->tol_feasibility && r->last_step <= o->tol_step &&
-        prev_full) { status = QO_STATUS_OK; break; }
+    if (mu <= o->ipm_mu_final && resid <= o->tol_feasibility && r->last_step <= o->tol_step) {
+      status = QO_STATUS_OK;
+      break;
+    }
     if (it > o->ipm_iterations_max) break;
     ws->ipm = 1;
     {
       /* centering: sigma until full steps are taken, then the fast value */
       double sg = o->ipm_sigma;
-      if (it > 1 && last_ap >= 0.999 && last_ad >= 0.999) sg = o->ipm_sigma_fast;
+      if (it > 1 && last_ap >= 0.99 && last_ad >= 0.99) sg = o->ipm_sigma_fast;
       ws->ipm_target = sg * mu;
     }
     const int bp = backward_pass(ws);
@@ -666,7 +676,9 @@ static int ipm_phase(solver_ws* ws, const qo_options* o, qo_result* r) {
     last_ap = ap; last_ad = ad;
     ws->ipm = 0;
     ipm_apply(ws, ap, ad);
+    /* convergence is judged on the FULL Newton step (the trial increment) */
     double step = 0.0;
+    for (int i = 0; i < N * m; ++i) step = fmax(step, fabs(ws->dU[i]));
     if (ap < 1.0) {   /* shortened primal step: scaled increment, open-loop states */
       for (int i = 0; i < N * m; ++i) {
         ws->dU[i] *= ap;
@@ -676,9 +688,6 @@ static int ipm_phase(solver_ws* ws, const qo_options* o, qo_result* r) {
       for (int k = 0; k < N; ++k)
         ws->prob->dyn(ws->prob->dyn_ctx, k, &ws->Xc[(k + 1) * n], &ws->Xc[k * n], &ws->Uc[k * m], ws->prob->h);
     }
-    for (int i = 0; i < N * m; ++i) step = fmax(step, fabs(ws->dU[i]));
-    const int full = (ap >= 0.999 && ad >= 0.999);
-    prev_full = full;
     memcpy(ws->U, ws->Uc, sizeof(double) * N * m);
     memcpy(ws->X, ws->Xc, sizeof(double) * (N + 1) * n);
     expansions(ws);

@@ -177,7 +177,7 @@ __device__ __forceinline__ double cone_value(const DevParams& P, const Layout& L
 // DESIGN.md "rotated stage solve") and the blocks the backward pass adds in the
 // rotated coordinates:
 //   Dblk = T' R_l T + sum_i w_i (T'a_i)(T'a_i)',   w_i = lam_i / s_i
-//   gq   = T' (R_l (u_l - uref_l)) + sum_i g_i (T'a_i),  g_i = target/s_i + w_i rc_i
+//   gq   = T' (R_l (u_l - uref_l)) + sum_i g_i (T'a_i),  g_i = target/s_i - kappa_i lam_i + w_i rc_i
 // ROT record per leg: T (9, row-major [a][b]), Dblk (9), gq (3).
 __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, double* sm, double target,
                                         int lane) {
@@ -202,9 +202,10 @@ __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, dou
     for (int i = 0; i < 6; ++i) {
       const double s = sm[L.S + 24 * k + 6 * l + i], lam = sm[L.LAM + 24 * k + 6 * l + i];
       const double rc = sm[L.RC + 24 * k + 6 * l + i];
+      const double kap = sm[L.DS + 24 * k + 6 * l + i];     // weakly-active flag (see ipm_apply)
       const double is = fast_rcp(s);
       w[i] = lam * is;
-      gi[i] = (target + lam * rc) * is;
+      gi[i] = (target + lam * rc) * is - kap * lam;
     }
     // heaviest row i1, second heaviest non-(anti)parallel row i2 (rows 4,5 are antiparallel)
     int i1 = 0;
@@ -506,7 +507,7 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
 // Slack / multiplier directions from the TRIAL rollout (alpha = 1).  The cone
 // rows are linear in u, so with the rollout's input increment dU
 //   ds = -(a_i . dU_l + rc),  rc = c(u) + s  (tracked analytically, see below),
-//   dlam = (target - s lam - lam ds) / s,
+//   dlam = (target - (1 + kappa) s lam - lam ds) / s,
 // followed by the fraction-to-the-boundary step lengths.
 __device__ inline void ipm_directions(const DevParams& P, const Layout& L, double* sm, double target,
                                       int lane, double* alpha_p, double* alpha_d) {
@@ -521,8 +522,9 @@ __device__ inline void ipm_directions(const DevParams& P, const Layout& L, doubl
       const double* du = sm + L.dU + 12 * k + 3 * l;
       const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
       const double sv = sm[L.S + idx], lv = sm[L.LAM + idx];
+      const double kap = sm[L.DS + idx];                     // flag left by the previous ipm_apply
       dsv = -(jd + sm[L.RC + idx]);
-      dlv = (target - sv * lv - lv * dsv) * fast_rcp(sv);
+      dlv = (target - (1.0 + kap) * sv * lv - lv * dsv) * fast_rcp(sv);
       if (dsv < 0.0) ap = fmin(ap, -P.tau * sv * fast_rcp(dsv));
       if (dlv < 0.0) ad = fmin(ad, -P.tau * lv * fast_rcp(dlv));
     }
@@ -540,15 +542,31 @@ __device__ inline void ipm_directions(const DevParams& P, const Layout& L, doubl
 // (dU <- alpha_p dU), hence s + alpha_p ds stays inside the interior exactly and
 // rc <- (1 - alpha_p) rc; a full step zeroes rc exactly.
 __device__ inline void ipm_apply(const DevParams& P, const Layout& L, double* sm, double ap, double ad,
-                                 unsigned conmask, int lane) {
+                                 unsigned conmask, int lane, unsigned& kapbits) {
   const int N = P.N;
-  for (int idx = lane; idx < N * 24; idx += kWave) {
+  unsigned newbits = 0;
+  int j = 0;
+  for (int idx = lane; idx < N * 24; idx += kWave, ++j) {
     const int l = (idx % 24) / 6;
     if (!(conmask & (1u << l))) continue;
-    sm[L.S + idx] += ap * sm[L.DS + idx];
+    const double s0 = sm[L.S + idx], l0 = sm[L.LAM + idx];
+    const bool kap0 = (kapbits >> j) & 1u;   // this lane owns row idx in every pass
+    const double s1 = s0 + ap * sm[L.DS + idx];
+    const double l1 = l0 + ad * sm[L.DLAM + idx];
+    sm[L.S + idx] = s1;
     sm[L.RC + idx] = (ap >= 1.0) ? 0.0 : (1.0 - ap) * sm[L.RC + idx];
-    sm[L.LAM + idx] += ad * sm[L.DLAM + idx];
+    sm[L.LAM + idx] = l1;
+    // Tapia indicators: a weakly active row halves BOTH s and lambda on a full Newton
+    // step (regular rows send one ratio to ~1, the other to ~sigma).  Such rows get the
+    // second-order complementarity right-hand side  target - 2 s lam  next iteration,
+    // which removes their linear (ratio 1/2) convergence.  The flag lives in the DS slot.
+    const double rs = s1 * fast_rcp(s0), rl = l1 * fast_rcp(l0);
+    const bool sig = (ap >= 0.99) && (ad >= 0.99) && (rs < 0.6) && (rl < 0.6) &&
+                     (kap0 || ((rs > 0.4) && (rl > 0.4)));
+    sm[L.DS + idx] = sig ? 1.0 : 0.0;        // read by the next rotation pre-pass / directions
+    newbits |= sig ? (1u << j) : 0u;
   }
+  kapbits = newbits;
 }
 
 // shortened primal step: scale the trial increment and re-roll the states open loop
@@ -634,11 +652,13 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
     sm[L.S + i] = s0;
     sm[L.RC + i] = c0 + s0;
     sm[L.LAM + i] = P.mu0 / s0;
+    sm[L.DS + i] = 0.0;
   }
   QSYNC();
   prof.tick(PH_SETUP);
   const double inv_rows = 1.0 / (double)(6 * N * __popc(conmask));
-  int it = 0, iters = 0, prev_full = 0;
+  int it = 0, iters = 0;
+  unsigned kapbits = 0;
   double mu = 0.0, resid = 0.0, last_step = 1e300, last_ap = 0.0, last_ad = 0.0;
   status = QMPC_MAX_ITER;
   for (it = 1; it <= P.iterations_max + 1; ++it) {
@@ -653,10 +673,10 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
     }
     mu = wave_sum(sl) * inv_rows;
     resid = wave_max(rs);
-    if (mu <= P.mu_final && resid <= P.tol_feas && last_step <= P.tol_step && prev_full) { status = QMPC_OK; break; }
+    if (mu <= P.mu_final && resid <= P.tol_feas && last_step <= P.tol_step) { status = QMPC_OK; break; }
     if (it > P.iterations_max) break;
     double sg = P.sigma;
-    if (it > 1 && last_ap >= 0.999 && last_ad >= 0.999) sg = P.sigma_fast;
+    if (it > 1 && last_ap >= 0.99 && last_ad >= 0.99) sg = P.sigma_fast;
     const double target = sg * mu;
     rotation_prepass(P, L, sm, target, lane);
     prof.tick(PH_MISC);
@@ -666,20 +686,19 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
     prof.tick(PH_ROLL);
     ipm_directions(P, L, sm, target, lane, &ap, &ad);
     last_ap = ap; last_ad = ad;
+    {
+      // convergence is judged on the FULL Newton step (the trial increment)
+      double step = 0.0;
+      for (int i = lane; i < N * 12; i += kWave) step = fmax(step, fabs(sm[L.dU + i]));
+      last_step = wave_max(step);
+    }
     prof.tick(PH_DIRS);
     if (ap < 1.0) rollout_scaled(P, L, sm, ap, lane);    // shortened primal step
     prof.tick(PH_ROLL);
-    ipm_apply(P, L, sm, ap, ad, conmask, lane);
-    prev_full = (ap >= 0.999 && ad >= 0.999);
+    ipm_apply(P, L, sm, ap, ad, conmask, lane, kapbits);
     // accept the candidate
-    double step = 0.0;
-    for (int i = lane; i < N * 12; i += kWave) {
-      const double du = sm[L.dU + i];
-      step = fmax(step, fabs(du));
-      sm[L.U + i] += du;
-    }
+    for (int i = lane; i < N * 12; i += kWave) sm[L.U + i] += sm[L.dU + i];
     for (int i = lane; i < (N + 1) * 13; i += kWave) sm[L.X + i] = sm[L.Xc + i];
-    last_step = wave_max(step);
     QSYNC();
     prof.tick(PH_MISC);
     expansions(P, L, sm, lane);
