@@ -145,6 +145,14 @@ def main():
     mean_iters = float(info["iterations"].mean())
 
     if rank == 0:
+        # HBM traffic per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
+        traffic = None
+        try:
+            pm = json.loads((REPO / "profiles" / "r01_v6_pmc_traffic.json").read_text())
+            if B == 1024 and N == 10:
+                traffic = pm["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         total = world * B * args.steps
         value = total / elapsed
         w_alg = W_ALG_KFLOP_PER_KNOT * 1e3 * N          # algorithmic FP64 flops per solve
@@ -159,7 +167,7 @@ def main():
                        "batch_per_gpu": B, "horizon": N, "parallelism": f"instance-sharded x{world}",
                        "converged": n_ok, "mean_iterations": mean_iters},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "qmpc_solve_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_flops_per_launch": w_alg * B,
                          "note": "FP64 MFMA/vector roof (78.6 TF); algorithmic work W_alg=159*N kFLOP/solve (SURVEY 8d); "

@@ -738,12 +738,25 @@ int qo_altro_solve(const qo_problem* prob, const qo_options* opts, double* X, do
   ws.N = prob->N;
   ws.ne = prob->n - (prob->use_quaternion ? 1 : 0);
   const int n = ws.n, m = ws.m, N = ws.N;
-  ws.kn = (knot_ws*)calloc((size_t)N + 1, sizeof(knot_ws));
+  /* per-thread scratch, allocated once and reused by every solve on this thread */
+  static __thread knot_ws* tl_kn = NULL;
+  static __thread double* tl_buf = NULL;
+  if (!tl_kn) {
+    tl_kn = (knot_ws*)malloc(sizeof(knot_ws) * (QO_MAXH + 1));
+    tl_buf = (double*)malloc(sizeof(double) * ((QO_MAXH + 1) * QO_MAXN + 2 * QO_MAXH * QO_MAXM + 8));
+  }
+  ws.kn = tl_kn;
+  for (int k = 0; k <= N; ++k) {   /* only the state that persists across iterations */
+    memset(ws.kn[k].lam, 0, sizeof ws.kn[k].lam);
+    memset(ws.kn[k].kap, 0, sizeof ws.kn[k].kap);
+    memset(ws.kn[k].s, 0, sizeof ws.kn[k].s);
+    memset(ws.kn[k].rc, 0, sizeof ws.kn[k].rc);
+  }
   ws.X = X;
   ws.U = U;
-  ws.Xc = (double*)calloc((size_t)(N + 1) * n, sizeof(double));
-  ws.Uc = (double*)calloc((size_t)N * m + 1, sizeof(double));
-  ws.dU = (double*)calloc((size_t)N * m + 1, sizeof(double));
+  ws.Xc = tl_buf;
+  ws.Uc = ws.Xc + (QO_MAXH + 1) * QO_MAXN;
+  ws.dU = ws.Uc + QO_MAXH * QO_MAXM + 4;
   ws.rho = opts->penalty_initial;
 
   qo_result r;
@@ -765,7 +778,7 @@ int qo_altro_solve(const qo_problem* prob, const qo_options* opts, double* X, do
       r.status = st;
       r.penalty = r.ipm_mu;
       if (res) *res = r;
-      free(ws.kn); free(ws.Xc); free(ws.Uc); free(ws.dU);
+      
       return r.status;
     }
   }
@@ -823,9 +836,6 @@ int qo_altro_solve(const qo_problem* prob, const qo_options* opts, double* X, do
   r.max_violation = viol;
   r.penalty = ws.rho;
   if (res) *res = r;
-  free(ws.kn);
-  free(ws.Xc);
-  free(ws.Uc);
-  free(ws.dU);
+
   return r.status;
 }

@@ -132,7 +132,8 @@ static void setup_problem(const qmpc_params* p, const qmpc_input* in, mpc_ctx* c
   ctx->fz_max = p->fz_max;
   qo_cone_block(p->mu, in->rot, ctx->CR);
 
-  memset(prob, 0, sizeof *prob);
+  memset(prob->con, 0, sizeof prob->con);
+  memset(prob->x0, 0, sizeof prob->x0);
   prob->n = 13; prob->m = 12; prob->N = N;
   prob->use_quaternion = 1;       /* QuatMpc.cpp:24 */
   prob->quat_start_index = 3;     /* QuatMpc.cpp:25 */
@@ -204,8 +205,12 @@ int qo_solve_one(const qmpc_params* p, const qmpc_input* in, double* forces, qmp
     if (traj_x) memset(traj_x, 0, sizeof(double) * (N + 1) * 13);
     return inf.status;
   }
-  mpc_ctx* ctx = (mpc_ctx*)malloc(sizeof(mpc_ctx));
-  qo_problem* prob = (qo_problem*)malloc(sizeof(qo_problem));
+  static __thread mpc_ctx* ctx = NULL;     /* per-thread, reused */
+  static __thread qo_problem* prob = NULL;
+  if (!ctx) {
+    ctx = (mpc_ctx*)malloc(sizeof(mpc_ctx));
+    prob = (qo_problem*)malloc(sizeof(qo_problem));
+  }
   setup_problem(p, in, ctx, prob);
   qo_options o;
   options_from_params(p, &o, verbose);
@@ -225,8 +230,6 @@ int qo_solve_one(const qmpc_params* p, const qmpc_input* in, double* forces, qmp
   if (info) *info = inf;
   if (traj_u) memcpy(traj_u, U, sizeof(double) * N * 12);
   if (traj_x) memcpy(traj_x, X, sizeof(double) * (N + 1) * 13);
-  free(ctx);
-  free(prob);
   return inf.status;
 }
 
