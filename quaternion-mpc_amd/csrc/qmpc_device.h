@@ -53,7 +53,10 @@ constexpr int kXT = 21;    // lxx attitude block (9), lx (12)
 constexpr int kKD = 156;   // gains [K | d], 12 x 13 row-major
 constexpr int kROT = 84;   // per leg: T(9), Dblk(9), gq(3)
 
-__host__ __device__ inline Layout make_layout(int N) {
+// kd_global: the per-knot gains KD and rotation blocks ROT (the two largest
+// arrays) live in an HBM/L2-resident workspace instead of LDS; N=20 then fits 4
+// instances per CU (36 KB) instead of 2 (75 KB), N=10 fits 8 (19 KB).
+__host__ __device__ inline Layout make_layout(int N, bool kd_global = false) {
   Layout L;
   int o = 0;
   auto take = [&](int n) { int r = o; o += n; return r; };
@@ -73,10 +76,16 @@ __host__ __device__ inline Layout make_layout(int N) {
   L.RC = take(N * 24);   // slack residual c(u) + s, tracked analytically
   L.AB = take(N * kAB);
   L.XT = take((N + 1) * kXT);
-  L.KD = take(N * kKD);
-  L.ROT = take(N * kROT);
-  o = (o + 1) & ~1;  // 16-byte alignment of the tile
-  L.tile = take(MAT);
+  if (kd_global) {
+    L.KD = -1;
+    L.ROT = -1;
+    L.tile = L.S;    // set-up scratch aliases the (not yet initialised) slack array
+  } else {
+    L.KD = take(N * kKD);
+    L.ROT = take(N * kROT);
+    o = (o + 1) & ~1;
+    L.tile = take(MAT);
+  }
   L.total = (o + 1) & ~1;
   return L;
 }

@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -28,7 +29,10 @@ struct qmpc_handle {
   double* d_traj_x;
   double* d_A;
   double* d_B;
-  size_t lds_bytes;
+  size_t lds_bytes;       // LDS-resident gains
+  size_t lds_bytes_g;     // gains in the global workspace
+  double* d_gws;          // [max_batch][N*(156+84)] workspace of the global-gains variant
+  int variant;            // 0: auto, 1: LDS gains, 2: global gains (env QMPC_VARIANT)
 };
 
 #define HIP_TRY(expr)                                                                      \
@@ -173,21 +177,33 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
   h->device = device;
   h->max_batch = max_batch;
   const int N = params->horizon;
-  const Layout L = make_layout(N);
+  const Layout L = make_layout(N, false), Lg = make_layout(N, true);
   h->lds_bytes = (size_t)L.total * sizeof(double);
-  if (h->lds_bytes > 160 * 1024) { delete h; return QMPC_BAD_ARGUMENT; }
+  h->lds_bytes_g = (size_t)Lg.total * sizeof(double);
+  if (h->lds_bytes_g > 160 * 1024) { delete h; return QMPC_BAD_ARGUMENT; }
+  {
+    const char* v = std::getenv("QMPC_VARIANT");
+    h->variant = v ? std::atoi(v) : 0;
+  }
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&h->ev0));
   HIP_TRY(hipEventCreate(&h->ev1));
   HIP_TRY(hipMalloc(&h->d_in, sizeof(qmpc_input) * (size_t)max_batch));
   HIP_TRY(hipMalloc(&h->d_forces, sizeof(double) * 12 * (size_t)max_batch));
   HIP_TRY(hipMalloc(&h->d_info, sizeof(qmpc_info) * (size_t)max_batch));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+  if (h->lds_bytes <= 160 * 1024) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_kernel<false, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_kernel<true, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+  }
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_kernel<false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_g));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_kernel<true, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_g));
+  HIP_TRY(hipMalloc(&h->d_gws, sizeof(double) * (size_t)N * (kKD + kROT) * (size_t)max_batch));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_linearize_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_g));
   *out = h;
   return QMPC_OK;
 }
@@ -197,6 +213,7 @@ void qmpc_destroy(qmpc_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->d_in) (void)hipFree(h->d_in);
   if (h->d_forces) (void)hipFree(h->d_forces);
+  if (h->d_gws) (void)hipFree(h->d_gws);
   if (h->d_info) (void)hipFree(h->d_info);
   if (h->d_traj_u) (void)hipFree(h->d_traj_u);
   if (h->d_traj_x) (void)hipFree(h->d_traj_x);
@@ -208,11 +225,27 @@ void qmpc_destroy(qmpc_handle* h) {
   delete h;
 }
 
+// Variant choice: with the gains in LDS an instance needs 39.6 KB (N=10) / 75 KB (N=20):
+// 4 / 2 instances per CU.  Small batches (<= one instance per SIMD) keep everything in
+// LDS (lowest latency); long horizons and large batches move the gains to the
+// workspace to raise the number of resident instances.
+static bool use_global_gains(const qmpc_handle* h, int32_t batch) {
+  if (h->variant == 1) return h->lds_bytes > 160 * 1024 ? true : false;
+  if (h->variant == 2) return true;
+  if (h->lds_bytes > 40 * 1024) return true;   // fewer than 4 instances per CU otherwise
+  return batch > 4096;
+}
+
 static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces,
                                 qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s) {
   HIP_TRY(hipEventRecord(h->ev0, s));
-  hipLaunchKernelGGL(qmpc_solve_kernel<false>, dim3((unsigned)batch), dim3(kWave), h->lds_bytes, s, h->dev, d_in,
-                     d_forces, d_info, d_tu, d_tx, (int)batch, (long long*)nullptr);
+  if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;   // the gains workspace is sized by max_batch
+  if (use_global_gains(h, batch))
+    hipLaunchKernelGGL((qmpc_solve_kernel<false, true>), dim3((unsigned)batch), dim3(kWave), h->lds_bytes_g, s, h->dev,
+                       d_in, d_forces, d_info, d_tu, d_tx, (int)batch, (long long*)nullptr, h->d_gws);
+  else
+    hipLaunchKernelGGL((qmpc_solve_kernel<false, false>), dim3((unsigned)batch), dim3(kWave), h->lds_bytes, s, h->dev,
+                       d_in, d_forces, d_info, d_tu, d_tx, (int)batch, (long long*)nullptr, (double*)nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev1, s));
   h->timed = true;
@@ -280,7 +313,7 @@ qmpc_status qmpc_linearize(qmpc_handle* h, int32_t batch, const qmpc_input* in, 
   if (!h->d_B) HIP_TRY(hipMalloc(&h->d_B, nA));
   if (!h->d_traj_x) HIP_TRY(hipMalloc(&h->d_traj_x, sizeof(double) * 13 * (N + 1) * (size_t)h->max_batch));
   HIP_TRY(hipMemcpyAsync(h->d_in, in, sizeof(qmpc_input) * (size_t)batch, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(qmpc_linearize_kernel, dim3((unsigned)batch), dim3(kWave), h->lds_bytes, h->stream, h->dev,
+  hipLaunchKernelGGL(qmpc_linearize_kernel, dim3((unsigned)batch), dim3(kWave), h->lds_bytes_g, h->stream, h->dev,
                      h->d_in, h->d_A, h->d_B, h->d_traj_x, (int)batch);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(Abar, h->d_A, sizeof(double) * 144 * N * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
@@ -302,8 +335,14 @@ qmpc_status qmpc_debug_profile(qmpc_handle* h, int32_t batch, const qmpc_input* 
   HIP_TRY(hipMalloc(&d_prof, sizeof(long long) * 16 * (size_t)batch));
   HIP_TRY(hipMemsetAsync(d_prof, 0, sizeof(long long) * 16 * (size_t)batch, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_in, in, sizeof(qmpc_input) * (size_t)batch, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(qmpc_solve_kernel<true>, dim3((unsigned)batch), dim3(kWave), h->lds_bytes, h->stream, h->dev,
-                     h->d_in, h->d_forces, h->d_info, (double*)nullptr, (double*)nullptr, (int)batch, d_prof);
+  if (use_global_gains(h, batch))
+    hipLaunchKernelGGL((qmpc_solve_kernel<true, true>), dim3((unsigned)batch), dim3(kWave), h->lds_bytes_g, h->stream,
+                       h->dev, h->d_in, h->d_forces, h->d_info, (double*)nullptr, (double*)nullptr, (int)batch, d_prof,
+                       h->d_gws);
+  else
+    hipLaunchKernelGGL((qmpc_solve_kernel<true, false>), dim3((unsigned)batch), dim3(kWave), h->lds_bytes, h->stream,
+                       h->dev, h->d_in, h->d_forces, h->d_info, (double*)nullptr, (double*)nullptr, (int)batch, d_prof,
+                       (double*)nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(cycles_out, d_prof, sizeof(long long) * 16 * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));

@@ -179,8 +179,8 @@ __device__ __forceinline__ double cone_value(const DevParams& P, const Layout& L
 //   Dblk = T' R_l T + sum_i w_i (T'a_i)(T'a_i)',   w_i = lam_i / s_i
 //   gq   = T' (R_l (u_l - uref_l)) + sum_i g_i (T'a_i),  g_i = target/s_i - kappa_i lam_i + w_i rc_i
 // ROT record per leg: T (9, row-major [a][b]), Dblk (9), gq (3).
-__device__ inline void rotation_prepass(const DevParams& P, const Layout& L, double* sm, double target,
-                                        int lane) {
+__device__ inline void rotation_prepass(const DevParams& P, const Layout& L, double* sm, double* ROT,
+                                        double target, int lane) {
   const int N = P.N;
   const double* cst = sm + L.cst;
   double cr[18];
@@ -188,7 +188,7 @@ __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, dou
   for (int i = 0; i < 18; ++i) cr[i] = cst[C_CR + i];
   for (int q = lane; q < 4 * N; q += kWave) {
     const int k = q >> 2, l = q & 3;
-    double* out = sm + L.ROT + kROT * k + 21 * l;
+    double* out = ROT + kROT * k + 21 * l;
     const double R0 = P.R[3 * l], R1 = P.R[3 * l + 1], R2 = P.R[3 * l + 2];
     if (cst[C_CON + l] == 0.0) {
       // swing leg: identity frame, block = R, zero gradient (forces pinned to 0)
@@ -310,8 +310,8 @@ __device__ __forceinline__ void gj_finish(const double M[3], double Rr[3], int g
 // Riccati backward pass with interior-point weights; writes KD (unrotated gains
 // [K | d], 12 x 13 per knot).  Returns nonzero when a pivot is not positive.
 template <bool PROF>
-__device__ inline int backward_pass(const DevParams& P, const Layout& L, double* sm, int lane,
-                                    unsigned conmask, Prof<PROF>& prof) {
+__device__ inline int backward_pass(const DevParams& P, const Layout& L, double* sm, double* KD,
+                                    const double* ROT, int lane, unsigned conmask, Prof<PROF>& prof) {
   const int N = P.N;
   const double* cst = sm + L.cst;
   const double* bw0 = sm + L.bw0;
@@ -364,7 +364,7 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
   int bad = 0;
   for (int k = N - 1; k >= 0; --k) {
     const double* AB = sm + L.AB + kAB * k;
-    const double* ROTk = sm + L.ROT + kROT * k;
+    const double* ROTk = ROT + kROT * k;
     const double* XTk = sm + L.XT + kXT * k;
     // ---- operands: Abar and rotated Bbar * T, straight into fragments ----
     double Af[3], Bf[3];
@@ -423,7 +423,7 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
     // ---- store the ROTATED gains [Kt | dt] straight from the fragments; the rollouts
     //      apply T_l (3x3 per leg) to the 12 input increments ----
     {
-      double* KDk = sm + L.KD + kKD * k;
+      double* KDk = KD + kKD * k;
 #pragma unroll
       for (int e = 0; e < 3; ++e)
         if (koff[e] >= 0) KDk[koff[e]] = Kf[e];
@@ -438,8 +438,8 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
 // stored in the rotated input coordinates of the backward pass; lane 4l+a (a<3)
 // owns input 3l+a, so the 3x3 rotation T_l is applied inside a lane quad with
 // DPP quad_perm broadcasts.
-__device__ inline void rollout_closed(const DevParams& P, const Layout& L, double* sm, double alpha,
-                                      int lane) {
+__device__ inline void rollout_closed(const DevParams& P, const Layout& L, double* sm, const double* KD,
+                                      const double* ROT, double alpha, int lane) {
   const int N = P.N;
   const double* cst = sm + L.cst;
   ModelRegs M;
@@ -476,7 +476,7 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
     }
     {
       // rotated increment of input uj, then u-space increment through T_l
-      const double* kd = sm + L.KD + kKD * k + 13 * uj;
+      const double* kd = KD + kKD * k + 13 * uj;
       const double p0 = alpha * kd[12] + kd[0] * dx[0] + kd[1] * dx[1] + kd[2] * dx[2];
       const double p1 = kd[3] * dx[3] + kd[4] * dx[4] + kd[5] * dx[5];
       const double p2 = kd[6] * dx[6] + kd[7] * dx[7] + kd[8] * dx[8];
@@ -484,7 +484,7 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
       const double s = (p0 + p1) + (p2 + p3);
       const double s0 = dpp_mov<0x00>(s), s1 = dpp_mov<0x55>(s), s2 = dpp_mov<0xAA>(s);   // quad_perm broadcasts
       if (ulane) {
-        const double* T = sm + L.ROT + kROT * k + 21 * ql + 3 * qa;
+        const double* T = ROT + kROT * k + 21 * ql + 3 * qa;
         const double inc = T[0] * s0 + T[1] * s1 + T[2] * s2;
         sm[L.dU + 12 * k + uj] = inc;                         // the increment, as computed
         ub[uj] = sm[L.U + 12 * k + uj] + inc;
@@ -611,19 +611,23 @@ __device__ inline double cost_plain(const DevParams& P, const Layout& L, double*
 }
 
 // ---- the solve kernel ---------------------------------------------------------
-template <bool PROF>
-__global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_input* __restrict__ in,
+// KDG: gains / rotation blocks in the global workspace gws (one slice per instance)
+template <bool PROF, bool KDG>
+__global__ __launch_bounds__(64, KDG ? 2 : 1) void qmpc_solve_kernel(DevParams P, const qmpc_input* __restrict__ in,
                                                         double* __restrict__ forces,
                                                         qmpc_info* __restrict__ info,
                                                         double* __restrict__ traj_u,
                                                         double* __restrict__ traj_x, int batch,
-                                                        long long* __restrict__ prof_out) {
+                                                        long long* __restrict__ prof_out,
+                                                        double* __restrict__ gws) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int b = blockIdx.x;
   if (b >= batch) return;
   const int lane = threadIdx.x;
   const int N = P.N;
-  const Layout L = make_layout(N);
+  const Layout L = make_layout(N, KDG);
+  double* KD = KDG ? gws + (size_t)b * N * (kKD + kROT) : sm + L.KD;
+  double* ROT = KDG ? KD + N * kKD : sm + L.ROT;
   int status = QMPC_OK;
   Prof<PROF> prof;
   prof.start();
@@ -678,11 +682,13 @@ __global__ __launch_bounds__(64) void qmpc_solve_kernel(DevParams P, const qmpc_
     double sg = P.sigma;
     if (it > 1 && last_ap >= 0.99 && last_ad >= 0.99) sg = P.sigma_fast;
     const double target = sg * mu;
-    rotation_prepass(P, L, sm, target, lane);
+    rotation_prepass(P, L, sm, ROT, target, lane);
+    if (KDG) __syncthreads();
     prof.tick(PH_MISC);
-    if (backward_pass<PROF>(P, L, sm, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
+    if (backward_pass<PROF>(P, L, sm, KD, ROT, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
+    if (KDG) __syncthreads();
     double ap, ad;
-    rollout_closed(P, L, sm, 1.0, lane);                 // trial step
+    rollout_closed(P, L, sm, KD, ROT, 1.0, lane);        // trial step
     prof.tick(PH_ROLL);
     ipm_directions(P, L, sm, target, lane, &ap, &ad);
     last_ap = ap; last_ad = ad;
@@ -740,7 +746,7 @@ __global__ __launch_bounds__(64) void qmpc_linearize_kernel(DevParams P, const q
   if (b >= batch) return;
   const int lane = threadIdx.x;
   const int N = P.N;
-  const Layout L = make_layout(N);
+  const Layout L = make_layout(N, true);
   int status = QMPC_OK;
   setup_instance(P, L, sm, in + b, lane, &status);
   if (status != QMPC_OK) {
