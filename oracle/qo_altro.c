@@ -663,9 +663,13 @@ static int ipm_phase(solver_ws* ws, const qo_options* o, qo_result* r) {
     if (it > o->ipm_iterations_max) break;
     ws->ipm = 1;
     {
-      /* centering: sigma until full steps are taken, then the fast value */
+      /* centering: sigma until full steps are taken, then the fast value; short
+       * steps (jamming near the boundary) call for more centering */
       double sg = o->ipm_sigma;
-      if (it > 1 && last_ap >= 0.99 && last_ad >= 0.99) sg = o->ipm_sigma_fast;
+      const double amin = fmin(last_ap, last_ad);
+      if (it > 1 && amin >= 0.99) sg = o->ipm_sigma_fast;
+      else if (it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
+      else if (it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
       ws->ipm_target = sg * mu;
     }
     const int bp = backward_pass(ws);

@@ -679,8 +679,13 @@ __global__ __launch_bounds__(64, KDG ? 2 : 1) void qmpc_solve_kernel(DevParams P
     resid = wave_max(rs);
     if (mu <= P.mu_final && resid <= P.tol_feas && last_step <= P.tol_step) { status = QMPC_OK; break; }
     if (it > P.iterations_max) break;
+    // centering: sigma until full steps are taken, then the fast value; short steps
+    // (jamming near the boundary) call for more centering
     double sg = P.sigma;
-    if (it > 1 && last_ap >= 0.99 && last_ad >= 0.99) sg = P.sigma_fast;
+    const double amin = fmin(last_ap, last_ad);
+    if (it > 1 && amin >= 0.99) sg = P.sigma_fast;
+    else if (it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
+    else if (it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
     const double target = sg * mu;
     rotation_prepass(P, L, sm, ROT, target, lane);
     if (KDG) __syncthreads();
