@@ -94,6 +94,36 @@ def test_forces_match_oracle_random_trot(pkg, lib, oracle, N, cfg):
     s.close()
 
 
+@pytest.mark.parametrize("N", [1, 5, 16, 32])
+def test_other_horizons(pkg, lib, oracle, N):
+    """Horizon edge cases: a single knot, the humanoid-config horizon 16, QMPC_MAX_HORIZON."""
+    p, s = _solver(pkg, lib, N, cap=64)
+    rec = pkg.random_go1_trot_states(48, config_id=4)
+    f, info = s.solve(rec)
+    fo, io = oracle.solve(p, rec, threads=8)
+    assert (info["status"] == io["status"]).all()
+    ok = info["status"] == 0
+    assert ok.mean() > 0.9
+    assert np.abs(f[ok] - fo[ok]).max() < 1e-6
+    s.close()
+
+
+def test_host_buffer_entry_point_timing(pkg, lib):
+    """qmpc_solve (H2D + kernel + D2H, blocking): the PCIe-inclusive rate quoted in DESIGN.md."""
+    import time
+
+    p, s = _solver(pkg, lib, 10)
+    rec = pkg.random_go1_trot_states(1024, config_id=2)
+    s.solve(rec)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        s.solve(rec)
+    dt = (time.perf_counter() - t0) / 10
+    print(f"qmpc_solve host path: {1024 / dt:.0f} solves/s ({dt * 1e3:.3f} ms per 1024), kernel {s.last_kernel_ms():.3f} ms")
+    assert dt < 0.1
+    s.close()
+
+
 @pytest.mark.parametrize("which,name", [("stand", "quat_mpc_test.json"), ("trot", "trot_quat_mpc_test.json")])
 def test_golden_trajectories_on_gpu(pkg, lib, which, name):
     d = json.loads((GOLDEN / name).read_text())
