@@ -309,7 +309,8 @@ __device__ __forceinline__ void gj_finish(const double M[3], double Rr[3], int g
 
 // Riccati backward pass with interior-point weights; writes KD (unrotated gains
 // [K | d], 12 x 13 per knot).  Returns nonzero when a pivot is not positive.
-template <bool PROF>
+// PIPE: build the next knot's operands during the stage solve (needs 12 more VGPRs)
+template <bool PROF, bool PIPE>
 __device__ inline int backward_pass(const DevParams& P, const Layout& L, double* sm, double* KD,
                                     const double* ROT, int lane, unsigned conmask, Prof<PROF>& prof) {
   const int N = P.N;
@@ -362,27 +363,34 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
     for (int e = 0; e < 3; ++e) Pf[e] = qadd[e] + ((xoff[e] >= 0) ? XTk[xoff[e]] : 0.0);
   }
   int bad = 0;
-  for (int k = N - 1; k >= 0; --k) {
-    const double* AB = sm + L.AB + kAB * k;
-    const double* ROTk = ROT + kROT * k;
-    const double* XTk = sm + L.XT + kXT * k;
-    // ---- operands: Abar and rotated Bbar * T, straight into fragments ----
-    double Af[3], Bf[3];
+  // operands of knot kk: Abar and rotated Bbar * T, straight into fragments.  They do not
+  // depend on the cost-to-go, so the NEXT knot's operands are built while the
+  // latency-bound stage solve of the current knot runs (software pipelining).
+  auto build_operands = [&](int kk, double Afo[3], double Bfo[3]) {
+    const double* ABk = sm + L.AB + kAB * kk;
+    const double* ROTkk = ROT + kROT * kk;
     double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-    if (cval) { t0 = ROTk[21 * lc + bc]; t1 = ROTk[21 * lc + 3 + bc]; t2 = ROTk[21 * lc + 6 + bc]; }
+    if (cval) { t0 = ROTkk[21 * lc + bc]; t1 = ROTkk[21 * lc + 3 + bc]; t2 = ROTkk[21 * lc + 6 + bc]; }
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
-      Af[e] = (aoff[e] >= 0) ? AB[aoff[e]] : Ac[e];
+      Afo[e] = (aoff[e] >= 0) ? ABk[aoff[e]] : Ac[e];
       double b0 = Bc[e][0], b1 = Bc[e][1], b2 = Bc[e][2];
       if (phi[e]) {
-        const double* W = AB + 18 + 3 * (4 * e + g - 3);
+        const double* W = ABk + 18 + 3 * (4 * e + g - 3);
         const double w0 = W[0], w1 = W[1], w2 = W[2];
         b0 = (0.5 * P.hh) * (w0 * hbw[0][0] + w1 * hbw[1][0] + w2 * hbw[2][0]);
         b1 = (0.5 * P.hh) * (w0 * hbw[0][1] + w1 * hbw[1][1] + w2 * hbw[2][1]);
         b2 = (0.5 * P.hh) * (w0 * hbw[0][2] + w1 * hbw[1][2] + w2 * hbw[2][2]);
       }
-      Bf[e] = b0 * t0 + b1 * t1 + b2 * t2;
+      Bfo[e] = b0 * t0 + b1 * t1 + b2 * t2;
     }
+  };
+  double Af[3], Bf[3], Afn[3], Bfn[3];
+  if (PIPE) build_operands(N - 1, Af, Bf);
+  for (int k = N - 1; k >= 0; --k) {
+    if (!PIPE) build_operands(k, Af, Bf);
+    const double* ROTk = ROT + kROT * k;
+    const double* XTk = sm + L.XT + kXT * k;
     prof.tick(PH_BUILD);
     // ---- T = P'A (col 12 <- p), S = P'B ; Qxx = A'T, Qux = B'T, Quu = B'S ----
     const d4 z4 = {0.0, 0.0, 0.0, 0.0};
@@ -403,6 +411,7 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
       Rr[e] = Qux[e];
     }
     prof.tick(PH_MFMA);
+    if (PIPE && k > 0) build_operands(k - 1, Afn, Bfn);   // overlaps with the solve below
     // ---- stage solve: [Kt | dt] = -Quu^-1 [Qux | Qu]; swing-leg pivots are decoupled ----
     if (conmask & 1u) { gj_step<0>(Quu, Rr, c, g, bad); gj_step<1>(Quu, Rr, c, g, bad); gj_step<2>(Quu, Rr, c, g, bad); }
     if (conmask & 2u) { gj_step<3>(Quu, Rr, c, g, bad); gj_step<4>(Quu, Rr, c, g, bad); gj_step<5>(Quu, Rr, c, g, bad); }
@@ -428,6 +437,9 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
       for (int e = 0; e < 3; ++e)
         if (koff[e] >= 0) KDk[koff[e]] = Kf[e];
     }
+    if (PIPE)
+#pragma unroll
+      for (int e = 0; e < 3; ++e) { Af[e] = Afn[e]; Bf[e] = Bfn[e]; }
     prof.tick(PH_PUPD);
   }
   return bad;
@@ -437,46 +449,69 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
 // Xc and the input increment dU = T (alpha dt + Kt (x' (-) x)).  The gains are
 // stored in the rotated input coordinates of the backward pass; lane 4l+a (a<3)
 // owns input 3l+a, so the 3x3 rotation T_l is applied inside a lane quad with
-// DPP quad_perm broadcasts.
+// DPP quad_perm broadcasts.  The loads of knot k+1 (old state, gain row, T_l, old
+// input) do not depend on the rollout state and are issued one knot ahead.
+struct RollLoads {
+  double xo[13], kd[13], T[3], uo;
+};
+template <bool WITH_X>
+__device__ __forceinline__ void roll_load(const Layout& L, const double* sm, const double* KD,
+                                          const double* ROT, int k, int uj, int ql, int qa, RollLoads& r) {
+  if (WITH_X)
+#pragma unroll
+    for (int i = 0; i < 13; ++i) r.xo[i] = sm[L.X + 13 * k + i];
+  const double* kd = KD + kKD * k + 13 * uj;
+#pragma unroll
+  for (int i = 0; i < 13; ++i) r.kd[i] = kd[i];
+  const double* T = ROT + kROT * k + 21 * ql + 3 * qa;
+  r.T[0] = T[0]; r.T[1] = T[1]; r.T[2] = T[2];
+  r.uo = sm[L.U + 12 * k + uj];
+}
+// PF_X: also prefetch the old state (LDS variant: registers to spare); the global-gains
+// variant is register-bound (2 waves/SIMD) and prefetches only its high-latency gain row / T_l
+template <bool PF_X, bool PF_K>
 __device__ inline void rollout_closed(const DevParams& P, const Layout& L, double* sm, const double* KD,
                                       const double* ROT, double alpha, int lane) {
   const int N = P.N;
   const double* cst = sm + L.cst;
   ModelRegs M;
   M.load(cst, sm + L.bw0);
-  const int ql = lane >> 2, qa = lane & 3;             // leg, axis of this lane (lanes 0..15)
-  const bool ulane = (lane < 16) && (qa < 3);
-  const int uj = ulane ? 3 * ql + qa : 0;
+  const bool ulane = (lane < 16) && ((lane & 3) < 3);
+  const int ql = ulane ? (lane >> 2) : 0, qa = ulane ? (lane & 3) : 0;   // leg, axis of this lane
+  const int uj = 3 * ql + qa;
   double xc[13], xn[13];
 #pragma unroll
   for (int i = 0; i < 13; ++i) xc[i] = cst[C_X0 + i];
   if (lane == 0)
 #pragma unroll
     for (int i = 0; i < 13; ++i) sm[L.Xc + i] = xc[i];
+  RollLoads cur, nxt;
+  if (PF_K) roll_load<PF_X>(L, sm, KD, ROT, 0, uj, ql, qa, cur);
   for (int k = 0; k < N; ++k) {
     double* ub = sm + L.ub + 12 * (k & 1);
-    // dx = xc (-) X_k : inverse Cayley map of q_k^-1 * qc (QuaternionUtils.cpp:16-18)
-    double xo[13];
+    if (!PF_K) roll_load<PF_X>(L, sm, KD, ROT, k, uj, ql, qa, cur);
+    if (!PF_X)
 #pragma unroll
-    for (int i = 0; i < 13; ++i) xo[i] = sm[L.X + 13 * k + i];
+      for (int i = 0; i < 13; ++i) cur.xo[i] = sm[L.X + 13 * k + i];
+    // dx = xc (-) X_k : inverse Cayley map of q_k^-1 * qc (QuaternionUtils.cpp:16-18)
     double dx[12];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      dx[a] = xc[a] - xo[a];
-      dx[6 + a] = xc[7 + a] - xo[7 + a];
-      dx[9 + a] = xc[10 + a] - xo[10 + a];
+      dx[a] = xc[a] - cur.xo[a];
+      dx[6 + a] = xc[7 + a] - cur.xo[7 + a];
+      dx[9 + a] = xc[10 + a] - cur.xo[10 + a];
     }
     {
       double G[12];
-      quat_G(&xo[3], G);
-      const double isc = fast_rcp(xo[3] * xc[3] + xo[4] * xc[4] + xo[5] * xc[5] + xo[6] * xc[6]);
+      quat_G(&cur.xo[3], G);
+      const double isc = fast_rcp(cur.xo[3] * xc[3] + cur.xo[4] * xc[4] + cur.xo[5] * xc[5] + cur.xo[6] * xc[6]);
 #pragma unroll
       for (int a = 0; a < 3; ++a)
         dx[3 + a] = (G[a] * xc[3] + G[3 + a] * xc[4] + G[6 + a] * xc[5] + G[9 + a] * xc[6]) * isc;
     }
     {
       // rotated increment of input uj, then u-space increment through T_l
-      const double* kd = KD + kKD * k + 13 * uj;
+      const double* kd = cur.kd;
       const double p0 = alpha * kd[12] + kd[0] * dx[0] + kd[1] * dx[1] + kd[2] * dx[2];
       const double p1 = kd[3] * dx[3] + kd[4] * dx[4] + kd[5] * dx[5];
       const double p2 = kd[6] * dx[6] + kd[7] * dx[7] + kd[8] * dx[8];
@@ -484,13 +519,13 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
       const double s = (p0 + p1) + (p2 + p3);
       const double s0 = dpp_mov<0x00>(s), s1 = dpp_mov<0x55>(s), s2 = dpp_mov<0xAA>(s);   // quad_perm broadcasts
       if (ulane) {
-        const double* T = ROT + kROT * k + 21 * ql + 3 * qa;
-        const double inc = T[0] * s0 + T[1] * s1 + T[2] * s2;
+        const double inc = cur.T[0] * s0 + cur.T[1] * s1 + cur.T[2] * s2;
         sm[L.dU + 12 * k + uj] = inc;                         // the increment, as computed
-        ub[uj] = sm[L.U + 12 * k + uj] + inc;
+        ub[uj] = cur.uo + inc;
       }
     }
     QSYNC();
+    if (PF_K && k + 1 < N) roll_load<PF_X>(L, sm, KD, ROT, k + 1, uj, ql, qa, nxt);   // one knot ahead
     double un[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) un[j] = ub[j];
@@ -500,6 +535,7 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
     if (lane == 0)
 #pragma unroll
       for (int i = 0; i < 13; ++i) sm[L.Xc + 13 * (k + 1) + i] = xn[i];
+    if (PF_K) cur = nxt;
   }
   QSYNC();
 }
@@ -690,10 +726,10 @@ __global__ __launch_bounds__(64, KDG ? 2 : 1) void qmpc_solve_kernel(DevParams P
     rotation_prepass(P, L, sm, ROT, target, lane);
     if (KDG) __syncthreads();
     prof.tick(PH_MISC);
-    if (backward_pass<PROF>(P, L, sm, KD, ROT, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
+    if (backward_pass<PROF, !KDG>(P, L, sm, KD, ROT, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
     if (KDG) __syncthreads();
     double ap, ad;
-    rollout_closed(P, L, sm, KD, ROT, 1.0, lane);        // trial step
+    rollout_closed<!KDG, !KDG>(P, L, sm, KD, ROT, 1.0, lane);  // trial step
     prof.tick(PH_ROLL);
     ipm_directions(P, L, sm, target, lane, &ap, &ad);
     last_ap = ap; last_ad = ad;
