@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--horizon", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also compare a sample against the oracle")
+    ap.add_argument("--selftest-gloo", action="store_true",
+                    help="TEST ONLY: run the multi-rank pipeline (sharding, double buffering, async gather) on CPU "
+                         "tensors over gloo with the CPU oracle standing in for the kernel; prints no metric")
     args = ap.parse_args()
 
     import torch
@@ -84,61 +87,115 @@ def main():
             print(f"bench.py: WORLD_SIZE={world} != --gpus {args.gpus}; launch with torch.distributed.run", file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
-    if not torch.cuda.is_available():
+    selftest = args.selftest_gloo
+    if not selftest and not torch.cuda.is_available():
         print("bench.py: no GPU visible; the product path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
-    torch.cuda.set_device(local)
+    dev = "cpu" if selftest else "cuda"
+    if not selftest:
+        torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if selftest else "nccl", rank=rank, world_size=world)
 
     pkg = load_pkg()
-    lib = pkg.load_library()
     N, B = args.horizon, args.batch
     config_id = 2 if N == 10 else 3
-    params = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
-    solver = pkg.Solver(params, B, device=local, lib=lib)
-
     # synthetic Go1 trot states; rank r owns instances [r*B, (r+1)*B)
     rec = pkg.random_go1_trot_states(B, config_id=config_id, first=rank * B)
-    d_in = torch.from_numpy(rec.view(np.uint8).reshape(B, -1).copy()).cuda()
-    d_f = torch.zeros(B, 12, dtype=torch.float64, device="cuda")
-    d_info = torch.zeros(B, pkg.INFO_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
-    # a real (non-null) stream: the C ABI treats NULL as "the handle's own stream"
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
+    d_f = torch.zeros(B, 12, dtype=torch.float64, device=dev)
+    d_info = torch.zeros(B, pkg.INFO_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    if selftest:
+        from oracle import pyoracle   # test-only stand-in for the kernel
+        f_ref, _ = pyoracle.solve(pyoracle.default_params(N, 0), rec)
+        f_ref = torch.from_numpy(f_ref)
+        solver = stream = None
+
+        def launch(out):
+            out.copy_(f_ref)
+    else:
+        lib = pkg.load_library()
+        params = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
+        solver = pkg.Solver(params, B, device=local, lib=lib)
+        d_in = torch.from_numpy(rec.view(np.uint8).reshape(B, -1).copy()).cuda()
+        # a real (non-null) stream: the C ABI treats NULL as "the handle's own stream"
+        stream = torch.cuda.Stream()
+        torch.cuda.set_stream(stream)
+
+        def launch(out):
+            solver.solve_device(B, d_in.data_ptr(), out.data_ptr(), d_info.data_ptr(), stream.cuda_stream)
 
     counts = [B] * world
+    # double-buffered outputs: the gather of step i (RCCL's own stream) overlaps the solve of
+    # step i+1 (launch stream); one collective per step, never on the solve's critical path
+    d_fs = [d_f, torch.zeros_like(d_f)]
+    gathered = [torch.zeros(world * B, 12, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    pending = [None, None]
 
-    def step():
-        solver.solve_device(B, d_in.data_ptr(), d_f.data_ptr(), d_info.data_ptr(), stream.cuda_stream)
+    def step(i):
+        buf = i & 1
+        if pending[buf] is not None:          # the buffer's previous gather must have drained
+            pending[buf].wait()
+            pending[buf] = None
+        launch(d_fs[buf])
         if world > 1:
-            return pkg.gather_forces(d_f, world, counts)   # the single RCCL collective of the path
-        return d_f
+            pending[buf] = dist.all_gather_into_tensor(gathered[buf], d_fs[buf], async_op=True)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+    def drain():
+        for w in pending:
+            if w is not None:
+                w.wait()
+        pending[0] = pending[1] = None
+
+    def sync():
+        if not selftest:
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync()
+    if not selftest:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    torch.cuda.synchronize()
+    if not selftest:
+        ev0.record(stream)
+    for i in range(args.steps):
+        step(i)
+    if not selftest:
+        ev1.record(stream)
+    drain()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ev_ms = ev0.elapsed_time(ev1)                     # HIP events on the launch stream
-    kernel_ms = ev_ms / args.steps                    # average launch duration (back-to-back launches)
+    # HIP events on the launch stream: average launch duration (back-to-back launches)
+    kernel_ms = (ev0.elapsed_time(ev1) / args.steps) if not selftest else float("nan")
+    d_f = d_fs[(args.steps - 1) & 1]
+    if world > 1:
+        # every rank holds every force: check the gathered block against the local one
+        g = gathered[(args.steps - 1) & 1]
+        assert torch.equal(g[rank * B:(rank + 1) * B], d_f), "gathered forces differ from the local shard"
+    if selftest:
+        ok = True
+        if world > 1:
+            from oracle import pyoracle
+            full, _ = pyoracle.solve(pyoracle.default_params(N, 0),
+                                     pkg.random_go1_trot_states(world * B, config_id=config_id))
+            ok = bool(np.array_equal(gathered[(args.steps - 1) & 1].numpy(), full))
+        if rank == 0:
+            print(json.dumps({"selftest": "gloo", "n_ranks": world, "steps": args.steps, "ok": ok}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
 
     info = d_info.cpu().numpy().view(pkg.INFO_DTYPE).reshape(-1)
     n_ok = int((info["status"] == 0).sum())

@@ -37,3 +37,17 @@ def test_sharded_solve_gloo(world, total):
            str(REPO / "tests" / "_dist_worker.py"), str(total)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("world", [2])
+def test_bench_multirank_pipeline_gloo(world):
+    """bench.py's N > 1 code path (per-rank shard, double-buffered outputs, one async all_gather per
+    step, drain, max-over-ranks timing) on CPU tensors over gloo; the oracle stands in for the kernel."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
+           str(REPO / "bench.py"), "--gpus", str(world), "--steps", "5", "--warmup", "2", "--batch", "16",
+           "--selftest-gloo"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert '"ok": true' in r.stdout
