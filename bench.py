@@ -40,11 +40,30 @@ def load_pkg():
     return mod
 
 
+def usable_cores() -> int:
+    """Host threads this process may actually run on: CPU affinity capped by the cgroup CPU quota
+    (the GPU box shows 256 logical CPUs but grants 16 CPUs of quota; oversubscribing it is slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(-(-int(quota) // int(period)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(pkg, horizon: int, config_id: int, seconds: float = 12.0):
     """Time the CPU oracle ("port") on a bounded sample of the same workload."""
     from oracle import pyoracle  # checker / baseline only
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     p = pyoracle.default_params(horizon, 0)
     probe = pkg.random_go1_trot_states(4 * cores, config_id=config_id)
     t0 = time.perf_counter()
@@ -57,7 +76,8 @@ def cpu_baseline(pkg, horizon: int, config_id: int, seconds: float = 12.0):
     dt = time.perf_counter() - t0
     return {
         "value": n / dt, "unit": "solves/s", "cores": cores, "kind": "port",
-        "sample": f"first {n} instances of the same synthetic workload (N={horizon}), all {cores} host threads, "
+        "sample": f"first {n} instances of the same synthetic workload (N={horizon}), {cores} host threads "
+                  f"(= usable cores: affinity capped by the cgroup CPU quota; {os.cpu_count()} logical CPUs visible), "
                   f"instance-parallel; oracle/ C restatement, {dt:.1f} s; mean {float(info['iterations'].mean()):.1f} iterations",
     }
 
@@ -233,7 +253,7 @@ def main():
         if args.check:
             from oracle import pyoracle
             idx = np.arange(0, B, max(B // 64, 1))
-            fo, _ = pyoracle.solve(pyoracle.default_params(N, 0), rec[idx], threads=os.cpu_count() or 1)
+            fo, _ = pyoracle.solve(pyoracle.default_params(N, 0), rec[idx], threads=usable_cores())
             out["config"]["force_linf_vs_cpu"] = float(np.abs(d_f.cpu().numpy()[idx] - fo).max())
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, N, config_id)
