@@ -488,7 +488,6 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
   RollLoads cur, nxt;
   if (PF_K) roll_load<PF_X>(L, sm, KD, ROT, 0, uj, ql, qa, cur);
   for (int k = 0; k < N; ++k) {
-    double* ub = sm + L.ub + 12 * (k & 1);
     if (!PF_K) roll_load<PF_X>(L, sm, KD, ROT, k, uj, ql, qa, cur);
     if (!PF_X)
 #pragma unroll
@@ -509,6 +508,7 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
       for (int a = 0; a < 3; ++a)
         dx[3 + a] = (G[a] * xc[3] + G[3 + a] * xc[4] + G[6 + a] * xc[5] + G[9 + a] * xc[6]) * isc;
     }
+    double unew;
     {
       // rotated increment of input uj, then u-space increment through T_l
       const double* kd = cur.kd;
@@ -518,17 +518,15 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
       const double p3 = kd[9] * dx[9] + kd[10] * dx[10] + kd[11] * dx[11];
       const double s = (p0 + p1) + (p2 + p3);
       const double s0 = dpp_mov<0x00>(s), s1 = dpp_mov<0x55>(s), s2 = dpp_mov<0xAA>(s);   // quad_perm broadcasts
-      if (ulane) {
-        const double inc = cur.T[0] * s0 + cur.T[1] * s1 + cur.T[2] * s2;
-        sm[L.dU + 12 * k + uj] = inc;                         // the increment, as computed
-        ub[uj] = cur.uo + inc;
-      }
+      const double inc = cur.T[0] * s0 + cur.T[1] * s1 + cur.T[2] * s2;
+      if (ulane) sm[L.dU + 12 * k + uj] = inc;                  // the increment, as computed
+      unew = cur.uo + inc;
     }
-    QSYNC();
     if (PF_K && k + 1 < N) roll_load<PF_X>(L, sm, KD, ROT, k + 1, uj, ql, qa, nxt);   // one knot ahead
+    // broadcast the 12 new inputs from their owner lanes (4l+a) with v_readlane: no LDS round trip
     double un[12];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) un[j] = ub[j];
+    for (int j = 0; j < 12; ++j) un[j] = read_lane(unew, 4 * (j / 3) + (j % 3));
     srbd_step(P, M, xc, un, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) xc[i] = xn[i];
