@@ -29,3 +29,11 @@ print(f"batch {a.batch} N {a.horizon}: mean iterations {it.mean():.2f}; mean cyc
       f"max {tot.max()}; per iteration {np.mean(tot / np.maximum(it, 1)):.0f}")
 for i, n in enumerate(names):
     print(f"  {n:12s} {c[:, i].mean():12.0f} cycles  {100 * c[:, i].sum() / tot.sum():5.1f} %   per-iter {np.mean(c[:, i] / np.maximum(it, 1)):9.0f}")
+
+nc = rec["contacts"].sum(1)
+for k in (2, 4):
+    m = nc == k
+    print(f"stance legs {k}: {m.sum()} instances, cycles/iter {np.mean(tot[m] / it[m]):.0f}, iterations mean {it[m].mean():.2f} max {it[m].max():.0f}, "
+          f"total cycles mean {tot[m].mean():.0f} max {tot[m].max()}")
+top = np.argsort(tot)[-8:]
+print("slowest instances:", [(int(i), int(nc[i]), int(it[i]), int(tot[i])) for i in top])
