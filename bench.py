@@ -16,6 +16,7 @@ from __future__ import annotations
 import argparse
 import importlib.util
 import json
+import re
 import os
 import sys
 import time
@@ -225,7 +226,9 @@ def main():
         # HBM traffic per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
         traffic = None
         try:
-            pm = json.loads((REPO / "profiles" / "r01_v6_pmc_traffic.json").read_text())
+            latest = sorted((REPO / "profiles").glob("r*_pmc_traffic.json"),
+                            key=lambda q: [int(t) for t in re.findall(r"\d+", q.name)])[-1]
+            pm = json.loads(latest.read_text())
             if B == 1024 and N == 10:
                 traffic = pm["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
