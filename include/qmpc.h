@@ -69,6 +69,13 @@ typedef enum qmpc_mode {
   QMPC_MODE_REFERENCE = 1
 } qmpc_mode;
 
+/* ---- which reference controller's inner loop ----------------------------- */
+typedef enum qmpc_model {
+  QMPC_MODEL_QUAT = 0,      /* legged::QuatMpc::grf_update   (QuatMpc.cpp:109-276)   */
+  QMPC_MODEL_CONVEX = 1     /* legged::ConvexMpc::grf_update (ConvexMpc.cpp:81-198):
+                               12-state Euler-angle SRBD, world-frame forces    */
+} qmpc_model;
+
 /* ---- shared, read-only problem parameters -------------------------------- */
 /* Sources: legged_ctrl/config/gazebo_go1_quat_mpc.yaml:36-75,115-122 and
  * LeggedState.h:160-244 (LeggedParam). */
@@ -107,7 +114,8 @@ typedef struct qmpc_params {
   /* parity switches for the reference's quirks */
   int32_t drop_ang_vel;     /* 1: x_init[10:13]=0 (comma-initialiser bug at
                                QuatMpc.cpp:242-245); 0: use ang_vel_body       */
-  int32_t reserved_;
+  int32_t model;            /* qmpc_model: which controller's problem the handle
+                               solves (0 = QuatMpc, 1 = ConvexMpc)              */
 } qmpc_params;
 
 /* Fill *p with the Go1 values of gazebo_go1_quat_mpc.yaml and the solver
@@ -131,6 +139,25 @@ typedef struct qmpc_input {
                                TestAltroTrotQuatMpc.cpp:67-70 be expressed       */
   double quat_d[4];         /* ctrl.torso_quat_d AFTER the :128-137 update       */
 } qmpc_input;
+
+/* ---- one ConvexMpc instance -------------------------
+ * The LeggedState fields legged::ConvexMpc::grf_update reads
+ * (legged_ctrl/src/mpc/ConvexMpc.cpp:81-198), again 48 doubles = 384 B.
+ * State order of that controller: [roll pitch yaw, pos(3), ang_vel_world(3),
+ * lin_vel_world(3)] (ConvexMpc.cpp:156-167); forces are WORLD-frame
+ * (the caller rotates them: optimized_input = R' u, ConvexMpc.cpp:188-190). */
+typedef struct qmpc_convex_input {
+  double euler[3];            /* fbk.torso_euler                 ConvexMpc.cpp:156-158 */
+  double pos_world[3];        /* fbk.torso_pos_world             :159-161             */
+  double ang_vel_world[3];    /* fbk.torso_ang_vel_world         :162-164             */
+  double lin_vel_world[3];    /* fbk.torso_lin_vel_world         :165-167             */
+  double foot_pos_abs_com[12];/* fbk.foot_pos_abs_com, 3x4 col-major :115,118          */
+  double contacts[4];         /* ctrl.plan_contacts as 0.0 / 1.0 :92,107-110          */
+  double pos_d_world[3];      /* ctrl.torso_pos_d_world          :99-101              */
+  double lin_vel_d_world[3];  /* ctrl.torso_lin_vel_d_world (x, y used; vz ref = 0) :105-107 */
+  double yaw_rate_d;          /* ctrl.torso_ang_vel_d_body[2]    :98,104              */
+  double reserved[13];        /* must be finite (0)                                    */
+} qmpc_convex_input;
 
 /* ---- per-instance result ------------------------------------------------- */
 typedef struct qmpc_info {
@@ -183,6 +210,25 @@ qmpc_status qmpc_last_kernel_ms(qmpc_handle* h, float* ms);
 qmpc_status qmpc_linearize(qmpc_handle* h, int32_t batch, const qmpc_input* in,
                            double* Abar, double* Bbar, double* X);
 
+/* ---- ConvexMpc entry points (handle created with params.model = QMPC_MODEL_CONVEX)
+ * Replace ConvexMpc.cpp:84-186 (ALTRO set-up, Solve(), GetInput(0)).
+ * forces_world: [batch][12]; traj_u [batch][N][12], traj_x [batch][N+1][12] may be NULL.
+ * Calling a quaternion entry point on a convex handle (or vice versa) returns
+ * QMPC_BAD_ARGUMENT. */
+void        qmpc_default_convex_params(qmpc_params* p, int32_t horizon, int32_t mode);
+qmpc_status qmpc_convex_solve(qmpc_handle* h, int32_t batch, const qmpc_convex_input* in,
+                              double* forces_world, qmpc_info* info);
+qmpc_status qmpc_convex_solve_traj(qmpc_handle* h, int32_t batch, const qmpc_convex_input* in,
+                                   double* forces_world, qmpc_info* info,
+                                   double* traj_u, double* traj_x);
+qmpc_status qmpc_convex_solve_device(qmpc_handle* h, int32_t batch, const qmpc_convex_input* d_in,
+                                     double* d_forces_world, qmpc_info* d_info, void* stream);
+/* Discrete Jacobians A [batch][N][12][12], B [batch][N][12][12] (row-major, as the
+ * reference's midpoint_jacobian of ct_srb_jacobian produces them, AltroUtils.cpp:78-110,
+ * 297-359) along the rollout X [batch][N+1][12] of U = u_ref.  Host buffers. */
+qmpc_status qmpc_convex_linearize(qmpc_handle* h, int32_t batch, const qmpc_convex_input* in,
+                                  double* A, double* B, double* X);
+
 /* ---- diagnostics ----------------------------------------------------------- */
 /* C = X' * Y on [12][16] row-major tiles through the FP64 MFMA path the solver
  * uses (host buffers of 192 doubles each).  Lets the GPU tests pin the
@@ -203,6 +249,7 @@ const char* qmpc_version(void);
 int32_t     qmpc_sizeof_input(void);   /* ABI guards for foreign-language bindings */
 int32_t     qmpc_sizeof_params(void);
 int32_t     qmpc_sizeof_info(void);
+int32_t     qmpc_sizeof_convex_input(void);
 
 #ifdef __cplusplus
 }

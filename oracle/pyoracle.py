@@ -36,8 +36,8 @@ Params, INPUT_DTYPE, INFO_DTYPE = pkg.Params, pkg.INPUT_DTYPE, pkg.INFO_DTYPE
 
 
 def build(force: bool = False) -> Path:
-    srcs = [ORACLE_DIR / f for f in ("qo_srbd.c", "qo_altro.c", "qo_quatmpc.c", "qo_kat.c",
-                                     "qo_linalg.h", "qo_srbd.h", "qo_altro.h", "qo_quatmpc.h")]
+    srcs = [ORACLE_DIR / f for f in ("qo_srbd.c", "qo_altro.c", "qo_quatmpc.c", "qo_convex.c", "qo_kat.c",
+                                     "qo_linalg.h", "qo_srbd.h", "qo_altro.h", "qo_quatmpc.h", "qo_convex.h")]
     srcs.append(REPO_DIR / "include" / "qmpc.h")
     if force or not LIB_PATH.exists() or any(
             s.exists() and s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs):
@@ -64,6 +64,15 @@ def lib() -> C.CDLL:
         _lib.qo_linearize.argtypes = [C.POINTER(Params), i32, vp, vp, vp, vp]
         _lib.qo_linearize.restype = i32
         _lib.qo_build_reference.argtypes = [C.POINTER(Params), vp, vp, vp]
+        _lib.qo_default_convex_params.argtypes = [C.POINTER(Params), i32, i32]
+        _lib.qo_default_convex_params.restype = None
+        _lib.qo_convex_solve_batch.argtypes = [C.POINTER(Params), i32, vp, vp, vp, vp, vp, i32]
+        _lib.qo_convex_solve_batch.restype = i32
+        _lib.qo_convex_solve_one.argtypes = [C.POINTER(Params), vp, vp, vp, vp, vp, i32]
+        _lib.qo_convex_solve_one.restype = i32
+        _lib.qo_convex_linearize.argtypes = [C.POINTER(Params), i32, vp, vp, vp, vp]
+        _lib.qo_convex_linearize.restype = i32
+        _lib.qo_convex_step.argtypes = [C.POINTER(Params), vp, vp, vp, vp]
         _lib.qo_kat_double_integrator.argtypes = [i32, dp, i32]
         _lib.qo_kat_double_integrator.restype = i32
         _lib.qo_kat_pendulum_midpoint.argtypes = [dp, dp]
@@ -109,6 +118,51 @@ def linearize(params: Params, inputs: np.ndarray):
     A = np.zeros((B, N, 12, 12)); Bm = np.zeros((B, N, 12, 12)); X = np.zeros((B, N + 1, 13))
     lib().qo_linearize(C.byref(params), B, _ptr(inputs), _ptr(A), _ptr(Bm), _ptr(X))
     return A, Bm, X
+
+
+# ---- ConvexMpc model -----------------------------------
+def default_convex_params(horizon: int = 20, mode: int = 0) -> Params:
+    p = Params()
+    lib().qo_default_convex_params(C.byref(p), horizon, mode)
+    return p
+
+
+def convex_solve(params: Params, inputs: np.ndarray, threads: int = 1, want_traj: bool = False):
+    inputs = np.ascontiguousarray(inputs, dtype=pkg.CONVEX_INPUT_DTYPE)
+    B, N = inputs.shape[0], params.horizon
+    forces = np.zeros((B, 12))
+    info = np.zeros(B, dtype=INFO_DTYPE)
+    tu = np.zeros((B, N, 12)) if want_traj else None
+    tx = np.zeros((B, N + 1, 12)) if want_traj else None
+    lib().qo_convex_solve_batch(C.byref(params), B, _ptr(inputs), _ptr(forces), _ptr(info), _ptr(tu), _ptr(tx), threads)
+    if want_traj:
+        return forces, info, tu, tx
+    return forces, info
+
+
+def convex_solve_verbose(params: Params, inp: np.ndarray):
+    inp = np.ascontiguousarray(inp, dtype=pkg.CONVEX_INPUT_DTYPE)
+    f = np.zeros(12)
+    info = np.zeros(1, dtype=INFO_DTYPE)
+    lib().qo_convex_solve_one(C.byref(params), _ptr(inp), _ptr(f), _ptr(info), None, None, 1)
+    return f, info
+
+
+def convex_linearize(params: Params, inputs: np.ndarray):
+    inputs = np.ascontiguousarray(inputs, dtype=pkg.CONVEX_INPUT_DTYPE)
+    B, N = inputs.shape[0], params.horizon
+    A = np.zeros((B, N, 12, 12)); Bm = np.zeros((B, N, 12, 12)); X = np.zeros((B, N + 1, 12))
+    lib().qo_convex_linearize(C.byref(params), B, _ptr(inputs), _ptr(A), _ptr(Bm), _ptr(X))
+    return A, Bm, X
+
+
+def convex_step(params: Params, inp: np.ndarray, x: np.ndarray, u: np.ndarray) -> np.ndarray:
+    """One explicit-midpoint step of the ConvexMpc model (for finite-difference checks)."""
+    inp = np.ascontiguousarray(inp, dtype=pkg.CONVEX_INPUT_DTYPE)
+    x = np.ascontiguousarray(x, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+    xn = np.zeros(12)
+    lib().qo_convex_step(C.byref(params), _ptr(inp), _ptr(x), _ptr(u), _ptr(xn))
+    return xn
 
 
 def kat_double_integrator(which: int, verbose: int = 0):

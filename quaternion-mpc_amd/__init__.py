@@ -28,6 +28,7 @@ NX, NE, NU, NLEG, NC = 13, 12, 12, 4, 24
 OK, MAX_ITER, NO_CONTACT, NAN_INPUT, LINESEARCH_FAIL, NOT_PD = 0, 1, 2, 3, 4, 5
 BAD_ARGUMENT, NO_DEVICE, HIP_ERROR, BATCH_TOO_LARGE = 16, 17, 18, 19
 MODE_CONVERGED, MODE_REFERENCE = 0, 1
+MODEL_QUAT, MODEL_CONVEX = 0, 1
 
 
 class Params(C.Structure):
@@ -60,7 +61,7 @@ class Params(C.Structure):
         ("ipm_tau", C.c_double),
         ("linesearch_max", C.c_int32),
         ("drop_ang_vel", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("model", C.c_int32),
     ]
 
     def copy(self) -> "Params":
@@ -86,6 +87,24 @@ INPUT_DTYPE = np.dtype(
     align=False,
 )
 assert INPUT_DTYPE.itemsize == 48 * 8
+
+# struct qmpc_convex_input (ConvexMpc.cpp:81-198): 48 doubles, 384 B
+CONVEX_INPUT_DTYPE = np.dtype(
+    [
+        ("euler", "<f8", (3,)),
+        ("pos_world", "<f8", (3,)),
+        ("ang_vel_world", "<f8", (3,)),
+        ("lin_vel_world", "<f8", (3,)),
+        ("foot_pos_abs_com", "<f8", (12,)),
+        ("contacts", "<f8", (4,)),
+        ("pos_d_world", "<f8", (3,)),
+        ("lin_vel_d_world", "<f8", (3,)),
+        ("yaw_rate_d", "<f8"),
+        ("reserved", "<f8", (13,)),
+    ],
+    align=False,
+)
+assert CONVEX_INPUT_DTYPE.itemsize == 48 * 8
 
 # struct qmpc_info: 2 x int32 + 4 doubles = 40 B
 INFO_DTYPE = np.dtype(
@@ -162,11 +181,23 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.qmpc_status_string.restype = C.c_char_p
     lib.qmpc_version.argtypes = []
     lib.qmpc_version.restype = C.c_char_p
-    for name in ("qmpc_sizeof_input", "qmpc_sizeof_params", "qmpc_sizeof_info"):
+    lib.qmpc_default_convex_params.argtypes = [C.POINTER(Params), i32, i32]
+    lib.qmpc_default_convex_params.restype = None
+    lib.qmpc_convex_solve.argtypes = [vp, i32, vp, vp, vp]
+    lib.qmpc_convex_solve.restype = i32
+    lib.qmpc_convex_solve_traj.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    lib.qmpc_convex_solve_traj.restype = i32
+    lib.qmpc_convex_solve_device.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.qmpc_convex_solve_device.restype = i32
+    lib.qmpc_convex_linearize.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.qmpc_convex_linearize.restype = i32
+    for name in ("qmpc_sizeof_input", "qmpc_sizeof_params", "qmpc_sizeof_info", "qmpc_sizeof_convex_input"):
         getattr(lib, name).argtypes = []
         getattr(lib, name).restype = i32
     if lib.qmpc_sizeof_input() != INPUT_DTYPE.itemsize:
         raise RuntimeError("qmpc_input ABI size mismatch")
+    if lib.qmpc_sizeof_convex_input() != CONVEX_INPUT_DTYPE.itemsize:
+        raise RuntimeError("qmpc_convex_input ABI size mismatch")
     if lib.qmpc_sizeof_params() != C.sizeof(Params):
         raise RuntimeError("qmpc_params ABI size mismatch")
     if lib.qmpc_sizeof_info() != INFO_DTYPE.itemsize:
@@ -193,6 +224,12 @@ EXPORTED_SYMBOLS = (
     "qmpc_sizeof_input",
     "qmpc_sizeof_params",
     "qmpc_sizeof_info",
+    "qmpc_default_convex_params",
+    "qmpc_convex_solve",
+    "qmpc_convex_solve_traj",
+    "qmpc_convex_solve_device",
+    "qmpc_convex_linearize",
+    "qmpc_sizeof_convex_input",
 )
 
 
@@ -200,6 +237,14 @@ def default_params(horizon: int = 10, mode: int = MODE_CONVERGED, lib: C.CDLL | 
     lib = lib or load_library()
     p = Params()
     lib.qmpc_default_params(C.byref(p), horizon, mode)
+    return p
+
+
+def default_convex_params(horizon: int = 20, mode: int = MODE_CONVERGED, lib: C.CDLL | None = None) -> Params:
+    """ConvexMpc values of gazebo_go1_convex_mpc.yaml (params.model = MODEL_CONVEX)."""
+    lib = lib or load_library()
+    p = Params()
+    lib.qmpc_default_convex_params(C.byref(p), horizon, mode)
     return p
 
 
@@ -267,6 +312,43 @@ class Solver:
             raise QmpcError(st, "qmpc_last_kernel_ms")
         return float(ms.value)
 
+    # ---- ConvexMpc model (handle created with params.model = MODEL_CONVEX) ----
+    def convex_solve(self, inputs: np.ndarray, want_traj: bool = False):
+        """World-frame forces of legged::ConvexMpc::grf_update's problem, host buffers."""
+        inputs = np.ascontiguousarray(inputs, dtype=CONVEX_INPUT_DTYPE)
+        B, N = inputs.shape[0], self.params.horizon
+        forces = np.zeros((B, NU), dtype=np.float64)
+        info = np.zeros(B, dtype=INFO_DTYPE)
+        if want_traj:
+            tu = np.zeros((B, N, NU))
+            tx = np.zeros((B, N + 1, 12))
+            st = self.lib.qmpc_convex_solve_traj(self._h, B, _ptr(inputs), _ptr(forces), _ptr(info), _ptr(tu), _ptr(tx))
+            if st != OK:
+                raise QmpcError(st, "qmpc_convex_solve_traj")
+            return forces, info, tu, tx
+        st = self.lib.qmpc_convex_solve(self._h, B, _ptr(inputs), _ptr(forces), _ptr(info))
+        if st != OK:
+            raise QmpcError(st, "qmpc_convex_solve")
+        return forces, info
+
+    def convex_solve_device(self, batch: int, d_in: int, d_forces: int, d_info: int, stream: int = 0):
+        st = self.lib.qmpc_convex_solve_device(self._h, int(batch), C.c_void_p(d_in), C.c_void_p(d_forces),
+                                               C.c_void_p(d_info) if d_info else None,
+                                               C.c_void_p(stream) if stream else None)
+        if st != OK:
+            raise QmpcError(st, "qmpc_convex_solve_device")
+
+    def convex_linearize(self, inputs: np.ndarray):
+        inputs = np.ascontiguousarray(inputs, dtype=CONVEX_INPUT_DTYPE)
+        B, N = inputs.shape[0], self.params.horizon
+        A = np.zeros((B, N, 12, 12))
+        Bm = np.zeros((B, N, 12, 12))
+        X = np.zeros((B, N + 1, 12))
+        st = self.lib.qmpc_convex_linearize(self._h, B, _ptr(inputs), _ptr(A), _ptr(Bm), _ptr(X))
+        if st != OK:
+            raise QmpcError(st, "qmpc_convex_linearize")
+        return A, Bm, X
+
     def phase_profile(self, inputs: np.ndarray) -> np.ndarray:
         inputs = np.ascontiguousarray(inputs, dtype=INPUT_DTYPE)
         out = np.zeros((inputs.shape[0], 16), dtype=np.int64)
@@ -287,5 +369,6 @@ class Solver:
         return A, Bm, X
 
 
-from .scenarios import go1_stand_input, quat_to_rot, random_go1_trot_states  # noqa: E402,F401
+from .scenarios import (go1_stand_input, quat_to_rot, random_go1_trot_states,  # noqa: E402,F401
+                        random_go1_convex_states)
 from .sharding import gather_forces, shard_range, solve_sharded  # noqa: E402,F401

@@ -435,4 +435,385 @@ __device__ __forceinline__ double bbar_elem(const DevParams& P, const double* cs
   return P.h * bw0[12 * (r - 9) + col];
 }
 
+
+// =============================================================================
+// Model policies.  The solver core (Riccati backward pass in MFMA fragments,
+// stage solve, rollouts, interior-point bookkeeping) is shared; a policy supplies
+// what differs between the reference's two controllers:
+//   QuatModel   -- legged::QuatMpc   (QuatMpc.cpp:109-276, quaternion SRBD, error state)
+//   ConvexModel -- legged::ConvexMpc (ConvexMpc.cpp:81-198, Euler-angle SRBD)
+// Both keep a 13-double state slot per knot in LDS (the convex model uses 12).
+// =============================================================================
+
+// per-lane cost-Hessian pattern of the backward pass: Qxx[e] += qadd[e] + XT[xoff[e]]
+struct CostPattern {
+  double qadd[3];
+  int xoff[3];
+};
+
+struct QuatModel {
+  static constexpr int NX = 13;
+  typedef ModelRegs Regs;
+
+  static __device__ __forceinline__ void step(const DevParams& P, const Regs& M, const double* x,
+                                              const double* u, double* xn) {
+    srbd_step(P, M, x, u, xn);
+  }
+  // dx = xc (-) xo : inverse Cayley map of xo.q^-1 * xc.q (QuaternionUtils.cpp:16-18)
+  static __device__ __forceinline__ void state_diff(const double* xo, const double* xc, double* dx) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      dx[a] = xc[a] - xo[a];
+      dx[6 + a] = xc[7 + a] - xo[7 + a];
+      dx[9 + a] = xc[10 + a] - xo[10 + a];
+    }
+    double G[12];
+    quat_G(&xo[3], G);
+    const double isc = fast_rcp(xo[3] * xc[3] + xo[4] * xc[4] + xo[5] * xc[5] + xo[6] * xc[6]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      dx[3 + a] = (G[a] * xc[3] + G[3 + a] * xc[4] + G[6 + a] * xc[5] + G[9 + a] * xc[6]) * isc;
+  }
+  static __device__ __forceinline__ void expand(const DevParams& P, const double* cst, const double* bw0,
+                                                const double* refp, int k, const double* x, const double* u,
+                                                const double* xn, double* AB, double* lx, double* lxx) {
+    expand_knot(P, cst, bw0, refp, k, x, u, xn, AB, lx, lxx);
+  }
+  // un-augmented objective of knot k (u == nullptr at the terminal knot)
+  static __device__ __forceinline__ double knot_cost(const DevParams& P, const double* refp, const double* uref,
+                                                     int k, const double* x, const double* u) {
+    double xr[13];
+    xref_at(P, refp, k, xr);
+    double J = 0.0;
+    for (int i = 0; i < 13; ++i) { const double e = x[i] - xr[i]; J += 0.5 * P.Q[i] * e * e; }
+    const double dq = xr[3] * x[3] + xr[4] * x[4] + xr[5] * x[5] + xr[6] * x[6];
+    J += P.w * (1.0 - fabs(dq));
+    if (u)
+      for (int j = 0; j < 12; ++j) { const double e = u[j] - uref[j]; J += 0.5 * P.R[j] * e * e; }
+    return J;
+  }
+
+  // operand patterns of the backward pass for fragment rows r_e = 4e + g, column c
+  struct Operands {
+    double Ac[3], Bc[3][3], hbw[3][3];
+    int aoff[3];
+    bool phi[3];
+    int g;
+    __device__ __forceinline__ void init(const DevParams& P, const double* cst, const double* bw0, int lane,
+                                         CostPattern& cp) {
+      const int c = lane & 15;
+      g = lane >> 4;
+      const bool cval = c < 12;
+      const int lc = cval ? c / 3 : 0;
+      const double conl = cval ? cst[C_CON + lc] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) hbw[j][a] = cval ? P.h * bw0[12 * j + 3 * lc + a] : 0.0;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int r = 4 * e + g;
+        phi[e] = (r >= 3 && r < 6);
+        Ac[e] = cval ? ((((r == c) && !phi[e]) ? 1.0 : 0.0) + ((r < 3 && c == r + 6) ? P.h : 0.0)) : 0.0;
+        aoff[e] = -1;
+        if (phi[e] && c >= 3 && c < 6) aoff[e] = 3 * (r - 3) + (c - 3);
+        if (phi[e] && c >= 9 && c < 12) aoff[e] = 9 + 3 * (r - 3) + (c - 9);
+        cp.qadd[e] = (cval && r == c && !phi[e]) ? P.Q[(r < 3) ? r : r + 1] : 0.0;
+        cp.xoff[e] = -1;
+        if (phi[e] && c >= 3 && c < 6) cp.xoff[e] = 3 * (r - 3) + (c - 3);
+        if (c == 12) cp.xoff[e] = 9 + r;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          double v = 0.0;
+          if (cval) {
+            if (r < 3) v = (r == a) ? conl * (P.h * (P.hh * (1.0 / P.mass))) : 0.0;
+            else if (r >= 6 && r < 9) v = (r - 6 == a) ? conl * (P.h * (1.0 / P.mass)) : 0.0;
+            else if (r >= 9) v = P.h * bw0[12 * (r - 9) + 3 * lc + a];
+          }
+          Bc[e][a] = v;
+        }
+      }
+    }
+    // Abar and rotated Bbar*T (t = column bc of the leg's frame T) straight into fragments
+    __device__ __forceinline__ void build(const DevParams& P, const double* ABk, double t0, double t1, double t2,
+                                          double Afo[3], double Bfo[3]) const {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        Afo[e] = (aoff[e] >= 0) ? ABk[aoff[e]] : Ac[e];
+        double b0 = Bc[e][0], b1 = Bc[e][1], b2 = Bc[e][2];
+        if (phi[e]) {
+          const double* W = ABk + 18 + 3 * (4 * e + g - 3);
+          const double w0 = W[0], w1 = W[1], w2 = W[2];
+          b0 = (0.5 * P.hh) * (w0 * hbw[0][0] + w1 * hbw[1][0] + w2 * hbw[2][0]);
+          b1 = (0.5 * P.hh) * (w0 * hbw[0][1] + w1 * hbw[1][1] + w2 * hbw[2][1]);
+          b2 = (0.5 * P.hh) * (w0 * hbw[0][2] + w1 * hbw[1][2] + w2 * hbw[2][2]);
+        }
+        Bfo[e] = b0 * t0 + b1 * t1 + b2 * t2;
+      }
+    }
+  };
+
+  static __device__ __forceinline__ double a_elem(const DevParams& P, const double* cst, const double* bw0,
+                                                  const double* AB, int r, int c) {
+    return abar_elem(P, AB, r, c);
+  }
+  static __device__ __forceinline__ double b_elem(const DevParams& P, const double* cst, const double* bw0,
+                                                  const double* AB, int r, int c) {
+    return bbar_elem(P, cst, bw0, AB, r, c);
+  }
+};
+
+// ---- legged::ConvexMpc's model ------------------------------------------------
+// state x = [roll pitch yaw, pos(3), ang_vel_world(3), lin_vel_world(3)], inputs =
+// world-frame foot forces.  Continuous dynamics (AltroUtils.cpp:224-293):
+//   d(rpy) = Rz(yaw)' w,  d(pos) = v,  d(w) = Iw(yaw)^-1 sum_l r_l x u_l,  d(v) = sum u_l/m + g
+// with Iw(yaw)^-1 = Rz diag(1/I) Rz'.  Its Jacobian (AltroUtils.cpp:295-359) omits
+// d(Iw^-1)/d(yaw); the midpoint chain rule (AltroUtils.cpp:78-110) then gives
+//   A = I + h Am + (h h/2) jm e8',   B = h ((h/2) Am B0 + Bm)
+// whose only state-dependent entries are the per-knot record CV_* below.
+enum { CV_JM0 = 0, CV_JM1, CV_CM, CV_SM, CV_M00, CV_M01, CV_M10, CV_M11, CV_W00, CV_W01, CV_W11, CV_COUNT };
+// reference record refp[]: yaw0, yaw_rate_d, pos_d(3), vx_d, vy_d
+enum { CR_YAW = 0, CR_RATE, CR_POS, CR_VX = 5, CR_VY = 6 };
+
+struct ConvexRegs {
+  double con[4], sk[36];      // contacts; masked skew rows: tau[a] = sum_j sk[12a+j] u[j]
+  __device__ __forceinline__ void load(const double* cst, const double* bw0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) con[i] = cst[C_CON + i];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) sk[i] = bw0[i];
+  }
+};
+
+struct ConvexModel {
+  static constexpr int NX = 12;
+  typedef ConvexRegs Regs;
+
+  // Iw(yaw)^-1 tau with c = cos(yaw), s = sin(yaw)
+  static __device__ __forceinline__ void winv(const DevParams& P, double c, double s, double& w00, double& w01,
+                                              double& w11) {
+    const double a = P.Iinv[0], b = P.Iinv[4];
+    w00 = c * c * a + s * s * b;
+    w01 = c * s * (a - b);
+    w11 = s * s * a + c * c * b;
+  }
+  static __device__ __forceinline__ void torque_force(const Regs& M, const double* u, double* tau, double* F) {
+    F[0] = F[1] = F[2] = 0.0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const double c = M.con[l];
+      F[0] += c * u[3 * l]; F[1] += c * u[3 * l + 1]; F[2] += c * u[3 * l + 2];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double* b = &M.sk[12 * a];
+      const double s0 = b[0] * u[0] + b[1] * u[1] + b[2] * u[2];
+      const double s1 = b[3] * u[3] + b[4] * u[4] + b[5] * u[5];
+      const double s2 = b[6] * u[6] + b[7] * u[7] + b[8] * u[8];
+      const double s3 = b[9] * u[9] + b[10] * u[10] + b[11] * u[11];
+      tau[a] = (s0 + s1) + (s2 + s3);
+    }
+  }
+  // explicit midpoint (AltroUtils.cpp:9-22) of ct_srb_dynamics
+  static __device__ __forceinline__ void step(const DevParams& P, const Regs& M, const double* x,
+                                              const double* u, double* xn) {
+    double tau[3], F[3];
+    torque_force(M, u, tau, F);
+    double s0, c0;
+    sincos(x[2], &s0, &c0);
+    double w00, w01, w11;
+    winv(P, c0, s0, w00, w01, w11);
+    const double vd[3] = {F[0] * P.inv_mass, F[1] * P.inv_mass, F[2] * P.inv_mass - 9.81};
+    const double wd0[3] = {w00 * tau[0] + w01 * tau[1], w01 * tau[0] + w11 * tau[1], P.Iinv[8] * tau[2]};
+    const double yawm = x[2] + P.hh * x[8];
+    const double wm[3] = {x[6] + P.hh * wd0[0], x[7] + P.hh * wd0[1], x[8] + P.hh * wd0[2]};
+    double sm_, cm_;
+    sincos(yawm, &sm_, &cm_);
+    winv(P, cm_, sm_, w00, w01, w11);
+    const double wdm[3] = {w00 * tau[0] + w01 * tau[1], w01 * tau[0] + w11 * tau[1], P.Iinv[8] * tau[2]};
+    xn[0] = x[0] + P.h * (cm_ * wm[0] + sm_ * wm[1]);
+    xn[1] = x[1] + P.h * (-sm_ * wm[0] + cm_ * wm[1]);
+    xn[2] = x[2] + P.h * wm[2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      xn[3 + a] = x[3 + a] + P.h * (x[9 + a] + P.hh * vd[a]);
+      xn[6 + a] = x[6 + a] + P.h * wdm[a];
+      xn[9 + a] = x[9 + a] + P.h * vd[a];
+    }
+    xn[12] = 0.0;
+  }
+  static __device__ __forceinline__ void state_diff(const double* xo, const double* xc, double* dx) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) dx[i] = xc[i] - xo[i];
+  }
+  // reference state of knot k (ConvexMpc.cpp:95-106)
+  static __device__ __forceinline__ void xref(const DevParams& P, const double* refp, int k, double* xr) {
+    const double h_ms = P.h_ref * 1000.0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) xr[i] = 0.0;
+    xr[2] = refp[CR_YAW] + refp[CR_RATE] * h_ms / 1000.0 * k;
+    xr[3] = refp[CR_POS]; xr[4] = refp[CR_POS + 1]; xr[5] = refp[CR_POS + 2];
+    xr[8] = refp[CR_RATE];
+    xr[9] = refp[CR_VX]; xr[10] = refp[CR_VY];
+  }
+  static __device__ inline void expand(const DevParams& P, const double* cst, const double* bw0,
+                                       const double* refp, int k, const double* x, const double* u,
+                                       const double* xn, double* AB, double* lx, double* lxx) {
+    if (k < P.N) {
+      double tau[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        double s = 0.0;
+        for (int j = 0; j < 12; ++j) s += bw0[12 * a + j] * u[j];
+        tau[a] = s;
+      }
+      double s0, c0;
+      sincos(x[2], &s0, &c0);
+      double w00, w01, w11;
+      winv(P, c0, s0, w00, w01, w11);
+      const double wm0 = x[6] + P.hh * (w00 * tau[0] + w01 * tau[1]);
+      const double wm1 = x[7] + P.hh * (w01 * tau[0] + w11 * tau[1]);
+      double sm_, cm_;
+      sincos(x[2] + P.hh * x[8], &sm_, &cm_);
+      AB[CV_JM0] = wm1 * cm_ - wm0 * sm_;       // AltroUtils.cpp:354 at the midpoint
+      AB[CV_JM1] = -wm0 * cm_ - wm1 * sm_;      // :355
+      AB[CV_CM] = cm_;
+      AB[CV_SM] = sm_;
+      // M1 = Rz(yaw_m)' Iw(yaw)^-1  (upper-left 2x2; the rest is (0,0,1/Izz))
+      AB[CV_M00] = cm_ * w00 + sm_ * w01;
+      AB[CV_M01] = cm_ * w01 + sm_ * w11;
+      AB[CV_M10] = -sm_ * w00 + cm_ * w01;
+      AB[CV_M11] = -sm_ * w01 + cm_ * w11;
+      winv(P, cm_, sm_, w00, w01, w11);
+      AB[CV_W00] = w00; AB[CV_W01] = w01; AB[CV_W11] = w11;
+#pragma unroll
+      for (int i = CV_COUNT; i < kAB; ++i) AB[i] = 0.0;
+    }
+    double xr[12];
+    xref(P, refp, k, xr);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) lx[i] = P.Q[i] * (x[i] - xr[i]);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) lxx[i] = 0.0;
+  }
+  static __device__ __forceinline__ double knot_cost(const DevParams& P, const double* refp, const double* uref,
+                                                     int k, const double* x, const double* u) {
+    double xr[12];
+    xref(P, refp, k, xr);
+    double J = 0.0;
+    for (int i = 0; i < 12; ++i) { const double e = x[i] - xr[i]; J += 0.5 * P.Q[i] * e * e; }
+    if (u)
+      for (int j = 0; j < 12; ++j) { const double e = u[j] - uref[j]; J += 0.5 * P.R[j] * e * e; }
+    return J;
+  }
+
+  // entries of A that vary per knot: (row, col, record slot, scale)
+  struct Operands {
+    double Ac[3], asc[3], Bc[3][3], sk[3][3];
+    double m0s[3], m1s[3], mz[3];      // row of the 3x3 factor: m0s*AB[mo0] , m1s*AB[mo1], mz
+    int aoff[3], mo0[3], mo1[3];
+    bool var[3];
+    __device__ __forceinline__ void init(const DevParams& P, const double* cst, const double* bw0, int lane,
+                                         CostPattern& cp) {
+      const int c = lane & 15, g = lane >> 4;
+      const bool cval = c < 12;
+      const int lc = cval ? c / 3 : 0;
+      const double conl = cval ? cst[C_CON + lc] : 0.0;
+      const double hhh = P.h * P.hh;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) sk[j][a] = cval ? bw0[12 * j + 3 * lc + a] : 0.0;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int r = 4 * e + g;
+        double ac = 0.0;
+        if (cval) {
+          if (r == c) ac = 1.0;
+          if (r >= 3 && r < 6 && c == r + 6) ac = P.h;
+          if (r == 2 && c == 8) ac = P.h;
+        }
+        Ac[e] = ac;
+        aoff[e] = -1; asc[e] = 0.0;
+        if (r == 0 && c == 2) { aoff[e] = CV_JM0; asc[e] = P.h; }
+        if (r == 1 && c == 2) { aoff[e] = CV_JM1; asc[e] = P.h; }
+        if (r == 0 && c == 6) { aoff[e] = CV_CM; asc[e] = P.h; }
+        if (r == 0 && c == 7) { aoff[e] = CV_SM; asc[e] = P.h; }
+        if (r == 1 && c == 6) { aoff[e] = CV_SM; asc[e] = -P.h; }
+        if (r == 1 && c == 7) { aoff[e] = CV_CM; asc[e] = P.h; }
+        if (r == 0 && c == 8) { aoff[e] = CV_JM0; asc[e] = hhh; }
+        if (r == 1 && c == 8) { aoff[e] = CV_JM1; asc[e] = hhh; }
+        cp.qadd[e] = (cval && r == c) ? P.Q[r] : 0.0;
+        cp.xoff[e] = (c == 12) ? 9 + r : -1;
+        // B rows: 0..2 = h h/2 (Rz_m' Iw0^-1) S, 3..5 = h h/2 con/m, 6..8 = h Iw_m^-1 S, 9..11 = h con/m
+        var[e] = cval && (r < 3 || (r >= 6 && r < 9));
+        mo0[e] = 0; mo1[e] = 0; m0s[e] = 0.0; m1s[e] = 0.0; mz[e] = 0.0;
+        if (r == 0) { mo0[e] = CV_M00; mo1[e] = CV_M01; m0s[e] = hhh; m1s[e] = hhh; }
+        if (r == 1) { mo0[e] = CV_M10; mo1[e] = CV_M11; m0s[e] = hhh; m1s[e] = hhh; }
+        if (r == 2) mz[e] = hhh * P.Iinv[8];
+        if (r == 6) { mo0[e] = CV_W00; mo1[e] = CV_W01; m0s[e] = P.h; m1s[e] = P.h; }
+        if (r == 7) { mo0[e] = CV_W01; mo1[e] = CV_W11; m0s[e] = P.h; m1s[e] = P.h; }
+        if (r == 8) mz[e] = P.h * P.Iinv[8];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          double v = 0.0;
+          if (cval) {
+            if (r >= 3 && r < 6) v = (r - 3 == a) ? conl * (hhh * (1.0 / P.mass)) : 0.0;
+            else if (r >= 9) v = (r - 9 == a) ? conl * (P.h * (1.0 / P.mass)) : 0.0;
+          }
+          Bc[e][a] = v;
+        }
+      }
+    }
+    __device__ __forceinline__ void build(const DevParams& P, const double* ABk, double t0, double t1, double t2,
+                                          double Afo[3], double Bfo[3]) const {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        Afo[e] = (aoff[e] >= 0) ? asc[e] * ABk[aoff[e]] : Ac[e];
+        double b0 = Bc[e][0], b1 = Bc[e][1], b2 = Bc[e][2];
+        if (var[e]) {
+          const double m0 = m0s[e] * ABk[mo0[e]], m1 = m1s[e] * ABk[mo1[e]], m2 = mz[e];
+          b0 = m0 * sk[0][0] + m1 * sk[1][0] + m2 * sk[2][0];
+          b1 = m0 * sk[0][1] + m1 * sk[1][1] + m2 * sk[2][1];
+          b2 = m0 * sk[0][2] + m1 * sk[1][2] + m2 * sk[2][2];
+        }
+        Bfo[e] = b0 * t0 + b1 * t1 + b2 * t2;
+      }
+    }
+  };
+
+  // dense discrete Jacobians (qmpc_convex_linearize)
+  static __device__ __forceinline__ double a_elem(const DevParams& P, const double* cst, const double* bw0,
+                                                  const double* AB, int r, int c) {
+    const double hhh = P.h * P.hh;
+    double v = (r == c) ? 1.0 : 0.0;
+    if (r >= 3 && r < 6 && c == r + 6) v = P.h;
+    if (r == 2 && c == 8) v = P.h;
+    if (r == 0 && c == 2) v = P.h * AB[CV_JM0];
+    if (r == 1 && c == 2) v = P.h * AB[CV_JM1];
+    if (r == 0 && c == 6) v = P.h * AB[CV_CM];
+    if (r == 0 && c == 7) v = P.h * AB[CV_SM];
+    if (r == 1 && c == 6) v = -P.h * AB[CV_SM];
+    if (r == 1 && c == 7) v = P.h * AB[CV_CM];
+    if (r == 0 && c == 8) v = hhh * AB[CV_JM0];
+    if (r == 1 && c == 8) v = hhh * AB[CV_JM1];
+    return v;
+  }
+  static __device__ __forceinline__ double b_elem(const DevParams& P, const double* cst, const double* bw0,
+                                                  const double* AB, int r, int col) {
+    const int l = col / 3, a = col - 3 * l;
+    const double hhh = P.h * P.hh;
+    const double cl = cst[C_CON + l];
+    const double s0 = bw0[col], s1 = bw0[12 + col], s2 = bw0[24 + col];
+    if (r == 0) return hhh * AB[CV_M00] * s0 + hhh * AB[CV_M01] * s1;
+    if (r == 1) return hhh * AB[CV_M10] * s0 + hhh * AB[CV_M11] * s1;
+    if (r == 2) return hhh * P.Iinv[8] * s2;
+    if (r < 6) return (r - 3 == a) ? cl * (hhh * (1.0 / P.mass)) : 0.0;
+    if (r == 6) return P.h * AB[CV_W00] * s0 + P.h * AB[CV_W01] * s1;
+    if (r == 7) return P.h * AB[CV_W01] * s0 + P.h * AB[CV_W11] * s1;
+    if (r == 8) return P.h * P.Iinv[8] * s2;
+    return (r - 9 == a) ? cl * (P.h * (1.0 / P.mass)) : 0.0;
+  }
+};
+
 }  // namespace qmpc

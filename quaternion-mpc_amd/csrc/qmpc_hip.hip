@@ -1,9 +1,11 @@
 // qmpc_hip.hip -- C ABI (include/qmpc.h) over the gfx950 kernels.
 //
 // Drop-in boundary: replaces the ALTRO set-up / Solve() / GetInput(0) block of
-// legged::QuatMpc::grf_update (legged_ctrl/src/mpc/QuatMpc.cpp:217-265) for a
-// batch of independent LeggedState records.  No CPU fallback exists here: with
-// no HIP device every entry point returns QMPC_NO_DEVICE.
+// legged::QuatMpc::grf_update (legged_ctrl/src/mpc/QuatMpc.cpp:217-265) -- and, for
+// handles created with params.model = QMPC_MODEL_CONVEX, of legged::ConvexMpc::grf_update
+// (legged_ctrl/src/mpc/ConvexMpc.cpp:84-186) -- for a batch of independent LeggedState
+// records.  No CPU fallback exists here: with no HIP device every entry point returns
+// QMPC_NO_DEVICE.
 #include "qmpc_kernels.hip"
 
 #include <cmath>
@@ -50,6 +52,8 @@ const char* qmpc_version(void) { return "qmpc-hip 0.1 (gfx950, wave-per-instance
 int32_t qmpc_sizeof_input(void) { return (int32_t)sizeof(qmpc_input); }
 int32_t qmpc_sizeof_params(void) { return (int32_t)sizeof(qmpc_params); }
 int32_t qmpc_sizeof_info(void) { return (int32_t)sizeof(qmpc_info); }
+int32_t qmpc_sizeof_convex_input(void) { return (int32_t)sizeof(qmpc_convex_input); }
+static_assert(sizeof(qmpc_convex_input) == sizeof(qmpc_input), "both records are 48 doubles");
 
 const char* qmpc_status_string(int32_t s) {
   switch (s) {
@@ -106,9 +110,28 @@ void qmpc_default_params(qmpc_params* p, int32_t horizon, int32_t mode) {
   }
 }
 
+// legged_ctrl/config/gazebo_go1_convex_mpc.yaml:35-73; AltroUtils.cpp:239,270-272 (the model's
+// hard-coded mass and un-scaled trunk inertia); ConvexMpc.cpp:36-38
+void qmpc_default_convex_params(qmpc_params* p, int32_t horizon, int32_t mode) {
+  qmpc_default_params(p, horizon, mode);
+  p->model = QMPC_MODEL_CONVEX;
+  p->h = (float)(5.0 / 1000.0);
+  p->h_ref = 5.0 / 1000.0;
+  const double trunk[3] = {0.0168128557, 0.063009565, 0.0716547275};
+  for (int a = 0; a < 3; ++a) p->inertia[4 * a] = trunk[a];
+  const double q[13] = {3.0, 3.0, 3.0, 1.0, 1.0, 20.0, 0.0, 0.0, 3.0, 2.0, 3.0, 2.0, 0.0};
+  std::memcpy(p->q_weights, q, sizeof q);
+  p->w = 0.0;
+  p->mu = 0.6;
+  p->fz_max = 200.0;
+  p->drop_ang_vel = 0;
+  if (mode == QMPC_MODE_REFERENCE) p->iterations_max = 5;   // ConvexMpc.cpp:37
+}
+
 static int fill_dev_params(const qmpc_params* p, DevParams* d) {
   if (!p || p->horizon < 1 || p->horizon > QMPC_MAX_HORIZON) return QMPC_BAD_ARGUMENT;
   if (p->mode != QMPC_MODE_CONVERGED) return QMPC_BAD_ARGUMENT;  // device path: converged mode
+  if (p->model != QMPC_MODEL_QUAT && p->model != QMPC_MODEL_CONVEX) return QMPC_BAD_ARGUMENT;
   if (!(p->mass > 0.0) || !(p->h > 0.0f) || !(p->ipm_mu0 > 0.0)) return QMPC_BAD_ARGUMENT;
   std::memset(d, 0, sizeof *d);
   d->N = p->horizon;
@@ -151,6 +174,7 @@ qmpc_status qmpc_set_params(qmpc_handle* h, const qmpc_params* params) {
   const int st = fill_dev_params(params, &d);
   if (st != QMPC_OK) return (qmpc_status)st;
   if (params->horizon != h->params.horizon) return QMPC_BAD_ARGUMENT;  // buffers are sized by N
+  if (params->model != h->params.model) return QMPC_BAD_ARGUMENT;
   h->params = *params;
   h->dev = d;
   return QMPC_OK;
@@ -191,19 +215,23 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
   HIP_TRY(hipMalloc(&h->d_in, sizeof(qmpc_input) * (size_t)max_batch));
   HIP_TRY(hipMalloc(&h->d_forces, sizeof(double) * 12 * (size_t)max_batch));
   HIP_TRY(hipMalloc(&h->d_info, sizeof(qmpc_info) * (size_t)max_batch));
-  if (h->lds_bytes <= 160 * 1024) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_kernel<false, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_kernel<true, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+#define QMPC_SET_LDS(kern, bytes) \
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
+  if (params->model == QMPC_MODEL_CONVEX) {
+    if (h->lds_bytes <= 160 * 1024) QMPC_SET_LDS((qmpc_solve_kernel<ConvexModel, false, false>), h->lds_bytes);
+    QMPC_SET_LDS((qmpc_solve_kernel<ConvexModel, false, true>), h->lds_bytes_g);
+    QMPC_SET_LDS(qmpc_linearize_kernel<ConvexModel>, h->lds_bytes_g);
+  } else {
+    if (h->lds_bytes <= 160 * 1024) {
+      QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, false, false>), h->lds_bytes);
+      QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, true, false>), h->lds_bytes);
+    }
+    QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, false, true>), h->lds_bytes_g);
+    QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, true, true>), h->lds_bytes_g);
+    QMPC_SET_LDS(qmpc_linearize_kernel<QuatModel>, h->lds_bytes_g);
   }
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_kernel<false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_g));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_kernel<true, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_g));
+#undef QMPC_SET_LDS
   HIP_TRY(hipMalloc(&h->d_gws, sizeof(double) * (size_t)N * (kKD + kROT) * (size_t)max_batch));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_linearize_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_g));
   *out = h;
   return QMPC_OK;
 }
@@ -240,12 +268,20 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
                                 qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s) {
   HIP_TRY(hipEventRecord(h->ev0, s));
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;   // the gains workspace is sized by max_batch
-  if (use_global_gains(h, batch))
-    hipLaunchKernelGGL((qmpc_solve_kernel<false, true>), dim3((unsigned)batch), dim3(kWave), h->lds_bytes_g, s, h->dev,
-                       d_in, d_forces, d_info, d_tu, d_tx, (int)batch, (long long*)nullptr, h->d_gws);
-  else
-    hipLaunchKernelGGL((qmpc_solve_kernel<false, false>), dim3((unsigned)batch), dim3(kWave), h->lds_bytes, s, h->dev,
-                       d_in, d_forces, d_info, d_tu, d_tx, (int)batch, (long long*)nullptr, (double*)nullptr);
+  const bool gg = use_global_gains(h, batch);
+  const size_t lds = gg ? h->lds_bytes_g : h->lds_bytes;
+  double* gws = gg ? h->d_gws : nullptr;
+#define QMPC_LAUNCH(kern) \
+  hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kWave), lds, s, h->dev, d_in, d_forces, d_info, d_tu, d_tx, \
+                     (int)batch, (long long*)nullptr, gws)
+  if (h->params.model == QMPC_MODEL_CONVEX) {
+    if (gg) QMPC_LAUNCH((qmpc_solve_kernel<ConvexModel, false, true>));
+    else QMPC_LAUNCH((qmpc_solve_kernel<ConvexModel, false, false>));
+  } else {
+    if (gg) QMPC_LAUNCH((qmpc_solve_kernel<QuatModel, false, true>));
+    else QMPC_LAUNCH((qmpc_solve_kernel<QuatModel, false, false>));
+  }
+#undef QMPC_LAUNCH
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev1, s));
   h->timed = true;
@@ -255,10 +291,21 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
 qmpc_status qmpc_solve_device(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces_body,
                               qmpc_info* d_info, void* stream) {
   if (!h || batch < 0 || (batch > 0 && (!d_in || !d_forces_body))) return QMPC_BAD_ARGUMENT;
+  if (h->params.model != QMPC_MODEL_QUAT) return QMPC_BAD_ARGUMENT;
   if (batch == 0) return QMPC_OK;
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   return launch_solve(h, batch, d_in, d_forces_body, d_info, nullptr, nullptr, s);
+}
+
+qmpc_status qmpc_convex_solve_device(qmpc_handle* h, int32_t batch, const qmpc_convex_input* d_in,
+                                     double* d_forces_world, qmpc_info* d_info, void* stream) {
+  if (!h || batch < 0 || (batch > 0 && (!d_in || !d_forces_world))) return QMPC_BAD_ARGUMENT;
+  if (h->params.model != QMPC_MODEL_CONVEX) return QMPC_BAD_ARGUMENT;
+  if (batch == 0) return QMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  return launch_solve(h, batch, reinterpret_cast<const qmpc_input*>(d_in), d_forces_world, d_info, nullptr, nullptr, s);
 }
 
 qmpc_status qmpc_wait(qmpc_handle* h) {
@@ -277,9 +324,11 @@ qmpc_status qmpc_last_kernel_ms(qmpc_handle* h, float* ms) {
   return QMPC_OK;
 }
 
-qmpc_status qmpc_solve_traj(qmpc_handle* h, int32_t batch, const qmpc_input* in, double* forces_body,
-                            qmpc_info* info, double* traj_u, double* traj_x) {
+// host-buffer solve shared by both models (nx = doubles per state in traj_x)
+static qmpc_status solve_host(qmpc_handle* h, int32_t batch, const qmpc_input* in, double* forces_body,
+                              qmpc_info* info, double* traj_u, double* traj_x, int model, int nx) {
   if (!h || batch < 0 || (batch > 0 && (!in || !forces_body))) return QMPC_BAD_ARGUMENT;
+  if (h->params.model != model) return QMPC_BAD_ARGUMENT;
   if (batch == 0) return QMPC_OK;
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
   HIP_TRY(hipSetDevice(h->device));
@@ -293,17 +342,35 @@ qmpc_status qmpc_solve_traj(qmpc_handle* h, int32_t batch, const qmpc_input* in,
   HIP_TRY(hipMemcpyAsync(forces_body, h->d_forces, sizeof(double) * 12 * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   if (info) HIP_TRY(hipMemcpyAsync(info, h->d_info, sizeof(qmpc_info) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   if (traj_u) HIP_TRY(hipMemcpyAsync(traj_u, h->d_traj_u, sizeof(double) * 12 * N * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
-  if (traj_x) HIP_TRY(hipMemcpyAsync(traj_x, h->d_traj_x, sizeof(double) * 13 * (N + 1) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+  if (traj_x) HIP_TRY(hipMemcpyAsync(traj_x, h->d_traj_x, sizeof(double) * nx * (N + 1) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return QMPC_OK;
+}
+
+qmpc_status qmpc_solve_traj(qmpc_handle* h, int32_t batch, const qmpc_input* in, double* forces_body,
+                            qmpc_info* info, double* traj_u, double* traj_x) {
+  return solve_host(h, batch, in, forces_body, info, traj_u, traj_x, QMPC_MODEL_QUAT, 13);
+}
+
+qmpc_status qmpc_convex_solve_traj(qmpc_handle* h, int32_t batch, const qmpc_convex_input* in, double* forces_world,
+                                   qmpc_info* info, double* traj_u, double* traj_x) {
+  return solve_host(h, batch, reinterpret_cast<const qmpc_input*>(in), forces_world, info, traj_u, traj_x,
+                    QMPC_MODEL_CONVEX, 12);
+}
+
+qmpc_status qmpc_convex_solve(qmpc_handle* h, int32_t batch, const qmpc_convex_input* in, double* forces_world,
+                              qmpc_info* info) {
+  return qmpc_convex_solve_traj(h, batch, in, forces_world, info, nullptr, nullptr);
 }
 
 qmpc_status qmpc_solve(qmpc_handle* h, int32_t batch, const qmpc_input* in, double* forces_body, qmpc_info* info) {
   return qmpc_solve_traj(h, batch, in, forces_body, info, nullptr, nullptr);
 }
 
-qmpc_status qmpc_linearize(qmpc_handle* h, int32_t batch, const qmpc_input* in, double* Abar, double* Bbar, double* X) {
+static qmpc_status linearize_host(qmpc_handle* h, int32_t batch, const qmpc_input* in, double* Abar, double* Bbar,
+                                  double* X, int model, int nx) {
   if (!h || batch < 0 || (batch > 0 && (!in || !Abar || !Bbar || !X))) return QMPC_BAD_ARGUMENT;
+  if (h->params.model != model) return QMPC_BAD_ARGUMENT;
   if (batch == 0) return QMPC_OK;
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
   HIP_TRY(hipSetDevice(h->device));
@@ -313,14 +380,27 @@ qmpc_status qmpc_linearize(qmpc_handle* h, int32_t batch, const qmpc_input* in, 
   if (!h->d_B) HIP_TRY(hipMalloc(&h->d_B, nA));
   if (!h->d_traj_x) HIP_TRY(hipMalloc(&h->d_traj_x, sizeof(double) * 13 * (N + 1) * (size_t)h->max_batch));
   HIP_TRY(hipMemcpyAsync(h->d_in, in, sizeof(qmpc_input) * (size_t)batch, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(qmpc_linearize_kernel, dim3((unsigned)batch), dim3(kWave), h->lds_bytes_g, h->stream, h->dev,
-                     h->d_in, h->d_A, h->d_B, h->d_traj_x, (int)batch);
+  if (model == QMPC_MODEL_CONVEX)
+    hipLaunchKernelGGL(qmpc_linearize_kernel<ConvexModel>, dim3((unsigned)batch), dim3(kWave), h->lds_bytes_g, h->stream,
+                       h->dev, h->d_in, h->d_A, h->d_B, h->d_traj_x, (int)batch);
+  else
+    hipLaunchKernelGGL(qmpc_linearize_kernel<QuatModel>, dim3((unsigned)batch), dim3(kWave), h->lds_bytes_g, h->stream,
+                       h->dev, h->d_in, h->d_A, h->d_B, h->d_traj_x, (int)batch);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(Abar, h->d_A, sizeof(double) * 144 * N * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(Bbar, h->d_B, sizeof(double) * 144 * N * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(X, h->d_traj_x, sizeof(double) * 13 * (N + 1) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(X, h->d_traj_x, sizeof(double) * nx * (N + 1) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return QMPC_OK;
+}
+
+qmpc_status qmpc_linearize(qmpc_handle* h, int32_t batch, const qmpc_input* in, double* Abar, double* Bbar, double* X) {
+  return linearize_host(h, batch, in, Abar, Bbar, X, QMPC_MODEL_QUAT, 13);
+}
+
+qmpc_status qmpc_convex_linearize(qmpc_handle* h, int32_t batch, const qmpc_convex_input* in, double* A, double* B,
+                                  double* X) {
+  return linearize_host(h, batch, reinterpret_cast<const qmpc_input*>(in), A, B, X, QMPC_MODEL_CONVEX, 12);
 }
 
 // Diagnostic: per-instance phase cycle counts (s_memtime) of one solve launch.
@@ -329,6 +409,7 @@ qmpc_status qmpc_linearize(qmpc_handle* h, int32_t batch, const qmpc_input* in, 
 // directions, rollout, misc; slot 15 = iterations.
 qmpc_status qmpc_debug_profile(qmpc_handle* h, int32_t batch, const qmpc_input* in, int64_t* cycles_out) {
   if (!h || batch < 1 || !in || !cycles_out) return QMPC_BAD_ARGUMENT;
+  if (h->params.model != QMPC_MODEL_QUAT) return QMPC_BAD_ARGUMENT;
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
   HIP_TRY(hipSetDevice(h->device));
   long long* d_prof = nullptr;
@@ -336,11 +417,11 @@ qmpc_status qmpc_debug_profile(qmpc_handle* h, int32_t batch, const qmpc_input* 
   HIP_TRY(hipMemsetAsync(d_prof, 0, sizeof(long long) * 16 * (size_t)batch, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_in, in, sizeof(qmpc_input) * (size_t)batch, hipMemcpyHostToDevice, h->stream));
   if (use_global_gains(h, batch))
-    hipLaunchKernelGGL((qmpc_solve_kernel<true, true>), dim3((unsigned)batch), dim3(kWave), h->lds_bytes_g, h->stream,
+    hipLaunchKernelGGL((qmpc_solve_kernel<QuatModel, true, true>), dim3((unsigned)batch), dim3(kWave), h->lds_bytes_g, h->stream,
                        h->dev, h->d_in, h->d_forces, h->d_info, (double*)nullptr, (double*)nullptr, (int)batch, d_prof,
                        h->d_gws);
   else
-    hipLaunchKernelGGL((qmpc_solve_kernel<true, false>), dim3((unsigned)batch), dim3(kWave), h->lds_bytes, h->stream,
+    hipLaunchKernelGGL((qmpc_solve_kernel<QuatModel, true, false>), dim3((unsigned)batch), dim3(kWave), h->lds_bytes, h->stream,
                        h->dev, h->d_in, h->d_forces, h->d_info, (double*)nullptr, (double*)nullptr, (int)batch, d_prof,
                        (double*)nullptr);
   HIP_TRY(hipGetLastError());

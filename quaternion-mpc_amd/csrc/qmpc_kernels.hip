@@ -42,22 +42,16 @@ struct Prof {
 };
 
 // ---- instance set-up: record -> LDS constants, reference, initial guess -----
-__device__ inline void setup_instance(const DevParams& P, const Layout& L, double* sm,
-                                      const qmpc_input* in, int lane, int* status) {
+// model-specific part: raw[48] (the record, in LDS scratch) -> cst, refp, uref, bw0
+template <class MD>
+__device__ inline void model_setup(const DevParams& P, const Layout& L, double* sm, const double* raw, int lane, int nc);
+
+// QuatMpc record (qmpc_input): quat 0..3, rot 4..12, linvel 13..15, angvel 16..18, foot 19..30,
+//      contacts 31..34, posref 35..37, velref 38..40, accref 41..43, quat_d 44..47
+template <>
+__device__ inline void model_setup<QuatModel>(const DevParams& P, const Layout& L, double* sm, const double* raw,
+                                              int lane, int nc) {
   double* cst = sm + L.cst;
-  const double* rec = reinterpret_cast<const double*>(in);
-  // one coalesced 8-byte-per-lane read of the 48-double record
-  const double v = (lane < 48) ? rec[lane] : 0.0;
-  const unsigned long long bad = __ballot(lane < 48 && !isfinite(v));
-  double* raw = sm + L.tile;  // scratch
-  if (lane < 48) raw[lane] = v;
-  QSYNC();
-  // raw: quat 0..3, rot 4..12, linvel 13..15, angvel 16..18, foot 19..30,
-  //      contacts 31..34, posref 35..37, velref 38..40, accref 41..43, quat_d 44..47
-  int nc = 0;
-  for (int l = 0; l < 4; ++l) nc += (raw[31 + l] != 0.0) ? 1 : 0;
-  *status = bad ? QMPC_NAN_INPUT : (nc == 0 ? QMPC_NO_CONTACT : QMPC_OK);
-  if (*status != QMPC_OK) return;
   if (lane < 12) cst[C_FOOT + lane] = raw[19 + lane];
   if (lane < 4) cst[C_CON + lane] = (raw[31 + lane] != 0.0) ? 1.0 : 0.0;
   if (lane < 3) {
@@ -110,11 +104,75 @@ __device__ inline void setup_instance(const DevParams& P, const Layout& L, doubl
   QSYNC();
 }
 
+// ConvexMpc record (qmpc_convex_input): euler 0..2, pos 3..5, angvel 6..8, linvel 9..11, foot 12..23,
+//      contacts 24..27, pos_d 28..30, lin_vel_d 31..33, yaw_rate_d 34
+template <>
+__device__ inline void model_setup<ConvexModel>(const DevParams& P, const Layout& L, double* sm, const double* raw,
+                                                int lane, int nc) {
+  double* cst = sm + L.cst;
+  if (lane < 12) cst[C_FOOT + lane] = raw[12 + lane];
+  if (lane < 4) cst[C_CON + lane] = (raw[24 + lane] != 0.0) ? 1.0 : 0.0;
+  if (lane < 13) {
+    cst[C_X0 + lane] = (lane < 12) ? raw[lane] : 0.0;      // x_init, ConvexMpc.cpp:156-167
+    double rp = 0.0;                                       // yaw0, yaw_rate_d, pos_d(3), vx_d, vy_d
+    if (lane == CR_YAW) rp = raw[2];
+    else if (lane == CR_RATE) rp = raw[34];
+    else if (lane >= CR_POS && lane < CR_POS + 3) rp = raw[28 + lane - CR_POS];
+    else if (lane == CR_VX) rp = raw[31];
+    else if (lane == CR_VY) rp = raw[32];
+    sm[L.refp + lane] = rp;
+  }
+  if (lane < 12) {
+    // u_ref (ConvexMpc.cpp:107-110)
+    const int l = lane / 3, a = lane - 3 * l;
+    sm[L.uref + lane] = (a == 2) ? P.mass * 9.81 / (double)nc * raw[24 + l] : 0.0;
+  }
+  if (lane < 18) {
+    // the pyramid acts on the world-frame forces directly (ConvexMpc.cpp:126-136)
+    const int r = lane / 3, c = lane - 3 * r;
+    const double C0 = (r == 0) ? 1.0 : (r == 1 ? -1.0 : 0.0);
+    const double C1 = (r == 2) ? 1.0 : (r == 3 ? -1.0 : 0.0);
+    const double C2 = (r < 4) ? -P.mu : (r == 4 ? 1.0 : -1.0);
+    cst[C_CR + lane] = (c == 0) ? C0 : (c == 1 ? C1 : C2);
+  }
+  QSYNC();
+  if (lane < 36) {
+    // S = skew(r_l) * contact_l (AltroUtils.cpp:284-286), 3x12 row-major: tau = S u
+    const int a = lane / 12, col = lane - 12 * a, l = col / 3, b = col - 3 * l;
+    const double* r = cst + C_FOOT + 3 * l;
+    double s0, s1, s2;
+    if (b == 0) { s0 = 0.0; s1 = r[2]; s2 = -r[1]; }
+    else if (b == 1) { s0 = -r[2]; s1 = 0.0; s2 = r[0]; }
+    else { s0 = r[1]; s1 = -r[0]; s2 = 0.0; }
+    sm[L.bw0 + lane] = cst[C_CON + l] * (a == 0 ? s0 : (a == 1 ? s1 : s2));
+  }
+  QSYNC();
+}
+
+template <class MD>
+__device__ inline void setup_instance(const DevParams& P, const Layout& L, double* sm,
+                                      const void* in, int lane, int* status) {
+  const double* rec = reinterpret_cast<const double*>(in);
+  // one coalesced 8-byte-per-lane read of the 48-double record
+  const double v = (lane < 48) ? rec[lane] : 0.0;
+  const unsigned long long bad = __ballot(lane < 48 && !isfinite(v));
+  double* raw = sm + L.tile;  // scratch
+  if (lane < 48) raw[lane] = v;
+  QSYNC();
+  constexpr int con0 = (MD::NX == 13) ? 31 : 24;   // contacts[4] inside the record
+  int nc = 0;
+  for (int l = 0; l < 4; ++l) nc += (raw[con0 + l] != 0.0) ? 1 : 0;
+  *status = bad ? QMPC_NAN_INPUT : (nc == 0 ? QMPC_NO_CONTACT : QMPC_OK);
+  if (*status != QMPC_OK) return;
+  model_setup<MD>(P, L, sm, raw, lane, nc);
+}
+
 // open-loop rollout of U from x0 into X (every lane computes it redundantly;
 // lane 0 publishes).  ALTRO's initial rollout.
+template <class MD>
 __device__ inline void rollout_open(const DevParams& P, const Layout& L, double* sm, int lane) {
   const double* cst = sm + L.cst;
-  ModelRegs M;
+  typename MD::Regs M;
   M.load(cst, sm + L.bw0);
   double x[13], xn[13], u[12];
 #pragma unroll
@@ -125,7 +183,7 @@ __device__ inline void rollout_open(const DevParams& P, const Layout& L, double*
   for (int k = 0; k < P.N; ++k) {
 #pragma unroll
     for (int j = 0; j < 12; ++j) u[j] = sm[L.U + 12 * k + j];
-    srbd_step(P, M, x, u, xn);
+    MD::step(P, M, x, u, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) x[i] = xn[i];
     if (lane == 0)
@@ -136,6 +194,7 @@ __device__ inline void rollout_open(const DevParams& P, const Layout& L, double*
 }
 
 // expansions at (X,U): one lane per knot
+template <class MD>
 __device__ inline void expansions(const DevParams& P, const Layout& L, double* sm, int lane) {
   const int N = P.N;
   if (lane <= N) {
@@ -148,7 +207,7 @@ __device__ inline void expansions(const DevParams& P, const Layout& L, double* s
 #pragma unroll
     for (int j = 0; j < 12; ++j) u[j] = (lane < N) ? sm[L.U + 12 * lane + j] : 0.0;
     double AB[27], lx[12], lxx[9];
-    expand_knot(P, sm + L.cst, sm + L.bw0, sm + L.refp, lane, x, u, xn, AB, lx, lxx);
+    MD::expand(P, sm + L.cst, sm + L.bw0, sm + L.refp, lane, x, u, xn, AB, lx, lxx);
     if (lane < N)
 #pragma unroll
       for (int i = 0; i < 27; ++i) sm[L.AB + kAB * lane + i] = AB[i];
@@ -310,7 +369,7 @@ __device__ __forceinline__ void gj_finish(const double M[3], double Rr[3], int g
 // Riccati backward pass with interior-point weights; writes KD (unrotated gains
 // [K | d], 12 x 13 per knot).  Returns nonzero when a pivot is not positive.
 // PIPE: build the next knot's operands during the stage solve (needs 12 more VGPRs)
-template <bool PROF, bool PIPE>
+template <class MD, bool PROF, bool PIPE>
 __device__ inline int backward_pass(const DevParams& P, const Layout& L, double* sm, double* KD,
                                     const double* ROT, int lane, unsigned conmask, Prof<PROF>& prof) {
   const int N = P.N;
@@ -319,48 +378,26 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
   const int c = lane & 15, g = lane >> 4;
   const bool cval = c < 12;
   const int lc = cval ? c / 3 : 0, bc = cval ? c - 3 * lc : 0;
-  // ---- per-lane, per-fragment patterns (row r_e = 4e + g) ----
-  double Ac[3], qadd[3], Bc[3][3], hbw[3][3];
-  int aoff[3], xoff[3], doff[3], goff[3], koff[3];
-  bool phi[3];
-  const double conl = cval ? cst[C_CON + lc] : 0.0;
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int a = 0; a < 3; ++a) hbw[j][a] = cval ? P.h * bw0[12 * j + 3 * lc + a] : 0.0;
+  // ---- per-lane, per-fragment patterns (row r_e = 4e + g): the model's operand / cost
+  //      patterns, and the rotated-block / gain offsets shared by both models ----
+  typename MD::Operands ops;
+  CostPattern cp;
+  ops.init(P, cst, bw0, lane, cp);
+  int doff[3], goff[3], koff[3];
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
     const int r = 4 * e + g;
     const int lr = r / 3, ar = r - 3 * lr;
-    phi[e] = (r >= 3 && r < 6);
-    Ac[e] = cval ? ((((r == c) && !phi[e]) ? 1.0 : 0.0) + ((r < 3 && c == r + 6) ? P.h : 0.0)) : 0.0;
-    aoff[e] = -1;
-    if (phi[e] && c >= 3 && c < 6) aoff[e] = 3 * (r - 3) + (c - 3);
-    if (phi[e] && c >= 9 && c < 12) aoff[e] = 9 + 3 * (r - 3) + (c - 9);
-    qadd[e] = (cval && r == c && !phi[e]) ? P.Q[(r < 3) ? r : r + 1] : 0.0;
-    xoff[e] = -1;
-    if (phi[e] && c >= 3 && c < 6) xoff[e] = 3 * (r - 3) + (c - 3);
-    if (c == 12) xoff[e] = 9 + r;
     doff[e] = (cval && lc == lr) ? 21 * lr + 9 + 3 * ar + bc : -1;
     goff[e] = (c == 12) ? 21 * lr + 18 + ar : -1;
     koff[e] = (c < 13) ? 13 * r + c : -1;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      double v = 0.0;
-      if (cval) {
-        if (r < 3) v = (r == a) ? conl * (P.h * (P.hh * (1.0 / P.mass))) : 0.0;
-        else if (r >= 6 && r < 9) v = (r - 6 == a) ? conl * (P.h * (1.0 / P.mass)) : 0.0;
-        else if (r >= 9) v = P.h * bw0[12 * (r - 9) + 3 * lc + a];
-      }
-      Bc[e][a] = v;
-    }
   }
   // ---- terminal cost-to-go  P_aug = [lxx_N | lx_N] ----
   double Pf[3];
   {
     const double* XTk = sm + L.XT + kXT * N;
 #pragma unroll
-    for (int e = 0; e < 3; ++e) Pf[e] = qadd[e] + ((xoff[e] >= 0) ? XTk[xoff[e]] : 0.0);
+    for (int e = 0; e < 3; ++e) Pf[e] = cp.qadd[e] + ((cp.xoff[e] >= 0) ? XTk[cp.xoff[e]] : 0.0);
   }
   int bad = 0;
   // operands of knot kk: Abar and rotated Bbar * T, straight into fragments.  They do not
@@ -371,19 +408,7 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
     const double* ROTkk = ROT + kROT * kk;
     double t0 = 0.0, t1 = 0.0, t2 = 0.0;
     if (cval) { t0 = ROTkk[21 * lc + bc]; t1 = ROTkk[21 * lc + 3 + bc]; t2 = ROTkk[21 * lc + 6 + bc]; }
-#pragma unroll
-    for (int e = 0; e < 3; ++e) {
-      Afo[e] = (aoff[e] >= 0) ? ABk[aoff[e]] : Ac[e];
-      double b0 = Bc[e][0], b1 = Bc[e][1], b2 = Bc[e][2];
-      if (phi[e]) {
-        const double* W = ABk + 18 + 3 * (4 * e + g - 3);
-        const double w0 = W[0], w1 = W[1], w2 = W[2];
-        b0 = (0.5 * P.hh) * (w0 * hbw[0][0] + w1 * hbw[1][0] + w2 * hbw[2][0]);
-        b1 = (0.5 * P.hh) * (w0 * hbw[0][1] + w1 * hbw[1][1] + w2 * hbw[2][1]);
-        b2 = (0.5 * P.hh) * (w0 * hbw[0][2] + w1 * hbw[1][2] + w2 * hbw[2][2]);
-      }
-      Bfo[e] = b0 * t0 + b1 * t1 + b2 * t2;
-    }
+    ops.build(P, ABk, t0, t1, t2, Afo, Bfo);
   };
   double Af[3], Bf[3], Afn[3], Bfn[3];
   if (PIPE) build_operands(N - 1, Af, Bf);
@@ -405,7 +430,7 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
     double Qxx[3], Qux[3], Quu[3], Rr[3];
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
-      Qxx[e] = aXX[e] + qadd[e] + ((xoff[e] >= 0) ? XTk[xoff[e]] : 0.0);
+      Qxx[e] = aXX[e] + cp.qadd[e] + ((cp.xoff[e] >= 0) ? XTk[cp.xoff[e]] : 0.0);
       Qux[e] = aUX[e] + ((goff[e] >= 0) ? ROTk[goff[e]] : 0.0);
       Quu[e] = aUU[e] + ((doff[e] >= 0) ? ROTk[doff[e]] : 0.0);
       Rr[e] = Qux[e];
@@ -469,12 +494,12 @@ __device__ __forceinline__ void roll_load(const Layout& L, const double* sm, con
 }
 // PF_X: also prefetch the old state (LDS variant: registers to spare); the global-gains
 // variant is register-bound (2 waves/SIMD) and prefetches only its high-latency gain row / T_l
-template <bool PF_X, bool PF_K>
+template <class MD, bool PF_X, bool PF_K>
 __device__ inline void rollout_closed(const DevParams& P, const Layout& L, double* sm, const double* KD,
                                       const double* ROT, double alpha, int lane) {
   const int N = P.N;
   const double* cst = sm + L.cst;
-  ModelRegs M;
+  typename MD::Regs M;
   M.load(cst, sm + L.bw0);
   const bool ulane = (lane < 16) && ((lane & 3) < 3);
   const int ql = ulane ? (lane >> 2) : 0, qa = ulane ? (lane & 3) : 0;   // leg, axis of this lane
@@ -492,22 +517,9 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
     if (!PF_X)
 #pragma unroll
       for (int i = 0; i < 13; ++i) cur.xo[i] = sm[L.X + 13 * k + i];
-    // dx = xc (-) X_k : inverse Cayley map of q_k^-1 * qc (QuaternionUtils.cpp:16-18)
+    // dx = xc (-) X_k in error-state coordinates
     double dx[12];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      dx[a] = xc[a] - cur.xo[a];
-      dx[6 + a] = xc[7 + a] - cur.xo[7 + a];
-      dx[9 + a] = xc[10 + a] - cur.xo[10 + a];
-    }
-    {
-      double G[12];
-      quat_G(&cur.xo[3], G);
-      const double isc = fast_rcp(cur.xo[3] * xc[3] + cur.xo[4] * xc[4] + cur.xo[5] * xc[5] + cur.xo[6] * xc[6]);
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-        dx[3 + a] = (G[a] * xc[3] + G[3 + a] * xc[4] + G[6 + a] * xc[5] + G[9 + a] * xc[6]) * isc;
-    }
+    MD::state_diff(cur.xo, xc, dx);
     double unew;
     {
       // rotated increment of input uj, then u-space increment through T_l
@@ -527,7 +539,7 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
     double un[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) un[j] = read_lane(unew, 4 * (j / 3) + (j % 3));
-    srbd_step(P, M, xc, un, xn);
+    MD::step(P, M, xc, un, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) xc[i] = xn[i];
     if (lane == 0)
@@ -604,12 +616,13 @@ __device__ inline void ipm_apply(const DevParams& P, const Layout& L, double* sm
 }
 
 // shortened primal step: scale the trial increment and re-roll the states open loop
+template <class MD>
 __device__ inline void rollout_scaled(const DevParams& P, const Layout& L, double* sm, double ap, int lane) {
   const int N = P.N;
   const double* cst = sm + L.cst;
   for (int i = lane; i < N * 12; i += kWave) sm[L.dU + i] *= ap;
   QSYNC();
-  ModelRegs M;
+  typename MD::Regs M;
   M.load(cst, sm + L.bw0);
   double x[13], xn[13], u[12];
 #pragma unroll
@@ -617,7 +630,7 @@ __device__ inline void rollout_scaled(const DevParams& P, const Layout& L, doubl
   for (int k = 0; k < N; ++k) {
 #pragma unroll
     for (int j = 0; j < 12; ++j) u[j] = sm[L.U + 12 * k + j] + sm[L.dU + 12 * k + j];
-    srbd_step(P, M, x, u, xn);
+    MD::step(P, M, x, u, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) x[i] = xn[i];
     if (lane == 0)
@@ -627,26 +640,18 @@ __device__ inline void rollout_scaled(const DevParams& P, const Layout& L, doubl
   QSYNC();
 }
 
+template <class MD>
 __device__ inline double cost_plain(const DevParams& P, const Layout& L, double* sm, int lane) {
   double J = 0.0;
-  if (lane <= P.N) {
-    double xr[13];
-    xref_at(P, sm + L.refp, lane, xr);
-    const double* x = sm + L.X + 13 * lane;
-    for (int i = 0; i < 13; ++i) { const double e = x[i] - xr[i]; J += 0.5 * P.Q[i] * e * e; }
-    const double dq = xr[3] * x[3] + xr[4] * x[4] + xr[5] * x[5] + xr[6] * x[6];
-    J += P.w * (1.0 - fabs(dq));
-    if (lane < P.N) {
-      const double* u = sm + L.U + 12 * lane;
-      for (int j = 0; j < 12; ++j) { const double e = u[j] - sm[L.uref + j]; J += 0.5 * P.R[j] * e * e; }
-    }
-  }
+  if (lane <= P.N)
+    J = MD::knot_cost(P, sm + L.refp, sm + L.uref, lane, sm + L.X + 13 * lane,
+                      (lane < P.N) ? sm + L.U + 12 * lane : nullptr);
   return wave_sum(J);
 }
 
 // ---- the solve kernel ---------------------------------------------------------
 // KDG: gains / rotation blocks in the global workspace gws (one slice per instance)
-template <bool PROF, bool KDG>
+template <class MD, bool PROF, bool KDG>
 __global__ __launch_bounds__(64, KDG ? 2 : 1) void qmpc_solve_kernel(DevParams P, const qmpc_input* __restrict__ in,
                                                         double* __restrict__ forces,
                                                         qmpc_info* __restrict__ info,
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(64, KDG ? 2 : 1) void qmpc_solve_kernel(DevParams P
   int status = QMPC_OK;
   Prof<PROF> prof;
   prof.start();
-  setup_instance(P, L, sm, in + b, lane, &status);
+  setup_instance<MD>(P, L, sm, in + b, lane, &status);
   if (status != QMPC_OK) {
     if (lane < 12) forces[12 * (size_t)b + lane] = 0.0;
     if (lane == 0 && info) {
@@ -673,7 +678,7 @@ __global__ __launch_bounds__(64, KDG ? 2 : 1) void qmpc_solve_kernel(DevParams P
       info[b] = r;
     }
     if (traj_u) for (int i = lane; i < N * 12; i += kWave) traj_u[(size_t)b * N * 12 + i] = 0.0;
-    if (traj_x) for (int i = lane; i < (N + 1) * 13; i += kWave) traj_x[(size_t)b * (N + 1) * 13 + i] = 0.0;
+    if (traj_x) for (int i = lane; i < (N + 1) * MD::NX; i += kWave) traj_x[(size_t)b * (N + 1) * MD::NX + i] = 0.0;
     return;
   }
   unsigned conmask = 0;
@@ -682,8 +687,8 @@ __global__ __launch_bounds__(64, KDG ? 2 : 1) void qmpc_solve_kernel(DevParams P
   // initial guess U = u_ref (QuatMpc.cpp:253), slacks and multipliers
   for (int i = lane; i < N * 12; i += kWave) sm[L.U + i] = sm[L.uref + (i % 12)];
   QSYNC();
-  rollout_open(P, L, sm, lane);
-  expansions(P, L, sm, lane);
+  rollout_open<MD>(P, L, sm, lane);
+  expansions<MD>(P, L, sm, lane);
   for (int i = lane; i < N * 24; i += kWave) {
     const double c0 = cone_value(P, L, sm, i);
     const double s0 = fmax(-c0, 1.0);
@@ -724,10 +729,10 @@ __global__ __launch_bounds__(64, KDG ? 2 : 1) void qmpc_solve_kernel(DevParams P
     rotation_prepass(P, L, sm, ROT, target, lane);
     if (KDG) __syncthreads();
     prof.tick(PH_MISC);
-    if (backward_pass<PROF, !KDG>(P, L, sm, KD, ROT, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
+    if (backward_pass<MD, PROF, !KDG>(P, L, sm, KD, ROT, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
     if (KDG) __syncthreads();
     double ap, ad;
-    rollout_closed<!KDG, !KDG>(P, L, sm, KD, ROT, 1.0, lane);  // trial step
+    rollout_closed<MD, !KDG, !KDG>(P, L, sm, KD, ROT, 1.0, lane);  // trial step
     prof.tick(PH_ROLL);
     ipm_directions(P, L, sm, target, lane, &ap, &ad);
     last_ap = ap; last_ad = ad;
@@ -738,7 +743,7 @@ __global__ __launch_bounds__(64, KDG ? 2 : 1) void qmpc_solve_kernel(DevParams P
       last_step = wave_max(step);
     }
     prof.tick(PH_DIRS);
-    if (ap < 1.0) rollout_scaled(P, L, sm, ap, lane);    // shortened primal step
+    if (ap < 1.0) rollout_scaled<MD>(P, L, sm, ap, lane);    // shortened primal step
     prof.tick(PH_ROLL);
     ipm_apply(P, L, sm, ap, ad, conmask, lane, kapbits);
     // accept the candidate
@@ -746,16 +751,20 @@ __global__ __launch_bounds__(64, KDG ? 2 : 1) void qmpc_solve_kernel(DevParams P
     for (int i = lane; i < (N + 1) * 13; i += kWave) sm[L.X + i] = sm[L.Xc + i];
     QSYNC();
     prof.tick(PH_MISC);
-    expansions(P, L, sm, lane);
+    expansions<MD>(P, L, sm, lane);
     prof.tick(PH_EXPAND);
     iters = it;
   }
   // outputs: GetInput(u, 0) (QuatMpc.cpp:264-265)
   if (lane < 12) forces[12 * (size_t)b + lane] = sm[L.U + lane];
   if (traj_u) for (int i = lane; i < N * 12; i += kWave) traj_u[(size_t)b * N * 12 + i] = sm[L.U + i];
-  if (traj_x) for (int i = lane; i < (N + 1) * 13; i += kWave) traj_x[(size_t)b * (N + 1) * 13 + i] = sm[L.X + i];
+  if (traj_x)
+    for (int i = lane; i < (N + 1) * MD::NX; i += kWave) {
+      const int k = i / MD::NX, j = i - MD::NX * k;
+      traj_x[(size_t)b * (N + 1) * MD::NX + i] = sm[L.X + 13 * k + j];
+    }
   if (info) {
-    const double J = cost_plain(P, L, sm, lane);
+    const double J = cost_plain<MD>(P, L, sm, lane);
     double viol = 0.0;
     for (int i = lane; i < N * 24; i += kWave) {
       const int l = (i % 24) / 6;
@@ -776,6 +785,7 @@ __global__ __launch_bounds__(64, KDG ? 2 : 1) void qmpc_solve_kernel(DevParams P
 }
 
 // ---- linearisation only (qmpc_linearize): rollout of U = u_ref + dense Abar/Bbar
+template <class MD>
 __global__ __launch_bounds__(64) void qmpc_linearize_kernel(DevParams P, const qmpc_input* __restrict__ in,
                                                             double* __restrict__ Abar,
                                                             double* __restrict__ Bbar,
@@ -787,23 +797,26 @@ __global__ __launch_bounds__(64) void qmpc_linearize_kernel(DevParams P, const q
   const int N = P.N;
   const Layout L = make_layout(N, true);
   int status = QMPC_OK;
-  setup_instance(P, L, sm, in + b, lane, &status);
+  setup_instance<MD>(P, L, sm, in + b, lane, &status);
   if (status != QMPC_OK) {
     for (int i = lane; i < N * 144; i += kWave) { Abar[(size_t)b * N * 144 + i] = 0.0; Bbar[(size_t)b * N * 144 + i] = 0.0; }
-    for (int i = lane; i < (N + 1) * 13; i += kWave) Xout[(size_t)b * (N + 1) * 13 + i] = 0.0;
+    for (int i = lane; i < (N + 1) * MD::NX; i += kWave) Xout[(size_t)b * (N + 1) * MD::NX + i] = 0.0;
     return;
   }
   for (int i = lane; i < N * 12; i += kWave) sm[L.U + i] = sm[L.uref + (i % 12)];
   QSYNC();
-  rollout_open(P, L, sm, lane);
-  expansions(P, L, sm, lane);
+  rollout_open<MD>(P, L, sm, lane);
+  expansions<MD>(P, L, sm, lane);
   for (int i = lane; i < N * 144; i += kWave) {
     const int k = i / 144, e = i - 144 * k, r = e / 12, c = e - 12 * r;
     const double* AB = sm + L.AB + kAB * k;
-    Abar[(size_t)b * N * 144 + i] = abar_elem(P, AB, r, c);
-    Bbar[(size_t)b * N * 144 + i] = bbar_elem(P, sm + L.cst, sm + L.bw0, AB, r, c);
+    Abar[(size_t)b * N * 144 + i] = MD::a_elem(P, sm + L.cst, sm + L.bw0, AB, r, c);
+    Bbar[(size_t)b * N * 144 + i] = MD::b_elem(P, sm + L.cst, sm + L.bw0, AB, r, c);
   }
-  for (int i = lane; i < (N + 1) * 13; i += kWave) Xout[(size_t)b * (N + 1) * 13 + i] = sm[L.X + i];
+  for (int i = lane; i < (N + 1) * MD::NX; i += kWave) {
+    const int k = i / MD::NX, j = i - MD::NX * k;
+    Xout[(size_t)b * (N + 1) * MD::NX + i] = sm[L.X + 13 * k + j];
+  }
 }
 
 // ---- MFMA layout self-test: C = X' * Y on [12][16] tiles -------------------------

@@ -139,3 +139,46 @@ def go1_stand_input(feet: np.ndarray | None = None) -> np.ndarray:
     rec["contacts"][0] = 1.0
     rec["quat_d"][0] = [1, 0, 0, 0]
     return rec
+
+
+def random_go1_convex_states(batch: int, config_id: int = 12, first: int = 0, vel_sigma: float = 0.3) -> np.ndarray:
+    """`batch` records of ``struct qmpc_convex_input`` (legged::ConvexMpc::grf_update's inputs,
+    ConvexMpc.cpp:81-198), same counter-based generator: yaw U(-pi,pi), roll/pitch N(0,0.1^2),
+    world-frame velocities N(0, vel_sigma^2) / N(0,0.5^2), footholds = Rz(yaw)(nominal + U(-.05,.05)^3),
+    contacts 40/40/20 % as for the quaternion path, yaw-rate command U(-0.5,0.5)."""
+    from . import CONVEX_INPUT_DTYPE
+
+    seed = 0x5EED0000 + int(config_id)
+    idx = np.arange(first, first + batch, dtype=np.uint64)
+    u = _uniform(seed, idx, 48)
+    c = iter(range(48))
+    nx = lambda: u[:, next(c)]  # noqa: E731
+    rec = np.zeros(batch, dtype=CONVEX_INPUT_DTYPE)
+    yaw = (2.0 * nx() - 1.0) * np.pi
+    roll = 0.1 * _normal(nx(), nx())
+    pitch = 0.1 * _normal(nx(), nx())
+    rec["euler"] = np.stack([roll, pitch, yaw], axis=-1)
+    pos = np.stack([0.05 * _normal(nx(), nx()), 0.05 * _normal(nx(), nx()), 0.3 + 0.02 * _normal(nx(), nx())], axis=-1)
+    rec["pos_world"] = pos
+    rec["ang_vel_world"] = np.stack([0.5 * _normal(nx(), nx()) for _ in range(3)], axis=-1)
+    rec["lin_vel_world"] = np.stack([vel_sigma * _normal(nx(), nx()) for _ in range(3)], axis=-1)
+    cy, sy = np.cos(yaw), np.sin(yaw)
+    feet = np.tile(NOMINAL_FEET[None], (batch, 1, 1))
+    for leg in range(4):
+        for ax in range(3):
+            feet[:, leg, ax] += 0.1 * nx() - 0.05
+    fw = np.empty_like(feet)
+    fw[:, :, 0] = cy[:, None] * feet[:, :, 0] - sy[:, None] * feet[:, :, 1]
+    fw[:, :, 1] = sy[:, None] * feet[:, :, 0] + cy[:, None] * feet[:, :, 1]
+    fw[:, :, 2] = feet[:, :, 2]
+    rec["foot_pos_abs_com"] = fw.reshape(batch, 12)
+    g = nx()
+    contacts = np.ones((batch, 4))
+    contacts[g < 0.4] = [1, 0, 0, 1]
+    contacts[(g >= 0.4) & (g < 0.8)] = [0, 1, 1, 0]
+    rec["contacts"] = contacts
+    rec["pos_d_world"] = np.stack([pos[:, 0], pos[:, 1], np.full(batch, 0.3)], axis=-1)
+    vx, vy = nx() - 0.5, 0.2 * nx() - 0.1
+    rec["lin_vel_d_world"] = np.stack([cy * vx - sy * vy, sy * vx + cy * vy, np.zeros(batch)], axis=-1)
+    rec["yaw_rate_d"] = nx() - 0.5
+    return rec

@@ -269,3 +269,75 @@ def test_host_class_drives_the_gpu(pkg, lib, oracle):
         assert np.abs(out[20:32].reshape(4, 3) - fo[0].reshape(4, 3) @ R.T).max() < 1e-6   # mpc_grf_world = R u
         assert out[39] > 0.0                                                                 # fbk.mpc_time [ms]
     host.qh_destroy(h)
+
+
+# ---- ConvexMpc model: same solver core, Euler-angle SRBD ------------------
+def _convex_solver(pkg, lib, N, cap=4096):
+    p = pkg.default_convex_params(N, pkg.MODE_CONVERGED, lib)
+    return p, pkg.Solver(p, cap, device=0, lib=lib)
+
+
+def test_convex_defaults_match_oracle(pkg, lib, oracle):
+    a = pkg.default_convex_params(20, pkg.MODE_CONVERGED, lib)
+    b = oracle.default_convex_params(20, 0)
+    assert bytes(a) == bytes(b)
+
+
+@pytest.mark.parametrize("N", [10, 20])
+def test_convex_linearisation_matches_oracle(pkg, lib, oracle, N):
+    p, s = _convex_solver(pkg, lib, N)
+    rec = pkg.random_go1_convex_states(64, config_id=12)
+    A, B, X = s.convex_linearize(rec)
+    Ao, Bo, Xo = oracle.convex_linearize(p, rec)
+    assert np.abs(X - Xo).max() < 1e-12
+    assert np.abs(A - Ao).max() < 1e-12
+    assert np.abs(B - Bo).max() < 1e-12
+    s.close()
+
+
+@pytest.mark.parametrize("N,cfg", [(10, 12), (20, 13)])
+def test_convex_forces_match_oracle(pkg, lib, oracle, N, cfg):
+    p, s = _convex_solver(pkg, lib, N)
+    rec = pkg.random_go1_convex_states(256, config_id=cfg)
+    f, info, tu, tx = s.convex_solve(rec, want_traj=True)
+    fo, io, tuo, txo = oracle.convex_solve(p, rec, threads=8, want_traj=True)
+    assert (info["status"] == 0).all(), np.unique(info["status"], return_counts=True)
+    assert (io["status"] == 0).all()
+    err = np.abs(f - fo).max(axis=1)
+    assert err.max() < 1e-6, (err.max(), int(err.argmax()))
+    assert np.abs(tu - tuo).max() < 1e-5
+    assert np.abs(tx - txo).max() < 1e-8
+    assert (info["iterations"] == io["iterations"]).mean() >= 0.95
+    swing = np.repeat(rec["contacts"] == 0, 3, axis=1)
+    assert np.abs(f[swing]).max() == 0.0
+    # large batch -> global-gains variant; must agree with the LDS variant
+    big = pkg.random_go1_convex_states(4608, config_id=cfg)
+    p2, s2 = _convex_solver(pkg, lib, N, cap=4608)
+    fb, ib = s2.convex_solve(big)
+    assert (ib["status"] == 0).all()
+    fs, _ = s.convex_solve(big[:256])
+    assert np.abs(fb[:256] - fs).max() < 1e-7
+    s.close(); s2.close()
+
+
+def test_convex_handle_rejects_quaternion_calls(pkg, lib):
+    p, s = _convex_solver(pkg, lib, 10)
+    with pytest.raises(pkg.QmpcError) as e:
+        s.solve(pkg.random_go1_trot_states(4))
+    assert e.value.code == 16
+    pq, sq = _solver(pkg, lib, 10)
+    with pytest.raises(pkg.QmpcError) as e:
+        sq.convex_solve(pkg.random_go1_convex_states(4))
+    assert e.value.code == 16
+    s.close(); sq.close()
+
+
+def test_convex_status_codes(pkg, lib):
+    p, s = _convex_solver(pkg, lib, 10)
+    rec = pkg.random_go1_convex_states(3, config_id=12)
+    rec["contacts"][0] = 0.0
+    rec["ang_vel_world"][1, 2] = np.inf
+    f, info = s.convex_solve(rec)
+    assert list(info["status"]) == [pkg.NO_CONTACT, pkg.NAN_INPUT, 0]
+    assert np.abs(f[:2]).max() == 0.0
+    s.close()
