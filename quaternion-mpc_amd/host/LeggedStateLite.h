@@ -69,6 +69,10 @@ struct LeggedFeedbackLite {   // LeggedState.h:20-77
   lite::Vector4d foot_contact_flag;
   lite::Mat<LEG_DOF, NUM_LEG> foot_pos_body;
   lite::Mat<LEG_DOF, NUM_LEG> foot_pos_world;
+  // read by ConvexMpc only (ConvexMpc.cpp:115-118,156-167)
+  lite::Vector3d torso_euler;
+  lite::Vector3d torso_ang_vel_world;
+  lite::Mat<LEG_DOF, NUM_LEG> foot_pos_abs_com;
   double mpc_time = 0.0;
 };
 
@@ -94,6 +98,7 @@ struct LeggedJoyCmdLite {     // LeggedState.h:127-158
   double velx = 0.0, vely = 0.0, velz = 0.0;
   double pitch_rate = 0.0, roll_rate = 0.0, yaw_rate = 0.0;
   double body_height = 0.05;
+  double body_x = 0.0, body_y = 0.0;   // ConvexMpc.cpp:57-58
   bool sin_ang_vel = false;
 };
 

@@ -32,6 +32,9 @@ struct QmpcApi {
   qmpc_status (*create)(const qmpc_params*, int32_t, int32_t, qmpc_handle**) = nullptr;
   qmpc_status (*solve)(qmpc_handle*, int32_t, const qmpc_input*, double*, qmpc_info*) = nullptr;
   void (*destroy)(qmpc_handle*) = nullptr;
+  // ConvexMpc entry points (only ConvexMpcHipT needs them)
+  void (*default_convex_params)(qmpc_params*, int32_t, int32_t) = nullptr;
+  qmpc_status (*convex_solve)(qmpc_handle*, int32_t, const qmpc_convex_input*, double*, qmpc_info*) = nullptr;
 };
 
 template <class State>

@@ -10,14 +10,17 @@
 
 #include "LeggedStateLite.h"
 #include "QuatMpcHip.h"
+#include "ConvexMpcHip.h"
 
 using legged::LeggedStateLite;
 using Mpc = legged::QuatMpcHipT<LeggedStateLite>;
+using CvxMpc = legged::ConvexMpcHipT<LeggedStateLite>;
 
 namespace {
 struct Harness {
   LeggedStateLite state;
   Mpc* mpc = nullptr;
+  CvxMpc* cvx = nullptr;
   void* dl = nullptr;
 };
 
@@ -27,43 +30,104 @@ void stub_default_params(qmpc_params* p, int32_t horizon, int32_t mode) {
   p->horizon = horizon;
   p->mode = mode;
 }
+
+// binds the C-ABI entry points from libqmpc_hip.so (or leaves the stubs for a device-less harness)
+bool bind_api(Harness* h, const char* lib_path, legged::QmpcApi& api);
 }  // namespace
 
 extern "C" {
+
+// ConvexMpc harness: gazebo_go1_convex_mpc.yaml values (5 ms, Q of the Euler-angle state, mu 0.6, fz_max 200)
+void* qh_convex_create(const char* lib_path, int horizon) {
+  Harness* h = new Harness();
+  h->state.param.mpc_horizon = horizon;
+  h->state.param.mpc_update_period = 5.0;
+  const double q[13] = {3.0, 3.0, 3.0, 1.0, 1.0, 20.0, 0.0, 0.0, 3.0, 2.0, 3.0, 2.0, 0.0};
+  for (int i = 0; i < 13; ++i) h->state.param.q_weights[i] = q[i];
+  h->state.param.mu = 0.6;
+  h->state.param.fz_max = 200.0;
+  legged::QmpcApi api;
+  if (!bind_api(h, lib_path, api)) { delete h; return nullptr; }
+  h->state.fbk.torso_rot_mat(0, 0) = h->state.fbk.torso_rot_mat(1, 1) = h->state.fbk.torso_rot_mat(2, 2) = 1.0;
+  h->state.fbk.torso_rot_mat_z = h->state.fbk.torso_rot_mat;
+  h->cvx = new CvxMpc(h->state, api, 0);
+  return h;
+}
+int qh_convex_device_status(void* p) { return (int)static_cast<Harness*>(p)->cvx->last_status(); }
+// extra feedback ConvexMpc reads: euler(3) ang_vel_world(3) foot_pos_abs_com(12, [3*leg+axis]) = 18 doubles
+void qh_convex_set_feedback(void* p, const double* f) {
+  LeggedStateLite& s = static_cast<Harness*>(p)->state;
+  for (int i = 0; i < 3; ++i) { s.fbk.torso_euler[i] = f[i]; s.fbk.torso_ang_vel_world[i] = f[3 + i]; }
+  for (int l = 0; l < 4; ++l)
+    for (int a = 0; a < 3; ++a) s.fbk.foot_pos_abs_com(a, l) = f[6 + 3 * l + a];
+}
+void qh_convex_set_body_xy(void* p, double x, double y) {
+  LeggedStateLite& s = static_cast<Harness*>(p)->state;
+  s.joy.body_x = x; s.joy.body_y = y;
+}
+void qh_convex_goal_update(void* p) { Harness* h = static_cast<Harness*>(p); h->cvx->goal_update(h->state); }
+void qh_convex_foot_update(void* p) { Harness* h = static_cast<Harness*>(p); h->cvx->foot_update(h->state); }
+int qh_convex_grf_update(void* p) { Harness* h = static_cast<Harness*>(p); return h->cvx->grf_update(h->state) ? 1 : 0; }
+int qh_convex_update(void* p) { Harness* h = static_cast<Harness*>(p); return h->cvx->update(h->state) ? 1 : 0; }
+void qh_convex_pack_input(void* p, qmpc_convex_input* out) { Harness* h = static_cast<Harness*>(p); h->cvx->pack_input(h->state, out); }
+// out: lin_vel_d_rel(3) lin_vel_d_world(3) pos_d_world(3) yaw_rate_d(1) optimized_state[0:6] = 16 doubles
+void qh_convex_get_goal(void* p, double* o) {
+  LeggedStateLite& s = static_cast<Harness*>(p)->state;
+  for (int i = 0; i < 3; ++i) {
+    o[i] = s.ctrl.torso_lin_vel_d_rel[i]; o[3 + i] = s.ctrl.torso_lin_vel_d_world[i]; o[6 + i] = s.ctrl.torso_pos_d_world[i];
+  }
+  o[9] = s.ctrl.torso_ang_vel_d_body[2];
+  for (int i = 0; i < 6; ++i) o[10 + i] = s.ctrl.optimized_state[i];
+}
 
 // lib_path: path of libqmpc_hip.so, or NULL/"" for a harness without a device
 void* qh_create(const char* lib_path, int horizon) {
   Harness* h = new Harness();
   h->state.param.mpc_horizon = horizon;
   legged::QmpcApi api;
-  api.default_params = stub_default_params;
-  if (lib_path && lib_path[0]) {
-    h->dl = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
-    if (!h->dl) {
-      std::fprintf(stderr, "qh_create: dlopen(%s) failed: %s\n", lib_path, dlerror());
-      delete h;
-      return nullptr;
-    }
-    api.default_params = reinterpret_cast<decltype(api.default_params)>(dlsym(h->dl, "qmpc_default_params"));
-    api.create = reinterpret_cast<decltype(api.create)>(dlsym(h->dl, "qmpc_create"));
-    api.solve = reinterpret_cast<decltype(api.solve)>(dlsym(h->dl, "qmpc_solve"));
-    api.destroy = reinterpret_cast<decltype(api.destroy)>(dlsym(h->dl, "qmpc_destroy"));
-    if (!api.default_params || !api.create || !api.solve || !api.destroy) {
-      std::fprintf(stderr, "qh_create: missing qmpc_* symbols in %s\n", lib_path);
-      delete h;
-      return nullptr;
-    }
-  }
+  if (!bind_api(h, lib_path, api)) { delete h; return nullptr; }
   h->state.fbk.torso_rot_mat(0, 0) = h->state.fbk.torso_rot_mat(1, 1) = h->state.fbk.torso_rot_mat(2, 2) = 1.0;
   h->state.fbk.torso_rot_mat_z = h->state.fbk.torso_rot_mat;
   h->mpc = new Mpc(h->state, api, 0);
   return h;
 }
 
+}  // extern "C"
+
+namespace {
+bool bind_api(Harness* h, const char* lib_path, legged::QmpcApi& api) {
+  api.default_params = stub_default_params;
+  api.default_convex_params = stub_default_params;
+  if (lib_path && lib_path[0]) {
+    h->dl = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
+    if (!h->dl) {
+      std::fprintf(stderr, "qh_create: dlopen(%s) failed: %s\n", lib_path, dlerror());
+      return false;
+    }
+    api.default_params = reinterpret_cast<decltype(api.default_params)>(dlsym(h->dl, "qmpc_default_params"));
+    api.create = reinterpret_cast<decltype(api.create)>(dlsym(h->dl, "qmpc_create"));
+    api.solve = reinterpret_cast<decltype(api.solve)>(dlsym(h->dl, "qmpc_solve"));
+    api.destroy = reinterpret_cast<decltype(api.destroy)>(dlsym(h->dl, "qmpc_destroy"));
+    api.default_convex_params =
+        reinterpret_cast<decltype(api.default_convex_params)>(dlsym(h->dl, "qmpc_default_convex_params"));
+    api.convex_solve = reinterpret_cast<decltype(api.convex_solve)>(dlsym(h->dl, "qmpc_convex_solve"));
+    if (!api.default_params || !api.create || !api.solve || !api.destroy || !api.default_convex_params ||
+        !api.convex_solve) {
+      std::fprintf(stderr, "qh_create: missing qmpc_* symbols in %s\n", lib_path);
+      return false;
+    }
+  }
+  return true;
+}
+}  // namespace
+
+extern "C" {
+
 void qh_destroy(void* p) {
   Harness* h = static_cast<Harness*>(p);
   if (!h) return;
   delete h->mpc;
+  delete h->cvx;
   // the HIP library stays loaded: unloading a library with live device code objects is not safe
   delete h;
 }

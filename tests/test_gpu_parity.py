@@ -341,3 +341,44 @@ def test_convex_status_codes(pkg, lib):
     assert list(info["status"]) == [pkg.NO_CONTACT, pkg.NAN_INPUT, 0]
     assert np.abs(f[:2]).max() == 0.0
     s.close()
+
+
+def test_convex_host_class_drives_the_gpu(pkg, lib, oracle):
+    """ConvexMpcHipT<LeggedStateLite>::update() (host C++) -> qmpc_convex_solve on the GPU; the body-frame
+    forces it writes (optimized_input = R' u, ConvexMpc.cpp:188-190) match the oracle on the packed record."""
+    import __graft_entry__ as g
+
+    host = C.CDLL(str(g.build_host()))
+    vp = C.c_void_p
+    host.qh_convex_create.argtypes = [C.c_char_p, C.c_int]; host.qh_convex_create.restype = vp
+    for f in ("qh_convex_device_status", "qh_convex_update", "qh_destroy"):
+        getattr(host, f).argtypes = [vp]
+    host.qh_set_feedback.argtypes = [vp, vp]; host.qh_set_command.argtypes = [vp, vp, C.c_double]
+    host.qh_convex_set_feedback.argtypes = [vp, vp]; host.qh_convex_pack_input.argtypes = [vp, vp]
+    host.qh_get_outputs.argtypes = [vp, vp]
+    h = host.qh_convex_create(str(pkg.LIB_PATH).encode(), 20)
+    assert h and host.qh_convex_device_status(h) == 0
+    recs = pkg.random_go1_convex_states(4, config_id=13)
+    for r in recs:
+        yaw = r["euler"][2]
+        c, s = np.cos(yaw), np.sin(yaw)
+        R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+        f = np.zeros(38)
+        f[0], f[3] = np.cos(yaw / 2), np.sin(yaw / 2)
+        f[4:13] = R.reshape(9)
+        f[13:16] = r["pos_world"]; f[16:19] = r["lin_vel_world"]
+        f[34:38] = 1.0
+        host.qh_set_feedback(h, f.ctypes.data)
+        extra = np.concatenate([r["euler"], r["ang_vel_world"], r["foot_pos_abs_com"]])
+        host.qh_convex_set_feedback(h, extra.ctypes.data)
+        joy = np.array([0.2, 0.05, 0.3, 0.0, 0.0, 0.3])
+        host.qh_set_command(h, joy.ctypes.data, 0.0)             # stand mode: all four legs in contact
+        assert host.qh_convex_update(h) == 1
+        inp = np.zeros(1, dtype=pkg.CONVEX_INPUT_DTYPE); host.qh_convex_pack_input(h, inp.ctypes.data)
+        assert list(inp["contacts"][0]) == [1.0] * 4
+        p = oracle.default_convex_params(20, 0)
+        fo, io = oracle.convex_solve(p, inp)
+        assert io["status"][0] == 0
+        out = np.zeros(40); host.qh_get_outputs(h, out.ctypes.data)
+        assert np.abs(out[8:20].reshape(4, 3) - fo[0].reshape(4, 3) @ R).max() < 1e-6   # rows: (R' u_i)'
+    host.qh_destroy(h)

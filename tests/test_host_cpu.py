@@ -209,3 +209,87 @@ def test_grf_update_fails_loudly_without_device(host, pkg):
     out = np.zeros(40); host.qh_get_outputs(h, out.ctypes.data)
     assert (out[8:32] == 0).all()
     host.qh_destroy(h)
+
+
+# ---- ConvexMpcHipT<State> (host mirror of legged::ConvexMpc) -----------------
+def _bind_convex(lib):
+    vp = C.c_void_p
+    lib.qh_convex_create.argtypes = [C.c_char_p, C.c_int]
+    lib.qh_convex_create.restype = vp
+    lib.qh_convex_device_status.argtypes = [vp]
+    lib.qh_convex_set_feedback.argtypes = [vp, vp]
+    lib.qh_convex_set_body_xy.argtypes = [vp, C.c_double, C.c_double]
+    for f in ("qh_convex_goal_update", "qh_convex_foot_update", "qh_convex_grf_update", "qh_convex_update"):
+        getattr(lib, f).argtypes = [vp]
+    lib.qh_convex_pack_input.argtypes = [vp, vp]
+    lib.qh_convex_get_goal.argtypes = [vp, vp]
+    return lib
+
+
+def _yaw_feedback(yaw=0.0):
+    """38-double feedback block of qh_set_feedback for a yaw-only attitude."""
+    f = np.zeros(38)
+    f[0], f[3] = np.cos(yaw / 2), np.sin(yaw / 2)
+    c, s = np.cos(yaw), np.sin(yaw)
+    f[4:13] = [c, -s, 0, s, c, 0, 0, 0, 1]
+    f[13:16] = [0.1, -0.2, 0.29]
+    f[16:19] = [0.3, 0.1, -0.05]
+    f[22:34] = [0.2, 0.14, -0.3, 0.2, -0.14, -0.3, -0.2, 0.14, -0.3, -0.2, -0.14, -0.3]
+    return f
+
+
+def test_convex_goal_update_ramps_and_rotates(host):
+    host = _bind_convex(host)
+    h = host.qh_convex_create(b"", 20)
+    assert h and host.qh_convex_device_status(h) == 17           # QMPC_NO_DEVICE: no library given
+    yaw = 0.7
+    f = _yaw_feedback(yaw)
+    host.qh_set_feedback(h, f.ctypes.data)
+    joy = np.array([0.02, -0.3, 0.31, 0.0, 0.0, 0.4])            # velx vely body_height roll pitch yaw rates
+    host.qh_set_command(h, joy.ctypes.data, 1.0)
+    host.qh_convex_set_body_xy(h, 0.5, -0.25)
+    vx = 0.0
+    out = np.zeros(16)
+    for tick in range(8):
+        host.qh_convex_goal_update(h)
+        # ConvexMpc.cpp:61-65: +-1.0 * h / 1000.0 per tick towards joy.velx (h = 5 ms), never settling exactly
+        if vx < joy[0]:
+            vx += 1.0 * 5.0 / 1000.0
+        elif vx > joy[0]:
+            vx -= 1.0 * 5.0 / 1000.0
+        host.qh_convex_get_goal(h, out.ctypes.data)
+        assert out[0] == vx and out[1] == joy[1] and out[2] == 0.0
+        c, s = np.cos(yaw), np.sin(yaw)
+        assert np.allclose(out[3:6], [c * vx - s * joy[1], s * vx + c * joy[1], 0.0], rtol=0, atol=1e-15)
+        assert list(out[6:9]) == [0.5, -0.25, 0.31] and out[9] == 0.4
+    host.qh_destroy(h)
+
+
+def test_convex_pack_input_and_schedule(host, pkg):
+    host = _bind_convex(host)
+    h = host.qh_convex_create(b"", 20)
+    f = _yaw_feedback(0.3)
+    f[34:38] = 0.0
+    host.qh_set_feedback(h, f.ctypes.data)
+    extra = np.concatenate([[0.01, -0.02, 0.3], [0.1, 0.2, 0.3], np.arange(12) * 0.01])
+    host.qh_convex_set_feedback(h, extra.ctypes.data)
+    joy = np.array([0.2, 0.05, 0.3, 0.0, 0.0, -0.2])
+    host.qh_set_command(h, joy.ctypes.data, 1.0)                 # walking: the FSM runs with dt = h/1000
+    fsm = [PyFSM(i) for i in range(4)]
+    for tick in range(120):
+        host.qh_convex_goal_update(h)
+        host.qh_convex_foot_update(h)
+        for m in fsm:
+            m.update(5.0 / 1000.0, 2.2, False)
+        rec = np.zeros(1, dtype=pkg.CONVEX_INPUT_DTYPE)
+        host.qh_convex_pack_input(h, rec.ctypes.data)
+        assert list(rec["contacts"][0]) == [float(m.s) for m in fsm], tick
+    assert list(rec["euler"][0]) == [0.01, -0.02, 0.3]
+    assert list(rec["ang_vel_world"][0]) == [0.1, 0.2, 0.3]
+    assert list(rec["pos_world"][0]) == list(f[13:16]) and list(rec["lin_vel_world"][0]) == list(f[16:19])
+    assert np.array_equal(rec["foot_pos_abs_com"][0], np.arange(12) * 0.01)
+    assert rec["yaw_rate_d"][0] == -0.2 and np.all(rec["reserved"][0] == 0.0)
+    g = np.zeros(16); host.qh_convex_get_goal(h, g.ctypes.data)
+    assert np.array_equal(rec["pos_d_world"][0], g[6:9]) and np.array_equal(rec["lin_vel_d_world"][0], g[3:6])
+    assert host.qh_convex_grf_update(h) == 0                     # no device behind it: fails loudly
+    host.qh_destroy(h)
