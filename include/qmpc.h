@@ -229,6 +229,39 @@ qmpc_status qmpc_convex_solve_device(qmpc_handle* h, int32_t batch, const qmpc_c
 qmpc_status qmpc_convex_linearize(qmpc_handle* h, int32_t batch, const qmpc_convex_input* in,
                                   double* A, double* B, double* X);
 
+/* ---- force -> joint-torque consumer --------------------
+ * The step right after the path: BaseInterface::tau_ctrl_update
+ * (legged_ctrl/src/interfaces/BaseInterface.cpp:343-408) maps the body-frame foot
+ * forces to joint torques, tau_leg = -J_leg(q)' f_leg (:368,401), with the leg
+ * Jacobian of A1Kinematics::jac (legged_ctrl/src/utils/A1Kinematics.cpp:15-19,
+ * evaluated in fbk.jac_foot at BaseInterface.cpp:209-212).  Batched here so that
+ * Monte-Carlo sweeps get joint torques without leaving the GPU.
+ * Leg geometry = the reference's rho_fix / rho_opt vectors (BaseInterface.cpp:10-34). */
+typedef struct qmpc_leg_geometry {
+  double rho_fix[4][5];     /* per leg: offset_x, offset_y, motor_offset, upper, lower length */
+  double rho_opt[4][3];     /* per leg: contact-point offsets (0 in the reference)           */
+} qmpc_leg_geometry;
+void qmpc_default_go1_geometry(qmpc_leg_geometry* g);   /* BaseInterface.cpp:12-26, LeggedParams.h:14-15 */
+
+/* Foot position in the body frame and leg Jacobian for every instance and leg
+ * (A1Kinematics::fk / ::jac).  joint_pos [batch][12] (leg-major: hip, thigh, calf);
+ * foot_pos_body [batch][12] (3x4 col-major, [3*leg+axis]); jac [batch][4][9], each
+ * 3x3 COLUMN-major like Eigen's Matrix3d::data().  Either output may be NULL.  Host buffers. */
+qmpc_status qmpc_leg_kinematics(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch,
+                                const double* joint_pos, double* foot_pos_body, double* jac);
+/* tau [batch][12] = -J' f per leg; legs with contacts == 0 get zero torque when
+ * `walking` != 0 (movement_mode > 0, BaseInterface.cpp:366-370); with walking == 0
+ * every leg is mapped (:401).  contacts [batch][4] may be NULL (= all stance).  Host buffers. */
+qmpc_status qmpc_torque_map(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch,
+                            const double* joint_pos, const double* forces_body,
+                            const double* contacts, int32_t walking, double* tau);
+/* Same with DEVICE buffers, stream-ordered (NULL = the handle's stream), e.g. straight
+ * after qmpc_solve_device on the forces it produced. */
+qmpc_status qmpc_torque_map_device(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch,
+                                   const double* d_joint_pos, const double* d_forces_body,
+                                   const double* d_contacts, int32_t walking, double* d_tau,
+                                   void* stream);
+
 /* ---- diagnostics ----------------------------------------------------------- */
 /* C = X' * Y on [12][16] row-major tiles through the FP64 MFMA path the solver
  * uses (host buffers of 192 doubles each).  Lets the GPU tests pin the

@@ -36,8 +36,8 @@ Params, INPUT_DTYPE, INFO_DTYPE = pkg.Params, pkg.INPUT_DTYPE, pkg.INFO_DTYPE
 
 
 def build(force: bool = False) -> Path:
-    srcs = [ORACLE_DIR / f for f in ("qo_srbd.c", "qo_altro.c", "qo_quatmpc.c", "qo_convex.c", "qo_kat.c",
-                                     "qo_linalg.h", "qo_srbd.h", "qo_altro.h", "qo_quatmpc.h", "qo_convex.h")]
+    srcs = [ORACLE_DIR / f for f in ("qo_srbd.c", "qo_altro.c", "qo_quatmpc.c", "qo_convex.c", "qo_legkin.c", "qo_kat.c",
+                                     "qo_linalg.h", "qo_srbd.h", "qo_altro.h", "qo_quatmpc.h", "qo_convex.h", "qo_legkin.h")]
     srcs.append(REPO_DIR / "include" / "qmpc.h")
     if force or not LIB_PATH.exists() or any(
             s.exists() and s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs):
@@ -73,6 +73,9 @@ def lib() -> C.CDLL:
         _lib.qo_convex_linearize.argtypes = [C.POINTER(Params), i32, vp, vp, vp, vp]
         _lib.qo_convex_linearize.restype = i32
         _lib.qo_convex_step.argtypes = [C.POINTER(Params), vp, vp, vp, vp]
+        _lib.qo_default_go1_geometry.argtypes = [vp]
+        _lib.qo_leg_kinematics.argtypes = [vp, i32, vp, vp, vp]
+        _lib.qo_torque_map.argtypes = [vp, i32, vp, vp, vp, i32, vp]
         _lib.qo_kat_double_integrator.argtypes = [i32, dp, i32]
         _lib.qo_kat_double_integrator.restype = i32
         _lib.qo_kat_pendulum_midpoint.argtypes = [dp, dp]
@@ -163,6 +166,29 @@ def convex_step(params: Params, inp: np.ndarray, x: np.ndarray, u: np.ndarray) -
     xn = np.zeros(12)
     lib().qo_convex_step(C.byref(params), _ptr(inp), _ptr(x), _ptr(u), _ptr(xn))
     return xn
+
+
+# ---- leg kinematics and the force -> torque map -------------
+def default_go1_geometry():
+    g = pkg.LegGeometry()
+    lib().qo_default_go1_geometry(C.byref(g))
+    return g
+
+
+def leg_kinematics(geom, joint_pos: np.ndarray):
+    q = np.ascontiguousarray(joint_pos, dtype=np.float64).reshape(-1, 12)
+    p = np.zeros((len(q), 12)); J = np.zeros((len(q), 4, 9))
+    lib().qo_leg_kinematics(C.byref(geom), len(q), _ptr(q), _ptr(p), _ptr(J))
+    return p, J
+
+
+def torque_map(geom, joint_pos, forces_body, contacts=None, walking: bool = True):
+    q = np.ascontiguousarray(joint_pos, dtype=np.float64).reshape(-1, 12)
+    f = np.ascontiguousarray(forces_body, dtype=np.float64).reshape(-1, 12)
+    c = None if contacts is None else np.ascontiguousarray(contacts, dtype=np.float64).reshape(-1, 4)
+    tau = np.zeros((len(q), 12))
+    lib().qo_torque_map(C.byref(geom), len(q), _ptr(q), _ptr(f), _ptr(c), int(bool(walking)), _ptr(tau))
+    return tau
 
 
 def kat_double_integrator(which: int, verbose: int = 0):

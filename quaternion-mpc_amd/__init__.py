@@ -70,6 +70,12 @@ class Params(C.Structure):
         return out
 
 
+class LegGeometry(C.Structure):
+    """struct qmpc_leg_geometry: the reference's rho_fix / rho_opt per leg (BaseInterface.cpp:10-34)."""
+
+    _fields_ = [("rho_fix", (C.c_double * 5) * 4), ("rho_opt", (C.c_double * 3) * 4)]
+
+
 # struct qmpc_input as a numpy structured dtype: 48 doubles, 384 B
 INPUT_DTYPE = np.dtype(
     [
@@ -191,6 +197,14 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.qmpc_convex_solve_device.restype = i32
     lib.qmpc_convex_linearize.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.qmpc_convex_linearize.restype = i32
+    lib.qmpc_default_go1_geometry.argtypes = [C.POINTER(LegGeometry)]
+    lib.qmpc_default_go1_geometry.restype = None
+    lib.qmpc_leg_kinematics.argtypes = [vp, C.POINTER(LegGeometry), i32, vp, vp, vp]
+    lib.qmpc_leg_kinematics.restype = i32
+    lib.qmpc_torque_map.argtypes = [vp, C.POINTER(LegGeometry), i32, vp, vp, vp, i32, vp]
+    lib.qmpc_torque_map.restype = i32
+    lib.qmpc_torque_map_device.argtypes = [vp, C.POINTER(LegGeometry), i32, vp, vp, vp, i32, vp, vp]
+    lib.qmpc_torque_map_device.restype = i32
     for name in ("qmpc_sizeof_input", "qmpc_sizeof_params", "qmpc_sizeof_info", "qmpc_sizeof_convex_input"):
         getattr(lib, name).argtypes = []
         getattr(lib, name).restype = i32
@@ -230,6 +244,10 @@ EXPORTED_SYMBOLS = (
     "qmpc_convex_solve_device",
     "qmpc_convex_linearize",
     "qmpc_sizeof_convex_input",
+    "qmpc_default_go1_geometry",
+    "qmpc_leg_kinematics",
+    "qmpc_torque_map",
+    "qmpc_torque_map_device",
 )
 
 
@@ -348,6 +366,40 @@ class Solver:
         if st != OK:
             raise QmpcError(st, "qmpc_convex_linearize")
         return A, Bm, X
+
+    # ---- force -> joint torque consumer (BaseInterface::tau_ctrl_update) ----
+    def default_go1_geometry(self) -> LegGeometry:
+        g = LegGeometry()
+        self.lib.qmpc_default_go1_geometry(C.byref(g))
+        return g
+
+    def leg_kinematics(self, geom: LegGeometry, joint_pos: np.ndarray):
+        q = np.ascontiguousarray(joint_pos, dtype=np.float64).reshape(-1, 12)
+        p = np.zeros((len(q), 12))
+        J = np.zeros((len(q), 4, 9))
+        st = self.lib.qmpc_leg_kinematics(self._h, C.byref(geom), len(q), _ptr(q), _ptr(p), _ptr(J))
+        if st != OK:
+            raise QmpcError(st, "qmpc_leg_kinematics")
+        return p, J
+
+    def torque_map(self, geom: LegGeometry, joint_pos, forces_body, contacts=None, walking: bool = True):
+        q = np.ascontiguousarray(joint_pos, dtype=np.float64).reshape(-1, 12)
+        f = np.ascontiguousarray(forces_body, dtype=np.float64).reshape(-1, 12)
+        c = None if contacts is None else np.ascontiguousarray(contacts, dtype=np.float64).reshape(-1, 4)
+        tau = np.zeros((len(q), 12))
+        st = self.lib.qmpc_torque_map(self._h, C.byref(geom), len(q), _ptr(q), _ptr(f), _ptr(c), int(bool(walking)), _ptr(tau))
+        if st != OK:
+            raise QmpcError(st, "qmpc_torque_map")
+        return tau
+
+    def torque_map_device(self, geom: LegGeometry, batch: int, d_joint_pos: int, d_forces: int, d_contacts: int,
+                          walking: bool, d_tau: int, stream: int = 0):
+        st = self.lib.qmpc_torque_map_device(self._h, C.byref(geom), int(batch), C.c_void_p(d_joint_pos),
+                                             C.c_void_p(d_forces), C.c_void_p(d_contacts) if d_contacts else None,
+                                             int(bool(walking)), C.c_void_p(d_tau),
+                                             C.c_void_p(stream) if stream else None)
+        if st != OK:
+            raise QmpcError(st, "qmpc_torque_map_device")
 
     def phase_profile(self, inputs: np.ndarray) -> np.ndarray:
         inputs = np.ascontiguousarray(inputs, dtype=INPUT_DTYPE)

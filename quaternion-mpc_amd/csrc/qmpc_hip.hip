@@ -403,6 +403,83 @@ qmpc_status qmpc_convex_linearize(qmpc_handle* h, int32_t batch, const qmpc_conv
   return linearize_host(h, batch, reinterpret_cast<const qmpc_input*>(in), A, B, X, QMPC_MODEL_CONVEX, 12);
 }
 
+// ---- leg kinematics / torque map (BaseInterface.cpp:10-34,209-212,343-408) ----------------
+void qmpc_default_go1_geometry(qmpc_leg_geometry* g) {
+  std::memset(g, 0, sizeof *g);
+  const double sx[4] = {1, 1, -1, -1}, sy[4] = {1, -1, 1, -1};
+  for (int l = 0; l < 4; ++l) {
+    g->rho_fix[l][0] = sx[l] * 0.1881;    // leg_offset_x
+    g->rho_fix[l][1] = sy[l] * 0.04675;   // leg_offset_y
+    g->rho_fix[l][2] = sy[l] * 0.0812;    // motor_offset
+    g->rho_fix[l][3] = 0.213;             // UPPER_LEG_LENGTH
+    g->rho_fix[l][4] = 0.213;             // LOWER_LEG_LENGTH
+  }
+}
+
+static_assert(sizeof(LegGeom) == sizeof(qmpc_leg_geometry), "kernel argument mirrors the ABI struct");
+
+static qmpc_status launch_leg(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch, const double* d_q,
+                              const double* d_f, const double* d_c, int walking, double* d_p, double* d_J,
+                              double* d_tau, hipStream_t s) {
+  LegGeom G;
+  std::memcpy(&G, g, sizeof G);
+  const unsigned threads = 256, blocks = (unsigned)(((size_t)batch * 4 + threads - 1) / threads);
+  hipLaunchKernelGGL(qmpc_leg_kernel, dim3(blocks), dim3(threads), 0, s, G, d_q, d_f, d_c, walking, d_p, d_J, d_tau,
+                     (int)batch);
+  HIP_TRY(hipGetLastError());
+  return QMPC_OK;
+}
+
+qmpc_status qmpc_torque_map_device(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch, const double* d_joint_pos,
+                                   const double* d_forces_body, const double* d_contacts, int32_t walking,
+                                   double* d_tau, void* stream) {
+  if (!h || !g || batch < 0 || (batch > 0 && (!d_joint_pos || !d_forces_body || !d_tau))) return QMPC_BAD_ARGUMENT;
+  if (batch == 0) return QMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  return launch_leg(h, g, batch, d_joint_pos, d_forces_body, d_contacts, walking, nullptr, nullptr, d_tau,
+                    stream ? (hipStream_t)stream : h->stream);
+}
+
+// host-buffer variants: staging buffers live for the call only (this is not the hot path)
+static qmpc_status leg_host(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch, const double* q, const double* f,
+                            const double* c, int walking, double* p, double* J, double* tau) {
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t B = (size_t)batch;
+  double* d = nullptr;
+  // layout: q[12B] f[12B] c[4B] p[12B] J[36B] tau[12B]
+  HIP_TRY(hipMalloc(&d, sizeof(double) * B * 88));
+  double *dq = d, *df = d + 12 * B, *dc = d + 24 * B, *dp = d + 28 * B, *dJ = d + 40 * B, *dt = d + 76 * B;
+  qmpc_status st = QMPC_OK;
+  do {
+    if (hipMemcpyAsync(dq, q, sizeof(double) * 12 * B, hipMemcpyHostToDevice, h->stream) != hipSuccess) { st = QMPC_HIP_ERROR; break; }
+    if (f && hipMemcpyAsync(df, f, sizeof(double) * 12 * B, hipMemcpyHostToDevice, h->stream) != hipSuccess) { st = QMPC_HIP_ERROR; break; }
+    if (c && hipMemcpyAsync(dc, c, sizeof(double) * 4 * B, hipMemcpyHostToDevice, h->stream) != hipSuccess) { st = QMPC_HIP_ERROR; break; }
+    st = launch_leg(h, g, batch, dq, f ? df : nullptr, c ? dc : nullptr, walking, p ? dp : nullptr, J ? dJ : nullptr,
+                    tau ? dt : nullptr, h->stream);
+    if (st != QMPC_OK) break;
+    if (p && hipMemcpyAsync(p, dp, sizeof(double) * 12 * B, hipMemcpyDeviceToHost, h->stream) != hipSuccess) { st = QMPC_HIP_ERROR; break; }
+    if (J && hipMemcpyAsync(J, dJ, sizeof(double) * 36 * B, hipMemcpyDeviceToHost, h->stream) != hipSuccess) { st = QMPC_HIP_ERROR; break; }
+    if (tau && hipMemcpyAsync(tau, dt, sizeof(double) * 12 * B, hipMemcpyDeviceToHost, h->stream) != hipSuccess) { st = QMPC_HIP_ERROR; break; }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) st = QMPC_HIP_ERROR;
+  } while (0);
+  (void)hipFree(d);
+  return st;
+}
+
+qmpc_status qmpc_leg_kinematics(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch, const double* joint_pos,
+                                double* foot_pos_body, double* jac) {
+  if (!h || !g || batch < 0 || (batch > 0 && (!joint_pos || (!foot_pos_body && !jac)))) return QMPC_BAD_ARGUMENT;
+  if (batch == 0) return QMPC_OK;
+  return leg_host(h, g, batch, joint_pos, nullptr, nullptr, 0, foot_pos_body, jac, nullptr);
+}
+
+qmpc_status qmpc_torque_map(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch, const double* joint_pos,
+                            const double* forces_body, const double* contacts, int32_t walking, double* tau) {
+  if (!h || !g || batch < 0 || (batch > 0 && (!joint_pos || !forces_body || !tau))) return QMPC_BAD_ARGUMENT;
+  if (batch == 0) return QMPC_OK;
+  return leg_host(h, g, batch, joint_pos, forces_body, contacts, walking, nullptr, nullptr, tau);
+}
+
 // Diagnostic: per-instance phase cycle counts (s_memtime) of one solve launch.
 // cycles_out: [batch][16] int64 on the host; slots 0..8 = setup, expansions,
 // operand build, MFMA + stage terms, stage solve, cost-to-go update, IPM

@@ -819,6 +819,68 @@ __global__ __launch_bounds__(64) void qmpc_linearize_kernel(DevParams P, const q
   }
 }
 
+// ---- leg kinematics + force -> joint torque map ------------
+// A1Kinematics::fk / ::jac (A1Kinematics.cpp:9-19, closed forms :38-128) and
+// BaseInterface::tau_ctrl_update (BaseInterface.cpp:343-408: tau = -J' f, zero for swing
+// legs while walking).  One thread per (instance, leg); consecutive threads touch
+// consecutive 24-byte triples, so every load/store of a wave is one contiguous span:
+// this pass is pure HBM streaming (40 doubles per instance).
+struct LegGeom {
+  double rho_fix[4][5];
+  double rho_opt[4][3];
+};
+struct LegTerms { double s0, c0, L, X, L2, X2, D; };
+__device__ __forceinline__ LegTerms leg_terms(const double* q, const double* c, const double* r) {
+  LegTerms t;
+  double s1, c1, s12, c12;
+  sincos(q[0], &t.s0, &t.c0);
+  sincos(q[1], &s1, &c1);
+  sincos(q[1] + q[2], &s12, &c12);
+  const double lce = r[4] - c[2];
+  t.L2 = lce * c12 + c[0] * s12;       // calf part of the leg extension
+  t.X2 = -lce * s12 + c[0] * c12;      // calf part of the fore-aft offset
+  t.L = r[3] * c1 + t.L2;
+  t.X = -r[3] * s1 + t.X2;
+  t.D = r[2] + c[1];
+  return t;
+}
+// mode 0: foot_pos_body / jac outputs (either may be null); mode 1: tau = -J' f
+__global__ __launch_bounds__(256) void qmpc_leg_kernel(LegGeom G, const double* __restrict__ joint_pos,
+                                                       const double* __restrict__ forces,
+                                                       const double* __restrict__ contacts, int walking,
+                                                       double* __restrict__ out_p, double* __restrict__ out_J,
+                                                       double* __restrict__ out_tau, int batch) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)batch * 4) return;
+  const int l = (int)(t & 3);
+  const double q[3] = {joint_pos[3 * t], joint_pos[3 * t + 1], joint_pos[3 * t + 2]};
+  if (out_tau) {
+    const bool stance = !contacts || contacts[t] != 0.0;
+    if (walking && !stance) {
+      out_tau[3 * t] = 0.0; out_tau[3 * t + 1] = 0.0; out_tau[3 * t + 2] = 0.0;
+      return;
+    }
+  }
+  const LegTerms k = leg_terms(q, G.rho_opt[l], G.rho_fix[l]);
+  // J column-major: J[3j+i] = d p_i / d q_j
+  const double J[9] = {0.0, -k.D * k.s0 + k.L * k.c0, k.D * k.c0 + k.L * k.s0,
+                       -k.L, k.X * k.s0, -k.X * k.c0,
+                       -k.L2, k.X2 * k.s0, -k.X2 * k.c0};
+  if (out_p) {
+    out_p[3 * t] = G.rho_fix[l][0] + k.X;
+    out_p[3 * t + 1] = G.rho_fix[l][1] + k.D * k.c0 + k.L * k.s0;
+    out_p[3 * t + 2] = k.D * k.s0 - k.L * k.c0;
+  }
+  if (out_J)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out_J[9 * t + i] = J[i];
+  if (out_tau) {
+    const double f[3] = {forces[3 * t], forces[3 * t + 1], forces[3 * t + 2]};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) out_tau[3 * t + j] = -(J[3 * j] * f[0] + J[3 * j + 1] * f[1] + J[3 * j + 2] * f[2]);
+  }
+}
+
 // ---- MFMA layout self-test: C = X' * Y on [12][16] tiles -------------------------
 __global__ __launch_bounds__(64) void qmpc_selftest_kernel(const double* __restrict__ X,
                                                            const double* __restrict__ Y,

@@ -382,3 +382,41 @@ def test_convex_host_class_drives_the_gpu(pkg, lib, oracle):
         out = np.zeros(40); host.qh_get_outputs(h, out.ctypes.data)
         assert np.abs(out[8:20].reshape(4, 3) - fo[0].reshape(4, 3) @ R).max() < 1e-6   # rows: (R' u_i)'
     host.qh_destroy(h)
+
+
+# ---- leg kinematics and the force -> joint-torque consumer ----------------
+def test_leg_kinematics_and_torque_map_match_oracle(pkg, lib, oracle):
+    import torch
+
+    p, s = _solver(pkg, lib, 10, cap=2048)
+    g = s.default_go1_geometry()
+    assert bytes(g) == bytes(oracle.default_go1_geometry())
+    rng = np.random.default_rng(11)
+    B = 2048
+    q = rng.uniform(-1.5, 1.5, (B, 12))
+    pos, J = s.leg_kinematics(g, q)
+    po, Jo = oracle.leg_kinematics(g, q)
+    assert np.abs(pos - po).max() < 1e-14 and np.abs(J - Jo).max() < 1e-14
+    # forces straight from the solver, contacts from the same records
+    rec = pkg.random_go1_trot_states(B, config_id=2)
+    f, info = s.solve(rec)
+    assert (info["status"] == 0).all()
+    for walking in (True, False):
+        tau = s.torque_map(g, q, f, rec["contacts"], walking=walking)
+        ref = oracle.torque_map(g, q, f, rec["contacts"], walking=walking)
+        assert np.abs(tau - ref).max() < 1e-11
+        if walking:
+            assert np.abs(tau[np.repeat(rec["contacts"] == 0, 3, axis=1)]).max() == 0.0
+    # device-resident chain: solve -> torque map on the same stream, no host round trip
+    d_in = torch.from_numpy(rec.view(np.uint8).reshape(B, -1).copy()).cuda()
+    d_f = torch.zeros(B, 12, dtype=torch.float64, device="cuda")
+    d_q = torch.from_numpy(q).cuda()
+    d_c = torch.from_numpy(np.ascontiguousarray(rec["contacts"])).cuda()
+    d_tau = torch.zeros(B, 12, dtype=torch.float64, device="cuda")
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    s.solve_device(B, d_in.data_ptr(), d_f.data_ptr(), 0, st.cuda_stream)
+    s.torque_map_device(g, B, d_q.data_ptr(), d_f.data_ptr(), d_c.data_ptr(), True, d_tau.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    assert np.array_equal(d_tau.cpu().numpy(), s.torque_map(g, q, f, rec["contacts"], walking=True))
+    s.close()
