@@ -60,14 +60,16 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(pkg, horizon: int, config_id: int, seconds: float = 12.0, convex: bool = False):
+def cpu_baseline(pkg, horizon: int, config_id: int, seconds: float = 12.0, model: str = "quat"):
     """Time the CPU oracle ("port") on a bounded sample of the same workload."""
     from oracle import pyoracle  # checker / baseline only
 
     cores = usable_cores()
-    p = (pyoracle.default_convex_params if convex else pyoracle.default_params)(horizon, 0)
-    gen = pkg.random_go1_convex_states if convex else pkg.random_go1_trot_states
-    solve = pyoracle.convex_solve if convex else pyoracle.solve
+    p = {"quat": pyoracle.default_params, "convex": pyoracle.default_convex_params,
+         "biped8": pyoracle.default_biped8_params}[model](horizon, 0)
+    gen = {"quat": pkg.random_go1_trot_states, "convex": pkg.random_go1_convex_states,
+           "biped8": pkg.random_biped8_states}[model]
+    solve = {"quat": pyoracle.solve, "convex": pyoracle.convex_solve, "biped8": pyoracle.solve8}[model]
     probe = gen(4 * cores, config_id=config_id)
     t0 = time.perf_counter()
     solve(p, probe, threads=cores)
@@ -92,9 +94,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU per step (BASELINE config 1)")
     ap.add_argument("--horizon", type=int, default=10)
-    ap.add_argument("--model", choices=["quat", "convex"], default="quat",
+    ap.add_argument("--model", choices=["quat", "convex", "biped8"], default="quat",
                     help="quat: legged::QuatMpc's inner loop (the BASELINE metric); convex: legged::ConvexMpc's "
-                         "(SURVEY 8f rank 1), same solver core")
+                         "(SURVEY 8f rank 1), same solver core; biped8: the QuatMpc problem with 8 contact points "
+                         "(BASELINE config 5, synthetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also compare a sample against the oracle")
     ap.add_argument("--selftest-gloo", action="store_true",
@@ -127,16 +130,24 @@ def main():
     pkg = load_pkg()
     N, B = args.horizon, args.batch
     convex = args.model == "convex"
-    config_id = (12 if N == 10 else 13) if convex else (2 if N == 10 else 3)
-    gen = pkg.random_go1_convex_states if convex else pkg.random_go1_trot_states
+    biped = args.model == "biped8"
+    NU = 24 if biped else 12
+    config_id = 5 if biped else ((12 if N == 10 else 13) if convex else (2 if N == 10 else 3))
+    gen = pkg.random_biped8_states if biped else (pkg.random_go1_convex_states if convex else pkg.random_go1_trot_states)
     # synthetic Go1 trot states; rank r owns instances [r*B, (r+1)*B)
     rec = gen(B, config_id=config_id, first=rank * B)
-    d_f = torch.zeros(B, 12, dtype=torch.float64, device=dev)
+    d_f = torch.zeros(B, NU, dtype=torch.float64, device=dev)
     d_info = torch.zeros(B, pkg.INFO_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    def oracle_solve(po, records, threads=1):
+        if biped:
+            return po.solve8(po.default_biped8_params(N, 0), records, threads=threads)
+        if convex:
+            return po.convex_solve(po.default_convex_params(N, 0), records, threads=threads)
+        return po.solve(po.default_params(N, 0), records, threads=threads)
+
     if selftest:
         from oracle import pyoracle   # test-only stand-in for the kernel
-        f_ref, _ = (pyoracle.convex_solve(pyoracle.default_convex_params(N, 0), rec) if convex
-                    else pyoracle.solve(pyoracle.default_params(N, 0), rec))
+        f_ref, _ = oracle_solve(pyoracle, rec)
         f_ref = torch.from_numpy(f_ref)
         solver = stream = None
 
@@ -144,7 +155,8 @@ def main():
             out.copy_(f_ref)
     else:
         lib = pkg.load_library()
-        params = (pkg.default_convex_params if convex else pkg.default_params)(N, pkg.MODE_CONVERGED, lib)
+        params = (pkg.default_biped8_params if biped else
+                  (pkg.default_convex_params if convex else pkg.default_params))(N, pkg.MODE_CONVERGED, lib)
         solver = pkg.Solver(params, B, device=local, lib=lib)
         d_in = torch.from_numpy(rec.view(np.uint8).reshape(B, -1).copy()).cuda()
         # a real (non-null) stream: the C ABI treats NULL as "the handle's own stream"
@@ -152,14 +164,14 @@ def main():
         torch.cuda.set_stream(stream)
 
         def launch(out):
-            (solver.convex_solve_device if convex else solver.solve_device)(
+            (solver.solve8_device if biped else (solver.convex_solve_device if convex else solver.solve_device))(
                 B, d_in.data_ptr(), out.data_ptr(), d_info.data_ptr(), stream.cuda_stream)
 
     counts = [B] * world
     # double-buffered outputs: the gather of step i (RCCL's own stream) overlaps the solve of
     # step i+1 (launch stream); one collective per step, never on the solve's critical path
     d_fs = [d_f, torch.zeros_like(d_f)]
-    gathered = [torch.zeros(world * B, 12, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    gathered = [torch.zeros(world * B, NU, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
     pending = [None, None]
 
     def step(i):
@@ -218,8 +230,7 @@ def main():
         ok = True
         if world > 1:
             from oracle import pyoracle
-            full, _ = (pyoracle.convex_solve(pyoracle.default_convex_params(N, 0), gen(world * B, config_id=config_id))
-                       if convex else pyoracle.solve(pyoracle.default_params(N, 0), gen(world * B, config_id=config_id)))
+            full, _ = oracle_solve(pyoracle, gen(world * B, config_id=config_id))
             ok = bool(np.array_equal(gathered[(args.steps - 1) & 1].numpy(), full))
         if rank == 0:
             print(json.dumps({"selftest": "gloo", "n_ranks": world, "steps": args.steps, "ok": ok}), flush=True)
@@ -238,20 +249,22 @@ def main():
             latest = sorted((REPO / "profiles").glob("r*_pmc_traffic.json"),
                             key=lambda q: [int(t) for t in re.findall(r"\d+", q.name)])[-1]
             pm = json.loads(latest.read_text())
-            if B == 1024 and N == 10 and not convex:
+            if B == 1024 and N == 10 and args.model == "quat":
                 traffic = pm["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
         total = world * B * args.steps
         value = total / elapsed
-        w_alg = W_ALG_KFLOP_PER_KNOT * 1e3 * N          # algorithmic FP64 flops per solve
+        # algorithmic FP64 flops per solve; SURVEY 8d prices the 24-input model at ~110 kFLOP/knot/iteration
+        w_alg = (330.0 if biped else W_ALG_KFLOP_PER_KNOT) * 1e3 * N
         achieved = w_alg * B / (kernel_ms * 1e-3) / 1e12
         out = {
-            "metric": "MPC QP solves/sec (Go1%s, 12 forces, N=%d)" % (" ConvexMpc" if convex else "", N),
+            "metric": ("MPC QP solves/sec (synthetic biped, 8 contact points, 24 forces, N=%d)" % N) if biped else
+                      "MPC QP solves/sec (Go1%s, 12 forces, N=%d)" % (" ConvexMpc" if convex else "", N),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"Batch={B} random Go1 {'ConvexMpc ' if convex else ''}trot states per GPU, N={N}, converged mode "
+            "config": {"workload": f"Batch={B} random {'biped8 ' if biped else 'Go1 '}{'ConvexMpc ' if convex else ''}states per GPU, N={N}, converged mode "
                                    f"(interior point to |dU|<=1e-8 N), generator seed 0x5EED0000+{config_id}",
                        "batch_per_gpu": B, "horizon": N, "parallelism": f"instance-sharded x{world}",
                        "converged": n_ok, "mean_iterations": mean_iters},
@@ -265,11 +278,10 @@ def main():
         if args.check:
             from oracle import pyoracle
             idx = np.arange(0, B, max(B // 64, 1))
-            fo, _ = (pyoracle.convex_solve(pyoracle.default_convex_params(N, 0), rec[idx], threads=usable_cores())
-                     if convex else pyoracle.solve(pyoracle.default_params(N, 0), rec[idx], threads=usable_cores()))
+            fo, _ = oracle_solve(pyoracle, rec[idx], threads=usable_cores())
             out["config"]["force_linf_vs_cpu"] = float(np.abs(d_f.cpu().numpy()[idx] - fo).max())
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, N, config_id, convex=convex)
+            out["cpu_baseline"] = cpu_baseline(pkg, N, config_id, model=args.model)
         print(json.dumps(out), flush=True)
     solver.close()
     if world > 1:

@@ -72,8 +72,12 @@ typedef enum qmpc_mode {
 /* ---- which reference controller's inner loop ----------------------------- */
 typedef enum qmpc_model {
   QMPC_MODEL_QUAT = 0,      /* legged::QuatMpc::grf_update   (QuatMpc.cpp:109-276)   */
-  QMPC_MODEL_CONVEX = 1     /* legged::ConvexMpc::grf_update (ConvexMpc.cpp:81-198):
+  QMPC_MODEL_CONVEX = 1,    /* legged::ConvexMpc::grf_update (ConvexMpc.cpp:81-198):
                                12-state Euler-angle SRBD, world-frame forces    */
+  QMPC_MODEL_QUAT8 = 2      /* the QuatMpc problem with 8 contact points (24 forces,
+                               48 cone rows per knot): BASELINE.json config 5, the
+                               SYNTHETIC stand-in for the humanoid branch that is not
+                               in the reference checkout           */
 } qmpc_model;
 
 /* ---- shared, read-only problem parameters -------------------------------- */
@@ -139,6 +143,24 @@ typedef struct qmpc_input {
                                TestAltroTrotQuatMpc.cpp:67-70 be expressed       */
   double quat_d[4];         /* ctrl.torso_quat_d AFTER the :128-137 update       */
 } qmpc_input;
+
+/* ---- one 8-contact-point instance (BASELINE config 5, synthetic) -----------
+ * Same fields as qmpc_input with 8 contact points (two feet x 4 corner points):
+ * 64 doubles = 512 B, one 8-byte-per-lane load of a whole wavefront. */
+#define QMPC_NLEG8 8
+#define QMPC_NU8 24
+typedef struct qmpc_input8 {
+  double quat[4];
+  double rot[9];
+  double lin_vel_body[3];
+  double ang_vel_body[3];
+  double foot_pos_body[24]; /* [3*point + axis]                                   */
+  double contacts[8];
+  double pos_ref_body[3];
+  double vel_ref_body[3];
+  double acc_ref_body[3];
+  double quat_d[4];
+} qmpc_input8;
 
 /* ---- one ConvexMpc instance -------------------------
  * The LeggedState fields legged::ConvexMpc::grf_update reads
@@ -229,6 +251,18 @@ qmpc_status qmpc_convex_solve_device(qmpc_handle* h, int32_t batch, const qmpc_c
 qmpc_status qmpc_convex_linearize(qmpc_handle* h, int32_t batch, const qmpc_convex_input* in,
                                   double* A, double* B, double* X);
 
+/* ---- 8-contact-point entry points (handle created with params.model = QMPC_MODEL_QUAT8)
+ * forces_body: [batch][24]; traj_u [batch][N][24], traj_x [batch][N+1][13] may be NULL.
+ * r_weights[j % 12] is used for input j.  The defaults are a synthetic 30 kg biped
+ * (stated in DESIGN.md); nothing in the reference pins them. */
+void        qmpc_default_biped8_params(qmpc_params* p, int32_t horizon, int32_t mode);
+qmpc_status qmpc_solve8(qmpc_handle* h, int32_t batch, const qmpc_input8* in,
+                        double* forces_body, qmpc_info* info);
+qmpc_status qmpc_solve8_traj(qmpc_handle* h, int32_t batch, const qmpc_input8* in,
+                             double* forces_body, qmpc_info* info, double* traj_u, double* traj_x);
+qmpc_status qmpc_solve8_device(qmpc_handle* h, int32_t batch, const qmpc_input8* d_in,
+                               double* d_forces_body, qmpc_info* d_info, void* stream);
+
 /* ---- force -> joint-torque consumer --------------------
  * The step right after the path: BaseInterface::tau_ctrl_update
  * (legged_ctrl/src/interfaces/BaseInterface.cpp:343-408) maps the body-frame foot
@@ -283,6 +317,7 @@ int32_t     qmpc_sizeof_input(void);   /* ABI guards for foreign-language bindin
 int32_t     qmpc_sizeof_params(void);
 int32_t     qmpc_sizeof_info(void);
 int32_t     qmpc_sizeof_convex_input(void);
+int32_t     qmpc_sizeof_input8(void);
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,12 @@ def lib() -> C.CDLL:
         _lib.qo_linearize.argtypes = [C.POINTER(Params), i32, vp, vp, vp, vp]
         _lib.qo_linearize.restype = i32
         _lib.qo_build_reference.argtypes = [C.POINTER(Params), vp, vp, vp]
+        _lib.qo_default_biped8_params.argtypes = [C.POINTER(Params), i32, i32]
+        _lib.qo_default_biped8_params.restype = None
+        _lib.qo_solve8_batch.argtypes = [C.POINTER(Params), i32, vp, vp, vp, vp, vp, i32]
+        _lib.qo_solve8_batch.restype = i32
+        _lib.qo_solve8_one.argtypes = [C.POINTER(Params), vp, vp, vp, vp, vp, i32]
+        _lib.qo_solve8_one.restype = i32
         _lib.qo_default_convex_params.argtypes = [C.POINTER(Params), i32, i32]
         _lib.qo_default_convex_params.restype = None
         _lib.qo_convex_solve_batch.argtypes = [C.POINTER(Params), i32, vp, vp, vp, vp, vp, i32]
@@ -121,6 +127,34 @@ def linearize(params: Params, inputs: np.ndarray):
     A = np.zeros((B, N, 12, 12)); Bm = np.zeros((B, N, 12, 12)); X = np.zeros((B, N + 1, 13))
     lib().qo_linearize(C.byref(params), B, _ptr(inputs), _ptr(A), _ptr(Bm), _ptr(X))
     return A, Bm, X
+
+
+# ---- 8 contact points (BASELINE config 5, synthetic biped) -----------------------
+def default_biped8_params(horizon: int = 16, mode: int = 0) -> Params:
+    p = Params()
+    lib().qo_default_biped8_params(C.byref(p), horizon, mode)
+    return p
+
+
+def solve8(params: Params, inputs: np.ndarray, threads: int = 1, want_traj: bool = False):
+    inputs = np.ascontiguousarray(inputs, dtype=pkg.INPUT8_DTYPE)
+    B, N = inputs.shape[0], params.horizon
+    forces = np.zeros((B, 24))
+    info = np.zeros(B, dtype=INFO_DTYPE)
+    tu = np.zeros((B, N, 24)) if want_traj else None
+    tx = np.zeros((B, N + 1, 13)) if want_traj else None
+    lib().qo_solve8_batch(C.byref(params), B, _ptr(inputs), _ptr(forces), _ptr(info), _ptr(tu), _ptr(tx), threads)
+    if want_traj:
+        return forces, info, tu, tx
+    return forces, info
+
+
+def solve8_verbose(params: Params, inp: np.ndarray):
+    inp = np.ascontiguousarray(inp, dtype=pkg.INPUT8_DTYPE)
+    f = np.zeros(24)
+    info = np.zeros(1, dtype=INFO_DTYPE)
+    lib().qo_solve8_one(C.byref(params), _ptr(inp), _ptr(f), _ptr(info), None, None, 1)
+    return f, info
 
 
 # ---- ConvexMpc model -----------------------------------

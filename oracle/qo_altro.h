@@ -23,8 +23,8 @@ extern "C" {
 #endif
 
 #define QO_MAXN 16   /* state dim     */
-#define QO_MAXM 16   /* input dim     */
-#define QO_MAXP 32   /* rows per constraint */
+#define QO_MAXM 24   /* input dim     */
+#define QO_MAXP 48   /* rows per constraint */
 #define QO_MAXH 64   /* horizon       */
 #define QO_MAXCON 4
 

@@ -59,8 +59,24 @@ typedef struct mpc_ctx {
   qo_srbd_model model;
   double mu, fz_max;
   double CR[18];
-  double row_enable[24];
+  double row_enable[48];
 } mpc_ctx;
+
+/* the fields of qmpc_input / qmpc_input8, by pointer */
+typedef struct in_view {
+  int nleg;
+  const double *quat, *rot, *lin_vel_body, *ang_vel_body, *foot, *contacts, *pos_ref, *vel_ref, *acc_ref, *quat_d;
+} in_view;
+static in_view view4(const qmpc_input* in) {
+  in_view v = {4, in->quat, in->rot, in->lin_vel_body, in->ang_vel_body, in->foot_pos_body, in->contacts,
+               in->pos_ref_body, in->vel_ref_body, in->acc_ref_body, in->quat_d};
+  return v;
+}
+static in_view view8(const qmpc_input8* in) {
+  in_view v = {8, in->quat, in->rot, in->lin_vel_body, in->ang_vel_body, in->foot_pos_body, in->contacts,
+               in->pos_ref_body, in->vel_ref_body, in->acc_ref_body, in->quat_d};
+  return v;
+}
 
 static void dyn_cb(void* ctx, int k, double* xn, const double* x, const double* u, float h) {
   (void)k;
@@ -74,26 +90,27 @@ static void jac_cb(void* ctx, int k, double* jac, const double* x, const double*
 static void cone_con(void* ctx, int k, double* c, const double* x, const double* u) {
   (void)k; (void)x;
   const mpc_ctx* m = (const mpc_ctx*)ctx;
-  qo_cone_eval(m->mu, m->fz_max, m->model.rot, m->model.contacts, u, c);
+  qo_cone_eval_n(m->model.nleg, m->mu, m->fz_max, m->model.rot, m->model.contacts, u, c);
 }
 /* QuatMpc.cpp:207-215: 24 x 24 col-major, block C_mat*R at rows 6i, cols 12+3i.
  * Swing-leg blocks are left zero (their forces are pinned to 0). */
 static void cone_jac(void* ctx, int k, double* jac, const double* x, const double* u) {
   (void)k; (void)x; (void)u;
   const mpc_ctx* m = (const mpc_ctx*)ctx;
-  for (int i = 0; i < 4; ++i) {
+  const int rows = 6 * m->model.nleg;
+  for (int i = 0; i < m->model.nleg; ++i) {
     if (m->model.contacts[i] == 0.0) continue;
     for (int r = 0; r < 6; ++r)
-      for (int c = 0; c < 3; ++c) jac[(6 * i + r) + 24 * (12 + 3 * i + c)] = m->CR[3 * r + c];
+      for (int c = 0; c < 3; ++c) jac[(6 * i + r) + rows * (12 + 3 * i + c)] = m->CR[3 * r + c];
   }
 }
 
-void qo_build_reference(const qmpc_params* p, const qmpc_input* in, double* xref, double* uref) {
+static void build_reference_v(const qmpc_params* p, const in_view* in, double* xref, double* uref) {
   /* QuatMpc.cpp:118-125 */
   int nc = 0;
-  for (int i = 0; i < 4; ++i) if (in->contacts[i] != 0.0) nc++;
-  memset(uref, 0, sizeof(double) * 12);
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < in->nleg; ++i) if (in->contacts[i] != 0.0) nc++;
+  memset(uref, 0, sizeof(double) * 3 * in->nleg);
+  for (int i = 0; i < in->nleg; ++i)
     uref[3 * i + 2] = in->contacts[i] * p->mass * 9.81 / (double)nc;
   /* QuatMpc.cpp:148-176 (h there is in ms: i*h/1000.0, left-to-right) */
   const double h_ms = p->h_ref * 1000.0;
@@ -101,32 +118,34 @@ void qo_build_reference(const qmpc_params* p, const qmpc_input* in, double* xref
     double* xr = &xref[13 * k];
     memset(xr, 0, sizeof(double) * 13);
     const double t = (double)k * p->h_ref;
-    xr[0] = in->pos_ref_body[0] + in->vel_ref_body[0] * k * h_ms / 1000.0 +
-            0.5 * in->acc_ref_body[0] * t * t;
-    xr[1] = in->pos_ref_body[1] + in->vel_ref_body[1] * k * h_ms / 1000.0 +
-            0.5 * in->acc_ref_body[1] * t * t;
-    xr[2] = in->pos_ref_body[2] + 0.5 * in->acc_ref_body[2] * t * t;
+    xr[0] = in->pos_ref[0] + in->vel_ref[0] * k * h_ms / 1000.0 + 0.5 * in->acc_ref[0] * t * t;
+    xr[1] = in->pos_ref[1] + in->vel_ref[1] * k * h_ms / 1000.0 + 0.5 * in->acc_ref[1] * t * t;
+    xr[2] = in->pos_ref[2] + 0.5 * in->acc_ref[2] * t * t;
     for (int a = 0; a < 4; ++a) xr[3 + a] = in->quat_d[a];
-    for (int a = 0; a < 3; ++a) xr[7 + a] = in->vel_ref_body[a] + in->acc_ref_body[a] * t;
+    for (int a = 0; a < 3; ++a) xr[7 + a] = in->vel_ref[a] + in->acc_ref[a] * t;
   }
 }
+void qo_build_reference(const qmpc_params* p, const qmpc_input* in, double* xref, double* uref) {
+  const in_view v = view4(in);
+  build_reference_v(p, &v, xref, uref);
+}
 
-static int input_is_finite(const qmpc_input* in) {
+static int record_is_finite(const void* in, size_t bytes) {
   const double* v = (const double*)in;
-  for (size_t i = 0; i < sizeof(qmpc_input) / sizeof(double); ++i)
+  for (size_t i = 0; i < bytes / sizeof(double); ++i)
     if (!isfinite(v[i])) return 0;
   return 1;
 }
 
-static void setup_problem(const qmpc_params* p, const qmpc_input* in, mpc_ctx* ctx,
-                          qo_problem* prob) {
-  const int N = p->horizon;
+static void setup_problem(const qmpc_params* p, const in_view* in, mpc_ctx* ctx, qo_problem* prob) {
+  const int N = p->horizon, nl = in->nleg, m = 3 * nl;
   memset(ctx, 0, sizeof *ctx);
-  memcpy(ctx->model.foot_pos_body, in->foot_pos_body, sizeof in->foot_pos_body);
+  ctx->model.nleg = nl;
+  memcpy(ctx->model.foot_pos_body, in->foot, sizeof(double) * 3 * nl);
   memcpy(ctx->model.inertia, p->inertia, sizeof p->inertia);
   ctx->model.mass = p->mass;
-  memcpy(ctx->model.rot, in->rot, sizeof in->rot);
-  for (int i = 0; i < 4; ++i) ctx->model.contacts[i] = (in->contacts[i] != 0.0) ? 1.0 : 0.0;
+  memcpy(ctx->model.rot, in->rot, sizeof(double) * 9);
+  for (int i = 0; i < nl; ++i) ctx->model.contacts[i] = (in->contacts[i] != 0.0) ? 1.0 : 0.0;
   qo_srbd_prepare(&ctx->model);
   ctx->mu = p->mu;
   ctx->fz_max = p->fz_max;
@@ -134,30 +153,30 @@ static void setup_problem(const qmpc_params* p, const qmpc_input* in, mpc_ctx* c
 
   memset(prob->con, 0, sizeof prob->con);
   memset(prob->x0, 0, sizeof prob->x0);
-  prob->n = 13; prob->m = 12; prob->N = N;
+  prob->n = 13; prob->m = m; prob->N = N;
   prob->use_quaternion = 1;       /* QuatMpc.cpp:24 */
   prob->quat_start_index = 3;     /* QuatMpc.cpp:25 */
   prob->h = p->h;
   prob->dyn = dyn_cb; prob->jac = jac_cb; prob->dyn_ctx = ctx;
-  double xref[(QMPC_MAX_HORIZON + 1) * 13], uref[12];
-  qo_build_reference(p, in, xref, uref);
+  double xref[(QMPC_MAX_HORIZON + 1) * 13], uref[24];
+  build_reference_v(p, in, xref, uref);
   for (int k = 0; k <= N; ++k) {
     memcpy(prob->Q[k], p->q_weights, sizeof(double) * 13);
-    memcpy(prob->R[k], p->r_weights, sizeof(double) * 12);
+    for (int j = 0; j < m; ++j) prob->R[k][j] = p->r_weights[j % 12];
     memcpy(prob->xref[k], &xref[13 * k], sizeof(double) * 13);
-    memcpy(prob->uref[k], uref, sizeof(double) * 12);
+    memcpy(prob->uref[k], uref, sizeof(double) * m);
     prob->w[k] = p->w;
   }
   /* SetConstraint(..., 24, INEQUALITY, "friction cone", 0, horizon): knots 0..N-1 */
   prob->ncon = 1;
   prob->con[0].type = QO_INEQUALITY;
-  prob->con[0].p = 24;
+  prob->con[0].p = 6 * nl;
   prob->con[0].k_start = 0;
   prob->con[0].k_stop = N;
   prob->con[0].con = cone_con;
   prob->con[0].jac = cone_jac;
   prob->con[0].ctx = ctx;
-  for (int i = 0; i < 24; ++i) ctx->row_enable[i] = ctx->model.contacts[i / 6];
+  for (int i = 0; i < 6 * nl; ++i) ctx->row_enable[i] = ctx->model.contacts[i / 6];
   prob->con[0].row_enable = ctx->row_enable;
   /* x_init, QuatMpc.cpp:231-246 (angular velocity dropped by the ';' at :242) */
   prob->x0[3] = in->quat[0]; prob->x0[4] = in->quat[1];
@@ -189,19 +208,19 @@ static void options_from_params(const qmpc_params* p, qo_options* o, int verbose
   o->ipm_tau = p->ipm_tau;
 }
 
-int qo_solve_one(const qmpc_params* p, const qmpc_input* in, double* forces, qmpc_info* info,
-                 double* traj_u, double* traj_x, int verbose) {
-  const int N = p->horizon;
+static int solve_one_v(const qmpc_params* p, const in_view* in, const void* rec, size_t rec_bytes,
+                       double* forces, qmpc_info* info, double* traj_u, double* traj_x, int verbose) {
+  const int N = p->horizon, m = 3 * in->nleg;
   qmpc_info inf;
   memset(&inf, 0, sizeof inf);
-  memset(forces, 0, sizeof(double) * 12);
+  memset(forces, 0, sizeof(double) * m);
   int nc = 0;
-  for (int i = 0; i < 4; ++i) if (in->contacts[i] != 0.0) nc++;
-  if (!input_is_finite(in)) inf.status = QMPC_NAN_INPUT;
+  for (int i = 0; i < in->nleg; ++i) if (in->contacts[i] != 0.0) nc++;
+  if (!record_is_finite(rec, rec_bytes)) inf.status = QMPC_NAN_INPUT;
   else if (nc == 0) inf.status = QMPC_NO_CONTACT;
   if (inf.status != QMPC_OK) {
     if (info) *info = inf;
-    if (traj_u) memset(traj_u, 0, sizeof(double) * N * 12);
+    if (traj_u) memset(traj_u, 0, sizeof(double) * N * m);
     if (traj_x) memset(traj_x, 0, sizeof(double) * (N + 1) * 13);
     return inf.status;
   }
@@ -214,13 +233,13 @@ int qo_solve_one(const qmpc_params* p, const qmpc_input* in, double* forces, qmp
   setup_problem(p, in, ctx, prob);
   qo_options o;
   options_from_params(p, &o, verbose);
-  double X[(QMPC_MAX_HORIZON + 1) * 13], U[QMPC_MAX_HORIZON * 12];
+  double X[(QMPC_MAX_HORIZON + 1) * 13], U[QMPC_MAX_HORIZON * 24];
   /* initial guess: SetInput(u_ref) on all knots (QuatMpc.cpp:253); the state
    * guess x_ref (:250-252) is overwritten by the solver's initial rollout */
-  for (int k = 0; k < N; ++k) memcpy(&U[12 * k], prob->uref[0], sizeof(double) * 12);
+  for (int k = 0; k < N; ++k) memcpy(&U[m * k], prob->uref[0], sizeof(double) * m);
   qo_result r;
   qo_altro_solve(prob, &o, X, U, &r);
-  memcpy(forces, U, sizeof(double) * 12); /* GetInput(u, 0), QuatMpc.cpp:264-265 */
+  memcpy(forces, U, sizeof(double) * m); /* GetInput(u, 0), QuatMpc.cpp:264-265 */
   inf.status = r.status;
   inf.iterations = r.iterations;
   inf.cost = r.cost;
@@ -228,14 +247,26 @@ int qo_solve_one(const qmpc_params* p, const qmpc_input* in, double* forces, qmp
   inf.last_step = r.last_step;
   inf.penalty = r.penalty;
   if (info) *info = inf;
-  if (traj_u) memcpy(traj_u, U, sizeof(double) * N * 12);
+  if (traj_u) memcpy(traj_u, U, sizeof(double) * N * m);
   if (traj_x) memcpy(traj_x, X, sizeof(double) * (N + 1) * 13);
   return inf.status;
+}
+
+int qo_solve_one(const qmpc_params* p, const qmpc_input* in, double* forces, qmpc_info* info,
+                 double* traj_u, double* traj_x, int verbose) {
+  const in_view v = view4(in);
+  return solve_one_v(p, &v, in, sizeof *in, forces, info, traj_u, traj_x, verbose);
+}
+int qo_solve8_one(const qmpc_params* p, const qmpc_input8* in, double* forces, qmpc_info* info,
+                  double* traj_u, double* traj_x, int verbose) {
+  const in_view v = view8(in);
+  return solve_one_v(p, &v, in, sizeof *in, forces, info, traj_u, traj_x, verbose);
 }
 
 typedef struct batch_job {
   const qmpc_params* p;
   const qmpc_input* in;
+  const qmpc_input8* in8;
   double* forces;
   qmpc_info* info;
   double* traj_u;
@@ -246,21 +277,27 @@ typedef struct batch_job {
 static void* batch_worker(void* arg) {
   batch_job* j = (batch_job*)arg;
   const int N = j->p->horizon;
-  for (int b = j->begin; b < j->end; ++b)
-    qo_solve_one(j->p, &j->in[b], &j->forces[12 * b], j->info ? &j->info[b] : NULL,
-                 j->traj_u ? &j->traj_u[(size_t)b * N * 12] : NULL,
-                 j->traj_x ? &j->traj_x[(size_t)b * (N + 1) * 13] : NULL, 0);
+  for (int b = j->begin; b < j->end; ++b) {
+    if (j->in8)
+      qo_solve8_one(j->p, &j->in8[b], &j->forces[24 * (size_t)b], j->info ? &j->info[b] : NULL,
+                    j->traj_u ? &j->traj_u[(size_t)b * N * 24] : NULL,
+                    j->traj_x ? &j->traj_x[(size_t)b * (N + 1) * 13] : NULL, 0);
+    else
+      qo_solve_one(j->p, &j->in[b], &j->forces[12 * (size_t)b], j->info ? &j->info[b] : NULL,
+                   j->traj_u ? &j->traj_u[(size_t)b * N * 12] : NULL,
+                   j->traj_x ? &j->traj_x[(size_t)b * (N + 1) * 13] : NULL, 0);
+  }
   return NULL;
 }
 
-int qo_solve_batch(const qmpc_params* p, int32_t batch, const qmpc_input* in, double* forces,
-                   qmpc_info* info, double* traj_u, double* traj_x, int32_t threads) {
+static int solve_batch_any(const qmpc_params* p, int32_t batch, const qmpc_input* in, const qmpc_input8* in8,
+                           double* forces, qmpc_info* info, double* traj_u, double* traj_x, int32_t threads) {
   if (threads < 1) threads = 1;
   if (threads > batch) threads = batch > 0 ? batch : 1;
   batch_job* jobs = (batch_job*)calloc((size_t)threads, sizeof(batch_job));
   pthread_t* tid = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
   for (int t = 0; t < threads; ++t) {
-    jobs[t].p = p; jobs[t].in = in; jobs[t].forces = forces; jobs[t].info = info;
+    jobs[t].p = p; jobs[t].in = in; jobs[t].in8 = in8; jobs[t].forces = forces; jobs[t].info = info;
     jobs[t].traj_u = traj_u; jobs[t].traj_x = traj_x;
     jobs[t].begin = (int)((long long)batch * t / threads);
     jobs[t].end = (int)((long long)batch * (t + 1) / threads);
@@ -276,13 +313,35 @@ int qo_solve_batch(const qmpc_params* p, int32_t batch, const qmpc_input* in, do
   return 0;
 }
 
+int qo_solve_batch(const qmpc_params* p, int32_t batch, const qmpc_input* in, double* forces,
+                   qmpc_info* info, double* traj_u, double* traj_x, int32_t threads) {
+  return solve_batch_any(p, batch, in, NULL, forces, info, traj_u, traj_x, threads);
+}
+int qo_solve8_batch(const qmpc_params* p, int32_t batch, const qmpc_input8* in, double* forces,
+                    qmpc_info* info, double* traj_u, double* traj_x, int32_t threads) {
+  return solve_batch_any(p, batch, NULL, in, forces, info, traj_u, traj_x, threads);
+}
+
+/* BASELINE.json config 5: SYNTHETIC 30 kg biped with two 0.2 x 0.1 m feet (4 corner
+ * contact points each); the humanoid branch itself is not in the reference checkout,
+ * so nothing upstream pins these values. */
+void qo_default_biped8_params(qmpc_params* p, int32_t horizon, int32_t mode) {
+  qo_default_params(p, horizon, mode);
+  p->model = QMPC_MODEL_QUAT8;
+  p->mass = 30.0;
+  memset(p->inertia, 0, sizeof p->inertia);
+  p->inertia[0] = 1.2; p->inertia[4] = 1.0; p->inertia[8] = 0.3;
+  p->fz_max = 250.0;
+}
+
 int qo_linearize(const qmpc_params* p, int32_t batch, const qmpc_input* in, double* Abar,
                  double* Bbar, double* X) {
   const int N = p->horizon;
   mpc_ctx* ctx = (mpc_ctx*)malloc(sizeof(mpc_ctx));
   qo_problem* prob = (qo_problem*)malloc(sizeof(qo_problem));
   for (int b = 0; b < batch; ++b) {
-    setup_problem(p, &in[b], ctx, prob);
+    const in_view v = view4(&in[b]);
+    setup_problem(p, &v, ctx, prob);
     double* Xb = &X[(size_t)b * (N + 1) * 13];
     memcpy(Xb, prob->x0, sizeof(double) * 13);
     double jac[13 * 25];

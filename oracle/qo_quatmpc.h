@@ -27,6 +27,13 @@ int qo_solve_one(const qmpc_params* p, const qmpc_input* in, double* forces, qmp
 int qo_solve_batch(const qmpc_params* p, int32_t batch, const qmpc_input* in, double* forces,
                    qmpc_info* info, double* traj_u, double* traj_x, int32_t threads);
 
+/* 8 contact points (BASELINE config 5, synthetic biped): forces 24 per instance */
+void qo_default_biped8_params(qmpc_params* p, int32_t horizon, int32_t mode);
+int qo_solve8_one(const qmpc_params* p, const qmpc_input8* in, double* forces, qmpc_info* info,
+                  double* traj_u, double* traj_x, int verbose);
+int qo_solve8_batch(const qmpc_params* p, int32_t batch, const qmpc_input8* in, double* forces,
+                    qmpc_info* info, double* traj_u, double* traj_x, int32_t threads);
+
 /* Linearisation only: rollout of U = u_ref from x0 and the projected
  * Jacobians (mirrors qmpc_linearize). */
 int qo_linearize(const qmpc_params* p, int32_t batch, const qmpc_input* in, double* Abar,

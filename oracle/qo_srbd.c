@@ -100,7 +100,8 @@ void qo_ct_srb_quat_dynamics(const qo_srbd_model* m, double* x_dot, const double
                              const double* u) {
   double fsum[3] = {0, 0, 0};
   double mom[3] = {m->moment_gravity[0], m->moment_gravity[1], m->moment_gravity[2]};
-  for (int i = 0; i < 4; ++i) {
+  const int nl = m->nleg ? m->nleg : 4;
+  for (int i = 0; i < nl; ++i) {
     const double* r = &m->foot_pos_body[3 * i];
     const double c = m->contacts[i];
     const double f[3] = {c * u[3 * i], c * u[3 * i + 1], c * u[3 * i + 2]};
@@ -126,7 +127,8 @@ void qo_ct_srb_quat_dynamics(const qo_srbd_model* m, double* x_dot, const double
 void qo_ct_srb_quat_jacobian(const qo_srbd_model* m, double* jac, const double* x,
                              const double* u) {
   (void)u;
-  memset(jac, 0, sizeof(double) * 13 * 25);
+  const int nl = m->nleg ? m->nleg : 4;
+  memset(jac, 0, sizeof(double) * 13 * (13 + 3 * nl));
 #define J(r, c) jac[(r) + 13 * (c)]
   /* dp_dot/dv */
   J(0, 7) = 1.0; J(1, 8) = 1.0; J(2, 9) = 1.0;
@@ -143,7 +145,7 @@ void qo_ct_srb_quat_jacobian(const qo_srbd_model* m, double* jac, const double* 
   J(5, 10) = 0.5 * x[6];  J(5, 11) = 0.5 * x[3];  J(5, 12) = -0.5 * x[4];
   J(6, 10) = -0.5 * x[5]; J(6, 11) = 0.5 * x[4];  J(6, 12) = 0.5 * x[3];
   /* d/du: dv_dot/df_i = I/m ; dw_dot/df_i = I^-1 skew(r_i) */
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < nl; ++i) {
     const double c = m->contacts[i];
     if (c == 0.0) continue; /* swing leg pinned: zero column block */
     double S[9], IS[9];
@@ -208,11 +210,11 @@ static void srbd_df(void* ctx, double* J, const double* x, const double* u) {
 }
 void qo_srbd_discrete_dynamics(const qo_srbd_model* m, double* xn, const double* x,
                                const double* u, float h) {
-  qo_midpoint_dynamics(13, 12, srbd_f, (void*)m, xn, x, u, h);
+  qo_midpoint_dynamics(13, 3 * (m->nleg ? m->nleg : 4), srbd_f, (void*)m, xn, x, u, h);
 }
 void qo_srbd_discrete_jacobian(const qo_srbd_model* m, double* jac, const double* x,
                                const double* u, float h) {
-  qo_midpoint_jacobian(13, 12, srbd_f, srbd_df, (void*)m, jac, x, u, h);
+  qo_midpoint_jacobian(13, 3 * (m->nleg ? m->nleg : 4), srbd_f, srbd_df, (void*)m, jac, x, u, h);
 }
 
 /* E(x) = blkdiag(I3, G(q), I3, I3): 13x12 row-major (AltroUtils.cpp:153-157) */
@@ -253,12 +255,16 @@ void qo_cone_block(double mu, const double rot[9], double CR[18]) {
 }
 
 /* QuatMpc.cpp:194-205: c_i = C_mat R u_i + (0,0,0,0,-fz_max*contact_i,0) */
-void qo_cone_eval(double mu, double fz_max, const double rot[9], const double contacts[4],
-                  const double* u, double* c) {
+void qo_cone_eval_n(int n, double mu, double fz_max, const double rot[9], const double* contacts,
+                    const double* u, double* c) {
   double CR[18];
   qo_cone_block(mu, rot, CR);
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < n; ++i) {
     qo_mv(6, 3, CR, 3, &u[3 * i], &c[6 * i]);
     c[6 * i + 4] += -fz_max * contacts[i];
   }
+}
+void qo_cone_eval(double mu, double fz_max, const double rot[9], const double contacts[4],
+                  const double* u, double* c) {
+  qo_cone_eval_n(4, mu, fz_max, rot, contacts, u, c);
 }

@@ -12,12 +12,13 @@ extern "C" {
 /* Per-instance constants of the model (what the reference's closures capture
  * by reference at QuatMpc.cpp:184-189). */
 typedef struct qo_srbd_model {
-  double foot_pos_body[12]; /* 3x4 col-major (Eigen layout)                  */
+  int nleg;                 /* contact points: 4 (Go1) or 8 (synthetic biped); 0 means 4 */
+  double foot_pos_body[24]; /* 3 x nleg col-major (Eigen layout)              */
   double inertia[9];        /* row-major                                     */
   double inertia_inv[9];    /* filled by qo_srbd_prepare                     */
   double mass;
   double rot[9];            /* torso_rot_mat body->world, row-major          */
-  double contacts[4];       /* 1 = stance; swing-leg forces are pinned to 0  */
+  double contacts[8];       /* 1 = stance; swing-leg forces are pinned to 0  */
   double g_body[3];         /* R' * (0,0,-9.81), filled by qo_srbd_prepare   */
   double moment_gravity[3]; /* c x (5.204 g_body), filled by prepare         */
 } qo_srbd_model;
@@ -57,7 +58,7 @@ void qo_midpoint_jacobian(int n, int m, qo_ct_dyn_fn f, qo_ct_jac_fn df, void* c
 /* SRBD-specialised wrappers used by the MPC oracle. */
 void qo_srbd_discrete_dynamics(const qo_srbd_model* m, double* xn, const double* x,
                                const double* u, float h);
-void qo_srbd_discrete_jacobian(const qo_srbd_model* m, double* jac /* 13x25 col-major */,
+void qo_srbd_discrete_jacobian(const qo_srbd_model* m, double* jac /* 13 x (13 + 3 nleg) col-major */,
                                const double* x, const double* u, float h);
 
 /* Attitude Jacobian E(x) = blkdiag(I3, G(q), I3, I3), 13 x 12 row-major
@@ -73,6 +74,9 @@ void qo_srbd_project(const double* jac, const double* x, const double* xn, doubl
 void qo_cone_block(double mu, const double rot[9], double CR[18]);
 void qo_cone_eval(double mu, double fz_max, const double rot[9], const double contacts[4],
                   const double* u, double* c);
+/* same for n contact points (6 n rows) */
+void qo_cone_eval_n(int n, double mu, double fz_max, const double rot[9], const double* contacts,
+                    const double* u, double* c);
 
 #ifdef __cplusplus
 }

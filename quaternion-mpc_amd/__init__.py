@@ -28,7 +28,7 @@ NX, NE, NU, NLEG, NC = 13, 12, 12, 4, 24
 OK, MAX_ITER, NO_CONTACT, NAN_INPUT, LINESEARCH_FAIL, NOT_PD = 0, 1, 2, 3, 4, 5
 BAD_ARGUMENT, NO_DEVICE, HIP_ERROR, BATCH_TOO_LARGE = 16, 17, 18, 19
 MODE_CONVERGED, MODE_REFERENCE = 0, 1
-MODEL_QUAT, MODEL_CONVEX = 0, 1
+MODEL_QUAT, MODEL_CONVEX, MODEL_QUAT8 = 0, 1, 2
 
 
 class Params(C.Structure):
@@ -93,6 +93,24 @@ INPUT_DTYPE = np.dtype(
     align=False,
 )
 assert INPUT_DTYPE.itemsize == 48 * 8
+
+# struct qmpc_input8 (8 contact points, BASELINE config 5): 64 doubles, 512 B
+INPUT8_DTYPE = np.dtype(
+    [
+        ("quat", "<f8", (4,)),
+        ("rot", "<f8", (9,)),
+        ("lin_vel_body", "<f8", (3,)),
+        ("ang_vel_body", "<f8", (3,)),
+        ("foot_pos_body", "<f8", (24,)),
+        ("contacts", "<f8", (8,)),
+        ("pos_ref_body", "<f8", (3,)),
+        ("vel_ref_body", "<f8", (3,)),
+        ("acc_ref_body", "<f8", (3,)),
+        ("quat_d", "<f8", (4,)),
+    ],
+    align=False,
+)
+assert INPUT8_DTYPE.itemsize == 64 * 8
 
 # struct qmpc_convex_input (ConvexMpc.cpp:81-198): 48 doubles, 384 B
 CONVEX_INPUT_DTYPE = np.dtype(
@@ -205,13 +223,24 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.qmpc_torque_map.restype = i32
     lib.qmpc_torque_map_device.argtypes = [vp, C.POINTER(LegGeometry), i32, vp, vp, vp, i32, vp, vp]
     lib.qmpc_torque_map_device.restype = i32
-    for name in ("qmpc_sizeof_input", "qmpc_sizeof_params", "qmpc_sizeof_info", "qmpc_sizeof_convex_input"):
+    lib.qmpc_default_biped8_params.argtypes = [C.POINTER(Params), i32, i32]
+    lib.qmpc_default_biped8_params.restype = None
+    lib.qmpc_solve8.argtypes = [vp, i32, vp, vp, vp]
+    lib.qmpc_solve8.restype = i32
+    lib.qmpc_solve8_traj.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    lib.qmpc_solve8_traj.restype = i32
+    lib.qmpc_solve8_device.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.qmpc_solve8_device.restype = i32
+    for name in ("qmpc_sizeof_input", "qmpc_sizeof_params", "qmpc_sizeof_info", "qmpc_sizeof_convex_input",
+                 "qmpc_sizeof_input8"):
         getattr(lib, name).argtypes = []
         getattr(lib, name).restype = i32
     if lib.qmpc_sizeof_input() != INPUT_DTYPE.itemsize:
         raise RuntimeError("qmpc_input ABI size mismatch")
     if lib.qmpc_sizeof_convex_input() != CONVEX_INPUT_DTYPE.itemsize:
         raise RuntimeError("qmpc_convex_input ABI size mismatch")
+    if lib.qmpc_sizeof_input8() != INPUT8_DTYPE.itemsize:
+        raise RuntimeError("qmpc_input8 ABI size mismatch")
     if lib.qmpc_sizeof_params() != C.sizeof(Params):
         raise RuntimeError("qmpc_params ABI size mismatch")
     if lib.qmpc_sizeof_info() != INFO_DTYPE.itemsize:
@@ -244,6 +273,11 @@ EXPORTED_SYMBOLS = (
     "qmpc_convex_solve_device",
     "qmpc_convex_linearize",
     "qmpc_sizeof_convex_input",
+    "qmpc_default_biped8_params",
+    "qmpc_solve8",
+    "qmpc_solve8_traj",
+    "qmpc_solve8_device",
+    "qmpc_sizeof_input8",
     "qmpc_default_go1_geometry",
     "qmpc_leg_kinematics",
     "qmpc_torque_map",
@@ -263,6 +297,14 @@ def default_convex_params(horizon: int = 20, mode: int = MODE_CONVERGED, lib: C.
     lib = lib or load_library()
     p = Params()
     lib.qmpc_default_convex_params(C.byref(p), horizon, mode)
+    return p
+
+
+def default_biped8_params(horizon: int = 16, mode: int = MODE_CONVERGED, lib: C.CDLL | None = None) -> Params:
+    """Synthetic 8-contact-point biped of BASELINE config 5 (params.model = MODEL_QUAT8)."""
+    lib = lib or load_library()
+    p = Params()
+    lib.qmpc_default_biped8_params(C.byref(p), horizon, mode)
     return p
 
 
@@ -329,6 +371,31 @@ class Solver:
         if st != OK:
             raise QmpcError(st, "qmpc_last_kernel_ms")
         return float(ms.value)
+
+    # ---- 8 contact points (handle created with params.model = MODEL_QUAT8) ----
+    def solve8(self, inputs: np.ndarray, want_traj: bool = False):
+        inputs = np.ascontiguousarray(inputs, dtype=INPUT8_DTYPE)
+        B, N = inputs.shape[0], self.params.horizon
+        forces = np.zeros((B, 24), dtype=np.float64)
+        info = np.zeros(B, dtype=INFO_DTYPE)
+        if want_traj:
+            tu = np.zeros((B, N, 24))
+            tx = np.zeros((B, N + 1, NX))
+            st = self.lib.qmpc_solve8_traj(self._h, B, _ptr(inputs), _ptr(forces), _ptr(info), _ptr(tu), _ptr(tx))
+            if st != OK:
+                raise QmpcError(st, "qmpc_solve8_traj")
+            return forces, info, tu, tx
+        st = self.lib.qmpc_solve8(self._h, B, _ptr(inputs), _ptr(forces), _ptr(info))
+        if st != OK:
+            raise QmpcError(st, "qmpc_solve8")
+        return forces, info
+
+    def solve8_device(self, batch: int, d_in: int, d_forces: int, d_info: int, stream: int = 0):
+        st = self.lib.qmpc_solve8_device(self._h, int(batch), C.c_void_p(d_in), C.c_void_p(d_forces),
+                                         C.c_void_p(d_info) if d_info else None,
+                                         C.c_void_p(stream) if stream else None)
+        if st != OK:
+            raise QmpcError(st, "qmpc_solve8_device")
 
     # ---- ConvexMpc model (handle created with params.model = MODEL_CONVEX) ----
     def convex_solve(self, inputs: np.ndarray, want_traj: bool = False):
@@ -422,5 +489,5 @@ class Solver:
 
 
 from .scenarios import (go1_stand_input, quat_to_rot, random_go1_trot_states,  # noqa: E402,F401
-                        random_go1_convex_states)
+                        random_go1_convex_states, random_biped8_states)
 from .sharding import gather_forces, shard_range, solve_sharded  # noqa: E402,F401

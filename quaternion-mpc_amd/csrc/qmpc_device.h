@@ -50,30 +50,43 @@ struct Layout {
 // Per-knot record sizes
 constexpr int kAB = 27;    // Aphiphi(9) Aphiw(9) W(9)
 constexpr int kXT = 21;    // lxx attitude block (9), lx (12)
-constexpr int kKD = 156;   // gains [K | d], 12 x 13 row-major
-constexpr int kROT = 84;   // per leg: T(9), Dblk(9), gq(3)
+constexpr int kKD = 156;   // gains [K | d], 12 x 13 row-major            (4 contact points)
+constexpr int kROT = 84;   // per leg: T(9), Dblk(9), gq(3)                (4 contact points)
+
+// Sizes and cst[] slots for NL contact points (4: Go1, the reference; 8: the synthetic biped of
+// BASELINE config 5).  Inputs come in tiles of 12 (= 4 contact points = one [12][16] MFMA tile).
+template <int NL>
+struct Dim {
+  static constexpr int NLEG = NL, NU = 3 * NL, NC = 6 * NL, TU = NL / 4;
+  static constexpr int KD = 13 * NU, ROT = 21 * NL;        // per-knot gains / rotation blocks
+  static constexpr int C_FOOT = 0, C_GB = 3 * NL, C_WD0 = C_GB + 3, C_CR = C_WD0 + 3, C_CON = C_CR + 18,
+                       C_X0 = C_CON + NL;
+  static constexpr int REC = 32 + 4 * NL;                  // doubles per input record (48 / 64)
+  static constexpr int R_FOOT = 19, R_CON = 19 + 3 * NL, R_POS = 19 + 4 * NL, R_QD = R_POS + 9;
+};
 
 // kd_global: the per-knot gains KD and rotation blocks ROT (the two largest
 // arrays) live in an HBM/L2-resident workspace instead of LDS; N=20 then fits 4
 // instances per CU (36 KB) instead of 2 (75 KB), N=10 fits 8 (19 KB).
-__host__ __device__ inline Layout make_layout(int N, bool kd_global = false) {
+__host__ __device__ inline Layout make_layout(int N, bool kd_global = false, int nl = 4) {
   Layout L;
   int o = 0;
   auto take = [&](int n) { int r = o; o += n; return r; };
-  L.cst = take(64);
-  L.bw0 = take(36);
+  const int nu = 3 * nl, nc = 6 * nl;
+  L.cst = take(nl == 4 ? 64 : 80);
+  L.bw0 = take(3 * nu);
   L.refp = take(13);
-  L.uref = take(12);
-  L.ub = take(24);       // 2 broadcast slots (ping-pong): candidate input of the current knot
+  L.uref = take(nu);
+  L.ub = -1;
   L.X = take((N + 1) * 13);
-  L.U = take(N * 12);
+  L.U = take(N * nu);
   L.Xc = take((N + 1) * 13);
-  L.dU = take(N * 12);   // candidate input increment alpha d + K dx (kept as computed)
-  L.S = take(N * 24);
-  L.LAM = take(N * 24);
-  L.DS = take(N * 24);
-  L.DLAM = take(N * 24);
-  L.RC = take(N * 24);   // slack residual c(u) + s, tracked analytically
+  L.dU = take(N * nu);   // candidate input increment alpha d + K dx (kept as computed)
+  L.S = take(N * nc);
+  L.LAM = take(N * nc);
+  L.DS = take(N * nc);
+  L.DLAM = take(N * nc);
+  L.RC = take(N * nc);   // slack residual c(u) + s, tracked analytically
   L.AB = take(N * kAB);
   L.XT = take((N + 1) * kXT);
   if (kd_global) {
@@ -81,8 +94,8 @@ __host__ __device__ inline Layout make_layout(int N, bool kd_global = false) {
     L.ROT = -1;
     L.tile = L.S;    // set-up scratch aliases the (not yet initialised) slack array
   } else {
-    L.KD = take(N * kKD);
-    L.ROT = take(N * kROT);
+    L.KD = take(N * 13 * nu);
+    L.ROT = take(N * 21 * nl);
     o = (o + 1) & ~1;
     L.tile = take(MAT);
   }
@@ -229,41 +242,70 @@ __device__ __forceinline__ void quat_Omega(const double* w, double O[16]) {
 }
 
 // Model constants of one instance held in registers by the rollouts.
-struct ModelRegs {
-  double con[4], gb[3], wd0[3], bw[36];
+// NL = 4: Bw0 = Iinv skew(r_l) c_l (36 numbers); NL = 8: the masked contact points c_l r_l (24 numbers) and
+// the torque is formed with cross products (72 numbers of Bw0 would not fit the register budget).
+template <int NL>
+struct ModelRegsT {
+  double con[NL], gb[3], wd0[3], bw[NL == 4 ? 36 : 3 * NL];
   __device__ __forceinline__ void load(const double* cst, const double* bw0) {
+    typedef Dim<NL> D;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) con[i] = cst[C_CON + i];
+    for (int i = 0; i < NL; ++i) con[i] = cst[D::C_CON + i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { gb[i] = cst[C_GB + i]; wd0[i] = cst[C_WD0 + i]; }
+    for (int i = 0; i < 3; ++i) { gb[i] = cst[D::C_GB + i]; wd0[i] = cst[D::C_WD0 + i]; }
+    if (NL == 4) {
 #pragma unroll
-    for (int i = 0; i < 36; ++i) bw[i] = bw0[i];
+      for (int i = 0; i < 36; ++i) bw[i] = bw0[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3 * NL; ++i) bw[i] = con[i / 3] * cst[D::C_FOOT + i];
+    }
   }
 };
+typedef ModelRegsT<4> ModelRegs;
 
 // Explicit-midpoint step of the quaternion SRBD (AltroUtils.cpp:9-22 applied to
 // :363-392).  vdot and wdot do not depend on the state, so both midpoint
 // evaluations share them.  x, xn: 13 doubles in registers.
-__device__ __forceinline__ void srbd_step(const DevParams& P, const ModelRegs& M, const double* x,
+template <int NL>
+__device__ __forceinline__ void srbd_step(const DevParams& P, const ModelRegsT<NL>& M, const double* x,
                                           const double* u, double* xn) {
   double F[3] = {0, 0, 0};
 #pragma unroll
-  for (int l = 0; l < 4; ++l) {
+  for (int l = 0; l < NL; ++l) {
     const double c = M.con[l];
     F[0] += c * u[3 * l]; F[1] += c * u[3 * l + 1]; F[2] += c * u[3 * l + 2];
   }
   double vd[3], wd[3];
+  if (NL == 4) {
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    vd[a] = F[a] * P.inv_mass + M.gb[a];
-    // four independent partial sums: the wave has no other work to hide a 12-deep FMA chain
-    const double* b = &M.bw[12 * a];
-    const double s0 = M.wd0[a] + b[0] * u[0] + b[1] * u[1] + b[2] * u[2];
-    const double s1 = b[3] * u[3] + b[4] * u[4] + b[5] * u[5];
-    const double s2 = b[6] * u[6] + b[7] * u[7] + b[8] * u[8];
-    const double s3 = b[9] * u[9] + b[10] * u[10] + b[11] * u[11];
-    wd[a] = (s0 + s1) + (s2 + s3);
+    for (int a = 0; a < 3; ++a) {
+      // four independent partial sums: the wave has no other work to hide a 12-deep FMA chain
+      const double* b = &M.bw[12 * a];
+      const double s0 = M.wd0[a] + b[0] * u[0] + b[1] * u[1] + b[2] * u[2];
+      const double s1 = b[3] * u[3] + b[4] * u[4] + b[5] * u[5];
+      const double s2 = b[6] * u[6] + b[7] * u[7] + b[8] * u[8];
+      const double s3 = b[9] * u[9] + b[10] * u[10] + b[11] * u[11];
+      wd[a] = (s0 + s1) + (s2 + s3);
+    }
+  } else {
+    // torque of the stance points about the CoM, then wd = wd0 + Iinv tau
+    double t0[2] = {0, 0}, t1[2] = {0, 0}, t2[2] = {0, 0};
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const double* r = &M.bw[3 * l];
+      const double* f = &u[3 * l];
+      t0[l & 1] += r[1] * f[2] - r[2] * f[1];
+      t1[l & 1] += r[2] * f[0] - r[0] * f[2];
+      t2[l & 1] += r[0] * f[1] - r[1] * f[0];
+    }
+    const double tau[3] = {t0[0] + t0[1], t1[0] + t1[1], t2[0] + t2[1]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      wd[a] = M.wd0[a] + (P.Iinv[3 * a] * tau[0] + P.Iinv[3 * a + 1] * tau[1] + P.Iinv[3 * a + 2] * tau[2]);
   }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) vd[a] = F[a] * P.inv_mass + M.gb[a];
   // midpoint state
   double G[12];
   quat_G(&x[3], G);
@@ -304,6 +346,7 @@ __device__ __forceinline__ void xref_at(const DevParams& P, const double* refp, 
 //      Bbar = [ (h^2/2m) c_i I ; (h/4) W (h Bw0) ; (h/m) c_i I ; h Bw0 ]
 //  - cost gradient lx(12) and attitude Hessian block lxx(9) in error coordinates
 //    (w (1 - |qref'q|) term)
+template <int NL>
 __device__ inline void expand_knot(const DevParams& P, const double* cst, const double* bw0,
                                    const double* refp, int k, const double* x, const double* u,
                                    const double* xn, double* AB, double* lx, double* lxx) {
@@ -312,8 +355,8 @@ __device__ inline void expand_knot(const DevParams& P, const double* cst, const 
     double wd[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      double s = cst[C_WD0 + a];
-      for (int j = 0; j < 12; ++j) s += bw0[12 * a + j] * u[j];
+      double s = cst[Dim<NL>::C_WD0 + a];
+      for (int j = 0; j < 3 * NL; ++j) s += bw0[3 * NL * a + j] * u[j];
       wd[a] = s;
     }
     double G0[12], Gm[12], Gn[12], O0[16], Om[16];
@@ -451,13 +494,16 @@ struct CostPattern {
   int xoff[3];
 };
 
-struct QuatModel {
+template <int NL_>
+struct QuatModelT {
   static constexpr int NX = 13;
-  typedef ModelRegs Regs;
+  static constexpr int NL = NL_;
+  typedef Dim<NL_> D;
+  typedef ModelRegsT<NL_> Regs;
 
   static __device__ __forceinline__ void step(const DevParams& P, const Regs& M, const double* x,
                                               const double* u, double* xn) {
-    srbd_step(P, M, x, u, xn);
+    srbd_step<NL_>(P, M, x, u, xn);
   }
   // dx = xc (-) xo : inverse Cayley map of xo.q^-1 * xc.q (QuaternionUtils.cpp:16-18)
   static __device__ __forceinline__ void state_diff(const double* xo, const double* xc, double* dx) {
@@ -477,7 +523,7 @@ struct QuatModel {
   static __device__ __forceinline__ void expand(const DevParams& P, const double* cst, const double* bw0,
                                                 const double* refp, int k, const double* x, const double* u,
                                                 const double* xn, double* AB, double* lx, double* lxx) {
-    expand_knot(P, cst, bw0, refp, k, x, u, xn, AB, lx, lxx);
+    expand_knot<NL_>(P, cst, bw0, refp, k, x, u, xn, AB, lx, lxx);
   }
   // un-augmented objective of knot k (u == nullptr at the terminal knot)
   static __device__ __forceinline__ double knot_cost(const DevParams& P, const double* refp, const double* uref,
@@ -489,13 +535,13 @@ struct QuatModel {
     const double dq = xr[3] * x[3] + xr[4] * x[4] + xr[5] * x[5] + xr[6] * x[6];
     J += P.w * (1.0 - fabs(dq));
     if (u)
-      for (int j = 0; j < 12; ++j) { const double e = u[j] - uref[j]; J += 0.5 * P.R[j] * e * e; }
+      for (int j = 0; j < D::NU; ++j) { const double e = u[j] - uref[j]; J += 0.5 * P.R[j % 12] * e * e; }
     return J;
   }
 
-  // operand patterns of the backward pass for fragment rows r_e = 4e + g, column c
+  // operand patterns of the backward pass for fragment rows r_e = 4e + g, column c of input tile t
   struct Operands {
-    double Ac[3], Bc[3][3], hbw[3][3];
+    double Ac[3], Bc[D::TU][3][3], hbw[D::TU][3][3];
     int aoff[3];
     bool phi[3];
     int g;
@@ -505,11 +551,12 @@ struct QuatModel {
       g = lane >> 4;
       const bool cval = c < 12;
       const int lc = cval ? c / 3 : 0;
-      const double conl = cval ? cst[C_CON + lc] : 0.0;
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
+      for (int t = 0; t < D::TU; ++t)
 #pragma unroll
-        for (int a = 0; a < 3; ++a) hbw[j][a] = cval ? P.h * bw0[12 * j + 3 * lc + a] : 0.0;
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int a = 0; a < 3; ++a) hbw[t][j][a] = cval ? P.h * bw0[D::NU * j + 12 * t + 3 * lc + a] : 0.0;
 #pragma unroll
       for (int e = 0; e < 3; ++e) {
         const int r = 4 * e + g;
@@ -523,32 +570,42 @@ struct QuatModel {
         if (phi[e] && c >= 3 && c < 6) cp.xoff[e] = 3 * (r - 3) + (c - 3);
         if (c == 12) cp.xoff[e] = 9 + r;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          double v = 0.0;
-          if (cval) {
-            if (r < 3) v = (r == a) ? conl * (P.h * (P.hh * (1.0 / P.mass))) : 0.0;
-            else if (r >= 6 && r < 9) v = (r - 6 == a) ? conl * (P.h * (1.0 / P.mass)) : 0.0;
-            else if (r >= 9) v = P.h * bw0[12 * (r - 9) + 3 * lc + a];
+        for (int t = 0; t < D::TU; ++t) {
+          const double conl = cval ? cst[D::C_CON + 4 * t + lc] : 0.0;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            double v = 0.0;
+            if (cval) {
+              if (r < 3) v = (r == a) ? conl * (P.h * (P.hh * (1.0 / P.mass))) : 0.0;
+              else if (r >= 6 && r < 9) v = (r - 6 == a) ? conl * (P.h * (1.0 / P.mass)) : 0.0;
+              else if (r >= 9) v = P.h * bw0[D::NU * (r - 9) + 12 * t + 3 * lc + a];
+            }
+            Bc[t][e][a] = v;
           }
-          Bc[e][a] = v;
         }
       }
     }
-    // Abar and rotated Bbar*T (t = column bc of the leg's frame T) straight into fragments
-    __device__ __forceinline__ void build(const DevParams& P, const double* ABk, double t0, double t1, double t2,
-                                          double Afo[3], double Bfo[3]) const {
+    // Abar and rotated Bbar*T (tc[t] = column bc of the frame T of the lane's leg in tile t) straight into fragments
+    __device__ __forceinline__ void build(const DevParams& P, const double* ABk, const double tc[][3],
+                                          double Afo[3], double Bfo[][3]) const {
 #pragma unroll
       for (int e = 0; e < 3; ++e) {
         Afo[e] = (aoff[e] >= 0) ? ABk[aoff[e]] : Ac[e];
-        double b0 = Bc[e][0], b1 = Bc[e][1], b2 = Bc[e][2];
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0;
         if (phi[e]) {
           const double* W = ABk + 18 + 3 * (4 * e + g - 3);
-          const double w0 = W[0], w1 = W[1], w2 = W[2];
-          b0 = (0.5 * P.hh) * (w0 * hbw[0][0] + w1 * hbw[1][0] + w2 * hbw[2][0]);
-          b1 = (0.5 * P.hh) * (w0 * hbw[0][1] + w1 * hbw[1][1] + w2 * hbw[2][1]);
-          b2 = (0.5 * P.hh) * (w0 * hbw[0][2] + w1 * hbw[1][2] + w2 * hbw[2][2]);
+          w0 = W[0]; w1 = W[1]; w2 = W[2];
         }
-        Bfo[e] = b0 * t0 + b1 * t1 + b2 * t2;
+#pragma unroll
+        for (int t = 0; t < D::TU; ++t) {
+          double b0 = Bc[t][e][0], b1 = Bc[t][e][1], b2 = Bc[t][e][2];
+          if (phi[e]) {
+            b0 = (0.5 * P.hh) * (w0 * hbw[t][0][0] + w1 * hbw[t][1][0] + w2 * hbw[t][2][0]);
+            b1 = (0.5 * P.hh) * (w0 * hbw[t][0][1] + w1 * hbw[t][1][1] + w2 * hbw[t][2][1]);
+            b2 = (0.5 * P.hh) * (w0 * hbw[t][0][2] + w1 * hbw[t][1][2] + w2 * hbw[t][2][2]);
+          }
+          Bfo[t][e] = b0 * tc[t][0] + b1 * tc[t][1] + b2 * tc[t][2];
+        }
       }
     }
   };
@@ -562,6 +619,8 @@ struct QuatModel {
     return bbar_elem(P, cst, bw0, AB, r, c);
   }
 };
+typedef QuatModelT<4> QuatModel;
+typedef QuatModelT<8> Quat8Model;   // BASELINE config 5: the same problem with 8 contact points (synthetic biped)
 
 // ---- legged::ConvexMpc's model ------------------------------------------------
 // state x = [roll pitch yaw, pos(3), ang_vel_world(3), lin_vel_world(3)], inputs =
@@ -587,6 +646,8 @@ struct ConvexRegs {
 
 struct ConvexModel {
   static constexpr int NX = 12;
+  static constexpr int NL = 4;
+  typedef Dim<4> D;
   typedef ConvexRegs Regs;
 
   // Iw(yaw)^-1 tau with c = cos(yaw), s = sin(yaw)
@@ -765,8 +826,9 @@ struct ConvexModel {
         }
       }
     }
-    __device__ __forceinline__ void build(const DevParams& P, const double* ABk, double t0, double t1, double t2,
-                                          double Afo[3], double Bfo[3]) const {
+    __device__ __forceinline__ void build(const DevParams& P, const double* ABk, const double tc[][3],
+                                          double Afo[3], double Bfo[][3]) const {
+      const double t0 = tc[0][0], t1 = tc[0][1], t2 = tc[0][2];
 #pragma unroll
       for (int e = 0; e < 3; ++e) {
         Afo[e] = (aoff[e] >= 0) ? asc[e] * ABk[aoff[e]] : Ac[e];
@@ -777,7 +839,7 @@ struct ConvexModel {
           b1 = m0 * sk[0][1] + m1 * sk[1][1] + m2 * sk[2][1];
           b2 = m0 * sk[0][2] + m1 * sk[1][2] + m2 * sk[2][2];
         }
-        Bfo[e] = b0 * t0 + b1 * t1 + b2 * t2;
+        Bfo[0][e] = b0 * t0 + b1 * t1 + b2 * t2;
       }
     }
   };

@@ -53,6 +53,9 @@ int32_t qmpc_sizeof_input(void) { return (int32_t)sizeof(qmpc_input); }
 int32_t qmpc_sizeof_params(void) { return (int32_t)sizeof(qmpc_params); }
 int32_t qmpc_sizeof_info(void) { return (int32_t)sizeof(qmpc_info); }
 int32_t qmpc_sizeof_convex_input(void) { return (int32_t)sizeof(qmpc_convex_input); }
+int32_t qmpc_sizeof_input8(void) { return (int32_t)sizeof(qmpc_input8); }
+static_assert(sizeof(qmpc_input8) == 8 * Dim<8>::REC && sizeof(qmpc_input) == 8 * Dim<4>::REC, "record sizes");
+static int model_nl(int model) { return model == QMPC_MODEL_QUAT8 ? 8 : 4; }
 static_assert(sizeof(qmpc_convex_input) == sizeof(qmpc_input), "both records are 48 doubles");
 
 const char* qmpc_status_string(int32_t s) {
@@ -128,10 +131,22 @@ void qmpc_default_convex_params(qmpc_params* p, int32_t horizon, int32_t mode) {
   if (mode == QMPC_MODE_REFERENCE) p->iterations_max = 5;   // ConvexMpc.cpp:37
 }
 
+// BASELINE.json config 5: SYNTHETIC 30 kg biped, two 0.2 x 0.1 m feet with 4 corner contact points
+// each.  The humanoid branch is not in the reference checkout; nothing upstream pins these values.
+void qmpc_default_biped8_params(qmpc_params* p, int32_t horizon, int32_t mode) {
+  qmpc_default_params(p, horizon, mode);
+  p->model = QMPC_MODEL_QUAT8;
+  p->mass = 30.0;
+  std::memset(p->inertia, 0, sizeof p->inertia);
+  p->inertia[0] = 1.2; p->inertia[4] = 1.0; p->inertia[8] = 0.3;
+  p->fz_max = 250.0;
+}
+
 static int fill_dev_params(const qmpc_params* p, DevParams* d) {
   if (!p || p->horizon < 1 || p->horizon > QMPC_MAX_HORIZON) return QMPC_BAD_ARGUMENT;
   if (p->mode != QMPC_MODE_CONVERGED) return QMPC_BAD_ARGUMENT;  // device path: converged mode
-  if (p->model != QMPC_MODEL_QUAT && p->model != QMPC_MODEL_CONVEX) return QMPC_BAD_ARGUMENT;
+  if (p->model != QMPC_MODEL_QUAT && p->model != QMPC_MODEL_CONVEX && p->model != QMPC_MODEL_QUAT8)
+    return QMPC_BAD_ARGUMENT;
   if (!(p->mass > 0.0) || !(p->h > 0.0f) || !(p->ipm_mu0 > 0.0)) return QMPC_BAD_ARGUMENT;
   std::memset(d, 0, sizeof *d);
   d->N = p->horizon;
@@ -201,7 +216,8 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
   h->device = device;
   h->max_batch = max_batch;
   const int N = params->horizon;
-  const Layout L = make_layout(N, false), Lg = make_layout(N, true);
+  const int nl = model_nl(params->model), nu = 3 * nl;
+  const Layout L = make_layout(N, false, nl), Lg = make_layout(N, true, nl);
   h->lds_bytes = (size_t)L.total * sizeof(double);
   h->lds_bytes_g = (size_t)Lg.total * sizeof(double);
   if (h->lds_bytes_g > 160 * 1024) { delete h; return QMPC_BAD_ARGUMENT; }
@@ -212,12 +228,14 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&h->ev0));
   HIP_TRY(hipEventCreate(&h->ev1));
-  HIP_TRY(hipMalloc(&h->d_in, sizeof(qmpc_input) * (size_t)max_batch));
-  HIP_TRY(hipMalloc(&h->d_forces, sizeof(double) * 12 * (size_t)max_batch));
+  HIP_TRY(hipMalloc(&h->d_in, sizeof(double) * (32 + 4 * nl) * (size_t)max_batch));
+  HIP_TRY(hipMalloc(&h->d_forces, sizeof(double) * nu * (size_t)max_batch));
   HIP_TRY(hipMalloc(&h->d_info, sizeof(qmpc_info) * (size_t)max_batch));
 #define QMPC_SET_LDS(kern, bytes) \
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
-  if (params->model == QMPC_MODEL_CONVEX) {
+  if (params->model == QMPC_MODEL_QUAT8) {
+    QMPC_SET_LDS((qmpc_solve_kernel<Quat8Model, false, true>), h->lds_bytes_g);   // global gains only
+  } else if (params->model == QMPC_MODEL_CONVEX) {
     if (h->lds_bytes <= 160 * 1024) QMPC_SET_LDS((qmpc_solve_kernel<ConvexModel, false, false>), h->lds_bytes);
     QMPC_SET_LDS((qmpc_solve_kernel<ConvexModel, false, true>), h->lds_bytes_g);
     QMPC_SET_LDS(qmpc_linearize_kernel<ConvexModel>, h->lds_bytes_g);
@@ -231,7 +249,7 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     QMPC_SET_LDS(qmpc_linearize_kernel<QuatModel>, h->lds_bytes_g);
   }
 #undef QMPC_SET_LDS
-  HIP_TRY(hipMalloc(&h->d_gws, sizeof(double) * (size_t)N * (kKD + kROT) * (size_t)max_batch));
+  HIP_TRY(hipMalloc(&h->d_gws, sizeof(double) * (size_t)N * (13 * nu + 21 * nl) * (size_t)max_batch));
   *out = h;
   return QMPC_OK;
 }
@@ -258,6 +276,7 @@ void qmpc_destroy(qmpc_handle* h) {
 // LDS (lowest latency); long horizons and large batches move the gains to the
 // workspace to raise the number of resident instances.
 static bool use_global_gains(const qmpc_handle* h, int32_t batch) {
+  if (h->params.model == QMPC_MODEL_QUAT8) return true;
   if (h->variant == 1) return h->lds_bytes > 160 * 1024 ? true : false;
   if (h->variant == 2) return true;
   if (h->lds_bytes > 40 * 1024) return true;   // fewer than 4 instances per CU otherwise
@@ -274,7 +293,9 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
 #define QMPC_LAUNCH(kern) \
   hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kWave), lds, s, h->dev, d_in, d_forces, d_info, d_tu, d_tx, \
                      (int)batch, (long long*)nullptr, gws)
-  if (h->params.model == QMPC_MODEL_CONVEX) {
+  if (h->params.model == QMPC_MODEL_QUAT8) {
+    QMPC_LAUNCH((qmpc_solve_kernel<Quat8Model, false, true>));
+  } else if (h->params.model == QMPC_MODEL_CONVEX) {
     if (gg) QMPC_LAUNCH((qmpc_solve_kernel<ConvexModel, false, true>));
     else QMPC_LAUNCH((qmpc_solve_kernel<ConvexModel, false, false>));
   } else {
@@ -296,6 +317,16 @@ qmpc_status qmpc_solve_device(qmpc_handle* h, int32_t batch, const qmpc_input* d
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   return launch_solve(h, batch, d_in, d_forces_body, d_info, nullptr, nullptr, s);
+}
+
+qmpc_status qmpc_solve8_device(qmpc_handle* h, int32_t batch, const qmpc_input8* d_in, double* d_forces_body,
+                               qmpc_info* d_info, void* stream) {
+  if (!h || batch < 0 || (batch > 0 && (!d_in || !d_forces_body))) return QMPC_BAD_ARGUMENT;
+  if (h->params.model != QMPC_MODEL_QUAT8) return QMPC_BAD_ARGUMENT;
+  if (batch == 0) return QMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  return launch_solve(h, batch, reinterpret_cast<const qmpc_input*>(d_in), d_forces_body, d_info, nullptr, nullptr, s);
 }
 
 qmpc_status qmpc_convex_solve_device(qmpc_handle* h, int32_t batch, const qmpc_convex_input* d_in,
@@ -333,15 +364,17 @@ static qmpc_status solve_host(qmpc_handle* h, int32_t batch, const qmpc_input* i
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
   HIP_TRY(hipSetDevice(h->device));
   const int N = h->params.horizon;
-  if (traj_u && !h->d_traj_u) HIP_TRY(hipMalloc(&h->d_traj_u, sizeof(double) * 12 * N * (size_t)h->max_batch));
+  const int nl = model_nl(model), nu = 3 * nl;
+  const size_t rec = sizeof(double) * (32 + 4 * nl);
+  if (traj_u && !h->d_traj_u) HIP_TRY(hipMalloc(&h->d_traj_u, sizeof(double) * nu * N * (size_t)h->max_batch));
   if (traj_x && !h->d_traj_x) HIP_TRY(hipMalloc(&h->d_traj_x, sizeof(double) * 13 * (N + 1) * (size_t)h->max_batch));
-  HIP_TRY(hipMemcpyAsync(h->d_in, in, sizeof(qmpc_input) * (size_t)batch, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_in, in, rec * (size_t)batch, hipMemcpyHostToDevice, h->stream));
   const qmpc_status st = launch_solve(h, batch, h->d_in, h->d_forces, h->d_info, traj_u ? h->d_traj_u : nullptr,
                                       traj_x ? h->d_traj_x : nullptr, h->stream);
   if (st != QMPC_OK) return st;
-  HIP_TRY(hipMemcpyAsync(forces_body, h->d_forces, sizeof(double) * 12 * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(forces_body, h->d_forces, sizeof(double) * nu * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   if (info) HIP_TRY(hipMemcpyAsync(info, h->d_info, sizeof(qmpc_info) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
-  if (traj_u) HIP_TRY(hipMemcpyAsync(traj_u, h->d_traj_u, sizeof(double) * 12 * N * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+  if (traj_u) HIP_TRY(hipMemcpyAsync(traj_u, h->d_traj_u, sizeof(double) * nu * N * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   if (traj_x) HIP_TRY(hipMemcpyAsync(traj_x, h->d_traj_x, sizeof(double) * nx * (N + 1) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return QMPC_OK;
@@ -350,6 +383,16 @@ static qmpc_status solve_host(qmpc_handle* h, int32_t batch, const qmpc_input* i
 qmpc_status qmpc_solve_traj(qmpc_handle* h, int32_t batch, const qmpc_input* in, double* forces_body,
                             qmpc_info* info, double* traj_u, double* traj_x) {
   return solve_host(h, batch, in, forces_body, info, traj_u, traj_x, QMPC_MODEL_QUAT, 13);
+}
+
+qmpc_status qmpc_solve8_traj(qmpc_handle* h, int32_t batch, const qmpc_input8* in, double* forces_body,
+                             qmpc_info* info, double* traj_u, double* traj_x) {
+  return solve_host(h, batch, reinterpret_cast<const qmpc_input*>(in), forces_body, info, traj_u, traj_x,
+                    QMPC_MODEL_QUAT8, 13);
+}
+
+qmpc_status qmpc_solve8(qmpc_handle* h, int32_t batch, const qmpc_input8* in, double* forces_body, qmpc_info* info) {
+  return qmpc_solve8_traj(h, batch, in, forces_body, info, nullptr, nullptr);
 }
 
 qmpc_status qmpc_convex_solve_traj(qmpc_handle* h, int32_t batch, const qmpc_convex_input* in, double* forces_world,

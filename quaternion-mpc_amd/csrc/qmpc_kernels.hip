@@ -46,17 +46,18 @@ struct Prof {
 template <class MD>
 __device__ inline void model_setup(const DevParams& P, const Layout& L, double* sm, const double* raw, int lane, int nc);
 
-// QuatMpc record (qmpc_input): quat 0..3, rot 4..12, linvel 13..15, angvel 16..18, foot 19..30,
-//      contacts 31..34, posref 35..37, velref 38..40, accref 41..43, quat_d 44..47
-template <>
-__device__ inline void model_setup<QuatModel>(const DevParams& P, const Layout& L, double* sm, const double* raw,
-                                              int lane, int nc) {
+// QuatMpc record (qmpc_input / qmpc_input8): quat 0..3, rot 4..12, linvel 13..15, angvel 16..18,
+//      foot 19.., contacts, posref, velref, accref, quat_d (offsets Dim<NL>::R_*)
+template <int NL>
+__device__ inline void quat_setup(const DevParams& P, const Layout& L, double* sm, const double* raw, int lane,
+                                  int nc) {
+  typedef Dim<NL> D;
   double* cst = sm + L.cst;
-  if (lane < 12) cst[C_FOOT + lane] = raw[19 + lane];
-  if (lane < 4) cst[C_CON + lane] = (raw[31 + lane] != 0.0) ? 1.0 : 0.0;
+  if (lane < D::NU) cst[D::C_FOOT + lane] = raw[D::R_FOOT + lane];
+  if (lane < NL) cst[D::C_CON + lane] = (raw[D::R_CON + lane] != 0.0) ? 1.0 : 0.0;
   if (lane < 3) {
     // g_body = R' (0,0,-9.81)  (AltroUtils.cpp:368-371)
-    cst[C_GB + lane] = raw[4 + 6 + lane] * (-9.81);
+    cst[D::C_GB + lane] = raw[4 + 6 + lane] * (-9.81);
   }
   if (lane < 13) {
     // x_init (QuatMpc.cpp:231-246; angular velocity dropped by the ';' at :242)
@@ -64,14 +65,14 @@ __device__ inline void model_setup<QuatModel>(const DevParams& P, const Layout& 
     if (lane >= 3 && lane < 7) x0 = raw[lane - 3];
     else if (lane >= 7 && lane < 10) x0 = raw[13 + lane - 7];
     else if (lane >= 10) x0 = P.drop_ang_vel ? 0.0 : raw[16 + lane - 10];
-    cst[C_X0 + lane] = x0;
+    cst[D::C_X0 + lane] = x0;
     // reference parameters: pos vel acc quat_d
-    sm[L.refp + lane] = (lane < 9) ? raw[35 + lane] : raw[44 + lane - 9];
+    sm[L.refp + lane] = (lane < 9) ? raw[D::R_POS + lane] : raw[D::R_QD + lane - 9];
   }
-  if (lane < 12) {
+  if (lane < D::NU) {
     // u_ref (QuatMpc.cpp:118-125)
     const int l = lane / 3, a = lane - 3 * l;
-    sm[L.uref + lane] = (a == 2) ? raw[31 + l] * P.mass * 9.81 / (double)nc : 0.0;
+    sm[L.uref + lane] = (a == 2) ? raw[D::R_CON + l] * P.mass * 9.81 / (double)nc : 0.0;
   }
   if (lane < 18) {
     // C_mat * R (QuatMpc.cpp:47-52,203): rows (1,0,-mu),(-1,0,-mu),(0,1,-mu),(0,-1,-mu),(0,0,1),(0,0,-1)
@@ -79,29 +80,39 @@ __device__ inline void model_setup<QuatModel>(const DevParams& P, const Layout& 
     const double C0 = (r == 0) ? 1.0 : (r == 1 ? -1.0 : 0.0);
     const double C1 = (r == 2) ? 1.0 : (r == 3 ? -1.0 : 0.0);
     const double C2 = (r < 4) ? -P.mu : (r == 4 ? 1.0 : -1.0);
-    cst[C_CR + lane] = C0 * raw[4 + c] + C1 * raw[4 + 3 + c] + C2 * raw[4 + 6 + c];
+    cst[D::C_CR + lane] = C0 * raw[4 + c] + C1 * raw[4 + 3 + c] + C2 * raw[4 + 6 + c];
   }
   QSYNC();
   if (lane < 3) {
     // wd0 = Iinv * (c x 5.204 g_body)  (AltroUtils.cpp:373-374,391)
     const double com[3] = {0.0223, 0.002, -0.0005};
-    const double fg[3] = {5.204 * cst[C_GB], 5.204 * cst[C_GB + 1], 5.204 * cst[C_GB + 2]};
+    const double fg[3] = {5.204 * cst[D::C_GB], 5.204 * cst[D::C_GB + 1], 5.204 * cst[D::C_GB + 2]};
     const double mg[3] = {com[1] * fg[2] - com[2] * fg[1], com[2] * fg[0] - com[0] * fg[2],
                           com[0] * fg[1] - com[1] * fg[0]};
-    cst[C_WD0 + lane] = P.Iinv[3 * lane] * mg[0] + P.Iinv[3 * lane + 1] * mg[1] + P.Iinv[3 * lane + 2] * mg[2];
+    cst[D::C_WD0 + lane] = P.Iinv[3 * lane] * mg[0] + P.Iinv[3 * lane + 1] * mg[1] + P.Iinv[3 * lane + 2] * mg[2];
   }
-  if (lane < 36) {
-    // Bw0 = Iinv * skew(r_l) * contact_l  (AltroUtils.cpp:431-434), 3x12 row-major
-    const int a = lane / 12, col = lane - 12 * a, l = col / 3, b = col - 3 * l;
-    const double* r = cst + C_FOOT + 3 * l;
+  for (int i = lane; i < 3 * D::NU; i += kWave) {
+    // Bw0 = Iinv * skew(r_l) * contact_l  (AltroUtils.cpp:431-434), 3 x NU row-major
+    const int a = i / D::NU, col = i - D::NU * a, l = col / 3, b = col - 3 * l;
+    const double* r = cst + D::C_FOOT + 3 * l;
     // skew(r) column b: b=0:(0, r2, -r1)  b=1:(-r2, 0, r0)  b=2:(r1, -r0, 0)
     double s0, s1, s2;
     if (b == 0) { s0 = 0.0; s1 = r[2]; s2 = -r[1]; }
     else if (b == 1) { s0 = -r[2]; s1 = 0.0; s2 = r[0]; }
     else { s0 = r[1]; s1 = -r[0]; s2 = 0.0; }
-    sm[L.bw0 + lane] = cst[C_CON + l] * (P.Iinv[3 * a] * s0 + P.Iinv[3 * a + 1] * s1 + P.Iinv[3 * a + 2] * s2);
+    sm[L.bw0 + i] = cst[D::C_CON + l] * (P.Iinv[3 * a] * s0 + P.Iinv[3 * a + 1] * s1 + P.Iinv[3 * a + 2] * s2);
   }
   QSYNC();
+}
+template <>
+__device__ inline void model_setup<QuatModel>(const DevParams& P, const Layout& L, double* sm, const double* raw,
+                                              int lane, int nc) {
+  quat_setup<4>(P, L, sm, raw, lane, nc);
+}
+template <>
+__device__ inline void model_setup<Quat8Model>(const DevParams& P, const Layout& L, double* sm, const double* raw,
+                                               int lane, int nc) {
+  quat_setup<8>(P, L, sm, raw, lane, nc);
 }
 
 // ConvexMpc record (qmpc_convex_input): euler 0..2, pos 3..5, angvel 6..8, linvel 9..11, foot 12..23,
@@ -152,16 +163,19 @@ __device__ inline void model_setup<ConvexModel>(const DevParams& P, const Layout
 template <class MD>
 __device__ inline void setup_instance(const DevParams& P, const Layout& L, double* sm,
                                       const void* in, int lane, int* status) {
+  typedef typename MD::D D;
+  constexpr bool quat = (MD::NX == 13);
+  constexpr int REC = quat ? D::REC : 48;          // doubles in one record
   const double* rec = reinterpret_cast<const double*>(in);
-  // one coalesced 8-byte-per-lane read of the 48-double record
-  const double v = (lane < 48) ? rec[lane] : 0.0;
-  const unsigned long long bad = __ballot(lane < 48 && !isfinite(v));
+  // one coalesced 8-byte-per-lane read of the record (48 or 64 doubles)
+  const double v = (lane < REC) ? rec[lane] : 0.0;
+  const unsigned long long bad = __ballot(lane < REC && !isfinite(v));
   double* raw = sm + L.tile;  // scratch
-  if (lane < 48) raw[lane] = v;
+  if (lane < REC) raw[lane] = v;
   QSYNC();
-  constexpr int con0 = (MD::NX == 13) ? 31 : 24;   // contacts[4] inside the record
+  constexpr int con0 = quat ? D::R_CON : 24;       // contacts[] inside the record
   int nc = 0;
-  for (int l = 0; l < 4; ++l) nc += (raw[con0 + l] != 0.0) ? 1 : 0;
+  for (int l = 0; l < MD::NL; ++l) nc += (raw[con0 + l] != 0.0) ? 1 : 0;
   *status = bad ? QMPC_NAN_INPUT : (nc == 0 ? QMPC_NO_CONTACT : QMPC_OK);
   if (*status != QMPC_OK) return;
   model_setup<MD>(P, L, sm, raw, lane, nc);
@@ -171,18 +185,19 @@ __device__ inline void setup_instance(const DevParams& P, const Layout& L, doubl
 // lane 0 publishes).  ALTRO's initial rollout.
 template <class MD>
 __device__ inline void rollout_open(const DevParams& P, const Layout& L, double* sm, int lane) {
+  typedef typename MD::D D;
   const double* cst = sm + L.cst;
   typename MD::Regs M;
   M.load(cst, sm + L.bw0);
-  double x[13], xn[13], u[12];
+  double x[13], xn[13], u[D::NU];
 #pragma unroll
-  for (int i = 0; i < 13; ++i) x[i] = cst[C_X0 + i];
+  for (int i = 0; i < 13; ++i) x[i] = cst[D::C_X0 + i];
   if (lane == 0)
 #pragma unroll
     for (int i = 0; i < 13; ++i) sm[L.X + i] = x[i];
   for (int k = 0; k < P.N; ++k) {
 #pragma unroll
-    for (int j = 0; j < 12; ++j) u[j] = sm[L.U + 12 * k + j];
+    for (int j = 0; j < D::NU; ++j) u[j] = sm[L.U + D::NU * k + j];
     MD::step(P, M, x, u, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) x[i] = xn[i];
@@ -196,16 +211,17 @@ __device__ inline void rollout_open(const DevParams& P, const Layout& L, double*
 // expansions at (X,U): one lane per knot
 template <class MD>
 __device__ inline void expansions(const DevParams& P, const Layout& L, double* sm, int lane) {
+  typedef typename MD::D D;
   const int N = P.N;
   if (lane <= N) {
-    double x[13], xn[13], u[12];
+    double x[13], xn[13], u[D::NU];
 #pragma unroll
     for (int i = 0; i < 13; ++i) {
       x[i] = sm[L.X + 13 * lane + i];
       xn[i] = (lane < N) ? sm[L.X + 13 * (lane + 1) + i] : 0.0;
     }
 #pragma unroll
-    for (int j = 0; j < 12; ++j) u[j] = (lane < N) ? sm[L.U + 12 * lane + j] : 0.0;
+    for (int j = 0; j < D::NU; ++j) u[j] = (lane < N) ? sm[L.U + D::NU * lane + j] : 0.0;
     double AB[27], lx[12], lxx[9];
     MD::expand(P, sm + L.cst, sm + L.bw0, sm + L.refp, lane, x, u, xn, AB, lx, lxx);
     if (lane < N)
@@ -219,14 +235,15 @@ __device__ inline void expansions(const DevParams& P, const Layout& L, double* s
   QSYNC();
 }
 
-// cone value of row idx = 24 k + 6 l + i at the current inputs:
+// cone value of row idx = NC k + 6 l + i at the current inputs:
 // c = C R u_l + b  (QuatMpc.cpp:194-205)
+template <class D>
 __device__ __forceinline__ double cone_value(const DevParams& P, const Layout& L, const double* sm, int idx) {
-  const int k = idx / 24, row = idx - 24 * k, l = row / 6, i = row - 6 * l;
-  const double* cr = sm + L.cst + C_CR + 3 * i;
-  const double* u = sm + L.U + 12 * k + 3 * l;
+  const int k = idx / D::NC, row = idx - D::NC * k, l = row / 6, i = row - 6 * l;
+  const double* cr = sm + L.cst + D::C_CR + 3 * i;
+  const double* u = sm + L.U + D::NU * k + 3 * l;
   double c = cr[0] * u[0] + cr[1] * u[1] + cr[2] * u[2];
-  if (i == 4) c += -P.fz_max * sm[L.cst + C_CON + l];
+  if (i == 4) c += -P.fz_max * sm[L.cst + D::C_CON + l];
   return c;
 }
 
@@ -238,18 +255,20 @@ __device__ __forceinline__ double cone_value(const DevParams& P, const Layout& L
 //   Dblk = T' R_l T + sum_i w_i (T'a_i)(T'a_i)',   w_i = lam_i / s_i
 //   gq   = T' (R_l (u_l - uref_l)) + sum_i g_i (T'a_i),  g_i = target/s_i - kappa_i lam_i + w_i rc_i
 // ROT record per leg: T (9, row-major [a][b]), Dblk (9), gq (3).
+template <class D>
 __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, double* sm, double* ROT,
                                         double target, int lane) {
   const int N = P.N;
   const double* cst = sm + L.cst;
   double cr[18];
 #pragma unroll
-  for (int i = 0; i < 18; ++i) cr[i] = cst[C_CR + i];
-  for (int q = lane; q < 4 * N; q += kWave) {
-    const int k = q >> 2, l = q & 3;
-    double* out = ROT + kROT * k + 21 * l;
-    const double R0 = P.R[3 * l], R1 = P.R[3 * l + 1], R2 = P.R[3 * l + 2];
-    if (cst[C_CON + l] == 0.0) {
+  for (int i = 0; i < 18; ++i) cr[i] = cst[D::C_CR + i];
+  for (int q = lane; q < D::NLEG * N; q += kWave) {
+    const int k = q / D::NLEG, l = q - D::NLEG * k;
+    double* out = ROT + D::ROT * k + 21 * l;
+    const int l4 = l & 3;     // R holds 12 weights: input j uses R[j % 12]
+    const double R0 = P.R[3 * l4], R1 = P.R[3 * l4 + 1], R2 = P.R[3 * l4 + 2];
+    if (cst[D::C_CON + l] == 0.0) {
       // swing leg: identity frame, block = R, zero gradient (forces pinned to 0)
       out[0] = 1; out[1] = 0; out[2] = 0; out[3] = 0; out[4] = 1; out[5] = 0; out[6] = 0; out[7] = 0; out[8] = 1;
       out[9] = R0; out[10] = 0; out[11] = 0; out[12] = 0; out[13] = R1; out[14] = 0; out[15] = 0; out[16] = 0; out[17] = R2;
@@ -259,9 +278,9 @@ __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, dou
     double w[6], gi[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const double s = sm[L.S + 24 * k + 6 * l + i], lam = sm[L.LAM + 24 * k + 6 * l + i];
-      const double rc = sm[L.RC + 24 * k + 6 * l + i];
-      const double kap = sm[L.DS + 24 * k + 6 * l + i];     // weakly-active flag (see ipm_apply)
+      const double s = sm[L.S + D::NC * k + 6 * l + i], lam = sm[L.LAM + D::NC * k + 6 * l + i];
+      const double rc = sm[L.RC + D::NC * k + 6 * l + i];
+      const double kap = sm[L.DS + D::NC * k + 6 * l + i];     // weakly-active flag (see ipm_apply)
       const double is = fast_rcp(s);
       w[i] = lam * is;
       gi[i] = (target + lam * rc) * is - kap * lam;
@@ -305,9 +324,9 @@ __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, dou
     double T[9];  // T[3a+b] = (q_b)_a
 #pragma unroll
     for (int a = 0; a < 3; ++a) { T[3 * a] = q1[a]; T[3 * a + 1] = q2[a]; T[3 * a + 2] = q3[a]; }
-    double D[9], gq[3];
+    double Db[9], gq[3];
     const double Rl[3] = {R0, R1, R2};
-    const double* u = sm + L.U + 12 * k + 3 * l;
+    const double* u = sm + L.U + D::NU * k + 3 * l;
     const double* ur = sm + L.uref + 3 * l;
     const double ru[3] = {R0 * (u[0] - ur[0]), R1 * (u[1] - ur[1]), R2 * (u[2] - ur[2])};
 #pragma unroll
@@ -315,7 +334,7 @@ __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, dou
       gq[a] = T[a] * ru[0] + T[3 + a] * ru[1] + T[6 + a] * ru[2];
 #pragma unroll
       for (int b = 0; b < 3; ++b)
-        D[3 * a + b] = T[a] * Rl[0] * T[b] + T[3 + a] * Rl[1] * T[3 + b] + T[6 + a] * Rl[2] * T[6 + b];
+        Db[3 * a + b] = T[a] * Rl[0] * T[b] + T[3 + a] * Rl[1] * T[3 + b] + T[6 + a] * Rl[2] * T[6 + b];
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -326,52 +345,70 @@ __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, dou
       for (int a = 0; a < 3; ++a) {
         gq[a] += gi[i] * at[a];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) D[3 * a + b] += w[i] * at[a] * at[b];
+        for (int b = 0; b < 3; ++b) Db[3 * a + b] += w[i] * at[a] * at[b];
       }
     }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { out[i] = T[i]; out[9 + i] = D[i]; }
+    for (int i = 0; i < 9; ++i) { out[i] = T[i]; out[9 + i] = Db[i]; }
     out[18] = gq[0]; out[19] = gq[1]; out[20] = gq[2];
   }
   QSYNC();
 }
 
-// One Gauss-Jordan step on pivot J of the pair (M | Rr) held in the fragment
-// layout: row J is eliminated from every OTHER row (the pivot row is left as it
-// is; gj_finish divides by the diagonal at the end).
-template <int J>
-__device__ __forceinline__ void gj_step(double M[3], double Rr[3], int c, int g, int& bad) {
-  constexpr int ej = J >> 2, gj = J & 3;
+// One Gauss-Jordan step on GLOBAL pivot J (input tile tj = J / 12, local index J % 12) of the
+// pair (M | Rr) held in the fragment layout, M as TU x TU tiles and Rr as TU tiles: row J is
+// eliminated from every OTHER row (the pivot row is left as it is; gj_finish divides by the
+// diagonal at the end).
+template <int J, int TU>
+__device__ __forceinline__ void gj_step(double M[][TU][3], double Rr[][3], int c, int g, int& bad) {
+  constexpr int tj = J / 12, Jl = J % 12, ej = Jl >> 2, gj = Jl & 3;
   const int src = (gj << 4) | c;
-  const double mrow = __shfl(M[ej], src);      // row J of M / Rr, same column, all row groups
-  const double rrow = __shfl(Rr[ej], src);
-  const double piv = read_lane(M[ej], (gj << 4) | J);
+  double mrow[TU];
+#pragma unroll
+  for (int t = 0; t < TU; ++t) mrow[t] = __shfl(M[tj][t][ej], src);   // row J, same column, all row groups
+  const double rrow = __shfl(Rr[tj][ej], src);
+  const double piv = read_lane(M[tj][tj][ej], (gj << 4) | Jl);
   bad |= !(piv > 0.0);
   const double ninv = -fast_rcp(piv);
 #pragma unroll
-  for (int e = 0; e < 3; ++e) {
-    const double col = row_bcast<J>(M[e]);
-    const double f = ((e == ej) && (g == gj)) ? 0.0 : col * ninv;
-    M[e] = fma(f, mrow, M[e]);
-    Rr[e] = fma(f, rrow, Rr[e]);
-  }
+  for (int t = 0; t < TU; ++t)
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const double col = row_bcast<Jl>(M[t][tj][e]);
+      const double f = ((t == tj) && (e == ej) && (g == gj)) ? 0.0 : col * ninv;
+#pragma unroll
+      for (int t2 = 0; t2 < TU; ++t2) M[t][t2][e] = fma(f, mrow[t2], M[t][t2][e]);
+      Rr[t][e] = fma(f, rrow, Rr[t][e]);
+    }
+}
+// the three pivots of contact point LEG (a wave-uniform branch skips swing legs)
+template <int LEG, int TU>
+__device__ __forceinline__ void gj_leg(double M[][TU][3], double Rr[][3], int c, int g, int& bad) {
+  gj_step<3 * LEG, TU>(M, Rr, c, g, bad);
+  gj_step<3 * LEG + 1, TU>(M, Rr, c, g, bad);
+  gj_step<3 * LEG + 2, TU>(M, Rr, c, g, bad);
 }
 // X = diag(M)^-1 Rr after all pivots (rows of skipped swing-leg pivots keep their
 // own positive diagonal R and a zero right-hand side)
-__device__ __forceinline__ void gj_finish(const double M[3], double Rr[3], int g) {
+template <int TU>
+__device__ __forceinline__ void gj_finish(const double M[][TU][3], double Rr[][3], int g) {
 #pragma unroll
-  for (int e = 0; e < 3; ++e) {
-    const double dg = __shfl(M[e], (g << 4) | (4 * e + g));   // M[r][r] lives in lane (g, r)
-    Rr[e] *= fast_rcp(dg);
-  }
+  for (int t = 0; t < TU; ++t)
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const double dg = __shfl(M[t][t][e], (g << 4) | (4 * e + g));   // M[r][r] lives in lane (g, r)
+      Rr[t][e] *= fast_rcp(dg);
+    }
 }
 
-// Riccati backward pass with interior-point weights; writes KD (unrotated gains
-// [K | d], 12 x 13 per knot).  Returns nonzero when a pivot is not positive.
+// Riccati backward pass with interior-point weights; writes KD (rotated gains
+// [Kt | dt], NU x 13 per knot).  Returns nonzero when a pivot is not positive.
 // PIPE: build the next knot's operands during the stage solve (needs 12 more VGPRs)
 template <class MD, bool PROF, bool PIPE>
 __device__ inline int backward_pass(const DevParams& P, const Layout& L, double* sm, double* KD,
                                     const double* ROT, int lane, unsigned conmask, Prof<PROF>& prof) {
+  typedef typename MD::D D;
+  constexpr int TU = D::TU;
   const int N = P.N;
   const double* cst = sm + L.cst;
   const double* bw0 = sm + L.bw0;
@@ -403,68 +440,105 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
   // operands of knot kk: Abar and rotated Bbar * T, straight into fragments.  They do not
   // depend on the cost-to-go, so the NEXT knot's operands are built while the
   // latency-bound stage solve of the current knot runs (software pipelining).
-  auto build_operands = [&](int kk, double Afo[3], double Bfo[3]) {
+  auto build_operands = [&](int kk, double Afo[3], double Bfo[][3]) {
     const double* ABk = sm + L.AB + kAB * kk;
-    const double* ROTkk = ROT + kROT * kk;
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-    if (cval) { t0 = ROTkk[21 * lc + bc]; t1 = ROTkk[21 * lc + 3 + bc]; t2 = ROTkk[21 * lc + 6 + bc]; }
-    ops.build(P, ABk, t0, t1, t2, Afo, Bfo);
+    const double* ROTkk = ROT + D::ROT * kk;
+    double tc[TU][3];
+#pragma unroll
+    for (int t = 0; t < TU; ++t) {
+      tc[t][0] = tc[t][1] = tc[t][2] = 0.0;
+      if (cval) {
+        const double* Tl = ROTkk + 21 * (4 * t + lc);
+        tc[t][0] = Tl[bc]; tc[t][1] = Tl[3 + bc]; tc[t][2] = Tl[6 + bc];
+      }
+    }
+    ops.build(P, ABk, tc, Afo, Bfo);
   };
-  double Af[3], Bf[3], Afn[3], Bfn[3];
+  double Af[3], Bf[TU][3], Afn[3], Bfn[TU][3];
   if (PIPE) build_operands(N - 1, Af, Bf);
   for (int k = N - 1; k >= 0; --k) {
     if (!PIPE) build_operands(k, Af, Bf);
-    const double* ROTk = ROT + kROT * k;
+    const double* ROTk = ROT + D::ROT * k;
     const double* XTk = sm + L.XT + kXT * k;
     prof.tick(PH_BUILD);
     // ---- T = P'A (col 12 <- p), S = P'B ; Qxx = A'T, Qux = B'T, Quu = B'S ----
     const d4 z4 = {0.0, 0.0, 0.0, 0.0};
     const d4 aT = mtm3(Pf, Af, z4);
-    const d4 aS = mtm3(Pf, Bf, z4);
-    double Tf[3], Sf[3];
+    double Tf[3], Sf[TU][3];
 #pragma unroll
-    for (int e = 0; e < 3; ++e) { Tf[e] = (c == 12) ? Pf[e] : aT[e]; Sf[e] = aS[e]; }
+    for (int t = 0; t < TU; ++t) {
+      const d4 aS = mtm3(Pf, Bf[t], z4);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) Sf[t][e] = aS[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) Tf[e] = (c == 12) ? Pf[e] : aT[e];
     const d4 aXX = mtm3(Af, Tf, z4);
-    const d4 aUX = mtm3(Bf, Tf, z4);
-    const d4 aUU = mtm3(Bf, Sf, z4);
-    double Qxx[3], Qux[3], Quu[3], Rr[3];
+    double Qxx[3], Qux[TU][3], Quu[TU][TU][3], Rr[TU][3];
 #pragma unroll
-    for (int e = 0; e < 3; ++e) {
-      Qxx[e] = aXX[e] + cp.qadd[e] + ((cp.xoff[e] >= 0) ? XTk[cp.xoff[e]] : 0.0);
-      Qux[e] = aUX[e] + ((goff[e] >= 0) ? ROTk[goff[e]] : 0.0);
-      Quu[e] = aUU[e] + ((doff[e] >= 0) ? ROTk[doff[e]] : 0.0);
-      Rr[e] = Qux[e];
+    for (int e = 0; e < 3; ++e) Qxx[e] = aXX[e] + cp.qadd[e] + ((cp.xoff[e] >= 0) ? XTk[cp.xoff[e]] : 0.0);
+#pragma unroll
+    for (int t = 0; t < TU; ++t) {
+      const d4 aUX = mtm3(Bf[t], Tf, z4);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        Qux[t][e] = aUX[e] + ((goff[e] >= 0) ? ROTk[84 * t + goff[e]] : 0.0);
+        Rr[t][e] = Qux[t][e];
+      }
+#pragma unroll
+      for (int t2 = 0; t2 < TU; ++t2) {
+        const d4 aUU = mtm3(Bf[t], Sf[t2], z4);
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+          Quu[t][t2][e] = aUU[e] + ((t == t2 && doff[e] >= 0) ? ROTk[84 * t + doff[e]] : 0.0);
+      }
     }
     prof.tick(PH_MFMA);
     if (PIPE && k > 0) build_operands(k - 1, Afn, Bfn);   // overlaps with the solve below
     // ---- stage solve: [Kt | dt] = -Quu^-1 [Qux | Qu]; swing-leg pivots are decoupled ----
-    if (conmask & 1u) { gj_step<0>(Quu, Rr, c, g, bad); gj_step<1>(Quu, Rr, c, g, bad); gj_step<2>(Quu, Rr, c, g, bad); }
-    if (conmask & 2u) { gj_step<3>(Quu, Rr, c, g, bad); gj_step<4>(Quu, Rr, c, g, bad); gj_step<5>(Quu, Rr, c, g, bad); }
-    if (conmask & 4u) { gj_step<6>(Quu, Rr, c, g, bad); gj_step<7>(Quu, Rr, c, g, bad); gj_step<8>(Quu, Rr, c, g, bad); }
-    if (conmask & 8u) { gj_step<9>(Quu, Rr, c, g, bad); gj_step<10>(Quu, Rr, c, g, bad); gj_step<11>(Quu, Rr, c, g, bad); }
-    gj_finish(Quu, Rr, g);
-    double Kf[3];
+    if (conmask & 1u) gj_leg<0, TU>(Quu, Rr, c, g, bad);
+    if (conmask & 2u) gj_leg<1, TU>(Quu, Rr, c, g, bad);
+    if (conmask & 4u) gj_leg<2, TU>(Quu, Rr, c, g, bad);
+    if (conmask & 8u) gj_leg<3, TU>(Quu, Rr, c, g, bad);
+    if (TU > 1) {
+      if (conmask & 16u) gj_leg<(TU > 1 ? 4 : 0), TU>(Quu, Rr, c, g, bad);
+      if (conmask & 32u) gj_leg<(TU > 1 ? 5 : 0), TU>(Quu, Rr, c, g, bad);
+      if (conmask & 64u) gj_leg<(TU > 1 ? 6 : 0), TU>(Quu, Rr, c, g, bad);
+      if (conmask & 128u) gj_leg<(TU > 1 ? 7 : 0), TU>(Quu, Rr, c, g, bad);
+    }
+    gj_finish<TU>(Quu, Rr, g);
+    double Kf[TU][3];
 #pragma unroll
-    for (int e = 0; e < 3; ++e) Kf[e] = -Rr[e];
+    for (int t = 0; t < TU; ++t)
+#pragma unroll
+      for (int e = 0; e < 3; ++e) Kf[t][e] = -Rr[t][e];
     prof.tick(PH_SOLVE);
     // ---- cost-to-go: P_aug <- Qxx_aug + Qux_aug' [Kt | dt] ----
     {
       d4 acc = {Qxx[0], Qxx[1], Qxx[2], 0.0};
-      acc = mtm3(Qux, Kf, acc);
+#pragma unroll
+      for (int t = 0; t < TU; ++t) acc = mtm3(Qux[t], Kf[t], acc);
 #pragma unroll
       for (int e = 0; e < 3; ++e) Pf[e] = acc[e];
     }
     // ---- store the ROTATED gains [Kt | dt] straight from the fragments; the rollouts
-    //      apply T_l (3x3 per leg) to the 12 input increments ----
+    //      apply T_l (3x3 per leg) to the input increments ----
     {
-      double* KDk = KD + kKD * k;
+      double* KDk = KD + D::KD * k;
 #pragma unroll
-      for (int e = 0; e < 3; ++e)
-        if (koff[e] >= 0) KDk[koff[e]] = Kf[e];
+      for (int t = 0; t < TU; ++t)
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+          if (koff[e] >= 0) KDk[156 * t + koff[e]] = Kf[t][e];
     }
-    if (PIPE)
+    if (PIPE) {
 #pragma unroll
-      for (int e = 0; e < 3; ++e) { Af[e] = Afn[e]; Bf[e] = Bfn[e]; }
+      for (int e = 0; e < 3; ++e) Af[e] = Afn[e];
+#pragma unroll
+      for (int t = 0; t < TU; ++t)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) Bf[t][e] = Bfn[t][e];
+    }
     prof.tick(PH_PUPD);
   }
   return bad;
@@ -479,41 +553,42 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
 struct RollLoads {
   double xo[13], kd[13], T[3], uo;
 };
-template <bool WITH_X>
+template <class D, bool WITH_X>
 __device__ __forceinline__ void roll_load(const Layout& L, const double* sm, const double* KD,
                                           const double* ROT, int k, int uj, int ql, int qa, RollLoads& r) {
   if (WITH_X)
 #pragma unroll
     for (int i = 0; i < 13; ++i) r.xo[i] = sm[L.X + 13 * k + i];
-  const double* kd = KD + kKD * k + 13 * uj;
+  const double* kd = KD + D::KD * k + 13 * uj;
 #pragma unroll
   for (int i = 0; i < 13; ++i) r.kd[i] = kd[i];
-  const double* T = ROT + kROT * k + 21 * ql + 3 * qa;
+  const double* T = ROT + D::ROT * k + 21 * ql + 3 * qa;
   r.T[0] = T[0]; r.T[1] = T[1]; r.T[2] = T[2];
-  r.uo = sm[L.U + 12 * k + uj];
+  r.uo = sm[L.U + D::NU * k + uj];
 }
 // PF_X: also prefetch the old state (LDS variant: registers to spare); the global-gains
 // variant is register-bound (2 waves/SIMD) and prefetches only its high-latency gain row / T_l
 template <class MD, bool PF_X, bool PF_K>
 __device__ inline void rollout_closed(const DevParams& P, const Layout& L, double* sm, const double* KD,
                                       const double* ROT, double alpha, int lane) {
+  typedef typename MD::D D;
   const int N = P.N;
   const double* cst = sm + L.cst;
   typename MD::Regs M;
   M.load(cst, sm + L.bw0);
-  const bool ulane = (lane < 16) && ((lane & 3) < 3);
-  const int ql = ulane ? (lane >> 2) : 0, qa = ulane ? (lane & 3) : 0;   // leg, axis of this lane
+  const bool ulane = (lane < 4 * D::NLEG) && ((lane & 3) < 3);
+  const int ql = ulane ? (lane >> 2) : 0, qa = ulane ? (lane & 3) : 0;   // contact point, axis of this lane
   const int uj = 3 * ql + qa;
   double xc[13], xn[13];
 #pragma unroll
-  for (int i = 0; i < 13; ++i) xc[i] = cst[C_X0 + i];
+  for (int i = 0; i < 13; ++i) xc[i] = cst[D::C_X0 + i];
   if (lane == 0)
 #pragma unroll
     for (int i = 0; i < 13; ++i) sm[L.Xc + i] = xc[i];
   RollLoads cur, nxt;
-  if (PF_K) roll_load<PF_X>(L, sm, KD, ROT, 0, uj, ql, qa, cur);
+  if (PF_K) roll_load<D, PF_X>(L, sm, KD, ROT, 0, uj, ql, qa, cur);
   for (int k = 0; k < N; ++k) {
-    if (!PF_K) roll_load<PF_X>(L, sm, KD, ROT, k, uj, ql, qa, cur);
+    if (!PF_K) roll_load<D, PF_X>(L, sm, KD, ROT, k, uj, ql, qa, cur);
     if (!PF_X)
 #pragma unroll
       for (int i = 0; i < 13; ++i) cur.xo[i] = sm[L.X + 13 * k + i];
@@ -531,14 +606,14 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
       const double s = (p0 + p1) + (p2 + p3);
       const double s0 = dpp_mov<0x00>(s), s1 = dpp_mov<0x55>(s), s2 = dpp_mov<0xAA>(s);   // quad_perm broadcasts
       const double inc = cur.T[0] * s0 + cur.T[1] * s1 + cur.T[2] * s2;
-      if (ulane) sm[L.dU + 12 * k + uj] = inc;                  // the increment, as computed
+      if (ulane) sm[L.dU + D::NU * k + uj] = inc;               // the increment, as computed
       unew = cur.uo + inc;
     }
-    if (PF_K && k + 1 < N) roll_load<PF_X>(L, sm, KD, ROT, k + 1, uj, ql, qa, nxt);   // one knot ahead
-    // broadcast the 12 new inputs from their owner lanes (4l+a) with v_readlane: no LDS round trip
-    double un[12];
+    if (PF_K && k + 1 < N) roll_load<D, PF_X>(L, sm, KD, ROT, k + 1, uj, ql, qa, nxt);   // one knot ahead
+    // broadcast the new inputs from their owner lanes (4l+a) with v_readlane: no LDS round trip
+    double un[D::NU];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) un[j] = read_lane(unew, 4 * (j / 3) + (j % 3));
+    for (int j = 0; j < D::NU; ++j) un[j] = read_lane(unew, 4 * (j / 3) + (j % 3));
     MD::step(P, M, xc, un, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) xc[i] = xn[i];
@@ -555,17 +630,18 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
 //   ds = -(a_i . dU_l + rc),  rc = c(u) + s  (tracked analytically, see below),
 //   dlam = (target - (1 + kappa) s lam - lam ds) / s,
 // followed by the fraction-to-the-boundary step lengths.
+template <class D>
 __device__ inline void ipm_directions(const DevParams& P, const Layout& L, double* sm, double target,
                                       int lane, double* alpha_p, double* alpha_d) {
   const int N = P.N;
   const double* cst = sm + L.cst;
-  const double* cr = cst + C_CR;
+  const double* cr = cst + D::C_CR;
   double ap = 1.0, ad = 1.0;
-  for (int idx = lane; idx < N * 24; idx += kWave) {
-    const int k = idx / 24, row = idx - 24 * k, l = row / 6, i = row - 6 * l;
+  for (int idx = lane; idx < N * D::NC; idx += kWave) {
+    const int k = idx / D::NC, row = idx - D::NC * k, l = row / 6, i = row - 6 * l;
     double dsv = 0.0, dlv = 0.0;
-    if (cst[C_CON + l] != 0.0) {
-      const double* du = sm + L.dU + 12 * k + 3 * l;
+    if (cst[D::C_CON + l] != 0.0) {
+      const double* du = sm + L.dU + D::NU * k + 3 * l;
       const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
       const double sv = sm[L.S + idx], lv = sm[L.LAM + idx];
       const double kap = sm[L.DS + idx];                     // flag left by the previous ipm_apply
@@ -587,13 +663,14 @@ __device__ inline void ipm_directions(const DevParams& P, const Layout& L, doubl
 // rows are linear in u: a shortened primal step scales the trial increment
 // (dU <- alpha_p dU), hence s + alpha_p ds stays inside the interior exactly and
 // rc <- (1 - alpha_p) rc; a full step zeroes rc exactly.
+template <class D>
 __device__ inline void ipm_apply(const DevParams& P, const Layout& L, double* sm, double ap, double ad,
                                  unsigned conmask, int lane, unsigned& kapbits) {
   const int N = P.N;
   unsigned newbits = 0;
   int j = 0;
-  for (int idx = lane; idx < N * 24; idx += kWave, ++j) {
-    const int l = (idx % 24) / 6;
+  for (int idx = lane; idx < N * D::NC; idx += kWave, ++j) {
+    const int l = (idx % D::NC) / 6;
     if (!(conmask & (1u << l))) continue;
     const double s0 = sm[L.S + idx], l0 = sm[L.LAM + idx];
     const bool kap0 = (kapbits >> j) & 1u;   // this lane owns row idx in every pass
@@ -618,18 +695,19 @@ __device__ inline void ipm_apply(const DevParams& P, const Layout& L, double* sm
 // shortened primal step: scale the trial increment and re-roll the states open loop
 template <class MD>
 __device__ inline void rollout_scaled(const DevParams& P, const Layout& L, double* sm, double ap, int lane) {
+  typedef typename MD::D D;
   const int N = P.N;
   const double* cst = sm + L.cst;
-  for (int i = lane; i < N * 12; i += kWave) sm[L.dU + i] *= ap;
+  for (int i = lane; i < N * D::NU; i += kWave) sm[L.dU + i] *= ap;
   QSYNC();
   typename MD::Regs M;
   M.load(cst, sm + L.bw0);
-  double x[13], xn[13], u[12];
+  double x[13], xn[13], u[D::NU];
 #pragma unroll
-  for (int i = 0; i < 13; ++i) x[i] = cst[C_X0 + i];
+  for (int i = 0; i < 13; ++i) x[i] = cst[D::C_X0 + i];
   for (int k = 0; k < N; ++k) {
 #pragma unroll
-    for (int j = 0; j < 12; ++j) u[j] = sm[L.U + 12 * k + j] + sm[L.dU + 12 * k + j];
+    for (int j = 0; j < D::NU; ++j) u[j] = sm[L.U + D::NU * k + j] + sm[L.dU + D::NU * k + j];
     MD::step(P, M, x, u, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) x[i] = xn[i];
@@ -645,52 +723,53 @@ __device__ inline double cost_plain(const DevParams& P, const Layout& L, double*
   double J = 0.0;
   if (lane <= P.N)
     J = MD::knot_cost(P, sm + L.refp, sm + L.uref, lane, sm + L.X + 13 * lane,
-                      (lane < P.N) ? sm + L.U + 12 * lane : nullptr);
+                      (lane < P.N) ? sm + L.U + MD::D::NU * lane : nullptr);
   return wave_sum(J);
 }
 
 // ---- the solve kernel ---------------------------------------------------------
 // KDG: gains / rotation blocks in the global workspace gws (one slice per instance)
 template <class MD, bool PROF, bool KDG>
-__global__ __launch_bounds__(64, KDG ? 2 : 1) void qmpc_solve_kernel(DevParams P, const qmpc_input* __restrict__ in,
-                                                        double* __restrict__ forces,
-                                                        qmpc_info* __restrict__ info,
-                                                        double* __restrict__ traj_u,
-                                                        double* __restrict__ traj_x, int batch,
-                                                        long long* __restrict__ prof_out,
-                                                        double* __restrict__ gws) {
+__global__ __launch_bounds__(64, (KDG && MD::NL == 4) ? 2 : 1) void qmpc_solve_kernel(
+    DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
+    double* __restrict__ traj_u, double* __restrict__ traj_x, int batch, long long* __restrict__ prof_out,
+    double* __restrict__ gws) {
+  typedef typename MD::D D;
+  constexpr int NU = D::NU, NC = D::NC;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int b = blockIdx.x;
   if (b >= batch) return;
   const int lane = threadIdx.x;
   const int N = P.N;
-  const Layout L = make_layout(N, KDG);
-  double* KD = KDG ? gws + (size_t)b * N * (kKD + kROT) : sm + L.KD;
-  double* ROT = KDG ? KD + N * kKD : sm + L.ROT;
+  const Layout L = make_layout(N, KDG, MD::NL);
+  double* KD = KDG ? gws + (size_t)b * N * (D::KD + D::ROT) : sm + L.KD;
+  double* ROT = KDG ? KD + N * D::KD : sm + L.ROT;
+  // records are 8 * D::REC bytes apart (48 doubles; 64 for the 8-contact-point model)
+  const void* in = reinterpret_cast<const double*>(in_) + (size_t)b * ((MD::NX == 13) ? D::REC : 48);
   int status = QMPC_OK;
   Prof<PROF> prof;
   prof.start();
-  setup_instance<MD>(P, L, sm, in + b, lane, &status);
+  setup_instance<MD>(P, L, sm, in, lane, &status);
   if (status != QMPC_OK) {
-    if (lane < 12) forces[12 * (size_t)b + lane] = 0.0;
+    if (lane < NU) forces[NU * (size_t)b + lane] = 0.0;
     if (lane == 0 && info) {
       qmpc_info r = {status, 0, 0.0, 0.0, 0.0, 0.0};
       info[b] = r;
     }
-    if (traj_u) for (int i = lane; i < N * 12; i += kWave) traj_u[(size_t)b * N * 12 + i] = 0.0;
+    if (traj_u) for (int i = lane; i < N * NU; i += kWave) traj_u[(size_t)b * N * NU + i] = 0.0;
     if (traj_x) for (int i = lane; i < (N + 1) * MD::NX; i += kWave) traj_x[(size_t)b * (N + 1) * MD::NX + i] = 0.0;
     return;
   }
   unsigned conmask = 0;
-  for (int l = 0; l < 4; ++l) conmask |= (sm[L.cst + C_CON + l] != 0.0) ? (1u << l) : 0u;
+  for (int l = 0; l < MD::NL; ++l) conmask |= (sm[L.cst + D::C_CON + l] != 0.0) ? (1u << l) : 0u;
   conmask = __builtin_amdgcn_readfirstlane(conmask);
   // initial guess U = u_ref (QuatMpc.cpp:253), slacks and multipliers
-  for (int i = lane; i < N * 12; i += kWave) sm[L.U + i] = sm[L.uref + (i % 12)];
+  for (int i = lane; i < N * NU; i += kWave) sm[L.U + i] = sm[L.uref + (i % NU)];
   QSYNC();
   rollout_open<MD>(P, L, sm, lane);
   expansions<MD>(P, L, sm, lane);
-  for (int i = lane; i < N * 24; i += kWave) {
-    const double c0 = cone_value(P, L, sm, i);
+  for (int i = lane; i < N * NC; i += kWave) {
+    const double c0 = cone_value<D>(P, L, sm, i);
     const double s0 = fmax(-c0, 1.0);
     sm[L.S + i] = s0;
     sm[L.RC + i] = c0 + s0;
@@ -707,8 +786,8 @@ __global__ __launch_bounds__(64, KDG ? 2 : 1) void qmpc_solve_kernel(DevParams P
   for (it = 1; it <= P.iterations_max + 1; ++it) {
     // barrier parameter and slack residual over the enabled rows
     double sl = 0.0, rs = 0.0;
-    for (int i = lane; i < N * 24; i += kWave) {
-      const int l = (i % 24) / 6;
+    for (int i = lane; i < N * NC; i += kWave) {
+      const int l = (i % NC) / 6;
       if (conmask & (1u << l)) {
         sl += sm[L.S + i] * sm[L.LAM + i];
         rs = fmax(rs, fabs(sm[L.RC + i]));
@@ -726,7 +805,7 @@ __global__ __launch_bounds__(64, KDG ? 2 : 1) void qmpc_solve_kernel(DevParams P
     else if (it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
     else if (it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
     const double target = sg * mu;
-    rotation_prepass(P, L, sm, ROT, target, lane);
+    rotation_prepass<D>(P, L, sm, ROT, target, lane);
     if (KDG) __syncthreads();
     prof.tick(PH_MISC);
     if (backward_pass<MD, PROF, !KDG>(P, L, sm, KD, ROT, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
@@ -734,20 +813,20 @@ __global__ __launch_bounds__(64, KDG ? 2 : 1) void qmpc_solve_kernel(DevParams P
     double ap, ad;
     rollout_closed<MD, !KDG, !KDG>(P, L, sm, KD, ROT, 1.0, lane);  // trial step
     prof.tick(PH_ROLL);
-    ipm_directions(P, L, sm, target, lane, &ap, &ad);
+    ipm_directions<D>(P, L, sm, target, lane, &ap, &ad);
     last_ap = ap; last_ad = ad;
     {
       // convergence is judged on the FULL Newton step (the trial increment)
       double step = 0.0;
-      for (int i = lane; i < N * 12; i += kWave) step = fmax(step, fabs(sm[L.dU + i]));
+      for (int i = lane; i < N * NU; i += kWave) step = fmax(step, fabs(sm[L.dU + i]));
       last_step = wave_max(step);
     }
     prof.tick(PH_DIRS);
     if (ap < 1.0) rollout_scaled<MD>(P, L, sm, ap, lane);    // shortened primal step
     prof.tick(PH_ROLL);
-    ipm_apply(P, L, sm, ap, ad, conmask, lane, kapbits);
+    ipm_apply<D>(P, L, sm, ap, ad, conmask, lane, kapbits);
     // accept the candidate
-    for (int i = lane; i < N * 12; i += kWave) sm[L.U + i] += sm[L.dU + i];
+    for (int i = lane; i < N * NU; i += kWave) sm[L.U + i] += sm[L.dU + i];
     for (int i = lane; i < (N + 1) * 13; i += kWave) sm[L.X + i] = sm[L.Xc + i];
     QSYNC();
     prof.tick(PH_MISC);
@@ -756,8 +835,8 @@ __global__ __launch_bounds__(64, KDG ? 2 : 1) void qmpc_solve_kernel(DevParams P
     iters = it;
   }
   // outputs: GetInput(u, 0) (QuatMpc.cpp:264-265)
-  if (lane < 12) forces[12 * (size_t)b + lane] = sm[L.U + lane];
-  if (traj_u) for (int i = lane; i < N * 12; i += kWave) traj_u[(size_t)b * N * 12 + i] = sm[L.U + i];
+  if (lane < NU) forces[NU * (size_t)b + lane] = sm[L.U + lane];
+  if (traj_u) for (int i = lane; i < N * NU; i += kWave) traj_u[(size_t)b * N * NU + i] = sm[L.U + i];
   if (traj_x)
     for (int i = lane; i < (N + 1) * MD::NX; i += kWave) {
       const int k = i / MD::NX, j = i - MD::NX * k;
@@ -766,9 +845,9 @@ __global__ __launch_bounds__(64, KDG ? 2 : 1) void qmpc_solve_kernel(DevParams P
   if (info) {
     const double J = cost_plain<MD>(P, L, sm, lane);
     double viol = 0.0;
-    for (int i = lane; i < N * 24; i += kWave) {
-      const int l = (i % 24) / 6;
-      if (conmask & (1u << l)) viol = fmax(viol, fmax(cone_value(P, L, sm, i), 0.0));
+    for (int i = lane; i < N * NC; i += kWave) {
+      const int l = (i % NC) / 6;
+      if (conmask & (1u << l)) viol = fmax(viol, fmax(cone_value<D>(P, L, sm, i), 0.0));
     }
     viol = wave_max(viol);
     if (lane == 0) {
@@ -795,7 +874,7 @@ __global__ __launch_bounds__(64) void qmpc_linearize_kernel(DevParams P, const q
   if (b >= batch) return;
   const int lane = threadIdx.x;
   const int N = P.N;
-  const Layout L = make_layout(N, true);
+  const Layout L = make_layout(N, true, MD::NL);
   int status = QMPC_OK;
   setup_instance<MD>(P, L, sm, in + b, lane, &status);
   if (status != QMPC_OK) {

@@ -182,3 +182,55 @@ def random_go1_convex_states(batch: int, config_id: int = 12, first: int = 0, ve
     rec["lin_vel_d_world"] = np.stack([cy * vx - sy * vy, sy * vx + cy * vy, np.zeros(batch)], axis=-1)
     rec["yaw_rate_d"] = nx() - 0.5
     return rec
+
+
+def random_biped8_states(batch: int, config_id: int = 5, first: int = 0, tilt_max: float = 0.3,
+                         vel_sigma: float = 0.3) -> np.ndarray:
+    """`batch` records of ``struct qmpc_input8`` for BASELINE config 5: a SYNTHETIC biped with two
+    0.2 x 0.1 m feet, 4 corner contact points each (points 0-3 left foot, 4-7 right foot), hip height
+    0.85 m.  The humanoid branch is not in the reference checkout, so this footprint is this
+    repository's choice; same counter-based generator as the Go1 states.  Support:
+    40 % both feet, 30 % left only, 30 % right only."""
+    from . import INPUT8_DTYPE
+
+    seed = 0x5EED0000 + int(config_id)
+    idx = np.arange(first, first + batch, dtype=np.uint64)
+    u = _uniform(seed, idx, 64)
+    c = iter(range(64))
+    nx = lambda: u[:, next(c)]  # noqa: E731
+    rec = np.zeros(batch, dtype=INPUT8_DTYPE)
+    yaw = (2.0 * nx() - 1.0) * np.pi
+    tilt_dir = 2.0 * np.pi * nx()
+    tilt = tilt_max * nx()
+    zaxis = np.zeros((batch, 3)); zaxis[:, 2] = 1.0
+    haxis = np.stack([np.cos(tilt_dir), np.sin(tilt_dir), np.zeros(batch)], axis=-1)
+    q_yaw = _axis_angle(zaxis, yaw)
+    q = quat_mul(q_yaw, _axis_angle(haxis, tilt))
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    rec["quat"] = q
+    rec["rot"] = quat_to_rot(q)
+    rec["lin_vel_body"] = np.stack([vel_sigma * _normal(nx(), nx()) for _ in range(3)], axis=-1)
+    rec["ang_vel_body"] = np.stack([0.5 * _normal(nx(), nx()) for _ in range(3)], axis=-1)
+    feet = np.zeros((batch, 8, 3))
+    corners = np.array([[0.1, 0.05], [0.1, -0.05], [-0.1, 0.05], [-0.1, -0.05]])
+    for foot, ysign in ((0, 1.0), (1, -1.0)):
+        centre = np.stack([0.06 * nx() - 0.03, ysign * 0.1 + 0.06 * nx() - 0.03, -0.85 + 0.06 * nx() - 0.03], axis=-1)
+        for k in range(4):
+            feet[:, 4 * foot + k, 0] = centre[:, 0] + corners[k, 0]
+            feet[:, 4 * foot + k, 1] = centre[:, 1] + corners[k, 1]
+            feet[:, 4 * foot + k, 2] = centre[:, 2]
+    rec["foot_pos_body"] = feet.reshape(batch, 24)
+    g = nx()
+    contacts = np.ones((batch, 8))
+    contacts[(g >= 0.4) & (g < 0.7), 4:] = 0.0      # left foot only
+    contacts[g >= 0.7, :4] = 0.0                    # right foot only
+    rec["contacts"] = contacts
+    rec["pos_ref_body"] = np.stack([0.02 * _normal(nx(), nx()) for _ in range(3)], axis=-1)
+    rec["vel_ref_body"] = np.stack([nx() - 0.5, 0.2 * nx() - 0.1, np.zeros(batch)], axis=-1)
+    small = np.stack([0.05 * _normal(nx(), nx()) for _ in range(2)] + [np.zeros(batch)], axis=-1)
+    ang = np.linalg.norm(small, axis=-1)
+    ax_ = np.where(ang[:, None] > 0, small / np.maximum(ang, 1e-300)[:, None], haxis)
+    qd = quat_mul(q_yaw, _axis_angle(ax_, ang))
+    qd /= np.linalg.norm(qd, axis=-1, keepdims=True)
+    rec["quat_d"] = qd
+    return rec

@@ -420,3 +420,27 @@ def test_leg_kinematics_and_torque_map_match_oracle(pkg, lib, oracle):
     st.synchronize()
     assert np.array_equal(d_tau.cpu().numpy(), s.torque_map(g, q, f, rec["contacts"], walking=True))
     s.close()
+
+
+# ---- 8 contact points (BASELINE config 5: synthetic biped, 24 forces, 48 cone rows per knot) ----------
+@pytest.mark.parametrize("N", [16, 10])
+def test_biped8_forces_match_oracle(pkg, lib, oracle, N):
+    p = pkg.default_biped8_params(N, pkg.MODE_CONVERGED, lib)
+    assert bytes(p) == bytes(oracle.default_biped8_params(N, 0))
+    s = pkg.Solver(p, 256, device=0, lib=lib)
+    rec = pkg.random_biped8_states(256, config_id=5)
+    f, info, tu, tx = s.solve8(rec, want_traj=True)
+    fo, io, tuo, txo = oracle.solve8(p, rec, threads=8, want_traj=True)
+    assert (info["status"] == 0).all(), np.unique(info["status"], return_counts=True)
+    assert (io["status"] == 0).all()
+    # the 4 corner points of a foot share 6 wrench degrees of freedom: the split of the load among them is
+    # fixed only by R = 1e-6, so individual corner forces are far more sensitive than the foot wrench
+    err = np.abs(f - fo).max(axis=1)
+    assert err.max() < 1e-5, (err.max(), int(err.argmax()))
+    assert np.abs(tx - txo).max() < 1e-8
+    swing = np.repeat(rec["contacts"] == 0, 3, axis=1)
+    assert np.abs(f[swing]).max() == 0.0
+    assert (info["iterations"] == io["iterations"]).mean() >= 0.9
+    with pytest.raises(pkg.QmpcError):
+        s.solve(pkg.random_go1_trot_states(4))
+    s.close()

@@ -62,16 +62,18 @@ def test_golden_rollout_reproduces_states(oracle, pkg, which, name):
     lib = oracle.lib()
 
     class Model(C.Structure):
-        _fields_ = [("foot", C.c_double * 12), ("inertia", C.c_double * 9), ("inertia_inv", C.c_double * 9),
-                    ("mass", C.c_double), ("rot", C.c_double * 9), ("contacts", C.c_double * 4),
-                    ("g_body", C.c_double * 3), ("moment_gravity", C.c_double * 3)]
+        # struct qo_srbd_model (oracle/qo_srbd.h): nleg = 0 means the 4-leg Go1 model
+        _fields_ = [("nleg", C.c_int), ("foot", C.c_double * 24), ("inertia", C.c_double * 9),
+                    ("inertia_inv", C.c_double * 9), ("mass", C.c_double), ("rot", C.c_double * 9),
+                    ("contacts", C.c_double * 8), ("g_body", C.c_double * 3), ("moment_gravity", C.c_double * 3)]
 
     m = Model()
-    m.foot[:] = rec["foot_pos_body"][0]
+    m.nleg = 4
+    m.foot[:12] = rec["foot_pos_body"][0]
     m.inertia[:] = list(p.inertia)
     m.mass = p.mass
     m.rot[:] = rec["rot"][0]
-    m.contacts[:] = rec["contacts"][0]
+    m.contacts[:4] = rec["contacts"][0]
     lib.qo_srbd_prepare(C.byref(m))
     lib.qo_srbd_discrete_dynamics.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
     x = Xg[0].copy()
