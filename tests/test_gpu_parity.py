@@ -444,3 +444,26 @@ def test_biped8_forces_match_oracle(pkg, lib, oracle, N):
     with pytest.raises(pkg.QmpcError):
         s.solve(pkg.random_go1_trot_states(4))
     s.close()
+
+
+def test_eight_point_kernel_reduces_to_the_four_leg_one(pkg, lib):
+    """Go1 parameters, Go1 footholds in points 0-3, points 4-7 in swing: the TU=2 kernel must return the
+    forces of the (golden-pinned) 4-leg kernel."""
+    rec4 = pkg.random_go1_trot_states(512, config_id=2)
+    rec8 = np.zeros(len(rec4), dtype=pkg.INPUT8_DTYPE)
+    for f in ("quat", "rot", "lin_vel_body", "ang_vel_body", "pos_ref_body", "vel_ref_body", "acc_ref_body", "quat_d"):
+        rec8[f] = rec4[f]
+    rec8["foot_pos_body"][:, :12] = rec4["foot_pos_body"]
+    rec8["foot_pos_body"][:, 12:] = rec4["foot_pos_body"] + 0.01
+    rec8["contacts"][:, :4] = rec4["contacts"]
+    p4, s4 = _solver(pkg, lib, 10)
+    p8 = pkg.default_params(10, pkg.MODE_CONVERGED, lib)
+    p8.model = pkg.MODEL_QUAT8
+    s8 = pkg.Solver(p8, 512, device=0, lib=lib)
+    f4, i4 = s4.solve(rec4)
+    f8, i8 = s8.solve8(rec8)
+    assert (i4["status"] == 0).all() and (i8["status"] == 0).all()
+    assert np.abs(f8[:, :12] - f4).max() < 1e-7
+    assert np.abs(f8[:, 12:]).max() == 0.0
+    assert (i8["iterations"] == i4["iterations"]).mean() >= 0.98
+    s4.close(); s8.close()
