@@ -150,8 +150,10 @@ typedef unsigned u2v __attribute__((ext_vector_type(2)));
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  // every lane of these controls has a valid source and the masks are full, so the `old` operand is dead:
+  // bound_ctrl lets the compiler drop its initialisation (two v_mov + a hazard nop per DPP pair)
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 // v_permlane16_swap(x,x): [0] = rows (r0,r0,r2,r2), [1] = rows (r1,r1,r3,r3)
@@ -212,8 +214,8 @@ __device__ __forceinline__ double fast_rcp(double x) {
 template <int J>
 __device__ __forceinline__ double row_bcast(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + J, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + J, 0xF, 0xF, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + J, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + J, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 // wave-uniform copy of lane l's value (v_readlane -> SGPRs)

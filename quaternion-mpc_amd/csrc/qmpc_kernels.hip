@@ -360,7 +360,7 @@ __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, dou
 // eliminated from every OTHER row (the pivot row is left as it is; gj_finish divides by the
 // diagonal at the end).
 template <int J, int TU>
-__device__ __forceinline__ void gj_step(double M[][TU][3], double Rr[][3], int c, int g, int& bad) {
+__device__ __forceinline__ void gj_step(double M[][TU][3], double Rr[][3], int c, int g, double& minpiv) {
   constexpr int tj = J / 12, Jl = J % 12, ej = Jl >> 2, gj = Jl & 3;
   const int src = (gj << 4) | c;
   double mrow[TU];
@@ -368,7 +368,7 @@ __device__ __forceinline__ void gj_step(double M[][TU][3], double Rr[][3], int c
   for (int t = 0; t < TU; ++t) mrow[t] = __shfl(M[tj][t][ej], src);   // row J, same column, all row groups
   const double rrow = __shfl(Rr[tj][ej], src);
   const double piv = read_lane(M[tj][tj][ej], (gj << 4) | Jl);
-  bad |= !(piv > 0.0);
+  minpiv = fmin(minpiv, piv);          // positivity is checked once per pass (NaN pivots poison the gains -> NOT_PD below)
   const double ninv = -fast_rcp(piv);
 #pragma unroll
   for (int t = 0; t < TU; ++t)
@@ -383,10 +383,10 @@ __device__ __forceinline__ void gj_step(double M[][TU][3], double Rr[][3], int c
 }
 // the three pivots of contact point LEG (a wave-uniform branch skips swing legs)
 template <int LEG, int TU>
-__device__ __forceinline__ void gj_leg(double M[][TU][3], double Rr[][3], int c, int g, int& bad) {
-  gj_step<3 * LEG, TU>(M, Rr, c, g, bad);
-  gj_step<3 * LEG + 1, TU>(M, Rr, c, g, bad);
-  gj_step<3 * LEG + 2, TU>(M, Rr, c, g, bad);
+__device__ __forceinline__ void gj_leg(double M[][TU][3], double Rr[][3], int c, int g, double& minpiv) {
+  gj_step<3 * LEG, TU>(M, Rr, c, g, minpiv);
+  gj_step<3 * LEG + 1, TU>(M, Rr, c, g, minpiv);
+  gj_step<3 * LEG + 2, TU>(M, Rr, c, g, minpiv);
 }
 // X = diag(M)^-1 Rr after all pivots (rows of skipped swing-leg pivots keep their
 // own positive diagonal R and a zero right-hand side)
@@ -436,7 +436,7 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
 #pragma unroll
     for (int e = 0; e < 3; ++e) Pf[e] = cp.qadd[e] + ((cp.xoff[e] >= 0) ? XTk[cp.xoff[e]] : 0.0);
   }
-  int bad = 0;
+  double minpiv = 1e300;
   // operands of knot kk: Abar and rotated Bbar * T, straight into fragments.  They do not
   // depend on the cost-to-go, so the NEXT knot's operands are built while the
   // latency-bound stage solve of the current knot runs (software pipelining).
@@ -496,15 +496,15 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
     prof.tick(PH_MFMA);
     if (PIPE && k > 0) build_operands(k - 1, Afn, Bfn);   // overlaps with the solve below
     // ---- stage solve: [Kt | dt] = -Quu^-1 [Qux | Qu]; swing-leg pivots are decoupled ----
-    if (conmask & 1u) gj_leg<0, TU>(Quu, Rr, c, g, bad);
-    if (conmask & 2u) gj_leg<1, TU>(Quu, Rr, c, g, bad);
-    if (conmask & 4u) gj_leg<2, TU>(Quu, Rr, c, g, bad);
-    if (conmask & 8u) gj_leg<3, TU>(Quu, Rr, c, g, bad);
+    if (conmask & 1u) gj_leg<0, TU>(Quu, Rr, c, g, minpiv);
+    if (conmask & 2u) gj_leg<1, TU>(Quu, Rr, c, g, minpiv);
+    if (conmask & 4u) gj_leg<2, TU>(Quu, Rr, c, g, minpiv);
+    if (conmask & 8u) gj_leg<3, TU>(Quu, Rr, c, g, minpiv);
     if (TU > 1) {
-      if (conmask & 16u) gj_leg<(TU > 1 ? 4 : 0), TU>(Quu, Rr, c, g, bad);
-      if (conmask & 32u) gj_leg<(TU > 1 ? 5 : 0), TU>(Quu, Rr, c, g, bad);
-      if (conmask & 64u) gj_leg<(TU > 1 ? 6 : 0), TU>(Quu, Rr, c, g, bad);
-      if (conmask & 128u) gj_leg<(TU > 1 ? 7 : 0), TU>(Quu, Rr, c, g, bad);
+      if (conmask & 16u) gj_leg<(TU > 1 ? 4 : 0), TU>(Quu, Rr, c, g, minpiv);
+      if (conmask & 32u) gj_leg<(TU > 1 ? 5 : 0), TU>(Quu, Rr, c, g, minpiv);
+      if (conmask & 64u) gj_leg<(TU > 1 ? 6 : 0), TU>(Quu, Rr, c, g, minpiv);
+      if (conmask & 128u) gj_leg<(TU > 1 ? 7 : 0), TU>(Quu, Rr, c, g, minpiv);
     }
     gj_finish<TU>(Quu, Rr, g);
     double Kf[TU][3];
@@ -541,7 +541,7 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
     }
     prof.tick(PH_PUPD);
   }
-  return bad;
+  return !(minpiv > 0.0);   // also true for a NaN pivot
 }
 
 // nonlinear closed-loop rollout with step alpha from (X,U) into the candidate
