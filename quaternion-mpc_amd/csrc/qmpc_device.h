@@ -587,28 +587,42 @@ struct QuatModelT {
         }
       }
     }
-    // Abar and rotated Bbar*T (tc[t] = column bc of the frame T of the lane's leg in tile t) straight into fragments
+    // Abar and rotated Bbar*T (tc[t] = column bc of the frame T of the lane's leg in tile t) straight into
+    // fragments, one fragment row e at a time.  Branch-free (unconditional loads at clamped offsets, then
+    // selects): the rows are scheduled between the MFMAs of the backward pass.
+    // first half of row e: A entry and the attitude-row candidates of the unrotated B entries
+    __device__ __forceinline__ void row_a(const DevParams& P, const double* ABk, int e, double Afo[3],
+                                          double pr[][3]) const {
+      const double av = ABk[(aoff[e] >= 0) ? aoff[e] : 0];
+      Afo[e] = (aoff[e] >= 0) ? av : Ac[e];
+      const double* W = ABk + 18 + (phi[e] ? 3 * (4 * e + g - 3) : 0);
+      const double w0 = W[0], w1 = W[1], w2 = W[2];
+#pragma unroll
+      for (int t = 0; t < D::TU; ++t) {
+        pr[t][0] = (0.5 * P.hh) * (w0 * hbw[t][0][0] + w1 * hbw[t][1][0] + w2 * hbw[t][2][0]);
+        pr[t][1] = (0.5 * P.hh) * (w0 * hbw[t][0][1] + w1 * hbw[t][1][1] + w2 * hbw[t][2][1]);
+        pr[t][2] = (0.5 * P.hh) * (w0 * hbw[t][0][2] + w1 * hbw[t][1][2] + w2 * hbw[t][2][2]);
+      }
+    }
+    // second half: select and rotate into the frame column
+    __device__ __forceinline__ void row_b(const double tc[][3], int e, const double pr[][3], double Bfo[][3]) const {
+#pragma unroll
+      for (int t = 0; t < D::TU; ++t) {
+        const double b0 = phi[e] ? pr[t][0] : Bc[t][e][0], b1 = phi[e] ? pr[t][1] : Bc[t][e][1],
+                     b2 = phi[e] ? pr[t][2] : Bc[t][e][2];
+        Bfo[t][e] = b0 * tc[t][0] + b1 * tc[t][1] + b2 * tc[t][2];
+      }
+    }
+    __device__ __forceinline__ void build_row(const DevParams& P, const double* ABk, const double tc[][3], int e,
+                                              double Afo[3], double Bfo[][3]) const {
+      double pr[D::TU][3];
+      row_a(P, ABk, e, Afo, pr);
+      row_b(tc, e, pr, Bfo);
+    }
     __device__ __forceinline__ void build(const DevParams& P, const double* ABk, const double tc[][3],
                                           double Afo[3], double Bfo[][3]) const {
 #pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        Afo[e] = (aoff[e] >= 0) ? ABk[aoff[e]] : Ac[e];
-        double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-        if (phi[e]) {
-          const double* W = ABk + 18 + 3 * (4 * e + g - 3);
-          w0 = W[0]; w1 = W[1]; w2 = W[2];
-        }
-#pragma unroll
-        for (int t = 0; t < D::TU; ++t) {
-          double b0 = Bc[t][e][0], b1 = Bc[t][e][1], b2 = Bc[t][e][2];
-          if (phi[e]) {
-            b0 = (0.5 * P.hh) * (w0 * hbw[t][0][0] + w1 * hbw[t][1][0] + w2 * hbw[t][2][0]);
-            b1 = (0.5 * P.hh) * (w0 * hbw[t][0][1] + w1 * hbw[t][1][1] + w2 * hbw[t][2][1]);
-            b2 = (0.5 * P.hh) * (w0 * hbw[t][0][2] + w1 * hbw[t][1][2] + w2 * hbw[t][2][2]);
-          }
-          Bfo[t][e] = b0 * tc[t][0] + b1 * tc[t][1] + b2 * tc[t][2];
-        }
-      }
+      for (int e = 0; e < 3; ++e) build_row(P, ABk, tc, e, Afo, Bfo);
     }
   };
 
@@ -828,21 +842,29 @@ struct ConvexModel {
         }
       }
     }
+    __device__ __forceinline__ void row_a(const DevParams& P, const double* ABk, int e, double Afo[3],
+                                          double pr[][3]) const {
+      const double av = asc[e] * ABk[(aoff[e] >= 0) ? aoff[e] : 0];
+      Afo[e] = (aoff[e] >= 0) ? av : Ac[e];
+      const double m0 = m0s[e] * ABk[mo0[e]], m1 = m1s[e] * ABk[mo1[e]], m2 = mz[e];
+      pr[0][0] = m0 * sk[0][0] + m1 * sk[1][0] + m2 * sk[2][0];
+      pr[0][1] = m0 * sk[0][1] + m1 * sk[1][1] + m2 * sk[2][1];
+      pr[0][2] = m0 * sk[0][2] + m1 * sk[1][2] + m2 * sk[2][2];
+    }
+    __device__ __forceinline__ void row_b(const double tc[][3], int e, const double pr[][3], double Bfo[][3]) const {
+      const double b0 = var[e] ? pr[0][0] : Bc[e][0], b1 = var[e] ? pr[0][1] : Bc[e][1], b2 = var[e] ? pr[0][2] : Bc[e][2];
+      Bfo[0][e] = b0 * tc[0][0] + b1 * tc[0][1] + b2 * tc[0][2];
+    }
+    __device__ __forceinline__ void build_row(const DevParams& P, const double* ABk, const double tc[][3], int e,
+                                              double Afo[3], double Bfo[][3]) const {
+      double pr[1][3];
+      row_a(P, ABk, e, Afo, pr);
+      row_b(tc, e, pr, Bfo);
+    }
     __device__ __forceinline__ void build(const DevParams& P, const double* ABk, const double tc[][3],
                                           double Afo[3], double Bfo[][3]) const {
-      const double t0 = tc[0][0], t1 = tc[0][1], t2 = tc[0][2];
 #pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        Afo[e] = (aoff[e] >= 0) ? asc[e] * ABk[aoff[e]] : Ac[e];
-        double b0 = Bc[e][0], b1 = Bc[e][1], b2 = Bc[e][2];
-        if (var[e]) {
-          const double m0 = m0s[e] * ABk[mo0[e]], m1 = m1s[e] * ABk[mo1[e]], m2 = mz[e];
-          b0 = m0 * sk[0][0] + m1 * sk[1][0] + m2 * sk[2][0];
-          b1 = m0 * sk[0][1] + m1 * sk[1][1] + m2 * sk[2][1];
-          b2 = m0 * sk[0][2] + m1 * sk[1][2] + m2 * sk[2][2];
-        }
-        Bfo[0][e] = b0 * t0 + b1 * t1 + b2 * t2;
-      }
+      for (int e = 0; e < 3; ++e) build_row(P, ABk, tc, e, Afo, Bfo);
     }
   };
 

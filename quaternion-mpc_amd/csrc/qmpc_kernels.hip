@@ -440,17 +440,24 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
   // operands of knot kk: Abar and rotated Bbar * T, straight into fragments.  They do not
   // depend on the cost-to-go, so the NEXT knot's operands are built while the
   // latency-bound stage solve of the current knot runs (software pipelining).
+  // clamped offsets of the per-knot terms: loaded unconditionally (no exec-mask juggling between the
+  // MFMAs) and selected afterwards
+  int xo[3], go[3], dof[3];
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    xo[e] = (cp.xoff[e] >= 0) ? cp.xoff[e] : 0;
+    go[e] = (goff[e] >= 0) ? goff[e] : 0;
+    dof[e] = (doff[e] >= 0) ? doff[e] : 0;
+  }
   auto build_operands = [&](int kk, double Afo[3], double Bfo[][3]) {
     const double* ABk = sm + L.AB + kAB * kk;
     const double* ROTkk = ROT + D::ROT * kk;
     double tc[TU][3];
 #pragma unroll
     for (int t = 0; t < TU; ++t) {
-      tc[t][0] = tc[t][1] = tc[t][2] = 0.0;
-      if (cval) {
-        const double* Tl = ROTkk + 21 * (4 * t + lc);
-        tc[t][0] = Tl[bc]; tc[t][1] = Tl[3 + bc]; tc[t][2] = Tl[6 + bc];
-      }
+      const double* Tl = ROTkk + 21 * (4 * t + lc);     // lc = bc = 0 on the lanes without a column
+      const double v0 = Tl[bc], v1 = Tl[3 + bc], v2 = Tl[6 + bc];
+      tc[t][0] = cval ? v0 : 0.0; tc[t][1] = cval ? v1 : 0.0; tc[t][2] = cval ? v2 : 0.0;
     }
     ops.build(P, ABk, tc, Afo, Bfo);
   };
@@ -461,28 +468,80 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
     const double* ROTk = ROT + D::ROT * k;
     const double* XTk = sm + L.XT + kXT * k;
     prof.tick(PH_BUILD);
-    // ---- T = P'A (col 12 <- p), S = P'B ; Qxx = A'T, Qux = B'T, Quu = B'S ----
-    const d4 z4 = {0.0, 0.0, 0.0, 0.0};
-    const d4 aT = mtm3(Pf, Af, z4);
-    double Tf[3], Sf[TU][3];
+    // per-knot terms (independent of the products below)
+    double xt[3], gt[TU][3], dt_[TU][3];
 #pragma unroll
-    for (int t = 0; t < TU; ++t) {
-      const d4 aS = mtm3(Pf, Bf[t], z4);
+    for (int e = 0; e < 3; ++e) {
+      xt[e] = XTk[xo[e]];
 #pragma unroll
-      for (int e = 0; e < 3; ++e) Sf[t][e] = aS[e];
+      for (int t = 0; t < TU; ++t) { gt[t][e] = ROTk[84 * t + go[e]]; dt_[t][e] = ROTk[84 * t + dof[e]]; }
     }
+    // ---- T = P'A (col 12 <- p), S = P'B ; Qxx = A'T, Qux = B'T, Quu = B'S ----
+    // One v_mfma_f64_16x16x4_f64 occupies the matrix pipe for 64 cycles; the next knot's operand build is
+    // independent VALU work and is placed between the products so that it issues under them.
+    const d4 z4 = {0.0, 0.0, 0.0, 0.0};
+    d4 aT = z4, aS[TU];
+    double Tf[3], Sf[TU][3];
+    if (PIPE) {
+      // T and S chains interleaved, one fragment row of the NEXT knot's operands between the products
+      // (scheduling fences keep the compiler from clustering the MFMAs again)
+      const int kn = k > 0 ? k - 1 : 0;
+      const double* ABn = sm + L.AB + kAB * kn;
+      const double* ROTn = ROT + D::ROT * kn;
+      double tc[TU][3];
+#pragma unroll
+      for (int t = 0; t < TU; ++t) {
+        aS[t] = z4;
+        const double* Tl = ROTn + 21 * (4 * t + lc);
+        const double v0 = Tl[bc], v1 = Tl[3 + bc], v2 = Tl[6 + bc];
+        tc[t][0] = cval ? v0 : 0.0; tc[t][1] = cval ? v1 : 0.0; tc[t][2] = cval ? v2 : 0.0;
+      }
+      // Ordering pins (empty volatile asm statements keep their mutual order): each MFMA's A operand and the
+      // inputs / outputs of each half row pass through one, which leaves  MFMA, half row, MFMA, half row, ...
+      int abofs = kAB * kn;
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        double pr[TU][3];
+        double pa = Pf[kk];
+        asm volatile("" : "+v"(pa));
+        aT = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, Af[kk], aT, 0, 0, 0);
+        asm volatile("" : "+v"(abofs));
+        ops.row_a(P, sm + L.AB + abofs, kk, Afn, pr);
+        asm volatile("" : "+v"(Afn[kk]));
+#pragma unroll
+        for (int t = 0; t < TU; ++t) {
+          asm volatile("" : "+v"(pr[t][0]), "+v"(pr[t][1]), "+v"(pr[t][2]));
+          double pb = Pf[kk];
+          asm volatile("" : "+v"(pb));
+          aS[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pb, Bf[t][kk], aS[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < TU; ++t) asm volatile("" : "+v"(pr[t][0]), "+v"(pr[t][1]), "+v"(pr[t][2]));
+        ops.row_b(tc, kk, pr, Bfn);
+#pragma unroll
+        for (int t = 0; t < TU; ++t) asm volatile("" : "+v"(Bfn[t][kk]));
+      }
+    } else {
+      aT = mtm3(Pf, Af, z4);
+#pragma unroll
+      for (int t = 0; t < TU; ++t) aS[t] = mtm3(Pf, Bf[t], z4);
+    }
+#pragma unroll
+    for (int t = 0; t < TU; ++t)
+#pragma unroll
+      for (int e = 0; e < 3; ++e) Sf[t][e] = aS[t][e];
 #pragma unroll
     for (int e = 0; e < 3; ++e) Tf[e] = (c == 12) ? Pf[e] : aT[e];
     const d4 aXX = mtm3(Af, Tf, z4);
     double Qxx[3], Qux[TU][3], Quu[TU][TU][3], Rr[TU][3];
 #pragma unroll
-    for (int e = 0; e < 3; ++e) Qxx[e] = aXX[e] + cp.qadd[e] + ((cp.xoff[e] >= 0) ? XTk[cp.xoff[e]] : 0.0);
+    for (int e = 0; e < 3; ++e) Qxx[e] = aXX[e] + cp.qadd[e] + ((cp.xoff[e] >= 0) ? xt[e] : 0.0);
 #pragma unroll
     for (int t = 0; t < TU; ++t) {
       const d4 aUX = mtm3(Bf[t], Tf, z4);
 #pragma unroll
       for (int e = 0; e < 3; ++e) {
-        Qux[t][e] = aUX[e] + ((goff[e] >= 0) ? ROTk[84 * t + goff[e]] : 0.0);
+        Qux[t][e] = aUX[e] + ((goff[e] >= 0) ? gt[t][e] : 0.0);
         Rr[t][e] = Qux[t][e];
       }
 #pragma unroll
@@ -490,11 +549,10 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
         const d4 aUU = mtm3(Bf[t], Sf[t2], z4);
 #pragma unroll
         for (int e = 0; e < 3; ++e)
-          Quu[t][t2][e] = aUU[e] + ((t == t2 && doff[e] >= 0) ? ROTk[84 * t + doff[e]] : 0.0);
+          Quu[t][t2][e] = aUU[e] + ((t == t2 && doff[e] >= 0) ? dt_[t][e] : 0.0);
       }
     }
     prof.tick(PH_MFMA);
-    if (PIPE && k > 0) build_operands(k - 1, Afn, Bfn);   // overlaps with the solve below
     // ---- stage solve: [Kt | dt] = -Quu^-1 [Qux | Qu]; swing-leg pivots are decoupled ----
     if (conmask & 1u) gj_leg<0, TU>(Quu, Rr, c, g, minpiv);
     if (conmask & 2u) gj_leg<1, TU>(Quu, Rr, c, g, minpiv);
