@@ -68,7 +68,10 @@ struct Dim {
 // kd_global: the per-knot gains KD and rotation blocks ROT (the two largest
 // arrays) live in an HBM/L2-resident workspace instead of LDS; N=20 then fits 4
 // instances per CU (36 KB) instead of 2 (75 KB), N=10 fits 8 (19 KB).
-__host__ __device__ inline Layout make_layout(int N, bool kd_global = false, int nl = 4) {
+// sl_global: the five slack / multiplier arrays (lane-parallel, coalesced accesses only) live in the
+// workspace as well; offsets S..RC are then relative to that slice.  N=20 drops from 36 KB to 17 KB of LDS
+// (two waves per SIMD instead of one).
+__host__ __device__ inline Layout make_layout(int N, bool kd_global = false, int nl = 4, bool sl_global = false) {
   Layout L;
   int o = 0;
   auto take = [&](int n) { int r = o; o += n; return r; };
@@ -82,17 +85,23 @@ __host__ __device__ inline Layout make_layout(int N, bool kd_global = false, int
   L.U = take(N * nu);
   L.Xc = take((N + 1) * 13);
   L.dU = take(N * nu);   // candidate input increment alpha d + K dx (kept as computed)
-  L.S = take(N * nc);
-  L.LAM = take(N * nc);
-  L.DS = take(N * nc);
-  L.DLAM = take(N * nc);
-  L.RC = take(N * nc);   // slack residual c(u) + s, tracked analytically
+  if (sl_global) {
+    L.S = 0; L.LAM = N * nc; L.DS = 2 * N * nc; L.DLAM = 3 * N * nc; L.RC = 4 * N * nc;
+  } else {
+    L.S = take(N * nc);
+    L.LAM = take(N * nc);
+    L.DS = take(N * nc);
+    L.DLAM = take(N * nc);
+    L.RC = take(N * nc);   // slack residual c(u) + s, tracked analytically
+  }
   L.AB = take(N * kAB);
   L.XT = take((N + 1) * kXT);
   if (kd_global) {
     L.KD = -1;
     L.ROT = -1;
-    L.tile = L.S;    // set-up scratch aliases the (not yet initialised) slack array
+    // set-up scratch (one record, <= 64 doubles) aliases arrays that are not yet initialised: the slack
+    // array, or X..U..Xc (contiguous) when the slacks are in the workspace
+    L.tile = sl_global ? L.X : L.S;
   } else {
     L.KD = take(N * 13 * nu);
     L.ROT = take(N * 21 * nl);

@@ -33,6 +33,7 @@ struct qmpc_handle {
   double* d_B;
   size_t lds_bytes;       // LDS-resident gains
   size_t lds_bytes_g;     // gains in the global workspace
+  size_t lds_bytes_s;     // gains and slack arrays in the global workspace
   double* d_gws;          // [max_batch][N*(156+84)] workspace of the global-gains variant
   int variant;            // 0: auto, 1: LDS gains, 2: global gains (env QMPC_VARIANT)
 };
@@ -217,9 +218,10 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
   h->max_batch = max_batch;
   const int N = params->horizon;
   const int nl = model_nl(params->model), nu = 3 * nl;
-  const Layout L = make_layout(N, false, nl), Lg = make_layout(N, true, nl);
+  const Layout L = make_layout(N, false, nl), Lg = make_layout(N, true, nl), Ls = make_layout(N, true, nl, true);
   h->lds_bytes = (size_t)L.total * sizeof(double);
   h->lds_bytes_g = (size_t)Lg.total * sizeof(double);
+  h->lds_bytes_s = (size_t)Ls.total * sizeof(double);
   if (h->lds_bytes_g > 160 * 1024) { delete h; return QMPC_BAD_ARGUMENT; }
   {
     const char* v = std::getenv("QMPC_VARIANT");
@@ -234,22 +236,25 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
 #define QMPC_SET_LDS(kern, bytes) \
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
   if (params->model == QMPC_MODEL_QUAT8) {
-    QMPC_SET_LDS((qmpc_solve_kernel<Quat8Model, false, true>), h->lds_bytes_g);   // global gains only
+    QMPC_SET_LDS((qmpc_solve_kernel<Quat8Model, false, 1>), h->lds_bytes_g);   // never everything in LDS
+    QMPC_SET_LDS((qmpc_solve_kernel<Quat8Model, false, 2>), h->lds_bytes_s);
   } else if (params->model == QMPC_MODEL_CONVEX) {
-    if (h->lds_bytes <= 160 * 1024) QMPC_SET_LDS((qmpc_solve_kernel<ConvexModel, false, false>), h->lds_bytes);
-    QMPC_SET_LDS((qmpc_solve_kernel<ConvexModel, false, true>), h->lds_bytes_g);
+    if (h->lds_bytes <= 160 * 1024) QMPC_SET_LDS((qmpc_solve_kernel<ConvexModel, false, 0>), h->lds_bytes);
+    QMPC_SET_LDS((qmpc_solve_kernel<ConvexModel, false, 1>), h->lds_bytes_g);
+    QMPC_SET_LDS((qmpc_solve_kernel<ConvexModel, false, 2>), h->lds_bytes_s);
     QMPC_SET_LDS(qmpc_linearize_kernel<ConvexModel>, h->lds_bytes_g);
   } else {
     if (h->lds_bytes <= 160 * 1024) {
-      QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, false, false>), h->lds_bytes);
-      QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, true, false>), h->lds_bytes);
+      QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, false, 0>), h->lds_bytes);
+      QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, true, 0>), h->lds_bytes);
     }
-    QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, false, true>), h->lds_bytes_g);
-    QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, true, true>), h->lds_bytes_g);
+    QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, false, 1>), h->lds_bytes_g);
+    QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, true, 1>), h->lds_bytes_g);
+    QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, false, 2>), h->lds_bytes_s);
     QMPC_SET_LDS(qmpc_linearize_kernel<QuatModel>, h->lds_bytes_g);
   }
 #undef QMPC_SET_LDS
-  HIP_TRY(hipMalloc(&h->d_gws, sizeof(double) * (size_t)N * (13 * nu + 21 * nl) * (size_t)max_batch));
+  HIP_TRY(hipMalloc(&h->d_gws, sizeof(double) * (size_t)N * (13 * nu + 21 * nl + 30 * nl) * (size_t)max_batch));
   *out = h;
   return QMPC_OK;
 }
@@ -271,36 +276,43 @@ void qmpc_destroy(qmpc_handle* h) {
   delete h;
 }
 
-// Variant choice: with the gains in LDS an instance needs 39.6 KB (N=10) / 75 KB (N=20):
-// 4 / 2 instances per CU.  Small batches (<= one instance per SIMD) keep everything in
-// LDS (lowest latency); long horizons and large batches move the gains to the
-// workspace to raise the number of resident instances.
-static bool use_global_gains(const qmpc_handle* h, int32_t batch) {
-  if (h->params.model == QMPC_MODEL_QUAT8) return true;
-  if (h->variant == 1) return h->lds_bytes > 160 * 1024 ? true : false;
-  if (h->variant == 2) return true;
-  if (h->lds_bytes > 40 * 1024) return true;   // fewer than 4 instances per CU otherwise
-  return batch > 4096;
+// Variant choice (0: all LDS, 1: gains in the workspace, 2: gains and slack arrays in the workspace).
+// With everything in LDS an instance needs 39.6 KB (N=10) / 75 KB (N=20): 4 / 2 instances per CU.  Small
+// batches (<= one instance per SIMD) keep everything in LDS (lowest latency); long horizons and large batches
+// move the gains (N=10: 19 KB, two waves per SIMD) and, when that is still more than 20 KB, the slack arrays
+// (N=20: 36 KB -> 17 KB) to the workspace to raise the number of resident instances.
+static int pick_variant(const qmpc_handle* h, int32_t batch) {
+  const bool big = batch > 4096;
+  if (h->variant == 1) return h->lds_bytes > 160 * 1024 ? 1 : 0;
+  if (h->variant == 2) return 1;
+  if (h->variant == 3) return 2;
+  if (h->params.model == QMPC_MODEL_QUAT8) return (big && h->lds_bytes_g > 40 * 1024) ? 2 : 1;
+  if (h->lds_bytes > 40 * 1024) return (big && h->lds_bytes_g > 20 * 1024) ? 2 : 1;   // < 4 instances per CU otherwise
+  return big ? 1 : 0;
 }
+static bool use_global_gains(const qmpc_handle* h, int32_t batch) { return pick_variant(h, batch) >= 1; }
 
 static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces,
                                 qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s) {
   HIP_TRY(hipEventRecord(h->ev0, s));
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;   // the gains workspace is sized by max_batch
-  const bool gg = use_global_gains(h, batch);
-  const size_t lds = gg ? h->lds_bytes_g : h->lds_bytes;
-  double* gws = gg ? h->d_gws : nullptr;
+  const int var = pick_variant(h, batch);
+  const size_t lds = var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes);
+  double* gws = var >= 1 ? h->d_gws : nullptr;
 #define QMPC_LAUNCH(kern) \
   hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kWave), lds, s, h->dev, d_in, d_forces, d_info, d_tu, d_tx, \
                      (int)batch, (long long*)nullptr, gws)
   if (h->params.model == QMPC_MODEL_QUAT8) {
-    QMPC_LAUNCH((qmpc_solve_kernel<Quat8Model, false, true>));
+    if (var == 2) QMPC_LAUNCH((qmpc_solve_kernel<Quat8Model, false, 2>));
+    else QMPC_LAUNCH((qmpc_solve_kernel<Quat8Model, false, 1>));
   } else if (h->params.model == QMPC_MODEL_CONVEX) {
-    if (gg) QMPC_LAUNCH((qmpc_solve_kernel<ConvexModel, false, true>));
-    else QMPC_LAUNCH((qmpc_solve_kernel<ConvexModel, false, false>));
+    if (var == 2) QMPC_LAUNCH((qmpc_solve_kernel<ConvexModel, false, 2>));
+    else if (var == 1) QMPC_LAUNCH((qmpc_solve_kernel<ConvexModel, false, 1>));
+    else QMPC_LAUNCH((qmpc_solve_kernel<ConvexModel, false, 0>));
   } else {
-    if (gg) QMPC_LAUNCH((qmpc_solve_kernel<QuatModel, false, true>));
-    else QMPC_LAUNCH((qmpc_solve_kernel<QuatModel, false, false>));
+    if (var == 2) QMPC_LAUNCH((qmpc_solve_kernel<QuatModel, false, 2>));
+    else if (var == 1) QMPC_LAUNCH((qmpc_solve_kernel<QuatModel, false, 1>));
+    else QMPC_LAUNCH((qmpc_solve_kernel<QuatModel, false, 0>));
   }
 #undef QMPC_LAUNCH
   HIP_TRY(hipGetLastError());
@@ -537,11 +549,11 @@ qmpc_status qmpc_debug_profile(qmpc_handle* h, int32_t batch, const qmpc_input* 
   HIP_TRY(hipMemsetAsync(d_prof, 0, sizeof(long long) * 16 * (size_t)batch, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_in, in, sizeof(qmpc_input) * (size_t)batch, hipMemcpyHostToDevice, h->stream));
   if (use_global_gains(h, batch))
-    hipLaunchKernelGGL((qmpc_solve_kernel<QuatModel, true, true>), dim3((unsigned)batch), dim3(kWave), h->lds_bytes_g, h->stream,
+    hipLaunchKernelGGL((qmpc_solve_kernel<QuatModel, true, 1>), dim3((unsigned)batch), dim3(kWave), h->lds_bytes_g, h->stream,
                        h->dev, h->d_in, h->d_forces, h->d_info, (double*)nullptr, (double*)nullptr, (int)batch, d_prof,
                        h->d_gws);
   else
-    hipLaunchKernelGGL((qmpc_solve_kernel<QuatModel, true, false>), dim3((unsigned)batch), dim3(kWave), h->lds_bytes, h->stream,
+    hipLaunchKernelGGL((qmpc_solve_kernel<QuatModel, true, 0>), dim3((unsigned)batch), dim3(kWave), h->lds_bytes, h->stream,
                        h->dev, h->d_in, h->d_forces, h->d_info, (double*)nullptr, (double*)nullptr, (int)batch, d_prof,
                        (double*)nullptr);
   HIP_TRY(hipGetLastError());

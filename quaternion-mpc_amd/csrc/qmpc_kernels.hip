@@ -256,8 +256,8 @@ __device__ __forceinline__ double cone_value(const DevParams& P, const Layout& L
 //   gq   = T' (R_l (u_l - uref_l)) + sum_i g_i (T'a_i),  g_i = target/s_i - kappa_i lam_i + w_i rc_i
 // ROT record per leg: T (9, row-major [a][b]), Dblk (9), gq (3).
 template <class D>
-__device__ inline void rotation_prepass(const DevParams& P, const Layout& L, double* sm, double* ROT,
-                                        double target, int lane) {
+__device__ inline void rotation_prepass(const DevParams& P, const Layout& L, double* sm, const double* sl,
+                                        double* ROT, double target, int lane) {
   const int N = P.N;
   const double* cst = sm + L.cst;
   double cr[18];
@@ -278,9 +278,9 @@ __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, dou
     double w[6], gi[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const double s = sm[L.S + D::NC * k + 6 * l + i], lam = sm[L.LAM + D::NC * k + 6 * l + i];
-      const double rc = sm[L.RC + D::NC * k + 6 * l + i];
-      const double kap = sm[L.DS + D::NC * k + 6 * l + i];     // weakly-active flag (see ipm_apply)
+      const double s = sl[L.S + D::NC * k + 6 * l + i], lam = sl[L.LAM + D::NC * k + 6 * l + i];
+      const double rc = sl[L.RC + D::NC * k + 6 * l + i];
+      const double kap = sl[L.DS + D::NC * k + 6 * l + i];     // weakly-active flag (see ipm_apply)
       const double is = fast_rcp(s);
       w[i] = lam * is;
       gi[i] = (target + lam * rc) * is - kap * lam;
@@ -689,7 +689,7 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
 //   dlam = (target - (1 + kappa) s lam - lam ds) / s,
 // followed by the fraction-to-the-boundary step lengths.
 template <class D>
-__device__ inline void ipm_directions(const DevParams& P, const Layout& L, double* sm, double target,
+__device__ inline void ipm_directions(const DevParams& P, const Layout& L, double* sm, double* sl, double target,
                                       int lane, double* alpha_p, double* alpha_d) {
   const int N = P.N;
   const double* cst = sm + L.cst;
@@ -701,15 +701,15 @@ __device__ inline void ipm_directions(const DevParams& P, const Layout& L, doubl
     if (cst[D::C_CON + l] != 0.0) {
       const double* du = sm + L.dU + D::NU * k + 3 * l;
       const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
-      const double sv = sm[L.S + idx], lv = sm[L.LAM + idx];
-      const double kap = sm[L.DS + idx];                     // flag left by the previous ipm_apply
-      dsv = -(jd + sm[L.RC + idx]);
+      const double sv = sl[L.S + idx], lv = sl[L.LAM + idx];
+      const double kap = sl[L.DS + idx];                     // flag left by the previous ipm_apply
+      dsv = -(jd + sl[L.RC + idx]);
       dlv = (target - (1.0 + kap) * sv * lv - lv * dsv) * fast_rcp(sv);
       if (dsv < 0.0) ap = fmin(ap, -P.tau * sv * fast_rcp(dsv));
       if (dlv < 0.0) ad = fmin(ad, -P.tau * lv * fast_rcp(dlv));
     }
-    sm[L.DS + idx] = dsv;
-    sm[L.DLAM + idx] = dlv;
+    sl[L.DS + idx] = dsv;
+    sl[L.DLAM + idx] = dlv;
   }
   *alpha_p = wave_min(ap);
   *alpha_d = wave_min(ad);
@@ -722,7 +722,7 @@ __device__ inline void ipm_directions(const DevParams& P, const Layout& L, doubl
 // (dU <- alpha_p dU), hence s + alpha_p ds stays inside the interior exactly and
 // rc <- (1 - alpha_p) rc; a full step zeroes rc exactly.
 template <class D>
-__device__ inline void ipm_apply(const DevParams& P, const Layout& L, double* sm, double ap, double ad,
+__device__ inline void ipm_apply(const DevParams& P, const Layout& L, double* sl, double ap, double ad,
                                  unsigned conmask, int lane, unsigned& kapbits) {
   const int N = P.N;
   unsigned newbits = 0;
@@ -730,13 +730,13 @@ __device__ inline void ipm_apply(const DevParams& P, const Layout& L, double* sm
   for (int idx = lane; idx < N * D::NC; idx += kWave, ++j) {
     const int l = (idx % D::NC) / 6;
     if (!(conmask & (1u << l))) continue;
-    const double s0 = sm[L.S + idx], l0 = sm[L.LAM + idx];
+    const double s0 = sl[L.S + idx], l0 = sl[L.LAM + idx];
     const bool kap0 = (kapbits >> j) & 1u;   // this lane owns row idx in every pass
-    const double s1 = s0 + ap * sm[L.DS + idx];
-    const double l1 = l0 + ad * sm[L.DLAM + idx];
-    sm[L.S + idx] = s1;
-    sm[L.RC + idx] = (ap >= 1.0) ? 0.0 : (1.0 - ap) * sm[L.RC + idx];
-    sm[L.LAM + idx] = l1;
+    const double s1 = s0 + ap * sl[L.DS + idx];
+    const double l1 = l0 + ad * sl[L.DLAM + idx];
+    sl[L.S + idx] = s1;
+    sl[L.RC + idx] = (ap >= 1.0) ? 0.0 : (1.0 - ap) * sl[L.RC + idx];
+    sl[L.LAM + idx] = l1;
     // Tapia indicators: a weakly active row halves BOTH s and lambda on a full Newton
     // step (regular rows send one ratio to ~1, the other to ~sigma).  Such rows get the
     // second-order complementarity right-hand side  target - 2 s lam  next iteration,
@@ -744,7 +744,7 @@ __device__ inline void ipm_apply(const DevParams& P, const Layout& L, double* sm
     const double rs = s1 * fast_rcp(s0), rl = l1 * fast_rcp(l0);
     const bool sig = (ap >= 0.99) && (ad >= 0.99) && (rs < 0.6) && (rl < 0.6) &&
                      (kap0 || ((rs > 0.4) && (rl > 0.4)));
-    sm[L.DS + idx] = sig ? 1.0 : 0.0;        // read by the next rotation pre-pass / directions
+    sl[L.DS + idx] = sig ? 1.0 : 0.0;        // read by the next rotation pre-pass / directions
     newbits |= sig ? (1u << j) : 0u;
   }
   kapbits = newbits;
@@ -786,9 +786,10 @@ __device__ inline double cost_plain(const DevParams& P, const Layout& L, double*
 }
 
 // ---- the solve kernel ---------------------------------------------------------
-// KDG: gains / rotation blocks in the global workspace gws (one slice per instance)
-template <class MD, bool PROF, bool KDG>
-__global__ __launch_bounds__(64, (KDG && MD::NL == 4) ? 2 : 1) void qmpc_solve_kernel(
+// VAR 0: everything in LDS; 1: gains / rotation blocks in the global workspace gws (one slice per instance);
+// 2: the slack / multiplier arrays there as well
+template <class MD, bool PROF, int VAR>
+__global__ __launch_bounds__(64, (VAR >= 1 && MD::NL == 4) ? 2 : 1) void qmpc_solve_kernel(
     DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
     double* __restrict__ traj_u, double* __restrict__ traj_x, int batch, long long* __restrict__ prof_out,
     double* __restrict__ gws) {
@@ -799,9 +800,12 @@ __global__ __launch_bounds__(64, (KDG && MD::NL == 4) ? 2 : 1) void qmpc_solve_k
   if (b >= batch) return;
   const int lane = threadIdx.x;
   const int N = P.N;
-  const Layout L = make_layout(N, KDG, MD::NL);
-  double* KD = KDG ? gws + (size_t)b * N * (D::KD + D::ROT) : sm + L.KD;
+  constexpr bool KDG = VAR >= 1, SLG = VAR == 2;
+  const Layout L = make_layout(N, KDG, MD::NL, SLG);
+  const size_t slice = (size_t)N * (D::KD + D::ROT + (SLG ? 5 * NC : 0));
+  double* KD = KDG ? gws + (size_t)b * slice : sm + L.KD;
   double* ROT = KDG ? KD + N * D::KD : sm + L.ROT;
+  double* sl = SLG ? ROT + N * D::ROT : sm;      // base of the slack arrays (offsets L.S .. L.RC)
   // records are 8 * D::REC bytes apart (48 doubles; 64 for the 8-contact-point model)
   const void* in = reinterpret_cast<const double*>(in_) + (size_t)b * ((MD::NX == 13) ? D::REC : 48);
   int status = QMPC_OK;
@@ -829,10 +833,10 @@ __global__ __launch_bounds__(64, (KDG && MD::NL == 4) ? 2 : 1) void qmpc_solve_k
   for (int i = lane; i < N * NC; i += kWave) {
     const double c0 = cone_value<D>(P, L, sm, i);
     const double s0 = fmax(-c0, 1.0);
-    sm[L.S + i] = s0;
-    sm[L.RC + i] = c0 + s0;
-    sm[L.LAM + i] = P.mu0 / s0;
-    sm[L.DS + i] = 0.0;
+    sl[L.S + i] = s0;
+    sl[L.RC + i] = c0 + s0;
+    sl[L.LAM + i] = P.mu0 / s0;
+    sl[L.DS + i] = 0.0;
   }
   QSYNC();
   prof.tick(PH_SETUP);
@@ -843,15 +847,15 @@ __global__ __launch_bounds__(64, (KDG && MD::NL == 4) ? 2 : 1) void qmpc_solve_k
   status = QMPC_MAX_ITER;
   for (it = 1; it <= P.iterations_max + 1; ++it) {
     // barrier parameter and slack residual over the enabled rows
-    double sl = 0.0, rs = 0.0;
+    double sl_sum = 0.0, rs = 0.0;
     for (int i = lane; i < N * NC; i += kWave) {
       const int l = (i % NC) / 6;
       if (conmask & (1u << l)) {
-        sl += sm[L.S + i] * sm[L.LAM + i];
-        rs = fmax(rs, fabs(sm[L.RC + i]));
+        sl_sum += sl[L.S + i] * sl[L.LAM + i];
+        rs = fmax(rs, fabs(sl[L.RC + i]));
       }
     }
-    mu = wave_sum(sl) * inv_rows;
+    mu = wave_sum(sl_sum) * inv_rows;
     resid = wave_max(rs);
     if (mu <= P.mu_final && resid <= P.tol_feas && last_step <= P.tol_step) { status = QMPC_OK; break; }
     if (it > P.iterations_max) break;
@@ -863,7 +867,7 @@ __global__ __launch_bounds__(64, (KDG && MD::NL == 4) ? 2 : 1) void qmpc_solve_k
     else if (it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
     else if (it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
     const double target = sg * mu;
-    rotation_prepass<D>(P, L, sm, ROT, target, lane);
+    rotation_prepass<D>(P, L, sm, sl, ROT, target, lane);
     if (KDG) __syncthreads();
     prof.tick(PH_MISC);
     if (backward_pass<MD, PROF, !KDG>(P, L, sm, KD, ROT, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
@@ -871,7 +875,7 @@ __global__ __launch_bounds__(64, (KDG && MD::NL == 4) ? 2 : 1) void qmpc_solve_k
     double ap, ad;
     rollout_closed<MD, !KDG, !KDG>(P, L, sm, KD, ROT, 1.0, lane);  // trial step
     prof.tick(PH_ROLL);
-    ipm_directions<D>(P, L, sm, target, lane, &ap, &ad);
+    ipm_directions<D>(P, L, sm, sl, target, lane, &ap, &ad);
     last_ap = ap; last_ad = ad;
     {
       // convergence is judged on the FULL Newton step (the trial increment)
@@ -882,7 +886,8 @@ __global__ __launch_bounds__(64, (KDG && MD::NL == 4) ? 2 : 1) void qmpc_solve_k
     prof.tick(PH_DIRS);
     if (ap < 1.0) rollout_scaled<MD>(P, L, sm, ap, lane);    // shortened primal step
     prof.tick(PH_ROLL);
-    ipm_apply<D>(P, L, sm, ap, ad, conmask, lane, kapbits);
+    ipm_apply<D>(P, L, sl, ap, ad, conmask, lane, kapbits);
+    if (SLG) __syncthreads();
     // accept the candidate
     for (int i = lane; i < N * NU; i += kWave) sm[L.U + i] += sm[L.dU + i];
     for (int i = lane; i < (N + 1) * 13; i += kWave) sm[L.X + i] = sm[L.Xc + i];
