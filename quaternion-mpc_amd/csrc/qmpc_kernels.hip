@@ -19,6 +19,9 @@
 #ifndef QMPC_V2_WAVES
 #define QMPC_V2_WAVES 2
 #endif
+#ifndef QMPC_NL8_WAVES
+#define QMPC_NL8_WAVES 2
+#endif
 
 namespace qmpc {
 
@@ -793,7 +796,7 @@ __device__ inline double cost_plain(const DevParams& P, const Layout& L, double*
 // VAR 0: everything in LDS; 1: gains / rotation blocks in the global workspace gws (one slice per instance);
 // 2: the slack / multiplier arrays there as well
 template <class MD, bool PROF, int VAR>
-__global__ __launch_bounds__(64, (MD::NL != 4 || VAR == 0) ? 1 : (VAR == 2 ? QMPC_V2_WAVES : 2)) void qmpc_solve_kernel(
+__global__ __launch_bounds__(64, VAR == 0 ? 1 : (MD::NL != 4 ? (VAR == 2 ? QMPC_NL8_WAVES : 1) : (VAR == 2 ? QMPC_V2_WAVES : 2))) void qmpc_solve_kernel(
     DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
     double* __restrict__ traj_u, double* __restrict__ traj_x, int batch, long long* __restrict__ prof_out,
     double* __restrict__ gws) {
