@@ -27,7 +27,8 @@ namespace qmpc {
 
 // Optional phase-level cycle accounting (s_memtime), compiled in only for the
 // diagnostic instantiation qmpc_solve_kernel<true>.
-enum { PH_SETUP = 0, PH_EXPAND, PH_BUILD, PH_MFMA, PH_SOLVE, PH_PUPD, PH_DIRS, PH_ROLL, PH_MISC, PH_COUNT };
+enum { PH_SETUP = 0, PH_EXPAND, PH_BUILD, PH_MFMA, PH_SOLVE, PH_PUPD, PH_DIRS, PH_ROLL, PH_MISC,
+       PH_PREPASS, PH_R_GAIN, PH_R_BCAST, PH_R_STEP, PH_APPLY, PH_COUNT };   // 9.. : finer split, diagnostics only
 template <bool PROF>
 struct Prof {
   long long t[PH_COUNT];
@@ -633,9 +634,9 @@ __device__ __forceinline__ void roll_load(const Layout& L, const double* sm, con
 }
 // PF_X: also prefetch the old state (LDS variant: registers to spare); the global-gains
 // variant is register-bound (2 waves/SIMD) and prefetches only its high-latency gain row / T_l
-template <class MD, bool PF_X, bool PF_K>
+template <class MD, bool PF_X, bool PF_K, bool PROF>
 __device__ inline void rollout_closed(const DevParams& P, const Layout& L, double* sm, const double* KD,
-                                      const double* ROT, double alpha, int lane) {
+                                      const double* ROT, double alpha, int lane, Prof<PROF>& prof) {
   typedef typename MD::D D;
   const int N = P.N;
   const double* cst = sm + L.cst;
@@ -674,11 +675,13 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
       if (ulane) sm[L.dU + D::NU * k + uj] = inc;               // the increment, as computed
       unew = cur.uo + inc;
     }
+    prof.tick(PH_R_GAIN);
     if (PF_K && k + 1 < N) roll_load<D, PF_X>(L, sm, KD, ROT, k + 1, uj, ql, qa, nxt);   // one knot ahead
     // broadcast the new inputs from their owner lanes (4l+a) with v_readlane: no LDS round trip
     double un[D::NU];
 #pragma unroll
     for (int j = 0; j < D::NU; ++j) un[j] = read_lane(unew, 4 * (j / 3) + (j % 3));
+    prof.tick(PH_R_BCAST);
     MD::step(P, M, xc, un, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) xc[i] = xn[i];
@@ -686,6 +689,7 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
 #pragma unroll
       for (int i = 0; i < 13; ++i) sm[L.Xc + 13 * (k + 1) + i] = xn[i];
     if (PF_K) cur = nxt;
+    prof.tick(PH_R_STEP);
   }
   QSYNC();
 }
@@ -874,13 +878,14 @@ __global__ __launch_bounds__(64, VAR == 0 ? 1 : (MD::NL != 4 ? (VAR == 2 ? QMPC_
     else if (it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
     else if (it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
     const double target = sg * mu;
+    prof.tick(PH_MISC);
     rotation_prepass<D>(P, L, sm, sl, ROT, target, lane);
     if (KDG) __syncthreads();
-    prof.tick(PH_MISC);
+    prof.tick(PH_PREPASS);
     if (backward_pass<MD, PROF, !KDG>(P, L, sm, KD, ROT, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
     if (KDG) __syncthreads();
     double ap, ad;
-    rollout_closed<MD, !KDG, !KDG>(P, L, sm, KD, ROT, 1.0, lane);  // trial step
+    rollout_closed<MD, !KDG, !KDG, PROF>(P, L, sm, KD, ROT, 1.0, lane, prof);  // trial step
     prof.tick(PH_ROLL);
     ipm_directions<D>(P, L, sm, sl, target, lane, &ap, &ad);
     last_ap = ap; last_ad = ad;
@@ -893,8 +898,10 @@ __global__ __launch_bounds__(64, VAR == 0 ? 1 : (MD::NL != 4 ? (VAR == 2 ? QMPC_
     prof.tick(PH_DIRS);
     if (ap < 1.0) rollout_scaled<MD>(P, L, sm, ap, lane);    // shortened primal step
     prof.tick(PH_ROLL);
+    prof.tick(PH_MISC);
     ipm_apply<D>(P, L, sl, ap, ad, conmask, lane, kapbits);
     if (SLG) __syncthreads();
+    prof.tick(PH_APPLY);
     // accept the candidate
     for (int i = lane; i < N * NU; i += kWave) sm[L.U + i] += sm[L.dU + i];
     for (int i = lane; i < (N + 1) * 13; i += kWave) sm[L.X + i] = sm[L.Xc + i];
