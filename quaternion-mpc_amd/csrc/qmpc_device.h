@@ -1,12 +1,16 @@
-// qmpc_device.h -- device-side building blocks of the batched quaternion-MPC
-// solver for gfx950 (MI355X).  One 64-lane wavefront owns one MPC instance; the
-// whole per-instance working set lives in LDS.
+// qmpc_device.h -- device-side building blocks of the batched MPC inner loop for gfx950 (MI355X).
+// One 64-lane wavefront owns one MPC instance; its working set lives in LDS (the gains and, for long
+// horizons and large batches, the slack arrays move to an L2-resident workspace: make_layout()).
+//
+// Contents: DevParams, the LDS layout, FP64 MFMA helpers on [12][16] tiles, cross-lane primitives (DPP,
+// v_permlane*_swap, v_readlane), wave reductions, and the model policies QuatModelT<NL> / ConvexModel.
 //
 // Reference arithmetic being accelerated (zixinz990/quaternion-mpc, legged_ctrl/):
 //   src/utils/AltroUtils.cpp:363-439   ct_srb_quat_dynamics / _jacobian
+//   src/utils/AltroUtils.cpp:224-359   ct_srb_dynamics / _jacobian (ConvexMpc's model)
 //   src/utils/AltroUtils.cpp:9-22,78-110 explicit midpoint + chain rule (float h)
 //   src/utils/QuaternionUtils.cpp:30-52 L(q), G(q)
-//   src/mpc/QuatMpc.cpp:109-276        problem construction, cone rows, output
+//   src/mpc/QuatMpc.cpp:109-276, src/mpc/ConvexMpc.cpp:81-198   problem construction, cone rows, output
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -44,14 +48,14 @@ struct DevParams {
 
 // ---- per-instance LDS layout (offsets in doubles) ---------------------------
 struct Layout {
-  int cst, bw0, refp, uref, ub, X, U, Xc, dU, S, LAM, DS, DLAM, RC, AB, XT, KD, ROT, tile, total;
+  int cst, bw0, refp, uref, X, U, Xc, dU, S, LAM, DS, DLAM, RC, AB, XT, KD, ROT, tile, total;
 };
 
 // Per-knot record sizes
 constexpr int kAB = 27;    // Aphiphi(9) Aphiw(9) W(9)
 constexpr int kXT = 21;    // lxx attitude block (9), lx (12)
-constexpr int kKD = 156;   // gains [K | d], 12 x 13 row-major            (4 contact points)
-constexpr int kROT = 84;   // per leg: T(9), Dblk(9), gq(3)                (4 contact points)
+// gains [K | d] (13 per input row) and rotation blocks (21 per contact point: T(9), Dblk(9), gq(3)) are sized
+// by Dim<NL>::KD / ::ROT below
 
 // Sizes and cst[] slots for NL contact points (4: Go1, the reference; 8: the synthetic biped of
 // BASELINE config 5).  Inputs come in tiles of 12 (= 4 contact points = one [12][16] MFMA tile).
@@ -80,7 +84,6 @@ __host__ __device__ inline Layout make_layout(int N, bool kd_global = false, int
   L.bw0 = take(3 * nu);
   L.refp = take(13);
   L.uref = take(nu);
-  L.ub = -1;
   L.X = take((N + 1) * 13);
   L.U = take(N * nu);
   L.Xc = take((N + 1) * 13);

@@ -1,19 +1,25 @@
-// qmpc_kernels.hip -- gfx950 kernels of the batched quaternion-MPC solve (v2).
+// qmpc_kernels.hip -- gfx950 kernels of the batched MPC inner loop.
 //
-// One wavefront (64 lanes, one workgroup) owns one MPC instance.  The solve is
-// the converged mode of include/qmpc.h: a primal-dual interior-point iteration
-// whose Newton systems are solved with the iLQR/Riccati recursion over the
-// horizon (12-dim error state, 12 inputs), i.e. the same backward/forward pass
-// structure as the reference's external AL-iLQR solver (QuatMpc.cpp:218-256),
-// with the cone rows (QuatMpc.cpp:194-215) handled by barrier weights instead of
-// penalties.
+// One wavefront (64 lanes, one workgroup) owns one MPC instance.  The solve is the converged mode of
+// include/qmpc.h: a primal-dual interior-point iteration whose Newton systems are solved with the
+// iLQR/Riccati recursion over the horizon (12-dim error state, 3 NL inputs), i.e. the same backward /
+// forward pass structure as the reference's external AL-iLQR solver (QuatMpc.cpp:218-256), with the cone
+// rows (QuatMpc.cpp:194-215) handled by barrier weights instead of penalties.
 //
-// v2 data flow of the backward pass: every 12x12 (+1 gradient column) matrix is
-// held in REGISTERS in the FP64 MFMA fragment layout (lane 16g+c holds rows
-// {g,4+g,8+g} of column c), so the 18 v_mfma_f64_16x16x4_f64 per knot chain
-// without any LDS round trip; per-lane index patterns are computed once; the
-// stage solve is a Gauss-Jordan elimination done with cross-lane moves (DPP
-// row broadcast + ds_bpermute) in the same layout.
+// Everything that differs between the reference's two controllers and the 8-contact-point stand-in of
+// BASELINE config 5 sits in a model policy (qmpc_device.h: QuatModelT<NL>, ConvexModel); this file is the
+// shared core, templated on it:
+//   setup_instance      record -> constants, reference, initial guess
+//   expansions          one lane per knot: compact Jacobian record + cost expansion
+//   rotation_prepass    one lane per (knot, contact point): frame T_l, rotated block, gradient
+//   backward_pass       every 12x12 (+1 gradient column) matrix lives in REGISTERS in the FP64 MFMA fragment
+//                       layout (lane 16g+c holds rows {g,4+g,8+g} of column c), so the v_mfma_f64_16x16x4_f64
+//                       products of a knot chain without any LDS round trip; Gauss-Jordan stage solve with
+//                       cross-lane moves (DPP row broadcast, ds_bpermute, v_readlane) in the same layout
+//   rollout_*           nonlinear rollouts; rotated gains applied inside lane quads
+//   ipm_directions / ipm_apply   slack / multiplier bookkeeping over the cone rows
+//   qmpc_solve_kernel<MD, PROF, VAR>   VAR: where the gains and the slack arrays live (LDS / workspace)
+//   qmpc_linearize_kernel, qmpc_leg_kernel, self-test kernels
 #include "qmpc_device.h"
 
 #ifndef QMPC_V2_WAVES
