@@ -6,7 +6,7 @@
 // grf_update packs the LeggedState fields the reference reads (ConvexMpc.cpp:92-167)
 // into one qmpc_convex_input and replaces the ALTRO set-up / Solve() / GetInput(0)
 // block (ConvexMpc.cpp:84-187) by ONE call into the C ABI (include/qmpc.h).
-// The swing-foot targets the FSM would publish (:216-220) are out of scope (8f rank 3).
+// foot_update also publishes the FSM's swing-foot targets (:216-220; SwingTrajectoryHip.h).
 #pragma once
 
 #include <chrono>
@@ -77,11 +77,21 @@ class ConvexMpcHipT : public LeggedMpcHipT<State> {
         state.ctrl.plan_contacts[i] = true;
       }
     } else {
-      for (int i = 0; i < NUM_LEG; ++i)
-        state.ctrl.gait_counter[i] =
-            leg_FSM[i].update(h / 1000.0, state.param.gait_freq, static_cast<bool>(state.fbk.foot_contact_flag[i]));
+      for (int i = 0; i < NUM_LEG; ++i) {
+        const double cur[3] = {state.fbk.foot_pos_world(0, i), state.fbk.foot_pos_world(1, i), state.fbk.foot_pos_world(2, i)};
+        const double tgt[3] = {state.ctrl.foot_pos_target_world(0, i), state.ctrl.foot_pos_target_world(1, i),
+                               state.ctrl.foot_pos_target_world(2, i)};
+        state.ctrl.gait_counter[i] = leg_FSM[i].update(h / 1000.0, state.param.gait_freq, cur, tgt,
+                                                       static_cast<bool>(state.fbk.foot_contact_flag[i]));
+      }
       for (int i = 0; i < NUM_LEG; ++i) state.ctrl.plan_contacts[i] = leg_FSM[i].get_contact_state();
     }
+    for (int i = 0; i < NUM_LEG; ++i)   // FSM foot targets for the joint-level controller (:216-220)
+      for (int a = 0; a < 3; ++a) {
+        state.ctrl.optimized_state[6 + 3 * i + a] = leg_FSM[i].FSM_foot_pos_target_world[a];
+        state.ctrl.optimized_input[12 + 3 * i + a] = leg_FSM[i].FSM_foot_vel_target_world[a];
+        state.ctrl.optimized_input[24 + 3 * i + a] = leg_FSM[i].FSM_foot_acc_target_world[a];
+      }
     return true;
   }
 

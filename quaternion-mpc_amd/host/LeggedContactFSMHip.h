@@ -10,12 +10,15 @@
 //                       pattern index wraps)
 //   percent_in_state()  :261-270
 //   reset()/reset_params()/set_default_gait_pattern()  :4-31,87-108
-// The swing-foot quintic trajectory (swing_update, :237-246) is NOT on the force
-// path and is out of scope; the foot targets it would fill
-// are left untouched.
+// The swing-foot side (not on the force path) is the second update() overload:
+//   swing_enter / stance_enter / stance_exit   :80-86,225-235
+//   swing_update (quintic foot target)         :237-246
+// It leaves the schedule arithmetic untouched.
 #pragma once
 
 #include <vector>
+
+#include "SwingTrajectoryHip.h"
 
 namespace legged {
 
@@ -79,7 +82,53 @@ class LeggedContactFSMHip {
     return gait_phase;
   }
 
+  // Full update (:33-78): the schedule step above plus the foot targets of the state entered / held.
+  double update(double dt, double gait_freq_now, const double foot_pos_cur_world[3],
+                const double foot_pos_target_world[3], bool foot_force_flag) {
+    if (not_first_call == false) {                      // :37-43
+      for (int a = 0; a < 3; ++a) {
+        swing_start_foot_pos_world[a] = foot_pos_cur_world[a];
+        swing_end_foot_pos_world[a] = foot_pos_target_world[a];
+        FSM_foot_pos_target_world[a] = foot_pos_target_world[a];
+        FSM_foot_vel_target_world[a] = 0.0;
+      }
+      not_first_call = true;
+    }
+    gait_phase += gait_freq_now * dt;
+    if (s == STANCE_HIP) {
+      if (gait_phase >= cur_state_end_time) {
+        terrain_height = foot_pos_cur_world[2];         // stance_exit, :80-84
+        common_enter();                                 // swing_enter, :225-229
+        for (int a = 0; a < 3; ++a) { swing_start_foot_pos_world[a] = foot_pos_cur_world[a]; swing_extend_foot_pos_world[a] = 0.0; }
+        s = SWING_HIP;
+      }
+    } else if (s == SWING_HIP) {
+      if ((percent_in_state() > 0.9 && foot_force_flag) || percent_in_state() >= 1.0) {
+        s = STANCE_HIP;
+        common_enter();                                 // stance_enter, :231-235
+        for (int a = 0; a < 3; ++a) { FSM_foot_pos_target_world[a] = foot_pos_cur_world[a]; FSM_foot_vel_target_world[a] = 0.0; }
+      }
+    }
+    if (s == SWING_HIP) {                               // swing_update, :237-246 (stance_update is empty upstream)
+      const double t = percent_in_state();
+      double fin[3], out[9];
+      for (int a = 0; a < 3; ++a) fin[a] = foot_pos_target_world[a] + swing_extend_foot_pos_world[a];
+      quintic_curve.get_foot_swing_target(static_cast<float>(0.5 * t / gait_freq_now),
+                                          static_cast<float>(0.5 / gait_freq_now), swing_start_foot_pos_world, fin, out);
+      for (int a = 0; a < 3; ++a) {
+        FSM_foot_pos_target_world[a] = out[a];
+        FSM_foot_vel_target_world[a] = out[3 + a];
+        FSM_foot_acc_target_world[a] = out[6 + a];
+      }
+    }
+    return gait_phase;
+  }
+
   LeggedContactStateHip get_contact_state() const { return s; }
+  double FSM_foot_pos_target_world[3] = {0, 0, 0};      // LeggedContactFSM.h:67-69
+  double FSM_foot_vel_target_world[3] = {0, 0, 0};
+  double FSM_foot_acc_target_world[3] = {0, 0, 0};
+  double terrain_height = 0.0;
   double phase() const { return gait_phase; }
 
  private:
@@ -97,6 +146,11 @@ class LeggedContactFSMHip {
     return percent;
   }
 
+  bool not_first_call = false;                          // LeggedContactFSM.h:96-99,105
+  double swing_start_foot_pos_world[3] = {0, 0, 0};
+  double swing_end_foot_pos_world[3] = {0, 0, 0};
+  double swing_extend_foot_pos_world[3] = {0, 0, 0};    // never assigned upstream before the first swing_enter
+  QuinticCurveHip quintic_curve;
   int leg_id = 0;
   LeggedContactStateHip s = STANCE_HIP;
   // The reference first assigns gait_phase in reset() (:12), i.e. it is

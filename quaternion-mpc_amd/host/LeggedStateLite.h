@@ -65,6 +65,7 @@ struct LeggedFeedbackLite {   // LeggedState.h:20-77
   lite::Matrix3d torso_rot_mat_z;
   lite::Vector3d torso_lin_vel_world;
   lite::Vector3d torso_lin_vel_body;
+  lite::Vector3d torso_lin_vel_rel;            // BaseInterface.cpp:267
   lite::Vector3d torso_ang_vel_body;
   lite::Vector4d foot_contact_flag;
   lite::Mat<LEG_DOF, NUM_LEG> foot_pos_body;
@@ -87,6 +88,8 @@ struct LeggedCtrlLite {       // LeggedState.h:79-125
   lite::Vector3d torso_lin_vel_d_world;
   lite::Vector3d torso_ang_vel_d_body;
   lite::Mat<3, NUM_LEG> foot_pos_target_world;
+  lite::Mat<3, NUM_LEG> foot_pos_target_abs;   // LeggedState.h:102-104
+  lite::Mat<3, NUM_LEG> foot_pos_target_rel;
   bool plan_contacts[NUM_LEG] = {true, true, true, true};
   lite::Mat<6 + 3 * NUM_LEG, 1> optimized_state;
   lite::Mat<9 * NUM_LEG, 1> optimized_input;
@@ -113,7 +116,11 @@ struct LeggedParamLite {      // LeggedState.h:160-244, values of gazebo_go1_qua
   lite::Matrix3d trunk_inertia;
   double mu = 0.7;
   double fz_max = 100.0;
+  lite::Mat<3, NUM_LEG> default_foot_pos_rel;  // LeggedState.h:172, yaml default_foot_pos_*
   LeggedParamLite() {
+    const double f[4][3] = {{0.20, 0.14, -0.3}, {0.20, -0.14, -0.3}, {-0.20, 0.14, -0.3}, {-0.20, -0.14, -0.3}};
+    for (int l = 0; l < NUM_LEG; ++l)
+      for (int a = 0; a < 3; ++a) default_foot_pos_rel(a, l) = f[l][a];
     const double q[13] = {2.5, 2.5, 10.0, 0, 0, 0, 0, 0.1, 0.1, 0.1, 0.15, 0.15, 0.15};
     for (int i = 0; i < 13; ++i) q_weights[i] = q[i];
     for (int i = 0; i < 12; ++i) r_weights[i] = 0.000001;

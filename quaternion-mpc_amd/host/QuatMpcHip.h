@@ -138,9 +138,13 @@ class QuatMpcHipT : public LeggedMpcHipT<State> {
         state.ctrl.plan_contacts[i] = true;
       }
     } else {
-      for (int i = 0; i < NUM_LEG; ++i)
-        state.ctrl.gait_counter[i] =
-            leg_FSM[i].update(5.0 / 1000.0, state.param.gait_freq, static_cast<bool>(state.fbk.foot_contact_flag[i]));
+      for (int i = 0; i < NUM_LEG; ++i) {
+        const double cur[3] = {state.fbk.foot_pos_world(0, i), state.fbk.foot_pos_world(1, i), state.fbk.foot_pos_world(2, i)};
+        const double tgt[3] = {state.ctrl.foot_pos_target_world(0, i), state.ctrl.foot_pos_target_world(1, i),
+                               state.ctrl.foot_pos_target_world(2, i)};
+        state.ctrl.gait_counter[i] = leg_FSM[i].update(5.0 / 1000.0, state.param.gait_freq, cur, tgt,
+                                                       static_cast<bool>(state.fbk.foot_contact_flag[i]));
+      }
       for (int i = 0; i < NUM_LEG; ++i) state.ctrl.plan_contacts[i] = leg_FSM[i].get_contact_state();
     }
     return true;

@@ -203,6 +203,44 @@ void qh_fsm_run(double gait_freq, int ticks, const double* mode, const double* f
   }
 }
 
+// swing-foot quintic (Utils.cpp:236-293): out = pos(3) vel(3) acc(3)
+void qh_swing_target(float t, float T, const double* start, const double* fin, double* out) {
+  legged::QuinticCurveHip q;
+  q.get_foot_swing_target(t, T, start, fin, out);
+}
+
+// full FSM update over `ticks` ticks for one leg: cur / tgt are [ticks][3], flags [ticks];
+// outputs contacts [ticks], phases [ticks], targets [ticks][9] (pos, vel, acc)
+void qh_fsm_leg_run(int leg, double gait_freq, double dt, int ticks, const double* cur, const double* tgt,
+                    const double* flags, int32_t* contacts, double* phases, double* targets) {
+  legged::LeggedContactFSMHip fsm;
+  fsm.reset_params(gait_freq, leg);
+  fsm.reset();
+  for (int t = 0; t < ticks; ++t) {
+    phases[t] = fsm.update(dt, gait_freq, cur + 3 * t, tgt + 3 * t, static_cast<bool>(flags[t]));
+    contacts[t] = (int32_t)fsm.get_contact_state();
+    for (int a = 0; a < 3; ++a) {
+      targets[9 * t + a] = fsm.FSM_foot_pos_target_world[a];
+      targets[9 * t + 3 + a] = fsm.FSM_foot_vel_target_world[a];
+      targets[9 * t + 6 + a] = fsm.FSM_foot_acc_target_world[a];
+    }
+  }
+}
+
+// Raibert foothold targets (BaseInterface.cpp:266-288) on the harness state; vel_d_rel(3) is
+// ctrl.torso_lin_vel_d_rel; out = foot_pos_target_abs(12) rel(12) world(12), [3*leg+axis]
+void qh_raibert(void* p, const double* vel_d_rel, double* out) {
+  LeggedStateLite& s = static_cast<Harness*>(p)->state;
+  for (int i = 0; i < 3; ++i) s.ctrl.torso_lin_vel_d_rel[i] = vel_d_rel[i];
+  legged::raibert_foot_targets(s);
+  for (int l = 0; l < 4; ++l)
+    for (int a = 0; a < 3; ++a) {
+      out[3 * l + a] = s.ctrl.foot_pos_target_abs(a, l);
+      out[12 + 3 * l + a] = s.ctrl.foot_pos_target_rel(a, l);
+      out[24 + 3 * l + a] = s.ctrl.foot_pos_target_world(a, l);
+    }
+}
+
 void qh_filter_run(int window, int n, const double* in, double* out) {
   legged::MovingWindowFilterHip f(window);
   for (int i = 0; i < n; ++i) out[i] = f.CalculateAverage(in[i]);

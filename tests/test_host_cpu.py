@@ -293,3 +293,113 @@ def test_convex_pack_input_and_schedule(host, pkg):
     assert np.array_equal(rec["pos_d_world"][0], g[6:9]) and np.array_equal(rec["lin_vel_d_world"][0], g[3:6])
     assert host.qh_convex_grf_update(h) == 0                     # no device behind it: fails loudly
     host.qh_destroy(h)
+
+
+# ---- the step before the force path: swing trajectory, Raibert foothold, FSM targets -------
+def _py_quintic(t, T, start, fin):
+    """Independent restatement of QuinticCurve::get_foot_swing_target (Utils.cpp:236-293): matrix entries and the
+    powers of t in float32 (t, T are float arguments upstream), the 6x6 solve in double."""
+    f = np.float32
+    t, T = f(t), f(T)
+    C = np.array([[1, 0, 0, 0, 0, 0],
+                  [1, T, T * T, T * T * T, T * T * T * T, T * T * T * T * T],
+                  [0, 1, 0, 0, 0, 0],
+                  [0, 1, f(2) * T, f(3) * T * T, f(4) * T * T * T, f(5) * T * T * T * T],
+                  [1, T / f(2), T * T / f(4), T * T * T / f(8), T * T * T * T / f(16), T * T * T * T * T / f(32)],
+                  [0, 1, T, f(3) * T * T / f(4), f(4) * T * T * T / f(8), f(5) * T * T * T * T / f(16)]], dtype=np.float64)
+    dx, dy = fin[0] - start[0], fin[1] - start[1]
+    k = 1.26 / float(T)
+    vm = k * np.sqrt(dx * dx + dy * dy)
+    th = np.arctan2(abs(dy), abs(dx))
+    vx = (1 if dx >= 0 else -1) * vm * np.cos(th)
+    vy = (1 if dy >= 0 else -1) * vm * np.sin(th)
+    cons = [[start[0], fin[0], 0, 0, (start[0] + fin[0]) / 2, vx], [start[1], fin[1], 0, 0, (start[1] + fin[1]) / 2, vy],
+            [start[2], fin[2], 0.1, -0.1, 0.1, 0.0]]
+    out = np.zeros(9)
+    td = float(t); t2 = float(t * t); t3 = float(t * t * t); t4 = float(t * t * t * t); t5 = float(t * t * t * t * t)
+    for ax in range(3):
+        a = np.linalg.solve(C, np.array(cons[ax], dtype=float))
+        out[ax] = a[0] + a[1] * td + a[2] * t2 + a[3] * t3 + a[4] * t4 + a[5] * t5
+        out[3 + ax] = a[1] + 2 * a[2] * td + 3 * a[3] * t2 + 4 * a[4] * t3 + 5 * a[5] * t4
+        out[6 + ax] = 2 * a[2] + 6 * a[3] * td + 12 * a[4] * t2 + 20 * a[5] * t3
+    return out
+
+
+def test_swing_quintic_matches_restatement_and_boundary_conditions(host):
+    host.qh_swing_target.argtypes = [C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(9)
+    T = 0.5 / 2.2
+    for _ in range(50):
+        start = rng.uniform(-0.3, 0.3, 3); fin = start + rng.uniform(-0.2, 0.2, 3); fin[2] = start[2] + rng.uniform(-0.02, 0.02)
+        for t in (0.0, 0.13 * T, 0.5 * T, 0.9 * T, T):
+            out = np.zeros(9)
+            host.qh_swing_target(t, T, start.ctypes.data, fin.ctypes.data, out.ctypes.data)
+            assert np.abs(out - _py_quintic(t, T, start, fin)).max() < 1e-8
+        o0 = np.zeros(9); oT = np.zeros(9); om = np.zeros(9)
+        host.qh_swing_target(0.0, T, start.ctypes.data, fin.ctypes.data, o0.ctypes.data)
+        host.qh_swing_target(T, T, start.ctypes.data, fin.ctypes.data, oT.ctypes.data)
+        host.qh_swing_target(T / 2, T, start.ctypes.data, fin.ctypes.data, om.ctypes.data)
+        assert np.abs(o0[:3] - start).max() < 1e-12 and np.abs(o0[3:6] - [0, 0, 0.1]).max() < 1e-12
+        # the float32 matrix entries / powers of t limit these to ~1e-5 (the reference's own rounding)
+        assert np.abs(oT[:3] - fin).max() < 1e-5 and np.abs(oT[3:6] - [0, 0, -0.1]).max() < 1e-3
+        assert abs(om[2] - 0.1) < 1e-5 and abs(om[5]) < 1e-3                     # apex: ABSOLUTE height 0.1, Utils.cpp:259
+
+
+def test_fsm_full_update_publishes_foot_targets(host):
+    host.qh_fsm_leg_run.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int] + [C.c_void_p] * 6
+    ticks, freq, dt = 400, 2.2, 0.005
+    rng = np.random.default_rng(10)
+    cur = np.cumsum(rng.normal(0, 1e-3, (ticks, 3)), axis=0) + [0.2, 0.14, 0.0]
+    tgt = cur + [0.05, 0.0, 0.0]
+    flags = (rng.random(ticks) < 0.2).astype(float)
+    for leg in range(4):
+        contacts = np.zeros(ticks, dtype=np.int32); phases = np.zeros(ticks); targets = np.zeros((ticks, 9))
+        host.qh_fsm_leg_run(leg, freq, dt, ticks, cur.ctypes.data, tgt.ctypes.data, flags.ctypes.data,
+                            contacts.ctypes.data, phases.ctypes.data, targets.ctypes.data)
+        # the schedule is the one of the schedule-only update (bit-exact restatement above)
+        m = PyFSM(leg); m.reset()
+        start = cur[0].copy(); pos = tgt[0].copy(); vel = np.zeros(3); acc = np.zeros(3)
+        for t in range(ticks):
+            prev = m.s
+            m.update(dt, freq, bool(flags[t]))
+            assert contacts[t] == m.s and phases[t] == m.phase
+            if prev == PyFSM.STANCE and m.s == PyFSM.SWING:
+                start = cur[t].copy()                                   # swing_enter
+            if prev == PyFSM.SWING and m.s == PyFSM.STANCE:
+                pos, vel = cur[t].copy(), np.zeros(3)                   # stance_enter
+            if m.s == PyFSM.SWING:
+                o = _py_quintic(0.5 * m._pct() / freq, 0.5 / freq, start, tgt[t])
+                pos, vel, acc = o[:3], o[3:6], o[6:]
+            assert np.abs(targets[t, :3] - pos).max() < 1e-8, (leg, t)
+            assert np.abs(targets[t, 3:6] - vel).max() < 1e-7 and np.abs(targets[t, 6:] - acc).max() < 1e-5
+
+
+def test_raibert_foot_targets(host):
+    host.qh_raibert.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    h = host.qh_create(None, 10)
+    yaw = -0.4
+    f = _yaw_feedback(yaw)
+    host.qh_set_feedback(h, f.ctypes.data)
+    vd = np.array([0.4, -0.1, 0.0])
+    out = np.zeros(36)
+    host.qh_raibert(h, vd.ctypes.data, out.ctypes.data)
+    c, s = np.cos(yaw), np.sin(yaw)
+    Rz = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    vrel = Rz.T @ f[16:19]
+    k = np.sqrt(abs(f[15]) / 9.81)
+    d = np.array([k * (vrel[0] - vd[0]) + (1 / 2.2) / 2 * vd[0], k * (vrel[1] - vd[1]) + (1 / 2.2) / 2 * vd[1], 0.0])
+    d[0] = np.clip(d[0], -0.5, 0.5); d[1] = np.clip(d[1], -0.3, 0.3)
+    feet = np.array([[0.20, 0.14, -0.3], [0.20, -0.14, -0.3], [-0.20, 0.14, -0.3], [-0.20, -0.14, -0.3]])
+    a = (Rz @ feet.T).T + [*(Rz @ d)[:2], 0.0]
+    assert np.abs(out[:12].reshape(4, 3) - a).max() < 1e-14
+    assert np.abs(out[12:24].reshape(4, 3) - a @ Rz).max() < 1e-14          # torso_rot_mat' * abs (yaw-only attitude)
+    assert np.abs(out[24:].reshape(4, 3) - (a + f[13:16])).max() < 1e-14
+    # the clamp (FOOT_DELTA_X/Y_LIMIT, LeggedParams.h:21-22)
+    vd2 = np.array([-20.0, 30.0, 0.0])
+    host.qh_raibert(h, vd2.ctypes.data, out.ctypes.data)
+    d2 = np.array([k * (vrel[0] - vd2[0]) + (1 / 2.2) / 2 * vd2[0], k * (vrel[1] - vd2[1]) + (1 / 2.2) / 2 * vd2[1], 0.0])
+    assert abs(d2[0]) > 0.5 and abs(d2[1]) > 0.3                            # both limits are hit
+    d2[0] = np.clip(d2[0], -0.5, 0.5); d2[1] = np.clip(d2[1], -0.3, 0.3)
+    a2 = (Rz @ feet.T).T + [*(Rz @ d2)[:2], 0.0]
+    assert np.abs(out[:12].reshape(4, 3) - a2).max() < 1e-14
+    host.qh_destroy(h)
