@@ -87,6 +87,8 @@ def lib() -> C.CDLL:
         _lib.qo_kat_pendulum_midpoint.argtypes = [dp, dp]
         _lib.qo_kat_pendulum_swingup.argtypes = [dp, i32]
         _lib.qo_kat_pendulum_swingup.restype = i32
+        _lib.qo_kat_pendulum_goal.argtypes = [dp, i32]
+        _lib.qo_kat_pendulum_goal.restype = i32
     return _lib
 
 
@@ -235,6 +237,12 @@ def kat_pendulum_midpoint():
     xn = (C.c_double * 2)(); J = (C.c_double * 6)()
     lib().qo_kat_pendulum_midpoint(xn, J)
     return np.array(xn), np.array(J).reshape(3, 2).T  # col-major 2x3
+
+
+def kat_pendulum_goal(verbose: int = 0):
+    out = (C.c_double * 8)()
+    lib().qo_kat_pendulum_goal(out, verbose)
+    return list(out)
 
 
 def kat_pendulum_swingup(verbose: int = 0):

@@ -8,6 +8,10 @@
  *     GetIterations()==5)
  *   legged_ctrl/src/test/test_altro/TestPendulum.cpp:13-43 (midpoint KAT),
  *     :45-115 (swing-up, xN_expected, <= 10 iterations)
+ *   legged_ctrl/src/test/test_altro/TestDoubleIntegrator.cpp:69-168 (unconstrained,
+ *     3 iterations: closer to the goal than x0 but farther than 1e-3)
+ *   legged_ctrl/src/test/test_altro/TestPendulum.cpp:117-203 (goal constrained,
+ *     |xN - xf| < 1e-4 in <= 10 iterations)
  *   legged_ctrl/src/test/test_altro/AltroTestUtils.cpp:45-82 (pendulum model)
  */
 #include <math.h>
@@ -73,7 +77,7 @@ static void di_problem(qo_problem* p, double x00, double x01) {
   p->x0[0] = x00; p->x0[1] = x01;
 }
 
-/* which: 0 = SolveGoalConstraint, 1 = ControlBounds.
+/* which: 0 = SolveGoalConstraint, 1 = ControlBounds, 2 = SolverUnconstrained (iterations_max = 3).
  * out[0]=iterations, out[1]=status, out[2]=|x_N|, out[3..4]=u_0 */
 int qo_kat_double_integrator(int which, double* out, int verbose) {
   static qo_problem p;
@@ -81,7 +85,11 @@ int qo_kat_double_integrator(int which, double* out, int verbose) {
   qo_default_options(&o, QO_MODE_REFERENCE);
   o.verbose = verbose;
   o.penalty_scaling = 100.0;
-  if (which == 0) {
+  if (which == 2) {
+    di_problem(&p, 1.0, 2.0);
+    p.ncon = 0;
+    o.iterations_max = 3;   /* TestDoubleIntegrator.cpp:129 */
+  } else if (which == 0) {
     di_problem(&p, 1.0, 2.0);
     p.ncon = 1;
     p.con[0] = (qo_constraint){QO_EQUALITY, 4, 10, 11, goal_con, goal_jac, NULL, NULL};
@@ -165,5 +173,45 @@ int qo_kat_pendulum_swingup(double* out, int verbose) {
   out[1] = r.status;
   out[2] = X[100];
   out[3] = X[101];
+  return r.status;
+}
+
+/* TestPendulum.cpp:117-203: N = 20, tf = 2, terminal equality x_N = (pi, 0).
+ * out[0]=iterations, out[1]=status, out[2]=|x_N - xf| */
+static void pend_goal_con(void* ctx, int k, double* c, const double* x, const double* u) {
+  (void)ctx; (void)k; (void)u;
+  c[0] = M_PI - x[0];
+  c[1] = 0.0 - x[1];
+}
+static void pend_goal_jac(void* ctx, int k, double* J, const double* x, const double* u) {
+  (void)ctx; (void)k; (void)x; (void)u;
+  J[0 + 2 * 0] = -1.0; /* 2 x 3 col-major, -I on the state block */
+  J[1 + 2 * 1] = -1.0;
+}
+int qo_kat_pendulum_goal(double* out, int verbose) {
+  static qo_problem p;
+  memset(&p, 0, sizeof p);
+  p.n = 2; p.m = 1; p.N = 20;
+  const float tf = 2.0f;
+  p.h = tf / (float)20.0;
+  p.dyn = pend_dyn; p.jac = pend_jac;
+  for (int k = 0; k <= 20; ++k) {
+    for (int i = 0; i < 2; ++i) p.Q[k][i] = (k == 20) ? 1.0 : 1e-2;
+    p.R[k][0] = 1e-3;
+    p.xref[k][0] = M_PI;
+  }
+  p.ncon = 1;
+  p.con[0] = (qo_constraint){QO_EQUALITY, 2, 20, 21, pend_goal_con, pend_goal_jac, NULL, NULL};
+  qo_options o;
+  qo_default_options(&o, QO_MODE_REFERENCE);
+  o.iterations_max = 100;
+  o.verbose = verbose;
+  double X[21 * 2], U[20];
+  for (int k = 0; k < 20; ++k) U[k] = 0.1;
+  qo_result r;
+  qo_altro_solve(&p, &o, X, U, &r);
+  out[0] = r.iterations;
+  out[1] = r.status;
+  out[2] = hypot(X[40] - M_PI, X[41]);
   return r.status;
 }

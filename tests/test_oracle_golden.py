@@ -198,3 +198,19 @@ def test_scenarios_are_counter_based(pkg):
     assert a[48:].tobytes() != c.tobytes()
     assert np.allclose(np.linalg.norm(a["quat"], axis=1), 1.0)
     assert set(np.unique(a["contacts"].sum(1))) <= {2.0, 4.0}
+
+
+def test_kat_double_integrator_unconstrained(oracle):
+    """TestDoubleIntegrator.cpp:69-168: Success within iterations_max = 3; the final state is closer to
+    the goal than x0 = (1, 2, 0, 0) but not on it (:166-167)."""
+    it, status, dist, *_ = oracle.kat_double_integrator(2)
+    assert status == 0 and it <= 3
+    assert 1e-3 < dist < np.hypot(1.0, 2.0)
+
+
+def test_kat_pendulum_goal_constrained(oracle):
+    """TestPendulum.cpp:117-203: terminal equality x_N = (pi, 0) met to 1e-4 in at most 10 iterations."""
+    it, status, dist, *_ = oracle.kat_pendulum_goal()
+    assert status == 0
+    assert dist < 1e-4          # :201
+    assert it <= 10             # :202
