@@ -719,11 +719,11 @@ void qo_default_options(qo_options* o, int mode) {
     o->penalty_scaling = 10.0;
     o->tol_step = 0.0;
   } else {
-    o->iterations_max = 40;
+    o->iterations_max = 120;
     o->penalty_scaling = 10.0;
     o->tol_feasibility = 1e-8;
     o->tol_step = 1e-8;
-    o->ipm_iterations_max = 40;
+    o->ipm_iterations_max = 120;
     o->ipm_mu_final = 1e-12;
     o->ipm_sigma = 0.2;
     o->ipm_sigma_fast = 0.01;

@@ -102,7 +102,7 @@ void qmpc_default_params(qmpc_params* p, int32_t horizon, int32_t mode) {
     p->penalty_scaling = 20.0;  // QuatMpc.cpp:26
     p->tol_feasibility = 1e-4;
   } else {
-    p->iterations_max = 40;
+    p->iterations_max = 120;  // horizon 32 needs up to 86 interior-point iterations on the synthetic states
     p->penalty_scaling = 10.0;
     p->tol_feasibility = 1e-8;
     p->tol_step = 1e-8;
