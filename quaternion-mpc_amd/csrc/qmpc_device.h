@@ -255,64 +255,44 @@ __device__ __forceinline__ void quat_Omega(const double* w, double O[16]) {
   O[12] = z; O[13] = y; O[14] = -x; O[15] = 0;
 }
 
-// Model constants of one instance held in registers by the rollouts.
-// NL = 4: Bw0 = Iinv skew(r_l) c_l (36 numbers); NL = 8: the masked contact points c_l r_l (24 numbers) and
-// the torque is formed with cross products (72 numbers of Bw0 would not fit the register budget).
+// Model constants of one instance held in registers by the rollouts: the masked contact points c_l r_l
+// (3 NL numbers; Bw0 = Iinv skew(r_l) c_l would be 9 NL) -- the torque is formed with cross products, as
+// the reference does (AltroUtils.cpp:376-391).
 template <int NL>
 struct ModelRegsT {
-  double con[NL], gb[3], wd0[3], bw[NL == 4 ? 36 : 3 * NL];
+  double gb[3], wd0[3], rm[3 * NL];
   __device__ __forceinline__ void load(const double* cst, const double* bw0) {
     typedef Dim<NL> D;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) con[i] = cst[D::C_CON + i];
-#pragma unroll
     for (int i = 0; i < 3; ++i) { gb[i] = cst[D::C_GB + i]; wd0[i] = cst[D::C_WD0 + i]; }
-    if (NL == 4) {
 #pragma unroll
-      for (int i = 0; i < 36; ++i) bw[i] = bw0[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 3 * NL; ++i) bw[i] = con[i / 3] * cst[D::C_FOOT + i];
-    }
+    for (int i = 0; i < 3 * NL; ++i) rm[i] = cst[D::C_CON + i / 3] * cst[D::C_FOOT + i];
   }
 };
 typedef ModelRegsT<4> ModelRegs;
 
 // Explicit-midpoint step of the quaternion SRBD (AltroUtils.cpp:9-22 applied to
 // :363-392).  vdot and wdot do not depend on the state, so both midpoint
-// evaluations share them.  x, xn: 13 doubles in registers.
+// evaluations share them.  x, xn: 13 doubles in registers.  Swing-point inputs are
+// identically zero in every rollout (zero reference, zero gains), so the force sum needs no mask.
 template <int NL>
 __device__ __forceinline__ void srbd_step(const DevParams& P, const ModelRegsT<NL>& M, const double* x,
                                           const double* u, double* xn) {
-  double F[3] = {0, 0, 0};
-#pragma unroll
-  for (int l = 0; l < NL; ++l) {
-    const double c = M.con[l];
-    F[0] += c * u[3 * l]; F[1] += c * u[3 * l + 1]; F[2] += c * u[3 * l + 2];
-  }
-  double vd[3], wd[3];
-  if (NL == 4) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      // four independent partial sums: the wave has no other work to hide a 12-deep FMA chain
-      const double* b = &M.bw[12 * a];
-      const double s0 = M.wd0[a] + b[0] * u[0] + b[1] * u[1] + b[2] * u[2];
-      const double s1 = b[3] * u[3] + b[4] * u[4] + b[5] * u[5];
-      const double s2 = b[6] * u[6] + b[7] * u[7] + b[8] * u[8];
-      const double s3 = b[9] * u[9] + b[10] * u[10] + b[11] * u[11];
-      wd[a] = (s0 + s1) + (s2 + s3);
-    }
-  } else {
-    // torque of the stance points about the CoM, then wd = wd0 + Iinv tau
+  double F[3], vd[3], wd[3];
+  {
+    // two independent partial sums per component: the wave has no other work to hide the add chains
+    double f0[2] = {0, 0}, f1[2] = {0, 0}, f2[2] = {0, 0};
     double t0[2] = {0, 0}, t1[2] = {0, 0}, t2[2] = {0, 0};
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-      const double* r = &M.bw[3 * l];
+      const double* r = &M.rm[3 * l];
       const double* f = &u[3 * l];
+      f0[l & 1] += f[0]; f1[l & 1] += f[1]; f2[l & 1] += f[2];
       t0[l & 1] += r[1] * f[2] - r[2] * f[1];
       t1[l & 1] += r[2] * f[0] - r[0] * f[2];
       t2[l & 1] += r[0] * f[1] - r[1] * f[0];
     }
+    F[0] = f0[0] + f0[1]; F[1] = f1[0] + f1[1]; F[2] = f2[0] + f2[1];
     const double tau[3] = {t0[0] + t0[1], t1[0] + t1[1], t2[0] + t2[1]};
 #pragma unroll
     for (int a = 0; a < 3; ++a)
