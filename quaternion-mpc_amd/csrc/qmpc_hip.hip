@@ -282,11 +282,13 @@ void qmpc_destroy(qmpc_handle* h) {
 // move the gains (N=10: 19 KB, two waves per SIMD) and, when that is still more than 20 KB, the slack arrays
 // (N=20: 36 KB -> 17 KB) to the workspace to raise the number of resident instances.
 static int pick_variant(const qmpc_handle* h, int32_t batch) {
-  const bool big = batch > 4096;
+  // one instance per SIMD (1024 on the chip) is the break-even: beyond it a second resident wave per SIMD
+  // (x1.6 throughput) beats a second round of one-wave instances (measured at B = 2048 / 4096)
+  const bool big = batch > 1024;
   if (h->variant == 1) return h->lds_bytes > 160 * 1024 ? 1 : 0;
   if (h->variant == 2) return 1;
   if (h->variant == 3) return 2;
-  if (h->params.model == QMPC_MODEL_QUAT8) return (big && h->lds_bytes_g > 40 * 1024) ? 2 : 1;
+  if (h->params.model == QMPC_MODEL_QUAT8) return (batch > 768 && h->lds_bytes_g > 40 * 1024) ? 2 : 1;  // 3 per CU in LDS
   if (h->lds_bytes > 40 * 1024) return (big && h->lds_bytes_g > 20 * 1024) ? 2 : 1;   // < 4 instances per CU otherwise
   return big ? 1 : 0;
 }
