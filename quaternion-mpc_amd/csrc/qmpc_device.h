@@ -255,48 +255,67 @@ __device__ __forceinline__ void quat_Omega(const double* w, double O[16]) {
   O[12] = z; O[13] = y; O[14] = -x; O[15] = 0;
 }
 
-// Model constants of one instance held in registers by the rollouts: the masked contact points c_l r_l
-// (3 NL numbers; Bw0 = Iinv skew(r_l) c_l would be 9 NL) -- the torque is formed with cross products, as
-// the reference does (AltroUtils.cpp:376-391).
-template <int NL>
+// Model constants of one instance held in registers by the rollouts.
+//   LEAN: the masked contact points c_l r_l (3 NL numbers); the torque is formed with cross products, as the
+//         reference does (AltroUtils.cpp:376-391).  Used where registers are the occupancy limit (workspace
+//         variants, 8 contact points).
+//   else: Bw0 = Iinv skew(r_l) c_l (9 NL numbers): one fused dot product per angular axis, ~1 % faster when a
+//         wave has the SIMD's registers to itself (variant 0).
+template <int NL, bool LEAN>
 struct ModelRegsT {
-  double gb[3], wd0[3], rm[3 * NL];
+  double gb[3], wd0[3], rm[LEAN ? 3 * NL : 9 * NL];
   __device__ __forceinline__ void load(const double* cst, const double* bw0) {
     typedef Dim<NL> D;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { gb[i] = cst[D::C_GB + i]; wd0[i] = cst[D::C_WD0 + i]; }
+    if (LEAN) {
 #pragma unroll
-    for (int i = 0; i < 3 * NL; ++i) rm[i] = cst[D::C_CON + i / 3] * cst[D::C_FOOT + i];
+      for (int i = 0; i < 3 * NL; ++i) rm[i] = cst[D::C_CON + i / 3] * cst[D::C_FOOT + i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 9 * NL; ++i) rm[i] = bw0[i];
+    }
   }
 };
-typedef ModelRegsT<4> ModelRegs;
 
 // Explicit-midpoint step of the quaternion SRBD (AltroUtils.cpp:9-22 applied to
 // :363-392).  vdot and wdot do not depend on the state, so both midpoint
 // evaluations share them.  x, xn: 13 doubles in registers.  Swing-point inputs are
 // identically zero in every rollout (zero reference, zero gains), so the force sum needs no mask.
-template <int NL>
-__device__ __forceinline__ void srbd_step(const DevParams& P, const ModelRegsT<NL>& M, const double* x,
+template <int NL, bool LEAN>
+__device__ __forceinline__ void srbd_step(const DevParams& P, const ModelRegsT<NL, LEAN>& M, const double* x,
                                           const double* u, double* xn) {
   double F[3], vd[3], wd[3];
   {
-    // two independent partial sums per component: the wave has no other work to hide the add chains
+    // independent partial sums: the wave has no other work to hide the add chains
     double f0[2] = {0, 0}, f1[2] = {0, 0}, f2[2] = {0, 0};
-    double t0[2] = {0, 0}, t1[2] = {0, 0}, t2[2] = {0, 0};
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
-      const double* r = &M.rm[3 * l];
-      const double* f = &u[3 * l];
-      f0[l & 1] += f[0]; f1[l & 1] += f[1]; f2[l & 1] += f[2];
-      t0[l & 1] += r[1] * f[2] - r[2] * f[1];
-      t1[l & 1] += r[2] * f[0] - r[0] * f[2];
-      t2[l & 1] += r[0] * f[1] - r[1] * f[0];
-    }
+    for (int l = 0; l < NL; ++l) { f0[l & 1] += u[3 * l]; f1[l & 1] += u[3 * l + 1]; f2[l & 1] += u[3 * l + 2]; }
     F[0] = f0[0] + f0[1]; F[1] = f1[0] + f1[1]; F[2] = f2[0] + f2[1];
-    const double tau[3] = {t0[0] + t0[1], t1[0] + t1[1], t2[0] + t2[1]};
+    if (LEAN) {
+      double t0[2] = {0, 0}, t1[2] = {0, 0}, t2[2] = {0, 0};
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
-      wd[a] = M.wd0[a] + (P.Iinv[3 * a] * tau[0] + P.Iinv[3 * a + 1] * tau[1] + P.Iinv[3 * a + 2] * tau[2]);
+      for (int l = 0; l < NL; ++l) {
+        const double* r = &M.rm[3 * l];
+        const double* f = &u[3 * l];
+        t0[l & 1] += r[1] * f[2] - r[2] * f[1];
+        t1[l & 1] += r[2] * f[0] - r[0] * f[2];
+        t2[l & 1] += r[0] * f[1] - r[1] * f[0];
+      }
+      const double tau[3] = {t0[0] + t0[1], t1[0] + t1[1], t2[0] + t2[1]};
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+        wd[a] = M.wd0[a] + (P.Iinv[3 * a] * tau[0] + P.Iinv[3 * a + 1] * tau[1] + P.Iinv[3 * a + 2] * tau[2]);
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double* b = &M.rm[3 * NL * a];
+        double s[4] = {M.wd0[a], 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 3 * NL; ++j) s[(j / 3) & 3] += b[j] * u[j];
+        wd[a] = (s[0] + s[1]) + (s[2] + s[3]);
+      }
+    }
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a) vd[a] = F[a] * P.inv_mass + M.gb[a];
@@ -493,11 +512,12 @@ struct QuatModelT {
   static constexpr int NX = 13;
   static constexpr int NL = NL_;
   typedef Dim<NL_> D;
-  typedef ModelRegsT<NL_> Regs;
+  template <bool LEAN> using RegsT = ModelRegsT<NL_, LEAN>;
 
-  static __device__ __forceinline__ void step(const DevParams& P, const Regs& M, const double* x,
+  template <bool LEAN>
+  static __device__ __forceinline__ void step(const DevParams& P, const RegsT<LEAN>& M, const double* x,
                                               const double* u, double* xn) {
-    srbd_step<NL_>(P, M, x, u, xn);
+    srbd_step<NL_, LEAN>(P, M, x, u, xn);
   }
   // dx = xc (-) xo : inverse Cayley map of xo.q^-1 * xc.q (QuaternionUtils.cpp:16-18)
   static __device__ __forceinline__ void state_diff(const double* xo, const double* xc, double* dx) {
@@ -657,6 +677,7 @@ struct ConvexModel {
   static constexpr int NL = 4;
   typedef Dim<4> D;
   typedef ConvexRegs Regs;
+  template <bool LEAN> using RegsT = ConvexRegs;
 
   // Iw(yaw)^-1 tau with c = cos(yaw), s = sin(yaw)
   static __device__ __forceinline__ void winv(const DevParams& P, double c, double s, double& w00, double& w01,
@@ -684,6 +705,7 @@ struct ConvexModel {
     }
   }
   // explicit midpoint (AltroUtils.cpp:9-22) of ct_srb_dynamics
+  template <bool LEAN>
   static __device__ __forceinline__ void step(const DevParams& P, const Regs& M, const double* x,
                                               const double* u, double* xn) {
     double tau[3], F[3];

@@ -197,11 +197,11 @@ __device__ inline void setup_instance(const DevParams& P, const Layout& L, doubl
 
 // open-loop rollout of U from x0 into X (every lane computes it redundantly;
 // lane 0 publishes).  ALTRO's initial rollout.
-template <class MD>
+template <class MD, bool LEAN>
 __device__ inline void rollout_open(const DevParams& P, const Layout& L, double* sm, int lane) {
   typedef typename MD::D D;
   const double* cst = sm + L.cst;
-  typename MD::Regs M;
+  typename MD::template RegsT<LEAN> M;
   M.load(cst, sm + L.bw0);
   double x[13], xn[13], u[D::NU];
 #pragma unroll
@@ -212,7 +212,7 @@ __device__ inline void rollout_open(const DevParams& P, const Layout& L, double*
   for (int k = 0; k < P.N; ++k) {
 #pragma unroll
     for (int j = 0; j < D::NU; ++j) u[j] = sm[L.U + D::NU * k + j];
-    MD::step(P, M, x, u, xn);
+    MD::template step<LEAN>(P, M, x, u, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) x[i] = xn[i];
     if (lane == 0)
@@ -640,13 +640,13 @@ __device__ __forceinline__ void roll_load(const Layout& L, const double* sm, con
 }
 // PF_X: also prefetch the old state (LDS variant: registers to spare); the global-gains
 // variant is register-bound (2 waves/SIMD) and prefetches only its high-latency gain row / T_l
-template <class MD, bool PF_X, bool PF_K, bool PROF>
+template <class MD, bool PF_X, bool PF_K, bool LEAN, bool PROF>
 __device__ inline void rollout_closed(const DevParams& P, const Layout& L, double* sm, const double* KD,
                                       const double* ROT, double alpha, int lane, Prof<PROF>& prof) {
   typedef typename MD::D D;
   const int N = P.N;
   const double* cst = sm + L.cst;
-  typename MD::Regs M;
+  typename MD::template RegsT<LEAN> M;
   M.load(cst, sm + L.bw0);
   const bool ulane = (lane < 4 * D::NLEG) && ((lane & 3) < 3);
   const int ql = ulane ? (lane >> 2) : 0, qa = ulane ? (lane & 3) : 0;   // contact point, axis of this lane
@@ -688,7 +688,7 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
 #pragma unroll
     for (int j = 0; j < D::NU; ++j) un[j] = read_lane(unew, 4 * (j / 3) + (j % 3));
     prof.tick(PH_R_BCAST);
-    MD::step(P, M, xc, un, xn);
+    MD::template step<LEAN>(P, M, xc, un, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) xc[i] = xn[i];
     if (lane == 0)
@@ -768,14 +768,14 @@ __device__ inline void ipm_apply(const DevParams& P, const Layout& L, double* sl
 }
 
 // shortened primal step: scale the trial increment and re-roll the states open loop
-template <class MD>
+template <class MD, bool LEAN>
 __device__ inline void rollout_scaled(const DevParams& P, const Layout& L, double* sm, double ap, int lane) {
   typedef typename MD::D D;
   const int N = P.N;
   const double* cst = sm + L.cst;
   for (int i = lane; i < N * D::NU; i += kWave) sm[L.dU + i] *= ap;
   QSYNC();
-  typename MD::Regs M;
+  typename MD::template RegsT<LEAN> M;
   M.load(cst, sm + L.bw0);
   double x[13], xn[13], u[D::NU];
 #pragma unroll
@@ -783,7 +783,7 @@ __device__ inline void rollout_scaled(const DevParams& P, const Layout& L, doubl
   for (int k = 0; k < N; ++k) {
 #pragma unroll
     for (int j = 0; j < D::NU; ++j) u[j] = sm[L.U + D::NU * k + j] + sm[L.dU + D::NU * k + j];
-    MD::step(P, M, x, u, xn);
+    MD::template step<LEAN>(P, M, x, u, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) x[i] = xn[i];
     if (lane == 0)
@@ -818,6 +818,7 @@ __global__ __launch_bounds__(64, VAR == 0 ? 1 : (MD::NL != 4 ? (VAR == 2 ? QMPC_
   const int lane = threadIdx.x;
   const int N = P.N;
   constexpr bool KDG = VAR >= 1, SLG = VAR == 2;
+  constexpr bool LEAN = KDG || MD::NL != 4;     // register-lean model constants where registers bound the occupancy
   const Layout L = make_layout(N, KDG, MD::NL, SLG);
   const size_t slice = (size_t)N * (D::KD + D::ROT + (SLG ? 5 * NC : 0));
   double* KD = KDG ? gws + (size_t)b * slice : sm + L.KD;
@@ -845,7 +846,7 @@ __global__ __launch_bounds__(64, VAR == 0 ? 1 : (MD::NL != 4 ? (VAR == 2 ? QMPC_
   // initial guess U = u_ref (QuatMpc.cpp:253), slacks and multipliers
   for (int i = lane; i < N * NU; i += kWave) sm[L.U + i] = sm[L.uref + (i % NU)];
   QSYNC();
-  rollout_open<MD>(P, L, sm, lane);
+  rollout_open<MD, LEAN>(P, L, sm, lane);
   expansions<MD>(P, L, sm, lane);
   for (int i = lane; i < N * NC; i += kWave) {
     const double c0 = cone_value<D>(P, L, sm, i);
@@ -891,7 +892,7 @@ __global__ __launch_bounds__(64, VAR == 0 ? 1 : (MD::NL != 4 ? (VAR == 2 ? QMPC_
     if (backward_pass<MD, PROF, !KDG>(P, L, sm, KD, ROT, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
     if (KDG) __syncthreads();
     double ap, ad;
-    rollout_closed<MD, !KDG, !KDG, PROF>(P, L, sm, KD, ROT, 1.0, lane, prof);  // trial step
+    rollout_closed<MD, !KDG, !KDG, LEAN, PROF>(P, L, sm, KD, ROT, 1.0, lane, prof);  // trial step
     prof.tick(PH_ROLL);
     ipm_directions<D>(P, L, sm, sl, target, lane, &ap, &ad);
     last_ap = ap; last_ad = ad;
@@ -902,7 +903,7 @@ __global__ __launch_bounds__(64, VAR == 0 ? 1 : (MD::NL != 4 ? (VAR == 2 ? QMPC_
       last_step = wave_max(step);
     }
     prof.tick(PH_DIRS);
-    if (ap < 1.0) rollout_scaled<MD>(P, L, sm, ap, lane);    // shortened primal step
+    if (ap < 1.0) rollout_scaled<MD, LEAN>(P, L, sm, ap, lane);    // shortened primal step
     prof.tick(PH_ROLL);
     prof.tick(PH_MISC);
     ipm_apply<D>(P, L, sl, ap, ad, conmask, lane, kapbits);
@@ -967,7 +968,7 @@ __global__ __launch_bounds__(64) void qmpc_linearize_kernel(DevParams P, const q
   }
   for (int i = lane; i < N * 12; i += kWave) sm[L.U + i] = sm[L.uref + (i % 12)];
   QSYNC();
-  rollout_open<MD>(P, L, sm, lane);
+  rollout_open<MD, true>(P, L, sm, lane);
   expansions<MD>(P, L, sm, lane);
   for (int i = lane; i < N * 144; i += kWave) {
     const int k = i / 144, e = i - 144 * k, r = e / 12, c = e - 12 * r;
