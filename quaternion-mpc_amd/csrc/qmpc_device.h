@@ -220,6 +220,14 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return r;
 }
 
+// 1/sqrt(x): v_rsq_f64 + two Newton steps (replaces an IEEE sqrt followed by three IEEE divisions)
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  return r;
+}
+
 // ---- cross-lane moves inside the MFMA fragment layout --------------------------
 // lane = 16*g + c holds rows {g, 4+g, 8+g} of column c.
 // value of lane (g, J) of the same 16-lane row (DPP row_newbcast, no LDS)

@@ -319,19 +319,19 @@ __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, dou
         a1[a] = (i == i1) ? cr[3 * i + a] : a1[a];
         a2[a] = (i == i2) ? cr[3 * i + a] : a2[a];
       }
-    const double n1 = sqrt(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
+    const double in1 = fast_rsqrt(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
     double q1[3], q2[3], q3[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) q1[a] = a1[a] / n1;
+    for (int a = 0; a < 3; ++a) q1[a] = a1[a] * in1;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const double dp = a2[0] * q1[0] + a2[1] * q1[1] + a2[2] * q1[2];
 #pragma unroll
       for (int a = 0; a < 3; ++a) a2[a] -= dp * q1[a];
     }
-    const double n2 = sqrt(a2[0] * a2[0] + a2[1] * a2[1] + a2[2] * a2[2]);
+    const double in2 = fast_rsqrt(a2[0] * a2[0] + a2[1] * a2[1] + a2[2] * a2[2]);
 #pragma unroll
-    for (int a = 0; a < 3; ++a) q2[a] = a2[a] / n2;
+    for (int a = 0; a < 3; ++a) q2[a] = a2[a] * in2;
     q3[0] = q1[1] * q2[2] - q1[2] * q2[1];
     q3[1] = q1[2] * q2[0] - q1[0] * q2[2];
     q3[2] = q1[0] * q2[1] - q1[1] * q2[0];
