@@ -635,9 +635,9 @@ static void ipm_apply(solver_ws* ws, double alpha_p, double alpha_d) {
         kw->lam[ci][i] += alpha_d * kw->dlam[ci][i];
         /* Tapia indicators: a weakly active row halves BOTH s and lambda on a full
          * Newton step (regular rows send one of the two ratios to ~1, the other to ~sigma) */
-        const double rs = kw->s[ci][i] / s0, rl = kw->lam[ci][i] / l0;
-        const int sig = (alpha_p >= 0.99 && alpha_d >= 0.99 && rs < 0.6 && rl < 0.6 &&
-                         (kw->kap[ci][i] != 0.0 || (rs > 0.4 && rl > 0.4)));
+        const double s1 = kw->s[ci][i], l1 = kw->lam[ci][i];   /* ratios vs 0.4 / 0.6 without dividing */
+        const int sig = (alpha_p >= 0.99 && alpha_d >= 0.99 && s1 < 0.6 * s0 && l1 < 0.6 * l0 &&
+                         (kw->kap[ci][i] != 0.0 || (s1 > 0.4 * s0 && l1 > 0.4 * l0)));
         kw->kap[ci][i] = sig ? 1.0 : 0.0;
       }
     }

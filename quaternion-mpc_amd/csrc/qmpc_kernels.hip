@@ -758,9 +758,9 @@ __device__ inline void ipm_apply(const DevParams& P, const Layout& L, double* sl
     // step (regular rows send one ratio to ~1, the other to ~sigma).  Such rows get the
     // second-order complementarity right-hand side  target - 2 s lam  next iteration,
     // which removes their linear (ratio 1/2) convergence.  The flag lives in the DS slot.
-    const double rs = s1 * fast_rcp(s0), rl = l1 * fast_rcp(l0);
-    const bool sig = (ap >= 0.99) && (ad >= 0.99) && (rs < 0.6) && (rl < 0.6) &&
-                     (kap0 || ((rs > 0.4) && (rl > 0.4)));
+    // ratios s1/s0, l1/l0 against 0.4 / 0.6, written without the divisions (s0, l0 > 0)
+    const bool sig = (ap >= 0.99) && (ad >= 0.99) && (s1 < 0.6 * s0) && (l1 < 0.6 * l0) &&
+                     (kap0 || ((s1 > 0.4 * s0) && (l1 > 0.4 * l0)));
     sl[L.DS + idx] = sig ? 1.0 : 0.0;        // read by the next rotation pre-pass / directions
     newbits |= sig ? (1u << j) : 0u;
   }
