@@ -476,3 +476,64 @@ def test_eight_point_kernel_reduces_to_the_four_leg_one(pkg, lib):
     assert np.abs(f8[:, 12:]).max() == 0.0
     assert (i8["iterations"] == i4["iterations"]).mean() >= 0.98
     s4.close(); s8.close()
+
+
+# ---- BASELINE.json's full sizes, through size-independent properties ---------------------------------------
+@pytest.mark.parametrize("N,B,cfg", [(20, 65536, 3), (10, 32768, 2)])   # config 2; the per-GPU share of config 3
+def test_full_size_batches_properties(pkg, lib, oracle, N, B, cfg):
+    p, s = _solver(pkg, lib, N, cap=B)
+    rec = pkg.random_go1_trot_states(B, config_id=cfg)
+    f, info = s.solve(rec)
+    # every instance converges and is feasible
+    assert (info["status"] == 0).all(), np.unique(info["status"], return_counts=True)
+    assert info["max_violation"].max() < 1e-8
+    # contact schedule: swing-leg forces are exactly zero, stance legs push (world-frame fz >= 0) inside the pyramid
+    swing = np.repeat(rec["contacts"] == 0, 3, axis=1)
+    assert np.abs(f[swing]).max() == 0.0
+    R = rec["rot"].reshape(B, 3, 3)
+    fw = np.einsum("bij,blj->bli", R, f.reshape(B, 4, 3))
+    assert (fw[..., 2] >= -1e-8).all() and (fw[..., 2] <= p.fz_max + 1e-8).all()
+    assert (np.abs(fw[..., 0]) <= p.mu * fw[..., 2] + 1e-7).all() and (np.abs(fw[..., 1]) <= p.mu * fw[..., 2] + 1e-7).all()
+    # determinism: a second launch returns the same bits
+    f2, info2 = s.solve(rec)
+    assert np.array_equal(f, f2) and np.array_equal(info["iterations"], info2["iterations"])
+    # an instance's result does not depend on the batch it is solved in (nor on the kernel variant the batch size picks)
+    idx = np.arange(0, B, B // 1024)[:1024]
+    fs, _ = s.solve(rec[idx])
+    assert np.abs(fs - f[idx]).max() < 1e-7
+    perm = np.random.default_rng(0).permutation(B)
+    fp, _ = s.solve(rec[perm])
+    assert np.array_equal(fp, f[perm])
+    # and a sample against the oracle
+    sub = idx[::16]
+    fo, io = oracle.solve(p, rec[sub], threads=8)
+    assert (io["status"] == 0).all() and np.abs(f[sub] - fo).max() < 1e-6
+    s.close()
+
+
+def test_full_size_biped8_properties(pkg, lib, oracle):
+    """BASELINE config 5 (B = 65536, N = 16, 8 contact points) through size-independent properties."""
+    B, N = 65536, 16
+    p = pkg.default_biped8_params(N, pkg.MODE_CONVERGED, lib)
+    s = pkg.Solver(p, B, device=0, lib=lib)
+    rec = pkg.random_biped8_states(B, config_id=5)
+    f, info = s.solve8(rec)
+    assert (info["status"] == 0).all(), np.unique(info["status"], return_counts=True)
+    assert info["max_violation"].max() < 1e-8
+    assert np.abs(f[np.repeat(rec["contacts"] == 0, 3, axis=1)]).max() == 0.0
+    R = rec["rot"].reshape(B, 3, 3)
+    fw = np.einsum("bij,blj->bli", R, f.reshape(B, 8, 3))
+    assert (fw[..., 2] >= -1e-8).all() and (fw[..., 2] <= p.fz_max + 1e-8).all()
+    assert (np.abs(fw[..., 0]) <= p.mu * fw[..., 2] + 1e-7).all() and (np.abs(fw[..., 1]) <= p.mu * fw[..., 2] + 1e-7).all()
+    # what the four corner points of a foot cannot hide: the total force and moment about the CoM (6 numbers)
+    feet = rec["foot_pos_body"].reshape(B, 8, 3)
+    wrench = np.concatenate([f.reshape(B, 8, 3).sum(1), np.cross(feet, f.reshape(B, 8, 3)).sum(1)], axis=1)
+    perm = np.random.default_rng(1).permutation(B)
+    fp, _ = s.solve8(rec[perm])
+    assert np.array_equal(fp, f[perm])
+    sub = np.arange(0, B, B // 64)[:64]
+    fo, io = oracle.solve8(p, rec[sub], threads=8)
+    wo = np.concatenate([fo.reshape(-1, 8, 3).sum(1), np.cross(feet[sub], fo.reshape(-1, 8, 3)).sum(1)], axis=1)
+    assert (io["status"] == 0).all()
+    assert np.abs(wrench[sub] - wo).max() < 1e-7 and np.abs(f[sub] - fo).max() < 1e-5
+    s.close()
