@@ -537,3 +537,36 @@ def test_full_size_biped8_properties(pkg, lib, oracle):
     assert (io["status"] == 0).all()
     assert np.abs(wrench[sub] - wo).max() < 1e-7 and np.abs(f[sub] - fo).max() < 1e-5
     s.close()
+
+
+def test_independent_handles_overlap_on_their_streams(pkg, lib):
+    """Distinct handles are independent: launches on two streams may overlap; results equal
+    the ones obtained one after the other.  set_params on a live handle equals a fresh handle."""
+    import torch
+
+    pq, sq = _solver(pkg, lib, 10, cap=2048)
+    pc, sc = _convex_solver(pkg, lib, 20, cap=2048)
+    rq = pkg.random_go1_trot_states(2048, config_id=2)
+    rc = pkg.random_go1_convex_states(2048, config_id=13)
+    fq_ref, _ = sq.solve(rq)
+    fc_ref, _ = sc.convex_solve(rc)
+    dq = torch.from_numpy(rq.view(np.uint8).reshape(2048, -1).copy()).cuda()
+    dc = torch.from_numpy(rc.view(np.uint8).reshape(2048, -1).copy()).cuda()
+    oq = torch.zeros(2048, 12, dtype=torch.float64, device="cuda")
+    oc = torch.zeros(2048, 12, dtype=torch.float64, device="cuda")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        sq.solve_device(2048, dq.data_ptr(), oq.data_ptr(), 0, s1.cuda_stream)
+        sc.convex_solve_device(2048, dc.data_ptr(), oc.data_ptr(), 0, s2.cuda_stream)
+    s1.synchronize(); s2.synchronize()
+    assert np.array_equal(oq.cpu().numpy(), fq_ref) and np.array_equal(oc.cpu().numpy(), fc_ref)
+    # parameter update on a live handle
+    p2 = pq.copy()
+    p2.mu, p2.fz_max, p2.w = 0.5, 80.0, 20.0
+    sq.set_params(p2)
+    f_live, _ = sq.solve(rq[:256])
+    fresh = pkg.Solver(p2, 256, device=0, lib=lib)
+    f_fresh, _ = fresh.solve(rq[:256])
+    assert np.array_equal(f_live, f_fresh) and np.abs(f_live - fq_ref[:256]).max() > 1e-3
+    sq.close(); sc.close(); fresh.close()
