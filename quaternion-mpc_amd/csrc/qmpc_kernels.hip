@@ -25,6 +25,9 @@
 #ifndef QMPC_V2_WAVES
 #define QMPC_V2_WAVES 2
 #endif
+#ifndef QMPC_PF_K
+#define QMPC_PF_K true   // prefetch the next knot's gain row / frame in the rollout (all variants)
+#endif
 #ifndef QMPC_NL8_WAVES
 #define QMPC_NL8_WAVES 2
 #endif
@@ -892,7 +895,7 @@ __global__ __launch_bounds__(64, VAR == 0 ? 1 : (MD::NL != 4 ? (VAR == 2 ? QMPC_
     if (backward_pass<MD, PROF, !KDG>(P, L, sm, KD, ROT, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
     if (KDG) __syncthreads();
     double ap, ad;
-    rollout_closed<MD, !KDG, !KDG, LEAN, PROF>(P, L, sm, KD, ROT, 1.0, lane, prof);  // trial step
+    rollout_closed<MD, !KDG, QMPC_PF_K, LEAN, PROF>(P, L, sm, KD, ROT, 1.0, lane, prof);  // trial step
     prof.tick(PH_ROLL);
     ipm_directions<D>(P, L, sm, sl, target, lane, &ap, &ad);
     last_ap = ap; last_ad = ad;
