@@ -28,6 +28,9 @@
 #ifndef QMPC_PF_K
 #define QMPC_PF_K true   // prefetch the next knot's gain row / frame in the rollout (all variants)
 #endif
+#ifndef QMPC_PIPE_ALL
+#define QMPC_PIPE_ALL false  // pipelined operand build in the workspace variants: measured slower (register pressure)
+#endif
 #ifndef QMPC_NL8_WAVES
 #define QMPC_NL8_WAVES 2
 #endif
@@ -892,7 +895,7 @@ __global__ __launch_bounds__(64, VAR == 0 ? 1 : (MD::NL != 4 ? (VAR == 2 ? QMPC_
     rotation_prepass<D>(P, L, sm, sl, ROT, target, lane);
     if (KDG) __syncthreads();
     prof.tick(PH_PREPASS);
-    if (backward_pass<MD, PROF, !KDG>(P, L, sm, KD, ROT, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
+    if (backward_pass<MD, PROF, (!KDG || QMPC_PIPE_ALL)>(P, L, sm, KD, ROT, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
     if (KDG) __syncthreads();
     double ap, ad;
     rollout_closed<MD, !KDG, QMPC_PF_K, LEAN, PROF>(P, L, sm, KD, ROT, 1.0, lane, prof);  // trial step
