@@ -474,6 +474,101 @@ __device__ inline void expand_knot(const DevParams& P, const double* cst, const 
     }
 }
 
+// The same expansion split over FOUR lanes per knot (the wave executes a quarter of the instructions):
+// part c = 0, 1, 2 produces column c of the three 3x3 blocks -- with A_qq = I + (h/2) Om (I + (h/4) O0),
+//   Aphiphi[:,c] = Gn' (g + (h/2) Om (g + (h/4) O0 g)),  g = G0[:,c]
+//   Aphiw[:,c]   = Gn' (h/2) (Om (h/4) g + Gm[:,c]),     W[:,c] = Gn' Gm[:,c]
+// (Om v, O0 v are the quaternion-rate products with 12 nonzeros) -- and part 3 the cost expansion.
+// Omega(w) v for a 4-vector v
+__device__ __forceinline__ void omega_mul(const double* w, const double* v, double* o) {
+  o[0] = -w[0] * v[1] - w[1] * v[2] - w[2] * v[3];
+  o[1] = w[0] * v[0] + w[2] * v[2] - w[1] * v[3];
+  o[2] = w[1] * v[0] - w[2] * v[1] + w[0] * v[3];
+  o[3] = w[2] * v[0] + w[1] * v[1] - w[0] * v[2];
+}
+template <int NL>
+__device__ inline void expand_knot_part(const DevParams& P, const double* cst, const double* bw0,
+                                        const double* refp, int k, int part, const double* x, const double* u,
+                                        const double* xn, double* ABk, double* XTk) {
+  if (part < 3) {
+    if (k >= P.N) return;
+    const int c = part;
+    double wd[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      double s = cst[Dim<NL>::C_WD0 + a];
+      for (int j = 0; j < 3 * NL; ++j) s += bw0[3 * NL * a + j] * u[j];
+      wd[a] = s;
+    }
+    double G0[12], Gm[12], Gn[12];
+    quat_G(&x[3], G0);
+    double qm[4], wm[3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      qm[r] = x[3 + r] + P.hh * (0.5 * (G0[3 * r] * x[10] + G0[3 * r + 1] * x[11] + G0[3 * r + 2] * x[12]));
+#pragma unroll
+    for (int a = 0; a < 3; ++a) wm[a] = x[10 + a] + P.hh * wd[a];
+    quat_G(qm, Gm);
+    quat_G(&xn[3], Gn);
+    double g[4], gm[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {      // column c of G0 / Gm (c is lane-dependent: selects, no indexing)
+      g[r] = (c == 0) ? G0[3 * r] : (c == 1 ? G0[3 * r + 1] : G0[3 * r + 2]);
+      gm[r] = (c == 0) ? Gm[3 * r] : (c == 1 ? Gm[3 * r + 1] : Gm[3 * r + 2]);
+    }
+    double t0[4], t1[4], t2[4], ag[4], aw[4];
+    omega_mul(&x[10], g, t0);                                        // O0 g
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t1[r] = g[r] + (0.5 * P.hh) * t0[r];  // (I + (h/4) O0) g
+    omega_mul(wm, t1, t2);                                           // Om (.)
+    omega_mul(wm, g, t0);                                            // Om g
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ag[r] = g[r] + P.hh * t2[r];
+      aw[r] = P.hh * ((0.5 * P.hh) * t0[r] + gm[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double s1 = Gn[r] * ag[0] + Gn[3 + r] * ag[1] + Gn[6 + r] * ag[2] + Gn[9 + r] * ag[3];
+      const double s2 = Gn[r] * aw[0] + Gn[3 + r] * aw[1] + Gn[6 + r] * aw[2] + Gn[9 + r] * aw[3];
+      const double s3 = Gn[r] * gm[0] + Gn[3 + r] * gm[1] + Gn[6 + r] * gm[2] + Gn[9 + r] * gm[3];
+      ABk[3 * r + c] = s1;
+      ABk[9 + 3 * r + c] = s2;
+      ABk[18 + 3 * r + c] = s3;
+    }
+    return;
+  }
+  // ---- part 3: cost expansion at knot k (k = 0..N), as in expand_knot ----
+  double xr[13];
+  xref_at(P, refp, k, xr);
+  double lxf[13];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) lxf[i] = P.Q[i] * (x[i] - xr[i]);
+  const double dq = xr[3] * x[3] + xr[4] * x[4] + xr[5] * x[5] + xr[6] * x[6];
+  const double sg = (dq >= 0.0) ? 1.0 : -1.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) lxf[3 + r] += -sg * P.w * xr[3 + r];
+  const double qh = -(x[3] * lxf[3] + x[4] * lxf[4] + x[5] * lxf[5] + x[6] * lxf[6]);
+  double G[12];
+  quat_G(&x[3], G);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    XTk[9 + a] = lxf[a];
+    XTk[9 + 6 + a] = lxf[7 + a];
+    XTk[9 + 9 + a] = lxf[10 + a];
+    XTk[9 + 3 + a] = G[a] * lxf[3] + G[3 + a] * lxf[4] + G[6 + a] * lxf[5] + G[9 + a] * lxf[6];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      double s = (a == b) ? qh : 0.0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s += G[3 * t + a] * P.Q[3 + t] * G[3 * t + b];
+      XTk[3 * a + b] = s;
+    }
+}
+
 // Element (r,c) of the dense 12x12 Abar from the compact blocks.
 __device__ __forceinline__ double abar_elem(const DevParams& P, const double* AB, int r, int c) {
   if (r < 3) return ((r == c) ? 1.0 : 0.0) + ((c == r + 6) ? P.h : 0.0);
@@ -519,6 +614,7 @@ template <int NL_>
 struct QuatModelT {
   static constexpr int NX = 13;
   static constexpr int NL = NL_;
+  static constexpr int EXPAND_PARTS = 4;     // lanes per knot in the expansions
   typedef Dim<NL_> D;
   template <bool LEAN> using RegsT = ModelRegsT<NL_, LEAN>;
 
@@ -546,6 +642,11 @@ struct QuatModelT {
                                                 const double* refp, int k, const double* x, const double* u,
                                                 const double* xn, double* AB, double* lx, double* lxx) {
     expand_knot<NL_>(P, cst, bw0, refp, k, x, u, xn, AB, lx, lxx);
+  }
+  static __device__ __forceinline__ void expand_part(const DevParams& P, const double* cst, const double* bw0,
+                                                     const double* refp, int k, int part, const double* x,
+                                                     const double* u, const double* xn, double* ABk, double* XTk) {
+    expand_knot_part<NL_>(P, cst, bw0, refp, k, part, x, u, xn, ABk, XTk);
   }
   // un-augmented objective of knot k (u == nullptr at the terminal knot)
   static __device__ __forceinline__ double knot_cost(const DevParams& P, const double* refp, const double* uref,
@@ -683,6 +784,7 @@ struct ConvexRegs {
 struct ConvexModel {
   static constexpr int NX = 12;
   static constexpr int NL = 4;
+  static constexpr int EXPAND_PARTS = 1;     // one lane per knot (two sincos dominate; nothing to split)
   typedef Dim<4> D;
   typedef ConvexRegs Regs;
   template <bool LEAN> using RegsT = ConvexRegs;
@@ -755,6 +857,9 @@ struct ConvexModel {
     xr[8] = refp[CR_RATE];
     xr[9] = refp[CR_VX]; xr[10] = refp[CR_VY];
   }
+  static __device__ __forceinline__ void expand_part(const DevParams&, const double*, const double*, const double*,
+                                                     int, int, const double*, const double*, const double*,
+                                                     double*, double*) {}
   static __device__ inline void expand(const DevParams& P, const double* cst, const double* bw0,
                                        const double* refp, int k, const double* x, const double* u,
                                        const double* xn, double* AB, double* lx, double* lxx) {

@@ -228,11 +228,31 @@ __device__ inline void rollout_open(const DevParams& P, const Layout& L, double*
   QSYNC();
 }
 
-// expansions at (X,U): one lane per knot
+// expansions at (X,U): one lane per knot, or EXPAND_PARTS lanes per knot (knots and parts are independent)
 template <class MD>
 __device__ inline void expansions(const DevParams& P, const Layout& L, double* sm, int lane) {
   typedef typename MD::D D;
   const int N = P.N;
+  if (MD::EXPAND_PARTS == 4 && N <= 15) {     // one round of 4 (N + 1) lanes; longer horizons gain nothing from two
+    const int part = lane & 3;
+    {
+      const int k = lane >> 2;
+      if (k <= N) {
+        double x[13], xn[13], u[D::NU];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+          x[i] = sm[L.X + 13 * k + i];
+          xn[i] = (k < N) ? sm[L.X + 13 * (k + 1) + i] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < D::NU; ++j) u[j] = (k < N) ? sm[L.U + D::NU * k + j] : 0.0;
+        MD::expand_part(P, sm + L.cst, sm + L.bw0, sm + L.refp, k, part, x, u, xn, sm + L.AB + kAB * k,
+                        sm + L.XT + kXT * k);
+      }
+    }
+    QSYNC();
+    return;
+  }
   if (lane <= N) {
     double x[13], xn[13], u[D::NU];
 #pragma unroll
