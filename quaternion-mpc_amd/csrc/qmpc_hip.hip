@@ -475,7 +475,7 @@ void qmpc_default_go1_geometry(qmpc_leg_geometry* g) {
 
 static_assert(sizeof(LegGeom) == sizeof(qmpc_leg_geometry), "kernel argument mirrors the ABI struct");
 
-static qmpc_status launch_leg(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch, const double* d_q,
+static qmpc_status launch_leg(const qmpc_leg_geometry* g, int32_t batch, const double* d_q,
                               const double* d_f, const double* d_c, int walking, double* d_p, double* d_J,
                               double* d_tau, hipStream_t s) {
   LegGeom G;
@@ -493,7 +493,7 @@ qmpc_status qmpc_torque_map_device(qmpc_handle* h, const qmpc_leg_geometry* g, i
   if (!h || !g || batch < 0 || (batch > 0 && (!d_joint_pos || !d_forces_body || !d_tau))) return QMPC_BAD_ARGUMENT;
   if (batch == 0) return QMPC_OK;
   HIP_TRY(hipSetDevice(h->device));
-  return launch_leg(h, g, batch, d_joint_pos, d_forces_body, d_contacts, walking, nullptr, nullptr, d_tau,
+  return launch_leg(g, batch, d_joint_pos, d_forces_body, d_contacts, walking, nullptr, nullptr, d_tau,
                     stream ? (hipStream_t)stream : h->stream);
 }
 
@@ -511,7 +511,7 @@ static qmpc_status leg_host(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t 
     if (hipMemcpyAsync(dq, q, sizeof(double) * 12 * B, hipMemcpyHostToDevice, h->stream) != hipSuccess) { st = QMPC_HIP_ERROR; break; }
     if (f && hipMemcpyAsync(df, f, sizeof(double) * 12 * B, hipMemcpyHostToDevice, h->stream) != hipSuccess) { st = QMPC_HIP_ERROR; break; }
     if (c && hipMemcpyAsync(dc, c, sizeof(double) * 4 * B, hipMemcpyHostToDevice, h->stream) != hipSuccess) { st = QMPC_HIP_ERROR; break; }
-    st = launch_leg(h, g, batch, dq, f ? df : nullptr, c ? dc : nullptr, walking, p ? dp : nullptr, J ? dJ : nullptr,
+    st = launch_leg(g, batch, dq, f ? df : nullptr, c ? dc : nullptr, walking, p ? dp : nullptr, J ? dJ : nullptr,
                     tau ? dt : nullptr, h->stream);
     if (st != QMPC_OK) break;
     if (p && hipMemcpyAsync(p, dp, sizeof(double) * 12 * B, hipMemcpyDeviceToHost, h->stream) != hipSuccess) { st = QMPC_HIP_ERROR; break; }

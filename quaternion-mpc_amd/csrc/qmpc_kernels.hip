@@ -526,7 +526,6 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
       // T and S chains interleaved, one fragment row of the NEXT knot's operands between the products
       // (scheduling fences keep the compiler from clustering the MFMAs again)
       const int kn = k > 0 ? k - 1 : 0;
-      const double* ABn = sm + L.AB + kAB * kn;
       const double* ROTn = ROT + D::ROT * kn;
       double tc[TU][3];
 #pragma unroll
