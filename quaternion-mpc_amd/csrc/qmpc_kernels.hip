@@ -765,10 +765,12 @@ __device__ inline void ipm_directions(const DevParams& P, const Layout& L, doubl
 // rc <- (1 - alpha_p) rc; a full step zeroes rc exactly.
 template <class D>
 __device__ inline void ipm_apply(const DevParams& P, const Layout& L, double* sl, double ap, double ad,
-                                 unsigned conmask, int lane, unsigned& kapbits) {
+                                 unsigned conmask, int lane, unsigned& kapbits, double& sl_part, double& rc_part) {
   const int N = P.N;
   unsigned newbits = 0;
   int j = 0;
+  sl_part = 0.0;      // this lane's share of sum s*lambda and max |rc| at the NEW point: the next iteration's
+  rc_part = 0.0;      // barrier parameter / residual come from these, without re-reading the arrays
   for (int idx = lane; idx < N * D::NC; idx += kWave, ++j) {
     const int l = (idx % D::NC) / 6;
     if (!(conmask & (1u << l))) continue;
@@ -776,9 +778,12 @@ __device__ inline void ipm_apply(const DevParams& P, const Layout& L, double* sl
     const bool kap0 = (kapbits >> j) & 1u;   // this lane owns row idx in every pass
     const double s1 = s0 + ap * sl[L.DS + idx];
     const double l1 = l0 + ad * sl[L.DLAM + idx];
+    const double rc1 = (ap >= 1.0) ? 0.0 : (1.0 - ap) * sl[L.RC + idx];
     sl[L.S + idx] = s1;
-    sl[L.RC + idx] = (ap >= 1.0) ? 0.0 : (1.0 - ap) * sl[L.RC + idx];
+    sl[L.RC + idx] = rc1;
     sl[L.LAM + idx] = l1;
+    sl_part += s1 * l1;
+    rc_part = fmax(rc_part, fabs(rc1));
     // Tapia indicators: a weakly active row halves BOTH s and lambda on a full Newton
     // step (regular rows send one ratio to ~1, the other to ~sigma).  Such rows get the
     // second-order complementarity right-hand side  target - 2 s lam  next iteration,
@@ -873,13 +878,19 @@ __global__ __launch_bounds__(64, VAR == 0 ? 1 : (MD::NL != 4 ? (VAR == 2 ? QMPC_
   QSYNC();
   rollout_open<MD, LEAN>(P, L, sm, lane);
   expansions<MD>(P, L, sm, lane);
+  double sl_part = 0.0, rc_part = 0.0;     // per-lane shares of sum s*lambda / max |rc| over the enabled rows
   for (int i = lane; i < N * NC; i += kWave) {
     const double c0 = cone_value<D>(P, L, sm, i);
     const double s0 = fmax(-c0, 1.0);
+    const double lam0 = P.mu0 / s0;
     sl[L.S + i] = s0;
     sl[L.RC + i] = c0 + s0;
-    sl[L.LAM + i] = P.mu0 / s0;
+    sl[L.LAM + i] = lam0;
     sl[L.DS + i] = 0.0;
+    if (conmask & (1u << ((i % NC) / 6))) {
+      sl_part += s0 * lam0;
+      rc_part = fmax(rc_part, fabs(c0 + s0));
+    }
   }
   QSYNC();
   prof.tick(PH_SETUP);
@@ -889,17 +900,9 @@ __global__ __launch_bounds__(64, VAR == 0 ? 1 : (MD::NL != 4 ? (VAR == 2 ? QMPC_
   double mu = 0.0, resid = 0.0, last_step = 1e300, last_ap = 0.0, last_ad = 0.0;
   status = QMPC_MAX_ITER;
   for (it = 1; it <= P.iterations_max + 1; ++it) {
-    // barrier parameter and slack residual over the enabled rows
-    double sl_sum = 0.0, rs = 0.0;
-    for (int i = lane; i < N * NC; i += kWave) {
-      const int l = (i % NC) / 6;
-      if (conmask & (1u << l)) {
-        sl_sum += sl[L.S + i] * sl[L.LAM + i];
-        rs = fmax(rs, fabs(sl[L.RC + i]));
-      }
-    }
-    mu = wave_sum(sl_sum) * inv_rows;
-    resid = wave_max(rs);
+    // barrier parameter and slack residual over the enabled rows (shares left by the set-up / the last apply)
+    mu = wave_sum(sl_part) * inv_rows;
+    resid = wave_max(rc_part);
     if (mu <= P.mu_final && resid <= P.tol_feas && last_step <= P.tol_step) { status = QMPC_OK; break; }
     if (it > P.iterations_max) break;
     // centering: sigma until full steps are taken, then the fast value; short steps
@@ -931,7 +934,7 @@ __global__ __launch_bounds__(64, VAR == 0 ? 1 : (MD::NL != 4 ? (VAR == 2 ? QMPC_
     if (ap < 1.0) rollout_scaled<MD, LEAN>(P, L, sm, ap, lane);    // shortened primal step
     prof.tick(PH_ROLL);
     prof.tick(PH_MISC);
-    ipm_apply<D>(P, L, sl, ap, ad, conmask, lane, kapbits);
+    ipm_apply<D>(P, L, sl, ap, ad, conmask, lane, kapbits, sl_part, rc_part);
     if (SLG) __syncthreads();
     prof.tick(PH_APPLY);
     // accept the candidate
