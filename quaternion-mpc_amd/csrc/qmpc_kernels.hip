@@ -732,17 +732,19 @@ __device__ inline void rollout_closed(const DevParams& P, const Layout& L, doubl
 // followed by the fraction-to-the-boundary step lengths.
 template <class D>
 __device__ inline void ipm_directions(const DevParams& P, const Layout& L, double* sm, double* sl, double target,
-                                      int lane, double* alpha_p, double* alpha_d) {
+                                      int lane, double* alpha_p, double* alpha_d, double* full_step) {
   const int N = P.N;
   const double* cst = sm + L.cst;
   const double* cr = cst + D::C_CR;
-  double ap = 1.0, ad = 1.0;
+  double ap = 1.0, ad = 1.0, stp = 0.0;
   for (int idx = lane; idx < N * D::NC; idx += kWave) {
     const int k = idx / D::NC, row = idx - D::NC * k, l = row / 6, i = row - 6 * l;
     double dsv = 0.0, dlv = 0.0;
     if (cst[D::C_CON + l] != 0.0) {
       const double* du = sm + L.dU + D::NU * k + 3 * l;
-      const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
+      const double d0 = du[0], d1 = du[1], d2 = du[2];
+      const double jd = cr[3 * i] * d0 + cr[3 * i + 1] * d1 + cr[3 * i + 2] * d2;
+      stp = fmax(stp, fmax(fabs(d0), fmax(fabs(d1), fabs(d2))));
       const double sv = sl[L.S + idx], lv = sl[L.LAM + idx];
       const double kap = sl[L.DS + idx];                     // flag left by the previous ipm_apply
       dsv = -(jd + sl[L.RC + idx]);
@@ -755,6 +757,9 @@ __device__ inline void ipm_directions(const DevParams& P, const Layout& L, doubl
   }
   *alpha_p = wave_min(ap);
   *alpha_d = wave_min(ad);
+  // convergence is judged on the FULL Newton step (the trial increment): swing inputs do not move and every
+  // stance input is seen by the six rows of its contact point
+  *full_step = wave_max(stp);
 }
 
 // Apply the step to (s, rc, lam).  The slack residual rc = c(u) + s is carried
@@ -922,14 +927,8 @@ __global__ __launch_bounds__(64, VAR == 0 ? 1 : (MD::NL != 4 ? (VAR == 2 ? QMPC_
     double ap, ad;
     rollout_closed<MD, !KDG, QMPC_PF_K, LEAN, PROF>(P, L, sm, KD, ROT, 1.0, lane, prof);  // trial step
     prof.tick(PH_ROLL);
-    ipm_directions<D>(P, L, sm, sl, target, lane, &ap, &ad);
+    ipm_directions<D>(P, L, sm, sl, target, lane, &ap, &ad, &last_step);
     last_ap = ap; last_ad = ad;
-    {
-      // convergence is judged on the FULL Newton step (the trial increment)
-      double step = 0.0;
-      for (int i = lane; i < N * NU; i += kWave) step = fmax(step, fabs(sm[L.dU + i]));
-      last_step = wave_max(step);
-    }
     prof.tick(PH_DIRS);
     if (ap < 1.0) rollout_scaled<MD, LEAN>(P, L, sm, ap, lane);    // shortened primal step
     prof.tick(PH_ROLL);
