@@ -400,7 +400,7 @@ __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, dou
 // eliminated from every OTHER row (the pivot row is left as it is; gj_finish divides by the
 // diagonal at the end).
 template <int J, int TU>
-__device__ __forceinline__ void gj_step(double M[][TU][3], double Rr[][3], int c, int g, double& minpiv) {
+__device__ __forceinline__ void gj_step_mov(double M[][TU][3], double Rr[][3], int c, int g, double& minpiv) {
   constexpr int tj = J / 12, Jl = J % 12, ej = Jl >> 2, gj = Jl & 3;
   const int src = (gj << 4) | c;
   double mrow[TU];
@@ -421,12 +421,95 @@ __device__ __forceinline__ void gj_step(double M[][TU][3], double Rr[][3], int c
       Rr[t][e] = fma(f, rrow, Rr[t][e]);
     }
 }
+// The rank-one update is issued as v_fmac_f64 with a DPP source: gfx90a+ lets the 64-bit VOP2 ops take
+// row_newbcast on src0, so  M[r][c] += M[r][J] * (-row_J[c] / piv)  is ONE instruction per fragment (no
+// broadcast move, no multiplier register), and the DPP row mask (one bit per 16-lane row = one bit per row
+// group g) leaves the pivot row itself untouched.  The leading s_nop covers the VALU-write -> DPP-read
+// hazard, which the compiler does not track through inline asm.
+#define QMPC_FMAC_DPP(dst, srcb, mul, JL, MASK) \
+  "v_fmac_f64_dpp " dst ", " srcb ", " mul " row_newbcast:" JL " row_mask:" MASK " bank_mask:0xf\n"
+template <int J, int TU>
+__device__ __forceinline__ void gj_step_dpp64(double M[][TU][3], double Rr[][3], int c, int g, double& minpiv) {
+  constexpr int tj = J / 12, Jl = J % 12, ej = Jl >> 2, gj = Jl & 3;
+  const int src = (gj << 4) | c;
+  double mrow[TU];
+#pragma unroll
+  for (int t = 0; t < TU; ++t) mrow[t] = __shfl(M[tj][t][ej], src);   // row J, same column, all row groups
+  const double rrow = __shfl(Rr[tj][ej], src);
+  const double piv = read_lane(M[tj][tj][ej], (gj << 4) | Jl);
+  minpiv = fmin(minpiv, piv);          // positivity is checked once per pass (NaN pivots poison the gains -> NOT_PD below)
+  const double ninv = -fast_rcp(piv);
+  double nr[TU];
+#pragma unroll
+  for (int t = 0; t < TU; ++t) nr[t] = ninv * mrow[t];
+  const double nrr = ninv * rrow;
+  constexpr int pm = 0xf ^ (1 << gj);       // every row group but the pivot's
+#pragma unroll
+  for (int t = 0; t < TU; ++t) {
+    if constexpr (TU == 1) {
+      asm volatile(
+          "s_nop 1\n"
+          QMPC_FMAC_DPP("%3", "%0", "%7", "%8", "%9")
+          QMPC_FMAC_DPP("%0", "%0", "%6", "%8", "%9")
+          QMPC_FMAC_DPP("%4", "%1", "%7", "%8", "%10")
+          QMPC_FMAC_DPP("%1", "%1", "%6", "%8", "%10")
+          QMPC_FMAC_DPP("%5", "%2", "%7", "%8", "%11")
+          QMPC_FMAC_DPP("%2", "%2", "%6", "%8", "%11")
+          : "+v"(M[0][0][0]), "+v"(M[0][0][1]), "+v"(M[0][0][2]), "+v"(Rr[0][0]), "+v"(Rr[0][1]), "+v"(Rr[0][2])
+          : "v"(nr[0]), "v"(nrr), "n"(Jl), "n"(ej == 0 ? pm : 0xf), "n"(ej == 1 ? pm : 0xf), "n"(ej == 2 ? pm : 0xf));
+    } else {
+      // source column: tile tj of this row tile; it is updated last (in place)
+      double(&Ms)[3] = M[t][tj];
+      double(&Mo)[3] = M[t][1 - tj];
+      const bool pt = (t == tj);     // the row tile that holds the pivot row
+      if (pt) {
+        asm volatile(
+            "s_nop 1\n"
+            QMPC_FMAC_DPP("%6", "%0", "%11", "%12", "%13")
+            QMPC_FMAC_DPP("%3", "%0", "%10", "%12", "%13")
+            QMPC_FMAC_DPP("%0", "%0", "%9", "%12", "%13")
+            QMPC_FMAC_DPP("%7", "%1", "%11", "%12", "%14")
+            QMPC_FMAC_DPP("%4", "%1", "%10", "%12", "%14")
+            QMPC_FMAC_DPP("%1", "%1", "%9", "%12", "%14")
+            QMPC_FMAC_DPP("%8", "%2", "%11", "%12", "%15")
+            QMPC_FMAC_DPP("%5", "%2", "%10", "%12", "%15")
+            QMPC_FMAC_DPP("%2", "%2", "%9", "%12", "%15")
+            : "+v"(Ms[0]), "+v"(Ms[1]), "+v"(Ms[2]), "+v"(Mo[0]), "+v"(Mo[1]), "+v"(Mo[2]), "+v"(Rr[t][0]),
+              "+v"(Rr[t][1]), "+v"(Rr[t][2])
+            : "v"(nr[tj]), "v"(nr[1 - tj]), "v"(nrr), "n"(Jl), "n"(ej == 0 ? pm : 0xf), "n"(ej == 1 ? pm : 0xf),
+              "n"(ej == 2 ? pm : 0xf));
+      } else {
+        asm volatile(
+            "s_nop 1\n"
+            QMPC_FMAC_DPP("%6", "%0", "%11", "%12", "0xf")
+            QMPC_FMAC_DPP("%3", "%0", "%10", "%12", "0xf")
+            QMPC_FMAC_DPP("%0", "%0", "%9", "%12", "0xf")
+            QMPC_FMAC_DPP("%7", "%1", "%11", "%12", "0xf")
+            QMPC_FMAC_DPP("%4", "%1", "%10", "%12", "0xf")
+            QMPC_FMAC_DPP("%1", "%1", "%9", "%12", "0xf")
+            QMPC_FMAC_DPP("%8", "%2", "%11", "%12", "0xf")
+            QMPC_FMAC_DPP("%5", "%2", "%10", "%12", "0xf")
+            QMPC_FMAC_DPP("%2", "%2", "%9", "%12", "0xf")
+            : "+v"(Ms[0]), "+v"(Ms[1]), "+v"(Ms[2]), "+v"(Mo[0]), "+v"(Mo[1]), "+v"(Mo[2]), "+v"(Rr[t][0]),
+              "+v"(Rr[t][1]), "+v"(Rr[t][2])
+            : "v"(nr[tj]), "v"(nr[1 - tj]), "v"(nrr), "n"(Jl));
+      }
+    }
+  }
+}
+// DPP64: the fused form wins where registers / issue slots bound the kernel (slack arrays in the workspace at
+// 2 waves/SIMD, two input tiles); at one wave per SIMD with one tile the separate broadcast moves are faster
+template <int J, int TU, bool DPP64>
+__device__ __forceinline__ void gj_step(double M[][TU][3], double Rr[][3], int c, int g, double& minpiv) {
+  if constexpr (DPP64) gj_step_dpp64<J, TU>(M, Rr, c, g, minpiv);
+  else gj_step_mov<J, TU>(M, Rr, c, g, minpiv);
+}
 // the three pivots of contact point LEG (a wave-uniform branch skips swing legs)
-template <int LEG, int TU>
+template <int LEG, int TU, bool DPP64>
 __device__ __forceinline__ void gj_leg(double M[][TU][3], double Rr[][3], int c, int g, double& minpiv) {
-  gj_step<3 * LEG, TU>(M, Rr, c, g, minpiv);
-  gj_step<3 * LEG + 1, TU>(M, Rr, c, g, minpiv);
-  gj_step<3 * LEG + 2, TU>(M, Rr, c, g, minpiv);
+  gj_step<3 * LEG, TU, DPP64>(M, Rr, c, g, minpiv);
+  gj_step<3 * LEG + 1, TU, DPP64>(M, Rr, c, g, minpiv);
+  gj_step<3 * LEG + 2, TU, DPP64>(M, Rr, c, g, minpiv);
 }
 // X = diag(M)^-1 Rr after all pivots (rows of skipped swing-leg pivots keep their
 // own positive diagonal R and a zero right-hand side)
@@ -444,7 +527,7 @@ __device__ __forceinline__ void gj_finish(const double M[][TU][3], double Rr[][3
 // Riccati backward pass with interior-point weights; writes KD (rotated gains
 // [Kt | dt], NU x 13 per knot).  Returns nonzero when a pivot is not positive.
 // PIPE: build the next knot's operands during the stage solve (needs 12 more VGPRs)
-template <class MD, bool PROF, bool PIPE>
+template <class MD, bool PROF, bool PIPE, bool DPP64>
 __device__ inline int backward_pass(const DevParams& P, const Layout& L, double* sm, double* KD,
                                     const double* ROT, int lane, unsigned conmask, Prof<PROF>& prof) {
   typedef typename MD::D D;
@@ -593,15 +676,15 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
     }
     prof.tick(PH_MFMA);
     // ---- stage solve: [Kt | dt] = -Quu^-1 [Qux | Qu]; swing-leg pivots are decoupled ----
-    if (conmask & 1u) gj_leg<0, TU>(Quu, Rr, c, g, minpiv);
-    if (conmask & 2u) gj_leg<1, TU>(Quu, Rr, c, g, minpiv);
-    if (conmask & 4u) gj_leg<2, TU>(Quu, Rr, c, g, minpiv);
-    if (conmask & 8u) gj_leg<3, TU>(Quu, Rr, c, g, minpiv);
+    if (conmask & 1u) gj_leg<0, TU, DPP64>(Quu, Rr, c, g, minpiv);
+    if (conmask & 2u) gj_leg<1, TU, DPP64>(Quu, Rr, c, g, minpiv);
+    if (conmask & 4u) gj_leg<2, TU, DPP64>(Quu, Rr, c, g, minpiv);
+    if (conmask & 8u) gj_leg<3, TU, DPP64>(Quu, Rr, c, g, minpiv);
     if (TU > 1) {
-      if (conmask & 16u) gj_leg<(TU > 1 ? 4 : 0), TU>(Quu, Rr, c, g, minpiv);
-      if (conmask & 32u) gj_leg<(TU > 1 ? 5 : 0), TU>(Quu, Rr, c, g, minpiv);
-      if (conmask & 64u) gj_leg<(TU > 1 ? 6 : 0), TU>(Quu, Rr, c, g, minpiv);
-      if (conmask & 128u) gj_leg<(TU > 1 ? 7 : 0), TU>(Quu, Rr, c, g, minpiv);
+      if (conmask & 16u) gj_leg<(TU > 1 ? 4 : 0), TU, DPP64>(Quu, Rr, c, g, minpiv);
+      if (conmask & 32u) gj_leg<(TU > 1 ? 5 : 0), TU, DPP64>(Quu, Rr, c, g, minpiv);
+      if (conmask & 64u) gj_leg<(TU > 1 ? 6 : 0), TU, DPP64>(Quu, Rr, c, g, minpiv);
+      if (conmask & 128u) gj_leg<(TU > 1 ? 7 : 0), TU, DPP64>(Quu, Rr, c, g, minpiv);
     }
     gj_finish<TU>(Quu, Rr, g);
     double Kf[TU][3];
@@ -922,7 +1005,7 @@ __global__ __launch_bounds__(64, VAR == 0 ? 1 : (MD::NL != 4 ? (VAR == 2 ? QMPC_
     rotation_prepass<D>(P, L, sm, sl, ROT, target, lane);
     if (KDG) __syncthreads();
     prof.tick(PH_PREPASS);
-    if (backward_pass<MD, PROF, (!KDG || QMPC_PIPE_ALL)>(P, L, sm, KD, ROT, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
+    if (backward_pass<MD, PROF, (!KDG || QMPC_PIPE_ALL), (SLG || D::TU > 1)>(P, L, sm, KD, ROT, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
     if (KDG) __syncthreads();
     double ap, ad;
     rollout_closed<MD, !KDG, QMPC_PF_K, LEAN, PROF>(P, L, sm, KD, ROT, 1.0, lane, prof);  // trial step
