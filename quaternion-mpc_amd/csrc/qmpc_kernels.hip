@@ -40,7 +40,7 @@ namespace qmpc {
 // Optional phase-level cycle accounting (s_memtime), compiled in only for the
 // diagnostic instantiation qmpc_solve_kernel<true>.
 enum { PH_SETUP = 0, PH_EXPAND, PH_BUILD, PH_MFMA, PH_SOLVE, PH_PUPD, PH_DIRS, PH_ROLL, PH_MISC,
-       PH_PREPASS, PH_R_GAIN, PH_R_BCAST, PH_R_STEP, PH_APPLY, PH_COUNT };   // 9.. : finer split, diagnostics only
+       PH_PREPASS, PH_R_GAIN, PH_R_BCAST, PH_R_STEP, PH_APPLY, PH_DRAIN, PH_COUNT };   // 9.. : finer split, diagnostics only
 template <bool PROF>
 struct Prof {
   long long t[PH_COUNT];
@@ -675,6 +675,12 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
       }
     }
     prof.tick(PH_MFMA);
+    if (PROF) {   // diagnostics: wait for the last product before the stage solve is timed
+      double sink;
+      asm volatile("v_mov_b64 %0, %1" : "=v"(sink) : "v"(Quu[TU - 1][TU - 1][2]));
+      asm volatile("v_mov_b64 %0, %1" : "=v"(sink) : "v"(Rr[TU - 1][2]));
+      prof.tick(PH_DRAIN);
+    }
     // ---- stage solve: [Kt | dt] = -Quu^-1 [Qux | Qu]; swing-leg pivots are decoupled ----
     if (conmask & 1u) gj_leg<0, TU, DPP64>(Quu, Rr, c, g, minpiv);
     if (conmask & 2u) gj_leg<1, TU, DPP64>(Quu, Rr, c, g, minpiv);

@@ -23,9 +23,9 @@ rec = pkg.random_go1_trot_states(a.batch, config_id=2 if a.horizon == 10 else 3)
 s.solve(rec)
 c = s.phase_profile(rec)
 names = ["setup", "expand", "build", "mfma+terms", "stage_solve", "P_update", "directions", "rollout(rest)", "misc",
-         "rot.prepass", "roll:dx+gain", "roll:bcast", "roll:step", "ipm_apply"]
+         "rot.prepass", "roll:dx+gain", "roll:bcast", "roll:step", "ipm_apply", "mfma drain"]
 it = c[:, 15].astype(float)
-tot = c[:, :14].sum(1)
+tot = c[:, :15].sum(1)
 print(f"batch {a.batch} N {a.horizon}: mean iterations {it.mean():.2f}; mean cycles/instance {tot.mean():.0f}; "
       f"max {tot.max()}; per iteration {np.mean(tot / np.maximum(it, 1)):.0f}")
 for i, n in enumerate(names):
