@@ -600,8 +600,9 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
       for (int t = 0; t < TU; ++t) { gt[t][e] = ROTk[84 * t + go[e]]; dt_[t][e] = ROTk[84 * t + dof[e]]; }
     }
     // ---- T = P'A (col 12 <- p), S = P'B ; Qxx = A'T, Qux = B'T, Quu = B'S ----
-    // One v_mfma_f64_16x16x4_f64 occupies the matrix pipe for 64 cycles; the next knot's operand build is
-    // independent VALU work and is placed between the products so that it issues under them.
+    // The next knot's operand build is independent work placed between the products: its LDS reads are in
+    // flight while the products run (the vector arithmetic itself does not overlap an FP64 MFMA of the same
+    // wave: tools/microbench/mfma_bench.hip).
     const d4 z4 = {0.0, 0.0, 0.0, 0.0};
     d4 aT = z4, aS[TU];
     double Tf[3], Sf[TU][3];
