@@ -87,6 +87,38 @@ def cpu_baseline(pkg, horizon: int, config_id: int, seconds: float = 12.0, model
     }
 
 
+def two_in_flight(pkg, lib, params, args, d_in, NU):
+    """Secondary measurement, never `value`: the same K steps with TWO batches in flight (two handles, two
+    streams, separate outputs).  With one launch in flight a step lasts as long as its slowest instance (every
+    SIMD holds one instance at B=1024); SIMDs released early then start on the next, independent batch."""
+    import torch
+    B = args.batch
+    biped, convex = args.model == "biped8", args.model == "convex"
+    solvers = [pkg.Solver(params, B, device=torch.cuda.current_device(), lib=lib) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    outs = [torch.zeros(B, NU, dtype=torch.float64, device="cuda") for _ in range(2)]
+    infos = [torch.zeros(B, pkg.INFO_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in range(2)]
+
+    def run(steps):
+        for i in range(steps):
+            j = i & 1
+            fn = solvers[j].solve8_device if biped else (solvers[j].convex_solve_device if convex else solvers[j].solve_device)
+            fn(B, d_in.data_ptr(), outs[j].data_ptr(), infos[j].data_ptr(), streams[j].cuda_stream)
+
+    run(max(args.warmup, 2))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    same = bool(torch.equal(outs[0], outs[1]))
+    for sv in solvers:
+        sv.close()
+    return {"value": B * args.steps / dt, "unit": "solves/s", "ms_per_step": 1e3 * dt / args.steps, "steps": args.steps,
+            "outputs_identical": same,
+            "note": "secondary: consecutive independent batches on two streams (two handles); not the contract value"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,6 +131,8 @@ def main():
                          "(SURVEY 8f rank 1), same solver core; biped8: the QuatMpc problem with 8 contact points "
                          "(BASELINE config 5, synthetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-in-flight", action="store_true",
+                    help="skip the secondary measurement with two batches in flight (N=1 only)")
     ap.add_argument("--check", action="store_true", help="also compare a sample against the oracle")
     ap.add_argument("--selftest-gloo", action="store_true",
                     help="TEST ONLY: run the multi-rank pipeline (sharding, double buffering, async gather) on CPU "
@@ -280,6 +314,8 @@ def main():
             idx = np.arange(0, B, max(B // 64, 1))
             fo, _ = oracle_solve(pyoracle, rec[idx], threads=usable_cores())
             out["config"]["force_linf_vs_cpu"] = float(np.abs(d_f.cpu().numpy()[idx] - fo).max())
+        if world == 1 and not args.no_in_flight:
+            out["two_in_flight"] = two_in_flight(pkg, lib, params, args, d_in, NU)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, N, config_id, model=args.model)
         print(json.dumps(out), flush=True)

@@ -570,3 +570,28 @@ def test_independent_handles_overlap_on_their_streams(pkg, lib):
     f_fresh, _ = fresh.solve(rq[:256])
     assert np.array_equal(f_live, f_fresh) and np.abs(f_live - fq_ref[:256]).max() > 1e-3
     sq.close(); sc.close(); fresh.close()
+
+
+def test_bench_line_contract(pkg, lib):
+    """bench.py prints ONE JSON line with the contract keys, the roofline and cpu_baseline objects and the
+    secondary two-batches-in-flight figure (whose outputs equal the single-stream ones)."""
+    import subprocess
+    import sys
+
+    repo = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(repo / "bench.py"), "--steps", "4", "--warmup", "1", "--batch", "256"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "two_in_flight"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 / (256 * 4) * 4 - 1.0) < 1e-6
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
+    assert d["two_in_flight"]["outputs_identical"] is True and d["config"]["converged"] == 256
