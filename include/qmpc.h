@@ -106,9 +106,8 @@ typedef struct qmpc_params {
   double  tol_feasibility;        /* both modes (cone violation / |c+s|)       */
   double  tol_cost_intermediate;  /* dual update trigger                       */
   /* converged mode: interior-point options                                    */
-  double  tol_step;               /* stop when |dU|_inf <= tol_step [N] (or, on a
-                                     geometric tail, when two consecutive Aitken
-                                     extrapolations agree to tol_step) ...      */
+  double  tol_step;               /* stop when the full Newton step |dU|_inf <=
+                                     tol_step [N] ...                           */
   double  ipm_mu0;                /* initial barrier: s0=max(-c,1), lam0=mu0/s0 */
   double  ipm_mu_final;           /* ... and the barrier is <= ipm_mu_final    */
   double  ipm_sigma;              /* centering parameter                       */

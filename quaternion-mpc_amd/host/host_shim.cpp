@@ -11,6 +11,7 @@
 #include "LeggedStateLite.h"
 #include "QuatMpcHip.h"
 #include "ConvexMpcHip.h"
+#include "LeggedLoggerHip.h"
 
 using legged::LeggedStateLite;
 using Mpc = legged::QuatMpcHipT<LeggedStateLite>;
@@ -239,6 +240,41 @@ void qh_raibert(void* p, const double* vel_d_rel, double* out) {
       out[12 + 3 * l + a] = s.ctrl.foot_pos_target_rel(a, l);
       out[24 + 3 * l + a] = s.ctrl.foot_pos_target_world(a, l);
     }
+}
+
+// /debug topic payloads (LeggedLogger.hpp:48-106) of the harness state, flattened:
+// out[0:13] torso_odom (pos3, quat wxyz, lin3, ang3), out[13:26] torso_odom_d, out[26:30] mpc_grf.position,
+// out[30:34] .velocity, out[34:38] .effort, out[38] mpc_time; names -> 4 x 3 chars (NUL terminated)
+void qh_debug_records(void* p, double* out, char* names) {
+  const LeggedStateLite& s = static_cast<Harness*>(p)->state;
+  legged::DebugRecords r;
+  legged::debug_records(s, r);
+  const legged::OdomRecord* od[2] = {&r.torso_odom, &r.torso_odom_d};
+  for (int k = 0; k < 2; ++k) {
+    double* o = out + 13 * k;
+    for (int a = 0; a < 3; ++a) { o[a] = od[k]->position[a]; o[7 + a] = od[k]->linear[a]; o[10 + a] = od[k]->angular[a]; }
+    for (int a = 0; a < 4; ++a) o[3 + a] = od[k]->orientation[a];
+  }
+  for (int i = 0; i < 4; ++i) {
+    out[26 + i] = r.mpc_grf.position[i];
+    out[30 + i] = r.mpc_grf.velocity[i];
+    out[34 + i] = r.mpc_grf.effort[i];
+    std::snprintf(names + 3 * i, 3, "%s", r.mpc_grf.name[i]);
+  }
+  out[38] = r.mpc_time;
+}
+
+// test hook: the controller outputs the logger reads
+void qh_set_mpc_outputs(void* p, const double* grf_world, const double* contacts, double mpc_time) {
+  LeggedStateLite& s = static_cast<Harness*>(p)->state;
+  for (int i = 0; i < 12; ++i) s.ctrl.mpc_grf_world[i] = grf_world[i];
+  for (int i = 0; i < 4; ++i) s.ctrl.plan_contacts[i] = contacts[i] != 0.0;
+  s.fbk.mpc_time = mpc_time;
+}
+
+void qh_debug_grf_batch(int32_t batch, const double* forces_world, const double* contacts, double* position,
+                        double* effort) {
+  legged::debug_grf_batch(batch, forces_world, contacts, position, effort);
 }
 
 void qh_filter_run(int window, int n, const double* in, double* out) {

@@ -403,3 +403,43 @@ def test_raibert_foot_targets(host):
     a2 = (Rz @ feet.T).T + [*(Rz @ d2)[:2], 0.0]
     assert np.abs(out[:12].reshape(4, 3) - a2).max() < 1e-14
     host.qh_destroy(h)
+
+
+def test_debug_topic_records(host):
+    """/debug/{torso_odom,torso_odom_d,mpc_grf,mpc_time} payloads (LeggedLogger.hpp:48-106) from the harness
+    state: field-for-field the numbers the reference's logger publishes."""
+    host.qh_debug_records.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+    host.qh_set_mpc_outputs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+    host.qh_debug_grf_batch.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    h = host.qh_create(None, 10)
+    f = _yaw_feedback(0.3)
+    f[19:22] = [0.01, -0.02, 0.4]
+    host.qh_set_feedback(h, f.ctypes.data)
+    joy = np.array([0.3, -0.1, 0.28, 0.0, 0.0, 0.2])
+    host.qh_set_command(h, joy.ctypes.data, 1.0)
+    host.qh_goal_update(h)
+    grf = np.array([1.0, 2.0, 2.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, -3.0, 4.0, 12.0])
+    con = np.array([1.0, 0.0, 0.0, 1.0])
+    host.qh_set_mpc_outputs(h, grf.ctypes.data, con.ctypes.data, 0.734)
+    out = np.zeros(39)
+    names = C.create_string_buffer(12)
+    host.qh_debug_records(h, out.ctypes.data, names)
+    assert [names.raw[3 * i:3 * i + 2].decode() for i in range(4)] == ["FL", "FR", "RL", "RR"]
+    # torso_odom: world position, attitude (w x y z), BODY-frame linear velocity, body angular velocity
+    assert np.array_equal(out[0:3], f[13:16]) and np.array_equal(out[3:7], f[0:4]) and np.array_equal(out[10:13], f[19:22])
+    assert np.array_equal(out[7:10], np.zeros(3))      # fbk.torso_lin_vel_body is written by grf_update (QuatMpc.cpp:231)
+    # torso_odom_d: the desired quantities goal_update produced (same numbers as qh_get_outputs / pack_input)
+    o = np.zeros(40)
+    host.qh_get_outputs(h, o.ctypes.data)
+    assert np.array_equal(out[16:20], o[32:36])
+    assert abs(out[20] - 0.3) < 0.31 and out[25] == pytest.approx(0.2)    # filtered vx command, yaw rate
+    # mpc_grf: planned contacts, zero velocities, force norms; mpc_time
+    assert np.array_equal(out[26:30], con) and np.array_equal(out[30:34], np.zeros(4))
+    assert np.allclose(out[34:38], [3.0, 0.0, 0.0, 13.0], rtol=0, atol=1e-15) and out[38] == 0.734
+    # batch form
+    rng = np.random.default_rng(5)
+    F = rng.normal(size=(64, 12)); Cn = (rng.random((64, 4)) < 0.5).astype(np.float64)
+    pos = np.zeros((64, 4)); eff = np.zeros((64, 4))
+    host.qh_debug_grf_batch(64, F.ctypes.data, Cn.ctypes.data, pos.ctypes.data, eff.ctypes.data)
+    assert np.array_equal(pos, Cn) and np.abs(eff - np.linalg.norm(F.reshape(64, 4, 3), axis=2)).max() < 1e-15
+    host.qh_destroy(h)
