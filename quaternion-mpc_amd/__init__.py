@@ -322,11 +322,16 @@ class Solver:
             raise QmpcError(st, "qmpc_create")
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
-            self.lib.qmpc_destroy(self._h)
-            self._h = C.c_void_p()
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._h = None
+            self.lib.qmpc_destroy(h)
 
-    __del__ = close
+    def __del__(self):
+        try:                      # module globals may already be gone at interpreter shutdown
+            self.close()
+        except Exception:
+            pass
 
     def set_params(self, params: Params):
         self.params = params.copy()

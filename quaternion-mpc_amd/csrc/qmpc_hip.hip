@@ -480,6 +480,14 @@ static qmpc_status launch_leg(const qmpc_leg_geometry* g, int32_t batch, const d
                               double* d_tau, hipStream_t s) {
   LegGeom G;
   std::memcpy(&G, g, sizeof G);
+  const bool aligned = ((reinterpret_cast<uintptr_t>(d_q) | reinterpret_cast<uintptr_t>(d_f) |
+                         reinterpret_cast<uintptr_t>(d_tau)) & 15u) == 0;
+  if (d_tau && !d_p && !d_J && aligned) {      // the torque map proper: LDS-staged streaming pass, 64 instances per block
+    hipLaunchKernelGGL(qmpc_tau_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(256), 0, s, G, d_q, d_f, d_c, walking,
+                       d_tau, (int)batch);
+    HIP_TRY(hipGetLastError());
+    return QMPC_OK;
+  }
   const unsigned threads = 256, blocks = (unsigned)(((size_t)batch * 4 + threads - 1) / threads);
   hipLaunchKernelGGL(qmpc_leg_kernel, dim3(blocks), dim3(threads), 0, s, G, d_q, d_f, d_c, walking, d_p, d_J, d_tau,
                      (int)batch);

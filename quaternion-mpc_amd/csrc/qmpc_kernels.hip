@@ -1161,6 +1161,47 @@ __global__ __launch_bounds__(256) void qmpc_leg_kernel(LegGeom G, const double* 
   }
 }
 
+// Torque map as a streaming pass: a block owns 64 consecutive instances (768 doubles of joint angles, of forces
+// and of torques).  The arrays move between HBM and LDS as contiguous 16-byte-per-lane accesses; the per-(instance,
+// leg) triples are picked out of LDS, where the 24-byte stride costs nothing.  The pointers must be 16-byte
+// aligned (the launcher falls back to qmpc_leg_kernel otherwise).
+__global__ __launch_bounds__(256) void qmpc_tau_kernel(LegGeom G, const double* __restrict__ joint_pos,
+                                                       const double* __restrict__ forces,
+                                                       const double* __restrict__ contacts, int walking,
+                                                       double* __restrict__ out_tau, int batch) {
+  __shared__ __attribute__((aligned(16))) double sq[768], sf[768];
+  const int tid = threadIdx.x;
+  const size_t inst0 = (size_t)blockIdx.x * 64;
+  const int n = (int)(((size_t)batch - inst0 < 64) ? ((size_t)batch - inst0) : 64);   // instances of this block
+  const int pairs = 6 * n;                                                            // double2 per array
+  const double2* q2 = reinterpret_cast<const double2*>(joint_pos + 12 * inst0);
+  const double2* f2 = reinterpret_cast<const double2*>(forces + 12 * inst0);
+  for (int i = tid; i < pairs; i += 256) {
+    reinterpret_cast<double2*>(sq)[i] = q2[i];
+    reinterpret_cast<double2*>(sf)[i] = f2[i];
+  }
+  const bool live = tid < 4 * n;
+  const bool stance = live && (!contacts || contacts[4 * inst0 + tid] != 0.0);
+  __syncthreads();
+  double tau[3] = {0.0, 0.0, 0.0};
+  if (live && !(walking && !stance)) {
+    const int l = tid & 3;
+    const double q[3] = {sq[3 * tid], sq[3 * tid + 1], sq[3 * tid + 2]};
+    const double f[3] = {sf[3 * tid], sf[3 * tid + 1], sf[3 * tid + 2]};
+    const LegTerms k = leg_terms(q, G.rho_opt[l], G.rho_fix[l]);
+    const double J[9] = {0.0, -k.D * k.s0 + k.L * k.c0, k.D * k.c0 + k.L * k.s0,
+                         -k.L, k.X * k.s0, -k.X * k.c0,
+                         -k.L2, k.X2 * k.s0, -k.X2 * k.c0};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) tau[j] = -(J[3 * j] * f[0] + J[3 * j + 1] * f[1] + J[3 * j + 2] * f[2]);
+  }
+  __syncthreads();            // every triple has been read: sq is reused for the torques
+  if (live) { sq[3 * tid] = tau[0]; sq[3 * tid + 1] = tau[1]; sq[3 * tid + 2] = tau[2]; }
+  __syncthreads();
+  double2* t2 = reinterpret_cast<double2*>(out_tau + 12 * inst0);
+  for (int i = tid; i < pairs; i += 256) t2[i] = reinterpret_cast<const double2*>(sq)[i];
+}
+
 // ---- MFMA layout self-test: C = X' * Y on [12][16] tiles -------------------------
 __global__ __launch_bounds__(64) void qmpc_selftest_kernel(const double* __restrict__ X,
                                                            const double* __restrict__ Y,

@@ -428,6 +428,24 @@ def test_leg_kinematics_and_torque_map_match_oracle(pkg, lib, oracle):
     s.torque_map_device(g, B, d_q.data_ptr(), d_f.data_ptr(), d_c.data_ptr(), True, d_tau.data_ptr(), st.cuda_stream)
     st.synchronize()
     assert np.array_equal(d_tau.cpu().numpy(), s.torque_map(g, q, f, rec["contacts"], walking=True))
+    # ragged batches (the streaming kernel owns 64 instances per block) and 8-byte-aligned pointers (the
+    # per-thread kernel takes over): same numbers, nothing written past the batch
+    full = s.torque_map(g, q, f, rec["contacts"], walking=True)
+    for n in (1, 63, 64, 65, 1000):
+        d_tau.fill_(7.0)
+        torch.cuda.synchronize()
+        s.torque_map_device(g, n, d_q.data_ptr(), d_f.data_ptr(), d_c.data_ptr(), True, d_tau.data_ptr(), st.cuda_stream)
+        st.synchronize()
+        t = d_tau.cpu().numpy()
+        assert np.array_equal(t[:n], full[:n]) and (t[n:] == 7.0).all()
+    d_q1 = torch.zeros(12 * B + 1, dtype=torch.float64, device="cuda")
+    d_q1[1:] = d_q.reshape(-1)
+    d_tau.fill_(7.0)
+    torch.cuda.synchronize()
+    s.torque_map_device(g, 1000, d_q1.data_ptr() + 8, d_f.data_ptr(), d_c.data_ptr(), True, d_tau.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    t = d_tau.cpu().numpy()
+    assert np.abs(t[:1000] - full[:1000]).max() < 1e-12 and (t[1000:] == 7.0).all()   # another kernel: not bit-equal
     s.close()
 
 
