@@ -196,6 +196,41 @@ qmpc_status qmpc_set_params(qmpc_handle* h, const qmpc_params* params) {
   return QMPC_OK;
 }
 
+// device resources of a handle; on failure the caller destroys the (partially filled) handle
+static qmpc_status create_resources(qmpc_handle* h, int N, int nl, int nu) {
+  const qmpc_params* params = &h->params;
+  const int32_t max_batch = h->max_batch;
+  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&h->ev0));
+  HIP_TRY(hipEventCreate(&h->ev1));
+  HIP_TRY(hipMalloc(&h->d_in, sizeof(double) * (32 + 4 * nl) * (size_t)max_batch));
+  HIP_TRY(hipMalloc(&h->d_forces, sizeof(double) * nu * (size_t)max_batch));
+  HIP_TRY(hipMalloc(&h->d_info, sizeof(qmpc_info) * (size_t)max_batch));
+#define QMPC_SET_LDS(kern, bytes) \
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
+  if (params->model == QMPC_MODEL_QUAT8) {
+    QMPC_SET_LDS((qmpc_solve_kernel<Quat8Model, false, 1>), h->lds_bytes_g);   // never everything in LDS
+    QMPC_SET_LDS((qmpc_solve_kernel<Quat8Model, false, 2>), h->lds_bytes_s);
+  } else if (params->model == QMPC_MODEL_CONVEX) {
+    if (h->lds_bytes <= 160 * 1024) QMPC_SET_LDS((qmpc_solve_kernel<ConvexModel, false, 0>), h->lds_bytes);
+    QMPC_SET_LDS((qmpc_solve_kernel<ConvexModel, false, 1>), h->lds_bytes_g);
+    QMPC_SET_LDS((qmpc_solve_kernel<ConvexModel, false, 2>), h->lds_bytes_s);
+    QMPC_SET_LDS(qmpc_linearize_kernel<ConvexModel>, h->lds_bytes_g);
+  } else {
+    if (h->lds_bytes <= 160 * 1024) {
+      QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, false, 0>), h->lds_bytes);
+      QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, true, 0>), h->lds_bytes);
+    }
+    QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, false, 1>), h->lds_bytes_g);
+    QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, true, 1>), h->lds_bytes_g);
+    QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, false, 2>), h->lds_bytes_s);
+    QMPC_SET_LDS(qmpc_linearize_kernel<QuatModel>, h->lds_bytes_g);
+  }
+#undef QMPC_SET_LDS
+  HIP_TRY(hipMalloc(&h->d_gws, sizeof(double) * (size_t)N * (13 * nu + 21 * nl + 30 * nl) * (size_t)max_batch));
+  return QMPC_OK;
+}
+
 qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t device, qmpc_handle** out) {
   if (!out) return QMPC_BAD_ARGUMENT;
   *out = nullptr;
@@ -227,34 +262,8 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     const char* v = std::getenv("QMPC_VARIANT");
     h->variant = v ? std::atoi(v) : 0;
   }
-  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreate(&h->ev0));
-  HIP_TRY(hipEventCreate(&h->ev1));
-  HIP_TRY(hipMalloc(&h->d_in, sizeof(double) * (32 + 4 * nl) * (size_t)max_batch));
-  HIP_TRY(hipMalloc(&h->d_forces, sizeof(double) * nu * (size_t)max_batch));
-  HIP_TRY(hipMalloc(&h->d_info, sizeof(qmpc_info) * (size_t)max_batch));
-#define QMPC_SET_LDS(kern, bytes) \
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
-  if (params->model == QMPC_MODEL_QUAT8) {
-    QMPC_SET_LDS((qmpc_solve_kernel<Quat8Model, false, 1>), h->lds_bytes_g);   // never everything in LDS
-    QMPC_SET_LDS((qmpc_solve_kernel<Quat8Model, false, 2>), h->lds_bytes_s);
-  } else if (params->model == QMPC_MODEL_CONVEX) {
-    if (h->lds_bytes <= 160 * 1024) QMPC_SET_LDS((qmpc_solve_kernel<ConvexModel, false, 0>), h->lds_bytes);
-    QMPC_SET_LDS((qmpc_solve_kernel<ConvexModel, false, 1>), h->lds_bytes_g);
-    QMPC_SET_LDS((qmpc_solve_kernel<ConvexModel, false, 2>), h->lds_bytes_s);
-    QMPC_SET_LDS(qmpc_linearize_kernel<ConvexModel>, h->lds_bytes_g);
-  } else {
-    if (h->lds_bytes <= 160 * 1024) {
-      QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, false, 0>), h->lds_bytes);
-      QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, true, 0>), h->lds_bytes);
-    }
-    QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, false, 1>), h->lds_bytes_g);
-    QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, true, 1>), h->lds_bytes_g);
-    QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, false, 2>), h->lds_bytes_s);
-    QMPC_SET_LDS(qmpc_linearize_kernel<QuatModel>, h->lds_bytes_g);
-  }
-#undef QMPC_SET_LDS
-  HIP_TRY(hipMalloc(&h->d_gws, sizeof(double) * (size_t)N * (13 * nu + 21 * nl + 30 * nl) * (size_t)max_batch));
+  const qmpc_status rs = create_resources(h, N, nl, nu);
+  if (rs != QMPC_OK) { qmpc_destroy(h); return rs; }   // release whatever was created
   *out = h;
   return QMPC_OK;
 }
@@ -296,8 +305,8 @@ static bool use_global_gains(const qmpc_handle* h, int32_t batch) { return pick_
 
 static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces,
                                 qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s) {
-  HIP_TRY(hipEventRecord(h->ev0, s));
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;   // the gains workspace is sized by max_batch
+  HIP_TRY(hipEventRecord(h->ev0, s));
   const int var = pick_variant(h, batch);
   const size_t lds = var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes);
   double* gws = var >= 1 ? h->d_gws : nullptr;
