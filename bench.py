@@ -77,9 +77,10 @@ def cpu_baseline(pkg, horizon: int, config_id: int, seconds: float = 12.0, model
     n = int(min(max(rate * seconds, 4 * cores), 65536))
     rec = gen(n, config_id=config_id)
     t0 = time.perf_counter()
-    _, info = solve(p, rec, threads=cores)
+    forces, info = solve(p, rec, threads=cores)
     dt = time.perf_counter() - t0
     return {
+        "_forces": forces,       # popped by the caller: parity of the GPU batch against the same instances
         "value": n / dt, "unit": "solves/s", "cores": cores, "kind": "port",
         "sample": f"first {n} instances of the same synthetic workload (N={horizon}), {cores} host threads "
                   f"(= usable cores: affinity capped by the cgroup CPU quota; {os.cpu_count()} logical CPUs visible), "
@@ -317,7 +318,12 @@ def main():
         if world == 1 and not args.no_in_flight:
             out["two_in_flight"] = two_in_flight(pkg, lib, params, args, d_in, NU)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, N, config_id, model=args.model)
+            cb = cpu_baseline(pkg, N, config_id, model=args.model)
+            f_cpu = cb.pop("_forces")
+            m = min(len(f_cpu), B)      # the sample starts with the instances of the timed batch
+            cb["force_linf_gpu_vs_cpu"] = float(np.abs(d_f.cpu().numpy()[:m] - f_cpu[:m]).max())
+            cb["force_linf_instances"] = m
+            out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     solver.close()
     if world > 1:

@@ -612,4 +612,5 @@ def test_bench_line_contract(pkg, lib):
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
+    assert cb["force_linf_instances"] == 256 and cb["force_linf_gpu_vs_cpu"] < 1e-6      # the stated tolerance
     assert d["two_in_flight"]["outputs_identical"] is True and d["config"]["converged"] == 256
