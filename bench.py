@@ -171,8 +171,17 @@ def main():
     gen = pkg.random_biped8_states if biped else (pkg.random_go1_convex_states if convex else pkg.random_go1_trot_states)
     # synthetic Go1 trot states; rank r owns instances [r*B, (r+1)*B)
     rec = gen(B, config_id=config_id, first=rank * B)
-    d_f = torch.zeros(B, NU, dtype=torch.float64, device=dev)
-    d_info = torch.zeros(B, pkg.INFO_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    # one result block per step slot: [B x NU forces | B x qmpc_info (status, iterations, cost, ...)] in ONE buffer,
+    # so that a single collective carries forces and status
+    IW = pkg.INFO_DTYPE.itemsize // 8           # qmpc_info is 40 bytes = 5 doubles
+    assert pkg.INFO_DTYPE.itemsize == 8 * IW
+    blocks = [torch.zeros(B * (NU + IW), dtype=torch.float64, device=dev) for _ in range(2)]
+
+    def forces_of(blk):
+        return blk[:B * NU].view(B, NU)
+
+    def info_of(blk):
+        return blk[B * NU:]
     def oracle_solve(po, records, threads=1):
         if biped:
             return po.solve8(po.default_biped8_params(N, 0), records, threads=threads)
@@ -186,8 +195,8 @@ def main():
         f_ref = torch.from_numpy(f_ref)
         solver = stream = None
 
-        def launch(out):
-            out.copy_(f_ref)
+        def launch(blk):
+            forces_of(blk).copy_(f_ref)
     else:
         lib = pkg.load_library()
         params = (pkg.default_biped8_params if biped else
@@ -198,15 +207,14 @@ def main():
         stream = torch.cuda.Stream()
         torch.cuda.set_stream(stream)
 
-        def launch(out):
+        def launch(blk):
             (solver.solve8_device if biped else (solver.convex_solve_device if convex else solver.solve_device))(
-                B, d_in.data_ptr(), out.data_ptr(), d_info.data_ptr(), stream.cuda_stream)
+                B, d_in.data_ptr(), forces_of(blk).data_ptr(), info_of(blk).data_ptr(), stream.cuda_stream)
 
     counts = [B] * world
     # double-buffered outputs: the gather of step i (RCCL's own stream) overlaps the solve of
     # step i+1 (launch stream); one collective per step, never on the solve's critical path
-    d_fs = [d_f, torch.zeros_like(d_f)]
-    gathered = [torch.zeros(world * B, NU, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    gathered = [torch.zeros(world, B * (NU + IW), dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
     pending = [None, None]
 
     def step(i):
@@ -214,9 +222,9 @@ def main():
         if pending[buf] is not None:          # the buffer's previous gather must have drained
             pending[buf].wait()
             pending[buf] = None
-        launch(d_fs[buf])
+        launch(blocks[buf])
         if world > 1:
-            pending[buf] = dist.all_gather_into_tensor(gathered[buf], d_fs[buf], async_op=True)
+            pending[buf] = dist.all_gather_into_tensor(gathered[buf].view(-1), blocks[buf], async_op=True)
 
     def drain():
         for w in pending:
@@ -256,24 +264,28 @@ def main():
         elapsed = float(t.item())
     # HIP events on the launch stream: average launch duration (back-to-back launches)
     kernel_ms = (ev0.elapsed_time(ev1) / args.steps) if not selftest else float("nan")
-    d_f = d_fs[(args.steps - 1) & 1]
+    last = blocks[(args.steps - 1) & 1]
+    d_f = forces_of(last)
     if world > 1:
-        # every rank holds every force: check the gathered block against the local one
+        # every rank holds every rank's forces and status: check the gathered block against the local one
         g = gathered[(args.steps - 1) & 1]
-        assert torch.equal(g[rank * B:(rank + 1) * B], d_f), "gathered forces differ from the local shard"
+        assert torch.equal(g[rank], last), "gathered block differs from the local shard"
     if selftest:
         ok = True
         if world > 1:
             from oracle import pyoracle
             full, _ = oracle_solve(pyoracle, gen(world * B, config_id=config_id))
-            ok = bool(np.array_equal(gathered[(args.steps - 1) & 1].numpy(), full))
+            gf = gathered[(args.steps - 1) & 1][:, :B * NU].reshape(world * B, NU)
+            ok = bool(np.array_equal(gf.numpy(), full))
         if rank == 0:
             print(json.dumps({"selftest": "gloo", "n_ranks": world, "steps": args.steps, "ok": ok}), flush=True)
         if world > 1:
             dist.destroy_process_group()
         sys.exit(0 if ok else 1)
 
-    info = d_info.cpu().numpy().view(pkg.INFO_DTYPE).reshape(-1)
+    # status of EVERY rank's instances (the gathered blocks carry them); iterations of the local shard
+    all_info = (gathered[(args.steps - 1) & 1][:, B * NU:] if world > 1 else info_of(last).view(1, -1))
+    info = np.ascontiguousarray(all_info.cpu().numpy()).view(pkg.INFO_DTYPE).reshape(world, B)
     n_ok = int((info["status"] == 0).sum())
     mean_iters = float(info["iterations"].mean())
 
@@ -302,7 +314,7 @@ def main():
             "config": {"workload": f"Batch={B} random {'biped8 ' if biped else 'Go1 '}{'ConvexMpc ' if convex else ''}states per GPU, N={N}, converged mode "
                                    f"(interior point to |dU|<=1e-8 N), generator seed 0x5EED0000+{config_id}",
                        "batch_per_gpu": B, "horizon": N, "parallelism": f"instance-sharded x{world}",
-                       "converged": n_ok, "mean_iterations": mean_iters},
+                       "instances": world * B, "converged": n_ok, "mean_iterations": mean_iters},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "qmpc_solve_kernel", "kernel_ms": kernel_ms,
