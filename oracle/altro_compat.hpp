@@ -1,0 +1,303 @@
+// altro_compat.hpp -- the call surface of the reference's external solver (altro::ALTROSolver of
+// zixinz990/altro @ b47202ff, used at legged_ctrl/src/mpc/QuatMpc.cpp:218-265 and in
+// legged_ctrl/src/test/test_altro/*.cpp) over this repository's CPU restatement (qo_altro.h).
+// lets code written against that API -- the reference's controller and its
+// solver tests -- run on the oracle where the un-vendored fork is not available.
+// TEST INFRASTRUCTURE like the rest of oracle/: CPU only, never linked into the HIP product.
+//
+// Index conventions (from the reference's own call sites): [k_start, k_stop) with k_stop
+// exclusive; k_stop == 0 means the single knot k_start; LastIndex means "through the terminal knot".
+// Supported: one (n, m) and one time step for all knots, one explicit dynamics function, diagonal LQR and
+// quaternion costs per knot, EQUALITY / INEQUALITY constraints (at most QO_MAXCON blocks), AltroOptions
+// fields the reference sets.  Not supported (ErrorCodes::NotSupported): SECOND_ORDER_CONE constraints,
+// generic cost functions, UpdateLinearCosts, ShiftTrajectory.
+#pragma once
+
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "qo_altro.h"
+
+namespace altro {
+
+using a_float = double;
+constexpr int LastIndex = -1;
+constexpr int AllIndices = -2;
+
+enum class ErrorCodes {
+  NoError = 0,
+  DimensionUnknown,
+  BadIndex,
+  DimensionMismatch,
+  SolverNotInitialized,
+  SolverAlreadyInitialized,
+  TooManyConstraints,
+  NotSupported
+};
+enum class SolveStatus { Success = 0, Unsolved, MaxIterations, LineSearchFailure, NotPositiveDefinite };
+enum class ConstraintType { EQUALITY, INEQUALITY, SECOND_ORDER_CONE };
+enum class Verbosity { Silent = 0, Outer = 1, Inner = 2 };
+
+using ExplicitDynamicsFunction = std::function<void(double*, const double*, const double*, float)>;
+using ExplicitDynamicsJacobian = std::function<void(double*, const double*, const double*, float)>;
+using ConstraintFunction = std::function<void(a_float*, const a_float*, const a_float*)>;
+using ConstraintJacobian = std::function<void(a_float*, const a_float*, const a_float*)>;
+using ConstraintIndex = int;
+
+struct AltroOptions {
+  int iterations_max = 200;
+  double tol_cost = 1e-4;
+  double tol_cost_intermediate = 1e-4;
+  double tol_primal_feasibility = 1e-4;
+  double tol_stationarity = 1e-4;
+  double penalty_initial = 1.0;
+  double penalty_scaling = 10.0;
+  double penalty_max = 1e8;
+  Verbosity verbose = Verbosity::Silent;
+  bool use_backtracking_linesearch = true;
+  bool use_quaternion = false;
+  int quat_start_index = 0;
+};
+
+class ALTROSolver {
+ public:
+  explicit ALTROSolver(int horizon_length) : prob_(new qo_problem()) {
+    std::memset(prob_.get(), 0, sizeof(qo_problem));
+    prob_->N = horizon_length;
+  }
+
+  ErrorCodes SetDimension(int num_states, int num_inputs, int k_start = 0, int k_stop = LastIndex) {
+    if (initialized_) return ErrorCodes::SolverAlreadyInitialized;
+    if (num_states < 1 || num_states > QO_MAXN || num_inputs < 1 || num_inputs > QO_MAXM || prob_->N > QO_MAXH)
+      return ErrorCodes::NotSupported;
+    int a, b;
+    if (!range(k_start, k_stop, a, b)) return ErrorCodes::BadIndex;
+    if (prob_->n && (prob_->n != num_states || prob_->m != num_inputs)) return ErrorCodes::NotSupported;  // one size
+    prob_->n = num_states;
+    prob_->m = num_inputs;
+    return ErrorCodes::NoError;
+  }
+
+  ErrorCodes SetTimeStep(float h, int k_start = 0, int k_stop = LastIndex) {
+    int a, b;
+    if (!range(k_start, k_stop, a, b)) return ErrorCodes::BadIndex;
+    if (have_h_ && prob_->h != h) return ErrorCodes::NotSupported;      // one step for all knots
+    prob_->h = h;
+    have_h_ = true;
+    return ErrorCodes::NoError;
+  }
+
+  ErrorCodes SetExplicitDynamics(ExplicitDynamicsFunction dyn, ExplicitDynamicsJacobian jac, int k_start = 0,
+                                 int k_stop = LastIndex) {
+    if (!prob_->n) return ErrorCodes::DimensionUnknown;
+    int a, b;
+    if (!range(k_start, k_stop, a, b)) return ErrorCodes::BadIndex;
+    dyn_ = std::move(dyn);
+    jac_ = std::move(jac);
+    prob_->dyn = &ALTROSolver::dyn_tramp;
+    prob_->jac = &ALTROSolver::jac_tramp;
+    prob_->dyn_ctx = this;
+    return ErrorCodes::NoError;
+  }
+
+  // 0.5 (x-xr)' diag(Q) (x-xr) + 0.5 (u-ur)' diag(R) (u-ur); the terminal knot has no input term
+  ErrorCodes SetLQRCost(int n, int m, const a_float* Qdiag, const a_float* Rdiag, const a_float* xref,
+                        const a_float* uref, int k_start = 0, int k_stop = 0) {
+    return set_cost(n, m, Qdiag, Rdiag, 0.0, xref, uref, k_start, k_stop);
+  }
+  // ... + w (1 - |q_ref' q|) on the quaternion at AltroOptions::quat_start_index (QuatMpc.cpp:226-228)
+  ErrorCodes SetQuaternionCost(int n, int m, const a_float* Qdiag, const a_float* Rdiag, a_float w,
+                               const a_float* xref, const a_float* uref, int k_start = 0, int k_stop = 0) {
+    return set_cost(n, m, Qdiag, Rdiag, w, xref, uref, k_start, k_stop);
+  }
+
+  ErrorCodes SetConstraint(ConstraintFunction con, ConstraintJacobian jac, int dim, ConstraintType type,
+                           std::string label, int k_start = 0, int k_stop = 0,
+                           std::vector<ConstraintIndex>* con_inds = nullptr) {
+    if (initialized_) return ErrorCodes::SolverAlreadyInitialized;
+    if (!prob_->n) return ErrorCodes::DimensionUnknown;
+    if (type == ConstraintType::SECOND_ORDER_CONE) return ErrorCodes::NotSupported;
+    if (dim < 1 || dim > QO_MAXP) return ErrorCodes::NotSupported;
+    if (prob_->ncon >= QO_MAXCON) return ErrorCodes::TooManyConstraints;
+    int a, b;
+    if (!range(k_start, k_stop, a, b)) return ErrorCodes::BadIndex;
+    cons_.push_back(std::unique_ptr<ConBlock>(new ConBlock{std::move(con), std::move(jac), std::move(label)}));
+    qo_constraint& c = prob_->con[prob_->ncon];
+    c.type = (type == ConstraintType::EQUALITY) ? QO_EQUALITY : QO_INEQUALITY;
+    c.p = dim;
+    c.k_start = a;
+    c.k_stop = b;
+    c.con = &ALTROSolver::con_tramp;
+    c.jac = &ALTROSolver::conjac_tramp;
+    c.ctx = cons_.back().get();
+    c.row_enable = nullptr;
+    if (con_inds)
+      for (int k = a; k < b; ++k) con_inds->push_back(prob_->ncon);
+    prob_->ncon++;
+    return ErrorCodes::NoError;
+  }
+
+  ErrorCodes SetInitialState(const a_float* x0, int n) {
+    if (!prob_->n) return ErrorCodes::DimensionUnknown;
+    if (n != prob_->n) return ErrorCodes::DimensionMismatch;
+    std::memcpy(prob_->x0, x0, sizeof(double) * n);
+    return ErrorCodes::NoError;
+  }
+
+  ErrorCodes Initialize() {
+    if (initialized_) return ErrorCodes::SolverAlreadyInitialized;
+    if (!prob_->n || !prob_->dyn || !have_h_) return ErrorCodes::DimensionUnknown;
+    X_.assign((size_t)(prob_->N + 1) * prob_->n, 0.0);
+    U_.assign((size_t)prob_->N * prob_->m, 0.0);
+    initialized_ = true;
+    return ErrorCodes::NoError;
+  }
+  bool IsInitialized() const { return initialized_; }
+
+  ErrorCodes SetState(const a_float* x, int n, int k_start = 0, int k_stop = 0) {
+    if (!initialized_) return ErrorCodes::SolverNotInitialized;
+    if (n != prob_->n) return ErrorCodes::DimensionMismatch;
+    int a, b;
+    if (!range(k_start, k_stop, a, b)) return ErrorCodes::BadIndex;
+    for (int k = a; k < b; ++k) std::memcpy(&X_[(size_t)k * n], x, sizeof(double) * n);
+    return ErrorCodes::NoError;
+  }
+  ErrorCodes SetInput(const a_float* u, int m, int k_start = 0, int k_stop = LastIndex) {
+    if (!initialized_) return ErrorCodes::SolverNotInitialized;
+    if (m != prob_->m) return ErrorCodes::DimensionMismatch;
+    int a, b;
+    if (!range(k_start, k_stop, a, b)) return ErrorCodes::BadIndex;
+    for (int k = a; k < b && k < prob_->N; ++k) std::memcpy(&U_[(size_t)k * m], u, sizeof(double) * m);
+    return ErrorCodes::NoError;
+  }
+
+  void SetOptions(const AltroOptions& opts) { opts_ = opts; }
+  AltroOptions& GetOptions() { return opts_; }
+
+  // un-augmented objective of the stored trajectory
+  a_float CalcCost() const {
+    const int n = prob_->n, m = prob_->m, N = prob_->N;
+    double J = 0.0;
+    for (int k = 0; k <= N; ++k) {
+      const double* x = &X_[(size_t)k * n];
+      for (int i = 0; i < n; ++i) {
+        const double d = x[i] - prob_->xref[k][i];
+        J += 0.5 * prob_->Q[k][i] * d * d;
+      }
+      if (prob_->w[k] != 0.0) {
+        double dot = 0.0;
+        for (int i = 0; i < 4; ++i) dot += prob_->xref[k][opts_.quat_start_index + i] * x[opts_.quat_start_index + i];
+        J += prob_->w[k] * (1.0 - (dot < 0 ? -dot : dot));
+      }
+      if (k < N)
+        for (int j = 0; j < m; ++j) {
+          const double d = U_[(size_t)k * m + j] - prob_->uref[k][j];
+          J += 0.5 * prob_->R[k][j] * d * d;
+        }
+    }
+    return J;
+  }
+
+  SolveStatus Solve() {
+    if (!initialized_) return SolveStatus::Unsolved;
+    qo_options o;
+    qo_default_options(&o, QO_MODE_REFERENCE);
+    o.iterations_max = opts_.iterations_max;
+    o.penalty_initial = opts_.penalty_initial;
+    o.penalty_scaling = opts_.penalty_scaling;
+    o.penalty_max = opts_.penalty_max;
+    o.tol_stationarity = opts_.tol_stationarity;
+    o.tol_feasibility = opts_.tol_primal_feasibility;
+    o.tol_cost_intermediate = opts_.tol_cost_intermediate;
+    o.verbose = static_cast<int>(opts_.verbose);
+    prob_->use_quaternion = opts_.use_quaternion ? 1 : 0;
+    prob_->quat_start_index = opts_.quat_start_index;
+    std::memcpy(&X_[0], prob_->x0, sizeof(double) * prob_->n);
+    qo_altro_solve(prob_.get(), &o, X_.data(), U_.data(), &res_);
+    solved_ = true;
+    switch (res_.status) {
+      case QO_STATUS_OK: return SolveStatus::Success;
+      case QO_STATUS_MAX_ITER: return SolveStatus::MaxIterations;
+      case QO_STATUS_LINESEARCH_FAIL: return SolveStatus::LineSearchFailure;
+      default: return SolveStatus::NotPositiveDefinite;
+    }
+  }
+
+  ErrorCodes GetState(a_float* x, int k) const {
+    if (k < 0 || k > prob_->N) return ErrorCodes::BadIndex;
+    std::memcpy(x, &X_[(size_t)k * prob_->n], sizeof(double) * prob_->n);
+    return ErrorCodes::NoError;
+  }
+  ErrorCodes GetInput(a_float* u, int k) const {
+    if (k < 0 || k >= prob_->N) return ErrorCodes::BadIndex;
+    std::memcpy(u, &U_[(size_t)k * prob_->m], sizeof(double) * prob_->m);
+    return ErrorCodes::NoError;
+  }
+  int GetHorizonLength() const { return prob_->N; }
+  int GetStateDim(int = 0) const { return prob_->n; }
+  int GetInputDim(int = 0) const { return prob_->m; }
+  a_float GetTimeStep(int = 0) const { return prob_->h; }
+  int GetIterations() const { return solved_ ? res_.iterations : 0; }
+  a_float GetFinalObjective() const { return solved_ ? res_.cost : 0.0; }
+  a_float GetPrimalFeasibility() const { return solved_ ? res_.max_violation : 0.0; }
+
+ private:
+  struct ConBlock {
+    ConstraintFunction con;
+    ConstraintJacobian jac;
+    std::string label;
+  };
+
+  // [k_start, k_stop): 0 = the single knot k_start, LastIndex = through the terminal knot N
+  bool range(int k_start, int k_stop, int& a, int& b) const {
+    const int N = prob_->N;
+    if (k_start == AllIndices) { a = 0; b = N + 1; return true; }
+    if (k_start == LastIndex) k_start = N;
+    a = k_start;
+    b = (k_stop == LastIndex) ? N + 1 : (k_stop == 0 ? k_start + 1 : k_stop);
+    return a >= 0 && a <= N && b > a && b <= N + 1;
+  }
+
+  ErrorCodes set_cost(int n, int m, const a_float* Qd, const a_float* Rd, double w, const a_float* xref,
+                      const a_float* uref, int k_start, int k_stop) {
+    if (!prob_->n) return ErrorCodes::DimensionUnknown;
+    if (n != prob_->n || m != prob_->m) return ErrorCodes::DimensionMismatch;
+    int a, b;
+    if (!range(k_start, k_stop, a, b)) return ErrorCodes::BadIndex;
+    for (int k = a; k < b; ++k) {
+      std::memcpy(prob_->Q[k], Qd, sizeof(double) * n);
+      std::memcpy(prob_->xref[k], xref, sizeof(double) * n);
+      std::memcpy(prob_->R[k], Rd, sizeof(double) * m);
+      std::memcpy(prob_->uref[k], uref, sizeof(double) * m);
+      prob_->w[k] = w;
+    }
+    return ErrorCodes::NoError;
+  }
+
+  static void dyn_tramp(void* ctx, int, double* xn, const double* x, const double* u, float h) {
+    static_cast<ALTROSolver*>(ctx)->dyn_(xn, x, u, h);
+  }
+  static void jac_tramp(void* ctx, int, double* J, const double* x, const double* u, float h) {
+    static_cast<ALTROSolver*>(ctx)->jac_(J, x, u, h);
+  }
+  static void con_tramp(void* ctx, int, double* c, const double* x, const double* u) {
+    static_cast<ConBlock*>(ctx)->con(c, x, u);
+  }
+  static void conjac_tramp(void* ctx, int, double* J, const double* x, const double* u) {
+    static_cast<ConBlock*>(ctx)->jac(J, x, u);
+  }
+
+  std::unique_ptr<qo_problem> prob_;
+  ExplicitDynamicsFunction dyn_;
+  ExplicitDynamicsJacobian jac_;
+  std::vector<std::unique_ptr<ConBlock>> cons_;
+  std::vector<double> X_, U_;
+  AltroOptions opts_;
+  qo_result res_{};
+  bool have_h_ = false, initialized_ = false, solved_ = false;
+};
+
+}  // namespace altro

@@ -1,0 +1,75 @@
+"""The reference solver's C++ call surface over the CPU restatement (oracle/altro_compat.hpp).
+
+oracle/altro_compat_check.cpp poses the reference's generic solver tests through that API; the expectations are
+the ones those tests state:
+  TestDoubleIntegrator.cpp:129-167  unconstrained, iterations_max = 3: Success, closer to the goal than x0, not within 1e-3
+  TestDoubleIntegrator.cpp:242-255  goal constraint: Success, |x_N| < 1e-4, GetIterations() == 3
+  TestDoubleIntegrator.cpp:353-374  control bounds: Success, |x_N| < 1e-4, u_0 = -u_bnd to 1e-4, GetIterations() == 5
+  TestPendulum.cpp:194-202          terminal goal: Success, |x_N - x_f| < 1e-4, GetIterations() <= 10
+CPU only (test infrastructure)."""
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ORACLE = Path(__file__).resolve().parents[1] / "oracle"
+
+
+@pytest.fixture(scope="module")
+def cases():
+    subprocess.run(["make", "-C", str(ORACLE), "altro_compat_check"], check=True, capture_output=True)
+    out = subprocess.run([str(ORACLE / "altro_compat_check")], check=True, capture_output=True, text=True).stdout
+    res = {}
+    for line in out.splitlines():
+        name, *kv = line.split()
+        res[name] = {k: float(v) for k, v in (item.split("=") for item in kv)}
+    return res
+
+
+def test_double_integrator_unconstrained(cases):
+    c = cases["di_unconstrained"]
+    assert c["bad"] == 0 and c["initialized"] == 1 and c["status"] == 0          # every call NoError, Success
+    assert c["cost0"] == 27.5                                                     # 0.5 x0'Qx0 over 11 knots
+    assert c["cost"] < c["cost0"] and 1e-3 < c["dist"] < c["dist0"]
+
+
+def test_double_integrator_goal_constraint(cases):
+    c = cases["di_goal"]
+    assert c["bad"] == 0 and c["status"] == 0 and c["dist"] < 1e-4 and c["iterations"] == 3
+    assert c["feas"] < 1e-4
+
+
+def test_double_integrator_control_bounds(cases):
+    c = cases["di_bounds"]
+    assert c["bad"] == 0 and c["status"] == 0 and c["dist"] < 1e-4 and c["iterations"] == 5
+    assert abs(c["u0"] + 1.0) < 1e-4 and abs(c["u1"] + 1.0) < 1e-4
+    assert c["ncon_idx"] == 10                                                    # one index per knot of [0, N)
+
+
+def test_pendulum_goal_constraint(cases):
+    c = cases["pendulum_goal"]
+    assert c["bad"] == 0 and c["status"] == 0 and c["dist"] < 1e-4 and c["iterations"] <= 10
+
+
+def test_error_codes(cases):
+    c = cases["api_errors"]
+    # DimensionUnknown, SolverNotInitialized, DimensionMismatch, BadIndex, NotSupported (second-order cone), DimensionUnknown
+    assert [c[k] for k in ("e1", "e2", "e3", "e4", "e5", "e6")] == [1, 4, 3, 2, 7, 1]
+    assert c["unsolved"] == 1                                                     # Solve() before Initialize()
+
+
+def test_quatmpc_call_pattern_reproduces_the_golden_forces(cases):
+    """QuatMpc.cpp:179-265 written against the API (quaternion cost per knot, 24-row INEQUALITY block, error-state
+    Jacobians, X = x_ref / U = u_ref guess) on the stand-pose problem of TestAltroQuatMpc.cpp: u_0 against the
+    reference's own output (tests/golden/quat_mpc_test.json, input_trajectory[0])."""
+    import json
+
+    import numpy as np
+
+    gold = np.array(json.loads((ORACLE.parent / "tests" / "golden" / "quat_mpc_test.json").read_text())["input_trajectory"][0])
+    for name, tol in (("quatmpc_stand", 5e-4), ("quatmpc_stand_tight", 1e-5)):
+        c = cases[name]
+        u0 = np.array([c[f"u{j}"] for j in range(12)])
+        assert c["bad"] == 0 and c["status"] == 0 and c["feas"] == 0.0
+        assert np.abs(u0 - gold).max() < tol, (name, np.abs(u0 - gold).max())
+    assert cases["quatmpc_stand"]["iterations"] <= 10          # opts.iterations_max of QuatMpc.cpp:22
