@@ -614,3 +614,71 @@ def test_bench_line_contract(pkg, lib):
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
     assert cb["force_linf_instances"] == 256 and cb["force_linf_gpu_vs_cpu"] < 1e-6      # the stated tolerance
     assert d["two_in_flight"]["outputs_identical"] is True and d["config"]["converged"] == 256
+
+
+def test_randomised_parameter_sets_match_oracle(pkg, lib, oracle):
+    """Friction, force limit, weights, mass, knot spacing, horizon and the angular-velocity quirk drawn at random
+    (8 sets x 64 states): the GPU path follows the oracle for every set, not just the YAML values."""
+    rng = np.random.default_rng(77)
+    worst = 0.0
+    for t in range(8):
+        N = int(rng.choice([6, 10, 14, 20]))
+        p = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
+        p.mu = float(rng.uniform(0.3, 1.0))
+        p.fz_max = float(rng.uniform(60, 300))
+        p.w = float(rng.uniform(1, 100))
+        p.mass = float(rng.uniform(9, 16))
+        for i in range(13):
+            p.q_weights[i] = float(p.q_weights[i] * rng.uniform(0.3, 3.0))
+        for i in range(12):
+            p.r_weights[i] = float(10 ** rng.uniform(-6.5, -4))
+        p.drop_ang_vel = int(t % 2)
+        hs = float(rng.choice([0.005, 0.01]))
+        p.h, p.h_ref = hs, hs
+        rec = pkg.random_go1_trot_states(64, config_id=40 + t)
+        s = pkg.Solver(p, 64, device=0, lib=lib)
+        f, info = s.solve(rec)
+        fo, io = oracle.solve(p, rec, threads=8)
+        s.close()
+        assert (io["status"] == 0).all() and (info["status"] == 0).all(), (t, np.unique(info["status"]), np.unique(io["status"]))
+        err = np.abs(f - fo).max()
+        worst = max(worst, err)
+        assert err < 1e-6, (t, N, err)
+        assert (f.reshape(-1, 4, 3)[rec["contacts"] == 0] == 0).all()
+    assert worst < 1e-6
+
+
+def test_randomised_parameter_sets_convex_and_biped(pkg, lib, oracle):
+    """The same for the other two models on the core: ConvexMpc (Euler-angle SRBD) and the 8-contact-point problem."""
+    rng = np.random.default_rng(78)
+    for t in range(4):
+        N = int(rng.choice([8, 12, 20]))
+        p = pkg.default_convex_params(N, pkg.MODE_CONVERGED, lib)
+        p.mu = float(rng.uniform(0.3, 1.0))
+        p.fz_max = float(rng.uniform(80, 300))
+        p.mass = float(rng.uniform(10, 15))
+        for i in range(12):
+            p.q_weights[i] = float(p.q_weights[i] * rng.uniform(0.5, 2.0))
+            p.r_weights[i] = float(p.r_weights[i] * rng.uniform(0.5, 2.0))
+        rec = pkg.random_go1_convex_states(64, config_id=50 + t)
+        s = pkg.Solver(p, 64, device=0, lib=lib)
+        f, info = s.convex_solve(rec)
+        fo, io = oracle.convex_solve(p, rec, threads=8)
+        s.close()
+        assert (io["status"] == 0).all() and (info["status"] == 0).all(), (t, np.unique(info["status"]), np.unique(io["status"]))
+        assert np.abs(f - fo).max() < 1e-6, (t, N, np.abs(f - fo).max())
+    for t in range(3):
+        N = int(rng.choice([6, 10, 16]))
+        p = pkg.default_biped8_params(N, pkg.MODE_CONVERGED, lib)
+        p.mu = float(rng.uniform(0.4, 1.0))
+        p.fz_max = float(p.fz_max * rng.uniform(0.7, 1.5))
+        p.w = float(rng.uniform(5, 80))
+        rec = pkg.random_biped8_states(48, config_id=60 + t)
+        s = pkg.Solver(p, 48, device=0, lib=lib)
+        f, info = s.solve8(rec)
+        fo, io = oracle.solve8(p, rec, threads=8)
+        s.close()
+        assert (io["status"] == 0).all() and (info["status"] == 0).all(), (t, np.unique(info["status"]), np.unique(io["status"]))
+        feet = rec["foot_pos_body"].reshape(-1, 8, 3)
+        wr = lambda F: np.concatenate([F.reshape(-1, 8, 3).sum(1), np.cross(feet, F.reshape(-1, 8, 3)).sum(1)], axis=1)
+        assert np.abs(wr(f) - wr(fo)).max() < 1e-6 and np.abs(f - fo).max() < 1e-4, (t, N)
