@@ -329,6 +329,17 @@ def main():
             out["config"]["force_linf_vs_cpu"] = float(np.abs(d_f.cpu().numpy()[idx] - fo).max())
         if world == 1 and not args.no_in_flight:
             out["two_in_flight"] = two_in_flight(pkg, lib, params, args, d_in, NU)
+            # the drop-in entry point as the controller calls it: HOST buffers, H2D + kernel + D2H, blocking
+            # (SURVEY 8d quotes this beside the resident figure; never `value`)
+            hsolve = solver.solve8 if biped else (solver.convex_solve if convex else solver.solve)
+            hsolve(rec)
+            reps = max(3, min(20, args.steps))
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                hsolve(rec)
+            dt = time.perf_counter() - t0
+            out["host_buffer_call"] = {"value": B * reps / dt, "unit": "solves/s", "ms_per_call": 1e3 * dt / reps,
+                                       "note": "qmpc_solve with host buffers (PCIe both ways + kernel, blocking)"}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(pkg, N, config_id, model=args.model)
             f_cpu = cb.pop("_forces")

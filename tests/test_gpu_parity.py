@@ -604,7 +604,7 @@ def test_bench_line_contract(pkg, lib):
     assert len(lines) == 1
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "two_in_flight"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "two_in_flight", "host_buffer_call"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 / (256 * 4) * 4 - 1.0) < 1e-6
