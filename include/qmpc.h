@@ -56,7 +56,8 @@ typedef enum qmpc_status {
   QMPC_BAD_ARGUMENT = 16,
   QMPC_NO_DEVICE = 17,      /* HIP runtime / device missing: fail loudly       */
   QMPC_HIP_ERROR = 18,
-  QMPC_BATCH_TOO_LARGE = 19
+  QMPC_BATCH_TOO_LARGE = 19,
+  QMPC_UNSUPPORTED = 20     /* optional dependency missing (RCCL for qmpc_gather)  */
 } qmpc_status;
 
 /* ---- solver mode --------------------------------------------------------- */
@@ -219,6 +220,21 @@ qmpc_status qmpc_solve_traj(qmpc_handle* h, int32_t batch, const qmpc_input* in,
 qmpc_status qmpc_solve_device(qmpc_handle* h, int32_t batch, const qmpc_input* d_in,
                               double* d_forces_body, qmpc_info* d_info, void* stream);
 qmpc_status qmpc_wait(qmpc_handle* h);
+
+/* Host buffers, NOT blocking: H2D copy, kernel and D2H copies are queued on the handle's stream and the call
+ * returns; qmpc_wait(h) completes them.  `in`, `forces_body` and `info` must stay valid until then (pinned
+ * host memory makes the copies truly asynchronous).  Lets the caller of the controller thread (Main.cpp:103-118)
+ * do other work during the solve. */
+qmpc_status qmpc_solve_async(qmpc_handle* h, int32_t batch, const qmpc_input* in,
+                             double* forces_body, qmpc_info* info);
+
+/* Multi-GPU: the single collective of the path.  All-gathers `count` doubles per rank (e.g. the
+ * [B/G][12] force block, or forces + qmpc_info records laid out in one buffer) from every rank's `d_local` into
+ * `d_all` ([ranks * count], rank order) with RCCL's ncclAllGather on `stream` (NULL = the handle's stream),
+ * stream-ordered after the solve that produced `d_local`.  `nccl_comm` is the caller's ncclComm_t (one per GPU /
+ * process, created by the host program).  RCCL is looked up at run time; QMPC_UNSUPPORTED when it is absent. */
+qmpc_status qmpc_gather(qmpc_handle* h, void* nccl_comm, const double* d_local, int64_t count,
+                        double* d_all, void* stream);
 
 /* Time (ms, HIP events on the launch stream) of the most recent
  * qmpc_solve_device / qmpc_solve kernel, after it completed. */

@@ -26,7 +26,7 @@ NX, NE, NU, NLEG, NC = 13, 12, 12, 4, 24
 
 # status codes (include/qmpc.h)
 OK, MAX_ITER, NO_CONTACT, NAN_INPUT, LINESEARCH_FAIL, NOT_PD = 0, 1, 2, 3, 4, 5
-BAD_ARGUMENT, NO_DEVICE, HIP_ERROR, BATCH_TOO_LARGE = 16, 17, 18, 19
+BAD_ARGUMENT, NO_DEVICE, HIP_ERROR, BATCH_TOO_LARGE, UNSUPPORTED = 16, 17, 18, 19, 20
 MODE_CONVERGED, MODE_REFERENCE = 0, 1
 MODEL_QUAT, MODEL_CONVEX, MODEL_QUAT8 = 0, 1, 2
 
@@ -191,6 +191,10 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.qmpc_solve_device.restype = i32
     lib.qmpc_wait.argtypes = [vp]
     lib.qmpc_wait.restype = i32
+    lib.qmpc_solve_async.argtypes = [vp, i32, vp, vp, vp]
+    lib.qmpc_solve_async.restype = i32
+    lib.qmpc_gather.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
+    lib.qmpc_gather.restype = i32
     lib.qmpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.qmpc_last_kernel_ms.restype = i32
     lib.qmpc_linearize.argtypes = [vp, i32, vp, vp, vp, vp]
@@ -257,6 +261,8 @@ EXPORTED_SYMBOLS = (
     "qmpc_solve_traj",
     "qmpc_solve_device",
     "qmpc_wait",
+    "qmpc_solve_async",
+    "qmpc_gather",
     "qmpc_last_kernel_ms",
     "qmpc_linearize",
     "qmpc_selftest_mtm",
@@ -364,6 +370,21 @@ class Solver:
                                         C.c_void_p(stream) if stream else None)
         if st != OK:
             raise QmpcError(st, "qmpc_solve_device")
+
+    def solve_async(self, inputs: np.ndarray, forces: np.ndarray, info: np.ndarray = None):
+        """Host buffers, non-blocking (qmpc_solve_async); the arrays must stay alive until wait()."""
+        assert inputs.dtype == INPUT_DTYPE and inputs.flags.c_contiguous and forces.flags.c_contiguous
+        st = self.lib.qmpc_solve_async(self._h, inputs.shape[0], _ptr(inputs), _ptr(forces),
+                                       _ptr(info) if info is not None else None)
+        if st != OK:
+            raise QmpcError(st, "qmpc_solve_async")
+
+    def gather(self, nccl_comm: int, d_local: int, count: int, d_all: int, stream: int = 0):
+        """ncclAllGather of `count` doubles per rank (qmpc_gather); nccl_comm is the caller's ncclComm_t."""
+        st = self.lib.qmpc_gather(self._h, C.c_void_p(nccl_comm), C.c_void_p(d_local), int(count),
+                                  C.c_void_p(d_all), C.c_void_p(stream) if stream else None)
+        if st != OK:
+            raise QmpcError(st, "qmpc_gather")
 
     def wait(self):
         st = self.lib.qmpc_wait(self._h)

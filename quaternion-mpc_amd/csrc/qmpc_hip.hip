@@ -8,6 +8,8 @@
 // QMPC_NO_DEVICE.
 #include "qmpc_kernels.hip"
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -71,6 +73,7 @@ const char* qmpc_status_string(int32_t s) {
     case QMPC_NO_DEVICE: return "no HIP device (there is no CPU fallback)";
     case QMPC_HIP_ERROR: return "HIP runtime error";
     case QMPC_BATCH_TOO_LARGE: return "batch exceeds the handle's capacity";
+    case QMPC_UNSUPPORTED: return "optional dependency not available";
     default: return "unknown status";
   }
 }
@@ -380,7 +383,8 @@ qmpc_status qmpc_last_kernel_ms(qmpc_handle* h, float* ms) {
 
 // host-buffer solve shared by both models (nx = doubles per state in traj_x)
 static qmpc_status solve_host(qmpc_handle* h, int32_t batch, const qmpc_input* in, double* forces_body,
-                              qmpc_info* info, double* traj_u, double* traj_x, int model, int nx) {
+                              qmpc_info* info, double* traj_u, double* traj_x, int model, int nx,
+                              bool blocking = true) {
   if (!h || batch < 0 || (batch > 0 && (!in || !forces_body))) return QMPC_BAD_ARGUMENT;
   if (h->params.model != model) return QMPC_BAD_ARGUMENT;
   if (batch == 0) return QMPC_OK;
@@ -399,8 +403,13 @@ static qmpc_status solve_host(qmpc_handle* h, int32_t batch, const qmpc_input* i
   if (info) HIP_TRY(hipMemcpyAsync(info, h->d_info, sizeof(qmpc_info) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   if (traj_u) HIP_TRY(hipMemcpyAsync(traj_u, h->d_traj_u, sizeof(double) * nu * N * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   if (traj_x) HIP_TRY(hipMemcpyAsync(traj_x, h->d_traj_x, sizeof(double) * nx * (N + 1) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (blocking) HIP_TRY(hipStreamSynchronize(h->stream));
   return QMPC_OK;
+}
+
+// non-blocking host-buffer call: copies and kernel are queued on the handle's stream; qmpc_wait completes them
+qmpc_status qmpc_solve_async(qmpc_handle* h, int32_t batch, const qmpc_input* in, double* forces_body, qmpc_info* info) {
+  return solve_host(h, batch, in, forces_body, info, nullptr, nullptr, QMPC_MODEL_QUAT, 13, false);
 }
 
 qmpc_status qmpc_solve_traj(qmpc_handle* h, int32_t batch, const qmpc_input* in, double* forces_body,
@@ -467,6 +476,47 @@ qmpc_status qmpc_linearize(qmpc_handle* h, int32_t batch, const qmpc_input* in, 
 qmpc_status qmpc_convex_linearize(qmpc_handle* h, int32_t batch, const qmpc_convex_input* in, double* A, double* B,
                                   double* X) {
   return linearize_host(h, batch, reinterpret_cast<const qmpc_input*>(in), A, B, X, QMPC_MODEL_CONVEX, 12);
+}
+
+// ---- multi-GPU: the one collective of the path --------------------------------
+// RCCL is resolved at run time (dlopen), so the library carries no link-time dependency on it and a
+// single-GPU user never loads it.  ncclAllGather(sendbuff, recvbuff, sendcount, datatype, comm, stream);
+// ncclFloat64 = 8 in nccl.h.
+typedef int (*nccl_all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+static nccl_all_gather_fn resolve_all_gather() {
+  static nccl_all_gather_fn fn = nullptr;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");          // already in the process (e.g. under torch)?
+    if (!sym) {
+      const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+      for (const char* n : names) {
+        void* lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (lib && (sym = dlsym(lib, "ncclAllGather"))) break;
+      }
+    }
+    fn = reinterpret_cast<nccl_all_gather_fn>(sym);
+  }
+  return fn;
+}
+
+qmpc_status qmpc_gather(qmpc_handle* h, void* nccl_comm, const double* d_local, int64_t count, double* d_all,
+                        void* stream) {
+  if (!h || !nccl_comm || count < 0 || (count > 0 && (!d_local || !d_all))) return QMPC_BAD_ARGUMENT;
+  if (count == 0) return QMPC_OK;
+  nccl_all_gather_fn fn = resolve_all_gather();
+  if (!fn) {
+    std::fprintf(stderr, "qmpc_gather: RCCL (ncclAllGather) not found\n");
+    return QMPC_UNSUPPORTED;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  const int rc = fn(d_local, d_all, (size_t)count, /*ncclFloat64*/ 8, nccl_comm, stream ? (hipStream_t)stream : h->stream);
+  if (rc != 0) {
+    std::fprintf(stderr, "qmpc_gather: ncclAllGather failed (%d)\n", rc);
+    return QMPC_HIP_ERROR;
+  }
+  return QMPC_OK;
 }
 
 // ---- leg kinematics / torque map (BaseInterface.cpp:10-34,209-212,343-408) ----------------

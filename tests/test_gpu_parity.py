@@ -682,3 +682,49 @@ def test_randomised_parameter_sets_convex_and_biped(pkg, lib, oracle):
         feet = rec["foot_pos_body"].reshape(-1, 8, 3)
         wr = lambda F: np.concatenate([F.reshape(-1, 8, 3).sum(1), np.cross(feet, F.reshape(-1, 8, 3)).sum(1)], axis=1)
         assert np.abs(wr(f) - wr(fo)).max() < 1e-6 and np.abs(f - fo).max() < 1e-4, (t, N)
+
+
+def test_async_host_call_and_rccl_gather(pkg, lib):
+    """qmpc_solve_async + qmpc_wait equal the blocking call; qmpc_gather (ncclAllGather through the C ABI) on a
+    one-rank RCCL communicator returns the local block (the multi-rank path runs in the driver's 8-GPU bench)."""
+    import torch
+
+    p, s = _solver(pkg, lib, 10, cap=512)
+    rec = pkg.random_go1_trot_states(512, config_id=2)
+    f_ref, i_ref = s.solve(rec)
+    f = np.zeros((512, 12)); info = np.zeros(512, dtype=pkg.INFO_DTYPE)
+    s.solve_async(rec, f, info)
+    s.wait()
+    assert np.array_equal(f, f_ref) and np.array_equal(info["iterations"], i_ref["iterations"])
+    # one-rank communicator straight from librccl
+    rccl = None
+    for name in ("librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"):
+        try:
+            rccl = C.CDLL(name, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("no librccl on this box")
+    uid = (C.c_char * 128)()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+
+    class _Uid(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _Uid, C.c_int]
+    u = _Uid()
+    C.memmove(C.byref(u), uid, 128)
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, u, 0) == 0
+    d_local = torch.from_numpy(f_ref).cuda()
+    d_all = torch.zeros_like(d_local)
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    s.gather(comm.value, d_local.data_ptr(), d_local.numel(), d_all.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    assert torch.equal(d_all, d_local)
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
+    s.close()
