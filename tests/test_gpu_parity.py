@@ -728,3 +728,26 @@ def test_async_host_call_and_rccl_gather(pkg, lib):
     rccl.ncclCommDestroy.argtypes = [C.c_void_p]
     rccl.ncclCommDestroy(comm)
     s.close()
+
+
+@pytest.mark.parametrize("name,gen,dp,solve,N,cfg", [
+    ("quat_n10", "random_go1_trot_states", "default_params", "solve", 10, 2),
+    ("quat_n20", "random_go1_trot_states", "default_params", "solve", 20, 3),
+    ("convex_n20", "random_go1_convex_states", "default_convex_params", "convex_solve", 20, 13),
+    ("biped8_n16", "random_biped8_states", "default_biped8_params", "solve8", 16, 5)])
+def test_gpu_against_committed_oracle_fixture(pkg, lib, name, gen, dp, solve, N, cfg):
+    """The HIP path against the COMMITTED answers of the oracle (tests/golden/oracle_regimes.npz), without
+    running the oracle: the regimes the reference's goldens do not cover."""
+    fx = np.load(Path(__file__).parent / "golden" / "oracle_regimes.npz")
+    want = fx[name + "_forces"]
+    rec = getattr(pkg, gen)(len(want), config_id=cfg)
+    s = pkg.Solver(getattr(pkg, dp)(N, pkg.MODE_CONVERGED, lib), len(want), device=0, lib=lib)
+    f, info = getattr(s, solve)(rec)
+    s.close()
+    assert (info["status"] == 0).all()
+    if name.startswith("biped8"):      # corner forces of a foot are fixed only by R = 1e-6: compare foot wrenches
+        feet = rec["foot_pos_body"].reshape(-1, 8, 3)
+        wr = lambda F: np.concatenate([F.reshape(-1, 8, 3).sum(1), np.cross(feet, F.reshape(-1, 8, 3)).sum(1)], axis=1)
+        assert np.abs(wr(f) - wr(want)).max() < 1e-6 and np.abs(f - want).max() < 1e-4
+    else:
+        assert np.abs(f - want).max() < 1e-6

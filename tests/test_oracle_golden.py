@@ -214,3 +214,23 @@ def test_kat_pendulum_goal_constrained(oracle):
     assert status == 0
     assert dist < 1e-4          # :201
     assert it <= 10             # :202
+
+
+# ---- regimes no reference golden covers: the oracle's own frozen answers ---------------------
+REGIMES = (("quat_n10", "random_go1_trot_states", "default_params", "solve", 10, 2),
+           ("quat_n20", "random_go1_trot_states", "default_params", "solve", 20, 3),
+           ("convex_n20", "random_go1_convex_states", "default_convex_params", "convex_solve", 20, 13),
+           ("biped8_n16", "random_biped8_states", "default_biped8_params", "solve8", 16, 5))
+
+
+@pytest.mark.parametrize("name,gen,dp,solve,N,cfg", REGIMES)
+def test_oracle_reproduces_its_frozen_answers(oracle, pkg, name, gen, dp, solve, N, cfg):
+    """tests/golden/oracle_regimes.npz (made by tests/golden/make_oracle_fixtures.py): random attitudes, trot
+    contacts, active cone faces.  A change to oracle/ or to the state generators shows up here."""
+    fx = np.load(GOLDEN / "oracle_regimes.npz")
+    want = fx[name + "_forces"]
+    rec = getattr(pkg, gen)(len(want), config_id=cfg)
+    f, info = getattr(oracle, solve)(getattr(oracle, dp)(N, 0), rec, threads=4)
+    assert (info["status"] == 0).all()
+    assert np.abs(f - want).max() < 1e-9
+    assert np.array_equal(info["iterations"], fx[name + "_iterations"])
