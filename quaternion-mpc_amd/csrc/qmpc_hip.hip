@@ -209,8 +209,11 @@ static qmpc_status create_resources(qmpc_handle* h, int N, int nl, int nu) {
   HIP_TRY(hipMalloc(&h->d_in, sizeof(double) * (32 + 4 * nl) * (size_t)max_batch));
   HIP_TRY(hipMalloc(&h->d_forces, sizeof(double) * nu * (size_t)max_batch));
   HIP_TRY(hipMalloc(&h->d_info, sizeof(qmpc_info) * (size_t)max_batch));
+  // the attribute belongs to the kernel, not to the handle: always raise it to the CU's 160 KB so that handles
+  // with different horizons can coexist (a smaller value set by a later handle would fail the earlier one's launches)
 #define QMPC_SET_LDS(kern, bytes) \
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (bytes) <= 160 * 1024 ? 160 * 1024 : (int)(bytes)))
   if (params->model == QMPC_MODEL_QUAT8) {
     QMPC_SET_LDS((qmpc_solve_kernel<Quat8Model, false, 1>), h->lds_bytes_g);   // never everything in LDS
     QMPC_SET_LDS((qmpc_solve_kernel<Quat8Model, false, 2>), h->lds_bytes_s);

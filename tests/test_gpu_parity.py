@@ -587,7 +587,14 @@ def test_independent_handles_overlap_on_their_streams(pkg, lib):
     fresh = pkg.Solver(p2, 256, device=0, lib=lib)
     f_fresh, _ = fresh.solve(rq[:256])
     assert np.array_equal(f_live, f_fresh) and np.abs(f_live - fq_ref[:256]).max() > 1e-3
-    sq.close(); sc.close(); fresh.close()
+    # two handles of the SAME model with different horizons (the LDS attribute is per kernel, not per handle)
+    p20, s20 = _solver(pkg, lib, 20, cap=256)
+    p10, s10 = _solver(pkg, lib, 10, cap=256)          # created later, needs less LDS
+    r20 = pkg.random_go1_trot_states(256, config_id=3)
+    f20, i20 = s20.solve(r20)                           # must still launch with its larger footprint
+    f10, i10 = s10.solve(rq[:256])
+    assert (i20["status"] == 0).all() and (i10["status"] == 0).all()
+    sq.close(); sc.close(); fresh.close(); s20.close(); s10.close()
 
 
 def test_bench_line_contract(pkg, lib):
