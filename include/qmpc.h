@@ -320,9 +320,11 @@ qmpc_status qmpc_selftest_mtm(int32_t device, const double* X, const double* Y, 
  * (row-group broadcasts 0..3, wave sum / max / min, row_newbcast:5, quad_perm[1,1,1,1]). */
 qmpc_status qmpc_selftest_lanes(int32_t device, const double* in, double* out);
 /* Per-instance phase cycle counts (s_memtime) of one instrumented solve launch:
- * cycles_out [batch][16] int64 (host); slots 0..8 = set-up, expansions, operand
+ * cycles_out [batch][16] int64 (host); slots 0..14 = set-up, expansions, operand
  * build, MFMA + stage terms, stage solve, cost-to-go update, IPM directions,
- * rollout, misc; slot 15 = iterations.  Used by tools/phase_profile.py. */
+ * rollout (rest), misc, rotation pre-pass, rollout gain / broadcast / step,
+ * apply, wait for the last products; slot 15 = iterations.  Used by
+ * tools/phase_profile.py. */
 qmpc_status qmpc_debug_profile(qmpc_handle* h, int32_t batch, const qmpc_input* in, int64_t* cycles_out);
 
 /* ---- introspection -------------------------------------------------------- */

@@ -608,9 +608,9 @@ qmpc_status qmpc_torque_map(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t 
 }
 
 // Diagnostic: per-instance phase cycle counts (s_memtime) of one solve launch.
-// cycles_out: [batch][16] int64 on the host; slots 0..8 = setup, expansions,
-// operand build, MFMA + stage terms, stage solve, cost-to-go update, IPM
-// directions, rollout, misc; slot 15 = iterations.
+// cycles_out: [batch][16] int64 on the host; slots 0..14 follow the PH_* enum of qmpc_kernels.hip (setup, expansions,
+// operand build, MFMA + stage terms, stage solve, cost-to-go update, directions, rollout, misc, rotation pre-pass,
+// rollout gain / broadcast / step, apply, MFMA drain); slot 15 = iterations.
 qmpc_status qmpc_debug_profile(qmpc_handle* h, int32_t batch, const qmpc_input* in, int64_t* cycles_out) {
   if (!h || batch < 1 || !in || !cycles_out) return QMPC_BAD_ARGUMENT;
   if (h->params.model != QMPC_MODEL_QUAT) return QMPC_BAD_ARGUMENT;
