@@ -95,7 +95,15 @@ def two_in_flight(pkg, lib, params, args, d_in, NU):
     import torch
     B = args.batch
     biped, convex = args.model == "biped8", args.model == "convex"
-    solvers = [pkg.Solver(params, B, device=torch.cuda.current_device(), lib=lib) for _ in range(2)]
+    # gains in the workspace (19 KB of LDS per instance at N=10): both batches are resident from the start
+    prev = os.environ.get("QMPC_VARIANT")
+    if prev is None and B <= 1024 and not biped:   # the 8-point model already picks its workspace variant
+        os.environ["QMPC_VARIANT"] = "2"           # read by qmpc_create
+    try:
+        solvers = [pkg.Solver(params, B, device=torch.cuda.current_device(), lib=lib) for _ in range(2)]
+    finally:
+        if prev is None:
+            os.environ.pop("QMPC_VARIANT", None)
     streams = [torch.cuda.Stream() for _ in range(2)]
     outs = [torch.zeros(B, NU, dtype=torch.float64, device="cuda") for _ in range(2)]
     infos = [torch.zeros(B, pkg.INFO_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in range(2)]
@@ -117,7 +125,8 @@ def two_in_flight(pkg, lib, params, args, d_in, NU):
         sv.close()
     return {"value": B * args.steps / dt, "unit": "solves/s", "ms_per_step": 1e3 * dt / args.steps, "steps": args.steps,
             "outputs_identical": same,
-            "note": "secondary: consecutive independent batches on two streams (two handles); not the contract value"}
+            "note": "secondary: consecutive independent batches on two streams (two handles, gains in the workspace "
+                    "so that both batches are resident); not the contract value"}
 
 
 def main():
