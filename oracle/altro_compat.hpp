@@ -8,9 +8,9 @@
 // Index conventions (from the reference's own call sites): [k_start, k_stop) with k_stop
 // exclusive; k_stop == 0 means the single knot k_start; LastIndex means "through the terminal knot".
 // Supported: one (n, m) and one time step for all knots, one explicit dynamics function, diagonal LQR and
-// quaternion costs per knot, EQUALITY / INEQUALITY constraints (at most QO_MAXCON blocks), AltroOptions
-// fields the reference sets.  Not supported (ErrorCodes::NotSupported): SECOND_ORDER_CONE constraints,
-// generic cost functions, UpdateLinearCosts, ShiftTrajectory.
+// quaternion costs per knot, EQUALITY / INEQUALITY / SECOND_ORDER_CONE constraints (at most QO_MAXCON blocks, cones
+// of at most QO_SOC_MAXP rows), AltroOptions fields the reference sets.  Not supported: generic cost functions,
+// UpdateLinearCosts, ShiftTrajectory.
 #pragma once
 
 #include <cstring>
@@ -119,14 +119,14 @@ class ALTROSolver {
                            std::vector<ConstraintIndex>* con_inds = nullptr) {
     if (initialized_) return ErrorCodes::SolverAlreadyInitialized;
     if (!prob_->n) return ErrorCodes::DimensionUnknown;
-    if (type == ConstraintType::SECOND_ORDER_CONE) return ErrorCodes::NotSupported;
+    if (type == ConstraintType::SECOND_ORDER_CONE && (dim < 2 || dim > QO_SOC_MAXP)) return ErrorCodes::NotSupported;
     if (dim < 1 || dim > QO_MAXP) return ErrorCodes::NotSupported;
     if (prob_->ncon >= QO_MAXCON) return ErrorCodes::TooManyConstraints;
     int a, b;
     if (!range(k_start, k_stop, a, b)) return ErrorCodes::BadIndex;
     cons_.push_back(std::unique_ptr<ConBlock>(new ConBlock{std::move(con), std::move(jac), std::move(label)}));
     qo_constraint& c = prob_->con[prob_->ncon];
-    c.type = (type == ConstraintType::EQUALITY) ? QO_EQUALITY : QO_INEQUALITY;
+    c.type = (type == ConstraintType::EQUALITY) ? QO_EQUALITY : (type == ConstraintType::INEQUALITY ? QO_INEQUALITY : QO_SOC);
     c.p = dim;
     c.k_start = a;
     c.k_stop = b;

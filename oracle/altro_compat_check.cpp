@@ -210,7 +210,7 @@ void case_api_errors() {
   const int e3 = (int)s.SetInitialState(v, 3);                                // wrong size
   const int e4 = (int)s.SetTimeStep(0.1f, 11, 0);                             // knot beyond the horizon
   auto c = [](a_float*, const a_float*, const a_float*) {};
-  const int e5 = (int)s.SetConstraint(c, c, 3, ConstraintType::SECOND_ORDER_CONE, "soc", 0, 10, nullptr);
+  const int e5 = (int)s.SetConstraint(c, c, 9, ConstraintType::SECOND_ORDER_CONE, "soc", 0, 10, nullptr);   // > QO_SOC_MAXP rows
   const int e6 = (int)s.Initialize();                                         // no dynamics / time step yet
   std::printf("api_errors e1=%d e2=%d e3=%d e4=%d e5=%d e6=%d unsolved=%d\n", e1, e2, e3, e4, e5, e6, (int)s.Solve());
 }
@@ -273,6 +273,41 @@ void case_quatmpc_stand(bool tight) {
   std::printf("\n");
 }
 
+// TestDoubleIntegrator.cpp:377-492: goal constraint + |u| <= u_bnd as a second-order cone c = (u, u_bnd)
+void case_soc() {
+  DiSetup d;
+  ALTROSolver s(d.horizon);
+  const std::vector<double> x0 = {2.0, 2.0, 0.0, 0.0};
+  int bad = di_common(s, d, x0);
+  const double ub = 1.0;
+  auto goal = [](a_float* c, const a_float* x, const a_float*) { for (int i = 0; i < kN; ++i) c[i] = x[i]; };
+  auto goal_j = [](a_float* J, const a_float*, const a_float*) {
+    for (int i = 0; i < kN * (kN + kM); ++i) J[i] = 0.0;
+    for (int i = 0; i < kN; ++i) J[i + kN * i] = 1.0;
+  };
+  auto soc = [ub](a_float* c, const a_float*, const a_float* u) { c[0] = u[0]; c[1] = u[1]; c[2] = ub; };
+  auto soc_j = [](a_float* J, const a_float*, const a_float*) {            // 3 x 6 column-major
+    for (int i = 0; i < 3 * (kN + kM); ++i) J[i] = 0.0;
+    for (int i = 0; i < kM; ++i) J[i + 3 * (kN + i)] = 1.0;
+  };
+  bad += s.SetConstraint(goal, goal_j, kN, ConstraintType::EQUALITY, "goal", d.horizon, 0, nullptr) != ErrorCodes::NoError;
+  bad += s.SetConstraint(soc, soc_j, kM + 1, ConstraintType::SECOND_ORDER_CONE, "bounds", 0, d.horizon, nullptr) != ErrorCodes::NoError;
+  bad += s.Initialize() != ErrorCodes::NoError;
+  std::vector<double> u0(kM, 0.0);
+  s.SetState(x0.data(), kN, 0, LastIndex);
+  s.SetInput(u0.data(), kM, 0, LastIndex);
+  AltroOptions o;
+  o.penalty_initial = 1.0;
+  o.penalty_scaling = 100;
+  s.SetOptions(o);
+  const SolveStatus st = s.Solve();
+  std::vector<double> xN(kN), u(kM);
+  s.GetState(xN.data(), d.horizon);
+  s.GetInput(u.data(), 0);
+  std::printf("di_soc bad=%d status=%d iterations=%d dist=%.17g unorm=%.17g feas=%.17g\n", bad, (int)st, s.GetIterations(),
+              norm(xN), norm(u), s.GetPrimalFeasibility());
+}
+
 }  // namespace
 
 int main() {
@@ -281,6 +316,7 @@ int main() {
   case_bounds();
   case_pendulum_goal();
   case_api_errors();
+  case_soc();
   case_quatmpc_stand(false);
   case_quatmpc_stand(true);
   return 0;

@@ -46,6 +46,12 @@ typedef struct knot_ws {
   double kap[QO_MAXCON][QO_MAXP];  /* 1 on rows showing the weakly-active signature       */
   double ds[QO_MAXCON][QO_MAXP];
   double dlam[QO_MAXCON][QO_MAXP];
+  /* second-order-cone blocks: raw Jacobians (Jx / Ju of such a block hold rows rotated into the eigenbasis of
+   * the projection Jacobian, see soc_refresh), multiplier and curvature weights in that basis */
+  double socJx[QO_MAXCON][QO_SOC_MAXP * NE_MAX];
+  double socJu[QO_MAXCON][QO_SOC_MAXP * M_MAX];
+  double soc_zp[QO_MAXCON][QO_SOC_MAXP];
+  double soc_w[QO_MAXCON][QO_SOC_MAXP];
 } knot_ws;
 
 typedef struct solver_ws {
@@ -127,10 +133,98 @@ static double knot_cost(const qo_problem* p, int k, const double* x, const doubl
   return J;
 }
 
+
+/* ---- second-order cone K = {(v, t): |v| <= t} (self-dual) ------------------------------------
+ * Constraint c(x,u) in K.  AL term (|Proj_K(lam - rho c)|^2 - |lam|^2) / (2 rho), gradient -J' Proj_K(lam - rho c),
+ * Gauss-Newton curvature rho J' dProj J, dual update lam <- Proj_K(lam - rho c)  (conic augmented Lagrangian of
+ * Jackson, Howell et al., "ALTRO-C").  dProj is symmetric with eigenvalues 1 on (w,1)/sqrt2, (1 + t/a)/2 on the
+ * directions (e,0) with e orthogonal to w = v/|v| (a = |v|), and 0 on (w,-1)/sqrt2 when the point is outside both the
+ * cone and its polar; the identity inside the cone, zero inside the polar.  soc_refresh rotates the block's Jacobian
+ * rows into that eigenbasis, so the per-row machinery (multiplier zp, weight act) applies unchanged. */
+static void soc_project(int p, const double* z, double* out) {
+  const int nv = p - 1;
+  double a = 0.0;
+  for (int i = 0; i < nv; ++i) a += z[i] * z[i];
+  a = sqrt(a);
+  const double t = z[nv];
+  if (a <= t) { memcpy(out, z, sizeof(double) * p); return; }
+  if (a <= -t) { memset(out, 0, sizeof(double) * p); return; }
+  const double sc = 0.5 * (a + t);
+  for (int i = 0; i < nv; ++i) out[i] = sc * z[i] / a;
+  out[nv] = sc;
+}
+
+static void soc_refresh(solver_ws* ws) {
+  const qo_problem* pr = ws->prob;
+  const int ne = ws->ne, m = ws->m;
+  for (int ci = 0; ci < pr->ncon; ++ci) {
+    const qo_constraint* cn = &pr->con[ci];
+    if (cn->type != QO_SOC) continue;
+    const int p = cn->p, nv = p - 1;
+    for (int k = 0; k <= ws->N; ++k) {
+      if (!con_active_at(cn, k)) continue;
+      knot_ws* kw = &ws->kn[k];
+      double z[QO_SOC_MAXP], pz[QO_SOC_MAXP], Q[QO_SOC_MAXP * QO_SOC_MAXP], ev[QO_SOC_MAXP];
+      for (int i = 0; i < p; ++i) z[i] = kw->lam[ci][i] - ws->rho * kw->c[ci][i];
+      soc_project(p, z, pz);
+      double a = 0.0;
+      for (int i = 0; i < nv; ++i) a += z[i] * z[i];
+      a = sqrt(a);
+      const double t = z[nv];
+      /* eigenbasis (columns of Q) and eigenvalues of dProj at z */
+      memset(Q, 0, sizeof Q);
+      if (a <= t || a <= -t || a == 0.0) {
+        for (int i = 0; i < p; ++i) { Q[i * p + i] = 1.0; ev[i] = (a <= t) ? 1.0 : 0.0; }
+      } else {
+        double w[QO_SOC_MAXP];
+        for (int i = 0; i < nv; ++i) w[i] = z[i] / a;
+        const double r2 = sqrt(0.5);
+        for (int i = 0; i < nv; ++i) { Q[i * p + 0] = r2 * w[i]; Q[i * p + (p - 1)] = r2 * w[i]; }
+        Q[nv * p + 0] = r2;  Q[nv * p + (p - 1)] = -r2;
+        ev[0] = 1.0; ev[p - 1] = 0.0;
+        /* Householder reflection mapping e_1 to w: its other columns span the complement of w */
+        double hv[QO_SOC_MAXP], hn = 0.0;
+        for (int i = 0; i < nv; ++i) { hv[i] = ((i == 0) ? 1.0 : 0.0) - w[i]; hn += hv[i] * hv[i]; }
+        for (int c = 1; c < nv; ++c) {
+          for (int i = 0; i < nv; ++i) {
+            const double hic = ((i == c) ? 1.0 : 0.0) - ((hn > 0.0) ? 2.0 * hv[i] * hv[c] / hn : 0.0);
+            Q[i * p + c] = hic;
+          }
+          ev[c] = 0.5 * (1.0 + t / a);
+        }
+      }
+      /* rows in the eigenbasis: J_eff = Q' J ; multiplier zp = Q' (-Proj(z)) ; weight rho * eigenvalue */
+      for (int r = 0; r < p; ++r) {
+        for (int c = 0; c < ne; ++c) {
+          double sx = 0.0;
+          for (int i = 0; i < p; ++i) sx += Q[i * p + r] * kw->socJx[ci][i * ne + c];
+          kw->Jx[ci][r * ne + c] = sx;
+        }
+        for (int c = 0; c < m; ++c) {
+          double su = 0.0;
+          for (int i = 0; i < p; ++i) su += Q[i * p + r] * kw->socJu[ci][i * m + c];
+          kw->Ju[ci][r * m + c] = su;
+        }
+        double sz = 0.0;
+        for (int i = 0; i < p; ++i) sz += Q[i * p + r] * pz[i];
+        kw->soc_zp[ci][r] = -sz;
+        kw->soc_w[ci][r] = ws->rho * ev[r];
+      }
+    }
+  }
+}
+
 /* AL merit term of one constraint block:  (|Proj(lam + rho c)|^2 - |lam|^2) / (2 rho) */
 static double al_term(const qo_constraint* cn, int type, int pr, const double* c,
                       const double* lam, double rho) {
   double s = 0.0;
+  if (type == QO_SOC) {
+    double z[QO_SOC_MAXP], pz[QO_SOC_MAXP];
+    for (int i = 0; i < pr; ++i) z[i] = lam[i] - rho * c[i];
+    soc_project(pr, z, pz);
+    for (int i = 0; i < pr; ++i) s += pz[i] * pz[i] - lam[i] * lam[i];
+    return s / (2.0 * rho);
+  }
   for (int i = 0; i < pr; ++i) {
     if (!row_on(cn, i)) continue;
     double z = lam[i] + rho * c[i];
@@ -154,6 +248,12 @@ static double total_cost(const solver_ws* ws, const double* X, const double* U, 
       if (!con_active_at(cn, k)) continue;
       cn->con(cn->ctx, k, c, x, u);
       Jal += al_term(cn, cn->type, cn->p, c, ws->kn[k].lam[ci], ws->rho);
+      if (cn->type == QO_SOC) {   /* distance of c from the cone */
+        double pc[QO_SOC_MAXP];
+        soc_project(cn->p, c, pc);
+        for (int i = 0; i < cn->p; ++i) v = fmax(v, fabs(c[i] - pc[i]));
+        continue;
+      }
       for (int i = 0; i < cn->p; ++i) {
         if (!row_on(cn, i)) continue;
         const double vi = (cn->type == QO_INEQUALITY) ? fmax(c[i], 0.0) : fabs(c[i]);
@@ -235,6 +335,10 @@ static void expansions(solver_ws* ws) {
         for (int c = 0; c < ne; ++c) kw->Jx[ci][r * ne + c] = cj[r + cn->p * c];
         for (int c = 0; c < m; ++c) kw->Ju[ci][r * m + c] = cj[r + cn->p * (ne + c)];
       }
+      if (cn->type == QO_SOC) {
+        memcpy(kw->socJx[ci], kw->Jx[ci], sizeof(double) * cn->p * ne);
+        memcpy(kw->socJu[ci], kw->Ju[ci], sizeof(double) * cn->p * m);
+      }
     }
   }
 }
@@ -246,6 +350,10 @@ static void expansions(solver_ws* ws) {
 static void al_multiplier(const solver_ws* ws, int k, int ci, double* zp, double* act) {
   const qo_constraint* cn = &ws->prob->con[ci];
   const knot_ws* kw = &ws->kn[k];
+  if (cn->type == QO_SOC) {       /* rotated rows, see soc_refresh */
+    for (int i = 0; i < cn->p; ++i) { zp[i] = kw->soc_zp[ci][i]; act[i] = kw->soc_w[ci][i]; }
+    return;
+  }
   for (int i = 0; i < cn->p; ++i) {
     if (!row_on(cn, i)) { zp[i] = 0.0; act[i] = 0.0; continue; }
     if (ws->ipm && cn->type == QO_INEQUALITY) {
@@ -314,6 +422,7 @@ static void build_rotation(const solver_ws* ws, int k, double hw[QO_MAXCON][QO_M
 
 static int backward_pass(solver_ws* ws) {
   const qo_problem* p = ws->prob;
+  soc_refresh(ws);
   const int ne = ws->ne, m = ws->m, N = ws->N;
   double P[NE_MAX * NE_MAX], pv[NE_MAX];
   double zp[QO_MAXP], act[QO_MAXP];
@@ -522,6 +631,13 @@ static double dual_update(solver_ws* ws) {
       const qo_constraint* cn = &p->con[ci];
       if (!con_active_at(cn, k)) continue;
       knot_ws* kw = &ws->kn[k];
+      if (cn->type == QO_SOC) {
+        double z[QO_SOC_MAXP], pz[QO_SOC_MAXP];
+        for (int i = 0; i < cn->p; ++i) z[i] = kw->lam[ci][i] - ws->rho * kw->c[ci][i];
+        soc_project(cn->p, z, pz);
+        for (int i = 0; i < cn->p; ++i) { dl = fmax(dl, fabs(pz[i] - kw->lam[ci][i])); kw->lam[ci][i] = pz[i]; }
+        continue;
+      }
       for (int i = 0; i < cn->p; ++i) {
         if (!row_on(cn, i)) continue;
         double z = kw->lam[ci][i] + ws->rho * kw->c[ci][i];
@@ -819,6 +935,7 @@ int qo_altro_solve(const qo_problem* prob, const qo_options* opts, double* X, do
       fprintf(stderr, "iter %2d  J=%.12e  dJ=%.3e  alpha=%.4f  step=%.3e  viol=%.3e  rho=%.1e\n",
               iter, J, dJ, alpha, step, viol, ws.rho);
     if (opts->mode == QO_MODE_REFERENCE) {
+      soc_refresh(&ws);   /* rotated rows / multipliers at the accepted point */
       const double stat = stationarity(&ws);
       r.stationarity = stat;
       if (opts->verbose) fprintf(stderr, "         stationarity=%.3e\n", stat);

@@ -28,7 +28,10 @@ extern "C" {
 #define QO_MAXH 64   /* horizon       */
 #define QO_MAXCON 4
 
-enum { QO_EQUALITY = 0, QO_INEQUALITY = 1 };
+enum { QO_EQUALITY = 0, QO_INEQUALITY = 1,
+       QO_SOC = 2 /* c(x,u) = (v, t) in the second-order cone |v| <= t; reference (AL) mode only,
+                     at most QO_SOC_MAXP rows */ };
+#define QO_SOC_MAXP 8
 enum { QO_MODE_CONVERGED = 0, QO_MODE_REFERENCE = 1 };
 enum {
   QO_STATUS_OK = 0,
