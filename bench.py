@@ -41,6 +41,16 @@ def load_pkg():
     return mod
 
 
+def flush_c_stdio():
+    """RCCL prints its version banner through C stdio (NCCL_DEBUG=VERSION on the GPU boxes), which sits in the C
+    buffer until exit when stdout is a pipe: push it out now, so that the JSON line is the last line of stdout."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def usable_cores() -> int:
     """Host threads this process may actually run on: CPU affinity capped by the cgroup CPU quota
     (the GPU box shows 256 logical CPUs but grants 16 CPUs of quota; oversubscribing it is slower)."""
@@ -252,6 +262,7 @@ def main():
     if world > 1:
         dist.barrier()
     sync()
+    flush_c_stdio()
     if not selftest:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -356,6 +367,8 @@ def main():
             cb["force_linf_gpu_vs_cpu"] = float(np.abs(d_f.cpu().numpy()[:m] - f_cpu[:m]).max())
             cb["force_linf_instances"] = m
             out["cpu_baseline"] = cb
+        flush_c_stdio()
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
     solver.close()
     if world > 1:
