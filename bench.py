@@ -154,6 +154,9 @@ def main():
     ap.add_argument("--no-in-flight", action="store_true",
                     help="skip the secondary measurement with two batches in flight (N=1 only)")
     ap.add_argument("--check", action="store_true", help="also compare a sample against the oracle")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="DIAGNOSTIC: run the multi-rank code path (process group, async all_gather per step, barriers) "
+                         "even with one rank, to exercise the RCCL calls on a single GPU")
     ap.add_argument("--selftest-gloo", action="store_true",
                     help="TEST ONLY: run the multi-rank pipeline (sharding, double buffering, async gather) on CPU "
                          "tensors over gloo with the CPU oracle standing in for the kernel; prints no metric")
@@ -171,13 +174,14 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(2)
     selftest = args.selftest_gloo
+    multi = world > 1 or args.force_dist        # the collective path is on
     if not selftest and not torch.cuda.is_available():
         print("bench.py: no GPU visible; the product path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
     dev = "cpu" if selftest else "cuda"
     if not selftest:
         torch.cuda.set_device(local)
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if selftest else "nccl", rank=rank, world_size=world)
 
@@ -233,7 +237,7 @@ def main():
     counts = [B] * world
     # double-buffered outputs: the gather of step i (RCCL's own stream) overlaps the solve of
     # step i+1 (launch stream); one collective per step, never on the solve's critical path
-    gathered = [torch.zeros(world, B * (NU + IW), dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    gathered = [torch.zeros(world, B * (NU + IW), dtype=torch.float64, device=dev) for _ in range(2)] if multi else None
     pending = [None, None]
 
     def step(i):
@@ -242,7 +246,7 @@ def main():
             pending[buf].wait()
             pending[buf] = None
         launch(blocks[buf])
-        if world > 1:
+        if multi:
             pending[buf] = dist.all_gather_into_tensor(gathered[buf].view(-1), blocks[buf], async_op=True)
 
     def drain():
@@ -259,7 +263,7 @@ def main():
         step(i)
     drain()
     sync()
-    if world > 1:
+    if multi:
         dist.barrier()
     sync()
     flush_c_stdio()
@@ -274,11 +278,11 @@ def main():
         ev1.record(stream)
     drain()
     sync()
-    if world > 1:
+    if multi:
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -286,25 +290,25 @@ def main():
     kernel_ms = (ev0.elapsed_time(ev1) / args.steps) if not selftest else float("nan")
     last = blocks[(args.steps - 1) & 1]
     d_f = forces_of(last)
-    if world > 1:
+    if multi:
         # every rank holds every rank's forces and status: check the gathered block against the local one
         g = gathered[(args.steps - 1) & 1]
         assert torch.equal(g[rank], last), "gathered block differs from the local shard"
     if selftest:
         ok = True
-        if world > 1:
+        if multi:
             from oracle import pyoracle
             full, _ = oracle_solve(pyoracle, gen(world * B, config_id=config_id))
             gf = gathered[(args.steps - 1) & 1][:, :B * NU].reshape(world * B, NU)
             ok = bool(np.array_equal(gf.numpy(), full))
         if rank == 0:
             print(json.dumps({"selftest": "gloo", "n_ranks": world, "steps": args.steps, "ok": ok}), flush=True)
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         sys.exit(0 if ok else 1)
 
     # status of EVERY rank's instances (the gathered blocks carry them); iterations of the local shard
-    all_info = (gathered[(args.steps - 1) & 1][:, B * NU:] if world > 1 else info_of(last).view(1, -1))
+    all_info = (gathered[(args.steps - 1) & 1][:, B * NU:] if multi else info_of(last).view(1, -1))
     info = np.ascontiguousarray(all_info.cpu().numpy()).view(pkg.INFO_DTYPE).reshape(world, B)
     n_ok = int((info["status"] == 0).sum())
     mean_iters = float(info["iterations"].mean())
@@ -371,7 +375,7 @@ def main():
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
     solver.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
