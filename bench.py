@@ -198,7 +198,8 @@ def main():
     # so that a single collective carries forces and status
     IW = pkg.INFO_DTYPE.itemsize // 8           # qmpc_info is 40 bytes = 5 doubles
     assert pkg.INFO_DTYPE.itemsize == 8 * IW
-    blocks = [torch.zeros(B * (NU + IW), dtype=torch.float64, device=dev) for _ in range(2)]
+    SLOTS = int(os.environ.get("QMPC_BENCH_SLOTS", "2"))   # result blocks in rotation (gather of step i drains under later solves)
+    blocks = [torch.zeros(B * (NU + IW), dtype=torch.float64, device=dev) for _ in range(SLOTS)]
 
     def forces_of(blk):
         return blk[:B * NU].view(B, NU)
@@ -237,11 +238,11 @@ def main():
     counts = [B] * world
     # double-buffered outputs: the gather of step i (RCCL's own stream) overlaps the solve of
     # step i+1 (launch stream); one collective per step, never on the solve's critical path
-    gathered = [torch.zeros(world, B * (NU + IW), dtype=torch.float64, device=dev) for _ in range(2)] if multi else None
-    pending = [None, None]
+    gathered = [torch.zeros(world, B * (NU + IW), dtype=torch.float64, device=dev) for _ in range(SLOTS)] if multi else None
+    pending = [None] * SLOTS
 
     def step(i):
-        buf = i & 1
+        buf = i % SLOTS
         if pending[buf] is not None:          # the buffer's previous gather must have drained
             pending[buf].wait()
             pending[buf] = None
@@ -253,7 +254,8 @@ def main():
         for w in pending:
             if w is not None:
                 w.wait()
-        pending[0] = pending[1] = None
+        for j in range(SLOTS):
+            pending[j] = None
 
     def sync():
         if not selftest:
@@ -288,18 +290,18 @@ def main():
         elapsed = float(t.item())
     # HIP events on the launch stream: average launch duration (back-to-back launches)
     kernel_ms = (ev0.elapsed_time(ev1) / args.steps) if not selftest else float("nan")
-    last = blocks[(args.steps - 1) & 1]
+    last = blocks[(args.steps - 1) % SLOTS]
     d_f = forces_of(last)
     if multi:
         # every rank holds every rank's forces and status: check the gathered block against the local one
-        g = gathered[(args.steps - 1) & 1]
+        g = gathered[(args.steps - 1) % SLOTS]
         assert torch.equal(g[rank], last), "gathered block differs from the local shard"
     if selftest:
         ok = True
         if multi:
             from oracle import pyoracle
             full, _ = oracle_solve(pyoracle, gen(world * B, config_id=config_id))
-            gf = gathered[(args.steps - 1) & 1][:, :B * NU].reshape(world * B, NU)
+            gf = gathered[(args.steps - 1) % SLOTS][:, :B * NU].reshape(world * B, NU)
             ok = bool(np.array_equal(gf.numpy(), full))
         if rank == 0:
             print(json.dumps({"selftest": "gloo", "n_ranks": world, "steps": args.steps, "ok": ok}), flush=True)
@@ -308,7 +310,7 @@ def main():
         sys.exit(0 if ok else 1)
 
     # status of EVERY rank's instances (the gathered blocks carry them); iterations of the local shard
-    all_info = (gathered[(args.steps - 1) & 1][:, B * NU:] if multi else info_of(last).view(1, -1))
+    all_info = (gathered[(args.steps - 1) % SLOTS][:, B * NU:] if multi else info_of(last).view(1, -1))
     info = np.ascontiguousarray(all_info.cpu().numpy()).view(pkg.INFO_DTYPE).reshape(world, B)
     n_ok = int((info["status"] == 0).sum())
     mean_iters = float(info["iterations"].mean())
