@@ -758,3 +758,17 @@ def test_gpu_against_committed_oracle_fixture(pkg, lib, name, gen, dp, solve, N,
         assert np.abs(wr(f) - wr(want)).max() < 1e-6 and np.abs(f - want).max() < 1e-4
     else:
         assert np.abs(f - want).max() < 1e-6
+
+
+def test_c_example_runs_on_the_gpu(pkg, lib, tmp_path):
+    """examples/solve_batch.c through the C ABI from plain C: all instances converge, the stand pose carries the weight."""
+    import subprocess
+
+    repo = Path(__file__).resolve().parents[1]
+    so = repo / "quaternion-mpc_amd" / "csrc" / "libqmpc_hip.so"
+    exe = tmp_path / "solve_batch"
+    subprocess.run(["gcc", "-O2", "-I", str(repo / "include"), str(repo / "examples" / "solve_batch.c"), "-o", str(exe),
+                    str(so), f"-Wl,-rpath,{so.parent}", "-lm"], check=True)
+    r = subprocess.run([str(exe), "16"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("status 0") == 16

@@ -443,3 +443,29 @@ def test_debug_topic_records(host):
     host.qh_debug_grf_batch(64, F.ctypes.data, Cn.ctypes.data, pos.ctypes.data, eff.ctypes.data)
     assert np.array_equal(pos, Cn) and np.abs(eff - np.linalg.norm(F.reshape(64, 4, 3), axis=2)).max() < 1e-15
     host.qh_destroy(h)
+
+
+def test_c_example_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    """examples/solve_batch.c: the C ABI from plain C.  It compiles and links against the in-tree library; without
+    a GPU the product path refuses to run (QMPC_NO_DEVICE) instead of falling back to anything."""
+    import shutil
+    import subprocess
+
+    import __graft_entry__ as g
+
+    repo = Path(__file__).resolve().parents[1]
+    lib = g.build_hip()
+    exe = tmp_path / "solve_batch"
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I", str(repo / "include"), str(repo / "examples" / "solve_batch.c"),
+                    "-o", str(exe), str(lib), f"-Wl,-rpath,{lib.parent}", "-lm"], check=True)
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    r = subprocess.run([str(exe), "4"], capture_output=True, text=True)
+    if has_gpu:
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:
+        assert r.returncode == 2 and "no CPU fallback" in r.stderr
+    shutil.rmtree(tmp_path, ignore_errors=True)
