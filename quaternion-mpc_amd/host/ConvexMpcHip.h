@@ -127,6 +127,10 @@ class ConvexMpcHipT : public LeggedMpcHipT<State> {
       std::fprintf(stderr, "ConvexMpcHip::grf_update: qmpc_convex_solve failed with status %d\n", (int)last_status_);
       return false;
     }
+    if (info.status != QMPC_OK && info.status != QMPC_MAX_ITER) {   // zero forces / broken iterate: keep the previous ones
+      std::fprintf(stderr, "ConvexMpcHip::grf_update: instance status %d, previous forces kept\n", (int)info.status);
+      return false;
+    }
     for (int i = 0; i < NUM_LEG; ++i)   // optimized_input = R' u_i  (:188-190)
       for (int r = 0; r < 3; ++r)
         state.ctrl.optimized_input[3 * i + r] = state.fbk.torso_rot_mat(0, r) * u[3 * i] +

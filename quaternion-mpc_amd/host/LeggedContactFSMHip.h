@@ -58,7 +58,11 @@ class LeggedContactFSMHip {
     prev_gait_pattern_index = gait_pattern_size - 1;
     cur_state_start_time = 0;
     cur_state_end_time = gait_switch_time[gait_pattern_index];
+    if (s == SWING_HIP) {                               // :20-25 a swing foot goes to its saved target
+      for (int a = 0; a < 3; ++a) { FSM_foot_pos_target_world[a] = swing_end_foot_pos_world[a]; FSM_foot_vel_target_world[a] = 0.0; }
+    }
     s = gait_state_pattern[gait_pattern_index];
+    not_first_call = false;                             // :30 the next update() re-seeds the targets
   }
 
   // foot_force_flag is the reference's (bool)foot_contact_flag[i]: ANY non-zero

@@ -224,12 +224,28 @@ class QuatMpcHipT : public LeggedMpcHipT<State> {
     last_info_ = info;
     const auto t_end = std::chrono::high_resolution_clock::now();
     state.fbk.mpc_time = std::chrono::duration<double, std::milli>(t_end - t_start).count();   // :257-261
+    // The FSM foot targets (:270-272) do not depend on the solve: BaseInterface.cpp:349,358 reads them for every
+    // leg while movement_mode > 0 (inverse kinematics of the swing feet), so they are published whatever the
+    // solver says -- the reference writes them unconditionally after Solve() (status ignored, :256).
+    for (int i = 0; i < NUM_LEG; ++i)
+      for (int a = 0; a < 3; ++a) {
+        state.ctrl.optimized_state[6 + 3 * i + a] = leg_FSM[i].FSM_foot_pos_target_world[a];
+        state.ctrl.optimized_input[12 + 3 * i + a] = leg_FSM[i].FSM_foot_vel_target_world[a];
+        state.ctrl.optimized_input[24 + 3 * i + a] = leg_FSM[i].FSM_foot_acc_target_world[a];
+      }
     if (last_status_ != QMPC_OK) {
       // fail loudly: the reference ignores SolveStatus (:256); we keep the previous forces
       std::fprintf(stderr, "QuatMpcHip::grf_update: qmpc_solve failed with status %d\n", (int)last_status_);
       return false;
     }
-    for (int i = 0; i < NUM_LEG; ++i) {   // :267-273
+    // Per-instance status: QMPC_MAX_ITER still carries a usable iterate (it is what the reference itself applies,
+    // its solver being capped at 10 iterations); every other non-OK word means the forces are zeros or a broken
+    // iterate (NAN_INPUT, NO_CONTACT, LINESEARCH_FAIL, NOT_PD): keep the previous forces and say so.
+    if (info.status != QMPC_OK && info.status != QMPC_MAX_ITER) {
+      std::fprintf(stderr, "QuatMpcHip::grf_update: instance status %d, previous forces kept\n", (int)info.status);
+      return false;
+    }
+    for (int i = 0; i < NUM_LEG; ++i) {   // :267-269
       for (int r = 0; r < 3; ++r) {
         state.ctrl.mpc_grf_world[3 * i + r] = state.fbk.torso_rot_mat(r, 0) * u[3 * i] +
                                               state.fbk.torso_rot_mat(r, 1) * u[3 * i + 1] +

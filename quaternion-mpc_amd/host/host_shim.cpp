@@ -32,6 +32,23 @@ void stub_default_params(qmpc_params* p, int32_t horizon, int32_t mode) {
   p->mode = mode;
 }
 
+// Test double of the C ABI (CPU suite only): a "device" whose answer the test scripts, so that the host class's
+// handling of call-level and per-instance status words can be exercised without a GPU.
+struct FakeDevice { double forces[12]; int32_t call_status; int32_t inst_status; int calls; } g_fake = {{0}, 0, 0, 0};
+qmpc_status fake_create(const qmpc_params*, int32_t, int32_t, qmpc_handle** out) {
+  *out = reinterpret_cast<qmpc_handle*>(&g_fake);
+  return QMPC_OK;
+}
+qmpc_status fake_solve(qmpc_handle*, int32_t batch, const qmpc_input*, double* forces, qmpc_info* info) {
+  g_fake.calls += 1;
+  for (int b = 0; b < batch; ++b) {
+    for (int i = 0; i < 12; ++i) forces[12 * b + i] = g_fake.inst_status == QMPC_NAN_INPUT ? 0.0 : g_fake.forces[i];
+    if (info) { std::memset(&info[b], 0, sizeof(qmpc_info)); info[b].status = g_fake.inst_status; }
+  }
+  return static_cast<qmpc_status>(g_fake.call_status);
+}
+void fake_destroy(qmpc_handle*) {}
+
 // binds the C-ABI entry points from libqmpc_hip.so (or leaves the stubs for a device-less harness)
 bool bind_api(Harness* h, const char* lib_path, legged::QmpcApi& api);
 }  // namespace
@@ -124,6 +141,26 @@ bool bind_api(Harness* h, const char* lib_path, legged::QmpcApi& api) {
 
 extern "C" {
 
+// harness over the scripted test double above
+void* qh_create_fake(int horizon) {
+  Harness* h = new Harness();
+  h->state.param.mpc_horizon = horizon;
+  legged::QmpcApi api;
+  api.default_params = stub_default_params;
+  api.create = fake_create;
+  api.solve = fake_solve;
+  api.destroy = fake_destroy;
+  h->state.fbk.torso_rot_mat(0, 0) = h->state.fbk.torso_rot_mat(1, 1) = h->state.fbk.torso_rot_mat(2, 2) = 1.0;
+  h->state.fbk.torso_rot_mat_z = h->state.fbk.torso_rot_mat;
+  h->mpc = new Mpc(h->state, api, 0);
+  return h;
+}
+void qh_fake_script(const double* forces12, int call_status, int inst_status) {
+  for (int i = 0; i < 12; ++i) g_fake.forces[i] = forces12[i];
+  g_fake.call_status = call_status;
+  g_fake.inst_status = inst_status;
+}
+
 void qh_destroy(void* p) {
   Harness* h = static_cast<Harness*>(p);
   if (!h) return;
@@ -185,6 +222,34 @@ void qh_get_outputs(void* p, double* o) {
   o[32] = s.ctrl.torso_quat_d.w(); o[33] = s.ctrl.torso_quat_d.x(); o[34] = s.ctrl.torso_quat_d.y(); o[35] = s.ctrl.torso_quat_d.z();
   for (int i = 0; i < 3; ++i) o[36 + i] = s.ctrl.torso_pos_d_world[i];
   o[39] = s.fbk.mpc_time;
+}
+
+// what the low-level thread reads besides the forces (BaseInterface.cpp:349,358; QuatMpc.cpp:270-272):
+// out = optimized_state[6:18] optimized_input[12:24] optimized_input[24:36], then the FSM members themselves
+// (pos, vel, acc per leg, [3*leg+axis])                                 = 72 doubles
+void qh_get_foot_targets(void* p, double* o) {
+  Harness* h = static_cast<Harness*>(p);
+  LeggedStateLite& s = h->state;
+  for (int i = 0; i < 12; ++i) {
+    o[i] = s.ctrl.optimized_state[6 + i];
+    o[12 + i] = s.ctrl.optimized_input[12 + i];
+    o[24 + i] = s.ctrl.optimized_input[24 + i];
+  }
+  for (int l = 0; l < 4; ++l)
+    for (int a = 0; a < 3; ++a) {
+      o[36 + 3 * l + a] = h->mpc->leg_FSM[l].FSM_foot_pos_target_world[a];
+      o[48 + 3 * l + a] = h->mpc->leg_FSM[l].FSM_foot_vel_target_world[a];
+      o[60 + 3 * l + a] = h->mpc->leg_FSM[l].FSM_foot_acc_target_world[a];
+    }
+}
+// fbk.foot_pos_world and ctrl.foot_pos_target_world ([3*leg+axis]), the FSM's inputs (QuatMpc.cpp:291-294)
+void qh_set_foot_world(void* p, const double* cur12, const double* tgt12) {
+  LeggedStateLite& s = static_cast<Harness*>(p)->state;
+  for (int l = 0; l < 4; ++l)
+    for (int a = 0; a < 3; ++a) {
+      s.fbk.foot_pos_world(a, l) = cur12[3 * l + a];
+      s.ctrl.foot_pos_target_world(a, l) = tgt12[3 * l + a];
+    }
 }
 
 // ---- stand-alone pieces ---------------------------------------------------------

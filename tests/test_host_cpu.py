@@ -374,6 +374,120 @@ def test_fsm_full_update_publishes_foot_targets(host):
             assert np.abs(targets[t, 3:6] - vel).max() < 1e-7 and np.abs(targets[t, 6:] - acc).max() < 1e-5
 
 
+class PyLegFull(PyFSM):
+    """The full per-leg state machine (schedule + foot targets), LeggedContactFSM.cpp:11-86,225-246, restated
+    independently of host/LeggedContactFSMHip.h: reset() sends a swinging foot to its saved target and clears
+    not_first_call, so the first walking tick after a stand re-seeds swing start / end and the targets."""
+
+    def __init__(self, leg):
+        super().__init__(leg)
+        self.first = False                        # not_first_call
+        self.start = np.zeros(3); self.end = np.zeros(3)
+        self.pos = np.zeros(3); self.vel = np.zeros(3); self.acc = np.zeros(3)
+
+    def reset(self):
+        was_swing = self.s == self.SWING
+        super().reset()
+        if was_swing:                             # :20-25
+            self.pos = self.end.copy(); self.vel = np.zeros(3)
+        self.first = False                        # :30
+
+    def step(self, dt, freq, cur, tgt, flag):
+        if not self.first:                        # :37-43
+            self.start, self.end = cur.copy(), tgt.copy()
+            self.pos, self.vel = tgt.copy(), np.zeros(3)
+            self.first = True
+        prev = self.s
+        self.update(dt, freq, flag)
+        if prev == self.STANCE and self.s == self.SWING:
+            self.start = cur.copy()               # swing_enter :225-229
+        if prev == self.SWING and self.s == self.STANCE:
+            self.pos, self.vel = cur.copy(), np.zeros(3)   # stance_enter :231-235
+        if self.s == self.SWING:                  # swing_update :237-246
+            o = _py_quintic(0.5 * self._pct() / freq, 0.5 / freq, self.start, tgt)
+            self.pos, self.vel, self.acc = o[:3], o[3:6], o[6:]
+
+
+def _fake_harness(host):
+    host.qh_create_fake.argtypes = [C.c_int]; host.qh_create_fake.restype = C.c_void_p
+    host.qh_fake_script.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    host.qh_get_foot_targets.argtypes = [C.c_void_p, C.c_void_p]
+    host.qh_set_foot_world.argtypes = [C.c_void_p] * 3
+    return host.qh_create_fake(10)
+
+
+def test_update_publishes_fsm_foot_targets_tick_for_tick(host, pkg):
+    """QuatMpc.cpp:270-272: optimized_state[6+3i], optimized_input[12+3i] and [24+3i] carry the FSM foot position /
+    velocity / acceleration targets that BaseInterface.cpp:349,358 servo the legs to.  Stand -> walk -> stand -> walk,
+    so the reset semantics (:11-31) are covered, through the whole update() of the drop-in class."""
+    h = _fake_harness(host)
+    assert h
+    f12 = np.arange(12, dtype=float) + 1.0
+    host.qh_fake_script(f12.ctypes.data, pkg.OK, pkg.OK)
+    rec = pkg.go1_stand_input()[0]
+    rng = np.random.default_rng(21)
+    T, freq, dt = 700, 2.2, 5.0 / 1000.0          # param.gait_freq default, the reference's hard-wired 5 ms
+    mode = np.ones(T); mode[:5] = 0; mode[330:340] = 0
+    base = np.array([[0.2, 0.14, 0.02], [0.2, -0.14, 0.02], [-0.2, 0.14, 0.02], [-0.2, -0.14, 0.02]])
+    legs = [PyLegFull(i) for i in range(4)]
+    joy = np.array([0.3, 0.0, 0.28, 0, 0, 0])
+    saw_swing_at_reset = False
+    for t in range(T):
+        cur = base + np.cumsum(rng.normal(0, 1e-3, (4, 3)), axis=0) + [0.001 * t, 0, 0]
+        tgt = cur + [0.06, 0.01, 0.0]
+        flags = (rng.random(4) < 0.15).astype(float)
+        fb = _feedback(pkg, rec, flags=flags)
+        host.qh_set_feedback(h, fb.ctypes.data)
+        host.qh_set_foot_world(h, np.ascontiguousarray(cur).ctypes.data, np.ascontiguousarray(tgt).ctypes.data)
+        host.qh_set_command(h, joy.ctypes.data, float(mode[t]))
+        assert host.qh_update(h) == 1
+        out = np.zeros(72); host.qh_get_foot_targets(h, out.ctypes.data)
+        o40 = np.zeros(40); host.qh_get_outputs(h, o40.ctypes.data)
+        # the three published blocks ARE the FSM members, bit for bit
+        assert np.array_equal(out[0:12], out[36:48]) and np.array_equal(out[12:24], out[48:60])
+        assert np.array_equal(out[24:36], out[60:72])
+        assert np.array_equal(o40[8:20], f12)                          # optimized_input[0:12] = u
+        for i, m in enumerate(legs):
+            if mode[t] == 0:
+                saw_swing_at_reset |= (m.s == PyFSM.SWING and t > 10)
+                m.reset()
+            else:
+                m.step(dt, freq, cur[i], tgt[i], bool(flags[i]))
+                assert int(o40[i]) == m.s
+            assert np.abs(out[36 + 3 * i:39 + 3 * i] - m.pos).max() < 1e-8, (t, i)
+            assert np.abs(out[48 + 3 * i:51 + 3 * i] - m.vel).max() < 1e-7, (t, i)
+            assert np.abs(out[60 + 3 * i:63 + 3 * i] - m.acc).max() < 1e-5, (t, i)
+    assert saw_swing_at_reset                                           # the :20-25 branch was exercised
+    assert np.abs(out[0:12]).max() > 0.1 and np.abs(out[12:24]).max() > 0
+    host.qh_destroy(h)
+
+
+def test_grf_update_keeps_previous_forces_on_instance_failure(host, pkg):
+    """Per-instance status words (qmpc.h): zero-force answers (NAN_INPUT, NO_CONTACT) and broken iterates (NOT_PD)
+    must not overwrite the forces of the previous tick; MAX_ITER is an iterate like the reference's own."""
+    h = _fake_harness(host)
+    rec = pkg.go1_stand_input()[0]
+    fb = _feedback(pkg, rec); host.qh_set_feedback(h, fb.ctypes.data)
+    good = np.linspace(1.0, 12.0, 12)
+    host.qh_fake_script(good.ctypes.data, pkg.OK, pkg.OK)
+    assert host.qh_grf_update(h) == 1
+    o = np.zeros(40); host.qh_get_outputs(h, o.ctypes.data)
+    assert np.array_equal(o[8:20], good) and np.array_equal(o[20:32], good)      # R = I
+    bad = np.full(12, 777.0)
+    for st in (pkg.NAN_INPUT, pkg.NO_CONTACT, pkg.NOT_PD, pkg.LINESEARCH_FAIL):
+        host.qh_fake_script(bad.ctypes.data, pkg.OK, st)
+        assert host.qh_grf_update(h) == 0
+        host.qh_get_outputs(h, o.ctypes.data)
+        assert np.array_equal(o[8:20], good) and np.array_equal(o[20:32], good)
+    host.qh_fake_script(bad.ctypes.data, pkg.HIP_ERROR, pkg.OK)                     # call-level failure
+    assert host.qh_grf_update(h) == 0
+    host.qh_get_outputs(h, o.ctypes.data); assert np.array_equal(o[8:20], good)
+    host.qh_fake_script(bad.ctypes.data, pkg.OK, pkg.MAX_ITER)
+    assert host.qh_grf_update(h) == 1
+    host.qh_get_outputs(h, o.ctypes.data); assert np.array_equal(o[8:20], bad)
+    host.qh_destroy(h)
+
+
 def test_raibert_foot_targets(host):
     host.qh_raibert.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     h = host.qh_create(None, 10)
