@@ -205,7 +205,8 @@ void        qmpc_destroy(qmpc_handle* h);
 /* ---- solve --------------------------------------------------------------- */
 /* Synchronous, host buffers (replaces QuatMpc.cpp:217-265 for `batch`
  * independent LeggedStates).  forces_body: [batch][12]; info may be NULL;
- * traj_u ([batch][N][12]) and traj_x ([batch][N+1][13]) may be NULL.
+ * traj_u ([batch][N][12]) and traj_x ([batch][N+1][13]) may be NULL (the first call that asks for a trajectory
+ * allocates its device buffer, sized by max_batch; later calls reuse it).
  * batch == 1 keeps the blocking semantics of the reference's mpc_thread
  * (Main.cpp:106-108). */
 qmpc_status qmpc_solve(qmpc_handle* h, int32_t batch, const qmpc_input* in,

@@ -82,6 +82,9 @@ def lib() -> C.CDLL:
         _lib.qo_default_go1_geometry.argtypes = [vp]
         _lib.qo_leg_kinematics.argtypes = [vp, i32, vp, vp, vp]
         _lib.qo_torque_map.argtypes = [vp, i32, vp, vp, vp, i32, vp]
+        for fn in ("qo_solve_one_dual", "qo_solve8_one_dual", "qo_convex_solve_one_dual"):
+            getattr(_lib, fn).argtypes = [C.POINTER(Params)] + [vp] * 7
+            getattr(_lib, fn).restype = i32
         _lib.qo_kat_double_integrator.argtypes = [i32, dp, i32]
         _lib.qo_kat_double_integrator.restype = i32
         _lib.qo_kat_pendulum_midpoint.argtypes = [dp, dp]
@@ -249,3 +252,17 @@ def kat_pendulum_swingup(verbose: int = 0):
     out = (C.c_double * 8)()
     lib().qo_kat_pendulum_swingup(out, verbose)
     return list(out)
+
+
+# ---- primal-dual export (tests/golden/make_kkt_fixtures.py) ---------------------------------
+def solve_dual(params: Params, inp: np.ndarray, model: str = "quat"):
+    """One instance with the multipliers and slacks of its cone rows: returns (U [N][nu], X, lam [N][nc], s [N][nc], info)."""
+    dt, fn, nu, nx = {"quat": (INPUT_DTYPE, "qo_solve_one_dual", 12, 13),
+                      "biped8": (pkg.INPUT8_DTYPE, "qo_solve8_one_dual", 24, 13),
+                      "convex": (pkg.CONVEX_INPUT_DTYPE, "qo_convex_solve_one_dual", 12, 12)}[model]
+    inp = np.ascontiguousarray(inp, dtype=dt)
+    N = params.horizon
+    f = np.zeros(nu); info = np.zeros(1, dtype=INFO_DTYPE)
+    tu = np.zeros((N, nu)); tx = np.zeros((N + 1, nx)); lam = np.zeros((N, 2 * nu)); sl = np.zeros((N, 2 * nu))
+    getattr(lib(), fn)(C.byref(params), _ptr(inp), _ptr(f), _ptr(info), _ptr(tu), _ptr(tx), _ptr(lam), _ptr(sl))
+    return tu, tx, lam, sl, info[0]

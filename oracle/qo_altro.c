@@ -898,7 +898,18 @@ int qo_altro_solve(const qo_problem* prob, const qo_options* opts, double* X, do
       r.status = st;
       r.penalty = r.ipm_mu;
       if (res) *res = r;
-      
+      if (opts->dual_out || opts->slack_out) {
+        size_t o = 0;
+        for (int k = 0; k < N; ++k)
+          for (int ci = 0; ci < prob->ncon; ++ci) {
+            const qo_constraint* cn = &prob->con[ci];
+            for (int i = 0; i < cn->p; ++i, ++o) {
+              const int on = con_active_at(cn, k) && cn->type == QO_INEQUALITY && row_on(cn, i);
+              if (opts->dual_out) opts->dual_out[o] = on ? ws.kn[k].lam[ci][i] : 0.0;
+              if (opts->slack_out) opts->slack_out[o] = on ? ws.kn[k].s[ci][i] : 0.0;
+            }
+          }
+      }
       return r.status;
     }
   }

@@ -78,6 +78,10 @@ typedef struct qo_options {
   double ipm_sigma;        /* centering parameter                              */
   double ipm_sigma_fast;   /* centering once full steps are being taken        */
   double ipm_tau;          /* fraction to the boundary                         */
+  /* optional exports of the converged mode (NULL = off): multipliers and slacks of the inequality rows, laid out
+   * [k = 0..N-1][constraint ci in order][row 0..p-1]; rows that are switched off (row_enable == 0) report 0 */
+  double* dual_out;
+  double* slack_out;
 } qo_options;
 
 typedef struct qo_problem {

@@ -264,6 +264,10 @@ static int input_is_finite(const qmpc_convex_input* in) {
   return 1;
 }
 
+/* set by qo_convex_solve_one_dual around its call: where the multipliers / slacks go */
+static __thread double* tl_dual = NULL;
+static __thread double* tl_slack = NULL;
+
 int qo_convex_solve_one(const qmpc_params* p, const qmpc_convex_input* in, double* forces,
                         qmpc_info* info, double* traj_u, double* traj_x, int verbose) {
   const int N = p->horizon;
@@ -289,6 +293,8 @@ int qo_convex_solve_one(const qmpc_params* p, const qmpc_convex_input* in, doubl
   setup_problem(p, in, ctx, prob);
   qo_options o;
   options_from_params(p, &o, verbose);
+  o.dual_out = tl_dual;
+  o.slack_out = tl_slack;
   double X[(QMPC_MAX_HORIZON + 1) * 12], U[QMPC_MAX_HORIZON * 12];
   /* SetInput(u_ref) on all knots (ConvexMpc.cpp:176) */
   for (int k = 0; k < N; ++k) memcpy(&U[12 * k], prob->uref[0], sizeof(double) * 12);
@@ -305,6 +311,17 @@ int qo_convex_solve_one(const qmpc_params* p, const qmpc_convex_input* in, doubl
   if (traj_u) memcpy(traj_u, U, sizeof(double) * N * 12);
   if (traj_x) memcpy(traj_x, X, sizeof(double) * (N + 1) * 12);
   return inf.status;
+}
+
+/* As qo_convex_solve_one, plus multipliers and slacks of the cone rows, [N][24] (certificate fixtures only) */
+int qo_convex_solve_one_dual(const qmpc_params* p, const qmpc_convex_input* in, double* forces, qmpc_info* info,
+                             double* traj_u, double* traj_x, double* dual, double* slack) {
+  tl_dual = dual;
+  tl_slack = slack;
+  const int st = qo_convex_solve_one(p, in, forces, info, traj_u, traj_x, 0);
+  tl_dual = NULL;
+  tl_slack = NULL;
+  return st;
 }
 
 typedef struct batch_job {

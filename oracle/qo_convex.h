@@ -43,6 +43,9 @@ void qo_convex_discrete_jacobian(const qo_convex_model* m, double* jac /* 12x24 
 
 /* gazebo_go1_convex_mpc.yaml:35-73 + AltroUtils.cpp:239,270-272 + solver defaults */
 void qo_default_convex_params(qmpc_params* p, int32_t horizon, int32_t mode);
+/* As qo_convex_solve_one, plus multipliers and slacks of the cone rows [N][24] (tests/golden/make_kkt_fixtures.py) */
+int qo_convex_solve_one_dual(const qmpc_params* p, const qmpc_convex_input* in, double* forces, qmpc_info* info,
+                             double* traj_u, double* traj_x, double* dual, double* slack);
 /* reference trajectory (ConvexMpc.cpp:94-113): xref (N+1) x 12, uref 12 */
 void qo_convex_build_reference(const qmpc_params* p, const qmpc_convex_input* in, double* xref,
                                double* uref);

@@ -209,7 +209,8 @@ static void options_from_params(const qmpc_params* p, qo_options* o, int verbose
 }
 
 static int solve_one_v(const qmpc_params* p, const in_view* in, const void* rec, size_t rec_bytes,
-                       double* forces, qmpc_info* info, double* traj_u, double* traj_x, int verbose) {
+                       double* forces, qmpc_info* info, double* traj_u, double* traj_x, int verbose,
+                       double* dual, double* slack) {
   const int N = p->horizon, m = 3 * in->nleg;
   qmpc_info inf;
   memset(&inf, 0, sizeof inf);
@@ -233,6 +234,8 @@ static int solve_one_v(const qmpc_params* p, const in_view* in, const void* rec,
   setup_problem(p, in, ctx, prob);
   qo_options o;
   options_from_params(p, &o, verbose);
+  o.dual_out = dual;
+  o.slack_out = slack;
   double X[(QMPC_MAX_HORIZON + 1) * 13], U[QMPC_MAX_HORIZON * 24];
   /* initial guess: SetInput(u_ref) on all knots (QuatMpc.cpp:253); the state
    * guess x_ref (:250-252) is overwritten by the solver's initial rollout */
@@ -255,12 +258,24 @@ static int solve_one_v(const qmpc_params* p, const in_view* in, const void* rec,
 int qo_solve_one(const qmpc_params* p, const qmpc_input* in, double* forces, qmpc_info* info,
                  double* traj_u, double* traj_x, int verbose) {
   const in_view v = view4(in);
-  return solve_one_v(p, &v, in, sizeof *in, forces, info, traj_u, traj_x, verbose);
+  return solve_one_v(p, &v, in, sizeof *in, forces, info, traj_u, traj_x, verbose, NULL, NULL);
 }
 int qo_solve8_one(const qmpc_params* p, const qmpc_input8* in, double* forces, qmpc_info* info,
                   double* traj_u, double* traj_x, int verbose) {
   const in_view v = view8(in);
-  return solve_one_v(p, &v, in, sizeof *in, forces, info, traj_u, traj_x, verbose);
+  return solve_one_v(p, &v, in, sizeof *in, forces, info, traj_u, traj_x, verbose, NULL, NULL);
+}
+
+/* One instance with the multipliers and slacks of the cone rows, [N][6 nleg] each (certificate fixtures only) */
+int qo_solve_one_dual(const qmpc_params* p, const qmpc_input* in, double* forces, qmpc_info* info,
+                      double* traj_u, double* traj_x, double* dual, double* slack) {
+  const in_view v = view4(in);
+  return solve_one_v(p, &v, in, sizeof *in, forces, info, traj_u, traj_x, 0, dual, slack);
+}
+int qo_solve8_one_dual(const qmpc_params* p, const qmpc_input8* in, double* forces, qmpc_info* info,
+                       double* traj_u, double* traj_x, double* dual, double* slack) {
+  const in_view v = view8(in);
+  return solve_one_v(p, &v, in, sizeof *in, forces, info, traj_u, traj_x, 0, dual, slack);
 }
 
 typedef struct batch_job {

@@ -23,6 +23,13 @@ void qo_build_reference(const qmpc_params* p, const qmpc_input* in, double* xref
 int qo_solve_one(const qmpc_params* p, const qmpc_input* in, double* forces, qmpc_info* info,
                  double* traj_u, double* traj_x, int verbose);
 
+/* As qo_solve_one, plus the multipliers and slacks of the cone rows at the returned point, [N][24] each
+ * (swing-leg rows report 0).  Used by tests/golden/make_kkt_fixtures.py only. */
+int qo_solve_one_dual(const qmpc_params* p, const qmpc_input* in, double* forces, qmpc_info* info,
+                      double* traj_u, double* traj_x, double* dual, double* slack);
+int qo_solve8_one_dual(const qmpc_params* p, const qmpc_input8* in, double* forces, qmpc_info* info,
+                       double* traj_u, double* traj_x, double* dual, double* slack);
+
 /* Batch, `threads` >= 1 host threads over instances (instance-parallel). */
 int qo_solve_batch(const qmpc_params* p, int32_t batch, const qmpc_input* in, double* forces,
                    qmpc_info* info, double* traj_u, double* traj_x, int32_t threads);

@@ -516,4 +516,4 @@ class Solver:
 
 from .scenarios import (go1_stand_input, quat_to_rot, random_go1_trot_states,  # noqa: E402,F401
                         random_go1_convex_states, random_biped8_states)
-from .sharding import gather_forces, shard_range, solve_sharded  # noqa: E402,F401
+from .sharding import StepPipeline, gather_forces, shard_range, solve_sharded  # noqa: E402,F401

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 using namespace qmpc;
@@ -36,6 +37,8 @@ struct qmpc_handle {
   size_t lds_bytes;       // LDS-resident gains
   size_t lds_bytes_g;     // gains in the global workspace
   size_t lds_bytes_s;     // gains and slack arrays in the global workspace
+  double* d_leg;          // staging of the host-buffer leg calls (grown on demand, freed with the handle)
+  size_t leg_cap;         // its capacity in doubles
   double* d_gws;          // [max_batch][N*(156+84)] workspace of the global-gains variant
   int variant;            // 0: auto, 1: LDS gains, 2: global gains (env QMPC_VARIANT)
 };
@@ -280,6 +283,7 @@ void qmpc_destroy(qmpc_handle* h) {
   if (h->d_in) (void)hipFree(h->d_in);
   if (h->d_forces) (void)hipFree(h->d_forces);
   if (h->d_gws) (void)hipFree(h->d_gws);
+  if (h->d_leg) (void)hipFree(h->d_leg);
   if (h->d_info) (void)hipFree(h->d_info);
   if (h->d_traj_u) (void)hipFree(h->d_traj_u);
   if (h->d_traj_x) (void)hipFree(h->d_traj_x);
@@ -300,7 +304,10 @@ static int pick_variant(const qmpc_handle* h, int32_t batch) {
   // one instance per SIMD (1024 on the chip) is the break-even: beyond it a second resident wave per SIMD
   // (x1.6 throughput) beats a second round of one-wave instances (measured at B = 2048 / 4096)
   const bool big = batch > 1024;
-  if (h->variant == 1) return h->lds_bytes > 160 * 1024 ? 1 : 0;
+  // QMPC_VARIANT override (experiments).  Only the instantiations that exist may be named: the 8-point model has no
+  // all-LDS kernel, and an all-LDS request that does not fit the CU falls back to the workspace
+  const bool no_lds_variant = h->params.model == QMPC_MODEL_QUAT8 || h->lds_bytes > 160 * 1024;
+  if (h->variant == 1) return no_lds_variant ? 1 : 0;
   if (h->variant == 2) return 1;
   if (h->variant == 3) return 2;
   if (h->params.model == QMPC_MODEL_QUAT8) return (batch > 768 && h->lds_bytes_g > 40 * 1024) ? 2 : 1;  // 3 per CU in LDS
@@ -488,9 +495,8 @@ qmpc_status qmpc_convex_linearize(qmpc_handle* h, int32_t batch, const qmpc_conv
 typedef int (*nccl_all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
 static nccl_all_gather_fn resolve_all_gather() {
   static nccl_all_gather_fn fn = nullptr;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  static std::once_flag once;      // two handles may gather first from two threads
+  std::call_once(once, [] {
     void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");          // already in the process (e.g. under torch)?
     if (!sym) {
       const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
@@ -500,7 +506,7 @@ static nccl_all_gather_fn resolve_all_gather() {
       }
     }
     fn = reinterpret_cast<nccl_all_gather_fn>(sym);
-  }
+  });
   return fn;
 }
 
@@ -567,14 +573,20 @@ qmpc_status qmpc_torque_map_device(qmpc_handle* h, const qmpc_leg_geometry* g, i
                     stream ? (hipStream_t)stream : h->stream);
 }
 
-// host-buffer variants: staging buffers live for the call only (this is not the hot path)
+// host-buffer variants (not the hot path): staged through a buffer the handle keeps
 static qmpc_status leg_host(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch, const double* q, const double* f,
                             const double* c, int walking, double* p, double* J, double* tau) {
   HIP_TRY(hipSetDevice(h->device));
   const size_t B = (size_t)batch;
-  double* d = nullptr;
-  // layout: q[12B] f[12B] c[4B] p[12B] J[36B] tau[12B]
-  HIP_TRY(hipMalloc(&d, sizeof(double) * B * 88));
+  // layout: q[12B] f[12B] c[4B] p[12B] J[36B] tau[12B]; the staging buffer belongs to the handle and only grows
+  if (h->leg_cap < B * 88) {
+    if (h->d_leg) (void)hipFree(h->d_leg);
+    h->d_leg = nullptr;
+    h->leg_cap = 0;
+    HIP_TRY(hipMalloc(&h->d_leg, sizeof(double) * B * 88));
+    h->leg_cap = B * 88;
+  }
+  double* d = h->d_leg;
   double *dq = d, *df = d + 12 * B, *dc = d + 24 * B, *dp = d + 28 * B, *dJ = d + 40 * B, *dt = d + 76 * B;
   qmpc_status st = QMPC_OK;
   do {
@@ -589,7 +601,6 @@ static qmpc_status leg_host(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t 
     if (tau && hipMemcpyAsync(tau, dt, sizeof(double) * 12 * B, hipMemcpyDeviceToHost, h->stream) != hipSuccess) { st = QMPC_HIP_ERROR; break; }
     if (hipStreamSynchronize(h->stream) != hipSuccess) st = QMPC_HIP_ERROR;
   } while (0);
-  (void)hipFree(d);
   return st;
 }
 

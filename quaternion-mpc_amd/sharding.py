@@ -23,12 +23,20 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return first, last - first
 
 
+def _fused_gather_ok() -> bool:
+    """all_gather_into_tensor exists for every backend this path runs on (nccl = RCCL, gloo); the choice is made
+    from the backend name, once and identically on every rank -- never by catching an error on some ranks."""
+    import torch.distributed as dist
+
+    return dist.get_backend() in ("nccl", "gloo") and hasattr(dist, "all_gather_into_tensor")
+
+
 def gather_forces(local, world: int, counts=None):
-    """The single collective of the path: all_gather of the local [count,12] block.
+    """The single collective of the path: all_gather of the local [count, columns] block.
 
     `local` is a torch tensor on the device the process group lives on.  Equal
     shard sizes use all_gather_into_tensor; ragged shards pad to the largest.
-    Returns the [total, 12] tensor on every rank.
+    Returns the [total, columns] tensor on every rank.
     """
     import torch
     import torch.distributed as dist
@@ -43,14 +51,13 @@ def gather_forces(local, world: int, counts=None):
         counts = [int(c.item()) for c in allc]
     m = max(counts)
     if all(c == m for c in counts):
-        out = torch.empty((world * m, local.shape[1]), dtype=local.dtype, device=local.device)
-        try:
+        if _fused_gather_ok():
+            out = torch.empty((world * m, local.shape[1]), dtype=local.dtype, device=local.device)
             dist.all_gather_into_tensor(out, local.contiguous())
-        except (RuntimeError, NotImplementedError):   # backend without the fused form
-            parts = [torch.empty_like(local) for _ in range(world)]
-            dist.all_gather(parts, local.contiguous())
-            out = torch.cat(parts, 0)
-        return out
+            return out
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local.contiguous())
+        return torch.cat(parts, 0)
     pad = torch.zeros((m, local.shape[1]), dtype=local.dtype, device=local.device)
     pad[:n] = local
     parts = [torch.empty_like(pad) for _ in range(world)]
@@ -59,16 +66,61 @@ def gather_forces(local, world: int, counts=None):
 
 
 def solve_sharded(total: int, rank: int, world: int, make_inputs: Callable[[int, int], np.ndarray],
-                  solve_local: Callable[[np.ndarray], np.ndarray], device="cpu"):
+                  solve_local: Callable[[np.ndarray], np.ndarray], device="cpu", columns: int = 12):
     """Solve instances [0,total) across `world` ranks; every rank gets all forces.
 
-    make_inputs(first, count) -> structured records; solve_local(records) -> [count,12] float64.
+    make_inputs(first, count) -> structured records; solve_local(records) -> [count, columns] float64
+    (columns = 12 forces for Go1, 24 for the 8-contact-point model); an empty shard contributes a [0, columns] block.
     """
     import torch
 
     first, count = shard_range(total, rank, world)
     rec = make_inputs(first, count)
-    f = solve_local(rec) if count else np.zeros((0, 12))
+    f = np.asarray(solve_local(rec)) if count else np.zeros((0, columns))
+    if f.ndim != 2 or f.shape[1] != columns:
+        raise ValueError(f"solve_local returned {f.shape}, expected [{count}, {columns}]")
     local = torch.from_numpy(np.ascontiguousarray(f)).to(device)
     counts = [shard_range(total, r, world)[1] for r in range(world)]
     return gather_forces(local, world, counts)
+
+
+class StepPipeline:
+    """The per-step pipeline of a multi-rank run: `launch(block)` fills this rank's result block (forces and status
+    words of its shard, one contiguous float64 buffer), then ONE asynchronous all_gather returns every rank's block to
+    every rank.  `slots` blocks rotate, so the gather of step i drains under the solve of step i+1 and never sits on
+    the solve's critical path.  With world == 1 and multi=False there is no collective at all.  bench.py drives it
+    with the HIP launch; tests/_pipeline_worker.py drives the same code over gloo with a stand-in launch."""
+
+    def __init__(self, world: int, rank: int, block_elems: int, device, slots: int = 2, multi: bool | None = None):
+        import torch
+
+        self.world, self.rank, self.slots = world, rank, slots
+        self.multi = (world > 1) if multi is None else multi
+        self.blocks = [torch.zeros(block_elems, dtype=torch.float64, device=device) for _ in range(slots)]
+        self.gathered = ([torch.zeros(world, block_elems, dtype=torch.float64, device=device) for _ in range(slots)]
+                         if self.multi else None)
+        self.pending = [None] * slots
+
+    def step(self, i: int, launch) -> None:
+        import torch.distributed as dist
+
+        buf = i % self.slots
+        if self.pending[buf] is not None:          # the buffer's previous gather must have drained
+            self.pending[buf].wait()
+            self.pending[buf] = None
+        launch(self.blocks[buf])
+        if self.multi:
+            self.pending[buf] = dist.all_gather_into_tensor(self.gathered[buf].view(-1), self.blocks[buf], async_op=True)
+
+    def drain(self) -> None:
+        for j, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+            self.pending[j] = None
+
+    def block(self, i: int):
+        return self.blocks[i % self.slots]
+
+    def all_blocks(self, i: int):
+        """[world, block_elems]: every rank's block of step i (this rank's own block when there is no collective)."""
+        return self.gathered[i % self.slots] if self.multi else self.blocks[i % self.slots].view(1, -1)

@@ -742,6 +742,66 @@ def test_async_host_call_and_rccl_gather(pkg, lib):
     ("quat_n20", "random_go1_trot_states", "default_params", "solve", 20, 3),
     ("convex_n20", "random_go1_convex_states", "default_convex_params", "convex_solve", 20, 13),
     ("biped8_n16", "random_biped8_states", "default_biped8_params", "solve8", 16, 5)])
+def test_gpu_matches_kkt_certified_points(pkg, lib, name, gen, dp, solve, N, cfg):
+    """The HIP path against points whose optimality was certified WITHOUT the oracle's algorithm
+    (tests/golden/kkt_fixtures.npz, tests/test_kkt_certificate.py: independent autograd KKT residuals, multipliers
+    re-derived by NNLS, an active-set Newton solver reaching the same points): whole input trajectories, 1e-6 N."""
+    fx = np.load(GOLDEN / "kkt_fixtures.npz")
+    want = fx[name + "_U"]
+    n = want.shape[0]
+    rec = getattr(pkg, gen)(n, config_id=cfg)
+    s = pkg.Solver(getattr(pkg, dp)(N, pkg.MODE_CONVERGED, lib), n, device=0, lib=lib)
+    out = getattr(s, solve)(rec, want_traj=True)
+    s.close()
+    info, tu = out[1], out[2]
+    assert (info["status"] == 0).all()
+    if name.startswith("biped8"):      # corner forces of a foot are fixed only by R = 1e-6: compare foot wrenches too
+        feet = rec["foot_pos_body"].reshape(n, 1, 8, 3)
+        wr = lambda F: np.concatenate([F.reshape(n, N, 8, 3).sum(2), np.cross(feet, F.reshape(n, N, 8, 3)).sum(2)], axis=2)
+        assert np.abs(wr(tu) - wr(want)).max() < 1e-6 and np.abs(tu - want).max() < 1e-4
+    else:
+        assert np.abs(tu - want).max() < 1e-6
+
+
+@pytest.mark.parametrize("counts", ["64,64", "40,33,27"], ids=["2 ranks", "3 ranks ragged"])
+def test_multi_process_rccl_gather_on_one_gpu(counts, tmp_path):
+    """qmpc_gather with MORE than one RCCL rank: 2 (and 3, ragged shards) processes, each with its own
+    ncclCommInitRank communicator and its own handle, all on the one visible GPU.  Every rank must end with every
+    rank's forces and status words, equal to a single-process solve of the whole batch.  RCCL builds may refuse
+    several ranks on one device (ncclInvalidUsage, "Duplicate GPU detected"): that refusal is reported verbatim and
+    the test is skipped -- the 8-GPU run of the driver is then the first multi-rank execution."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    repo = Path(__file__).resolve().parent.parent
+    world = len(counts.split(","))
+    uid = tmp_path / "nccl_uid.bin"
+    procs = [subprocess.Popen([sys.executable, str(repo / "tests" / "_rccl_worker.py"), str(r), str(world), str(uid), counts],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("RCCL worker hung")
+        outs.append(o)
+    codes = [pr.returncode for pr in procs]
+    print("\n".join(o[-600:] for o in outs))
+    if any(c == 3 for c in codes):
+        pytest.skip("RCCL refuses several ranks on one device: " + " | ".join(o.strip().splitlines()[-1] for o in outs if o.strip()))
+    if any(c == 4 for c in codes):
+        pytest.skip("no librccl on this box")
+    assert codes == [0] * world, (codes, outs)
+
+
+@pytest.mark.parametrize("name,gen,dp,solve,N,cfg", [
+    ("quat_n10", "random_go1_trot_states", "default_params", "solve", 10, 2),
+    ("quat_n20", "random_go1_trot_states", "default_params", "solve", 20, 3),
+    ("convex_n20", "random_go1_convex_states", "default_convex_params", "convex_solve", 20, 13),
+    ("biped8_n16", "random_biped8_states", "default_biped8_params", "solve8", 16, 5)])
 def test_gpu_against_committed_oracle_fixture(pkg, lib, name, gen, dp, solve, N, cfg):
     """The HIP path against the COMMITTED answers of the oracle (tests/golden/oracle_regimes.npz), without
     running the oracle: the regimes the reference's goldens do not cover."""

@@ -3,8 +3,13 @@
 usage: tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [batch] [horizon]
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB on gfx950 (MI355X_MICROARCH.md: hbm_bytes =
-(FETCH_SIZE + WRITE_SIZE) * 1024); the record read is 8 bytes per lane, so the guide's x2
-correction for 16-byte streaming fetches does not apply."""
+(FETCH_SIZE + WRITE_SIZE) * 1024).  Calibration for THIS access pattern (tools/microbench/fetch_calib.hip, one
+wave per 384-byte record read with one 8-byte-per-lane load, 96 + 40 bytes written; known byte counts,
+profiles/r02_fetch_calibration.txt): FETCH_SIZE reports exactly 1/2 of the bytes read (196 624.5 KiB for
+393 216 KiB), as the guide found for 16-byte streaming reads -> x2; WRITE_SIZE counts 32-byte sectors
+(160 B per record for 136 B of payload) -> x1, i.e. it IS the sector traffic."""
+FETCH_CALIBRATION = 2.0
+WRITE_CALIBRATION = 1.0
 import csv
 import json
 import sys
@@ -35,6 +40,10 @@ out = {
     "FETCH_SIZE_KiB_per_launch": fetch,
     "WRITE_SIZE_KiB_per_launch": write,
     "traffic_bytes_per_launch": (fetch + write) * 1024.0,
+    "traffic_bytes_per_launch_calibrated": (FETCH_CALIBRATION * fetch + WRITE_CALIBRATION * write) * 1024.0,
+    "calibration_note": "FETCH_SIZE x2 (measured with tools/microbench/fetch_calib.hip on this access pattern), "
+                        "WRITE_SIZE x1 (32-byte sectors); the calibrated figure includes the kernel's instruction "
+                        "fetch through the 8 XCD L2s (~60 KB of code each)",
     "algorithmic_bytes_per_launch": batch * (384 + 96 + 40),
 }
 json.dump(out, open(sys.argv[3], "w"), indent=1)
