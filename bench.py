@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-in-flight", action="store_true",
                     help="skip the secondary measurement with two batches in flight (N=1 only)")
+    ap.add_argument("--no-closed-loop", action="store_true",
+                    help="skip the secondary device-resident closed-loop figure (N=1, quat only)")
     ap.add_argument("--no-config4", action="store_true",
                     help="multi-rank runs: skip the extra leg on BASELINE config 4 (262144 instances over the ranks)")
     ap.add_argument("--check", action="store_true", help="also compare a sample against the oracle")
@@ -354,6 +356,27 @@ def main():
             out["host_buffer_call"] = out["rates"]["host_buffer_call"]
         if world == 1 and not args.no_in_flight:
             out["two_in_flight"] = two_in_flight(pkg, lib, params, args, d_in, NU)
+        if world == 1 and args.model == "quat" and not args.no_closed_loop:
+            # secondary: the device-resident closed loop (front end + solve + plant per tick, state in HBM, one
+            # hipGraph replay per tick): B robots standing up from rest into a trot; never `value`
+            lp = pkg.default_loop_params(lib)
+            rng = np.random.default_rng(7)
+            cmds = np.zeros((B, 7)); cmds[:, 0] = rng.uniform(-0.4, 0.4, B); cmds[:, 1] = rng.uniform(-0.1, 0.1, B)
+            cmds[:, 2] = 0.3; cmds[:, 5] = rng.uniform(-0.3, 0.3, B); cmds[:, 6] = 1.0
+            st = pkg.loop_states(cmds, lp, height=0.3, yaw=rng.uniform(-3, 3, B), lib=lib)
+            d_st = torch.from_numpy(st.view(np.uint8).reshape(B, -1).copy()).cuda()
+            ticks = 20
+            solver.loop_run_device(B, d_st.data_ptr(), 2, lp, stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            solver.loop_run_device(B, d_st.data_ptr(), ticks, lp, stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            fin = np.ascontiguousarray(d_st.cpu().numpy()).view(pkg.LOOP_STATE_DTYPE).reshape(B)
+            out["closed_loop"] = {"value": B * ticks / dt, "unit": "robot-ticks/s", "ticks": ticks, "robots": B,
+                                  "ms_per_tick": 1e3 * dt / ticks, "solver_ok": int((fin["status"] == 0).sum()),
+                                  "note": "secondary: qmpc_loop_run_device (goal + gait FSM + swing quintic + Raibert + "
+                                          "record packing -> solve -> rigid-body plant), state resident in HBM"}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(pkg, N, config_id, model=args.model)
             f_cpu = cb.pop("_forces")

@@ -312,6 +312,65 @@ qmpc_status qmpc_torque_map_device(qmpc_handle* h, const qmpc_leg_geometry* g, i
                                    const double* d_contacts, int32_t walking, double* d_tau,
                                    void* stream);
 
+/* ---- device-resident closed loop -----------------------
+ * The step BEFORE the path, the path and a plant chained on the GPU, state kept in HBM, one tick =
+ *   feedback  (R, R_z, foot_pos_body, contact flags from the plant state)
+ *   Raibert foothold targets              BaseInterface.cpp:266-288
+ *   goal_update                            QuatMpc.cpp:68-107  (six 100-sample moving averages, MovingWindowFilter.hpp)
+ *   foot_update: gait FSM + swing quintic  QuatMpc.cpp:278-305, LeggedContactFSM.cpp:33-86,208-246, Utils.cpp:236-293
+ *   record packing (torso_quat_d update)   QuatMpc.cpp:112-176,231-246
+ *   qmpc_solve_device                      QuatMpc.cpp:217-265
+ *   outputs                                QuatMpc.cpp:263-273
+ *   plant: single rigid body under the forces, explicit midpoint, dt = 5 ms (this repository's; the reference
+ *          closes its loop through Gazebo / the robot); swing feet track the FSM target, stance feet stay.
+ * The host classes (host/QuatMpcHip.h + host/ClosedLoopHost.h) run the same tick on the CPU and are the parity
+ * reference, tick for tick.  Integers are stored as doubles so that the record is 818 doubles for every binding. */
+#define QMPC_LOOP_WINDOW 100
+typedef struct qmpc_loop_filter {      /* MovingWindowFilter.hpp:14-63 */
+  double ring[QMPC_LOOP_WINDOW];
+  double head, count, sum, correction;
+} qmpc_loop_filter;
+typedef struct qmpc_loop_leg {         /* LeggedContactFSM.h:60-108 */
+  double gait_phase, state /* 0 swing, 1 stance */, pattern_index, prev_pattern_index, start_time, end_time,
+         not_first_call;
+  double swing_start[3], swing_end[3], swing_extend[3];
+  double fsm_pos[3], fsm_vel[3], fsm_acc[3];   /* FSM_foot_{pos,vel,acc}_target_world */
+  double terrain_height;
+} qmpc_loop_leg;
+typedef struct qmpc_loop_state {
+  /* plant */
+  double pos_world[3], quat[4], lin_vel_world[3], ang_vel_body[3], foot_pos_world[12];
+  /* command: joy.{velx, vely, body_height, roll_rate, pitch_rate, yaw_rate}, ctrl.movement_mode */
+  double joy[6], movement_mode;
+  /* controller memory */
+  double pos_d_world[3], pos_d_init, quat_d[4], lin_vel_d_rel[3];
+  qmpc_loop_filter vel_filter[3], pos_filter[3];
+  qmpc_loop_leg leg[4];
+  /* outputs of the last tick */
+  double contacts[4], gait_counter[4], forces_body[12], grf_world[12], foot_target_world[12];
+  double status, iterations, tick;
+} qmpc_loop_state;
+typedef struct qmpc_loop_params {
+  double gait_freq;                 /* param.gait_freq (yaml: 2.2)                      */
+  double default_foot_pos_rel[12];  /* param.default_foot_pos_rel, [3*leg+axis]         */
+  double dt;                        /* tick: the reference's hard-wired 5 ms (QuatMpc.cpp:97-98,132,294) */
+  double contact_height;            /* plant: foot_contact_flag = foot z <= this [m]    */
+} qmpc_loop_params;
+void qmpc_default_loop_params(qmpc_loop_params* p);
+/* Host-side initialiser (no GPU involved): robot standing at `height` over its default footholds, at rest,
+ * yaw `yaw`; joy[6] and movement_mode as above. */
+void qmpc_loop_state_init(qmpc_loop_state* s, const qmpc_loop_params* lp, const double joy[6], double movement_mode,
+                          double height, double yaw);
+/* `ticks` ticks for `batch` instances.  Host buffers in/out; trace_forces [ticks][batch][12] and trace_contacts
+ * [ticks][batch][4] may be NULL.  The handle must be a QuatMpc handle (QMPC_MODEL_QUAT). */
+qmpc_status qmpc_loop_run(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* states,
+                          int32_t ticks, double* trace_forces, double* trace_contacts);
+/* The same with DEVICE buffers, stream-ordered (NULL = the handle's stream); the per-tick kernel sequence is
+ * captured once into a hipGraph and replayed `ticks` times. */
+qmpc_status qmpc_loop_run_device(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* d_states,
+                                 int32_t ticks, double* d_trace_forces, double* d_trace_contacts, void* stream);
+int32_t qmpc_sizeof_loop_state(void);
+
 /* ---- diagnostics ----------------------------------------------------------- */
 /* C = X' * Y on [12][16] row-major tiles through the FP64 MFMA path the solver
  * uses (host buffers of 192 doubles each).  Lets the GPU tests pin the

@@ -130,6 +130,34 @@ CONVEX_INPUT_DTYPE = np.dtype(
 )
 assert CONVEX_INPUT_DTYPE.itemsize == 48 * 8
 
+# ---- device-resident closed loop (include/qmpc.h: qmpc_loop_*), 818 doubles per instance ----
+LOOP_WINDOW = 100
+LOOP_FILTER_DTYPE = np.dtype([("ring", "<f8", (LOOP_WINDOW,)), ("head", "<f8"), ("count", "<f8"), ("sum", "<f8"),
+                              ("correction", "<f8")], align=False)
+LOOP_LEG_DTYPE = np.dtype([("gait_phase", "<f8"), ("state", "<f8"), ("pattern_index", "<f8"), ("prev_pattern_index", "<f8"),
+                           ("start_time", "<f8"), ("end_time", "<f8"), ("not_first_call", "<f8"),
+                           ("swing_start", "<f8", (3,)), ("swing_end", "<f8", (3,)), ("swing_extend", "<f8", (3,)),
+                           ("fsm_pos", "<f8", (3,)), ("fsm_vel", "<f8", (3,)), ("fsm_acc", "<f8", (3,)),
+                           ("terrain_height", "<f8")], align=False)
+LOOP_STATE_DTYPE = np.dtype([
+    ("pos_world", "<f8", (3,)), ("quat", "<f8", (4,)), ("lin_vel_world", "<f8", (3,)), ("ang_vel_body", "<f8", (3,)),
+    ("foot_pos_world", "<f8", (12,)),
+    ("joy", "<f8", (6,)), ("movement_mode", "<f8"),
+    ("pos_d_world", "<f8", (3,)), ("pos_d_init", "<f8"), ("quat_d", "<f8", (4,)), ("lin_vel_d_rel", "<f8", (3,)),
+    ("vel_filter", LOOP_FILTER_DTYPE, (3,)), ("pos_filter", LOOP_FILTER_DTYPE, (3,)),
+    ("leg", LOOP_LEG_DTYPE, (4,)),
+    ("contacts", "<f8", (4,)), ("gait_counter", "<f8", (4,)), ("forces_body", "<f8", (12,)), ("grf_world", "<f8", (12,)),
+    ("foot_target_world", "<f8", (12,)), ("status", "<f8"), ("iterations", "<f8"), ("tick", "<f8")], align=False)
+assert LOOP_STATE_DTYPE.itemsize == 818 * 8
+
+
+class LoopParams(C.Structure):
+    """struct qmpc_loop_params."""
+
+    _fields_ = [("gait_freq", C.c_double), ("default_foot_pos_rel", C.c_double * 12), ("dt", C.c_double),
+                ("contact_height", C.c_double)]
+
+
 # struct qmpc_info: 2 x int32 + 4 doubles = 40 B
 INFO_DTYPE = np.dtype(
     [
@@ -235,8 +263,16 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.qmpc_solve8_traj.restype = i32
     lib.qmpc_solve8_device.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.qmpc_solve8_device.restype = i32
+    lib.qmpc_default_loop_params.argtypes = [C.POINTER(LoopParams)]
+    lib.qmpc_default_loop_params.restype = None
+    lib.qmpc_loop_state_init.argtypes = [vp, C.POINTER(LoopParams), vp, C.c_double, C.c_double, C.c_double]
+    lib.qmpc_loop_state_init.restype = None
+    lib.qmpc_loop_run.argtypes = [vp, C.POINTER(LoopParams), i32, vp, i32, vp, vp]
+    lib.qmpc_loop_run.restype = i32
+    lib.qmpc_loop_run_device.argtypes = [vp, C.POINTER(LoopParams), i32, vp, i32, vp, vp, vp]
+    lib.qmpc_loop_run_device.restype = i32
     for name in ("qmpc_sizeof_input", "qmpc_sizeof_params", "qmpc_sizeof_info", "qmpc_sizeof_convex_input",
-                 "qmpc_sizeof_input8"):
+                 "qmpc_sizeof_input8", "qmpc_sizeof_loop_state"):
         getattr(lib, name).argtypes = []
         getattr(lib, name).restype = i32
     if lib.qmpc_sizeof_input() != INPUT_DTYPE.itemsize:
@@ -249,6 +285,8 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         raise RuntimeError("qmpc_params ABI size mismatch")
     if lib.qmpc_sizeof_info() != INFO_DTYPE.itemsize:
         raise RuntimeError("qmpc_info ABI size mismatch")
+    if lib.qmpc_sizeof_loop_state() != LOOP_STATE_DTYPE.itemsize:
+        raise RuntimeError("qmpc_loop_state ABI size mismatch")
     return lib
 
 
@@ -288,6 +326,11 @@ EXPORTED_SYMBOLS = (
     "qmpc_leg_kinematics",
     "qmpc_torque_map",
     "qmpc_torque_map_device",
+    "qmpc_default_loop_params",
+    "qmpc_loop_state_init",
+    "qmpc_loop_run",
+    "qmpc_loop_run_device",
+    "qmpc_sizeof_loop_state",
 )
 
 
@@ -314,8 +357,53 @@ def default_biped8_params(horizon: int = 16, mode: int = MODE_CONVERGED, lib: C.
     return p
 
 
+def default_loop_params(lib: C.CDLL | None = None) -> LoopParams:
+    lib = lib or load_library()
+    lp = LoopParams()
+    lib.qmpc_default_loop_params(C.byref(lp))
+    return lp
+
+
+def loop_states(commands, lp: LoopParams | None = None, height: float = 0.3, yaw=0.0, lib: C.CDLL | None = None) -> np.ndarray:
+    """qmpc_loop_state records of robots standing at `height` over their default footholds.
+    commands: [B][7] = joy.{velx, vely, body_height, roll_rate, pitch_rate, yaw_rate}, movement_mode."""
+    lib = lib or load_library()
+    lp = lp or default_loop_params(lib)
+    commands = np.atleast_2d(np.asarray(commands, dtype=np.float64))
+    yaws = np.broadcast_to(np.asarray(yaw, dtype=np.float64), (commands.shape[0],))
+    out = np.zeros(commands.shape[0], dtype=LOOP_STATE_DTYPE)
+    for i, c in enumerate(commands):
+        joy = np.ascontiguousarray(c[:6])
+        lib.qmpc_loop_state_init(C.c_void_p(out[i:i + 1].ctypes.data), C.byref(lp), _ptr(joy), float(c[6]), float(height),
+                                 float(yaws[i]))
+    return out
+
+
 class Solver:
     """Thin RAII wrapper over a qmpc_handle (one per GPU, single caller)."""
+
+    def loop_run(self, states: np.ndarray, ticks: int, lp: LoopParams | None = None, trace: bool = False):
+        """`ticks` ticks of the device-resident closed loop (front end + solve + plant per tick, state in HBM).
+        Returns the final states (and, with trace, forces [ticks][B][12] and contacts [ticks][B][4])."""
+        lp = lp or default_loop_params(self.lib)
+        st = np.ascontiguousarray(states, dtype=LOOP_STATE_DTYPE).copy()
+        B = st.shape[0]
+        tf = np.zeros((ticks, B, 12)) if trace else None
+        tc = np.zeros((ticks, B, 4)) if trace else None
+        rc = self.lib.qmpc_loop_run(self._h, C.byref(lp), B, _ptr(st), int(ticks), _ptr(tf), _ptr(tc))
+        if rc != OK:
+            raise QmpcError(rc, "qmpc_loop_run")
+        return (st, tf, tc) if trace else st
+
+    def loop_run_device(self, batch: int, d_states: int, ticks: int, lp: LoopParams | None = None, d_trace_forces: int = 0,
+                        d_trace_contacts: int = 0, stream: int = 0):
+        lp = lp or default_loop_params(self.lib)
+        rc = self.lib.qmpc_loop_run_device(self._h, C.byref(lp), int(batch), C.c_void_p(d_states), int(ticks),
+                                           C.c_void_p(d_trace_forces) if d_trace_forces else None,
+                                           C.c_void_p(d_trace_contacts) if d_trace_contacts else None,
+                                           C.c_void_p(stream) if stream else None)
+        if rc != OK:
+            raise QmpcError(rc, "qmpc_loop_run_device")
 
     def __init__(self, params: Params, max_batch: int, device: int = 0, lib: C.CDLL | None = None):
         self.lib = lib or load_library()

@@ -7,6 +7,7 @@
 // records.  No CPU fallback exists here: with no HIP device every entry point returns
 // QMPC_NO_DEVICE.
 #include "qmpc_kernels.hip"
+#include "qmpc_loop.hip"
 
 #include <dlfcn.h>
 
@@ -37,6 +38,7 @@ struct qmpc_handle {
   size_t lds_bytes;       // LDS-resident gains
   size_t lds_bytes_g;     // gains in the global workspace
   size_t lds_bytes_s;     // gains and slack arrays in the global workspace
+  int* d_loop_row;        // trace row counter of the closed loop (qmpc_loop_run*)
   double* d_leg;          // staging of the host-buffer leg calls (grown on demand, freed with the handle)
   size_t leg_cap;         // its capacity in doubles
   double* d_gws;          // [max_batch][N*(156+84)] workspace of the global-gains variant
@@ -284,6 +286,7 @@ void qmpc_destroy(qmpc_handle* h) {
   if (h->d_forces) (void)hipFree(h->d_forces);
   if (h->d_gws) (void)hipFree(h->d_gws);
   if (h->d_leg) (void)hipFree(h->d_leg);
+  if (h->d_loop_row) (void)hipFree(h->d_loop_row);
   if (h->d_info) (void)hipFree(h->d_info);
   if (h->d_traj_u) (void)hipFree(h->d_traj_u);
   if (h->d_traj_x) (void)hipFree(h->d_traj_x);
@@ -317,9 +320,9 @@ static int pick_variant(const qmpc_handle* h, int32_t batch) {
 static bool use_global_gains(const qmpc_handle* h, int32_t batch) { return pick_variant(h, batch) >= 1; }
 
 static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces,
-                                qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s) {
+                                qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s, bool timed = true) {
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;   // the gains workspace is sized by max_batch
-  HIP_TRY(hipEventRecord(h->ev0, s));
+  if (timed) HIP_TRY(hipEventRecord(h->ev0, s));
   const int var = pick_variant(h, batch);
   const size_t lds = var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes);
   double* gws = var >= 1 ? h->d_gws : nullptr;
@@ -340,8 +343,10 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
   }
 #undef QMPC_LAUNCH
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(h->ev1, s));
-  h->timed = true;
+  if (timed) {
+    HIP_TRY(hipEventRecord(h->ev1, s));
+    h->timed = true;
+  }
   return QMPC_OK;
 }
 
@@ -581,6 +586,7 @@ static qmpc_status leg_host(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t 
   // layout: q[12B] f[12B] c[4B] p[12B] J[36B] tau[12B]; the staging buffer belongs to the handle and only grows
   if (h->leg_cap < B * 88) {
     if (h->d_leg) (void)hipFree(h->d_leg);
+  if (h->d_loop_row) (void)hipFree(h->d_loop_row);
     h->d_leg = nullptr;
     h->leg_cap = 0;
     HIP_TRY(hipMalloc(&h->d_leg, sizeof(double) * B * 88));
@@ -616,6 +622,130 @@ qmpc_status qmpc_torque_map(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t 
   if (!h || !g || batch < 0 || (batch > 0 && (!joint_pos || !forces_body || !tau))) return QMPC_BAD_ARGUMENT;
   if (batch == 0) return QMPC_OK;
   return leg_host(h, g, batch, joint_pos, forces_body, contacts, walking, nullptr, nullptr, tau);
+}
+
+// ---- device-resident closed loop (kernels in qmpc_loop.hip) ----------------
+int32_t qmpc_sizeof_loop_state(void) { return (int32_t)sizeof(qmpc_loop_state); }
+static_assert(sizeof(qmpc_loop_state) == 8 * 818, "qmpc_loop_state is 818 doubles");
+
+void qmpc_default_loop_params(qmpc_loop_params* p) {
+  std::memset(p, 0, sizeof *p);
+  p->gait_freq = 2.2;                                               // LeggedState.h / yaml gait_freq
+  const double f[4][3] = {{0.20, 0.14, -0.3}, {0.20, -0.14, -0.3}, {-0.20, 0.14, -0.3}, {-0.20, -0.14, -0.3}};
+  for (int l = 0; l < 4; ++l)
+    for (int a = 0; a < 3; ++a) p->default_foot_pos_rel[3 * l + a] = f[l][a];   // yaml default_foot_pos_*
+  p->dt = 5.0 / 1000.0;
+  p->contact_height = 1e-3;
+}
+
+void qmpc_loop_state_init(qmpc_loop_state* s, const qmpc_loop_params* lp, const double joy[6], double movement_mode,
+                          double height, double yaw) {
+  std::memset(s, 0, sizeof *s);
+  s->pos_world[2] = height;
+  s->quat[0] = std::cos(0.5 * yaw);
+  s->quat[3] = std::sin(0.5 * yaw);
+  double R[9], Rz[9];
+  qmpc_loop::quat_to_rot(s->quat, R);
+  qmpc_loop::rot_to_rot_z(R, Rz);
+  for (int l = 0; l < 4; ++l)
+    for (int r = 0; r < 3; ++r)
+      s->foot_pos_world[3 * l + r] = Rz[3 * r] * lp->default_foot_pos_rel[3 * l] + Rz[3 * r + 1] * lp->default_foot_pos_rel[3 * l + 1] +
+                                     Rz[3 * r + 2] * lp->default_foot_pos_rel[3 * l + 2] + s->pos_world[r];
+  for (int a = 0; a < 6; ++a) s->joy[a] = joy[a];
+  s->movement_mode = movement_mode;
+  for (int a = 0; a < 3; ++a) s->pos_d_world[a] = s->pos_world[a];
+  s->pos_d_init = 1.0;
+  for (int a = 0; a < 4; ++a) s->quat_d[a] = s->quat[a];
+  for (int l = 0; l < 4; ++l) {          // LeggedContactFSM::reset_params (:4-9) + set_default_gait_pattern
+    qmpc_loop_leg& L = s->leg[l];
+    L.state = 1.0;
+    L.pattern_index = 0.0;
+    L.prev_pattern_index = 1.0;
+    L.start_time = 0.0;
+    L.end_time = 0.5;
+    s->contacts[l] = 1.0;
+  }
+}
+
+qmpc_status qmpc_loop_run_device(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* d_states,
+                                 int32_t ticks, double* d_trace_forces, double* d_trace_contacts, void* stream) {
+  if (!h || !lp || batch < 0 || ticks < 0 || (batch > 0 && !d_states)) return QMPC_BAD_ARGUMENT;
+  if (h->params.model != QMPC_MODEL_QUAT) return QMPC_BAD_ARGUMENT;
+  if (batch == 0 || ticks == 0) return QMPC_OK;
+  if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  if (!h->d_loop_row) HIP_TRY(hipMalloc(&h->d_loop_row, sizeof(int)));
+  const int minus1 = -1;
+  HIP_TRY(hipMemcpyAsync(h->d_loop_row, &minus1, sizeof(int), hipMemcpyHostToDevice, s));
+  const unsigned blocks = (unsigned)((batch + 63) / 64);
+  const qmpc_loop_params LP = *lp;
+  auto one_tick = [&]() -> qmpc_status {
+    hipLaunchKernelGGL(qmpc_loop_front_kernel, dim3(blocks), dim3(64), 0, s, LP, d_states, h->d_in, h->d_loop_row, (int)batch);
+    HIP_TRY(hipGetLastError());
+    const qmpc_status st = launch_solve(h, batch, h->d_in, h->d_forces, h->d_info, nullptr, nullptr, s, /*timed=*/false);
+    if (st != QMPC_OK) return st;
+    hipLaunchKernelGGL(qmpc_loop_post_kernel, dim3(blocks), dim3(64), 0, s, h->dev, LP, d_states, (const double*)h->d_forces,
+                       (const qmpc_info*)h->d_info, d_trace_forces, d_trace_contacts, (const int*)h->d_loop_row, (int)batch);
+    HIP_TRY(hipGetLastError());
+    return QMPC_OK;
+  };
+  // one tick = three kernels: captured once into a graph and replayed (the sequence is launch-bound for small
+  // batches); plain launches when capture is not available on this stream
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  bool captured = false;
+  if (ticks > 1 && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+    const qmpc_status st = one_tick();
+    const hipError_t ee = hipStreamEndCapture(s, &graph);
+    if (st == QMPC_OK && ee == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess)
+      captured = true;
+    else
+      (void)hipGetLastError();
+  }
+  qmpc_status rs = QMPC_OK;
+  for (int t = 0; t < ticks && rs == QMPC_OK; ++t) {
+    if (captured) {
+      if (hipGraphLaunch(exec, s) != hipSuccess) rs = QMPC_HIP_ERROR;
+    } else {
+      rs = one_tick();
+    }
+  }
+  if (exec) {
+    (void)hipStreamSynchronize(s);        // the executable graph must outlive its launches
+    (void)hipGraphExecDestroy(exec);
+  }
+  if (graph) (void)hipGraphDestroy(graph);
+  return rs;
+}
+
+qmpc_status qmpc_loop_run(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* states,
+                          int32_t ticks, double* trace_forces, double* trace_contacts) {
+  if (!h || !lp || batch < 0 || ticks < 0 || (batch > 0 && !states)) return QMPC_BAD_ARGUMENT;
+  if (h->params.model != QMPC_MODEL_QUAT) return QMPC_BAD_ARGUMENT;
+  if (batch == 0 || ticks == 0) return QMPC_OK;
+  if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
+  HIP_TRY(hipSetDevice(h->device));
+  qmpc_loop_state* d_st = nullptr;
+  double *d_tf = nullptr, *d_tc = nullptr;
+  const size_t B = (size_t)batch, T = (size_t)ticks;
+  qmpc_status rs = QMPC_OK;
+  do {
+    if (hipMalloc(&d_st, sizeof(qmpc_loop_state) * B) != hipSuccess) { rs = QMPC_HIP_ERROR; break; }
+    if (trace_forces && hipMalloc(&d_tf, sizeof(double) * 12 * B * T) != hipSuccess) { rs = QMPC_HIP_ERROR; break; }
+    if (trace_contacts && hipMalloc(&d_tc, sizeof(double) * 4 * B * T) != hipSuccess) { rs = QMPC_HIP_ERROR; break; }
+    if (hipMemcpyAsync(d_st, states, sizeof(qmpc_loop_state) * B, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rs = QMPC_HIP_ERROR; break; }
+    rs = qmpc_loop_run_device(h, lp, batch, d_st, ticks, d_tf, d_tc, nullptr);
+    if (rs != QMPC_OK) break;
+    if (hipMemcpyAsync(states, d_st, sizeof(qmpc_loop_state) * B, hipMemcpyDeviceToHost, h->stream) != hipSuccess) { rs = QMPC_HIP_ERROR; break; }
+    if (d_tf && hipMemcpyAsync(trace_forces, d_tf, sizeof(double) * 12 * B * T, hipMemcpyDeviceToHost, h->stream) != hipSuccess) { rs = QMPC_HIP_ERROR; break; }
+    if (d_tc && hipMemcpyAsync(trace_contacts, d_tc, sizeof(double) * 4 * B * T, hipMemcpyDeviceToHost, h->stream) != hipSuccess) { rs = QMPC_HIP_ERROR; break; }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) rs = QMPC_HIP_ERROR;
+  } while (0);
+  if (d_st) (void)hipFree(d_st);
+  if (d_tf) (void)hipFree(d_tf);
+  if (d_tc) (void)hipFree(d_tc);
+  return rs;
 }
 
 // Diagnostic: per-instance phase cycle counts (s_memtime) of one solve launch.

@@ -1,0 +1,311 @@
+// qmpc_loop.hip -- device-resident closed loop around the MPC solve: the step before the
+// path (goal, gait FSM, swing quintic, Raibert footholds, record packing), the path (qmpc_solve_kernel) and a
+// single-rigid-body plant, chained per tick on one stream with every instance's state kept in HBM
+// (qmpc_loop_state, include/qmpc.h).  One thread per instance in the front / post kernels: they are a few hundred
+// flops of branchy scalar logic per tick, against ~10^6 for the solve.
+//
+// Reference arithmetic mirrored here (legged_ctrl/):
+//   src/mpc/QuatMpc.cpp:68-107        goal_update              (host twin: host/QuatMpcHip.h)
+//   src/mpc/QuatMpc.cpp:278-305       foot_update
+//   src/utils/LeggedContactFSM.cpp:11-86,208-246,261-270   gait FSM        (host twin: host/LeggedContactFSMHip.h)
+//   src/utils/Utils.cpp:236-293       swing-foot quintic       (host twin: host/SwingTrajectoryHip.h)
+//   src/interfaces/BaseInterface.cpp:266-288  Raibert foothold targets
+//   include/utils/MovingWindowFilter.hpp:14-63  Neumaier moving average (host twin: host/MovingWindowFilter.h)
+//   src/mpc/QuatMpc.cpp:112-176,231-246,263-273  record packing, outputs
+// Floating-point contraction is switched off in the controller-side functions: the contact schedule must be
+// bit-exact against the host classes (compare-and-add state machine), and g++ does not fuse on the host.
+#pragma once
+
+#include "qmpc_device.h"      // DevParams; included after qmpc_kernels.hip by qmpc_hip.hip
+#include "qmpc_loop_math.h"
+
+namespace qmpc {
+
+__device__ inline double loop_filter(qmpc_loop_filter& f, double v) {   // MovingWindowFilter.hpp:28-62
+#pragma clang fp contract(off)
+  auto neumaier = [&](double a) {
+#pragma clang fp contract(off)
+    const double ns = f.sum + a;
+    if (fabs(f.sum) >= fabs(a)) f.correction += (f.sum - ns) + a;
+    else f.correction += (a - ns) + f.sum;
+    f.sum = ns;
+  };
+  int head = (int)f.head, count = (int)f.count;
+  if (count == QMPC_LOOP_WINDOW) neumaier(-f.ring[head]);
+  else ++count;
+  neumaier(v);
+  f.ring[head] = v;
+  head = (head + 1) % QMPC_LOOP_WINDOW;
+  f.head = (double)head;
+  f.count = (double)count;
+  return (f.sum + f.correction) / (double)QMPC_LOOP_WINDOW;
+}
+
+// QuinticCurve::get_foot_swing_target (Utils.cpp:236-293): matrix entries and powers of t in FLOAT (t, T are float
+// arguments upstream), the 6x6 solve in double (Gaussian elimination with partial pivoting, three right-hand sides)
+__device__ inline void loop_swing_target(float t, float T, const double* start, const double* fin, double* out) {
+#pragma clang fp contract(off)
+  double Cm[6][6] = {{1, 0, 0, 0, 0, 0},
+                     {1, T, T * T, T * T * T, T * T * T * T, T * T * T * T * T},
+                     {0, 1, 0, 0, 0, 0},
+                     {0, 1, 2 * T, 3 * T * T, 4 * T * T * T, 5 * T * T * T * T},
+                     {1, T / 2, T * T / 4, T * T * T / 8, T * T * T * T / 16, T * T * T * T * T / 32},
+                     {0, 1, T, 3 * T * T / 4, 4 * T * T * T / 8, 5 * T * T * T * T / 16}};
+  const double dx = fin[0] - start[0], dy = fin[1] - start[1];
+  const double k = 1.26 / T;
+  const double v_xy_mid = k * sqrt(dx * dx + dy * dy);
+  const double theta = atan2(fabs(dy), fabs(dx));
+  const double v_x_mid = (dx >= 0 ? 1 : -1) * v_xy_mid * cos(theta);
+  const double v_y_mid = (dy >= 0 ? 1 : -1) * v_xy_mid * sin(theta);
+  double b[6][3] = {{start[0], start[1], start[2]}, {fin[0], fin[1], fin[2]}, {0.0, 0.0, 0.1}, {0.0, 0.0, -0.1},
+                    {(start[0] + fin[0]) / 2, (start[1] + fin[1]) / 2, 0.1}, {v_x_mid, v_y_mid, 0.0}};
+  for (int col = 0; col < 6; ++col) {
+    int piv = col;
+    for (int i = col + 1; i < 6; ++i)
+      if (fabs(Cm[i][col]) > fabs(Cm[piv][col])) piv = i;
+    if (piv != col) {
+      for (int j = 0; j < 6; ++j) { const double tmp = Cm[col][j]; Cm[col][j] = Cm[piv][j]; Cm[piv][j] = tmp; }
+      for (int r = 0; r < 3; ++r) { const double tmp = b[col][r]; b[col][r] = b[piv][r]; b[piv][r] = tmp; }
+    }
+    for (int i = col + 1; i < 6; ++i) {
+      const double f = Cm[i][col] / Cm[col][col];
+      for (int j = col; j < 6; ++j) Cm[i][j] -= f * Cm[col][j];
+      for (int r = 0; r < 3; ++r) b[i][r] -= f * b[col][r];
+    }
+  }
+  const double td = t;
+  const float t2 = t * t, t3 = t * t * t, t4 = t * t * t * t, t5 = t * t * t * t * t;
+  for (int ax = 0; ax < 3; ++ax) {
+    double c[6];
+    for (int i = 5; i >= 0; --i) {
+      double s = b[i][ax];
+      for (int j = i + 1; j < 6; ++j) s -= Cm[i][j] * c[j];
+      c[i] = s / Cm[i][i];
+    }
+    out[ax] = c[0] + c[1] * td + c[2] * t2 + c[3] * t3 + c[4] * t4 + c[5] * t5;
+    out[3 + ax] = c[1] + 2 * c[2] * td + 3 * c[3] * t2 + 4 * c[4] * t3 + 5 * c[5] * t4;
+    out[6 + ax] = 2 * c[2] + 6 * c[3] * td + 12 * c[4] * t2 + 20 * c[5] * t3;
+  }
+}
+
+// trot pattern of set_default_gait_pattern (LeggedContactFSM.cpp:87-108): legs 0,3 = [STANCE, SWING], legs 1,2 =
+// [SWING, STANCE]; switch times 0.5, 1.0
+__device__ __forceinline__ double loop_pattern(int leg, int idx) {
+  const bool first_stance = (leg == 0 || leg == 3);
+  return (idx == 0) == first_stance ? 1.0 : 0.0;
+}
+__device__ __forceinline__ double loop_switch_time(int idx) { return idx == 0 ? 0.5 : 1.0; }
+
+__device__ inline void loop_fsm_common_enter(qmpc_loop_leg& L) {   // :208-223
+#pragma clang fp contract(off)
+  const int prev = (int)L.pattern_index;
+  const int idx = (prev + 1) % 2;
+  L.prev_pattern_index = (double)prev;
+  L.pattern_index = (double)idx;
+  if (idx < prev) L.gait_phase -= 1.0;
+  L.start_time = L.gait_phase;
+  L.end_time = loop_switch_time(idx);
+}
+__device__ inline double loop_fsm_percent(const qmpc_loop_leg& L) {   // :261-270
+#pragma clang fp contract(off)
+  double percent = (L.gait_phase - L.start_time) / (L.end_time - L.start_time);
+  if (percent < 0.0) percent = 0.0;
+  else if (percent > 1.0) percent = 1.0;
+  return percent;
+}
+__device__ inline void loop_fsm_reset(qmpc_loop_leg& L, int leg) {   // :11-31
+  L.gait_phase = 0.0;
+  L.pattern_index = 0.0;
+  L.prev_pattern_index = 1.0;
+  L.start_time = 0.0;
+  L.end_time = loop_switch_time(0);
+  if (L.state == 0.0) {
+    for (int a = 0; a < 3; ++a) { L.fsm_pos[a] = L.swing_end[a]; L.fsm_vel[a] = 0.0; }
+  }
+  L.state = loop_pattern(leg, 0);
+  L.not_first_call = 0.0;
+}
+__device__ inline double loop_fsm_update(qmpc_loop_leg& L, double dt, double gait_freq, const double* cur,
+                                         const double* tgt, bool flag) {   // :33-78
+#pragma clang fp contract(off)
+  if (L.not_first_call == 0.0) {
+    for (int a = 0; a < 3; ++a) {
+      L.swing_start[a] = cur[a];
+      L.swing_end[a] = tgt[a];
+      L.fsm_pos[a] = tgt[a];
+      L.fsm_vel[a] = 0.0;
+    }
+    L.not_first_call = 1.0;
+  }
+  L.gait_phase += gait_freq * dt;
+  if (L.state == 1.0) {
+    if (L.gait_phase >= L.end_time) {
+      L.terrain_height = cur[2];                        // stance_exit
+      loop_fsm_common_enter(L);                         // swing_enter
+      for (int a = 0; a < 3; ++a) { L.swing_start[a] = cur[a]; L.swing_extend[a] = 0.0; }
+      L.state = 0.0;
+    }
+  } else {
+    if ((loop_fsm_percent(L) > 0.9 && flag) || loop_fsm_percent(L) >= 1.0) {
+      L.state = 1.0;
+      loop_fsm_common_enter(L);                         // stance_enter
+      for (int a = 0; a < 3; ++a) { L.fsm_pos[a] = cur[a]; L.fsm_vel[a] = 0.0; }
+    }
+  }
+  if (L.state == 0.0) {                                 // swing_update
+    const double t = loop_fsm_percent(L);
+    double fin[3], out[9];
+    for (int a = 0; a < 3; ++a) fin[a] = tgt[a] + L.swing_extend[a];
+    loop_swing_target((float)(0.5 * t / gait_freq), (float)(0.5 / gait_freq), L.swing_start, fin, out);
+    for (int a = 0; a < 3; ++a) { L.fsm_pos[a] = out[a]; L.fsm_vel[a] = out[3 + a]; L.fsm_acc[a] = out[6 + a]; }
+  }
+  return L.gait_phase;
+}
+
+// ---- front end of one tick: feedback, Raibert, goal_update, foot_update, record ---------------
+__global__ __launch_bounds__(64) void qmpc_loop_front_kernel(qmpc_loop_params LP, qmpc_loop_state* __restrict__ st,
+                                                             qmpc_input* __restrict__ rec, int* __restrict__ row,
+                                                             int batch) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && row) *row += 1;                         // trace row of this tick (stream order: after the last post)
+  if (i >= batch) return;
+  qmpc_loop_state& s = st[i];
+  // feedback the controller reads (BaseInterface::fbk_update): R, R_z, foot_pos_body, contact flags
+  double R[9], Rz[9];
+  qmpc_loop::quat_to_rot(s.quat, R);
+  qmpc_loop::rot_to_rot_z(R, Rz);
+  double foot_body[12], flag[4];
+  for (int l = 0; l < 4; ++l) {
+    const double d[3] = {s.foot_pos_world[3 * l] - s.pos_world[0], s.foot_pos_world[3 * l + 1] - s.pos_world[1],
+                         s.foot_pos_world[3 * l + 2] - s.pos_world[2]};
+    for (int a = 0; a < 3; ++a) foot_body[3 * l + a] = R[a] * d[0] + R[3 + a] * d[1] + R[6 + a] * d[2];
+    flag[l] = (s.foot_pos_world[3 * l + 2] <= LP.contact_height) ? 1.0 : 0.0;
+  }
+  // Raibert foothold targets (BaseInterface.cpp:266-288), with last tick's ctrl.torso_lin_vel_d_rel
+  double tgt_world[12];
+  {
+    double vrel[3];
+    for (int r = 0; r < 3; ++r) vrel[r] = Rz[r] * s.lin_vel_world[0] + Rz[3 + r] * s.lin_vel_world[1] + Rz[6 + r] * s.lin_vel_world[2];
+    const double k = sqrt(fabs(s.pos_world[2]) / 9.81);
+    double d[3] = {0.0, 0.0, 0.0};
+    d[0] = k * (vrel[0] - s.lin_vel_d_rel[0]) + (1.0 / LP.gait_freq) / 2.0 * s.lin_vel_d_rel[0];
+    if (d[0] < -0.5) d[0] = -0.5;
+    if (d[0] > 0.5) d[0] = 0.5;
+    d[1] = k * (vrel[1] - s.lin_vel_d_rel[1]) + (1.0 / LP.gait_freq) / 2.0 * s.lin_vel_d_rel[1];
+    if (d[1] < -0.3) d[1] = -0.3;
+    if (d[1] > 0.3) d[1] = 0.3;
+    double dabs[3];
+    for (int r = 0; r < 3; ++r) dabs[r] = Rz[3 * r] * d[0] + Rz[3 * r + 1] * d[1] + Rz[3 * r + 2] * d[2];
+    for (int l = 0; l < 4; ++l) {
+      double ab[3];
+      for (int r = 0; r < 3; ++r)
+        ab[r] = Rz[3 * r] * LP.default_foot_pos_rel[3 * l] + Rz[3 * r + 1] * LP.default_foot_pos_rel[3 * l + 1] +
+                Rz[3 * r + 2] * LP.default_foot_pos_rel[3 * l + 2];
+      ab[0] += dabs[0];
+      ab[1] += dabs[1];
+      for (int r = 0; r < 3; ++r) tgt_world[3 * l + r] = ab[r] + s.pos_world[r];
+    }
+  }
+  // goal_update (QuatMpc.cpp:68-107)
+  double vel_f[3], pos_f[3], wd[3];
+  {
+    if (s.pos_d_init == 0.0) {
+      for (int a = 0; a < 3; ++a) s.pos_d_world[a] = s.pos_world[a];
+      s.pos_d_init = 1.0;
+    }
+    s.lin_vel_d_rel[0] = s.joy[0];
+    s.lin_vel_d_rel[1] = s.joy[1];
+    s.lin_vel_d_rel[2] = 0.0;
+    double vw[3], vb[3];
+    for (int r = 0; r < 3; ++r)
+      vw[r] = Rz[3 * r] * s.lin_vel_d_rel[0] + Rz[3 * r + 1] * s.lin_vel_d_rel[1] + Rz[3 * r + 2] * s.lin_vel_d_rel[2];
+    for (int r = 0; r < 3; ++r) vb[r] = R[r] * vw[0] + R[3 + r] * vw[1] + R[6 + r] * vw[2];
+    for (int a = 0; a < 3; ++a) vel_f[a] = loop_filter(s.vel_filter[a], vb[a]);
+    wd[0] = s.joy[3]; wd[1] = s.joy[4]; wd[2] = s.joy[5];
+    s.pos_d_world[0] += vw[0] * 5.0 / 1000.0;
+    s.pos_d_world[1] += vw[1] * 5.0 / 1000.0;
+    s.pos_d_world[2] = s.joy[2];
+    double dp[3], pb[3];
+    for (int a = 0; a < 3; ++a) dp[a] = s.pos_d_world[a] - s.pos_world[a];
+    for (int r = 0; r < 3; ++r) pb[r] = R[r] * dp[0] + R[3 + r] * dp[1] + R[6 + r] * dp[2];
+    for (int a = 0; a < 3; ++a) pos_f[a] = loop_filter(s.pos_filter[a], pb[a]);
+  }
+  // foot_update (QuatMpc.cpp:278-305)
+  if (s.movement_mode == 0.0) {
+    for (int l = 0; l < 4; ++l) {
+      loop_fsm_reset(s.leg[l], l);
+      s.contacts[l] = 1.0;
+    }
+  } else {
+    for (int l = 0; l < 4; ++l)
+      s.gait_counter[l] = loop_fsm_update(s.leg[l], 5.0 / 1000.0, LP.gait_freq, &s.foot_pos_world[3 * l], &tgt_world[3 * l],
+                                          flag[l] != 0.0);
+    for (int l = 0; l < 4; ++l) s.contacts[l] = s.leg[l].state;
+  }
+  for (int l = 0; l < 4; ++l)
+    for (int a = 0; a < 3; ++a) s.foot_target_world[3 * l + a] = s.leg[l].fsm_pos[a];   // QuatMpc.cpp:270
+  // record (QuatMpc.cpp:112-176,231-246): torso_quat_d += 1/2 G(quat_d) w_d 5 ms, normalised
+  {
+    double* qd = s.quat_d;
+    const double gw[4] = {-qd[1] * wd[0] - qd[2] * wd[1] - qd[3] * wd[2], qd[0] * wd[0] - qd[3] * wd[1] + qd[2] * wd[2],
+                          qd[3] * wd[0] + qd[0] * wd[1] - qd[1] * wd[2], -qd[2] * wd[0] + qd[1] * wd[1] + qd[0] * wd[2]};
+    for (int a = 0; a < 4; ++a) qd[a] += 0.5 * gw[a] * 5.0 / 1000.0;
+    const double n = sqrt(qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]);
+    for (int a = 0; a < 4; ++a) qd[a] = qd[a] / n;
+  }
+  qmpc_input& in = rec[i];
+  for (int a = 0; a < 4; ++a) { in.quat[a] = s.quat[a]; in.quat_d[a] = s.quat_d[a]; in.contacts[a] = (s.contacts[a] != 0.0) ? 1.0 : 0.0; }
+  for (int a = 0; a < 9; ++a) in.rot[a] = R[a];
+  for (int r = 0; r < 3; ++r) {
+    in.lin_vel_body[r] = R[r] * s.lin_vel_world[0] + R[3 + r] * s.lin_vel_world[1] + R[6 + r] * s.lin_vel_world[2];
+    in.ang_vel_body[r] = s.ang_vel_body[r];
+    in.pos_ref_body[r] = pos_f[r];
+    in.vel_ref_body[r] = vel_f[r];
+    in.acc_ref_body[r] = 0.0;
+  }
+  for (int a = 0; a < 12; ++a) in.foot_pos_body[a] = foot_body[a];
+}
+
+// ---- back end of one tick: outputs (QuatMpc.cpp:263-273), plant step, swing feet -----------------
+__global__ __launch_bounds__(64) void qmpc_loop_post_kernel(DevParams P, qmpc_loop_params LP, qmpc_loop_state* __restrict__ st,
+                                                            const double* __restrict__ forces,
+                                                            const qmpc_info* __restrict__ info, double* __restrict__ trace_f,
+                                                            double* __restrict__ trace_c, const int* __restrict__ row,
+                                                            int batch) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch) return;
+  qmpc_loop_state& s = st[i];
+  const int status = info[i].status;
+  s.status = (double)status;
+  s.iterations = (double)info[i].iterations;
+  if (status == QMPC_OK || status == QMPC_MAX_ITER)     // otherwise the previous forces stay (host/QuatMpcHip.h)
+    for (int a = 0; a < 12; ++a) s.forces_body[a] = forces[12 * (size_t)i + a];
+  double R[9];
+  qmpc_loop::quat_to_rot(s.quat, R);
+  for (int l = 0; l < 4; ++l)
+    for (int r = 0; r < 3; ++r)
+      s.grf_world[3 * l + r] = R[3 * r] * s.forces_body[3 * l] + R[3 * r + 1] * s.forces_body[3 * l + 1] +
+                               R[3 * r + 2] * s.forces_body[3 * l + 2];
+  if (trace_f || trace_c) {
+    const size_t t = (size_t)(*row);
+    if (trace_f) for (int a = 0; a < 12; ++a) trace_f[(t * batch + i) * 12 + a] = s.forces_body[a];
+    if (trace_c) for (int a = 0; a < 4; ++a) trace_c[(t * batch + i) * 4 + a] = s.contacts[a];
+  }
+  // plant: rigid body under the applied forces, feet fixed during the step
+  double x[13];
+  for (int a = 0; a < 3; ++a) { x[a] = s.pos_world[a]; x[7 + a] = s.lin_vel_world[a]; x[10 + a] = s.ang_vel_body[a]; }
+  for (int a = 0; a < 4; ++a) x[3 + a] = s.quat[a];
+  qmpc_loop::plant_step(x, s.forces_body, s.foot_pos_world, 4, P.mass, P.Iinv, LP.dt);
+  for (int a = 0; a < 3; ++a) { s.pos_world[a] = x[a]; s.lin_vel_world[a] = x[7 + a]; s.ang_vel_body[a] = x[10 + a]; }
+  for (int a = 0; a < 4; ++a) s.quat[a] = x[3 + a];
+  // swing feet track their FSM target perfectly; stance feet stay where they are
+  if (s.movement_mode != 0.0)
+    for (int l = 0; l < 4; ++l)
+      if (s.contacts[l] == 0.0)
+        for (int a = 0; a < 3; ++a) s.foot_pos_world[3 * l + a] = s.leg[l].fsm_pos[a];
+  s.tick += 1.0;
+}
+
+}  // namespace qmpc

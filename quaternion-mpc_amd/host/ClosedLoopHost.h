@@ -1,0 +1,139 @@
+// ClosedLoopHost.h -- CPU reference of the device-resident closed loop (csrc/qmpc_loop.hip):
+// the SAME tick, built from the host classes that mirror the reference (QuatMpcHipT: goal_update / foot_update /
+// grf_update, LeggedContactFSMHip, MovingWindowFilterHip, raibert_foot_targets) plus the shared plant of
+// csrc/qmpc_loop_math.h.  One instance, one B = 1 solve per tick through the C ABI -- i.e. exactly how the drop-in
+// runs inside the reference's mpc_thread -- so that the batched device loop can be checked against it tick for tick.
+//
+//   tick:  feedback from the plant state  (R, R_z, foot_pos_body, contact flags; BaseInterface::fbk_update)
+//          raibert_foot_targets           (BaseInterface.cpp:266-288)
+//          mpc.update(state)              (QuatMpc.cpp:57-66)
+//          plant step under ctrl.optimized_input[0:12]; swing feet go to their FSM targets
+#pragma once
+
+#include "../csrc/qmpc_loop_math.h"
+#include "QuatMpcHip.h"
+#include "SwingTrajectoryHip.h"
+
+namespace legged {
+
+template <class State>
+class ClosedLoopHostT {
+ public:
+  ClosedLoopHostT(const QmpcApi& api, const qmpc_loop_params& lp, const qmpc_loop_state& init, int horizon, int device)
+      : lp_(lp) {
+    state.param.mpc_horizon = horizon;
+    state.param.gait_freq = lp.gait_freq;
+    for (int l = 0; l < NUM_LEG; ++l)
+      for (int a = 0; a < 3; ++a) state.param.default_foot_pos_rel(a, l) = lp.default_foot_pos_rel[3 * l + a];
+    for (int a = 0; a < 3; ++a) { x_[a] = init.pos_world[a]; x_[7 + a] = init.lin_vel_world[a]; x_[10 + a] = init.ang_vel_body[a]; }
+    for (int a = 0; a < 4; ++a) x_[3 + a] = init.quat[a];
+    for (int a = 0; a < 12; ++a) feet_[a] = init.foot_pos_world[a];
+    state.joy.velx = init.joy[0]; state.joy.vely = init.joy[1]; state.joy.body_height = init.joy[2];
+    state.joy.roll_rate = init.joy[3]; state.joy.pitch_rate = init.joy[4]; state.joy.yaw_rate = init.joy[5];
+    state.ctrl.movement_mode = init.movement_mode;
+    state.ctrl.torso_quat_d.w() = init.quat_d[0]; state.ctrl.torso_quat_d.x() = init.quat_d[1];
+    state.ctrl.torso_quat_d.y() = init.quat_d[2]; state.ctrl.torso_quat_d.z() = init.quat_d[3];
+    for (int a = 0; a < 3; ++a) state.ctrl.torso_lin_vel_d_rel[a] = init.lin_vel_d_rel[a];
+    refresh_feedback();
+    state.estimator_init = true;
+    mpc = new QuatMpcHipT<State>(state, api, device);      // takes torso_pos_d_world from the feedback (QuatMpc.cpp:13-20)
+    double I[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) I[3 * r + c] = 1.2 * state.param.trunk_inertia(r, c);   // QuatMpc.cpp:182
+    qmpc_loop::inv3(I, Iinv_);
+  }
+  ~ClosedLoopHostT() { delete mpc; }
+
+  // what BaseInterface::fbk_update derives from the estimator for the fields the tick reads
+  void refresh_feedback() {
+    double R[9], Rz[9];
+    qmpc_loop::quat_to_rot(&x_[3], R);
+    qmpc_loop::rot_to_rot_z(R, Rz);
+    state.fbk.torso_quat.w() = x_[3]; state.fbk.torso_quat.x() = x_[4]; state.fbk.torso_quat.y() = x_[5]; state.fbk.torso_quat.z() = x_[6];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) { state.fbk.torso_rot_mat(r, c) = R[3 * r + c]; state.fbk.torso_rot_mat_z(r, c) = Rz[3 * r + c]; }
+    for (int a = 0; a < 3; ++a) {
+      state.fbk.torso_pos_world[a] = x_[a];
+      state.fbk.torso_lin_vel_world[a] = x_[7 + a];
+      state.fbk.torso_ang_vel_body[a] = x_[10 + a];
+    }
+    for (int l = 0; l < NUM_LEG; ++l) {
+      const double d[3] = {feet_[3 * l] - x_[0], feet_[3 * l + 1] - x_[1], feet_[3 * l + 2] - x_[2]};
+      for (int a = 0; a < 3; ++a) {
+        state.fbk.foot_pos_world(a, l) = feet_[3 * l + a];
+        state.fbk.foot_pos_body(a, l) = R[a] * d[0] + R[3 + a] * d[1] + R[6 + a] * d[2];
+      }
+      state.fbk.foot_contact_flag[l] = (feet_[3 * l + 2] <= lp_.contact_height) ? 1.0 : 0.0;
+    }
+  }
+
+  bool tick() {
+    refresh_feedback();
+    raibert_foot_targets(state);
+    mpc->goal_update(state);
+    mpc->foot_update(state);
+    const bool ok = mpc->grf_update(state);
+    double u[12];
+    for (int a = 0; a < 12; ++a) u[a] = state.ctrl.optimized_input[a];
+    qmpc_loop::plant_step(x_, u, feet_, NUM_LEG, state.param.robot_mass, Iinv_, lp_.dt);
+    if (state.ctrl.movement_mode != 0)
+      for (int l = 0; l < NUM_LEG; ++l)
+        if (!state.ctrl.plan_contacts[l])
+          for (int a = 0; a < 3; ++a) feet_[3 * l + a] = mpc->leg_FSM[l].FSM_foot_pos_target_world[a];
+    ticks_ += 1;
+    return ok;
+  }
+
+  // the state in the device loop's record layout (filter internals are private to the host class: left zero)
+  void export_state(qmpc_loop_state* o) const {
+    std::memset(o, 0, sizeof *o);
+    for (int a = 0; a < 3; ++a) { o->pos_world[a] = x_[a]; o->lin_vel_world[a] = x_[7 + a]; o->ang_vel_body[a] = x_[10 + a]; }
+    for (int a = 0; a < 4; ++a) o->quat[a] = x_[3 + a];
+    for (int a = 0; a < 12; ++a) o->foot_pos_world[a] = feet_[a];
+    o->joy[0] = state.joy.velx; o->joy[1] = state.joy.vely; o->joy[2] = state.joy.body_height;
+    o->joy[3] = state.joy.roll_rate; o->joy[4] = state.joy.pitch_rate; o->joy[5] = state.joy.yaw_rate;
+    o->movement_mode = state.ctrl.movement_mode;
+    for (int a = 0; a < 3; ++a) { o->pos_d_world[a] = state.ctrl.torso_pos_d_world[a]; o->lin_vel_d_rel[a] = state.ctrl.torso_lin_vel_d_rel[a]; }
+    o->pos_d_init = 1.0;
+    o->quat_d[0] = state.ctrl.torso_quat_d.w(); o->quat_d[1] = state.ctrl.torso_quat_d.x();
+    o->quat_d[2] = state.ctrl.torso_quat_d.y(); o->quat_d[3] = state.ctrl.torso_quat_d.z();
+    for (int l = 0; l < NUM_LEG; ++l) {
+      const LeggedContactFSMHip& F = mpc->leg_FSM[l];
+      qmpc_loop_leg& L = o->leg[l];
+      L.gait_phase = F.phase();
+      L.state = (double)F.get_contact_state();
+      L.pattern_index = F.pattern_index();
+      L.prev_pattern_index = F.prev_pattern_index();
+      L.start_time = F.state_start_time();
+      L.end_time = F.state_end_time();
+      L.not_first_call = F.first_call_done() ? 1.0 : 0.0;
+      L.terrain_height = F.terrain_height;
+      for (int a = 0; a < 3; ++a) {
+        L.swing_start[a] = F.swing_start()[a];
+        L.swing_end[a] = F.swing_end()[a];
+        L.fsm_pos[a] = F.FSM_foot_pos_target_world[a];
+        L.fsm_vel[a] = F.FSM_foot_vel_target_world[a];
+        L.fsm_acc[a] = F.FSM_foot_acc_target_world[a];
+        o->foot_target_world[3 * l + a] = state.ctrl.optimized_state[6 + 3 * l + a];
+      }
+      o->contacts[l] = state.ctrl.plan_contacts[l] ? 1.0 : 0.0;
+      o->gait_counter[l] = state.ctrl.gait_counter[l];
+    }
+    for (int a = 0; a < 12; ++a) { o->forces_body[a] = state.ctrl.optimized_input[a]; o->grf_world[a] = state.ctrl.mpc_grf_world[a]; }
+    o->status = (double)mpc->last_info().status;
+    o->iterations = (double)mpc->last_info().iterations;
+    o->tick = (double)ticks_;
+  }
+
+  State state;
+  QuatMpcHipT<State>* mpc = nullptr;
+
+ private:
+  qmpc_loop_params lp_;
+  double x_[13];
+  double feet_[12];
+  double Iinv_[9];
+  long ticks_ = 0;
+};
+
+}  // namespace legged

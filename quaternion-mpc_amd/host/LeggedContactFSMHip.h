@@ -134,6 +134,14 @@ class LeggedContactFSMHip {
   double FSM_foot_acc_target_world[3] = {0, 0, 0};
   double terrain_height = 0.0;
   double phase() const { return gait_phase; }
+  // read-only views of the schedule internals (closed-loop parity checks, host/ClosedLoopHost.h)
+  int pattern_index() const { return gait_pattern_index; }
+  int prev_pattern_index() const { return prev_gait_pattern_index; }
+  double state_start_time() const { return cur_state_start_time; }
+  double state_end_time() const { return cur_state_end_time; }
+  bool first_call_done() const { return not_first_call; }
+  const double* swing_start() const { return swing_start_foot_pos_world; }
+  const double* swing_end() const { return swing_end_foot_pos_world; }
 
  private:
   void common_enter() {                                 // :208-223

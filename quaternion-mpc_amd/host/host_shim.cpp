@@ -11,6 +11,7 @@
 #include "LeggedStateLite.h"
 #include "QuatMpcHip.h"
 #include "ConvexMpcHip.h"
+#include "ClosedLoopHost.h"
 #include "LeggedLoggerHip.h"
 
 using legged::LeggedStateLite;
@@ -159,6 +160,43 @@ void qh_fake_script(const double* forces12, int call_status, int inst_status) {
   for (int i = 0; i < 12; ++i) g_fake.forces[i] = forces12[i];
   g_fake.call_status = call_status;
   g_fake.inst_status = inst_status;
+}
+
+// ---- closed loop on the host: the parity reference of qmpc_loop_run (one instance) ----------------
+struct LoopHarness {
+  Harness base;                      // owns the dlopen handle
+  legged::ClosedLoopHostT<LeggedStateLite>* loop = nullptr;
+};
+// lib_path NULL / "": the scripted test double (qh_fake_script) stands in for the device
+void* qh_loop_create(const char* lib_path, int horizon, const qmpc_loop_params* lp, const qmpc_loop_state* init) {
+  LoopHarness* h = new LoopHarness();
+  legged::QmpcApi api;
+  if (lib_path && lib_path[0]) {
+    if (!bind_api(&h->base, lib_path, api)) { delete h; return nullptr; }
+  } else {
+    api.default_params = stub_default_params;
+    api.create = fake_create;
+    api.solve = fake_solve;
+    api.destroy = fake_destroy;
+  }
+  h->loop = new legged::ClosedLoopHostT<LeggedStateLite>(api, *lp, *init, horizon, 0);
+  return h;
+}
+int qh_loop_device_status(void* p) { return (int)static_cast<LoopHarness*>(p)->loop->mpc->last_status(); }
+int qh_loop_tick(void* p) { return static_cast<LoopHarness*>(p)->loop->tick() ? 1 : 0; }
+// joy.{velx, vely, body_height, roll_rate, pitch_rate, yaw_rate} and ctrl.movement_mode from the next tick on
+void qh_loop_set_command(void* p, const double* joy, double movement_mode) {
+  LeggedStateLite& s = static_cast<LoopHarness*>(p)->loop->state;
+  s.joy.velx = joy[0]; s.joy.vely = joy[1]; s.joy.body_height = joy[2];
+  s.joy.roll_rate = joy[3]; s.joy.pitch_rate = joy[4]; s.joy.yaw_rate = joy[5];
+  s.ctrl.movement_mode = movement_mode;
+}
+void qh_loop_export(void* p, qmpc_loop_state* out) { static_cast<LoopHarness*>(p)->loop->export_state(out); }
+void qh_loop_destroy(void* p) {
+  LoopHarness* h = static_cast<LoopHarness*>(p);
+  if (!h) return;
+  delete h->loop;
+  delete h;
 }
 
 void qh_destroy(void* p) {

@@ -763,6 +763,81 @@ def test_gpu_matches_kkt_certified_points(pkg, lib, name, gen, dp, solve, N, cfg
         assert np.abs(tu - want).max() < 1e-6
 
 
+LOOP_COMMANDS = [   # joy.{velx, vely, body_height, roll_rate, pitch_rate, yaw_rate}, movement_mode
+    [0.0, 0.0, 0.30, 0.0, 0.0, 0.0, 0.0],      # stand
+    [0.3, 0.0, 0.30, 0.0, 0.0, 0.0, 1.0],      # trot forward
+    [0.2, -0.1, 0.28, 0.0, 0.0, 0.3, 1.0],     # trot diagonally, turning, lower body
+    [0.0, 0.0, 0.30, 0.1, -0.1, 0.0, 1.0],     # trot in place with roll / pitch rate commands
+    [-0.2, 0.05, 0.32, 0.0, 0.0, -0.2, 1.0],   # backwards
+    [0.0, 0.0, 0.27, 0.0, 0.0, 0.0, 0.0],      # stand, squat
+]
+
+
+def test_device_closed_loop_matches_host_classes_tick_for_tick(pkg, lib):
+    """goal_update + gait FSM + swing quintic + Raibert + record packing -> qmpc_solve_device ->
+    plant, all on the GPU with the state in HBM (qmpc_loop_run, one hipGraph replay per tick), against the SAME tick
+    built from the host classes that mirror the reference (host/ClosedLoopHost.h: QuatMpcHipT::goal_update /
+    foot_update / grf_update, LeggedContactFSMHip, raibert_foot_targets; one B = 1 solve per tick like the
+    reference's mpc_thread).  Contact flags exact, forces <= 1e-6 N, every tick, more than one gait cycle."""
+    import __graft_entry__ as g
+
+    host = C.CDLL(str(g.build_host()))
+    vp = C.c_void_p
+    host.qh_loop_create.argtypes = [C.c_char_p, C.c_int, vp, vp]; host.qh_loop_create.restype = vp
+    for f in ("qh_loop_tick", "qh_loop_destroy", "qh_loop_device_status"):
+        getattr(host, f).argtypes = [vp]
+    host.qh_loop_export.argtypes = [vp, vp]
+    host.qh_loop_set_command.argtypes = [vp, vp, C.c_double]
+    T0, T, N = 6, 130, 10          # T0 stand ticks first (the controller always resets the gait FSM in stand mode
+    lp = pkg.default_loop_params(lib)   # before it walks, QuatMpc.cpp:283-289), then T ticks of the commanded mode
+    yaws = [0.0, 0.4, -1.0, 2.0, 0.7, -0.3]
+    cmds = np.array(LOOP_COMMANDS)
+    stand = cmds.copy(); stand[:, 6] = 0.0
+    st_init = pkg.loop_states(stand, lp, height=0.3, yaw=yaws, lib=lib)
+    B = len(st_init)
+    s = pkg.Solver(pkg.default_params(N, pkg.MODE_CONVERGED, lib), B, device=0, lib=lib)
+    st0 = s.loop_run(st_init, T0, lp)
+    st0["movement_mode"] = cmds[:, 6]                # the state sits in a host buffer between runs: edit the command
+    st, tf, tc = s.loop_run(st0, T, lp, trace=True)
+    # the run in two halves (state leaves and re-enters HBM) gives the same bits
+    sa = s.loop_run(st0, T // 2, lp)
+    sb = s.loop_run(sa, T - T // 2, lp)
+    assert sb.tobytes() == st.tobytes()
+    s.close()
+    assert (st["tick"] == T0 + T).all() and (st["status"] == 0).all()
+    worst_f = worst_x = 0.0
+    swings = 0
+    for i in range(B):
+        h = host.qh_loop_create(str(pkg.LIB_PATH).encode(), N, C.addressof(lp), st_init[i:i + 1].ctypes.data)
+        assert h and host.qh_loop_device_status(h) == 0
+        e = np.zeros(1, dtype=pkg.LOOP_STATE_DTYPE)
+        for t in range(T0):
+            assert host.qh_loop_tick(h) == 1
+        host.qh_loop_set_command(h, np.ascontiguousarray(cmds[i, :6]).ctypes.data, float(cmds[i, 6]))
+        for t in range(T):
+            assert host.qh_loop_tick(h) == 1, (i, t)
+            host.qh_loop_export(h, e.ctypes.data)
+            assert np.array_equal(e[0]["contacts"], tc[t, i]), (i, t, e[0]["contacts"], tc[t, i])     # exact
+            worst_f = max(worst_f, float(np.abs(e[0]["forces_body"] - tf[t, i]).max()))
+            swings += int((tc[t, i] == 0).sum())
+        host.qh_loop_destroy(h)
+        d, r = st[i], e[0]
+        for k in ("pos_world", "quat", "lin_vel_world", "ang_vel_body", "foot_pos_world", "pos_d_world", "quat_d",
+                  "grf_world", "foot_target_world"):
+            worst_x = max(worst_x, float(np.abs(d[k] - r[k]).max()))
+        for k in ("gait_phase", "state", "pattern_index", "start_time", "end_time", "not_first_call"):
+            assert np.array_equal(d["leg"][k], r["leg"][k]), (i, k)          # the schedule state is bit-exact
+        for k in ("fsm_pos", "fsm_vel", "swing_start", "swing_end"):
+            worst_x = max(worst_x, float(np.abs(d["leg"][k] - r["leg"][k]).max()))
+        assert np.array_equal(d["gait_counter"], r["gait_counter"])
+    print(f"closed loop, {B} robots x {T} ticks: worst force difference {worst_f:.2e} N, worst state difference {worst_x:.2e}")
+    assert worst_f <= 1e-6 and worst_x <= 1e-8
+    assert swings > 100                       # the walking robots really went through swing phases
+    walk = st[1]
+    assert walk["pos_world"][0] * np.cos(yaws[1]) + walk["pos_world"][1] * np.sin(yaws[1]) > 0.05   # it moved forward
+    assert 0.2 < walk["pos_world"][2] < 0.4 and abs(st[0]["pos_world"][2] - 0.3) < 0.02           # nobody fell
+
+
 @pytest.mark.parametrize("counts", ["64,64", "40,33,27"], ids=["2 ranks", "3 ranks ragged"])
 def test_multi_process_rccl_gather_on_one_gpu(counts, tmp_path):
     """qmpc_gather with MORE than one RCCL rank: 2 (and 3, ragged shards) processes, each with its own

@@ -583,3 +583,37 @@ def test_c_example_builds_and_fails_loudly_without_a_gpu(tmp_path):
     else:
         assert r.returncode == 2 and "no CPU fallback" in r.stderr
     shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+def test_host_closed_loop_stands_in_equilibrium_with_scripted_forces(host, pkg):
+    """host/ClosedLoopHost.h with the scripted test double: feet under the hips, a quarter of the weight on every
+    foot -> the plant (csrc/qmpc_loop_math.h) stays at rest; the same forces with one leg unloaded tip it over."""
+    lib = pkg.load_library()
+    vp = C.c_void_p
+    host.qh_loop_create.argtypes = [C.c_char_p, C.c_int, vp, vp]; host.qh_loop_create.restype = vp
+    for f in ("qh_loop_tick", "qh_loop_destroy"):
+        getattr(host, f).argtypes = [vp]
+    host.qh_loop_export.argtypes = [vp, vp]
+    host.qh_fake_script.argtypes = [vp, C.c_int, C.c_int]
+    lp = pkg.default_loop_params(lib)
+    st0 = pkg.loop_states([[0, 0, 0.3, 0, 0, 0, 0]], lp, lib=lib)
+    assert pkg.LOOP_STATE_DTYPE.itemsize == lib.qmpc_sizeof_loop_state() == 818 * 8
+    w = 12.84 * 9.81 / 4
+    f = np.array([0, 0, w] * 4)
+    host.qh_fake_script(f.ctypes.data, pkg.OK, pkg.OK)
+    h = host.qh_loop_create(None, 10, C.addressof(lp), st0.ctypes.data)
+    e = np.zeros(1, dtype=pkg.LOOP_STATE_DTYPE)
+    for _ in range(100):
+        assert host.qh_loop_tick(h) == 1
+    host.qh_loop_export(h, e.ctypes.data)
+    assert np.abs(e[0]["pos_world"] - [0, 0, 0.3]).max() < 1e-12 and np.abs(e[0]["quat"] - [1, 0, 0, 0]).max() < 1e-12
+    assert e[0]["tick"] == 100 and (e[0]["contacts"] == 1).all() and np.array_equal(e[0]["forces_body"], f)
+    host.qh_loop_destroy(h)
+    f2 = f.copy(); f2[2] = 0.0                     # front-left leg unloaded
+    host.qh_fake_script(f2.ctypes.data, pkg.OK, pkg.OK)
+    h = host.qh_loop_create(None, 10, C.addressof(lp), st0.ctypes.data)
+    for _ in range(40):
+        host.qh_loop_tick(h)
+    host.qh_loop_export(h, e.ctypes.data)
+    assert e[0]["pos_world"][2] < 0.3 - 1e-3 and abs(e[0]["quat"][1]) > 1e-3 and abs(e[0]["quat"][2]) > 1e-3
+    host.qh_loop_destroy(h)
