@@ -9,8 +9,9 @@
 // exclusive; k_stop == 0 means the single knot k_start; LastIndex means "through the terminal knot".
 // Supported: one (n, m) and one time step for all knots, one explicit dynamics function, diagonal LQR and
 // quaternion costs per knot, EQUALITY / INEQUALITY / SECOND_ORDER_CONE constraints (at most QO_MAXCON blocks, cones
-// of at most QO_SOC_MAXP rows), AltroOptions fields the reference sets.  Not supported: generic cost functions,
-// UpdateLinearCosts, ShiftTrajectory.
+// of at most QO_SOC_MAXP rows), AltroOptions fields the reference sets, and the two calls of the reference's MPC
+// loop (TestBicycle.cpp:185-199): UpdateLinearCosts (new linear term of a diagonal LQR cost = new reference point)
+// and ShiftTrajectory (warm start of the next solve).  Not supported: generic cost functions.
 #pragma once
 
 #include <cstring>
@@ -174,6 +175,41 @@ class ALTROSolver {
     return ErrorCodes::NoError;
   }
 
+  // The linear terms of knot k's quadratic cost 0.5 x'Qx + q'x + 0.5 u'Ru + r'u + c  (TestBicycle.cpp:185-195 passes
+  // q = -Q x_ref, r = nullptr, c = the constant).  With the diagonal costs of this layer that is a new reference
+  // point: x_ref = -q / Q (entries with Q = 0 keep theirs), u_ref = -r / R; a null pointer leaves that part alone.
+  ErrorCodes UpdateLinearCosts(const a_float* q, const a_float* r, a_float c, int k_start = 0, int k_stop = 0) {
+    (void)c;   // the constant shifts the objective value only
+    if (!prob_->n) return ErrorCodes::DimensionUnknown;
+    int a, b;
+    if (!range(k_start, k_stop, a, b)) return ErrorCodes::BadIndex;
+    for (int k = a; k < b; ++k) {
+      if (q)
+        for (int i = 0; i < prob_->n; ++i)
+          if (prob_->Q[k][i] != 0.0) prob_->xref[k][i] = -q[i] / prob_->Q[k][i];
+      if (r)
+        for (int j = 0; j < prob_->m; ++j)
+          if (prob_->R[k][j] != 0.0) prob_->uref[k][j] = -r[j] / prob_->R[k][j];
+    }
+    return ErrorCodes::NoError;
+  }
+
+  // Warm start of the next MPC solve: every knot takes the state / input of its successor, the last ones stay
+  // (TestBicycle.cpp:199, after SetInitialState)
+  ErrorCodes ShiftTrajectory() {
+    if (!initialized_) return ErrorCodes::SolverNotInitialized;
+    const int n = prob_->n, m = prob_->m, N = prob_->N;
+    for (int k = 0; k < N; ++k) std::memcpy(&X_[(size_t)k * n], &X_[(size_t)(k + 1) * n], sizeof(double) * n);
+    for (int k = 0; k + 1 < N; ++k) std::memcpy(&U_[(size_t)k * m], &U_[(size_t)(k + 1) * m], sizeof(double) * m);
+    if (shift_duals_ && !duals_.empty()) {
+      const size_t blk = (size_t)QO_MAXCON * QO_MAXP;
+      for (int k = 0; k < N; ++k) std::memcpy(&duals_[k * blk], &duals_[(k + 1) * blk], sizeof(double) * blk);
+    }
+    return ErrorCodes::NoError;
+  }
+  // experiment knobs of this layer (not part of the reference API): what carries over between Solve() calls
+  void SetWarmStart(int mode, bool shift_duals) { warm_mode_ = mode; shift_duals_ = shift_duals; }
+
   void SetOptions(const AltroOptions& opts) { opts_ = opts; }
   AltroOptions& GetOptions() { return opts_; }
 
@@ -215,6 +251,11 @@ class ALTROSolver {
     o.verbose = static_cast<int>(opts_.verbose);
     prob_->use_quaternion = opts_.use_quaternion ? 1 : 0;
     prob_->quat_start_index = opts_.quat_start_index;
+    if (warm_mode_ >= 1) {                 // multipliers (and with 2 the penalty) carry over to the next Solve()
+      if (duals_.empty()) duals_.assign((size_t)(prob_->N + 1) * QO_MAXCON * QO_MAXP, 0.0);
+      o.dual_io = duals_.data();
+      if (warm_mode_ >= 2) o.penalty_io = &penalty_;
+    }
     std::memcpy(&X_[0], prob_->x0, sizeof(double) * prob_->n);
     qo_altro_solve(prob_.get(), &o, X_.data(), U_.data(), &res_);
     solved_ = true;
@@ -298,6 +339,10 @@ class ALTROSolver {
   AltroOptions opts_;
   qo_result res_{};
   bool have_h_ = false, initialized_ = false, solved_ = false;
+  int warm_mode_ = 0;
+  bool shift_duals_ = false;
+  std::vector<double> duals_;
+  double penalty_ = 0.0;
 };
 
 }  // namespace altro

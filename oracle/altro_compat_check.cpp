@@ -5,6 +5,8 @@
 // TEST INFRASTRUCTURE ONLY.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "altro_compat.hpp"
@@ -310,7 +312,169 @@ void case_soc() {
 
 }  // namespace
 
-int main() {
+// ---- TestBicycle.cpp: closed-loop nonlinear MPC of a kinematic bicycle along the "Scotty dog" reference ---------
+// The reference commits BOTH the reference trajectory (scotty.json) and the output of that program
+// (scotty_mpc.json: 200 closed-loop states / inputs, solver iterations and tracking error per step); copies of the
+// two data files are in tests/golden/.  The loop below is TestBicycle.cpp:25-200 through the compat API.
+struct Bicycle {             // AltroTestUtils.cpp:134-237, ReferenceFrame::CenterOfGravity
+  double L = 2.7, lr = 1.5;
+  void f(double* xd, const double* x, const double* u) const {
+    const double v = u[0], th = x[2], de = x[3];
+    const double beta = std::atan2(lr * de, L), om = v * std::cos(beta) * std::tan(de) / L;
+    xd[0] = v * std::cos(th + beta); xd[1] = v * std::sin(th + beta); xd[2] = om; xd[3] = u[1];
+  }
+  void J(double* j, const double* x, const double* u) const {   // 4 x 6 column-major
+    for (int i = 0; i < 24; ++i) j[i] = 0.0;
+    const double v = u[0], th = x[2], de = x[3];
+    const double by = lr * de, bx = L, beta = std::atan2(by, bx), db = bx / (bx * bx + by * by) * lr;
+    const double dom_dde = v / L * (-std::sin(beta) * std::tan(de) * db + std::cos(beta) / (std::cos(de) * std::cos(de)));
+    const double dom_dv = std::cos(beta) * std::tan(de) / L;
+    const double st = std::sin(th + beta), ct = std::cos(th + beta);
+    j[0 + 4 * 2] = v * -st; j[0 + 4 * 3] = v * -st * db; j[0 + 4 * 4] = ct;
+    j[1 + 4 * 2] = v * ct;  j[1 + 4 * 3] = v * ct * db;  j[1 + 4 * 4] = st;
+    j[2 + 4 * 3] = dom_dde; j[2 + 4 * 4] = dom_dv;
+    j[3 + 4 * 5] = 1.0;
+  }
+};
+// numbers of the array stored under "key" in a JSON file of nested numeric arrays
+std::vector<double> json_numbers(const std::string& text, const std::string& key) {
+  std::vector<double> out;
+  size_t p = text.find("\"" + key + "\"");
+  if (p == std::string::npos) return out;
+  p = text.find(':', p) + 1;
+  while (p < text.size() && (text[p] == ' ' || text[p] == '\n')) ++p;
+  if (text[p] != '[') { out.push_back(std::strtod(text.c_str() + p, nullptr)); return out; }
+  int depth = 0;
+  for (; p < text.size(); ++p) {
+    const char ch = text[p];
+    if (ch == '[') ++depth;
+    else if (ch == ']') { if (--depth == 0) break; }
+    else if (ch == '-' || (ch >= '0' && ch <= '9')) {
+      char* end = nullptr;
+      out.push_back(std::strtod(text.c_str() + p, &end));
+      p = (size_t)(end - text.c_str()) - 1;
+    }
+  }
+  return out;
+}
+std::string slurp(const std::string& path) {
+  std::string s;
+  if (FILE* f = std::fopen(path.c_str(), "rb")) {
+    char buf[65536];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, n);
+    std::fclose(f);
+  }
+  return s;
+}
+void case_bicycle_mpc(const std::string& dir, int warm = 0, bool shift = false, bool verbose = false) {
+  const std::string ref = slurp(dir + "/scotty.json"), gold = slurp(dir + "/scotty_mpc.json");
+  const std::vector<double> xr = json_numbers(ref, "state_trajectory"), ur = json_numbers(ref, "input_trajectory");
+  const std::vector<double> xg = json_numbers(gold, "state_trajectory"), ug = json_numbers(gold, "input_trajectory");
+  const std::vector<double> ig = json_numbers(gold, "solve_iters"), eg = json_numbers(gold, "tracking_error");
+  if (xr.size() < 4 * 240 || xg.size() != 4 * 201 || ug.size() != 2 * 200 || ig.size() != 200) {
+    std::printf("bicycle_mpc bad=1\n");
+    return;
+  }
+  const int n = 4, m = 2, N = 30, Nsim = 200;
+  const float h = 0.1f;       // the golden's states reproduce under the midpoint rule with h = 0.1f to 0.0 (checked below)
+  Bicycle car;
+  auto dyn0 = [car](double* xd, const double* x, const double* u) { car.f(xd, x, u); };
+  auto dyn = [dyn0](double* xn, const double* x, const double* u, float hh) {     // AltroUtils.cpp:9-22
+    double xm[4], k[4];
+    dyn0(k, x, u);
+    for (int i = 0; i < 4; ++i) xm[i] = x[i] + hh / 2 * k[i];
+    dyn0(k, xm, u);
+    for (int i = 0; i < 4; ++i) xn[i] = x[i] + hh * k[i];
+  };
+  auto jac = [car, dyn0](double* Jo, const double* x, const double* u, float hh) {   // AltroUtils.cpp:78-110
+    double k[4], xm[4], J0[24], Jm[24];
+    dyn0(k, x, u);
+    for (int i = 0; i < 4; ++i) xm[i] = x[i] + hh / 2 * k[i];
+    car.J(J0, x, u);
+    car.J(Jm, xm, u);
+    for (int r = 0; r < 4; ++r) {
+      for (int c = 0; c < 4; ++c) {       // I + h Am (I + h/2 A)
+        double s = 0.0;
+        for (int t = 0; t < 4; ++t) s += Jm[r + 4 * t] * ((t == c ? 1.0 : 0.0) + hh / 2 * J0[t + 4 * c]);
+        Jo[r + 4 * c] = (r == c ? 1.0 : 0.0) + hh * s;
+      }
+      for (int c = 0; c < 2; ++c) {       // h (Am h/2 B + Bm)
+        double s = 0.0;
+        for (int t = 0; t < 4; ++t) s += Jm[r + 4 * t] * hh / 2 * J0[t + 4 * (4 + c)];
+        Jo[r + 4 * (4 + c)] = hh * (s + Jm[r + 4 * (4 + c)]);
+      }
+    }
+  };
+  // the golden itself pins model + midpoint + float h: roll its inputs through dyn
+  double pin = 0.0;
+  for (int k = 0; k < Nsim; ++k) {
+    double xn[4];
+    dyn(xn, &xg[4 * k], &ug[2 * k], h);
+    for (int i = 0; i < 4; ++i) pin = std::fmax(pin, std::fabs(xn[i] - xg[4 * (k + 1) + i]));
+  }
+  ALTROSolver solver(N);
+  int bad = 0;
+  bad += solver.SetDimension(n, m) != ErrorCodes::NoError;
+  bad += solver.SetExplicitDynamics(dyn, jac) != ErrorCodes::NoError;
+  bad += solver.SetTimeStep(h) != ErrorCodes::NoError;
+  const std::vector<double> Qd(n, 1e-2), Rd(m, 1e-3);
+  for (int k = 0; k <= N; ++k) bad += solver.SetLQRCost(n, m, Qd.data(), Rd.data(), &xr[4 * k], &ur[2 * k], k) != ErrorCodes::NoError;
+  const double dmax = 60 * M_PI / 180.0;
+  auto con = [dmax](a_float* c, const a_float* x, const a_float*) { c[0] = x[3] - dmax; c[1] = -dmax - x[3]; };
+  auto cjac = [](a_float* j, const a_float*, const a_float*) { for (int i = 0; i < 12; ++i) j[i] = 0.0; j[0 + 2 * 3] = 1.0; j[1 + 2 * 3] = -1.0; };
+  bad += solver.SetConstraint(con, cjac, 2, ConstraintType::INEQUALITY, "steering angle bound", 0, N + 1) != ErrorCodes::NoError;
+  bad += solver.SetInitialState(&xr[0], n) != ErrorCodes::NoError;
+  bad += solver.Initialize() != ErrorCodes::NoError;
+  const double u0[2] = {ur[0], 0.0};
+  bad += solver.SetInput(u0, m) != ErrorCodes::NoError;
+  for (int k = 0; k <= N; ++k) solver.SetState(&xr[4 * k], n, k);
+  AltroOptions opts;
+  opts.iterations_max = 80;
+  solver.SetOptions(opts);
+  solver.SetWarmStart(warm, shift);
+  std::vector<double> xs(4 * (Nsim + 1), 0.0), us(2 * Nsim, 0.0);
+  for (int i = 0; i < 4; ++i) xs[i] = xr[i];
+  double xdiff = 0.0, udiff = 0.0, ediff = 0.0, emax = 0.0;
+  int iters_sum = 0, iters_match = 0, iters_maxdiff = 0, fails = 0;
+  for (int it = 0; it < Nsim; ++it) {
+    const SolveStatus st = solver.Solve();
+    fails += st != SolveStatus::Success;
+    const int its = solver.GetIterations();
+    iters_sum += its;
+    iters_match += its == (int)ig[it];
+    iters_maxdiff = std::max(iters_maxdiff, std::abs(its - (int)ig[it]));
+    if (verbose) std::printf("  step %3d status %d iters %2d golden %2d\n", it, (int)st, its, (int)ig[it]);
+    solver.GetInput(&us[2 * it], 0);
+    dyn(&xs[4 * (it + 1)], &xs[4 * it], &us[2 * it], h);
+    double e = 0.0;
+    for (int i = 0; i < 4; ++i) { const double d = xs[4 * (it + 1) + i] - xr[4 * (it + 1) + i]; e += d * d; }
+    e = std::sqrt(e);
+    emax = std::fmax(emax, e);
+    ediff = std::fmax(ediff, std::fabs(e - eg[it]));
+    for (int i = 0; i < 4; ++i) xdiff = std::fmax(xdiff, std::fabs(xs[4 * (it + 1) + i] - xg[4 * (it + 1) + i]));
+    for (int j = 0; j < 2; ++j) udiff = std::fmax(udiff, std::fabs(us[2 * it + j] - ug[2 * it + j]));
+    for (int k = 0; k <= N; ++k) {       // TestBicycle.cpp:184-196
+      const double* xk = &xr[4 * (k + it + 1)];
+      double q[4];
+      for (int i = 0; i < 4; ++i) q[i] = -Qd[i] * xk[i];
+      solver.UpdateLinearCosts(q, nullptr, 0.0, k);
+    }
+    solver.SetInitialState(&xs[4 * (it + 1)], n);
+    solver.ShiftTrajectory();
+  }
+  int gsum = 0;
+  for (double v : ig) gsum += (int)v;
+  std::printf("bicycle_mpc warm=%d shift=%d bad=%d pin=%.3e fails=%d iters_sum=%d golden_iters_sum=%d iters_match=%d iters_maxdiff=%d xdiff=%.6e udiff=%.6e "
+              "terr_diff=%.6e terr_max=%.6e\n", warm, (int)shift, bad, pin, fails, iters_sum, gsum, iters_match, iters_maxdiff, xdiff, udiff, ediff, emax);
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1) {
+    const int warm = argc > 2 ? std::atoi(argv[2]) : 0;
+    case_bicycle_mpc(argv[1], warm, argc > 3 && std::atoi(argv[3]) != 0, argc > 4);
+    return 0;
+  }
   case_unconstrained();
   case_goal();
   case_bounds();

@@ -878,6 +878,11 @@ int qo_altro_solve(const qo_problem* prob, const qo_options* opts, double* X, do
   ws.Uc = ws.Xc + (QO_MAXH + 1) * QO_MAXN;
   ws.dU = ws.Uc + QO_MAXH * QO_MAXM + 4;
   ws.rho = opts->penalty_initial;
+  if (opts->penalty_io && *opts->penalty_io > 0.0) ws.rho = *opts->penalty_io;
+  if (opts->dual_io)
+    for (int k = 0; k <= N; ++k)
+      for (int ci = 0; ci < prob->ncon; ++ci)
+        memcpy(ws.kn[k].lam[ci], &opts->dual_io[((size_t)k * QO_MAXCON + ci) * QO_MAXP], sizeof(double) * QO_MAXP);
 
   qo_result r;
   memset(&r, 0, sizeof r);
@@ -962,6 +967,11 @@ int qo_altro_solve(const qo_problem* prob, const qo_options* opts, double* X, do
       }
     }
   }
+  if (opts->penalty_io) *opts->penalty_io = ws.rho;
+  if (opts->dual_io)
+    for (int k = 0; k <= N; ++k)
+      for (int ci = 0; ci < prob->ncon; ++ci)
+        memcpy(&opts->dual_io[((size_t)k * QO_MAXCON + ci) * QO_MAXP], ws.kn[k].lam[ci], sizeof(double) * QO_MAXP);
   if (iter > opts->iterations_max) iter = opts->iterations_max;
   r.iterations = iter;
   r.cost = Jplain;

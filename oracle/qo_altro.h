@@ -82,6 +82,11 @@ typedef struct qo_options {
    * [k = 0..N-1][constraint ci in order][row 0..p-1]; rows that are switched off (row_enable == 0) report 0 */
   double* dual_out;
   double* slack_out;
+  /* optional warm start of the reference (AL) mode across solves (NULL = multipliers 0, penalty_initial): in/out
+   * multipliers [k = 0..N][constraint ci][QO_MAXP] and the penalty; an MPC loop that re-solves a shifted problem
+   * (TestBicycle.cpp:165-200) keeps both between calls */
+  double* dual_io;
+  double* penalty_io;
 } qo_options;
 
 typedef struct qo_problem {
