@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-in-flight", action="store_true",
                     help="skip the secondary measurement with two batches in flight (N=1 only)")
+    ap.add_argument("--no-reference-mode", action="store_true",
+                    help="skip the secondary figure of the reference's own solver mode (AL-iLQR, 10 iterations) on the device")
     ap.add_argument("--no-closed-loop", action="store_true",
                     help="skip the secondary device-resident closed-loop figure (N=1, quat only)")
     ap.add_argument("--no-config4", action="store_true",
@@ -356,6 +358,34 @@ def main():
             out["host_buffer_call"] = out["rates"]["host_buffer_call"]
         if world == 1 and not args.no_in_flight:
             out["two_in_flight"] = two_in_flight(pkg, lib, params, args, d_in, NU)
+        if world == 1 and args.model in ("quat", "convex") and not args.no_reference_mode:
+            # secondary: the reference's OWN operating mode on the device (QMPC_MODE_REFERENCE: AL-iLQR, 10 iterations,
+            # penalty scaling 20, status ignored; QuatMpc.cpp:21-26,256) on the same batch, and how far the truncated
+            # iterate it returns is from the converged KKT point that `value` computes; never `value`
+            pr = (pkg.default_convex_params if convex else pkg.default_params)(N, pkg.MODE_REFERENCE, lib)
+            sr = pkg.Solver(pr, B, device=local, lib=lib)
+            fr = torch.zeros(B, NU, dtype=torch.float64, device="cuda")
+            ir = torch.zeros(B, pkg.INFO_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+            rfn = sr.convex_solve_device if convex else sr.solve_device
+            for _ in range(max(2, args.warmup)):
+                rfn(B, d_in.data_ptr(), fr.data_ptr(), ir.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                rfn(B, d_in.data_ptr(), fr.data_ptr(), ir.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            ri = np.ascontiguousarray(ir.cpu().numpy()).view(pkg.INFO_DTYPE).reshape(B)
+            du = np.abs(fr.cpu().numpy() - d_f).max(axis=1)
+            sr.close()
+            out["reference_mode"] = {
+                "value": B * args.steps / dt, "unit": "solves/s", "ms_per_step": 1e3 * dt / args.steps,
+                "iterations_max": int(pr.iterations_max), "mean_iterations": float(ri["iterations"].mean()),
+                "status_counts": {"converged": int((ri["status"] == 0).sum()), "iteration_cap": int((ri["status"] == 1).sum()),
+                                  "linesearch_fail": int((ri["status"] == 4).sum()), "not_pd": int((ri["status"] == 5).sum())},
+                "u0_distance_to_converged_N": {"median": float(np.median(du)), "p90": float(np.percentile(du, 90)), "max": float(du.max())},
+                "note": "secondary: what the reference's solver mode returns (a <=10-iteration AL-iLQR iterate) and what it "
+                        "costs on this GPU; the contract value is the converged mode"}
         if world == 1 and args.model == "quat" and not args.no_closed_loop:
             # secondary: the device-resident closed loop (front end + solve + plant per tick, state in HBM, one
             # hipGraph replay per tick): B robots standing up from rest into a trot; never `value`

@@ -44,6 +44,9 @@ struct DevParams {
   double mu;
   double fz_max;
   double tol_feas, tol_step, mu0, mu_final, sigma, sigma_fast, tau;
+  // reference mode (AL-iLQR, QuatMpc.cpp:21-26 + upstream ALTRO defaults)
+  double penalty_initial, penalty_scaling, penalty_max, tol_stat, tol_cost_int;
+  int linesearch_max;
 };
 
 // ---- per-instance LDS layout (offsets in doubles) ---------------------------

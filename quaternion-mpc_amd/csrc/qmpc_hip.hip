@@ -8,6 +8,7 @@
 // QMPC_NO_DEVICE.
 #include "qmpc_kernels.hip"
 #include "qmpc_loop.hip"
+#include "qmpc_ref.hip"
 
 #include <dlfcn.h>
 
@@ -153,10 +154,12 @@ void qmpc_default_biped8_params(qmpc_params* p, int32_t horizon, int32_t mode) {
 
 static int fill_dev_params(const qmpc_params* p, DevParams* d) {
   if (!p || p->horizon < 1 || p->horizon > QMPC_MAX_HORIZON) return QMPC_BAD_ARGUMENT;
-  if (p->mode != QMPC_MODE_CONVERGED) return QMPC_BAD_ARGUMENT;  // device path: converged mode
+  if (p->mode != QMPC_MODE_CONVERGED && p->mode != QMPC_MODE_REFERENCE) return QMPC_BAD_ARGUMENT;
+  if (p->mode == QMPC_MODE_REFERENCE && !(p->penalty_initial > 0.0 && p->penalty_scaling >= 1.0)) return QMPC_BAD_ARGUMENT;
   if (p->model != QMPC_MODEL_QUAT && p->model != QMPC_MODEL_CONVEX && p->model != QMPC_MODEL_QUAT8)
     return QMPC_BAD_ARGUMENT;
-  if (!(p->mass > 0.0) || !(p->h > 0.0f) || !(p->ipm_mu0 > 0.0)) return QMPC_BAD_ARGUMENT;
+  if (!(p->mass > 0.0) || !(p->h > 0.0f)) return QMPC_BAD_ARGUMENT;
+  if (p->mode == QMPC_MODE_CONVERGED && !(p->ipm_mu0 > 0.0)) return QMPC_BAD_ARGUMENT;
   std::memset(d, 0, sizeof *d);
   d->N = p->horizon;
   d->mode = p->mode;
@@ -189,6 +192,12 @@ static int fill_dev_params(const qmpc_params* p, DevParams* d) {
   d->sigma = p->ipm_sigma;
   d->sigma_fast = p->ipm_sigma_fast;
   d->tau = p->ipm_tau;
+  d->penalty_initial = p->penalty_initial;
+  d->penalty_scaling = p->penalty_scaling;
+  d->penalty_max = p->penalty_max;
+  d->tol_stat = p->tol_stationarity;
+  d->tol_cost_int = p->tol_cost_intermediate;
+  d->linesearch_max = p->linesearch_max;
   return QMPC_OK;
 }
 
@@ -237,6 +246,15 @@ static qmpc_status create_resources(qmpc_handle* h, int N, int nl, int nu) {
     QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, false, 2>), h->lds_bytes_s);
     QMPC_SET_LDS(qmpc_linearize_kernel<QuatModel>, h->lds_bytes_g);
   }
+  if (params->mode == QMPC_MODE_REFERENCE) {
+    if (params->model == QMPC_MODEL_CONVEX) {
+      if (h->lds_bytes <= 160 * 1024) QMPC_SET_LDS((qmpc_ref_kernel<ConvexModel, 0>), h->lds_bytes);
+      QMPC_SET_LDS((qmpc_ref_kernel<ConvexModel, 1>), h->lds_bytes_g);
+    } else {
+      if (h->lds_bytes <= 160 * 1024) QMPC_SET_LDS((qmpc_ref_kernel<QuatModel, 0>), h->lds_bytes);
+      QMPC_SET_LDS((qmpc_ref_kernel<QuatModel, 1>), h->lds_bytes_g);
+    }
+  }
 #undef QMPC_SET_LDS
   HIP_TRY(hipMalloc(&h->d_gws, sizeof(double) * (size_t)N * (13 * nu + 21 * nl + 30 * nl) * (size_t)max_batch));
   return QMPC_OK;
@@ -269,6 +287,10 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
   h->lds_bytes_g = (size_t)Lg.total * sizeof(double);
   h->lds_bytes_s = (size_t)Ls.total * sizeof(double);
   if (h->lds_bytes_g > 160 * 1024) { delete h; return QMPC_BAD_ARGUMENT; }
+  if (params->mode == QMPC_MODE_REFERENCE && params->model == QMPC_MODEL_QUAT8) {   // Go1 models only (qmpc_ref.hip)
+    delete h;
+    return QMPC_UNSUPPORTED;
+  }
   {
     const char* v = std::getenv("QMPC_VARIANT");
     h->variant = v ? std::atoi(v) : 0;
@@ -323,6 +345,28 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
                                 qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s, bool timed = true) {
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;   // the gains workspace is sized by max_batch
   if (timed) HIP_TRY(hipEventRecord(h->ev0, s));
+  if (h->params.mode == QMPC_MODE_REFERENCE) {     // the reference's own AL-iLQR mode (qmpc_ref.hip)
+    const bool ws = batch > 1024 || h->lds_bytes > 40 * 1024 || h->variant >= 2;
+    const size_t lds_r = ws ? h->lds_bytes_g : h->lds_bytes;
+    double* gws_r = ws ? h->d_gws : nullptr;
+#define QMPC_LAUNCH_REF(kern) \
+  hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kWave), lds_r, s, h->dev, d_in, d_forces, d_info, d_tu, d_tx, \
+                     (int)batch, gws_r)
+    if (h->params.model == QMPC_MODEL_CONVEX) {
+      if (ws) QMPC_LAUNCH_REF((qmpc_ref_kernel<ConvexModel, 1>));
+      else QMPC_LAUNCH_REF((qmpc_ref_kernel<ConvexModel, 0>));
+    } else {
+      if (ws) QMPC_LAUNCH_REF((qmpc_ref_kernel<QuatModel, 1>));
+      else QMPC_LAUNCH_REF((qmpc_ref_kernel<QuatModel, 0>));
+    }
+#undef QMPC_LAUNCH_REF
+    HIP_TRY(hipGetLastError());
+    if (timed) {
+      HIP_TRY(hipEventRecord(h->ev1, s));
+      h->timed = true;
+    }
+    return QMPC_OK;
+  }
   const int var = pick_variant(h, batch);
   const size_t lds = var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes);
   double* gws = var >= 1 ? h->d_gws : nullptr;
@@ -754,7 +798,7 @@ qmpc_status qmpc_loop_run(qmpc_handle* h, const qmpc_loop_params* lp, int32_t ba
 // rollout gain / broadcast / step, apply, MFMA drain); slot 15 = iterations.
 qmpc_status qmpc_debug_profile(qmpc_handle* h, int32_t batch, const qmpc_input* in, int64_t* cycles_out) {
   if (!h || batch < 1 || !in || !cycles_out) return QMPC_BAD_ARGUMENT;
-  if (h->params.model != QMPC_MODEL_QUAT) return QMPC_BAD_ARGUMENT;
+  if (h->params.model != QMPC_MODEL_QUAT || h->params.mode != QMPC_MODE_CONVERGED) return QMPC_BAD_ARGUMENT;
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
   HIP_TRY(hipSetDevice(h->device));
   long long* d_prof = nullptr;

@@ -295,7 +295,10 @@ __device__ __forceinline__ double cone_value(const DevParams& P, const Layout& L
 //   Dblk = T' R_l T + sum_i w_i (T'a_i)(T'a_i)',   w_i = lam_i / s_i
 //   gq   = T' (R_l (u_l - uref_l)) + sum_i g_i (T'a_i),  g_i = target/s_i - kappa_i lam_i + w_i rc_i
 // ROT record per leg: T (9, row-major [a][b]), Dblk (9), gq (3).
-template <class D>
+// AL = true (reference mode, qmpc_ref.hip): the rows carry augmented-Lagrangian weights instead of barrier weights,
+//   w_i = rho [lam_i + rho c_i > 0],  g_i = max(lam_i + rho c_i, 0)   (SURVEY.md Appendix B),
+// with c_i kept in the RC slot and `target` = rho.
+template <class D, bool AL = false>
 __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, double* sm, const double* sl,
                                         double* ROT, double target, int lane) {
   const int N = P.N;
@@ -318,12 +321,19 @@ __device__ inline void rotation_prepass(const DevParams& P, const Layout& L, dou
     double w[6], gi[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const double s = sl[L.S + D::NC * k + 6 * l + i], lam = sl[L.LAM + D::NC * k + 6 * l + i];
+      const double lam = sl[L.LAM + D::NC * k + 6 * l + i];
       const double rc = sl[L.RC + D::NC * k + 6 * l + i];
-      const double kap = sl[L.DS + D::NC * k + 6 * l + i];     // weakly-active flag (see ipm_apply)
-      const double is = fast_rcp(s);
-      w[i] = lam * is;
-      gi[i] = (target + lam * rc) * is - kap * lam;
+      if (AL) {
+        const double z = lam + target * rc;
+        w[i] = (z > 0.0) ? target : 0.0;
+        gi[i] = (z > 0.0) ? z : 0.0;
+      } else {
+        const double s = sl[L.S + D::NC * k + 6 * l + i];
+        const double kap = sl[L.DS + D::NC * k + 6 * l + i];     // weakly-active flag (see ipm_apply)
+        const double is = fast_rcp(s);
+        w[i] = lam * is;
+        gi[i] = (target + lam * rc) * is - kap * lam;
+      }
     }
     // heaviest row i1, second heaviest non-(anti)parallel row i2 (rows 4,5 are antiparallel)
     int i1 = 0;
@@ -528,8 +538,10 @@ __device__ __forceinline__ void gj_finish(const double M[][TU][3], double Rr[][3
 // [Kt | dt], NU x 13 per knot).  Returns nonzero when a pivot is not positive.
 // PIPE: build the next knot's operands during the stage solve (needs 12 more VGPRs)
 template <class MD, bool PROF, bool PIPE, bool DPP64>
+// dV1 (optional): the expected decrease sum_k d_k' Qu_k of the line-search test (reference mode).
 __device__ inline int backward_pass(const DevParams& P, const Layout& L, double* sm, double* KD,
-                                    const double* ROT, int lane, unsigned conmask, Prof<PROF>& prof) {
+                                    const double* ROT, int lane, unsigned conmask, Prof<PROF>& prof,
+                                    double* dV1 = nullptr) {
   typedef typename MD::D D;
   constexpr int TU = D::TU;
   const int N = P.N;
@@ -560,6 +572,7 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
     for (int e = 0; e < 3; ++e) Pf[e] = cp.qadd[e] + ((cp.xoff[e] >= 0) ? XTk[cp.xoff[e]] : 0.0);
   }
   double minpiv = 1e300;
+  double dv_part = 0.0;       // this lane's share of dV1 (gradient column only)
   // operands of knot kk: Abar and rotated Bbar * T, straight into fragments.  They do not
   // depend on the cost-to-go, so the NEXT knot's operands are built while the
   // latency-bound stage solve of the current knot runs (software pipelining).
@@ -699,6 +712,12 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
     for (int t = 0; t < TU; ++t)
 #pragma unroll
       for (int e = 0; e < 3; ++e) Kf[t][e] = -Rr[t][e];
+    if (dV1) {                // column 12 of Qux is the rotated Qu, of Kf the rotated feed-forward
+#pragma unroll
+      for (int t = 0; t < TU; ++t)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) dv_part += (c == 12) ? Kf[t][e] * Qux[t][e] : 0.0;
+    }
     prof.tick(PH_SOLVE);
     // ---- cost-to-go: P_aug <- Qxx_aug + Qux_aug' [Kt | dt] ----
     {
@@ -728,6 +747,7 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
     }
     prof.tick(PH_PUPD);
   }
+  if (dV1) *dV1 = wave_sum(dv_part);
   return !(minpiv > 0.0);   // also true for a NaN pivot
 }
 
