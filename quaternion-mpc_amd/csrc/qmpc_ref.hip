@@ -1,6 +1,6 @@
 // qmpc_ref.hip -- QMPC_MODE_REFERENCE on the device: the reference's OWN operating mode, i.e. the AL-iLQR scheme of
 // its external solver with QuatMpc's settings (iterations_max = 10, penalty_scaling = 20, backtracking line search,
-// status ignored; legged_ctrl/src/mpc/QuatMpc.cpp:21-26,256), as restated in oracle/qo_altro.c:
+// status ignored; legged_ctrl/src/mpc/QuatMpc.cpp:21-26,256), as SURVEY.md Appendix B states it (the CPU checker under oracle/ restates the same scheme):
 //
 //   lambda <- 0, rho <- penalty_initial; U <- u_ref; X <- rollout; J <- AL merit
 //   repeat iter = 1 .. iterations_max:
@@ -72,7 +72,7 @@ __device__ inline double ref_merit(const DevParams& P, const Layout& L, double* 
 }
 
 // |grad_U L_A|_inf at (X, U) through the costate recursion  y_k = lx_k + Abar_k' y_{k+1},
-// gu_k = R (u_k - u_ref) + Bbar_k' y_{k+1} + sum_i zp_i a_i   (oracle/qo_altro.c: stationarity())
+// gu_k = R (u_k - u_ref) + Bbar_k' y_{k+1} + sum_i zp_i a_i   (costate recursion of SURVEY.md Appendix B)
 template <class MD>
 __device__ inline double ref_stationarity(const DevParams& P, const Layout& L, double* sm, const double* sl, double rho,
                                           unsigned conmask, int lane) {
