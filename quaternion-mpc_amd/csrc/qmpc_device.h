@@ -665,9 +665,13 @@ struct QuatModelT {
     return J;
   }
 
-  // operand patterns of the backward pass for fragment rows r_e = 4e + g, column c of input tile t
-  struct Operands {
-    double Ac[3], Bc[D::TU][3][3], hbw[D::TU][3][3];
+  // operand patterns of the backward pass for fragment rows r_e = 4e + g, column c of input tile t.
+  // LEANOPS (workspace variants, two waves per SIMD, 256 registers): the nine h Bw0 entries of the lane's contact
+  // point are re-read from LDS for every attitude row instead of living in 18 registers for the whole pass.
+  template <bool LEANOPS>
+  struct OperandsT {
+    double Ac[3], Bc[D::TU][3][3], hbw[LEANOPS ? 1 : D::TU][LEANOPS ? 1 : 3][LEANOPS ? 1 : 3];
+    const double* bwl;          // LEANOPS: &bw0[3 * lc]
     int aoff[3];
     bool phi[3];
     int g;
@@ -677,12 +681,15 @@ struct QuatModelT {
       g = lane >> 4;
       const bool cval = c < 12;
       const int lc = cval ? c / 3 : 0;
+      bwl = bw0 + 3 * lc;
+      if (!LEANOPS) {
 #pragma unroll
-      for (int t = 0; t < D::TU; ++t)
+        for (int t = 0; t < D::TU; ++t)
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+          for (int j = 0; j < 3; ++j)
 #pragma unroll
-          for (int a = 0; a < 3; ++a) hbw[t][j][a] = cval ? P.h * bw0[D::NU * j + 12 * t + 3 * lc + a] : 0.0;
+            for (int a = 0; a < 3; ++a) hbw[LEANOPS ? 0 : t][LEANOPS ? 0 : j][LEANOPS ? 0 : a] = cval ? P.h * bw0[D::NU * j + 12 * t + 3 * lc + a] : 0.0;
+      }
 #pragma unroll
       for (int e = 0; e < 3; ++e) {
         const int r = 4 * e + g;
@@ -723,9 +730,16 @@ struct QuatModelT {
       const double w0 = W[0], w1 = W[1], w2 = W[2];
 #pragma unroll
       for (int t = 0; t < D::TU; ++t) {
-        pr[t][0] = (0.5 * P.hh) * (w0 * hbw[t][0][0] + w1 * hbw[t][1][0] + w2 * hbw[t][2][0]);
-        pr[t][1] = (0.5 * P.hh) * (w0 * hbw[t][0][1] + w1 * hbw[t][1][1] + w2 * hbw[t][2][1]);
-        pr[t][2] = (0.5 * P.hh) * (w0 * hbw[t][0][2] + w1 * hbw[t][1][2] + w2 * hbw[t][2][2]);
+        if (LEANOPS) {      // the lanes without a column read contact point 0; their frame column tc is zero
+          const double* b = bwl + 12 * t;
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+            pr[t][a] = (0.5 * P.hh) * (w0 * (P.h * b[a]) + w1 * (P.h * b[D::NU + a]) + w2 * (P.h * b[2 * D::NU + a]));
+        } else {
+          pr[t][0] = (0.5 * P.hh) * (w0 * hbw[t][0][0] + w1 * hbw[t][1][0] + w2 * hbw[t][2][0]);
+          pr[t][1] = (0.5 * P.hh) * (w0 * hbw[t][0][1] + w1 * hbw[t][1][1] + w2 * hbw[t][2][1]);
+          pr[t][2] = (0.5 * P.hh) * (w0 * hbw[t][0][2] + w1 * hbw[t][1][2] + w2 * hbw[t][2][2]);
+        }
       }
     }
     // second half: select and rotate into the frame column
@@ -749,6 +763,7 @@ struct QuatModelT {
       for (int e = 0; e < 3; ++e) build_row(P, ABk, tc, e, Afo, Bfo);
     }
   };
+  typedef OperandsT<false> Operands;
 
   static __device__ __forceinline__ double a_elem(const DevParams& P, const double* cst, const double* bw0,
                                                   const double* AB, int r, int c) {
@@ -915,6 +930,8 @@ struct ConvexModel {
   }
 
   // entries of A that vary per knot: (row, col, record slot, scale)
+  struct Operands;
+  template <bool LEANOPS> using OperandsT = Operands;
   struct Operands {
     double Ac[3], asc[3], Bc[3][3], sk[3][3];
     double m0s[3], m1s[3], mz[3];      // row of the 3x3 factor: m0s*AB[mo0] , m1s*AB[mo1], mz

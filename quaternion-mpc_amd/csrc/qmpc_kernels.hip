@@ -31,6 +31,9 @@
 #ifndef QMPC_PIPE_ALL
 #define QMPC_PIPE_ALL false  // pipelined operand build in the workspace variants: measured slower (register pressure)
 #endif
+#ifndef QMPC_LEANOPS
+#define QMPC_LEANOPS true    // workspace variants: h Bw0 entries re-read from LDS in the operand build (register pressure)
+#endif
 #ifndef QMPC_NL8_WAVES
 #define QMPC_NL8_WAVES 2
 #endif
@@ -537,7 +540,7 @@ __device__ __forceinline__ void gj_finish(const double M[][TU][3], double Rr[][3
 // Riccati backward pass with interior-point weights; writes KD (rotated gains
 // [Kt | dt], NU x 13 per knot).  Returns nonzero when a pivot is not positive.
 // PIPE: build the next knot's operands during the stage solve (needs 12 more VGPRs)
-template <class MD, bool PROF, bool PIPE, bool DPP64>
+template <class MD, bool PROF, bool PIPE, bool DPP64, bool LEANOPS = false>
 // dV1 (optional): the expected decrease sum_k d_k' Qu_k of the line-search test (reference mode).
 __device__ inline int backward_pass(const DevParams& P, const Layout& L, double* sm, double* KD,
                                     const double* ROT, int lane, unsigned conmask, Prof<PROF>& prof,
@@ -552,7 +555,7 @@ __device__ inline int backward_pass(const DevParams& P, const Layout& L, double*
   const int lc = cval ? c / 3 : 0, bc = cval ? c - 3 * lc : 0;
   // ---- per-lane, per-fragment patterns (row r_e = 4e + g): the model's operand / cost
   //      patterns, and the rotated-block / gain offsets shared by both models ----
-  typename MD::Operands ops;
+  typename MD::template OperandsT<LEANOPS> ops;
   CostPattern cp;
   ops.init(P, cst, bw0, lane, cp);
   int doff[3], goff[3], koff[3];
@@ -1032,7 +1035,7 @@ __global__ __launch_bounds__(64, VAR == 0 ? 1 : (MD::NL != 4 ? (VAR == 2 ? QMPC_
     rotation_prepass<D>(P, L, sm, sl, ROT, target, lane);
     if (KDG) __syncthreads();
     prof.tick(PH_PREPASS);
-    if (backward_pass<MD, PROF, (!KDG || QMPC_PIPE_ALL), (SLG || D::TU > 1)>(P, L, sm, KD, ROT, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
+    if (backward_pass<MD, PROF, (!KDG || QMPC_PIPE_ALL), (SLG || D::TU > 1), QMPC_LEANOPS && KDG>(P, L, sm, KD, ROT, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
     if (KDG) __syncthreads();
     double ap, ad;
     rollout_closed<MD, !KDG, QMPC_PF_K, LEAN, PROF>(P, L, sm, KD, ROT, 1.0, lane, prof);  // trial step

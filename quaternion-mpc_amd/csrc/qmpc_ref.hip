@@ -113,7 +113,7 @@ __device__ inline double ref_stationarity(const DevParams& P, const Layout& L, d
 }
 
 template <class MD, int VAR>
-__global__ __launch_bounds__(64, VAR == 0 ? 1 : 2) void qmpc_ref_kernel(
+__global__ __launch_bounds__(64, 1) void qmpc_ref_kernel(   // one wave per SIMD: the line-search loop keeps ~400 registers live
     DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
     double* __restrict__ traj_u, double* __restrict__ traj_x, int batch, double* __restrict__ gws) {
   typedef typename MD::D D;

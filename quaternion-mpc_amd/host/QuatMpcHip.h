@@ -51,7 +51,10 @@ class LeggedMpcHipT {   // LeggedMpc.h:21-28
 template <class State>
 class QuatMpcHipT : public LeggedMpcHipT<State> {
  public:
-  QuatMpcHipT(State& state, const QmpcApi& api, int device = 0) : api_(api) {   // QuatMpc.cpp:8-55
+  // mode: QMPC_MODE_CONVERGED (default: the KKT point of the problem the reference poses) or QMPC_MODE_REFERENCE
+  // (the reference's own solver mode: AL-iLQR capped at 10 iterations, QuatMpc.cpp:21-26 -- the iterate the robot
+  // would have applied upstream)
+  QuatMpcHipT(State& state, const QmpcApi& api, int device = 0, int mode = QMPC_MODE_CONVERGED) : api_(api), mode_(mode) {   // QuatMpc.cpp:8-55
     for (int i = 0; i < 3; ++i) {
       torso_lin_vel_d_body_filter[i] = MovingWindowFilterHip(100);
       torso_pos_d_body_filter[i] = MovingWindowFilterHip(100);
@@ -66,7 +69,7 @@ class QuatMpcHipT : public LeggedMpcHipT<State> {
     for (int i = 0; i < NUM_LEG; ++i) leg_FSM[i].reset_params(state.param.gait_freq, i);
     attitude_traj_count = 0;
     // solver parameters = the fields grf_update passes to ALTRO (QuatMpc.cpp:182,218-229)
-    api_.default_params(&params_, horizon, QMPC_MODE_CONVERGED);
+    api_.default_params(&params_, horizon, mode_);
     params_.h = static_cast<float>(h / 1000.0);
     params_.h_ref = h / 1000.0;
     params_.mass = state.param.robot_mass;
@@ -241,7 +244,9 @@ class QuatMpcHipT : public LeggedMpcHipT<State> {
     // Per-instance status: QMPC_MAX_ITER still carries a usable iterate (it is what the reference itself applies,
     // its solver being capped at 10 iterations); every other non-OK word means the forces are zeros or a broken
     // iterate (NAN_INPUT, NO_CONTACT, LINESEARCH_FAIL, NOT_PD): keep the previous forces and say so.
-    if (info.status != QMPC_OK && info.status != QMPC_MAX_ITER) {
+    // (in reference mode a failed line search also leaves the last accepted iterate, which upstream would apply)
+    if (info.status != QMPC_OK && info.status != QMPC_MAX_ITER &&
+        !(mode_ == QMPC_MODE_REFERENCE && info.status == QMPC_LINESEARCH_FAIL)) {
       std::fprintf(stderr, "QuatMpcHip::grf_update: instance status %d, previous forces kept\n", (int)info.status);
       return false;
     }
@@ -265,6 +270,7 @@ class QuatMpcHipT : public LeggedMpcHipT<State> {
 
  private:
   QmpcApi api_;
+  int mode_ = QMPC_MODE_CONVERGED;
   qmpc_handle* handle_ = nullptr;
   qmpc_params params_;
   qmpc_status last_status_ = QMPC_NO_DEVICE;
