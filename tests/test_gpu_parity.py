@@ -798,6 +798,70 @@ def test_reference_mode_on_device_matches_oracle_reference_mode(pkg, lib, oracle
         assert (f.reshape(-1, 4, 3)[rec["contacts"] == 0] == 0).all()          # swing legs exactly 0
 
 
+def test_reference_mode_edge_cases_and_convex_model(pkg, lib, oracle):
+    """Reference mode: non-finite and no-contact records get their status and zero forces, trajectories come back,
+    the 8-point model is refused at create time, and ConvexMpc's problem (ConvexMpc.cpp:36-38: 5 iterations) follows
+    the oracle's reference mode in status, iteration count and objective (forces to the conditioning of a truncated iterate)."""
+    p = pkg.default_params(10, pkg.MODE_REFERENCE, lib)
+    rec = pkg.random_go1_trot_states(8, config_id=2)
+    rec["contacts"][1] = 0.0
+    rec["quat"][2][1] = np.nan
+    s = pkg.Solver(p, 8, device=0, lib=lib)
+    f, info, tu, tx = s.solve(rec, want_traj=True)
+    s.close()
+    fo, io, tuo, txo = oracle.solve(p, rec, want_traj=True)
+    assert info["status"][1] == pkg.NO_CONTACT and info["status"][2] == pkg.NAN_INPUT
+    assert (f[1] == 0).all() and (f[2] == 0).all() and (tu[1] == 0).all()
+    assert np.array_equal(info["status"], io["status"]) and np.array_equal(info["iterations"], io["iterations"])
+    assert np.abs(tu - tuo).max() < 1e-6 and np.abs(tx - txo).max() < 1e-9
+    with pytest.raises(pkg.QmpcError) as e:
+        pkg.Solver(pkg.default_biped8_params(16, pkg.MODE_REFERENCE, lib), 4, device=0, lib=lib)
+    assert e.value.code == pkg.UNSUPPORTED
+    pc = pkg.default_convex_params(20, pkg.MODE_REFERENCE, lib)
+    assert pc.iterations_max == 5
+    recc = pkg.random_go1_convex_states(256, config_id=13)
+    s = pkg.Solver(pc, 256, device=0, lib=lib)
+    f, info = s.convex_solve(recc)
+    s.close()
+    fo, io = oracle.convex_solve(pc, recc, threads=8)
+    d = np.abs(f - fo).max(axis=1)
+    same = (info["status"] == io["status"]) & (info["iterations"] == io["iterations"])
+    print(f"ConvexMpc reference mode: {int(same.sum())}/256 identical status and iterations; forces median {np.median(d):.2e}, "
+          f"worst {d.max():.2e} N; cost worst {np.abs(info['cost'] - io['cost']).max():.2e}")
+    # 5 ms knots make the first Newton systems of this problem ~1e11-conditioned (only R = 1e-6 sees the force
+    # directions): five truncated iterations leave the two implementations' rounding 1e-7 ... 4e-4 N apart, while
+    # status, iteration count and objective agree (in converged mode the same pair meets to 1e-12 N)
+    assert same.mean() >= 0.95 and d.max() < 2e-3 and np.median(d) < 1e-4
+    assert np.abs(info["cost"] - io["cost"]).max() < 1e-6
+
+
+def test_closed_loop_argument_checks_and_failed_instances(pkg, lib):
+    """qmpc_loop_run: capacity / model checks; a robot whose state turns non-finite reports NAN_INPUT every tick, keeps
+    its last forces and does not disturb its neighbours."""
+    lp = pkg.default_loop_params(lib)
+    st0 = pkg.loop_states([[0.2, 0, 0.3, 0, 0, 0, 0]] * 3, lp, lib=lib)
+    s = pkg.Solver(pkg.default_params(10, pkg.MODE_CONVERGED, lib), 2, device=0, lib=lib)
+    with pytest.raises(pkg.QmpcError) as e:
+        s.loop_run(st0, 3, lp)
+    assert e.value.code == pkg.BATCH_TOO_LARGE
+    s.close()
+    sc = pkg.Solver(pkg.default_convex_params(20, pkg.MODE_CONVERGED, lib), 4, device=0, lib=lib)
+    with pytest.raises(pkg.QmpcError) as e:
+        sc.loop_run(st0, 3, lp)
+    assert e.value.code == pkg.BAD_ARGUMENT
+    sc.close()
+    s = pkg.Solver(pkg.default_params(10, pkg.MODE_CONVERGED, lib), 4, device=0, lib=lib)
+    assert s.loop_run(st0, 0, lp).tobytes() == st0.tobytes()            # zero ticks: untouched
+    a = s.loop_run(st0, 5, lp)
+    bad = a.copy()
+    bad["lin_vel_world"][1][0] = np.inf
+    b = s.loop_run(bad, 4, lp)
+    c = s.loop_run(a, 4, lp)
+    s.close()
+    assert b["status"][1] == pkg.NAN_INPUT and np.array_equal(b["forces_body"][1], a["forces_body"][1])
+    assert b[0].tobytes() == c[0].tobytes() and b[2].tobytes() == c[2].tobytes()
+
+
 LOOP_COMMANDS = [   # joy.{velx, vely, body_height, roll_rate, pitch_rate, yaw_rate}, movement_mode
     [0.0, 0.0, 0.30, 0.0, 0.0, 0.0, 0.0],      # stand
     [0.3, 0.0, 0.30, 0.0, 0.0, 0.0, 1.0],      # trot forward
