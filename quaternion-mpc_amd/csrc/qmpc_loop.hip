@@ -45,12 +45,8 @@ __device__ inline double loop_filter(qmpc_loop_filter& f, double v) {   // Movin
 // arguments upstream), the 6x6 solve in double (Gaussian elimination with partial pivoting, three right-hand sides)
 __device__ inline void loop_swing_target(float t, float T, const double* start, const double* fin, double* out) {
 #pragma clang fp contract(off)
-  double Cm[6][6] = {{1, 0, 0, 0, 0, 0},
-                     {1, T, T * T, T * T * T, T * T * T * T, T * T * T * T * T},
-                     {0, 1, 0, 0, 0, 0},
-                     {0, 1, 2 * T, 3 * T * T, 4 * T * T * T, 5 * T * T * T * T},
-                     {1, T / 2, T * T / 4, T * T * T / 8, T * T * T * T / 16, T * T * T * T * T / 32},
-                     {0, 1, T, 3 * T * T / 4, 4 * T * T * T / 8, 5 * T * T * T * T / 16}};
+  double Cm[6][6];
+  qmpc_loop::swing_condition_matrix(T, Cm);
   const double dx = fin[0] - start[0], dy = fin[1] - start[1];
   const double k = 1.26 / T;
   const double v_xy_mid = k * sqrt(dx * dx + dy * dy);

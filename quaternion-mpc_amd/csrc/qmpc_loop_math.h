@@ -89,6 +89,31 @@ QMPC_HD void plant_step(double* x, const double* u, const double* feet_world, in
   for (int i = 3; i < 7; ++i) x[i] = x[i] / n;
 }
 
+// Condition matrix of the swing-foot quintic p(t) = sum_k a_k t^k (QuinticCurve::get_foot_swing_target,
+// Utils.cpp:236-293): rows p(0), p(T), p'(0), p'(T), p(T/2), p'(T/2).  Generated, with the reference's FLOAT
+// evaluation order so that every entry carries the same rounding as upstream's hand-written expressions: a power is
+// the left-to-right product  (c * T) * T * ...  started from the derivative factor c, and the half-time rows divide
+// that product by 2^j afterwards.
+QMPC_HD void swing_condition_matrix(float T, double C[6][6]) {
+  QMPC_NO_CONTRACT
+  for (int r = 0; r < 6; ++r)
+    for (int k = 0; k < 6; ++k) C[r][k] = 0.0;
+  C[0][0] = 1.0;                                   // p(0)
+  C[2][1] = 1.0;                                   // p'(0)
+  for (int k = 0; k < 6; ++k) {
+    float pw = 1.0f;                               // T^k
+    for (int j = 0; j < k; ++j) pw = pw * T;
+    C[1][k] = pw;                                  // p(T)
+    C[4][k] = (k == 0) ? 1.0f : pw / (float)(1 << k);             // p(T/2) = T^k / 2^k
+    if (k >= 1) {
+      float dv = (float)k;                         // k T^(k-1), as (k * T) * T * ...
+      for (int j = 0; j < k - 1; ++j) dv = dv * T;
+      C[3][k] = (k == 1) ? 1.0f : dv;              // p'(T)
+      C[5][k] = (k == 1) ? 1.0f : dv / (float)(1 << (k - 1));     // p'(T/2) = k T^(k-1) / 2^(k-1)
+    }
+  }
+}
+
 // 3x3 inverse by cofactors (row-major)
 QMPC_HD void inv3(const double* A, double* B) {
   QMPC_NO_CONTRACT

@@ -8,6 +8,8 @@
 
 #include <cmath>
 
+#include "../csrc/qmpc_loop_math.h"
+
 namespace legged {
 
 // Per axis the reference fits a quintic a0..a5 through six conditions by inverting a 6x6 matrix
@@ -18,12 +20,8 @@ class QuinticCurveHip {
  public:
   // out: pos(3) vel(3) acc(3)
   void get_foot_swing_target(float t, float T, const double start[3], const double fin[3], double out[9]) {
-    double C[6][6] = {{1, 0, 0, 0, 0, 0},
-                      {1, T, T * T, T * T * T, T * T * T * T, T * T * T * T * T},
-                      {0, 1, 0, 0, 0, 0},
-                      {0, 1, 2 * T, 3 * T * T, 4 * T * T * T, 5 * T * T * T * T},
-                      {1, T / 2, T * T / 4, T * T * T / 8, T * T * T * T / 16, T * T * T * T * T / 32},
-                      {0, 1, T, 3 * T * T / 4, 4 * T * T * T / 8, 5 * T * T * T * T / 16}};
+    double C[6][6];
+    qmpc_loop::swing_condition_matrix(T, C);      // p(0), p(T), p'(0), p'(T), p(T/2), p'(T/2); float entries
     const double dx = fin[0] - start[0], dy = fin[1] - start[1];
     const double k = 1.26 / T;                                   // Utils.cpp:247
     const double v_xy_mid = k * std::sqrt(dx * dx + dy * dy);
