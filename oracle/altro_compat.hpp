@@ -58,7 +58,7 @@ struct AltroOptions {
   double penalty_scaling = 10.0;
   double penalty_max = 1e8;
   Verbosity verbose = Verbosity::Silent;
-  bool use_backtracking_linesearch = true;
+  bool use_backtracking_linesearch = true;   // the only search restated (what every caller on the path selects)
   bool use_quaternion = false;
   int quat_start_index = 0;
 };
