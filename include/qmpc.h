@@ -68,8 +68,7 @@ typedef enum qmpc_mode {
   /* Reference-style truncated AL-iLQR: iterations_max=10, penalty_scaling=20
      (QuatMpc.cpp:22,26) and the upstream ALTRO tolerances (1e-4): the iterate the
      reference's own solver returns (status ignored, QuatMpc.cpp:256).  On the device
-     for the Go1 models (QuatMpc, ConvexMpc); qmpc_create returns QMPC_UNSUPPORTED for
-     the 8-contact-point model.                                                  */
+     for all three models.                                                       */
   QMPC_MODE_REFERENCE = 1
 } qmpc_mode;
 

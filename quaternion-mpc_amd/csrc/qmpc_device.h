@@ -582,19 +582,21 @@ __device__ __forceinline__ double abar_elem(const DevParams& P, const double* AB
   }
   return (r == c) ? 1.0 : 0.0;
 }
-// Element (r, 3l+a) of the dense 12x12 Bbar (unrotated).
+// Element (r, 3l+a) of the dense 12 x 3NL Bbar (unrotated); bw0 is 3 x 3NL row-major.
+template <int NL>
 __device__ __forceinline__ double bbar_elem(const DevParams& P, const double* cst, const double* bw0,
                                             const double* AB, int r, int col) {
+  constexpr int NU = 3 * NL;
   const int l = col / 3, a = col - 3 * l;
-  const double cl = cst[C_CON + l];
+  const double cl = cst[Dim<NL>::C_CON + l];
   if (r < 3) return (r == a) ? cl * (P.h * (P.hh * (1.0 / P.mass))) : 0.0;
   if (r < 6) {
     const double* W = AB + 18 + 3 * (r - 3);
-    return (0.5 * P.hh) * (W[0] * (P.h * bw0[col]) + W[1] * (P.h * bw0[12 + col]) +
-                            W[2] * (P.h * bw0[24 + col]));
+    return (0.5 * P.hh) * (W[0] * (P.h * bw0[col]) + W[1] * (P.h * bw0[NU + col]) +
+                            W[2] * (P.h * bw0[2 * NU + col]));
   }
   if (r < 9) return (r - 6 == a) ? cl * (P.h * (1.0 / P.mass)) : 0.0;
-  return P.h * bw0[12 * (r - 9) + col];
+  return P.h * bw0[NU * (r - 9) + col];
 }
 
 
@@ -771,7 +773,7 @@ struct QuatModelT {
   }
   static __device__ __forceinline__ double b_elem(const DevParams& P, const double* cst, const double* bw0,
                                                   const double* AB, int r, int c) {
-    return bbar_elem(P, cst, bw0, AB, r, c);
+    return bbar_elem<NL_>(P, cst, bw0, AB, r, c);
   }
 };
 typedef QuatModelT<4> QuatModel;

@@ -247,7 +247,9 @@ static qmpc_status create_resources(qmpc_handle* h, int N, int nl, int nu) {
     QMPC_SET_LDS(qmpc_linearize_kernel<QuatModel>, h->lds_bytes_g);
   }
   if (params->mode == QMPC_MODE_REFERENCE) {
-    if (params->model == QMPC_MODEL_CONVEX) {
+    if (params->model == QMPC_MODEL_QUAT8) {
+      QMPC_SET_LDS((qmpc_ref_kernel<Quat8Model, 1>), h->lds_bytes_g);     // never everything in LDS
+    } else if (params->model == QMPC_MODEL_CONVEX) {
       if (h->lds_bytes <= 160 * 1024) QMPC_SET_LDS((qmpc_ref_kernel<ConvexModel, 0>), h->lds_bytes);
       QMPC_SET_LDS((qmpc_ref_kernel<ConvexModel, 1>), h->lds_bytes_g);
     } else {
@@ -287,10 +289,7 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
   h->lds_bytes_g = (size_t)Lg.total * sizeof(double);
   h->lds_bytes_s = (size_t)Ls.total * sizeof(double);
   if (h->lds_bytes_g > 160 * 1024) { delete h; return QMPC_BAD_ARGUMENT; }
-  if (params->mode == QMPC_MODE_REFERENCE && params->model == QMPC_MODEL_QUAT8) {   // Go1 models only (qmpc_ref.hip)
-    delete h;
-    return QMPC_UNSUPPORTED;
-  }
+
   {
     const char* v = std::getenv("QMPC_VARIANT");
     h->variant = v ? std::atoi(v) : 0;
@@ -346,13 +345,15 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;   // the gains workspace is sized by max_batch
   if (timed) HIP_TRY(hipEventRecord(h->ev0, s));
   if (h->params.mode == QMPC_MODE_REFERENCE) {     // the reference's own AL-iLQR mode (qmpc_ref.hip)
-    const bool ws = batch > 1024 || h->lds_bytes > 40 * 1024 || h->variant >= 2;
+    const bool ws = batch > 1024 || h->lds_bytes > 40 * 1024 || h->variant >= 2 || h->params.model == QMPC_MODEL_QUAT8;
     const size_t lds_r = ws ? h->lds_bytes_g : h->lds_bytes;
     double* gws_r = ws ? h->d_gws : nullptr;
 #define QMPC_LAUNCH_REF(kern) \
   hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kWave), lds_r, s, h->dev, d_in, d_forces, d_info, d_tu, d_tx, \
                      (int)batch, gws_r)
-    if (h->params.model == QMPC_MODEL_CONVEX) {
+    if (h->params.model == QMPC_MODEL_QUAT8) {
+      QMPC_LAUNCH_REF((qmpc_ref_kernel<Quat8Model, 1>));
+    } else if (h->params.model == QMPC_MODEL_CONVEX) {
       if (ws) QMPC_LAUNCH_REF((qmpc_ref_kernel<ConvexModel, 1>));
       else QMPC_LAUNCH_REF((qmpc_ref_kernel<ConvexModel, 0>));
     } else {

@@ -800,7 +800,7 @@ def test_reference_mode_on_device_matches_oracle_reference_mode(pkg, lib, oracle
 
 def test_reference_mode_edge_cases_and_convex_model(pkg, lib, oracle):
     """Reference mode: non-finite and no-contact records get their status and zero forces, trajectories come back,
-    the 8-point model is refused at create time, and ConvexMpc's problem (ConvexMpc.cpp:36-38: 5 iterations) follows
+    the 8-point model follows the oracle too, and ConvexMpc's problem (ConvexMpc.cpp:36-38: 5 iterations) follows
     the oracle's reference mode in status, iteration count and objective (forces to the conditioning of a truncated iterate)."""
     p = pkg.default_params(10, pkg.MODE_REFERENCE, lib)
     rec = pkg.random_go1_trot_states(8, config_id=2)
@@ -814,9 +814,19 @@ def test_reference_mode_edge_cases_and_convex_model(pkg, lib, oracle):
     assert (f[1] == 0).all() and (f[2] == 0).all() and (tu[1] == 0).all()
     assert np.array_equal(info["status"], io["status"]) and np.array_equal(info["iterations"], io["iterations"])
     assert np.abs(tu - tuo).max() < 1e-6 and np.abs(tx - txo).max() < 1e-9
-    with pytest.raises(pkg.QmpcError) as e:
-        pkg.Solver(pkg.default_biped8_params(16, pkg.MODE_REFERENCE, lib), 4, device=0, lib=lib)
-    assert e.value.code == pkg.UNSUPPORTED
+    p8 = pkg.default_biped8_params(16, pkg.MODE_REFERENCE, lib)
+    rec8 = pkg.random_biped8_states(128, config_id=5)
+    s = pkg.Solver(p8, 128, device=0, lib=lib)
+    f8, i8 = s.solve8(rec8)
+    s.close()
+    f8o, i8o = oracle.solve8(p8, rec8, threads=8)
+    same8 = (i8["status"] == i8o["status"]) & (i8["iterations"] == i8o["iterations"])
+    feet = rec8["foot_pos_body"].reshape(-1, 8, 3)
+    wr = lambda F: np.concatenate([F.reshape(-1, 8, 3).sum(1), np.cross(feet, F.reshape(-1, 8, 3)).sum(1)], axis=1)
+    dw = np.abs(wr(f8) - wr(f8o)).max(axis=1)
+    print(f"8-point model reference mode: {int(same8.sum())}/128 identical status and iterations; foot wrench median "
+          f"{np.median(dw):.2e}, worst {dw.max():.2e}")
+    assert same8.mean() >= 0.95 and np.median(dw) < 1e-6 and dw.max() < 1e-3
     pc = pkg.default_convex_params(20, pkg.MODE_REFERENCE, lib)
     assert pc.iterations_max == 5
     recc = pkg.random_go1_convex_states(256, config_id=13)
