@@ -201,6 +201,7 @@ def main():
     torch.cuda.set_device(local)
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")     # only a bare `--force-dist` run lacks the launcher's value
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     pkg = load_pkg()
@@ -291,7 +292,7 @@ def main():
     # BASELINE config 4 beside the weak-scaling value: 262144 Go1 instances, N=10, sharded over the ranks
     # (32768 per GPU at 8 GPUs), same pipeline, a few steps.  Every rank takes part (collectives).
     config4 = None
-    if world > 1 and not args.no_config4 and args.model == "quat":
+    if (world > 1 or (args.force_dist and os.environ.get("QMPC_BENCH_FORCE_CONFIG4"))) and not args.no_config4 and args.model == "quat":
         B4 = 262144 // world
         p4 = pkg.default_params(10, pkg.MODE_CONVERGED, lib)
         k4 = max(2, min(5, args.steps))
