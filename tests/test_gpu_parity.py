@@ -1004,6 +1004,20 @@ def test_gpu_against_committed_oracle_fixture(pkg, lib, name, gen, dp, solve, N,
         assert np.abs(f - want).max() < 1e-6
 
 
+def test_closed_loop_c_example_runs_on_the_gpu(pkg, lib, tmp_path):
+    """examples/closed_loop.c: the device-resident closed loop from plain C; 32 robots trot for 1.5 s, none falls."""
+    import subprocess
+
+    repo = Path(__file__).resolve().parents[1]
+    so = repo / "quaternion-mpc_amd" / "csrc" / "libqmpc_hip.so"
+    exe = tmp_path / "closed_loop"
+    subprocess.run(["gcc", "-O2", "-I", str(repo / "include"), str(repo / "examples" / "closed_loop.c"), "-o", str(exe),
+                    str(so), f"-Wl,-rpath,{so.parent}", "-lm"], check=True)
+    r = subprocess.run([str(exe), "32", "300"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 not upright" in r.stdout
+
+
 def test_c_example_runs_on_the_gpu(pkg, lib, tmp_path):
     """examples/solve_batch.c through the C ABI from plain C: all instances converge, the stand pose carries the weight."""
     import subprocess

@@ -582,6 +582,15 @@ def test_c_example_builds_and_fails_loudly_without_a_gpu(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
     else:
         assert r.returncode == 2 and "no CPU fallback" in r.stderr
+    # the closed-loop example too
+    exe2 = tmp_path / "closed_loop"
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I", str(repo / "include"), str(repo / "examples" / "closed_loop.c"),
+                    "-o", str(exe2), str(lib), f"-Wl,-rpath,{lib.parent}", "-lm"], check=True)
+    r = subprocess.run([str(exe2), "4", "10"], capture_output=True, text=True)
+    if has_gpu:
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:
+        assert r.returncode == 2 and "no CPU fallback" in r.stderr
     shutil.rmtree(tmp_path, ignore_errors=True)
 
 
