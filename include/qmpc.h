@@ -314,6 +314,39 @@ qmpc_status qmpc_torque_map_device(qmpc_handle* h, const qmpc_leg_geometry* g, i
                                    const double* d_contacts, int32_t walking, double* d_tau,
                                    void* stream);
 
+/* ---- the whole low-level command of a tick (completed) -----
+ * BaseInterface::tau_ctrl_update (BaseInterface.cpp:343-408) turns the outputs of grf_update into what the
+ * 1 kHz joint loop sends to the motors: per leg
+ *   walking (movement_mode > 0):
+ *     joint_ang_tgt = inv_kin(R'(optimized_state[6+3i] - torso_pos_world), joint_pos)     (:349-355; NaN -> joint_pos)
+ *     joint_vel_tgt = J^-1 R'(optimized_input[12+3i] - torso_lin_vel_world)               (:358-364; NaN -> joint_vel)
+ *     joint_tau_tgt = plan_contacts ? -J' optimized_input[3i] : 0                         (:367-371)
+ *   standing: joint_tau_tgt = -J' f, targets = the measured joint_pos / joint_vel          (:400-403)
+ * with J = A1Kinematics::jac(joint_pos) (BaseInterface.cpp:209-212) and A1Kinematics::inv_kin
+ * (A1Kinematics.cpp:335-459: closed-form, single-precision atan2 approximation :291-312, the hip-angle branch
+ * nearest to the current angle). */
+typedef struct qmpc_joint_feedback {
+  double joint_pos[12], joint_vel[12];                     /* fbk.joint_pos / joint_vel, leg-major (hip, thigh, calf)  */
+  double torso_pos_world[3], torso_quat[4] /* w,x,y,z */, torso_lin_vel_world[3];
+  double foot_pos_target_world[12];                        /* ctrl.optimized_state.segment<12>(6),  QuatMpc.cpp:270    */
+  double foot_vel_target_world[12];                        /* ctrl.optimized_input.segment<12>(12), QuatMpc.cpp:271    */
+  double forces_body[12];                                  /* ctrl.optimized_input.segment<12>(0),  QuatMpc.cpp:267    */
+  double plan_contacts[4];                                 /* ctrl.plan_contacts (0 / 1)                               */
+  double movement_mode;
+} qmpc_joint_feedback;                                     /* 75 doubles */
+typedef struct qmpc_joint_command {
+  double joint_ang_tgt[12], joint_vel_tgt[12], joint_tau_tgt[12];
+} qmpc_joint_command;                                      /* 36 doubles */
+/* A1Kinematics::inv_kin for every instance and leg: foot_pos_body [batch][12], cur_joint_pos [batch][12] (branch
+ * selection), joint_pos [batch][12] out (NaN where the foot is out of reach, as in the reference).  Host buffers. */
+qmpc_status qmpc_leg_inverse_kinematics(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch,
+                                        const double* foot_pos_body, const double* cur_joint_pos, double* joint_pos);
+/* tau_ctrl_update for `batch` robots.  Host buffers / device buffers (stream-ordered, NULL = the handle's stream). */
+qmpc_status qmpc_joint_commands(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch,
+                                const qmpc_joint_feedback* fb, qmpc_joint_command* cmd);
+qmpc_status qmpc_joint_commands_device(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch,
+                                       const qmpc_joint_feedback* d_fb, qmpc_joint_command* d_cmd, void* stream);
+
 /* ---- device-resident closed loop -----------------------
  * The step BEFORE the path, the path and a plant chained on the GPU, state kept in HBM, one tick =
  *   feedback  (R, R_z, foot_pos_body, contact flags from the plant state)
@@ -372,6 +405,18 @@ qmpc_status qmpc_loop_run(qmpc_handle* h, const qmpc_loop_params* lp, int32_t ba
 qmpc_status qmpc_loop_run_device(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* d_states,
                                  int32_t ticks, double* d_trace_forces, double* d_trace_contacts, void* stream);
 int32_t qmpc_sizeof_loop_state(void);
+/* Joint-level commands of the robots of a closed loop, from their states after a tick (device buffers): the plant has
+ * massless legs, so the measured joint angles are inv_kin of the plant's foot positions; d_joint_pos [batch][12] is
+ * in/out (in: the angles of the previous tick, which select the hip branch - initialise with
+ * qmpc_loop_joint_init; out: this tick's), the joint velocities are J^-1 R'(foot velocity - torso velocity) with
+ * swing feet moving at their FSM target velocity.  d_fb (may be NULL) receives the feedback records that were built,
+ * d_cmd the commands: exactly qmpc_joint_commands_device on those records. */
+qmpc_status qmpc_loop_joint_commands_device(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch,
+                                            const qmpc_loop_state* d_states, double* d_joint_pos,
+                                            qmpc_joint_feedback* d_fb, qmpc_joint_command* d_cmd, void* stream);
+/* Stand-pose joint angles (0, 0.67, -1.3 per leg: the reference's Gazebo start pose) for `batch`
+ * robots, host buffer [batch][12]. */
+void qmpc_loop_joint_init(double* joint_pos, int32_t batch);
 
 /* ---- diagnostics ----------------------------------------------------------- */
 /* C = X' * Y on [12][16] row-major tiles through the FP64 MFMA path the solver

@@ -82,6 +82,8 @@ def lib() -> C.CDLL:
         _lib.qo_default_go1_geometry.argtypes = [vp]
         _lib.qo_leg_kinematics.argtypes = [vp, i32, vp, vp, vp]
         _lib.qo_torque_map.argtypes = [vp, i32, vp, vp, vp, i32, vp]
+        _lib.qo_leg_inverse_kinematics.argtypes = [vp, i32, vp, vp, vp]
+        _lib.qo_joint_commands.argtypes = [vp, i32, vp, vp]
         for fn in ("qo_solve_one_dual", "qo_solve8_one_dual", "qo_convex_solve_one_dual"):
             getattr(_lib, fn).argtypes = [C.POINTER(Params)] + [vp] * 7
             getattr(_lib, fn).restype = i32
@@ -228,6 +230,21 @@ def torque_map(geom, joint_pos, forces_body, contacts=None, walking: bool = True
     tau = np.zeros((len(q), 12))
     lib().qo_torque_map(C.byref(geom), len(q), _ptr(q), _ptr(f), _ptr(c), int(bool(walking)), _ptr(tau))
     return tau
+
+
+def leg_inverse_kinematics(geom, foot_pos_body, cur_joint_pos):
+    p = np.ascontiguousarray(foot_pos_body, dtype=np.float64).reshape(-1, 12)
+    c = np.ascontiguousarray(cur_joint_pos, dtype=np.float64).reshape(-1, 12)
+    q = np.zeros((len(p), 12))
+    lib().qo_leg_inverse_kinematics(C.byref(geom), len(p), _ptr(p), _ptr(c), _ptr(q))
+    return q
+
+
+def joint_commands(geom, feedback):
+    fb = np.ascontiguousarray(feedback, dtype=pkg.JOINT_FEEDBACK_DTYPE)
+    cmd = np.zeros(len(fb), dtype=pkg.JOINT_COMMAND_DTYPE)
+    lib().qo_joint_commands(C.byref(geom), len(fb), _ptr(fb), _ptr(cmd))
+    return cmd
 
 
 def kat_double_integrator(which: int, verbose: int = 0):

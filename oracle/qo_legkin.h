@@ -27,6 +27,15 @@ void qo_leg_kinematics(const qmpc_leg_geometry* g, int32_t batch, const double* 
 void qo_torque_map(const qmpc_leg_geometry* g, int32_t batch, const double* joint_pos,
                    const double* forces_body, const double* contacts, int32_t walking, double* tau);
 
+/* A1Kinematics::inv_kin (A1Kinematics.cpp:335-459) with its single-precision atan2 approximation (:291-312).
+ * q = (hip, thigh, calf); cur_q selects the hip branch.  NaN when the foot is out of reach. */
+void qo_leg_inv_kin(const double p[3], const double cur_q[3], const double rho_fix[5], double q[3]);
+void qo_leg_inverse_kinematics(const qmpc_leg_geometry* g, int32_t batch, const double* foot_pos_body,
+                               const double* cur_joint_pos, double* joint_pos);
+/* BaseInterface::tau_ctrl_update (BaseInterface.cpp:343-408) */
+void qo_joint_commands(const qmpc_leg_geometry* g, int32_t batch, const qmpc_joint_feedback* fb,
+                       qmpc_joint_command* cmd);
+
 #ifdef __cplusplus
 }
 #endif

@@ -151,6 +151,16 @@ LOOP_STATE_DTYPE = np.dtype([
 assert LOOP_STATE_DTYPE.itemsize == 818 * 8
 
 
+# BaseInterface::tau_ctrl_update records (include/qmpc.h: qmpc_joint_feedback / qmpc_joint_command)
+JOINT_FEEDBACK_DTYPE = np.dtype([
+    ("joint_pos", "<f8", (12,)), ("joint_vel", "<f8", (12,)), ("torso_pos_world", "<f8", (3,)), ("torso_quat", "<f8", (4,)),
+    ("torso_lin_vel_world", "<f8", (3,)), ("foot_pos_target_world", "<f8", (12,)), ("foot_vel_target_world", "<f8", (12,)),
+    ("forces_body", "<f8", (12,)), ("plan_contacts", "<f8", (4,)), ("movement_mode", "<f8")])
+JOINT_COMMAND_DTYPE = np.dtype([("joint_ang_tgt", "<f8", (12,)), ("joint_vel_tgt", "<f8", (12,)),
+                                ("joint_tau_tgt", "<f8", (12,))])
+assert JOINT_FEEDBACK_DTYPE.itemsize == 75 * 8 and JOINT_COMMAND_DTYPE.itemsize == 36 * 8
+
+
 class LoopParams(C.Structure):
     """struct qmpc_loop_params."""
 
@@ -255,6 +265,16 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.qmpc_torque_map.restype = i32
     lib.qmpc_torque_map_device.argtypes = [vp, C.POINTER(LegGeometry), i32, vp, vp, vp, i32, vp, vp]
     lib.qmpc_torque_map_device.restype = i32
+    lib.qmpc_leg_inverse_kinematics.argtypes = [vp, C.POINTER(LegGeometry), i32, vp, vp, vp]
+    lib.qmpc_leg_inverse_kinematics.restype = i32
+    lib.qmpc_joint_commands.argtypes = [vp, C.POINTER(LegGeometry), i32, vp, vp]
+    lib.qmpc_joint_commands.restype = i32
+    lib.qmpc_joint_commands_device.argtypes = [vp, C.POINTER(LegGeometry), i32, vp, vp, vp]
+    lib.qmpc_joint_commands_device.restype = i32
+    lib.qmpc_loop_joint_commands_device.argtypes = [vp, C.POINTER(LegGeometry), i32, vp, vp, vp, vp, vp]
+    lib.qmpc_loop_joint_commands_device.restype = i32
+    lib.qmpc_loop_joint_init.argtypes = [vp, i32]
+    lib.qmpc_loop_joint_init.restype = None
     lib.qmpc_default_biped8_params.argtypes = [C.POINTER(Params), i32, i32]
     lib.qmpc_default_biped8_params.restype = None
     lib.qmpc_solve8.argtypes = [vp, i32, vp, vp, vp]
@@ -331,6 +351,11 @@ EXPORTED_SYMBOLS = (
     "qmpc_loop_run",
     "qmpc_loop_run_device",
     "qmpc_sizeof_loop_state",
+    "qmpc_leg_inverse_kinematics",
+    "qmpc_joint_commands",
+    "qmpc_joint_commands_device",
+    "qmpc_loop_joint_commands_device",
+    "qmpc_loop_joint_init",
 )
 
 
@@ -581,6 +606,40 @@ class Solver:
                                              C.c_void_p(stream) if stream else None)
         if st != OK:
             raise QmpcError(st, "qmpc_torque_map_device")
+
+    def leg_inverse_kinematics(self, geom: LegGeometry, foot_pos_body, cur_joint_pos):
+        """A1Kinematics::inv_kin for every (instance, leg); NaN where the foot is out of reach."""
+        p = np.ascontiguousarray(foot_pos_body, dtype=np.float64).reshape(-1, 12)
+        c = np.ascontiguousarray(cur_joint_pos, dtype=np.float64).reshape(-1, 12)
+        q = np.zeros((len(p), 12))
+        st = self.lib.qmpc_leg_inverse_kinematics(self._h, C.byref(geom), len(p), _ptr(p), _ptr(c), _ptr(q))
+        if st != OK:
+            raise QmpcError(st, "qmpc_leg_inverse_kinematics")
+        return q
+
+    def joint_commands(self, geom: LegGeometry, feedback: np.ndarray) -> np.ndarray:
+        """BaseInterface::tau_ctrl_update for a batch of JOINT_FEEDBACK_DTYPE records -> JOINT_COMMAND_DTYPE."""
+        fb = np.ascontiguousarray(feedback, dtype=JOINT_FEEDBACK_DTYPE)
+        cmd = np.zeros(len(fb), dtype=JOINT_COMMAND_DTYPE)
+        st = self.lib.qmpc_joint_commands(self._h, C.byref(geom), len(fb), _ptr(fb), _ptr(cmd))
+        if st != OK:
+            raise QmpcError(st, "qmpc_joint_commands")
+        return cmd
+
+    def joint_commands_device(self, geom: LegGeometry, batch: int, d_fb: int, d_cmd: int, stream: int = 0):
+        st = self.lib.qmpc_joint_commands_device(self._h, C.byref(geom), int(batch), C.c_void_p(d_fb), C.c_void_p(d_cmd),
+                                                 C.c_void_p(stream) if stream else None)
+        if st != OK:
+            raise QmpcError(st, "qmpc_joint_commands_device")
+
+    def loop_joint_commands_device(self, geom: LegGeometry, batch: int, d_states: int, d_joint_pos: int, d_fb: int,
+                                   d_cmd: int, stream: int = 0):
+        """Joint-level feedback (d_fb may be 0) and commands of the robots of a closed loop, from their states."""
+        st = self.lib.qmpc_loop_joint_commands_device(self._h, C.byref(geom), int(batch), C.c_void_p(d_states),
+                                                      C.c_void_p(d_joint_pos), C.c_void_p(d_fb) if d_fb else None,
+                                                      C.c_void_p(d_cmd), C.c_void_p(stream) if stream else None)
+        if st != OK:
+            raise QmpcError(st, "qmpc_loop_joint_commands_device")
 
     def phase_profile(self, inputs: np.ndarray) -> np.ndarray:
         inputs = np.ascontiguousarray(inputs, dtype=INPUT_DTYPE)

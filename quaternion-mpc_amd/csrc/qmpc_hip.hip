@@ -8,6 +8,7 @@
 // QMPC_NO_DEVICE.
 #include "qmpc_kernels.hip"
 #include "qmpc_loop.hip"
+#include "qmpc_joint.hip"
 #include "qmpc_ref.hip"
 
 #include <dlfcn.h>
@@ -631,7 +632,6 @@ static qmpc_status leg_host(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t 
   // layout: q[12B] f[12B] c[4B] p[12B] J[36B] tau[12B]; the staging buffer belongs to the handle and only grows
   if (h->leg_cap < B * 88) {
     if (h->d_leg) (void)hipFree(h->d_leg);
-  if (h->d_loop_row) (void)hipFree(h->d_loop_row);
     h->d_leg = nullptr;
     h->leg_cap = 0;
     HIP_TRY(hipMalloc(&h->d_leg, sizeof(double) * B * 88));
@@ -667,6 +667,89 @@ qmpc_status qmpc_torque_map(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t 
   if (!h || !g || batch < 0 || (batch > 0 && (!joint_pos || !forces_body || !tau))) return QMPC_BAD_ARGUMENT;
   if (batch == 0) return QMPC_OK;
   return leg_host(h, g, batch, joint_pos, forces_body, contacts, walking, nullptr, nullptr, tau);
+}
+
+// ---- joint-level commands (BaseInterface.cpp:343-408; kernels in qmpc_joint.hip) ------------------
+static qmpc_status grow_leg_staging(qmpc_handle* h, size_t doubles) {
+  if (h->leg_cap >= doubles) return QMPC_OK;
+  if (h->d_leg) (void)hipFree(h->d_leg);
+  h->d_leg = nullptr;
+  h->leg_cap = 0;
+  HIP_TRY(hipMalloc(&h->d_leg, sizeof(double) * doubles));
+  h->leg_cap = doubles;
+  return QMPC_OK;
+}
+
+qmpc_status qmpc_joint_commands_device(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch,
+                                       const qmpc_joint_feedback* d_fb, qmpc_joint_command* d_cmd, void* stream) {
+  if (!h || !g || batch < 0 || (batch > 0 && (!d_fb || !d_cmd))) return QMPC_BAD_ARGUMENT;
+  if (batch == 0) return QMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  LegGeom G;
+  std::memcpy(&G, g, sizeof G);
+  hipLaunchKernelGGL(qmpc_joint_cmd_kernel, dim3((unsigned)((batch + kJointTile - 1) / kJointTile)), dim3(256), 0,
+                     stream ? (hipStream_t)stream : h->stream, G, d_fb, d_cmd, (int)batch);
+  HIP_TRY(hipGetLastError());
+  return QMPC_OK;
+}
+
+qmpc_status qmpc_joint_commands(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch, const qmpc_joint_feedback* fb,
+                                qmpc_joint_command* cmd) {
+  if (!h || !g || batch < 0 || (batch > 0 && (!fb || !cmd))) return QMPC_BAD_ARGUMENT;
+  if (batch == 0) return QMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t B = (size_t)batch;
+  const qmpc_status gs = grow_leg_staging(h, B * (kJointFb + kJointCmd));
+  if (gs != QMPC_OK) return gs;
+  qmpc_joint_feedback* dfb = reinterpret_cast<qmpc_joint_feedback*>(h->d_leg);
+  qmpc_joint_command* dcmd = reinterpret_cast<qmpc_joint_command*>(h->d_leg + B * kJointFb);
+  HIP_TRY(hipMemcpyAsync(dfb, fb, sizeof(qmpc_joint_feedback) * B, hipMemcpyHostToDevice, h->stream));
+  const qmpc_status st = qmpc_joint_commands_device(h, g, batch, dfb, dcmd, h->stream);
+  if (st != QMPC_OK) return st;
+  HIP_TRY(hipMemcpyAsync(cmd, dcmd, sizeof(qmpc_joint_command) * B, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return QMPC_OK;
+}
+
+qmpc_status qmpc_leg_inverse_kinematics(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch,
+                                        const double* foot_pos_body, const double* cur_joint_pos, double* joint_pos) {
+  if (!h || !g || batch < 0 || (batch > 0 && (!foot_pos_body || !cur_joint_pos || !joint_pos))) return QMPC_BAD_ARGUMENT;
+  if (batch == 0) return QMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t B = (size_t)batch;
+  const qmpc_status gs = grow_leg_staging(h, B * 36);
+  if (gs != QMPC_OK) return gs;
+  double *dp = h->d_leg, *dc = h->d_leg + 12 * B, *dq = h->d_leg + 24 * B;
+  HIP_TRY(hipMemcpyAsync(dp, foot_pos_body, sizeof(double) * 12 * B, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(dc, cur_joint_pos, sizeof(double) * 12 * B, hipMemcpyHostToDevice, h->stream));
+  LegGeom G;
+  std::memcpy(&G, g, sizeof G);
+  hipLaunchKernelGGL(qmpc_leg_inverse_kernel, dim3((unsigned)((B * 4 + 255) / 256)), dim3(256), 0, h->stream, G,
+                     (const double*)dp, (const double*)dc, dq, (int)batch);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(joint_pos, dq, sizeof(double) * 12 * B, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return QMPC_OK;
+}
+
+qmpc_status qmpc_loop_joint_commands_device(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch,
+                                            const qmpc_loop_state* d_states, double* d_joint_pos,
+                                            qmpc_joint_feedback* d_fb, qmpc_joint_command* d_cmd, void* stream) {
+  if (!h || !g || batch < 0 || (batch > 0 && (!d_states || !d_joint_pos || !d_cmd))) return QMPC_BAD_ARGUMENT;
+  if (batch == 0) return QMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  LegGeom G;
+  std::memcpy(&G, g, sizeof G);
+  hipLaunchKernelGGL(qmpc_loop_joint_kernel, dim3((unsigned)(((size_t)batch * 4 + 255) / 256)), dim3(256), 0,
+                     stream ? (hipStream_t)stream : h->stream, G, d_states, d_joint_pos, d_fb, d_cmd, (int)batch);
+  HIP_TRY(hipGetLastError());
+  return QMPC_OK;
+}
+
+void qmpc_loop_joint_init(double* joint_pos, int32_t batch) {
+  const double stand[3] = {0.0, 0.67, -1.3};
+  for (size_t t = 0; t < (size_t)(batch > 0 ? batch : 0) * 4; ++t)
+    for (int j = 0; j < 3; ++j) joint_pos[3 * t + j] = stand[j];
 }
 
 // ---- device-resident closed loop (kernels in qmpc_loop.hip) ----------------

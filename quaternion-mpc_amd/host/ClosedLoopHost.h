@@ -11,6 +11,7 @@
 #pragma once
 
 #include "../csrc/qmpc_loop_math.h"
+#include "JointCommandsHip.h"
 #include "QuatMpcHip.h"
 #include "SwingTrajectoryHip.h"
 
@@ -84,6 +85,49 @@ class ClosedLoopHostT {
     return ok;
   }
 
+  // Joint level of the tick just made (the plant has massless legs): measured angles = inverse kinematics of the
+  // plant's feet (hip branch: joint_pos_io, the angles of the previous call; out of reach keeps them), measured
+  // velocities = J^-1 R'(foot velocity - torso velocity), swing feet moving at their FSM target velocity; then
+  // BaseInterface::tau_ctrl_update on that feedback.  Fills the records the device entry point produces.
+  void joint_commands(double* joint_pos_io, qmpc_joint_feedback* fb, qmpc_joint_command* cmd) {
+    refresh_feedback();
+    double R[9];
+    qmpc_loop::quat_to_rot(&x_[3], R);
+    for (int l = 0; l < NUM_LEG; ++l) {
+      const bool swing = state.ctrl.movement_mode != 0 && !state.ctrl.plan_contacts[l];
+      double pb[3], fv[3], vb[3], q[3], qd[3], J[9];
+      for (int a = 0; a < 3; ++a) {
+        pb[a] = state.fbk.foot_pos_body(a, l);
+        fv[a] = (swing ? mpc->leg_FSM[l].FSM_foot_vel_target_world[a] : 0.0) - x_[7 + a];
+      }
+      for (int a = 0; a < 3; ++a) vb[a] = R[a] * fv[0] + R[3 + a] * fv[1] + R[6 + a] * fv[2];
+      qmpc_joint::leg_inverse(pb, joint_pos_io[3 * l], joints_.geom.rho_fix[l], q);
+      if ((q[0] != q[0]) || (q[1] != q[1]) || (q[2] != q[2]))
+        for (int a = 0; a < 3; ++a) q[a] = joint_pos_io[3 * l + a];
+      qmpc_joint::leg_jacobian(qmpc_joint::leg_plane(q, joints_.geom.rho_opt[l], joints_.geom.rho_fix[l]), J);
+      qmpc_joint::solve3(J, vb, qd);
+      for (int a = 0; a < 3; ++a) {
+        joint_pos_io[3 * l + a] = q[a];
+        state.fbk.joint_pos(3 * l + a) = q[a];
+        state.fbk.joint_vel(3 * l + a) = qd[a];
+      }
+    }
+    joints_.tau_ctrl_update(state);
+    for (int a = 0; a < 12; ++a) {
+      fb->joint_pos[a] = state.fbk.joint_pos(a);
+      fb->joint_vel[a] = state.fbk.joint_vel(a);
+      fb->foot_pos_target_world[a] = state.ctrl.optimized_state(6 + a);
+      fb->foot_vel_target_world[a] = state.ctrl.optimized_input(12 + a);
+      fb->forces_body[a] = state.ctrl.optimized_input(a);
+      cmd->joint_ang_tgt[a] = state.ctrl.joint_ang_tgt(a);
+      cmd->joint_vel_tgt[a] = state.ctrl.joint_vel_tgt(a);
+      cmd->joint_tau_tgt[a] = state.ctrl.joint_tau_tgt(a);
+    }
+    for (int a = 0; a < 3; ++a) { fb->torso_pos_world[a] = x_[a]; fb->torso_lin_vel_world[a] = x_[7 + a]; }
+    for (int a = 0; a < 4; ++a) { fb->torso_quat[a] = x_[3 + a]; fb->plan_contacts[a] = state.ctrl.plan_contacts[a] ? 1.0 : 0.0; }
+    fb->movement_mode = state.ctrl.movement_mode;
+  }
+
   // the state in the device loop's record layout (filter internals are private to the host class: left zero)
   void export_state(qmpc_loop_state* o) const {
     std::memset(o, 0, sizeof *o);
@@ -130,6 +174,7 @@ class ClosedLoopHostT {
 
  private:
   qmpc_loop_params lp_;
+  JointCommandsHipT<State> joints_;
   double x_[13];
   double feet_[12];
   double Iinv_[9];

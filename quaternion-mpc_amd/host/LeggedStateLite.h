@@ -74,6 +74,10 @@ struct LeggedFeedbackLite {   // LeggedState.h:20-77
   lite::Vector3d torso_euler;
   lite::Vector3d torso_ang_vel_world;
   lite::Mat<LEG_DOF, NUM_LEG> foot_pos_abs_com;
+  // read by BaseInterface::tau_ctrl_update (BaseInterface.cpp:343-408; JointCommandsHip.h)
+  lite::Mat<NUM_DOF, 1> joint_pos;
+  lite::Mat<NUM_DOF, 1> joint_vel;
+  lite::Mat<LEG_DOF, NUM_DOF> jac_foot;        // LeggedState.h: 3 x 12, one 3 x 3 block per leg
   double mpc_time = 0.0;
 };
 
@@ -94,6 +98,9 @@ struct LeggedCtrlLite {       // LeggedState.h:79-125
   lite::Mat<6 + 3 * NUM_LEG, 1> optimized_state;
   lite::Mat<9 * NUM_LEG, 1> optimized_input;
   lite::Mat<3 * NUM_LEG, 1> mpc_grf_world;
+  lite::Mat<NUM_DOF, 1> joint_ang_tgt;         // written by tau_ctrl_update
+  lite::Mat<NUM_DOF, 1> joint_vel_tgt;
+  lite::Mat<NUM_DOF, 1> joint_tau_tgt;
   double movement_mode = 0;
 };
 

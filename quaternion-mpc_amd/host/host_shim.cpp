@@ -191,6 +191,45 @@ void qh_loop_set_command(void* p, const double* joy, double movement_mode) {
   s.joy.roll_rate = joy[3]; s.joy.pitch_rate = joy[4]; s.joy.yaw_rate = joy[5];
   s.ctrl.movement_mode = movement_mode;
 }
+// joint level of the tick just made: joint_pos_io [12] in/out, one feedback and one command record out
+void qh_loop_joint(void* p, double* joint_pos_io, qmpc_joint_feedback* fb, qmpc_joint_command* cmd) {
+  static_cast<LoopHarness*>(p)->loop->joint_commands(joint_pos_io, fb, cmd);
+}
+// BaseInterface::tau_ctrl_update on plain records (the host mirror of qmpc_joint_commands), batch instances
+void qh_joint_commands(int batch, const qmpc_joint_feedback* fb, qmpc_joint_command* cmd) {
+  legged::JointCommandsHipT<LeggedStateLite> jc;
+  for (int b = 0; b < batch; ++b) {
+    LeggedStateLite s;
+    double R[9];
+    qmpc_loop::quat_to_rot(fb[b].torso_quat, R);
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) s.fbk.torso_rot_mat(r, c) = R[3 * r + c];
+      s.fbk.torso_pos_world(r) = fb[b].torso_pos_world[r];
+      s.fbk.torso_lin_vel_world(r) = fb[b].torso_lin_vel_world[r];
+    }
+    for (int a = 0; a < 12; ++a) {
+      s.fbk.joint_pos(a) = fb[b].joint_pos[a];
+      s.fbk.joint_vel(a) = fb[b].joint_vel[a];
+      s.ctrl.optimized_state(6 + a) = fb[b].foot_pos_target_world[a];
+      s.ctrl.optimized_input(12 + a) = fb[b].foot_vel_target_world[a];
+      s.ctrl.optimized_input(a) = fb[b].forces_body[a];
+    }
+    for (int l = 0; l < 4; ++l) s.ctrl.plan_contacts[l] = fb[b].plan_contacts[l] != 0.0;
+    s.ctrl.movement_mode = fb[b].movement_mode;
+    jc.tau_ctrl_update(s);
+    for (int a = 0; a < 12; ++a) {
+      cmd[b].joint_ang_tgt[a] = s.ctrl.joint_ang_tgt(a);
+      cmd[b].joint_vel_tgt[a] = s.ctrl.joint_vel_tgt(a);
+      cmd[b].joint_tau_tgt[a] = s.ctrl.joint_tau_tgt(a);
+    }
+  }
+}
+// A1Kinematics::inv_kin through the shared arithmetic, host side: [batch][12] each
+void qh_leg_inverse(int batch, const double* foot_pos_body, const double* cur_joint_pos, double* joint_pos) {
+  legged::JointCommandsHipT<LeggedStateLite> jc;
+  for (size_t t = 0; t < (size_t)batch * 4; ++t)
+    qmpc_joint::leg_inverse(&foot_pos_body[3 * t], cur_joint_pos[3 * t], jc.geom.rho_fix[t & 3], &joint_pos[3 * t]);
+}
 void qh_loop_export(void* p, qmpc_loop_state* out) { static_cast<LoopHarness*>(p)->loop->export_state(out); }
 void qh_loop_destroy(void* p) {
   LoopHarness* h = static_cast<LoopHarness*>(p);

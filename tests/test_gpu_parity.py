@@ -947,6 +947,132 @@ def test_device_closed_loop_matches_host_classes_tick_for_tick(pkg, lib):
     assert 0.2 < walk["pos_world"][2] < 0.4 and abs(st[0]["pos_world"][2] - 0.3) < 0.02           # nobody fell
 
 
+def test_joint_commands_and_inverse_kinematics_match_oracle(pkg, lib, oracle):
+    """SURVEY 8f rank 2, completed: BaseInterface::tau_ctrl_update (BaseInterface.cpp:343-408) on the device --
+    inverse kinematics (A1Kinematics.cpp:335-459), J^-1 velocity targets, -J'f torques -- against oracle/qo_legkin.c.
+    Torques and velocity targets to 1e-9; angle targets to 1e-11 except where a one-ulp difference of a double
+    (device vs host sin / sqrt) lands on a rounding boundary of the single-precision atan2 approximation: one float
+    ulp of an angle, bounded by 1e-6 rad."""
+    import torch
+    from test_joint_commands_cpu import random_feedback, random_joint_angles
+    po = oracle
+    geom = po.default_go1_geometry()
+    rng = np.random.default_rng(21)
+    s = pkg.Solver(pkg.default_params(10, pkg.MODE_CONVERGED, lib), 64, device=0, lib=lib)
+    g = s.default_go1_geometry()
+    assert bytes(g) == bytes(geom)
+    q = random_joint_angles(rng, 6001)
+    p, _ = po.leg_kinematics(geom, q)
+    cur = q + rng.uniform(-0.3, 0.3, q.shape)
+    cur[::7, 0::3] += 2.5                           # some hips start nearer to the mirrored solution
+    qo = po.leg_inverse_kinematics(geom, p, cur)
+    qd = s.leg_inverse_kinematics(g, p, cur)
+    d = np.abs(qd - qo)
+    print(f"inverse kinematics, {4 * len(q)} legs: max |dq| {d.max():.2e}, 99.9 % below {np.quantile(d, 0.999):.2e}")
+    assert d.max() < 1e-6 and np.quantile(d, 0.999) < 1e-11
+    out = p.copy()
+    out[0, 3:6] = (0.23391, -0.364016, -0.294254)   # the reference's own test point (TestInvKin.cpp:29): out of reach
+    qn = s.leg_inverse_kinematics(g, out[:1], cur[:1])
+    assert np.isnan(qn[0, 4:6]).all() and np.isfinite(qn[0, 3]) and np.isfinite(qn[0, [0, 1, 2, 6, 7, 8, 9, 10, 11]]).all()
+    for B in (6001, 64, 1):                         # ragged last tile, exactly one tile, one robot
+        fb = random_feedback(rng, B)
+        if B == 6001:
+            fb["foot_pos_target_world"][5, 0:3] += 3.0   # out of reach -> the isnan fallback to the measured angles
+        co = po.joint_commands(geom, fb)
+        cd = s.joint_commands(g, fb)
+        da = np.abs(cd["joint_ang_tgt"] - co["joint_ang_tgt"])
+        dv = np.abs(cd["joint_vel_tgt"] - co["joint_vel_tgt"]) / (1.0 + np.abs(co["joint_vel_tgt"]))
+        dt = np.abs(cd["joint_tau_tgt"] - co["joint_tau_tgt"])
+        print(f"joint commands B={B}: angle {da.max():.2e}, velocity (rel) {dv.max():.2e}, torque {dt.max():.2e}")
+        assert da.max() < 1e-6 and np.quantile(da, 0.999) < 1e-11 and dv.max() < 1e-9 and dt.max() < 1e-9
+        if B == 6001:
+            np.testing.assert_array_equal(cd["joint_ang_tgt"][5, 0:3], fb["joint_pos"][5, 0:3])
+            # device buffers, caller's stream
+            d_fb = torch.from_numpy(fb.view(np.uint8).reshape(B, -1).copy()).cuda()
+            d_cmd = torch.zeros(B, 36, dtype=torch.float64, device="cuda")
+            st = torch.cuda.Stream()
+            torch.cuda.synchronize()
+            s.joint_commands_device(g, B, d_fb.data_ptr(), d_cmd.data_ptr(), stream=st.cuda_stream)
+            st.synchronize()
+            assert d_cmd.cpu().numpy().tobytes() == cd.tobytes()
+    assert len(s.joint_commands(g, np.zeros(0, dtype=pkg.JOINT_FEEDBACK_DTYPE))) == 0
+    assert lib.qmpc_joint_commands(s._h, None, 4, None, None) == pkg.BAD_ARGUMENT
+    s.close()
+
+
+def test_closed_loop_joint_commands_match_host_classes_tick_for_tick(pkg, lib):
+    """The tick down to the motors: after every tick of the device-resident loop, qmpc_loop_joint_commands_device
+    (measured joint angles by inverse kinematics of the plant's feet, then tau_ctrl_update) against the host classes
+    (host/ClosedLoopHost.h::joint_commands -> host/JointCommandsHip.h), one robot at a time, every tick."""
+    import torch
+    import __graft_entry__ as gentry
+
+    host = C.CDLL(str(gentry.build_host()))
+    vp = C.c_void_p
+    host.qh_loop_create.argtypes = [C.c_char_p, C.c_int, vp, vp]; host.qh_loop_create.restype = vp
+    for f in ("qh_loop_tick", "qh_loop_destroy"):
+        getattr(host, f).argtypes = [vp]
+    host.qh_loop_set_command.argtypes = [vp, vp, C.c_double]
+    host.qh_loop_joint.argtypes = [vp, vp, vp, vp]
+    T0, T, N = 6, 70, 10
+    lp = pkg.default_loop_params(lib)
+    yaws = [0.0, 0.4, -1.0, 2.0, 0.7, -0.3]
+    cmds = np.array(LOOP_COMMANDS)
+    stand = cmds.copy(); stand[:, 6] = 0.0
+    st_init = pkg.loop_states(stand, lp, height=0.3, yaw=yaws, lib=lib)
+    B = len(st_init)
+    s = pkg.Solver(pkg.default_params(N, pkg.MODE_CONVERGED, lib), B, device=0, lib=lib)
+    g = s.default_go1_geometry()
+    d_st = torch.from_numpy(st_init.view(np.uint8).reshape(B, -1).copy()).cuda()
+    jp0 = np.zeros((B, 12)); lib.qmpc_loop_joint_init(jp0.ctypes.data, B)
+    assert np.array_equal(jp0[0], np.tile([0.0, 0.67, -1.3], 4))
+    d_jp = torch.from_numpy(jp0).cuda()
+    d_fb = torch.zeros(B, 75, dtype=torch.float64, device="cuda")
+    d_cmd = torch.zeros(B, 36, dtype=torch.float64, device="cuda")
+    d_cmd2 = torch.zeros(B, 36, dtype=torch.float64, device="cuda")
+    dev_fb, dev_cmd = [], []
+    torch.cuda.synchronize()
+    for t in range(T0 + T):
+        if t == T0:
+            h_st = d_st.cpu().numpy().view(pkg.LOOP_STATE_DTYPE).reshape(B).copy()
+            h_st["movement_mode"] = cmds[:, 6]
+            d_st = torch.from_numpy(h_st.view(np.uint8).reshape(B, -1).copy()).cuda()
+        s.loop_run_device(B, d_st.data_ptr(), 1, lp)
+        s.loop_joint_commands_device(g, B, d_st.data_ptr(), d_jp.data_ptr(), d_fb.data_ptr(), d_cmd.data_ptr())
+        s.joint_commands_device(g, B, d_fb.data_ptr(), d_cmd2.data_ptr())   # the records it built, through the plain entry
+        s.wait()
+        assert d_cmd2.cpu().numpy().tobytes() == d_cmd.cpu().numpy().tobytes()
+        dev_fb.append(d_fb.cpu().numpy().view(pkg.JOINT_FEEDBACK_DTYPE).reshape(B).copy())
+        dev_cmd.append(d_cmd.cpu().numpy().view(pkg.JOINT_COMMAND_DTYPE).reshape(B).copy())
+    s.close()
+    worst = {"joint_pos": 0.0, "joint_vel": 0.0, "joint_ang_tgt": 0.0, "joint_vel_tgt": 0.0, "joint_tau_tgt": 0.0}
+    moved = 0.0
+    for i in range(B):
+        h = host.qh_loop_create(str(pkg.LIB_PATH).encode(), N, C.addressof(lp), st_init[i:i + 1].ctypes.data)
+        assert h
+        jp = np.tile([0.0, 0.67, -1.3], 4).astype(float)
+        fb = np.zeros(1, dtype=pkg.JOINT_FEEDBACK_DTYPE)
+        cmd = np.zeros(1, dtype=pkg.JOINT_COMMAND_DTYPE)
+        for t in range(T0 + T):
+            if t == T0:
+                host.qh_loop_set_command(h, np.ascontiguousarray(cmds[i, :6]).ctypes.data, float(cmds[i, 6]))
+            assert host.qh_loop_tick(h) == 1
+            host.qh_loop_joint(h, jp.ctypes.data, fb.ctypes.data, cmd.ctypes.data)
+            assert np.array_equal(fb[0]["plan_contacts"], dev_fb[t][i]["plan_contacts"]), (i, t)
+            for k in ("joint_pos", "joint_vel"):
+                worst[k] = max(worst[k], float(np.abs(fb[0][k] - dev_fb[t][i][k]).max()))
+            for k in ("joint_ang_tgt", "joint_vel_tgt", "joint_tau_tgt"):
+                worst[k] = max(worst[k], float(np.abs(cmd[0][k] - dev_cmd[t][i][k]).max()))
+            moved = max(moved, float(np.abs(fb[0]["joint_pos"] - np.tile([0.0, 0.67, -1.3], 4)).max()))
+        host.qh_loop_destroy(h)
+    print("closed loop joint level, worst device-vs-host differences:", {k: f"{v:.2e}" for k, v in worst.items()})
+    # angles: 1e-9 rad (forces agree to 1e-12 N, states to 1e-10), with the one-float-ulp allowance of the atan2
+    # approximation; velocities go through J^-1 (condition ~10); torques are -J'f of forces that agree to 1e-12 N
+    assert worst["joint_pos"] < 1e-6 and worst["joint_ang_tgt"] < 1e-6
+    assert worst["joint_vel"] < 1e-5 and worst["joint_vel_tgt"] < 1e-5 and worst["joint_tau_tgt"] < 1e-6
+    assert moved > 0.2                                   # the legs really swung
+
+
 @pytest.mark.parametrize("counts", ["64,64", "40,33,27"], ids=["2 ranks", "3 ranks ragged"])
 def test_multi_process_rccl_gather_on_one_gpu(counts, tmp_path):
     """qmpc_gather with MORE than one RCCL rank: 2 (and 3, ragged shards) processes, each with its own
