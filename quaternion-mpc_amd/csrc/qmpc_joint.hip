@@ -6,7 +6,8 @@
 //
 // These passes are HBM streaming: 75 doubles in and 36 out per robot (888 B), ~300 flops per leg.  A block owns 64
 // consecutive robots; their records move between HBM and LDS as contiguous 8-byte-per-lane accesses (a wave
-// instruction covers 512 contiguous bytes), one thread per (robot, leg) picks its fields out of LDS.
+// instruction covers 512 contiguous bytes), one thread per (robot, leg) -- wave w of the block takes leg w of the 64
+// robots -- picks its fields out of LDS.
 #pragma once
 
 #include "qmpc_joint_math.h"
@@ -27,7 +28,8 @@ __global__ __launch_bounds__(256) void qmpc_joint_cmd_kernel(LegGeom G, const qm
   const double* src = reinterpret_cast<const double*>(fb + r0);
   for (int i = tid; i < n * kJointFb; i += 256) rec[i] = src[i];
   __syncthreads();
-  const int r = tid >> 2, l = tid & 3;
+  const int r = tid & 63, l = tid >> 6;     // a wave works on ONE leg index: the left / right branches of the inverse
+                                            // kinematics do not diverge inside it
   double ang[3] = {0.0, 0.0, 0.0}, vel[3] = {0.0, 0.0, 0.0}, tau[3] = {0.0, 0.0, 0.0};
   if (r < n) {
     const qmpc_joint_feedback& f = *reinterpret_cast<const qmpc_joint_feedback*>(&rec[r * kJointFb]);

@@ -16,9 +16,10 @@ struct LegPlane {            // the leg seen from the hip: extension L / fore-af
 QMPC_HD LegPlane leg_plane(const double* q, const double* rho_opt, const double* rho_fix) {
   QMPC_NO_CONTRACT
   LegPlane t;
-  t.s0 = sin(q[0]); t.c0 = cos(q[0]);
-  const double s1 = sin(q[1]), c1 = cos(q[1]);
-  const double s12 = sin(q[1] + q[2]), c12 = cos(q[1] + q[2]);
+  double s1, c1, s12, c12;
+  sincos(q[0], &t.s0, &t.c0);
+  sincos(q[1], &s1, &c1);
+  sincos(q[1] + q[2], &s12, &c12);
   const double lce = rho_fix[4] - rho_opt[2];
   t.L2 = lce * c12 + rho_opt[0] * s12;
   t.X2 = -lce * s12 + rho_opt[0] * c12;
@@ -101,7 +102,9 @@ QMPC_HD void leg_inverse(const double* p, double cur_hip, const double* rho_fix,
   const double beta = fabs(cb + 1) < 0.001 ? kPi : fabs(cb - 1) < 0.001 ? 0.0 : acos(cb);
   const double calf = beta - kPi;
   if (zf > d * sin(hip)) L = -L;
-  double thigh = (double)atan2_single(-xs, L) + (double)atan2_single(lc * sin(-calf), lt + lc * cos(-calf));
+  double sk, ck;
+  sincos(-calf, &sk, &ck);
+  double thigh = (double)atan2_single(-xs, L) + (double)atan2_single(lc * sk, lt + lc * ck);
   if (thigh < -60 * kPi / 180) thigh += 2 * kPi;
   else if (thigh > 240 * kPi / 180) thigh -= 2 * kPi;
   q[0] = hip; q[1] = thigh; q[2] = calf;

@@ -46,3 +46,26 @@ th = s.torque_map(geom, q[:n].cpu().numpy(), f[:n].cpu().numpy(), c[:n].cpu().nu
 print(f"torque map: B={B}: {ms:.3f} ms per launch, {B / ms * 1e3:.3e} instances/s, {nbytes / ms * 1e-6:.0f} GB/s "
       f"({100 * nbytes / ms * 1e-6 / 8000:.1f} % of 8 TB/s; 320 B per instance); slice equals the host-buffer call: "
       f"{bool(np.array_equal(th, tau[:n].cpu().numpy()))}")
+
+# ---- joint commands (qmpc_joint_commands_device, BaseInterface::tau_ctrl_update): 75 doubles in, 36 out = 888 B per robot
+sys.path.insert(0, str(REPO / "tests"))
+from test_joint_commands_cpu import random_feedback  # noqa: E402  (input generator only)
+
+Bj = min(B, 2 * 1024 * 1024)
+fb_small = random_feedback(np.random.default_rng(2), 65536)
+d_fb = torch.from_numpy(fb_small.view(np.uint8).reshape(len(fb_small), -1).copy()).cuda().repeat(Bj // len(fb_small), 1)
+d_cmd = torch.zeros(Bj, 36, dtype=torch.float64, device="cuda")
+for _ in range(3):
+    s.joint_commands_device(geom, Bj, d_fb.data_ptr(), d_cmd.data_ptr(), st.cuda_stream)
+torch.cuda.synchronize()
+e0.record(st)
+for _ in range(a.steps):
+    s.joint_commands_device(geom, Bj, d_fb.data_ptr(), d_cmd.data_ptr(), st.cuda_stream)
+e1.record(st)
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / a.steps
+nbytes = 888 * Bj
+ch = s.joint_commands(geom, fb_small[:4096])
+print(f"joint commands (inverse kinematics + J^-1 + -J'f): B={Bj}: {ms:.3f} ms per launch, {Bj / ms * 1e3:.3e} robots/s, "
+      f"{nbytes / ms * 1e-6:.0f} GB/s ({100 * nbytes / ms * 1e-6 / 8000:.1f} % of 8 TB/s; 888 B per robot); slice equals the "
+      f"host-buffer call: {d_cmd[:4096].cpu().numpy().tobytes() == ch.tobytes()}")
