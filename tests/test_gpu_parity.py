@@ -640,7 +640,11 @@ def test_randomised_parameter_sets_match_oracle(pkg, lib, oracle):
         for i in range(12):
             p.r_weights[i] = float(10 ** rng.uniform(-6.5, -4))
         p.drop_ang_vel = int(t % 2)
-        hs = float(rng.choice([0.005, 0.01]))
+        # knot spacing up to the 20 ms the round-1 review asked back; what limits the scheme is the LOOK-AHEAD
+        # (N * h <= 0.3 s: every instance converges; beyond it see test_long_look_ahead_outside_the_envelope)
+        hs = float(rng.choice([0.005, 0.01, 0.02]))
+        if N * hs > 0.3:
+            hs = 0.015
         p.h, p.h_ref = hs, hs
         rec = pkg.random_go1_trot_states(64, config_id=40 + t)
         s = pkg.Solver(p, 64, device=0, lib=lib)
@@ -653,6 +657,30 @@ def test_randomised_parameter_sets_match_oracle(pkg, lib, oracle):
         assert err < 1e-6, (t, N, err)
         assert (f.reshape(-1, 4, 3)[rec["contacts"] == 0] == 0).all()
     assert worst < 1e-6
+
+
+def test_long_look_ahead_outside_the_envelope(pkg, lib, oracle):
+    """20 ms knots x N = 20 (0.4 s of look-ahead) on states tilted up to 0.5 rad: outside the envelope of the
+    Gauss-Newton scheme -- a third of the instances end as MAX_ITER / NOT_PD, in the oracle and on the
+    GPU alike.  What must hold there: the two sides fail at the same RATE (rounding decides which instances), every
+    failure is reported through the status word, and wherever both converge they converge to the same forces."""
+    p = pkg.default_params(20, pkg.MODE_CONVERGED, lib)
+    p.h, p.h_ref = 0.02, 0.02
+    rec = pkg.random_go1_trot_states(256, config_id=41)
+    s = pkg.Solver(p, 256, device=0, lib=lib)
+    f, info = s.solve(rec)
+    s.close()
+    fo, io = oracle.solve(p, rec, threads=8)
+    ok_g, ok_o = info["status"] == 0, io["status"] == 0
+    both = ok_g & ok_o
+    agree = float((info["status"] == io["status"]).mean())
+    err = float(np.abs(f - fo)[both].max())
+    print(f"0.4 s look-ahead: converged GPU {ok_g.mean():.2f} / oracle {ok_o.mean():.2f}, same status {agree:.2f}, "
+          f"worst force difference where both converge {err:.2e} N")
+    assert set(np.unique(info["status"])) <= {pkg.OK, pkg.MAX_ITER, pkg.NOT_PD}
+    assert abs(ok_g.mean() - ok_o.mean()) < 0.08 and both.mean() > 0.45 and agree > 0.7
+    assert err < 1e-5
+    assert np.isfinite(f).all()
 
 
 def test_randomised_parameter_sets_convex_and_biped(pkg, lib, oracle):
