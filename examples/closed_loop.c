@@ -49,6 +49,24 @@ int main(int argc, char** argv) {
              s[i].tick, s[i].pos_world[0], s[i].pos_world[1], s[i].pos_world[2], (int)s[i].contacts[0], (int)s[i].contacts[1],
              (int)s[i].contacts[2], (int)s[i].contacts[3], s[i].status, s[i].iterations);
   }
+  /* the tick down to the motors (BaseInterface::tau_ctrl_update): measured joint angles by inverse kinematics of the
+   * plant's feet, joint angle / velocity targets of the swing feet, joint torques -J'f of the stance feet */
+  qmpc_leg_geometry geom;
+  qmpc_default_go1_geometry(&geom);
+  double* joint_pos = malloc(sizeof(double) * 12 * (size_t)robots);
+  qmpc_joint_command* cmd = calloc((size_t)robots, sizeof *cmd);
+  qmpc_loop_joint_init(joint_pos, robots);
+  st = qmpc_loop_joint_commands(h, &geom, robots, s, joint_pos, NULL, cmd);
+  if (st != QMPC_OK) {
+    fprintf(stderr, "qmpc_loop_joint_commands: %s\n", qmpc_status_string(st));
+    return 5;
+  }
+  for (int l = 0; l < 4; ++l)
+    printf("robot   0 leg %d (%s): joint angles (%.3f, %.3f, %.3f) rad, torque command (%.2f, %.2f, %.2f) N m\n", l,
+           s[0].contacts[l] != 0.0 ? "stance" : "swing ", joint_pos[3 * l], joint_pos[3 * l + 1], joint_pos[3 * l + 2],
+           cmd[0].joint_tau_tgt[3 * l], cmd[0].joint_tau_tgt[3 * l + 1], cmd[0].joint_tau_tgt[3 * l + 2]);
+  free(joint_pos);
+  free(cmd);
   printf("%d robots x %d ticks (%.1f s of robot time): farthest walked %.3f m, %d not upright / not converged\n", robots, ticks,
          ticks * lp.dt, far, bad);
   qmpc_destroy(h);

@@ -414,6 +414,16 @@ int32_t qmpc_sizeof_loop_state(void);
 qmpc_status qmpc_loop_joint_commands_device(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch,
                                             const qmpc_loop_state* d_states, double* d_joint_pos,
                                             qmpc_joint_feedback* d_fb, qmpc_joint_command* d_cmd, void* stream);
+/* The same with HOST buffers (states as qmpc_loop_run leaves them; fb may be NULL). */
+qmpc_status qmpc_loop_joint_commands(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch,
+                                     const qmpc_loop_state* states, double* joint_pos, qmpc_joint_feedback* fb,
+                                     qmpc_joint_command* cmd);
+/* The closed loop down to the motors: qmpc_loop_run_device with the joint-level kernel closing every tick inside the
+ * captured graph.  d_joint_pos [batch][12] in/out as above; d_cmd [batch] receives the commands of the LAST tick,
+ * d_trace_cmd [ticks][batch] those of every tick (either may be NULL, not both). */
+qmpc_status qmpc_loop_run_joint_device(qmpc_handle* h, const qmpc_loop_params* lp, const qmpc_leg_geometry* g,
+                                       int32_t batch, qmpc_loop_state* d_states, double* d_joint_pos, int32_t ticks,
+                                       qmpc_joint_command* d_cmd, qmpc_joint_command* d_trace_cmd, void* stream);
 /* Stand-pose joint angles (0, 0.67, -1.3 per leg: the reference's Gazebo start pose) for `batch`
  * robots, host buffer [batch][12]. */
 void qmpc_loop_joint_init(double* joint_pos, int32_t batch);

@@ -273,6 +273,10 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.qmpc_joint_commands_device.restype = i32
     lib.qmpc_loop_joint_commands_device.argtypes = [vp, C.POINTER(LegGeometry), i32, vp, vp, vp, vp, vp]
     lib.qmpc_loop_joint_commands_device.restype = i32
+    lib.qmpc_loop_run_joint_device.argtypes = [vp, C.POINTER(LoopParams), C.POINTER(LegGeometry), i32, vp, vp, i32, vp, vp, vp]
+    lib.qmpc_loop_run_joint_device.restype = i32
+    lib.qmpc_loop_joint_commands.argtypes = [vp, C.POINTER(LegGeometry), i32, vp, vp, vp, vp]
+    lib.qmpc_loop_joint_commands.restype = i32
     lib.qmpc_loop_joint_init.argtypes = [vp, i32]
     lib.qmpc_loop_joint_init.restype = None
     lib.qmpc_default_biped8_params.argtypes = [C.POINTER(Params), i32, i32]
@@ -356,6 +360,8 @@ EXPORTED_SYMBOLS = (
     "qmpc_joint_commands_device",
     "qmpc_loop_joint_commands_device",
     "qmpc_loop_joint_init",
+    "qmpc_loop_run_joint_device",
+    "qmpc_loop_joint_commands",
 )
 
 
@@ -640,6 +646,33 @@ class Solver:
                                                       C.c_void_p(d_cmd), C.c_void_p(stream) if stream else None)
         if st != OK:
             raise QmpcError(st, "qmpc_loop_joint_commands_device")
+
+    def loop_joint_commands(self, geom: LegGeometry, states: np.ndarray, joint_pos: np.ndarray | None = None):
+        """Host-buffer form: (joint_pos [B][12] updated, feedback records, command records) of the robots' states."""
+        st = np.ascontiguousarray(states, dtype=LOOP_STATE_DTYPE)
+        B = len(st)
+        jp = np.zeros((B, 12))
+        if joint_pos is None:
+            self.lib.qmpc_loop_joint_init(_ptr(jp), B)
+        else:
+            jp[:] = np.asarray(joint_pos, dtype=np.float64).reshape(B, 12)
+        fb = np.zeros(B, dtype=JOINT_FEEDBACK_DTYPE)
+        cmd = np.zeros(B, dtype=JOINT_COMMAND_DTYPE)
+        rc = self.lib.qmpc_loop_joint_commands(self._h, C.byref(geom), B, _ptr(st), _ptr(jp), _ptr(fb), _ptr(cmd))
+        if rc != OK:
+            raise QmpcError(rc, "qmpc_loop_joint_commands")
+        return jp, fb, cmd
+
+    def loop_run_joint_device(self, geom: LegGeometry, batch: int, d_states: int, d_joint_pos: int, ticks: int,
+                              lp: LoopParams | None = None, d_cmd: int = 0, d_trace_cmd: int = 0, stream: int = 0):
+        """`ticks` ticks of the device-resident loop, each closed by the joint-level kernel (inside the captured graph)."""
+        lp = lp or default_loop_params(self.lib)
+        st = self.lib.qmpc_loop_run_joint_device(self._h, C.byref(lp), C.byref(geom), int(batch), C.c_void_p(d_states),
+                                                 C.c_void_p(d_joint_pos), int(ticks), C.c_void_p(d_cmd) if d_cmd else None,
+                                                 C.c_void_p(d_trace_cmd) if d_trace_cmd else None,
+                                                 C.c_void_p(stream) if stream else None)
+        if st != OK:
+            raise QmpcError(st, "qmpc_loop_run_joint_device")
 
     def phase_profile(self, inputs: np.ndarray) -> np.ndarray:
         inputs = np.ascontiguousarray(inputs, dtype=INPUT_DTYPE)

@@ -741,9 +741,39 @@ qmpc_status qmpc_loop_joint_commands_device(qmpc_handle* h, const qmpc_leg_geome
   LegGeom G;
   std::memcpy(&G, g, sizeof G);
   hipLaunchKernelGGL(qmpc_loop_joint_kernel, dim3((unsigned)(((size_t)batch * 4 + 255) / 256)), dim3(256), 0,
-                     stream ? (hipStream_t)stream : h->stream, G, d_states, d_joint_pos, d_fb, d_cmd, (int)batch);
+                     stream ? (hipStream_t)stream : h->stream, G, d_states, d_joint_pos, d_fb, d_cmd,
+                     (qmpc_joint_command*)nullptr, (const int*)nullptr, (int)batch);
   HIP_TRY(hipGetLastError());
   return QMPC_OK;
+}
+
+// host-buffer form of the above (not the hot path): staged through temporaries
+qmpc_status qmpc_loop_joint_commands(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch, const qmpc_loop_state* states,
+                                     double* joint_pos, qmpc_joint_feedback* fb, qmpc_joint_command* cmd) {
+  if (!h || !g || batch < 0 || (batch > 0 && (!states || !joint_pos || !cmd))) return QMPC_BAD_ARGUMENT;
+  if (batch == 0) return QMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t B = (size_t)batch;
+  qmpc_loop_state* d_st = nullptr;
+  qmpc_status rs = QMPC_OK;
+  do {
+    if (hipMalloc(&d_st, sizeof(qmpc_loop_state) * B) != hipSuccess) { rs = QMPC_HIP_ERROR; break; }
+    rs = grow_leg_staging(h, B * (12 + kJointFb + kJointCmd));
+    if (rs != QMPC_OK) break;
+    double* d_jp = h->d_leg;
+    qmpc_joint_feedback* d_fb = reinterpret_cast<qmpc_joint_feedback*>(h->d_leg + 12 * B);
+    qmpc_joint_command* d_cmd = reinterpret_cast<qmpc_joint_command*>(h->d_leg + (12 + kJointFb) * B);
+    if (hipMemcpyAsync(d_st, states, sizeof(qmpc_loop_state) * B, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemcpyAsync(d_jp, joint_pos, sizeof(double) * 12 * B, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rs = QMPC_HIP_ERROR; break; }
+    rs = qmpc_loop_joint_commands_device(h, g, batch, d_st, d_jp, d_fb, d_cmd, h->stream);
+    if (rs != QMPC_OK) break;
+    if (hipMemcpyAsync(joint_pos, d_jp, sizeof(double) * 12 * B, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipMemcpyAsync(cmd, d_cmd, sizeof(qmpc_joint_command) * B, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        (fb && hipMemcpyAsync(fb, d_fb, sizeof(qmpc_joint_feedback) * B, hipMemcpyDeviceToHost, h->stream) != hipSuccess)) { rs = QMPC_HIP_ERROR; break; }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) rs = QMPC_HIP_ERROR;
+  } while (0);
+  if (d_st) (void)hipFree(d_st);
+  return rs;
 }
 
 void qmpc_loop_joint_init(double* joint_pos, int32_t batch) {
@@ -795,9 +825,14 @@ void qmpc_loop_state_init(qmpc_loop_state* s, const qmpc_loop_params* lp, const 
   }
 }
 
-qmpc_status qmpc_loop_run_device(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* d_states,
-                                 int32_t ticks, double* d_trace_forces, double* d_trace_contacts, void* stream) {
+// g != NULL: the joint-level kernel closes every tick (d_joint_pos in/out, d_cmd = the last tick's commands, d_trace_cmd
+// one row per tick; either of the two may be NULL)
+static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* d_states,
+                                 int32_t ticks, double* d_trace_forces, double* d_trace_contacts,
+                                 const qmpc_leg_geometry* g, double* d_joint_pos, qmpc_joint_command* d_cmd,
+                                 qmpc_joint_command* d_trace_cmd, void* stream) {
   if (!h || !lp || batch < 0 || ticks < 0 || (batch > 0 && !d_states)) return QMPC_BAD_ARGUMENT;
+  if (g && batch > 0 && (!d_joint_pos || (!d_cmd && !d_trace_cmd))) return QMPC_BAD_ARGUMENT;
   if (h->params.model != QMPC_MODEL_QUAT) return QMPC_BAD_ARGUMENT;
   if (batch == 0 || ticks == 0) return QMPC_OK;
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
@@ -808,6 +843,9 @@ qmpc_status qmpc_loop_run_device(qmpc_handle* h, const qmpc_loop_params* lp, int
   HIP_TRY(hipMemcpyAsync(h->d_loop_row, &minus1, sizeof(int), hipMemcpyHostToDevice, s));
   const unsigned blocks = (unsigned)((batch + 63) / 64);
   const qmpc_loop_params LP = *lp;
+  LegGeom G;
+  std::memset(&G, 0, sizeof G);
+  if (g) std::memcpy(&G, g, sizeof G);
   auto one_tick = [&]() -> qmpc_status {
     hipLaunchKernelGGL(qmpc_loop_front_kernel, dim3(blocks), dim3(64), 0, s, LP, d_states, h->d_in, h->d_loop_row, (int)batch);
     HIP_TRY(hipGetLastError());
@@ -816,9 +854,15 @@ qmpc_status qmpc_loop_run_device(qmpc_handle* h, const qmpc_loop_params* lp, int
     hipLaunchKernelGGL(qmpc_loop_post_kernel, dim3(blocks), dim3(64), 0, s, h->dev, LP, d_states, (const double*)h->d_forces,
                        (const qmpc_info*)h->d_info, d_trace_forces, d_trace_contacts, (const int*)h->d_loop_row, (int)batch);
     HIP_TRY(hipGetLastError());
+    if (g) {
+      hipLaunchKernelGGL(qmpc_loop_joint_kernel, dim3((unsigned)(((size_t)batch * 4 + 255) / 256)), dim3(256), 0, s, G,
+                         (const qmpc_loop_state*)d_states, d_joint_pos, (qmpc_joint_feedback*)nullptr, d_cmd, d_trace_cmd,
+                         (const int*)h->d_loop_row, (int)batch);
+      HIP_TRY(hipGetLastError());
+    }
     return QMPC_OK;
   };
-  // one tick = three kernels: captured once into a graph and replayed (the sequence is launch-bound for small
+  // one tick = three kernels (four with the joint level): captured once into a graph and replayed (the sequence is launch-bound for small
   // batches); plain launches when capture is not available on this stream
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
@@ -845,6 +889,19 @@ qmpc_status qmpc_loop_run_device(qmpc_handle* h, const qmpc_loop_params* lp, int
   }
   if (graph) (void)hipGraphDestroy(graph);
   return rs;
+}
+
+qmpc_status qmpc_loop_run_device(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* d_states,
+                                 int32_t ticks, double* d_trace_forces, double* d_trace_contacts, void* stream) {
+  return loop_run_impl(h, lp, batch, d_states, ticks, d_trace_forces, d_trace_contacts, nullptr, nullptr, nullptr, nullptr,
+                       stream);
+}
+
+qmpc_status qmpc_loop_run_joint_device(qmpc_handle* h, const qmpc_loop_params* lp, const qmpc_leg_geometry* g, int32_t batch,
+                                       qmpc_loop_state* d_states, double* d_joint_pos, int32_t ticks,
+                                       qmpc_joint_command* d_cmd, qmpc_joint_command* d_trace_cmd, void* stream) {
+  if (!g) return QMPC_BAD_ARGUMENT;
+  return loop_run_impl(h, lp, batch, d_states, ticks, nullptr, nullptr, g, d_joint_pos, d_cmd, d_trace_cmd, stream);
 }
 
 qmpc_status qmpc_loop_run(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* states,

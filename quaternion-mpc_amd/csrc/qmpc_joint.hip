@@ -65,11 +65,14 @@ __global__ __launch_bounds__(256) void qmpc_leg_inverse_kernel(LegGeom G, const 
 // are massless: the measured joint angles are the inverse kinematics of the plant's foot positions (hip branch: the
 // angle of the previous tick; a foot out of reach keeps the previous angles), the joint velocities J^-1 R'(foot
 // velocity - torso velocity) with swing feet moving at their FSM target velocity and stance feet at rest.
-// One thread per (robot, leg); the loop state is an 818-double record, of which a leg reads ~45.
+// One thread per (robot, leg); the loop state is an 818-double record, of which a leg reads ~45.  `cmd` receives the
+// commands of this call, `trace` (with the loop's tick counter `row`) one row per tick; either may be null.
 __global__ __launch_bounds__(256) void qmpc_loop_joint_kernel(LegGeom G, const qmpc_loop_state* __restrict__ st,
                                                               double* __restrict__ joint_pos_io,
                                                               qmpc_joint_feedback* __restrict__ fb_out,
-                                                              qmpc_joint_command* __restrict__ cmd, int batch) {
+                                                              qmpc_joint_command* __restrict__ cmd,
+                                                              qmpc_joint_command* __restrict__ trace,
+                                                              const int* __restrict__ row, int batch) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)batch * 4) return;
   const size_t i = t >> 2;
@@ -104,13 +107,15 @@ __global__ __launch_bounds__(256) void qmpc_loop_joint_kernel(LegGeom G, const q
   double ang[3], vel[3], tau[3];
   qmpc_joint::leg_command(G.rho_opt[l], G.rho_fix[l], R, s.pos_world, s.lin_vel_world, q, qd, &s.foot_target_world[3 * l],
                           s.leg[l].fsm_vel, &s.forces_body[3 * l], s.contacts[l] != 0.0, walking, ang, vel, tau);
-  qmpc_joint_command& o = cmd[i];
-  for (int j = 0; j < 3; ++j) {
-    joint_pos_io[12 * i + 3 * l + j] = q[j];
-    o.joint_ang_tgt[3 * l + j] = ang[j];
-    o.joint_vel_tgt[3 * l + j] = vel[j];
-    o.joint_tau_tgt[3 * l + j] = tau[j];
-  }
+  for (int j = 0; j < 3; ++j) joint_pos_io[12 * i + 3 * l + j] = q[j];
+  qmpc_joint_command* outs[2] = {cmd ? &cmd[i] : nullptr, trace ? &trace[(size_t)(*row) * batch + i] : nullptr};
+  for (int w = 0; w < 2; ++w)
+    if (outs[w])
+      for (int j = 0; j < 3; ++j) {
+        outs[w]->joint_ang_tgt[3 * l + j] = ang[j];
+        outs[w]->joint_vel_tgt[3 * l + j] = vel[j];
+        outs[w]->joint_tau_tgt[3 * l + j] = tau[j];
+      }
   if (fb_out) {
     qmpc_joint_feedback& f = fb_out[i];
     for (int j = 0; j < 3; ++j) {

@@ -1072,6 +1072,40 @@ def test_closed_loop_joint_commands_match_host_classes_tick_for_tick(pkg, lib):
         assert d_cmd2.cpu().numpy().tobytes() == d_cmd.cpu().numpy().tobytes()
         dev_fb.append(d_fb.cpu().numpy().view(pkg.JOINT_FEEDBACK_DTYPE).reshape(B).copy())
         dev_cmd.append(d_cmd.cpu().numpy().view(pkg.JOINT_COMMAND_DTYPE).reshape(B).copy())
+    # the same walk in two calls of qmpc_loop_run_joint_device (joint kernel inside the captured graph, one trace row
+    # per tick): the same bits as the tick-by-tick sequence above
+    d_st2 = torch.from_numpy(st_init.view(np.uint8).reshape(B, -1).copy()).cuda()
+    d_jp2 = torch.from_numpy(jp0).cuda()
+    d_last = torch.zeros(B, 36, dtype=torch.float64, device="cuda")
+    tr0 = torch.zeros(T0, B, 36, dtype=torch.float64, device="cuda")
+    tr1 = torch.zeros(T, B, 36, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    s.loop_run_joint_device(g, B, d_st2.data_ptr(), d_jp2.data_ptr(), T0, lp, d_trace_cmd=tr0.data_ptr())
+    s.wait()
+    h_st = d_st2.cpu().numpy().view(pkg.LOOP_STATE_DTYPE).reshape(B).copy()
+    h_st["movement_mode"] = cmds[:, 6]
+    d_st2 = torch.from_numpy(h_st.view(np.uint8).reshape(B, -1).copy()).cuda()
+    torch.cuda.synchronize()
+    s.loop_run_joint_device(g, B, d_st2.data_ptr(), d_jp2.data_ptr(), T, lp, d_cmd=d_last.data_ptr(), d_trace_cmd=tr1.data_ptr())
+    s.wait()
+    tr = torch.cat([tr0, tr1]).cpu().numpy()
+    for t in range(T0 + T):
+        assert tr[t].tobytes() == dev_cmd[t].tobytes(), t
+    assert d_last.cpu().numpy().tobytes() == dev_cmd[-1].tobytes()
+    assert d_st2.cpu().numpy().tobytes() == d_st.cpu().numpy().tobytes() and torch.equal(d_jp2, d_jp)
+    # host-buffer form on the final states, previous angles = those before the last tick's call... i.e. a fresh call
+    # from the same inputs gives the same records
+    jp_h, fb_h, cmd_h = s.loop_joint_commands(g, d_st2.cpu().numpy().view(pkg.LOOP_STATE_DTYPE).reshape(B), d_jp2.cpu().numpy())
+    d_fb3 = torch.zeros(B, 75, dtype=torch.float64, device="cuda")
+    d_cmd3 = torch.zeros(B, 36, dtype=torch.float64, device="cuda")
+    d_jp3 = d_jp2.clone()
+    s.loop_joint_commands_device(g, B, d_st2.data_ptr(), d_jp3.data_ptr(), d_fb3.data_ptr(), d_cmd3.data_ptr())
+    s.wait()
+    assert cmd_h.tobytes() == d_cmd3.cpu().numpy().tobytes() and fb_h.tobytes() == d_fb3.cpu().numpy().tobytes()
+    assert jp_h.tobytes() == d_jp3.cpu().numpy().tobytes()
+    with pytest.raises(pkg.QmpcError) as e:
+        s.loop_run_joint_device(g, B, d_st2.data_ptr(), d_jp2.data_ptr(), 2, lp)      # nowhere to put the commands
+    assert e.value.code == pkg.BAD_ARGUMENT
     s.close()
     worst = {"joint_pos": 0.0, "joint_vel": 0.0, "joint_ang_tgt": 0.0, "joint_vel_tgt": 0.0, "joint_tau_tgt": 0.0}
     moved = 0.0
@@ -1170,6 +1204,8 @@ def test_closed_loop_c_example_runs_on_the_gpu(pkg, lib, tmp_path):
     r = subprocess.run([str(exe), "32", "300"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 not upright" in r.stdout
+    assert r.stdout.count("torque command") == 4 and "stance" in r.stdout      # the joint level of the last tick
+    print(r.stdout)
 
 
 def test_c_example_runs_on_the_gpu(pkg, lib, tmp_path):
