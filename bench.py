@@ -388,16 +388,23 @@ def main():
                 "note": "secondary: what the reference's solver mode returns (a <=10-iteration AL-iLQR iterate) and what it "
                         "costs on this GPU; the contract value is the converged mode"}
         if world == 1 and args.model == "quat" and not args.no_closed_loop:
-            # secondary: the device-resident closed loop (front end + solve + plant per tick, state in HBM, one
-            # hipGraph replay per tick): B robots standing up from rest into a trot; never `value`
+            # secondary: the device-resident closed loop (front end + solve + plant per tick, state in HBM) for B robots
+            # with DIFFERENT commands (the Monte-Carlo use; 10 % stand): 8 stand ticks, 40 ticks into the gait, then 100
+            # timed ticks; never `value`
             lp = pkg.default_loop_params(lib)
-            rng = np.random.default_rng(7)
-            cmds = np.zeros((B, 7)); cmds[:, 0] = rng.uniform(-0.4, 0.4, B); cmds[:, 1] = rng.uniform(-0.1, 0.1, B)
-            cmds[:, 2] = 0.3; cmds[:, 5] = rng.uniform(-0.3, 0.3, B); cmds[:, 6] = 1.0
-            st = pkg.loop_states(cmds, lp, height=0.3, yaw=rng.uniform(-3, 3, B), lib=lib)
+            rng = np.random.default_rng(11)
+            cmds = np.zeros((B, 7))
+            cmds[:, 0] = rng.uniform(-0.5, 0.5, B); cmds[:, 1] = rng.uniform(-0.2, 0.2, B); cmds[:, 2] = rng.uniform(0.26, 0.32, B)
+            cmds[:, 5] = rng.uniform(-0.5, 0.5, B)
+            walk = rng.random(B) < 0.9
+            cmds[~walk, :2] = 0.0
+            cmds[~walk, 5] = 0.0
+            st = pkg.loop_states(cmds, lp, height=0.3, yaw=rng.uniform(-3.1, 3.1, B), lib=lib)     # movement_mode 0: stand
+            st = solver.loop_run(st, 8, lp)
+            st["movement_mode"] = walk.astype(float)
             d_st = torch.from_numpy(st.view(np.uint8).reshape(B, -1).copy()).cuda()
-            ticks = 20
-            solver.loop_run_device(B, d_st.data_ptr(), 2, lp, stream=stream.cuda_stream)
+            ticks = 100
+            solver.loop_run_device(B, d_st.data_ptr(), 40, lp, stream=stream.cuda_stream)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             solver.loop_run_device(B, d_st.data_ptr(), ticks, lp, stream=stream.cuda_stream)
@@ -406,8 +413,12 @@ def main():
             fin = np.ascontiguousarray(d_st.cpu().numpy()).view(pkg.LOOP_STATE_DTYPE).reshape(B)
             out["closed_loop"] = {"value": B * ticks / dt, "unit": "robot-ticks/s", "ticks": ticks, "robots": B,
                                   "ms_per_tick": 1e3 * dt / ticks, "solver_ok": int((fin["status"] == 0).sum()),
+                                  "mean_iterations": float(fin["iterations"].mean()),
+                                  "launch_form": ("persistent wave-per-robot kernel" if B <= 2048 and os.environ.get("QMPC_LOOP_FUSED") != "0"
+                                                  else "three kernels per tick (graph replay)"),
                                   "note": "secondary: qmpc_loop_run_device (goal + gait FSM + swing quintic + Raibert + "
-                                          "record packing -> solve -> rigid-body plant), state resident in HBM"}
+                                          "record packing -> solve -> rigid-body plant), robots with random commands, state "
+                                          "resident in HBM; tools/loop_bench.py compares the two launch forms"}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(pkg, N, config_id, model=args.model)
             f_cpu = cb.pop("_forces")

@@ -22,6 +22,12 @@
 
 using namespace qmpc;
 
+// qmpc_loop_fused.hip (second translation unit): the closed loop's persistent kernel
+hipError_t qmpc_fused_set_lds(int var, int bytes);
+hipError_t qmpc_fused_launch(int var, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
+                             const qmpc_loop_params* lp, qmpc_loop_state* st, qmpc_input* rec, double* forces,
+                             qmpc_info* info, double* trace_f, double* trace_c, int ticks, double* gws);
+
 struct qmpc_handle {
   qmpc_params params;
   DevParams dev;
@@ -246,6 +252,7 @@ static qmpc_status create_resources(qmpc_handle* h, int N, int nl, int nu) {
     QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, true, 1>), h->lds_bytes_g);
     QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, false, 2>), h->lds_bytes_s);
     QMPC_SET_LDS(qmpc_linearize_kernel<QuatModel>, h->lds_bytes_g);
+    for (int v = 0; v < 3; ++v) HIP_TRY(qmpc_fused_set_lds(v, 160 * 1024));     // the closed loop's persistent kernel
   }
   if (params->mode == QMPC_MODE_REFERENCE) {
     if (params->model == QMPC_MODEL_QUAT8) {
@@ -862,6 +869,23 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
     }
     return QMPC_OK;
   };
+  // Converged mode without the joint level: ONE launch, a persistent wave per robot for all ticks (qmpc_loop_fused_kernel;
+  // the per-tick tails of different robots average out instead of adding up).  QMPC_LOOP_FUSED=0 keeps the per-tick
+  // launch sequence below, which is also the path of the reference mode and of the joint-level loop.
+  // Converged mode, no joint level, at most two robots per SIMD: ONE launch, a persistent wave per robot for all ticks
+  // (qmpc_loop_fused_kernel: the per-tick tails of different robots average out instead of adding up; +29 % at 1024
+  // robots with different commands).  Larger batches keep the per-tick sequence below (several robots per SIMD hide the
+  // tails, and the fused kernel pays for its register pressure); so do the reference mode and the joint-level loop.
+  // QMPC_LOOP_FUSED=0 / 1 forces one or the other (experiments, tests).
+  static const int fused_env = [] { const char* e = std::getenv("QMPC_LOOP_FUSED"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+  const bool fused = fused_env >= 0 ? fused_env == 1 : batch <= 2048;      // measured: +25 % (256), +28 % (1024), +8 % (2048), -3 % (4096)
+  if (fused && !g && h->params.mode == QMPC_MODE_CONVERGED) {
+    const int var = pick_variant(h, batch);
+    const size_t lds = var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes);
+    HIP_TRY(qmpc_fused_launch(var, (int)batch, lds, s, &h->dev, sizeof h->dev, &LP, d_states, h->d_in, h->d_forces, h->d_info,
+                              d_trace_forces, d_trace_contacts, (int)ticks, var >= 1 ? h->d_gws : nullptr));
+    return QMPC_OK;
+  }
   // one tick = three kernels (four with the joint level): captured once into a graph and replayed (the sequence is launch-bound for small
   // batches); plain launches when capture is not available on this stream
   hipGraph_t graph = nullptr;

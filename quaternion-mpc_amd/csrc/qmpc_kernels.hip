@@ -953,138 +953,18 @@ __device__ inline double cost_plain(const DevParams& P, const Layout& L, double*
 // ---- the solve kernel ---------------------------------------------------------
 // VAR 0: everything in LDS; 1: gains / rotation blocks in the global workspace gws (one slice per instance);
 // 2: the slack / multiplier arrays there as well
+#define QMPC_SOLVE_WAVES(MD, VAR) \
+  ((VAR) == 0 ? 1 : (MD::NL != 4 ? ((VAR) == 2 ? QMPC_NL8_WAVES : 1) : ((VAR) == 2 ? QMPC_V2_WAVES : 2)))
 template <class MD, bool PROF, int VAR>
-__global__ __launch_bounds__(64, VAR == 0 ? 1 : (MD::NL != 4 ? (VAR == 2 ? QMPC_NL8_WAVES : 1) : (VAR == 2 ? QMPC_V2_WAVES : 2))) void qmpc_solve_kernel(
+__global__ __launch_bounds__(64, QMPC_SOLVE_WAVES(MD, VAR)) void qmpc_solve_kernel(
     DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
     double* __restrict__ traj_u, double* __restrict__ traj_x, int batch, long long* __restrict__ prof_out,
     double* __restrict__ gws) {
-  typedef typename MD::D D;
-  constexpr int NU = D::NU, NC = D::NC;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int b = blockIdx.x;
   if (b >= batch) return;
   const int lane = threadIdx.x;
-  const int N = P.N;
-  constexpr bool KDG = VAR >= 1, SLG = VAR == 2;
-  constexpr bool LEAN = KDG || MD::NL != 4;     // register-lean model constants where registers bound the occupancy
-  const Layout L = make_layout(N, KDG, MD::NL, SLG);
-  const size_t slice = (size_t)N * (D::KD + D::ROT + (SLG ? 5 * NC : 0));
-  double* KD = KDG ? gws + (size_t)b * slice : sm + L.KD;
-  double* ROT = KDG ? KD + N * D::KD : sm + L.ROT;
-  double* sl = SLG ? ROT + N * D::ROT : sm;      // base of the slack arrays (offsets L.S .. L.RC)
-  // records are 8 * D::REC bytes apart (48 doubles; 64 for the 8-contact-point model)
-  const void* in = reinterpret_cast<const double*>(in_) + (size_t)b * ((MD::NX == 13) ? D::REC : 48);
-  int status = QMPC_OK;
-  Prof<PROF> prof;
-  prof.start();
-  setup_instance<MD>(P, L, sm, in, lane, &status);
-  if (status != QMPC_OK) {
-    if (lane < NU) forces[NU * (size_t)b + lane] = 0.0;
-    if (lane == 0 && info) {
-      qmpc_info r = {status, 0, 0.0, 0.0, 0.0, 0.0};
-      info[b] = r;
-    }
-    if (traj_u) for (int i = lane; i < N * NU; i += kWave) traj_u[(size_t)b * N * NU + i] = 0.0;
-    if (traj_x) for (int i = lane; i < (N + 1) * MD::NX; i += kWave) traj_x[(size_t)b * (N + 1) * MD::NX + i] = 0.0;
-    return;
-  }
-  unsigned conmask = 0;
-  for (int l = 0; l < MD::NL; ++l) conmask |= (sm[L.cst + D::C_CON + l] != 0.0) ? (1u << l) : 0u;
-  conmask = __builtin_amdgcn_readfirstlane(conmask);
-  // initial guess U = u_ref (QuatMpc.cpp:253), slacks and multipliers
-  for (int i = lane; i < N * NU; i += kWave) sm[L.U + i] = sm[L.uref + (i % NU)];
-  QSYNC();
-  rollout_open<MD, LEAN>(P, L, sm, lane);
-  expansions<MD>(P, L, sm, lane);
-  double sl_part = 0.0, rc_part = 0.0;     // per-lane shares of sum s*lambda / max |rc| over the enabled rows
-  for (int i = lane; i < N * NC; i += kWave) {
-    const double c0 = cone_value<D>(P, L, sm, i);
-    const double s0 = fmax(-c0, 1.0);
-    const double lam0 = P.mu0 / s0;
-    sl[L.S + i] = s0;
-    sl[L.RC + i] = c0 + s0;
-    sl[L.LAM + i] = lam0;
-    sl[L.DS + i] = 0.0;
-    if (conmask & (1u << ((i % NC) / 6))) {
-      sl_part += s0 * lam0;
-      rc_part = fmax(rc_part, fabs(c0 + s0));
-    }
-  }
-  QSYNC();
-  prof.tick(PH_SETUP);
-  const double inv_rows = 1.0 / (double)(6 * N * __popc(conmask));
-  int it = 0, iters = 0;
-  unsigned kapbits = 0;
-  double mu = 0.0, resid = 0.0, last_step = 1e300, last_ap = 0.0, last_ad = 0.0;
-  status = QMPC_MAX_ITER;
-  for (it = 1; it <= P.iterations_max + 1; ++it) {
-    // barrier parameter and slack residual over the enabled rows (shares left by the set-up / the last apply)
-    mu = wave_sum(sl_part) * inv_rows;
-    resid = wave_max(rc_part);
-    if (mu <= P.mu_final && resid <= P.tol_feas && last_step <= P.tol_step) { status = QMPC_OK; break; }
-    if (it > P.iterations_max) break;
-    // centering: sigma until full steps are taken, then the fast value; short steps
-    // (jamming near the boundary) call for more centering
-    double sg = P.sigma;
-    const double amin = fmin(last_ap, last_ad);
-    if (it > 1 && amin >= 0.99) sg = P.sigma_fast;
-    else if (it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
-    else if (it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
-    const double target = sg * mu;
-    prof.tick(PH_MISC);
-    rotation_prepass<D>(P, L, sm, sl, ROT, target, lane);
-    if (KDG) __syncthreads();
-    prof.tick(PH_PREPASS);
-    if (backward_pass<MD, PROF, (!KDG || QMPC_PIPE_ALL), (SLG || D::TU > 1), QMPC_LEANOPS && KDG>(P, L, sm, KD, ROT, lane, conmask, prof)) { status = QMPC_NOT_PD; break; }
-    if (KDG) __syncthreads();
-    double ap, ad;
-    rollout_closed<MD, !KDG, QMPC_PF_K, LEAN, PROF>(P, L, sm, KD, ROT, 1.0, lane, prof);  // trial step
-    prof.tick(PH_ROLL);
-    ipm_directions<D>(P, L, sm, sl, target, lane, &ap, &ad, &last_step);
-    last_ap = ap; last_ad = ad;
-    prof.tick(PH_DIRS);
-    if (ap < 1.0) rollout_scaled<MD, LEAN>(P, L, sm, ap, lane);    // shortened primal step
-    prof.tick(PH_ROLL);
-    prof.tick(PH_MISC);
-    ipm_apply<D>(P, L, sl, ap, ad, conmask, lane, kapbits, sl_part, rc_part);
-    if (SLG) __syncthreads();
-    prof.tick(PH_APPLY);
-    // accept the candidate
-    for (int i = lane; i < N * NU; i += kWave) sm[L.U + i] += sm[L.dU + i];
-    for (int i = lane; i < (N + 1) * 13; i += kWave) sm[L.X + i] = sm[L.Xc + i];
-    QSYNC();
-    prof.tick(PH_MISC);
-    expansions<MD>(P, L, sm, lane);
-    prof.tick(PH_EXPAND);
-    iters = it;
-  }
-  // outputs: GetInput(u, 0) (QuatMpc.cpp:264-265)
-  if (lane < NU) forces[NU * (size_t)b + lane] = sm[L.U + lane];
-  if (traj_u) for (int i = lane; i < N * NU; i += kWave) traj_u[(size_t)b * N * NU + i] = sm[L.U + i];
-  if (traj_x)
-    for (int i = lane; i < (N + 1) * MD::NX; i += kWave) {
-      const int k = i / MD::NX, j = i - MD::NX * k;
-      traj_x[(size_t)b * (N + 1) * MD::NX + i] = sm[L.X + 13 * k + j];
-    }
-  if (info) {
-    const double J = cost_plain<MD>(P, L, sm, lane);
-    double viol = 0.0;
-    for (int i = lane; i < N * NC; i += kWave) {
-      const int l = (i % NC) / 6;
-      if (conmask & (1u << l)) viol = fmax(viol, fmax(cone_value<D>(P, L, sm, i), 0.0));
-    }
-    viol = wave_max(viol);
-    if (lane == 0) {
-      qmpc_info r = {status, iters, J, viol, last_step, mu};
-      info[b] = r;
-    }
-  }
-  if (PROF && prof_out && lane == 0) {
-    prof.tick(PH_MISC);
-#pragma unroll
-    for (int i = 0; i < PH_COUNT; ++i) prof_out[16 * (size_t)b + i] = prof.t[i];
-    prof_out[16 * (size_t)b + 15] = iters;
-  }
+#include "qmpc_solve_body.inc"
 }
 
 // ---- linearisation only (qmpc_linearize): rollout of U = u_ref + dense Abar/Bbar
@@ -1122,6 +1002,7 @@ __global__ __launch_bounds__(64) void qmpc_linearize_kernel(DevParams P, const q
   }
 }
 
+#ifndef QMPC_FUSED_TU    // the kernels below are not templates: one definition, in the first translation unit
 // ---- leg kinematics + force -> joint torque map ------------
 // A1Kinematics::fk / ::jac (A1Kinematics.cpp:9-19, closed forms :38-128) and
 // BaseInterface::tau_ctrl_update (BaseInterface.cpp:343-408: tau = -J' f, zero for swing
@@ -1253,5 +1134,7 @@ __global__ __launch_bounds__(64) void qmpc_selftest_lanes_kernel(const double* _
   out[448 + lane] = row_bcast<5>(x);
   out[512 + lane] = dpp_mov<0x55>(x);   // quad_perm [1,1,1,1]
 }
+
+#endif  // QMPC_FUSED_TU
 
 }  // namespace qmpc

@@ -159,14 +159,8 @@ __device__ inline double loop_fsm_update(qmpc_loop_leg& L, double dt, double gai
 }
 
 // ---- front end of one tick: feedback, Raibert, goal_update, foot_update, record ---------------
-__global__ __launch_bounds__(64) void qmpc_loop_front_kernel(qmpc_loop_params LP, qmpc_loop_state* __restrict__ st,
-                                                             qmpc_input* __restrict__ rec, int* __restrict__ row,
-                                                             int batch) {
+__device__ inline void loop_front_one(const qmpc_loop_params& LP, qmpc_loop_state& s, qmpc_input& in) {
 #pragma clang fp contract(off)
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0 && row) *row += 1;                         // trace row of this tick (stream order: after the last post)
-  if (i >= batch) return;
-  qmpc_loop_state& s = st[i];
   // feedback the controller reads (BaseInterface::fbk_update): R, R_z, foot_pos_body, contact flags
   double R[9], Rz[9];
   qmpc_loop::quat_to_rot(s.quat, R);
@@ -250,7 +244,6 @@ __global__ __launch_bounds__(64) void qmpc_loop_front_kernel(qmpc_loop_params LP
     const double n = sqrt(qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]);
     for (int a = 0; a < 4; ++a) qd[a] = qd[a] / n;
   }
-  qmpc_input& in = rec[i];
   for (int a = 0; a < 4; ++a) { in.quat[a] = s.quat[a]; in.quat_d[a] = s.quat_d[a]; in.contacts[a] = (s.contacts[a] != 0.0) ? 1.0 : 0.0; }
   for (int a = 0; a < 9; ++a) in.rot[a] = R[a];
   for (int r = 0; r < 3; ++r) {
@@ -262,33 +255,36 @@ __global__ __launch_bounds__(64) void qmpc_loop_front_kernel(qmpc_loop_params LP
   }
   for (int a = 0; a < 12; ++a) in.foot_pos_body[a] = foot_body[a];
 }
+#ifndef QMPC_FUSED_TU
+__global__ __launch_bounds__(64) void qmpc_loop_front_kernel(qmpc_loop_params LP, qmpc_loop_state* __restrict__ st,
+                                                             qmpc_input* __restrict__ rec, int* __restrict__ row,
+                                                             int batch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && row) *row += 1;                         // trace row of this tick (stream order: after the last post)
+  if (i >= batch) return;
+  loop_front_one(LP, st[i], rec[i]);
+}
+#endif
 
 // ---- back end of one tick: outputs (QuatMpc.cpp:263-273), plant step, swing feet -----------------
-__global__ __launch_bounds__(64) void qmpc_loop_post_kernel(DevParams P, qmpc_loop_params LP, qmpc_loop_state* __restrict__ st,
-                                                            const double* __restrict__ forces,
-                                                            const qmpc_info* __restrict__ info, double* __restrict__ trace_f,
-                                                            double* __restrict__ trace_c, const int* __restrict__ row,
-                                                            int batch) {
+// forces: the 12 forces of this robot's solve; trace_f / trace_c: this robot's slots in the trace row of this tick (or null)
+__device__ inline void loop_post_one(const DevParams& P, const qmpc_loop_params& LP, qmpc_loop_state& s,
+                                     const double* __restrict__ forces, const qmpc_info& inf, double* __restrict__ trace_f,
+                                     double* __restrict__ trace_c) {
 #pragma clang fp contract(off)
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= batch) return;
-  qmpc_loop_state& s = st[i];
-  const int status = info[i].status;
+  const int status = inf.status;
   s.status = (double)status;
-  s.iterations = (double)info[i].iterations;
+  s.iterations = (double)inf.iterations;
   if (status == QMPC_OK || status == QMPC_MAX_ITER)     // otherwise the previous forces stay (host/QuatMpcHip.h)
-    for (int a = 0; a < 12; ++a) s.forces_body[a] = forces[12 * (size_t)i + a];
+    for (int a = 0; a < 12; ++a) s.forces_body[a] = forces[a];
   double R[9];
   qmpc_loop::quat_to_rot(s.quat, R);
   for (int l = 0; l < 4; ++l)
     for (int r = 0; r < 3; ++r)
       s.grf_world[3 * l + r] = R[3 * r] * s.forces_body[3 * l] + R[3 * r + 1] * s.forces_body[3 * l + 1] +
                                R[3 * r + 2] * s.forces_body[3 * l + 2];
-  if (trace_f || trace_c) {
-    const size_t t = (size_t)(*row);
-    if (trace_f) for (int a = 0; a < 12; ++a) trace_f[(t * batch + i) * 12 + a] = s.forces_body[a];
-    if (trace_c) for (int a = 0; a < 4; ++a) trace_c[(t * batch + i) * 4 + a] = s.contacts[a];
-  }
+  if (trace_f) for (int a = 0; a < 12; ++a) trace_f[a] = s.forces_body[a];
+  if (trace_c) for (int a = 0; a < 4; ++a) trace_c[a] = s.contacts[a];
   // plant: rigid body under the applied forces, feet fixed during the step
   double x[13];
   for (int a = 0; a < 3; ++a) { x[a] = s.pos_world[a]; x[7 + a] = s.lin_vel_world[a]; x[10 + a] = s.ang_vel_body[a]; }
@@ -303,5 +299,59 @@ __global__ __launch_bounds__(64) void qmpc_loop_post_kernel(DevParams P, qmpc_lo
         for (int a = 0; a < 3; ++a) s.foot_pos_world[3 * l + a] = s.leg[l].fsm_pos[a];
   s.tick += 1.0;
 }
+#ifndef QMPC_FUSED_TU
+__global__ __launch_bounds__(64) void qmpc_loop_post_kernel(DevParams P, qmpc_loop_params LP, qmpc_loop_state* __restrict__ st,
+                                                            const double* __restrict__ forces,
+                                                            const qmpc_info* __restrict__ info, double* __restrict__ trace_f,
+                                                            double* __restrict__ trace_c, const int* __restrict__ row,
+                                                            int batch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch) return;
+  const size_t slot = (trace_f || trace_c) ? (size_t)(*row) * batch + i : 0;
+  loop_post_one(P, LP, st[i], forces + 12 * (size_t)i, info[i], trace_f ? trace_f + 12 * slot : nullptr,
+                trace_c ? trace_c + 4 * slot : nullptr);
+}
+#endif
+
+#ifdef QMPC_FUSED_TU      // compiled in its own translation unit (qmpc_loop_fused.hip)
+// ---- the whole loop in ONE launch: a persistent wave per robot ------------------------------------------------
+// The robots of a batch do not interact, so nothing forces them to advance in lock-step: with one launch sequence per
+// tick every tick lasts as long as its slowest solve (mean / max of the iteration counts ~0.63 at 1024 robots), and
+// that tail is paid `ticks` times.  Here a wave owns one robot for all ticks -- front end (lane 0), solve (the wave,
+// solve_body of qmpc_kernels.hip), back end (lane 0) -- and the tails of different robots average out instead of
+// adding up.  Same arithmetic in the same order as the per-tick kernels: bit-identical states and traces.
+// It lives in a translation unit of its own because a second user of the solve body in THIS one changes the
+// compiler's inlining of the solve kernel (measured: 2 % slower contract workload).
+template <int VAR>
+__global__ __launch_bounds__(64, QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_loop_fused_kernel(
+    DevParams P, qmpc_loop_params LP, qmpc_loop_state* __restrict__ st, qmpc_input* __restrict__ rec,
+    double* __restrict__ forces, qmpc_info* __restrict__ info, double* __restrict__ trace_f, double* __restrict__ trace_c,
+    int ticks, int batch, double* __restrict__ gws) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int b = blockIdx.x;
+  if (b >= batch) return;
+  const int lane = threadIdx.x;
+  typedef QuatModel MD;
+  constexpr bool PROF = false;
+  const qmpc_input* in_ = rec;
+  double *traj_u = nullptr, *traj_x = nullptr;
+  long long* prof_out = nullptr;
+  for (int t = 0; t < ticks; ++t) {
+    if (lane == 0) loop_front_one(LP, st[b], rec[b]);
+    __syncthreads();                      // the record (global memory) is visible to the wave
+    [&]() {                               // `return` in the body (rejected input) ends this tick's solve only
+#include "qmpc_solve_body.inc"
+    }();
+    __syncthreads();
+    if (lane == 0) {
+      const size_t slot = (size_t)t * batch + b;
+      loop_post_one(P, LP, st[b], forces + 12 * (size_t)b, info[b], trace_f ? trace_f + 12 * slot : nullptr,
+                    trace_c ? trace_c + 4 * slot : nullptr);
+    }
+    __syncthreads();
+  }
+}
+
+#endif
 
 }  // namespace qmpc

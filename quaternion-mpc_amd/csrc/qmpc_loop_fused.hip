@@ -1,0 +1,41 @@
+// qmpc_loop_fused.hip -- second translation unit of libqmpc_hip.so: the persistent wave-per-robot kernel of the closed
+// loop (qmpc_loop_fused_kernel, defined in qmpc_loop.hip) and its launcher.  The kernel re-uses the body of the solve
+// kernel (qmpc_solve_body.inc); compiled next to qmpc_solve_kernel it perturbs that kernel's inlining and register
+// allocation (contract workload 2 % slower), so it gets a code object of its own.  The shared sources are included
+// under another namespace name: their non-template kernels would otherwise be defined twice at link time.
+#define QMPC_FUSED_TU 1
+#define qmpc qmpc_fused_tu
+#include "qmpc_kernels.hip"
+#include "qmpc_loop.hip"
+#undef qmpc
+
+#include <cstring>
+
+using namespace qmpc_fused_tu;
+
+// called from qmpc_hip.hip (declared there); hidden: not part of the C ABI
+__attribute__((visibility("hidden"))) hipError_t qmpc_fused_set_lds(int var, int bytes) {
+  const void* k = var == 2 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<2>)
+                           : (var == 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1>)
+                                       : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0>));
+  return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+__attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int batch, size_t lds, hipStream_t s,
+                                                                   const void* dev_params, size_t dev_params_size,
+                                                                   const qmpc_loop_params* lp, qmpc_loop_state* st,
+                                                                   qmpc_input* rec, double* forces, qmpc_info* info,
+                                                                   double* trace_f, double* trace_c, int ticks, double* gws) {
+  if (dev_params_size != sizeof(DevParams)) return hipErrorInvalidValue;
+  DevParams P;
+  std::memcpy(&P, dev_params, sizeof P);
+  const qmpc_loop_params LP = *lp;
+#define QMPC_LAUNCH_FUSED(V) \
+  hipLaunchKernelGGL(qmpc_loop_fused_kernel<V>, dim3((unsigned)batch), dim3(kWave), lds, s, P, LP, st, rec, forces, info, \
+                     trace_f, trace_c, ticks, batch, gws)
+  if (var == 2) QMPC_LAUNCH_FUSED(2);
+  else if (var == 1) QMPC_LAUNCH_FUSED(1);
+  else QMPC_LAUNCH_FUSED(0);
+#undef QMPC_LAUNCH_FUSED
+  return hipGetLastError();
+}

@@ -975,6 +975,30 @@ def test_device_closed_loop_matches_host_classes_tick_for_tick(pkg, lib):
     assert 0.2 < walk["pos_world"][2] < 0.4 and abs(st[0]["pos_world"][2] - 0.3) < 0.02           # nobody fell
 
 
+@pytest.mark.parametrize("robots,ticks,horizon", [(96, 90, 10), (3000, 12, 10), (40, 60, 20)],
+                         ids=["96 robots N=10", "3000 robots (several rounds per SIMD)", "N=20"])
+def test_persistent_loop_kernel_equals_the_per_tick_sequence(robots, ticks, horizon):
+    """qmpc_loop_run* has two launch forms: three kernels per tick (graph replay) and ONE persistent kernel in which a
+    wave owns a robot for all ticks (the default up to 2048 robots: the per-tick tails of different robots average out,
+    +28 % at 1024 robots, +51 % at N=20; profiles/r02_loop_bench.txt).  Same arithmetic in the same order: final
+    states and traces must be BIT-identical, including a robot whose records are rejected at every tick."""
+    import os
+    import subprocess
+    import sys
+
+    worker = Path(__file__).resolve().parent / "_loop_worker.py"
+    out = {}
+    for fused in ("0", "1"):
+        env = dict(os.environ, QMPC_LOOP_FUSED=fused)
+        r = subprocess.run([sys.executable, str(worker), str(robots), str(ticks), str(horizon)], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out[fused] = [l for l in r.stdout.splitlines() if l.startswith("SHA")][0]
+    print(out["1"])
+    assert out["0"] == out["1"]
+    assert int(out["1"].split()[3]) > 0          # swing phases happened
+
+
 def test_joint_commands_and_inverse_kinematics_match_oracle(pkg, lib, oracle):
     """SURVEY 8f rank 2, completed: BaseInterface::tau_ctrl_update (BaseInterface.cpp:343-408) on the device --
     inverse kinematics (A1Kinematics.cpp:335-459), J^-1 velocity targets, -J'f torques -- against oracle/qo_legkin.c.
