@@ -19,6 +19,7 @@ static_assert(sizeof(qmpc_joint_command) == 36 * sizeof(double), "command record
 
 constexpr int kJointFb = 75, kJointCmd = 36, kJointTile = 64;
 
+#ifndef QMPC_FUSED_TU
 __global__ __launch_bounds__(256) void qmpc_joint_cmd_kernel(LegGeom G, const qmpc_joint_feedback* __restrict__ fb,
                                                              qmpc_joint_command* __restrict__ cmd, int batch) {
   __shared__ double rec[kJointTile * kJointFb];          // 38.4 KB: the feedback records, then the commands
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(256) void qmpc_leg_inverse_kernel(LegGeom G, const 
   qmpc_joint::leg_inverse(p, cur_joint_pos[3 * t], G.rho_fix[t & 3], q);
   joint_pos[3 * t] = q[0]; joint_pos[3 * t + 1] = q[1]; joint_pos[3 * t + 2] = q[2];
 }
+#endif
 
 // Joint-level feedback and commands of the robots of a closed loop, from their states after a tick.  The plant's legs
 // are massless: the measured joint angles are the inverse kinematics of the plant's foot positions (hip branch: the
@@ -67,17 +69,10 @@ __global__ __launch_bounds__(256) void qmpc_leg_inverse_kernel(LegGeom G, const 
 // velocity - torso velocity) with swing feet moving at their FSM target velocity and stance feet at rest.
 // One thread per (robot, leg); the loop state is an 818-double record, of which a leg reads ~45.  `cmd` receives the
 // commands of this call, `trace` (with the loop's tick counter `row`) one row per tick; either may be null.
-__global__ __launch_bounds__(256) void qmpc_loop_joint_kernel(LegGeom G, const qmpc_loop_state* __restrict__ st,
-                                                              double* __restrict__ joint_pos_io,
-                                                              qmpc_joint_feedback* __restrict__ fb_out,
-                                                              qmpc_joint_command* __restrict__ cmd,
-                                                              qmpc_joint_command* __restrict__ trace,
-                                                              const int* __restrict__ row, int batch) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)batch * 4) return;
-  const size_t i = t >> 2;
-  const int l = (int)(t & 3);
-  const qmpc_loop_state& s = st[i];
+// leg l of robot s: joint_pos_io / fb_out / cmd / trace point at THIS robot's records (fb_out, cmd, trace may be null)
+__device__ inline void loop_joint_leg(const LegGeom& G, const qmpc_loop_state& s, const int l, double* __restrict__ joint_pos_io,
+                                      qmpc_joint_feedback* __restrict__ fb_out, qmpc_joint_command* __restrict__ cmd,
+                                      qmpc_joint_command* __restrict__ trace) {
   double R[9];
   qmpc_loop::quat_to_rot(s.quat, R);
   const bool walking = s.movement_mode > 0.0;
@@ -95,7 +90,7 @@ __global__ __launch_bounds__(256) void qmpc_loop_joint_kernel(LegGeom G, const q
       pb[a] = R[a] * d[0] + R[3 + a] * d[1] + R[6 + a] * d[2];
       vb[a] = R[a] * fv[0] + R[3 + a] * fv[1] + R[6 + a] * fv[2];
     }
-    for (int a = 0; a < 3; ++a) qprev[a] = joint_pos_io[12 * i + 3 * l + a];
+    for (int a = 0; a < 3; ++a) qprev[a] = joint_pos_io[3 * l + a];
     qmpc_joint::leg_inverse(pb, qprev[0], G.rho_fix[l], q);
     if ((q[0] != q[0]) || (q[1] != q[1]) || (q[2] != q[2]))
       for (int a = 0; a < 3; ++a) q[a] = qprev[a];
@@ -107,8 +102,8 @@ __global__ __launch_bounds__(256) void qmpc_loop_joint_kernel(LegGeom G, const q
   double ang[3], vel[3], tau[3];
   qmpc_joint::leg_command(G.rho_opt[l], G.rho_fix[l], R, s.pos_world, s.lin_vel_world, q, qd, &s.foot_target_world[3 * l],
                           s.leg[l].fsm_vel, &s.forces_body[3 * l], s.contacts[l] != 0.0, walking, ang, vel, tau);
-  for (int j = 0; j < 3; ++j) joint_pos_io[12 * i + 3 * l + j] = q[j];
-  qmpc_joint_command* outs[2] = {cmd ? &cmd[i] : nullptr, trace ? &trace[(size_t)(*row) * batch + i] : nullptr};
+  for (int j = 0; j < 3; ++j) joint_pos_io[3 * l + j] = q[j];
+  qmpc_joint_command* outs[2] = {cmd, trace};
   for (int w = 0; w < 2; ++w)
     if (outs[w])
       for (int j = 0; j < 3; ++j) {
@@ -117,7 +112,7 @@ __global__ __launch_bounds__(256) void qmpc_loop_joint_kernel(LegGeom G, const q
         outs[w]->joint_tau_tgt[3 * l + j] = tau[j];
       }
   if (fb_out) {
-    qmpc_joint_feedback& f = fb_out[i];
+    qmpc_joint_feedback& f = *fb_out;
     for (int j = 0; j < 3; ++j) {
       f.joint_pos[3 * l + j] = q[j];
       f.joint_vel[3 * l + j] = qd[j];
@@ -133,5 +128,20 @@ __global__ __launch_bounds__(256) void qmpc_loop_joint_kernel(LegGeom G, const q
     }
   }
 }
+
+#ifndef QMPC_FUSED_TU
+__global__ __launch_bounds__(256) void qmpc_loop_joint_kernel(LegGeom G, const qmpc_loop_state* __restrict__ st,
+                                                              double* __restrict__ joint_pos_io,
+                                                              qmpc_joint_feedback* __restrict__ fb_out,
+                                                              qmpc_joint_command* __restrict__ cmd,
+                                                              qmpc_joint_command* __restrict__ trace,
+                                                              const int* __restrict__ row, int batch) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)batch * 4) return;
+  const size_t i = t >> 2;
+  loop_joint_leg(G, st[i], (int)(t & 3), joint_pos_io + 12 * i, fb_out ? fb_out + i : nullptr, cmd ? cmd + i : nullptr,
+                 trace ? trace + ((size_t)(*row) * batch + i) : nullptr);
+}
+#endif
 
 }  // namespace qmpc

@@ -1002,7 +1002,6 @@ __global__ __launch_bounds__(64) void qmpc_linearize_kernel(DevParams P, const q
   }
 }
 
-#ifndef QMPC_FUSED_TU    // the kernels below are not templates: one definition, in the first translation unit
 // ---- leg kinematics + force -> joint torque map ------------
 // A1Kinematics::fk / ::jac (A1Kinematics.cpp:9-19, closed forms :38-128) and
 // BaseInterface::tau_ctrl_update (BaseInterface.cpp:343-408: tau = -J' f, zero for swing
@@ -1013,6 +1012,7 @@ struct LegGeom {
   double rho_fix[4][5];
   double rho_opt[4][3];
 };
+#ifndef QMPC_FUSED_TU    // the kernels below are not templates: one definition, in the first translation unit
 struct LegTerms { double s0, c0, L, X, L2, X2, D; };
 __device__ __forceinline__ LegTerms leg_terms(const double* q, const double* c, const double* r) {
   LegTerms t;

@@ -6,6 +6,7 @@
 #define QMPC_FUSED_TU 1
 #define qmpc qmpc_fused_tu
 #include "qmpc_kernels.hip"
+#include "qmpc_joint.hip"
 #include "qmpc_loop.hip"
 #undef qmpc
 
@@ -25,14 +26,26 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int 
                                                                    const void* dev_params, size_t dev_params_size,
                                                                    const qmpc_loop_params* lp, qmpc_loop_state* st,
                                                                    qmpc_input* rec, double* forces, qmpc_info* info,
-                                                                   double* trace_f, double* trace_c, int ticks, double* gws) {
+                                                                   double* trace_f, double* trace_c, int ticks, double* gws,
+                                                                   const qmpc_leg_geometry* geom, double* joint_pos,
+                                                                   qmpc_joint_command* cmd, qmpc_joint_command* trace_cmd) {
   if (dev_params_size != sizeof(DevParams)) return hipErrorInvalidValue;
   DevParams P;
   std::memcpy(&P, dev_params, sizeof P);
   const qmpc_loop_params LP = *lp;
+  FusedJoint JL;
+  std::memset(&JL, 0, sizeof JL);
+  if (geom) {
+    static_assert(sizeof(LegGeom) == sizeof(qmpc_leg_geometry), "kernel argument mirrors the ABI struct");
+    JL.on = 1;
+    std::memcpy(&JL.G, geom, sizeof JL.G);
+    JL.joint_pos = joint_pos;
+    JL.cmd = cmd;
+    JL.trace = trace_cmd;
+  }
 #define QMPC_LAUNCH_FUSED(V) \
   hipLaunchKernelGGL(qmpc_loop_fused_kernel<V>, dim3((unsigned)batch), dim3(kWave), lds, s, P, LP, st, rec, forces, info, \
-                     trace_f, trace_c, ticks, batch, gws)
+                     trace_f, trace_c, ticks, batch, gws, JL)
   if (var == 2) QMPC_LAUNCH_FUSED(2);
   else if (var == 1) QMPC_LAUNCH_FUSED(1);
   else QMPC_LAUNCH_FUSED(0);
