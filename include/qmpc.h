@@ -400,8 +400,10 @@ void qmpc_loop_state_init(qmpc_loop_state* s, const qmpc_loop_params* lp, const 
  * [ticks][batch][4] may be NULL.  The handle must be a QuatMpc handle (QMPC_MODEL_QUAT). */
 qmpc_status qmpc_loop_run(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* states,
                           int32_t ticks, double* trace_forces, double* trace_contacts);
-/* The same with DEVICE buffers, stream-ordered (NULL = the handle's stream); the per-tick kernel sequence is
- * captured once into a hipGraph and replayed `ticks` times. */
+/* The same with DEVICE buffers, stream-ordered (NULL = the handle's stream).  Up to 2048 robots (converged mode) the
+ * whole loop is ONE launch of a persistent kernel in which a wavefront owns a robot for all ticks; beyond, and in the
+ * reference mode, the per-tick kernel sequence is captured once into a hipGraph and replayed `ticks` times.  The two
+ * forms give the same bits (QMPC_LOOP_FUSED=0 / 1 forces one). */
 qmpc_status qmpc_loop_run_device(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* d_states,
                                  int32_t ticks, double* d_trace_forces, double* d_trace_contacts, void* stream);
 int32_t qmpc_sizeof_loop_state(void);
