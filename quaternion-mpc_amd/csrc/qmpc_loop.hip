@@ -322,14 +322,13 @@ __global__ __launch_bounds__(64) void qmpc_loop_post_kernel(DevParams P, qmpc_lo
 // adding up.  Same arithmetic in the same order as the per-tick kernels: bit-identical states and traces.
 // It lives in a translation unit of its own because a second user of the solve body in THIS one changes the
 // compiler's inlining of the solve kernel (measured: 2 % slower contract workload).
-struct FusedJoint {          // optional joint level closing every tick (on == 0: none)
-  int on;
+struct FusedJoint {          // the joint level closing every tick (JOINT instantiations)
   LegGeom G;
   double* joint_pos;
   qmpc_joint_command* cmd;
   qmpc_joint_command* trace;
 };
-template <int VAR>
+template <int VAR, bool JOINT>
 __global__ __launch_bounds__(64, QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_loop_fused_kernel(
     DevParams P, qmpc_loop_params LP, qmpc_loop_state* __restrict__ st, qmpc_input* __restrict__ rec,
     double* __restrict__ forces, qmpc_info* __restrict__ info, double* __restrict__ trace_f, double* __restrict__ trace_c,
@@ -356,7 +355,7 @@ __global__ __launch_bounds__(64, QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_loo
                     trace_c ? trace_c + 4 * slot : nullptr);
     }
     __syncthreads();
-    if (JL.on) {                          // the joint level of the tick (qmpc_joint.hip): one lane per leg
+    if (JOINT) {                          // the joint level of the tick (qmpc_joint.hip): one lane per leg
       if (lane < 4)
         loop_joint_leg(JL.G, st[b], lane, JL.joint_pos + 12 * (size_t)b, nullptr, JL.cmd ? JL.cmd + b : nullptr,
                        JL.trace ? JL.trace + ((size_t)t * batch + b) : nullptr);

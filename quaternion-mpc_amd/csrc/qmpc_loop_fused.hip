@@ -16,10 +16,14 @@ using namespace qmpc_fused_tu;
 
 // called from qmpc_hip.hip (declared there); hidden: not part of the C ABI
 __attribute__((visibility("hidden"))) hipError_t qmpc_fused_set_lds(int var, int bytes) {
-  const void* k = var == 2 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<2>)
-                           : (var == 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1>)
-                                       : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0>));
-  return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  const void* k[2] = {var == 2 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<2, false>)
+                               : (var == 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1, false>)
+                                           : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0, false>)),
+                      var == 2 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<2, true>)
+                               : (var == 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1, true>)
+                                           : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0, true>))};
+  const hipError_t e = hipFuncSetAttribute(k[0], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  return e != hipSuccess ? e : hipFuncSetAttribute(k[1], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 __attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int batch, size_t lds, hipStream_t s,
@@ -37,18 +41,23 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int 
   std::memset(&JL, 0, sizeof JL);
   if (geom) {
     static_assert(sizeof(LegGeom) == sizeof(qmpc_leg_geometry), "kernel argument mirrors the ABI struct");
-    JL.on = 1;
     std::memcpy(&JL.G, geom, sizeof JL.G);
     JL.joint_pos = joint_pos;
     JL.cmd = cmd;
     JL.trace = trace_cmd;
   }
-#define QMPC_LAUNCH_FUSED(V) \
-  hipLaunchKernelGGL(qmpc_loop_fused_kernel<V>, dim3((unsigned)batch), dim3(kWave), lds, s, P, LP, st, rec, forces, info, \
+#define QMPC_LAUNCH_FUSED(V, J) \
+  hipLaunchKernelGGL((qmpc_loop_fused_kernel<V, J>), dim3((unsigned)batch), dim3(kWave), lds, s, P, LP, st, rec, forces, info, \
                      trace_f, trace_c, ticks, batch, gws, JL)
-  if (var == 2) QMPC_LAUNCH_FUSED(2);
-  else if (var == 1) QMPC_LAUNCH_FUSED(1);
-  else QMPC_LAUNCH_FUSED(0);
+  if (geom) {
+    if (var == 2) QMPC_LAUNCH_FUSED(2, true);
+    else if (var == 1) QMPC_LAUNCH_FUSED(1, true);
+    else QMPC_LAUNCH_FUSED(0, true);
+  } else {
+    if (var == 2) QMPC_LAUNCH_FUSED(2, false);
+    else if (var == 1) QMPC_LAUNCH_FUSED(1, false);
+    else QMPC_LAUNCH_FUSED(0, false);
+  }
 #undef QMPC_LAUNCH_FUSED
   return hipGetLastError();
 }
