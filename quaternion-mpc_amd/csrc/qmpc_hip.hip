@@ -24,7 +24,7 @@ using namespace qmpc;
 
 // qmpc_loop_fused.hip (second translation unit): the closed loop's persistent kernel
 hipError_t qmpc_fused_set_lds(int var, int bytes);
-hipError_t qmpc_fused_launch(int var, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
+hipError_t qmpc_fused_launch(int var, int reference_mode, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
                              const qmpc_loop_params* lp, qmpc_loop_state* st, qmpc_input* rec, double* forces,
                              qmpc_info* info, double* trace_f, double* trace_c, int ticks, double* gws,
                              const qmpc_leg_geometry* geom, double* joint_pos, qmpc_joint_command* cmd,
@@ -874,19 +874,21 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   // Converged mode without the joint level: ONE launch, a persistent wave per robot for all ticks (qmpc_loop_fused_kernel;
   // the per-tick tails of different robots average out instead of adding up).  QMPC_LOOP_FUSED=0 keeps the per-tick
   // launch sequence below, which is also the path of the reference mode and of the joint-level loop.
-  // Converged mode, at most two robots per SIMD: ONE launch, a persistent wave per robot for all ticks
+  // At most two robots per SIMD: ONE launch, a persistent wave per robot for all ticks
   // (qmpc_loop_fused_kernel: the per-tick tails of different robots average out instead of adding up; +29 % at 1024
   // robots with different commands).  Larger batches keep the per-tick sequence below (several robots per SIMD hide the
-  // tails, and the fused kernel pays for its register pressure); so does the reference mode.
+  // tails, and the fused kernel pays for its register pressure).
   // QMPC_LOOP_FUSED=0 / 1 forces one or the other (experiments, tests).
   static const int fused_env = [] { const char* e = std::getenv("QMPC_LOOP_FUSED"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
   const bool fused = fused_env >= 0 ? fused_env == 1 : batch <= 2048;      // measured: +25 % (256), +28 % (1024), +8 % (2048), -3 % (4096)
-  if (fused && h->params.mode == QMPC_MODE_CONVERGED) {
-    const int var = pick_variant(h, batch);
+  if (fused) {
+    const bool ref = h->params.mode == QMPC_MODE_REFERENCE;
+    // the reference-mode kernels exist with everything in LDS (0) and with the gains in the workspace (1): launch_solve's rule
+    const int var = ref ? ((batch > 1024 || h->lds_bytes > 40 * 1024 || h->variant >= 2) ? 1 : 0) : pick_variant(h, batch);
     const size_t lds = var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes);
-    HIP_TRY(qmpc_fused_launch(var, (int)batch, lds, s, &h->dev, sizeof h->dev, &LP, d_states, h->d_in, h->d_forces, h->d_info,
-                              d_trace_forces, d_trace_contacts, (int)ticks, var >= 1 ? h->d_gws : nullptr, g, d_joint_pos, d_cmd,
-                              d_trace_cmd));
+    HIP_TRY(qmpc_fused_launch(var, ref ? 1 : 0, (int)batch, lds, s, &h->dev, sizeof h->dev, &LP, d_states, h->d_in, h->d_forces,
+                              h->d_info, d_trace_forces, d_trace_contacts, (int)ticks, var >= 1 ? h->d_gws : nullptr, g,
+                              d_joint_pos, d_cmd, d_trace_cmd));
     return QMPC_OK;
   }
   // one tick = three kernels (four with the joint level): captured once into a graph and replayed (the sequence is launch-bound for small

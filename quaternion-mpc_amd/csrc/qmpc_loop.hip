@@ -275,7 +275,8 @@ __device__ inline void loop_post_one(const DevParams& P, const qmpc_loop_params&
   const int status = inf.status;
   s.status = (double)status;
   s.iterations = (double)inf.iterations;
-  if (status == QMPC_OK || status == QMPC_MAX_ITER)     // otherwise the previous forces stay (host/QuatMpcHip.h)
+  if (status == QMPC_OK || status == QMPC_MAX_ITER ||   // otherwise the previous forces stay (host/QuatMpcHip.h):
+      (P.mode == QMPC_MODE_REFERENCE && status == QMPC_LINESEARCH_FAIL))   // the reference applies its last iterate
     for (int a = 0; a < 12; ++a) s.forces_body[a] = forces[a];
   double R[9];
   qmpc_loop::quat_to_rot(s.quat, R);
@@ -328,8 +329,9 @@ struct FusedJoint {          // the joint level closing every tick (JOINT instan
   qmpc_joint_command* cmd;
   qmpc_joint_command* trace;
 };
-template <int VAR, bool JOINT>
-__global__ __launch_bounds__(64, QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_loop_fused_kernel(
+// REF: the reference's own solver mode (AL-iLQR, <= 10 iterations; one wave per SIMD like qmpc_ref_kernel, VAR 0 / 1)
+template <int VAR, bool JOINT, bool REF>
+__global__ __launch_bounds__(64, REF ? 1 : QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_loop_fused_kernel(
     DevParams P, qmpc_loop_params LP, qmpc_loop_state* __restrict__ st, qmpc_input* __restrict__ rec,
     double* __restrict__ forces, qmpc_info* __restrict__ info, double* __restrict__ trace_f, double* __restrict__ trace_c,
     int ticks, int batch, double* __restrict__ gws, FusedJoint JL) {
@@ -345,9 +347,15 @@ __global__ __launch_bounds__(64, QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_loo
   for (int t = 0; t < ticks; ++t) {
     if (lane == 0) loop_front_one(LP, st[b], rec[b]);
     __syncthreads();                      // the record (global memory) is visible to the wave
-    [&]() {                               // `return` in the body (rejected input) ends this tick's solve only
+    if (REF) {
+      [&]() {                             // `return` in the body (rejected input) ends this tick's solve only
+#include "qmpc_ref_body.inc"
+      }();
+    } else {
+      [&]() {
 #include "qmpc_solve_body.inc"
-    }();
+      }();
+    }
     __syncthreads();
     if (lane == 0) {
       const size_t slot = (size_t)t * batch + b;

@@ -7,6 +7,7 @@
 #define qmpc qmpc_fused_tu
 #include "qmpc_kernels.hip"
 #include "qmpc_joint.hip"
+#include "qmpc_ref.hip"
 #include "qmpc_loop.hip"
 #undef qmpc
 
@@ -15,18 +16,27 @@
 using namespace qmpc_fused_tu;
 
 // called from qmpc_hip.hip (declared there); hidden: not part of the C ABI
-__attribute__((visibility("hidden"))) hipError_t qmpc_fused_set_lds(int var, int bytes) {
-  const void* k[2] = {var == 2 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<2, false>)
-                               : (var == 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1, false>)
-                                           : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0, false>)),
-                      var == 2 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<2, true>)
-                               : (var == 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1, true>)
-                                           : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0, true>))};
-  const hipError_t e = hipFuncSetAttribute(k[0], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  return e != hipSuccess ? e : hipFuncSetAttribute(k[1], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+template <bool JOINT, bool REF>
+static const void* fused_kernel(int var) {
+  if (REF) return var >= 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1, JOINT, true>)
+                           : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0, JOINT, true>);
+  return var == 2 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<2, JOINT, false>)
+                  : (var == 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1, JOINT, false>)
+                              : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0, JOINT, false>));
 }
 
-__attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int batch, size_t lds, hipStream_t s,
+__attribute__((visibility("hidden"))) hipError_t qmpc_fused_set_lds(int var, int bytes) {
+  const void* k[4] = {fused_kernel<false, false>(var), fused_kernel<true, false>(var), fused_kernel<false, true>(var),
+                      fused_kernel<true, true>(var)};
+  for (int i = 0; i < 4; ++i) {
+    const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+// var: 0 everything in LDS, 1 gains in the workspace, 2 gains and slack arrays there (converged mode only)
+__attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int reference_mode, int batch, size_t lds, hipStream_t s,
                                                                    const void* dev_params, size_t dev_params_size,
                                                                    const qmpc_loop_params* lp, qmpc_loop_state* st,
                                                                    qmpc_input* rec, double* forces, qmpc_info* info,
@@ -46,18 +56,20 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int 
     JL.cmd = cmd;
     JL.trace = trace_cmd;
   }
-#define QMPC_LAUNCH_FUSED(V, J) \
-  hipLaunchKernelGGL((qmpc_loop_fused_kernel<V, J>), dim3((unsigned)batch), dim3(kWave), lds, s, P, LP, st, rec, forces, info, \
-                     trace_f, trace_c, ticks, batch, gws, JL)
-  if (geom) {
-    if (var == 2) QMPC_LAUNCH_FUSED(2, true);
-    else if (var == 1) QMPC_LAUNCH_FUSED(1, true);
-    else QMPC_LAUNCH_FUSED(0, true);
+#define QMPC_LAUNCH_FUSED(V, J, R) \
+  hipLaunchKernelGGL((qmpc_loop_fused_kernel<V, J, R>), dim3((unsigned)batch), dim3(kWave), lds, s, P, LP, st, rec, forces, \
+                     info, trace_f, trace_c, ticks, batch, gws, JL)
+#define QMPC_LAUNCH_FUSED_J(V, R) \
+  do { if (geom) QMPC_LAUNCH_FUSED(V, true, R); else QMPC_LAUNCH_FUSED(V, false, R); } while (0)
+  if (reference_mode) {
+    if (var >= 1) QMPC_LAUNCH_FUSED_J(1, true);
+    else QMPC_LAUNCH_FUSED_J(0, true);
   } else {
-    if (var == 2) QMPC_LAUNCH_FUSED(2, false);
-    else if (var == 1) QMPC_LAUNCH_FUSED(1, false);
-    else QMPC_LAUNCH_FUSED(0, false);
+    if (var == 2) QMPC_LAUNCH_FUSED_J(2, false);
+    else if (var == 1) QMPC_LAUNCH_FUSED_J(1, false);
+    else QMPC_LAUNCH_FUSED_J(0, false);
   }
+#undef QMPC_LAUNCH_FUSED_J
 #undef QMPC_LAUNCH_FUSED
   return hipGetLastError();
 }

@@ -116,116 +116,11 @@ template <class MD, int VAR>
 __global__ __launch_bounds__(64, 1) void qmpc_ref_kernel(   // one wave per SIMD: the line-search loop keeps ~400 registers live
     DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
     double* __restrict__ traj_u, double* __restrict__ traj_x, int batch, double* __restrict__ gws) {
-  typedef typename MD::D D;
-  constexpr int NU = D::NU, NC = D::NC;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int b = blockIdx.x;
   if (b >= batch) return;
   const int lane = threadIdx.x;
-  const int N = P.N;
-  constexpr bool KDG = VAR >= 1;
-  constexpr bool LEAN = KDG || MD::NL != 4;
-  const Layout L = make_layout(N, KDG, MD::NL, false);
-  const size_t slice = (size_t)N * (D::KD + D::ROT);
-  double* KD = KDG ? gws + (size_t)b * slice : sm + L.KD;
-  double* ROT = KDG ? KD + N * D::KD : sm + L.ROT;
-  double* sl = sm;
-  const void* in = reinterpret_cast<const double*>(in_) + (size_t)b * ((MD::NX == 13) ? D::REC : 48);
-  int status = QMPC_OK;
-  Prof<false> prof;
-  setup_instance<MD>(P, L, sm, in, lane, &status);
-  if (status != QMPC_OK) {
-    if (lane < NU) forces[NU * (size_t)b + lane] = 0.0;
-    if (lane == 0 && info) {
-      qmpc_info r = {status, 0, 0.0, 0.0, 0.0, 0.0};
-      info[b] = r;
-    }
-    if (traj_u) for (int i = lane; i < N * NU; i += kWave) traj_u[(size_t)b * N * NU + i] = 0.0;
-    if (traj_x) for (int i = lane; i < (N + 1) * MD::NX; i += kWave) traj_x[(size_t)b * (N + 1) * MD::NX + i] = 0.0;
-    return;
-  }
-  unsigned conmask = 0;
-  for (int l = 0; l < MD::NL; ++l) conmask |= (sm[L.cst + D::C_CON + l] != 0.0) ? (1u << l) : 0u;
-  conmask = __builtin_amdgcn_readfirstlane(conmask);
-  for (int i = lane; i < N * NU; i += kWave) sm[L.U + i] = sm[L.uref + (i % NU)];
-  for (int i = lane; i < N * NC; i += kWave) sl[L.LAM + i] = 0.0;
-  QSYNC();
-  rollout_open<MD, LEAN>(P, L, sm, lane);
-  expansions<MD>(P, L, sm, lane);
-  ref_cone_refresh<D>(P, L, sm, sl, conmask, lane);
-  QSYNC();
-  double rho = P.penalty_initial;
-  double Jplain = 0.0, viol = 0.0;
-  double J = ref_merit<MD, false>(P, L, sm, sl, rho, conmask, lane, &Jplain, &viol);
-  int iter = 0;
-  double last_step = 0.0;
-  status = QMPC_MAX_ITER;
-  for (iter = 1; iter <= P.iterations_max; ++iter) {
-    rotation_prepass<D, true>(P, L, sm, sl, ROT, rho, lane);
-    if (KDG) __syncthreads();
-    double dV1 = 0.0;
-    if (backward_pass<MD, false, (!KDG || QMPC_PIPE_ALL), (D::TU > 1)>(P, L, sm, KD, ROT, lane, conmask, prof, &dV1)) {
-      status = QMPC_NOT_PD;
-      --iter;
-      break;
-    }
-    if (KDG) __syncthreads();
-    // forward pass: backtracking line search on the AL merit
-    double alpha = 1.0, Jn = J, Jn_plain = Jplain, vn = viol;
-    bool accepted = false;
-    for (int ls = 0; ls <= P.linesearch_max; ++ls) {
-      rollout_closed<MD, !KDG, QMPC_PF_K, LEAN, false>(P, L, sm, KD, ROT, alpha, lane, prof);
-      Jn = ref_merit<MD, true>(P, L, sm, sl, rho, conmask, lane, &Jn_plain, &vn);
-      const double expected = alpha * dV1;
-      const double slack = 1e-12 * fmax(1.0, fabs(J));
-      if (isfinite(Jn) && Jn - J <= 1e-4 * expected + slack) { accepted = true; break; }
-      alpha *= 0.5;
-    }
-    if (!accepted) {
-      status = QMPC_LINESEARCH_FAIL;
-      --iter;
-      break;
-    }
-    double step = 0.0;
-    for (int i = lane; i < N * NU; i += kWave) {
-      step = fmax(step, fabs(sm[L.dU + i]));
-      sm[L.U + i] += sm[L.dU + i];
-    }
-    for (int i = lane; i < (N + 1) * 13; i += kWave) sm[L.X + i] = sm[L.Xc + i];
-    last_step = wave_max(step);
-    QSYNC();
-    const double dJ = J - Jn;
-    J = Jn; Jplain = Jn_plain; viol = vn;
-    expansions<MD>(P, L, sm, lane);
-    ref_cone_refresh<D>(P, L, sm, sl, conmask, lane);
-    QSYNC();
-    const double stat = ref_stationarity<MD>(P, L, sm, sl, rho, conmask, lane);
-    if (stat < P.tol_stat && viol < P.tol_feas) {
-      status = QMPC_OK;
-      break;
-    }
-    if (stat < P.tol_stat || fabs(dJ) < P.tol_cost_int) {
-      for (int i = lane; i < N * NC; i += kWave) {       // lambda <- max(lambda + rho c, 0)
-        const double z = sl[L.LAM + i] + rho * sl[L.RC + i];
-        sl[L.LAM + i] = (z > 0.0) ? z : 0.0;
-      }
-      rho = fmin(rho * P.penalty_scaling, P.penalty_max);
-      QSYNC();
-      J = ref_merit<MD, false>(P, L, sm, sl, rho, conmask, lane, &Jplain, &viol);
-    }
-  }
-  if (iter > P.iterations_max) iter = P.iterations_max;
-  if (lane < NU) forces[NU * (size_t)b + lane] = sm[L.U + lane];
-  if (traj_u) for (int i = lane; i < N * NU; i += kWave) traj_u[(size_t)b * N * NU + i] = sm[L.U + i];
-  if (traj_x)
-    for (int i = lane; i < (N + 1) * MD::NX; i += kWave) {
-      const int k = i / MD::NX, j = i - MD::NX * k;
-      traj_x[(size_t)b * (N + 1) * MD::NX + i] = sm[L.X + 13 * k + j];
-    }
-  if (info && lane == 0) {
-    qmpc_info r = {status, iter, Jplain, viol, last_step, rho};
-    info[b] = r;
-  }
+#include "qmpc_ref_body.inc"
 }
 
 }  // namespace qmpc

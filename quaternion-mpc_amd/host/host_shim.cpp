@@ -168,7 +168,7 @@ struct LoopHarness {
   legged::ClosedLoopHostT<LeggedStateLite>* loop = nullptr;
 };
 // lib_path NULL / "": the scripted test double (qh_fake_script) stands in for the device
-void* qh_loop_create(const char* lib_path, int horizon, const qmpc_loop_params* lp, const qmpc_loop_state* init) {
+void* qh_loop_create_mode(const char* lib_path, int horizon, int mode, const qmpc_loop_params* lp, const qmpc_loop_state* init) {
   LoopHarness* h = new LoopHarness();
   legged::QmpcApi api;
   if (lib_path && lib_path[0]) {
@@ -179,8 +179,11 @@ void* qh_loop_create(const char* lib_path, int horizon, const qmpc_loop_params* 
     api.solve = fake_solve;
     api.destroy = fake_destroy;
   }
-  h->loop = new legged::ClosedLoopHostT<LeggedStateLite>(api, *lp, *init, horizon, 0);
+  h->loop = new legged::ClosedLoopHostT<LeggedStateLite>(api, *lp, *init, horizon, 0, mode);
   return h;
+}
+void* qh_loop_create(const char* lib_path, int horizon, const qmpc_loop_params* lp, const qmpc_loop_state* init) {
+  return qh_loop_create_mode(lib_path, horizon, QMPC_MODE_CONVERGED, lp, init);
 }
 int qh_loop_device_status(void* p) { return (int)static_cast<LoopHarness*>(p)->loop->mpc->last_status(); }
 int qh_loop_tick(void* p) { return static_cast<LoopHarness*>(p)->loop->tick() ? 1 : 0; }

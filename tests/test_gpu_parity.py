@@ -975,9 +975,57 @@ def test_device_closed_loop_matches_host_classes_tick_for_tick(pkg, lib):
     assert 0.2 < walk["pos_world"][2] < 0.4 and abs(st[0]["pos_world"][2] - 0.3) < 0.02           # nobody fell
 
 
-@pytest.mark.parametrize("robots,ticks,horizon", [(96, 90, 10), (3000, 12, 10), (40, 60, 20)],
-                         ids=["96 robots N=10", "3000 robots (several rounds per SIMD)", "N=20"])
-def test_persistent_loop_kernel_equals_the_per_tick_sequence(robots, ticks, horizon):
+def test_reference_mode_closed_loop_matches_host_classes(pkg, lib):
+    """The closed loop with the reference's OWN solver mode (AL-iLQR, <= 10 iterations, last iterate applied whatever its
+    status, QuatMpc.cpp:21-26,256) -- i.e. what a robot running the reference controller would do -- on the device
+    against the host classes in the same mode, tick for tick: contact flags exact, forces <= 1e-6 N."""
+    import __graft_entry__ as g
+
+    host = C.CDLL(str(g.build_host()))
+    vp = C.c_void_p
+    host.qh_loop_create_mode.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, vp]; host.qh_loop_create_mode.restype = vp
+    for f in ("qh_loop_tick", "qh_loop_destroy"):
+        getattr(host, f).argtypes = [vp]
+    host.qh_loop_export.argtypes = [vp, vp]
+    host.qh_loop_set_command.argtypes = [vp, vp, C.c_double]
+    T0, T, N = 6, 70, 10
+    lp = pkg.default_loop_params(lib)
+    cmds = np.array(LOOP_COMMANDS[:5])
+    yaws = [0.0, 0.4, -1.0, 2.0, 0.7]
+    stand = cmds.copy(); stand[:, 6] = 0.0
+    st_init = pkg.loop_states(stand, lp, height=0.3, yaw=yaws, lib=lib)
+    B = len(st_init)
+    s = pkg.Solver(pkg.default_params(N, pkg.MODE_REFERENCE, lib), B, device=0, lib=lib)
+    st0 = s.loop_run(st_init, T0, lp)
+    st0["movement_mode"] = cmds[:, 6]
+    st, tf, tc = s.loop_run(st0, T, lp, trace=True)
+    s.close()
+    statuses = set()
+    worst_f = 0.0
+    for i in range(B):
+        h = host.qh_loop_create_mode(str(pkg.LIB_PATH).encode(), N, pkg.MODE_REFERENCE, C.addressof(lp), st_init[i:i + 1].ctypes.data)
+        assert h
+        e = np.zeros(1, dtype=pkg.LOOP_STATE_DTYPE)
+        for t in range(T0):
+            host.qh_loop_tick(h)
+        host.qh_loop_set_command(h, np.ascontiguousarray(cmds[i, :6]).ctypes.data, float(cmds[i, 6]))
+        for t in range(T):
+            host.qh_loop_tick(h)
+            host.qh_loop_export(h, e.ctypes.data)
+            assert np.array_equal(e[0]["contacts"], tc[t, i]), (i, t)
+            worst_f = max(worst_f, float(np.abs(e[0]["forces_body"] - tf[t, i]).max()))
+            statuses.add(int(e[0]["status"]))
+        assert e[0]["status"] == st[i]["status"] and e[0]["iterations"] == st[i]["iterations"]
+        host.qh_loop_destroy(h)
+    print(f"reference-mode closed loop, {B} robots x {T} ticks: worst force difference {worst_f:.2e} N, status words seen {sorted(statuses)}")
+    assert worst_f <= 1e-6
+    assert (np.abs(st["pos_world"][:, 2] - 0.3) < 0.06).all()          # the truncated controller keeps the robots up
+    assert st[1]["pos_world"][0] * np.cos(yaws[1]) + st[1]["pos_world"][1] * np.sin(yaws[1]) > 0.015
+
+
+@pytest.mark.parametrize("robots,ticks,horizon,mode", [(96, 90, 10, 0), (3000, 12, 10, 0), (40, 60, 20, 0), (64, 90, 10, 1)],
+                         ids=["96 robots N=10", "3000 robots (several rounds per SIMD)", "N=20", "reference mode"])
+def test_persistent_loop_kernel_equals_the_per_tick_sequence(robots, ticks, horizon, mode):
     """qmpc_loop_run* has two launch forms: three kernels per tick (graph replay) and ONE persistent kernel in which a
     wave owns a robot for all ticks (the default up to 2048 robots: the per-tick tails of different robots average out,
     +28 % at 1024 robots, +51 % at N=20; profiles/r02_loop_bench.txt).  Same arithmetic in the same order: final
@@ -990,7 +1038,7 @@ def test_persistent_loop_kernel_equals_the_per_tick_sequence(robots, ticks, hori
     out = {}
     for fused in ("0", "1"):
         env = dict(os.environ, QMPC_LOOP_FUSED=fused)
-        r = subprocess.run([sys.executable, str(worker), str(robots), str(ticks), str(horizon)], env=env, capture_output=True,
+        r = subprocess.run([sys.executable, str(worker), str(robots), str(ticks), str(horizon), str(mode)], env=env, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         out[fused] = [l for l in r.stdout.splitlines() if l.startswith("SHA")][0]
