@@ -401,8 +401,8 @@ void qmpc_loop_state_init(qmpc_loop_state* s, const qmpc_loop_params* lp, const 
 qmpc_status qmpc_loop_run(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* states,
                           int32_t ticks, double* trace_forces, double* trace_contacts);
 /* The same with DEVICE buffers, stream-ordered (NULL = the handle's stream).  Up to 2048 robots (converged mode) the
- * whole loop is ONE launch of a persistent kernel in which a wavefront owns a robot for all ticks; beyond, and in the
- * reference mode, the per-tick kernel sequence is captured once into a hipGraph and replayed `ticks` times.  The two
+ * whole loop is ONE launch of a persistent kernel in which a wavefront owns a robot for all ticks (both solver
+ * modes); beyond, the per-tick kernel sequence is captured once into a hipGraph and replayed `ticks` times.  The two
  * forms give the same bits (QMPC_LOOP_FUSED=0 / 1 forces one). */
 qmpc_status qmpc_loop_run_device(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* d_states,
                                  int32_t ticks, double* d_trace_forces, double* d_trace_contacts, void* stream);
@@ -420,8 +420,8 @@ qmpc_status qmpc_loop_joint_commands_device(qmpc_handle* h, const qmpc_leg_geome
 qmpc_status qmpc_loop_joint_commands(qmpc_handle* h, const qmpc_leg_geometry* g, int32_t batch,
                                      const qmpc_loop_state* states, double* joint_pos, qmpc_joint_feedback* fb,
                                      qmpc_joint_command* cmd);
-/* The closed loop down to the motors: qmpc_loop_run_device with the joint-level kernel closing every tick inside the
- * captured graph.  d_joint_pos [batch][12] in/out as above; d_cmd [batch] receives the commands of the LAST tick,
+/* The closed loop down to the motors: qmpc_loop_run_device with the joint level closing every tick (inside the
+ * persistent kernel, or as the fourth kernel of the captured per-tick graph).  d_joint_pos [batch][12] in/out as above; d_cmd [batch] receives the commands of the LAST tick,
  * d_trace_cmd [ticks][batch] those of every tick (either may be NULL, not both). */
 qmpc_status qmpc_loop_run_joint_device(qmpc_handle* h, const qmpc_loop_params* lp, const qmpc_leg_geometry* g,
                                        int32_t batch, qmpc_loop_state* d_states, double* d_joint_pos, int32_t ticks,
