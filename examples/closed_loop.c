@@ -17,6 +17,8 @@ int main(int argc, char** argv) {
   const int ticks = (argc > 2) ? atoi(argv[2]) : 400;
   qmpc_params p;
   qmpc_default_params(&p, /*horizon=*/10, QMPC_MODE_CONVERGED);
+  p.drop_ang_vel = 0;   /* the MPC sees the body's angular velocity: the reference's x_init leaves it out (QuatMpc.cpp:242-245),
+                           which an ideal rigid-body plant without leg damping does not forgive for long */
   qmpc_handle* h = NULL;
   qmpc_status st = qmpc_create(&p, robots, /*device=*/0, &h);
   if (st != QMPC_OK) {

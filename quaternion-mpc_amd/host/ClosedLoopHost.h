@@ -21,7 +21,7 @@ template <class State>
 class ClosedLoopHostT {
  public:
   ClosedLoopHostT(const QmpcApi& api, const qmpc_loop_params& lp, const qmpc_loop_state& init, int horizon, int device,
-                  int mode = QMPC_MODE_CONVERGED)
+                  int mode = QMPC_MODE_CONVERGED, int drop_ang_vel = 1)
       : lp_(lp) {
     state.param.mpc_horizon = horizon;
     state.param.gait_freq = lp.gait_freq;
@@ -38,7 +38,7 @@ class ClosedLoopHostT {
     for (int a = 0; a < 3; ++a) state.ctrl.torso_lin_vel_d_rel[a] = init.lin_vel_d_rel[a];
     refresh_feedback();
     state.estimator_init = true;
-    mpc = new QuatMpcHipT<State>(state, api, device, mode);      // takes torso_pos_d_world from the feedback (QuatMpc.cpp:13-20)
+    mpc = new QuatMpcHipT<State>(state, api, device, mode, drop_ang_vel);      // takes torso_pos_d_world from the feedback (QuatMpc.cpp:13-20)
     double I[9];
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 3; ++c) I[3 * r + c] = 1.2 * state.param.trunk_inertia(r, c);   // QuatMpc.cpp:182

@@ -54,7 +54,12 @@ class QuatMpcHipT : public LeggedMpcHipT<State> {
   // mode: QMPC_MODE_CONVERGED (default: the KKT point of the problem the reference poses) or QMPC_MODE_REFERENCE
   // (the reference's own solver mode: AL-iLQR capped at 10 iterations, QuatMpc.cpp:21-26 -- the iterate the robot
   // would have applied upstream)
-  QuatMpcHipT(State& state, const QmpcApi& api, int device = 0, int mode = QMPC_MODE_CONVERGED) : api_(api), mode_(mode) {   // QuatMpc.cpp:8-55
+  // drop_ang_vel = 1 (default) reproduces the reference bit for bit: its x_init never receives fbk.torso_ang_vel_body (a
+  // `;` ends the comma initialiser one line early, QuatMpc.cpp:242-245), so the MPC plans from zero angular velocity at
+  // every tick.  On the robot the legs damp the body; on an ideal rigid-body plant that leaves the attitude loop without
+  // a rate term (robots lose balance after 6-9 s).  0 feeds the measured angular velocity, as evidently meant.
+  QuatMpcHipT(State& state, const QmpcApi& api, int device = 0, int mode = QMPC_MODE_CONVERGED, int drop_ang_vel = 1)
+      : api_(api), mode_(mode) {   // QuatMpc.cpp:8-55
     for (int i = 0; i < 3; ++i) {
       torso_lin_vel_d_body_filter[i] = MovingWindowFilterHip(100);
       torso_pos_d_body_filter[i] = MovingWindowFilterHip(100);
@@ -80,6 +85,7 @@ class QuatMpcHipT : public LeggedMpcHipT<State> {
     params_.w = state.param.w;
     params_.mu = state.param.mu;
     params_.fz_max = state.param.fz_max;
+    params_.drop_ang_vel = drop_ang_vel;
     last_status_ = api_.create ? api_.create(&params_, 1, device, &handle_) : QMPC_NO_DEVICE;
   }
   ~QuatMpcHipT() override {

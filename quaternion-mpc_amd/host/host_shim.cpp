@@ -168,7 +168,8 @@ struct LoopHarness {
   legged::ClosedLoopHostT<LeggedStateLite>* loop = nullptr;
 };
 // lib_path NULL / "": the scripted test double (qh_fake_script) stands in for the device
-void* qh_loop_create_mode(const char* lib_path, int horizon, int mode, const qmpc_loop_params* lp, const qmpc_loop_state* init) {
+void* qh_loop_create_opts(const char* lib_path, int horizon, int mode, int drop_ang_vel, const qmpc_loop_params* lp,
+                          const qmpc_loop_state* init) {
   LoopHarness* h = new LoopHarness();
   legged::QmpcApi api;
   if (lib_path && lib_path[0]) {
@@ -179,8 +180,11 @@ void* qh_loop_create_mode(const char* lib_path, int horizon, int mode, const qmp
     api.solve = fake_solve;
     api.destroy = fake_destroy;
   }
-  h->loop = new legged::ClosedLoopHostT<LeggedStateLite>(api, *lp, *init, horizon, 0, mode);
+  h->loop = new legged::ClosedLoopHostT<LeggedStateLite>(api, *lp, *init, horizon, 0, mode, drop_ang_vel);
   return h;
+}
+void* qh_loop_create_mode(const char* lib_path, int horizon, int mode, const qmpc_loop_params* lp, const qmpc_loop_state* init) {
+  return qh_loop_create_opts(lib_path, horizon, mode, 1, lp, init);
 }
 void* qh_loop_create(const char* lib_path, int horizon, const qmpc_loop_params* lp, const qmpc_loop_state* init) {
   return qh_loop_create_mode(lib_path, horizon, QMPC_MODE_CONVERGED, lp, init);

@@ -975,6 +975,43 @@ def test_device_closed_loop_matches_host_classes_tick_for_tick(pkg, lib):
     assert 0.2 < walk["pos_world"][2] < 0.4 and abs(st[0]["pos_world"][2] - 0.3) < 0.02           # nobody fell
 
 
+def test_long_closed_loop_and_the_angular_velocity_quirk(pkg, lib):
+    """The reference never hands fbk.torso_ang_vel_body to its solver (a `;` ends the comma initialiser of x_init one
+    line early, QuatMpc.cpp:242-245; params.drop_ang_vel = 1 reproduces it).  With legs and ground that is harmless; on
+    the ideal rigid-body plant of the device loop the attitude loop then has no rate term: the body's angular velocity
+    creeps up until the robots lose their balance after 6-9 s.  With drop_ang_vel = 0 (the measured angular velocity in
+    x_init, as evidently meant) the same robots walk for 20 s: every solve converges, nobody falls."""
+    lp = pkg.default_loop_params(lib)
+    rng = np.random.default_rng(3)
+    B = 96
+    cmds = np.zeros((B, 7))
+    cmds[:, 0] = rng.uniform(-0.5, 0.5, B); cmds[:, 1] = rng.uniform(-0.2, 0.2, B); cmds[:, 2] = rng.uniform(0.26, 0.32, B)
+    cmds[:, 5] = rng.uniform(-0.5, 0.5, B); cmds[:, 6] = (rng.random(B) < 0.85).astype(float)
+    cmds[cmds[:, 6] == 0, :2] = 0.0
+    cmds[cmds[:, 6] == 0, 5] = 0.0
+    stand = cmds.copy(); stand[:, 6] = 0.0
+    st0 = pkg.loop_states(stand, lp, height=0.3, yaw=rng.uniform(-3, 3, B), lib=lib)
+    out = {}
+    for drop in (1, 0):
+        p = pkg.default_params(10, pkg.MODE_CONVERGED, lib)
+        p.drop_ang_vel = drop
+        s = pkg.Solver(p, B, device=0, lib=lib)
+        st = s.loop_run(st0, 8, lp)
+        st["movement_mode"] = cmds[:, 6]
+        st = s.loop_run(st, 1000, lp)                       # 5 s
+        w5 = np.linalg.norm(st["ang_vel_body"], axis=1)
+        if drop == 0:
+            assert (np.abs(st["pos_world"][:, 2] - cmds[:, 2]) < 0.03).all() and (st["status"] == 0).all()
+        st = s.loop_run(st, 3000, lp)                       # 20 s
+        s.close()
+        z = st["pos_world"][:, 2]
+        out[drop] = (w5, int(((z < 0.15) | (z > 0.5) | ~np.isfinite(z)).sum()), int((st["status"] != 0).sum()))
+    print(f"after 5 s: median |omega| {np.median(out[1][0]):.3f} rad/s with the quirk, {np.median(out[0][0]):.3f} without; "
+          f"after 20 s: {out[1][1]} of {B} robots down with the quirk, {out[0][1]} without")
+    assert out[0][1] == 0 and out[0][2] == 0
+    assert np.median(out[1][0]) > 3 * np.median(out[0][0]) and out[1][1] > B // 4
+
+
 def test_reference_mode_closed_loop_matches_host_classes(pkg, lib):
     """The closed loop with the reference's OWN solver mode (AL-iLQR, <= 10 iterations, last iterate applied whatever its
     status, QuatMpc.cpp:21-26,256) -- i.e. what a robot running the reference controller would do -- on the device

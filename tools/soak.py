@@ -33,6 +33,8 @@ ap.add_argument("--closed-loop", action="store_true")
 ap.add_argument("--robots", type=int, default=4096)
 ap.add_argument("--ticks", type=int, default=1000)
 ap.add_argument("--check", type=int, default=4, help="closed loop: robots replayed on the host classes")
+ap.add_argument("--feed-ang-vel", action="store_true", help="closed loop: params.drop_ang_vel = 0 (the MPC sees the angular "
+                "velocity; with the reference's quirk the ideal plant is undamped and robots lose balance after 6-9 s)")
 a = ap.parse_args()
 lib = pkg.load_library()
 if a.closed_loop:
@@ -41,7 +43,7 @@ if a.closed_loop:
 
     host = C.CDLL(str(g.build_host()))
     vp = C.c_void_p
-    host.qh_loop_create.argtypes = [C.c_char_p, C.c_int, vp, vp]; host.qh_loop_create.restype = vp
+    host.qh_loop_create_opts.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, vp, vp]; host.qh_loop_create_opts.restype = vp
     for fn in ("qh_loop_tick", "qh_loop_destroy"):
         getattr(host, fn).argtypes = [vp]
     host.qh_loop_export.argtypes = [vp, vp]
@@ -57,7 +59,9 @@ if a.closed_loop:
     yaws = rng.uniform(-3.1, 3.1, B)
     stand = cmds.copy(); stand[:, 6] = 0.0
     st_init = pkg.loop_states(stand, lp, height=0.3, yaw=yaws, lib=lib)
-    s = pkg.Solver(pkg.default_params(a.horizon, pkg.MODE_CONVERGED, lib), B, device=0, lib=lib)
+    prm = pkg.default_params(a.horizon, pkg.MODE_CONVERGED, lib)
+    prm.drop_ang_vel = 0 if a.feed_ang_vel else 1
+    s = pkg.Solver(prm, B, device=0, lib=lib)
     t0 = time.time()
     st = s.loop_run(st_init, 8, lp)
     st["movement_mode"] = cmds[:, 6]
@@ -72,7 +76,8 @@ if a.closed_loop:
     nonok = int((st["status"] != 0).sum())
     worst_f, cdiff = 0.0, 0
     for i in range(min(a.check, B)):
-        h = host.qh_loop_create(str(pkg.LIB_PATH).encode(), a.horizon, C.addressof(lp), st_init[i:i + 1].ctypes.data)
+        h = host.qh_loop_create_opts(str(pkg.LIB_PATH).encode(), a.horizon, pkg.MODE_CONVERGED, 0 if a.feed_ang_vel else 1,
+                                     C.addressof(lp), st_init[i:i + 1].ctypes.data)
         e = np.zeros(1, dtype=pkg.LOOP_STATE_DTYPE)
         for _ in range(8):
             host.qh_loop_tick(h)
@@ -84,7 +89,7 @@ if a.closed_loop:
             worst_f = max(worst_f, float(np.abs(e[0]["forces_body"] - tf[t, i]).max()))
         host.qh_loop_destroy(h)
     dist = np.linalg.norm(st["pos_world"][:, :2] - st0["pos_world"][:, :2], axis=1)[~down]
-    print(f"closed-loop soak: {B} robots x {a.ticks} ticks ({a.ticks * 0.005:.1f} s of robot time) in {dt:.1f} s = "
+    print(f"closed-loop soak{' (angular velocity fed to the MPC)' if a.feed_ang_vel else ''}: {B} robots x {a.ticks} ticks ({a.ticks * 0.005:.1f} s of robot time) in {dt:.1f} s = "
           f"{B * a.ticks / dt:.3g} robot-ticks/s incl. traces; robots down {fell}, last-tick solver status != OK {nonok}; "
           f"distance walked median {np.median(dist):.3f} m, max {dist.max():.3f} m; {min(a.check, B)} robots replayed on the host "
           f"classes: contact-flag differences {cdiff}, worst force difference {worst_f:.3e} N")
