@@ -359,7 +359,7 @@ qmpc_status qmpc_joint_commands_device(qmpc_handle* h, const qmpc_leg_geometry* 
  *   plant: single rigid body under the forces, explicit midpoint, dt = 5 ms (this repository's; the reference
  *          closes its loop through Gazebo / the robot); swing feet track the FSM target, stance feet stay.
  * The host classes (host/QuatMpcHip.h + host/ClosedLoopHost.h) run the same tick on the CPU and are the parity
- * reference, tick for tick.  Integers are stored as doubles so that the record is 818 doubles for every binding. */
+ * reference, tick for tick.  Integers are stored as doubles so that the record is 820 doubles for every binding. */
 #define QMPC_LOOP_WINDOW 100
 typedef struct qmpc_loop_filter {      /* MovingWindowFilter.hpp:14-63 */
   double ring[QMPC_LOOP_WINDOW];
@@ -377,6 +377,8 @@ typedef struct qmpc_loop_state {
   double pos_world[3], quat[4], lin_vel_world[3], ang_vel_body[3], foot_pos_world[12];
   /* command: joy.{velx, vely, body_height, roll_rate, pitch_rate, yaw_rate}, ctrl.movement_mode */
   double joy[6], movement_mode;
+  double sin_ang_vel, attitude_traj_count;   /* joy.sin_ang_vel (LeggedState.h:157): the reference's attitude-sweep test mode,
+                                                torso_quat_d = euler_to_quat(pi/8 sin(2 pi k / 900) (1,1,1)), QuatMpc.cpp:138-146 */
   /* controller memory */
   double pos_d_world[3], pos_d_init, quat_d[4], lin_vel_d_rel[3];
   qmpc_loop_filter vel_filter[3], pos_filter[3];

@@ -130,7 +130,7 @@ CONVEX_INPUT_DTYPE = np.dtype(
 )
 assert CONVEX_INPUT_DTYPE.itemsize == 48 * 8
 
-# ---- device-resident closed loop (include/qmpc.h: qmpc_loop_*), 818 doubles per instance ----
+# ---- device-resident closed loop (include/qmpc.h: qmpc_loop_*), 820 doubles per instance ----
 LOOP_WINDOW = 100
 LOOP_FILTER_DTYPE = np.dtype([("ring", "<f8", (LOOP_WINDOW,)), ("head", "<f8"), ("count", "<f8"), ("sum", "<f8"),
                               ("correction", "<f8")], align=False)
@@ -142,13 +142,13 @@ LOOP_LEG_DTYPE = np.dtype([("gait_phase", "<f8"), ("state", "<f8"), ("pattern_in
 LOOP_STATE_DTYPE = np.dtype([
     ("pos_world", "<f8", (3,)), ("quat", "<f8", (4,)), ("lin_vel_world", "<f8", (3,)), ("ang_vel_body", "<f8", (3,)),
     ("foot_pos_world", "<f8", (12,)),
-    ("joy", "<f8", (6,)), ("movement_mode", "<f8"),
+    ("joy", "<f8", (6,)), ("movement_mode", "<f8"), ("sin_ang_vel", "<f8"), ("attitude_traj_count", "<f8"),
     ("pos_d_world", "<f8", (3,)), ("pos_d_init", "<f8"), ("quat_d", "<f8", (4,)), ("lin_vel_d_rel", "<f8", (3,)),
     ("vel_filter", LOOP_FILTER_DTYPE, (3,)), ("pos_filter", LOOP_FILTER_DTYPE, (3,)),
     ("leg", LOOP_LEG_DTYPE, (4,)),
     ("contacts", "<f8", (4,)), ("gait_counter", "<f8", (4,)), ("forces_body", "<f8", (12,)), ("grf_world", "<f8", (12,)),
     ("foot_target_world", "<f8", (12,)), ("status", "<f8"), ("iterations", "<f8"), ("tick", "<f8")], align=False)
-assert LOOP_STATE_DTYPE.itemsize == 818 * 8
+assert LOOP_STATE_DTYPE.itemsize == 820 * 8
 
 
 # BaseInterface::tau_ctrl_update records (include/qmpc.h: qmpc_joint_feedback / qmpc_joint_command)

@@ -793,7 +793,7 @@ void qmpc_loop_joint_init(double* joint_pos, int32_t batch) {
 
 // ---- device-resident closed loop (kernels in qmpc_loop.hip) ----------------
 int32_t qmpc_sizeof_loop_state(void) { return (int32_t)sizeof(qmpc_loop_state); }
-static_assert(sizeof(qmpc_loop_state) == 8 * 818, "qmpc_loop_state is 818 doubles");
+static_assert(sizeof(qmpc_loop_state) == 8 * 820, "qmpc_loop_state is 820 doubles");
 
 void qmpc_default_loop_params(qmpc_loop_params* p) {
   std::memset(p, 0, sizeof *p);

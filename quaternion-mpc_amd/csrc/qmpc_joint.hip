@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void qmpc_leg_inverse_kernel(LegGeom G, const 
 // are massless: the measured joint angles are the inverse kinematics of the plant's foot positions (hip branch: the
 // angle of the previous tick; a foot out of reach keeps the previous angles), the joint velocities J^-1 R'(foot
 // velocity - torso velocity) with swing feet moving at their FSM target velocity and stance feet at rest.
-// One thread per (robot, leg); the loop state is an 818-double record, of which a leg reads ~45.  `cmd` receives the
+// One thread per (robot, leg); the loop state is an 820-double record, of which a leg reads ~45.  `cmd` receives the
 // commands of this call, `trace` (with the loop's tick counter `row`) one row per tick; either may be null.
 // leg l of robot s: joint_pos_io / fb_out / cmd / trace point at THIS robot's records (fb_out, cmd, trace may be null)
 __device__ inline void loop_joint_leg(const LegGeom& G, const qmpc_loop_state& s, const int l, double* __restrict__ joint_pos_io,

@@ -243,6 +243,16 @@ __device__ inline void loop_front_one(const qmpc_loop_params& LP, qmpc_loop_stat
     for (int a = 0; a < 4; ++a) qd[a] += 0.5 * gw[a] * 5.0 / 1000.0;
     const double n = sqrt(qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]);
     for (int a = 0; a < 4; ++a) qd[a] = qd[a] / n;
+    if (s.sin_ang_vel != 0.0) {      // the attitude-sweep test mode (QuatMpc.cpp:138-146; 3.14 is the reference's literal)
+      const double e = 3.14 / 8 * sin(2 * 3.14 / 900 * s.attitude_traj_count);
+      s.attitude_traj_count += 1.0;
+      const double hr = e / 2;       // Utils::euler_to_quat (Utils.cpp:75-99) of (e, e, e)
+      const double c = cos(hr), sn = sin(hr);
+      qd[0] = c * c * c + sn * sn * sn;
+      qd[1] = c * c * sn - sn * sn * c;
+      qd[2] = c * sn * c + sn * c * sn;
+      qd[3] = sn * c * c - c * sn * sn;
+    }
   }
   for (int a = 0; a < 4; ++a) { in.quat[a] = s.quat[a]; in.quat_d[a] = s.quat_d[a]; in.contacts[a] = (s.contacts[a] != 0.0) ? 1.0 : 0.0; }
   for (int a = 0; a < 9; ++a) in.rot[a] = R[a];

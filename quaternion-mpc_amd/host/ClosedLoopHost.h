@@ -33,6 +33,7 @@ class ClosedLoopHostT {
     state.joy.velx = init.joy[0]; state.joy.vely = init.joy[1]; state.joy.body_height = init.joy[2];
     state.joy.roll_rate = init.joy[3]; state.joy.pitch_rate = init.joy[4]; state.joy.yaw_rate = init.joy[5];
     state.ctrl.movement_mode = init.movement_mode;
+    state.joy.sin_ang_vel = init.sin_ang_vel != 0.0;
     state.ctrl.torso_quat_d.w() = init.quat_d[0]; state.ctrl.torso_quat_d.x() = init.quat_d[1];
     state.ctrl.torso_quat_d.y() = init.quat_d[2]; state.ctrl.torso_quat_d.z() = init.quat_d[3];
     for (int a = 0; a < 3; ++a) state.ctrl.torso_lin_vel_d_rel[a] = init.lin_vel_d_rel[a];
@@ -138,6 +139,8 @@ class ClosedLoopHostT {
     o->joy[0] = state.joy.velx; o->joy[1] = state.joy.vely; o->joy[2] = state.joy.body_height;
     o->joy[3] = state.joy.roll_rate; o->joy[4] = state.joy.pitch_rate; o->joy[5] = state.joy.yaw_rate;
     o->movement_mode = state.ctrl.movement_mode;
+    o->sin_ang_vel = state.joy.sin_ang_vel ? 1.0 : 0.0;
+    o->attitude_traj_count = mpc->attitude_sweep_count();
     for (int a = 0; a < 3; ++a) { o->pos_d_world[a] = state.ctrl.torso_pos_d_world[a]; o->lin_vel_d_rel[a] = state.ctrl.torso_lin_vel_d_rel[a]; }
     o->pos_d_init = 1.0;
     o->quat_d[0] = state.ctrl.torso_quat_d.w(); o->quat_d[1] = state.ctrl.torso_quat_d.x();

@@ -270,6 +270,7 @@ class QuatMpcHipT : public LeggedMpcHipT<State> {
   bool terrain_update(State&) override { return true; }   // commented out upstream (:307-338)
 
   qmpc_status last_status() const { return last_status_; }
+  double attitude_sweep_count() const { return attitude_traj_count; }   // ticks spent in the sin_ang_vel test mode
   const qmpc_info& last_info() const { return last_info_; }
   const qmpc_params& params() const { return params_; }
   LeggedContactFSMHip leg_FSM[NUM_LEG];

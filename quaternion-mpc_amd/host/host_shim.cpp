@@ -237,6 +237,7 @@ void qh_leg_inverse(int batch, const double* foot_pos_body, const double* cur_jo
   for (size_t t = 0; t < (size_t)batch * 4; ++t)
     qmpc_joint::leg_inverse(&foot_pos_body[3 * t], cur_joint_pos[3 * t], jc.geom.rho_fix[t & 3], &joint_pos[3 * t]);
 }
+void qh_loop_set_sin_ang_vel(void* p, int on) { static_cast<LoopHarness*>(p)->loop->state.joy.sin_ang_vel = on != 0; }
 void qh_loop_export(void* p, qmpc_loop_state* out) { static_cast<LoopHarness*>(p)->loop->export_state(out); }
 void qh_loop_destroy(void* p) {
   LoopHarness* h = static_cast<LoopHarness*>(p);

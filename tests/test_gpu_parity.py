@@ -1012,6 +1012,62 @@ def test_long_closed_loop_and_the_angular_velocity_quirk(pkg, lib):
     assert np.median(out[1][0]) > 3 * np.median(out[0][0]) and out[1][1] > B // 4
 
 
+def test_attitude_sweep_closed_loop_matches_host_classes(pkg, lib):
+    """The reference's attitude test mode (joy.sin_ang_vel, QuatMpc.cpp:138-146): the desired attitude sweeps
+    euler = pi/8 sin(2 pi k / 900) on all three axes at once -- the large-rotation regime the quaternion formulation
+    exists for.  Device loop against the host classes tick for tick over half a period (peak: 22.5 degrees per axis,
+    0.66 rad of rotation), standing and trotting; and the robots really follow the sweep."""
+    import __graft_entry__ as g
+
+    host = C.CDLL(str(g.build_host()))
+    vp = C.c_void_p
+    host.qh_loop_create_opts.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, vp, vp]; host.qh_loop_create_opts.restype = vp
+    for f in ("qh_loop_tick", "qh_loop_destroy"):
+        getattr(host, f).argtypes = [vp]
+    host.qh_loop_export.argtypes = [vp, vp]
+    host.qh_loop_set_command.argtypes = [vp, vp, C.c_double]
+    host.qh_loop_set_sin_ang_vel.argtypes = [vp, C.c_int]
+    T0, T, N = 6, 450, 10
+    lp = pkg.default_loop_params(lib)
+    cmds = np.array([[0.0, 0.0, 0.30, 0.0, 0.0, 0.0, 0.0], [0.15, 0.0, 0.30, 0.0, 0.0, 0.0, 1.0], [0.0, 0.0, 0.27, 0.0, 0.0, 0.0, 0.0]])
+    stand = cmds.copy(); stand[:, 6] = 0.0
+    st_init = pkg.loop_states(stand, lp, height=0.3, yaw=0.0, lib=lib)
+    B = len(st_init)
+    p = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
+    p.drop_ang_vel = 0
+    s = pkg.Solver(p, B, device=0, lib=lib)
+    st0 = s.loop_run(st_init, T0, lp)
+    st0["movement_mode"] = cmds[:, 6]
+    st0["sin_ang_vel"] = 1.0
+    half = s.loop_run(st0, T // 2, lp)                               # the peak of the sweep
+    st, tf, tc = s.loop_run(st0, T, lp, trace=True)
+    s.close()
+    assert (st["attitude_traj_count"] == T).all() and (st["status"] == 0).all()
+    ang = 2 * np.arccos(np.clip(np.abs(half["quat"][:, 0]), 0, 1))                   # rotation angle of the body at the peak
+    err = 2 * np.arccos(np.clip(np.abs((half["quat"] * half["quat_d"]).sum(1)), 0, 1))
+    print(f"attitude sweep: body rotation at the peak {ang.round(3)} rad, error to the desired attitude {err.round(3)} rad")
+    assert (ang > 0.45).all() and (err < 0.2).all()
+    worst_f = 0.0
+    for i in range(B):
+        h = host.qh_loop_create_opts(str(pkg.LIB_PATH).encode(), N, pkg.MODE_CONVERGED, 0, C.addressof(lp), st_init[i:i + 1].ctypes.data)
+        assert h
+        e = np.zeros(1, dtype=pkg.LOOP_STATE_DTYPE)
+        for t in range(T0):
+            host.qh_loop_tick(h)
+        host.qh_loop_set_command(h, np.ascontiguousarray(cmds[i, :6]).ctypes.data, float(cmds[i, 6]))
+        host.qh_loop_set_sin_ang_vel(h, 1)
+        for t in range(T):
+            assert host.qh_loop_tick(h) == 1, (i, t)
+            host.qh_loop_export(h, e.ctypes.data)
+            assert np.array_equal(e[0]["contacts"], tc[t, i]), (i, t)
+            worst_f = max(worst_f, float(np.abs(e[0]["forces_body"] - tf[t, i]).max()))
+        assert e[0]["attitude_traj_count"] == T
+        assert np.abs(e[0]["quat"] - st[i]["quat"]).max() < 1e-8 and np.abs(e[0]["quat_d"] - st[i]["quat_d"]).max() < 1e-12
+        host.qh_loop_destroy(h)
+    print(f"attitude sweep, {B} robots x {T} ticks: worst force difference device vs host classes {worst_f:.2e} N")
+    assert worst_f <= 1e-6
+
+
 def test_reference_mode_closed_loop_matches_host_classes(pkg, lib):
     """The closed loop with the reference's OWN solver mode (AL-iLQR, <= 10 iterations, last iterate applied whatever its
     status, QuatMpc.cpp:21-26,256) -- i.e. what a robot running the reference controller would do -- on the device

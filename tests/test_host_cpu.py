@@ -606,7 +606,7 @@ def test_host_closed_loop_stands_in_equilibrium_with_scripted_forces(host, pkg):
     host.qh_fake_script.argtypes = [vp, C.c_int, C.c_int]
     lp = pkg.default_loop_params(lib)
     st0 = pkg.loop_states([[0, 0, 0.3, 0, 0, 0, 0]], lp, lib=lib)
-    assert pkg.LOOP_STATE_DTYPE.itemsize == lib.qmpc_sizeof_loop_state() == 818 * 8
+    assert pkg.LOOP_STATE_DTYPE.itemsize == lib.qmpc_sizeof_loop_state() == 820 * 8
     w = 12.84 * 9.81 / 4
     f = np.array([0, 0, w] * 4)
     host.qh_fake_script(f.ctypes.data, pkg.OK, pkg.OK)
