@@ -24,7 +24,7 @@ using namespace qmpc;
 
 // qmpc_loop_fused.hip (second translation unit): the closed loop's persistent kernel
 hipError_t qmpc_fused_set_lds(int var, int bytes);
-hipError_t qmpc_fused_launch(int var, int reference_mode, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
+hipError_t qmpc_fused_launch(int var, int reference_mode, int convex, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
                              const qmpc_loop_params* lp, qmpc_loop_state* st, qmpc_input* rec, double* forces,
                              qmpc_info* info, double* trace_f, double* trace_c, int ticks, double* gws,
                              const qmpc_leg_geometry* geom, double* joint_pos, qmpc_joint_command* cmd,
@@ -254,8 +254,9 @@ static qmpc_status create_resources(qmpc_handle* h, int N, int nl, int nu) {
     QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, true, 1>), h->lds_bytes_g);
     QMPC_SET_LDS((qmpc_solve_kernel<QuatModel, false, 2>), h->lds_bytes_s);
     QMPC_SET_LDS(qmpc_linearize_kernel<QuatModel>, h->lds_bytes_g);
-    for (int v = 0; v < 3; ++v) HIP_TRY(qmpc_fused_set_lds(v, 160 * 1024));     // the closed loop's persistent kernel
   }
+  if (params->model != QMPC_MODEL_QUAT8)
+    for (int v = 0; v < 3; ++v) HIP_TRY(qmpc_fused_set_lds(v, 160 * 1024));     // the closed loop's persistent kernels
   if (params->mode == QMPC_MODE_REFERENCE) {
     if (params->model == QMPC_MODEL_QUAT8) {
       QMPC_SET_LDS((qmpc_ref_kernel<Quat8Model, 1>), h->lds_bytes_g);     // never everything in LDS
@@ -842,7 +843,9 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
                                  qmpc_joint_command* d_trace_cmd, void* stream) {
   if (!h || !lp || batch < 0 || ticks < 0 || (batch > 0 && !d_states)) return QMPC_BAD_ARGUMENT;
   if (g && batch > 0 && (!d_joint_pos || (!d_cmd && !d_trace_cmd))) return QMPC_BAD_ARGUMENT;
-  if (h->params.model != QMPC_MODEL_QUAT) return QMPC_BAD_ARGUMENT;
+  if (h->params.model != QMPC_MODEL_QUAT && h->params.model != QMPC_MODEL_CONVEX) return QMPC_BAD_ARGUMENT;
+  const bool convex = h->params.model == QMPC_MODEL_CONVEX;
+  if (convex && h->params.mode != QMPC_MODE_CONVERGED) return QMPC_UNSUPPORTED;
   if (batch == 0 || ticks == 0) return QMPC_OK;
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
   HIP_TRY(hipSetDevice(h->device));
@@ -856,12 +859,20 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   std::memset(&G, 0, sizeof G);
   if (g) std::memcpy(&G, g, sizeof G);
   auto one_tick = [&]() -> qmpc_status {
-    hipLaunchKernelGGL(qmpc_loop_front_kernel, dim3(blocks), dim3(64), 0, s, LP, d_states, h->d_in, h->d_loop_row, (int)batch);
+    if (convex)
+      hipLaunchKernelGGL(qmpc_loop_front_convex_kernel, dim3(blocks), dim3(64), 0, s, LP, d_states,
+                         reinterpret_cast<qmpc_convex_input*>(h->d_in), h->d_loop_row, (int)batch);
+    else
+      hipLaunchKernelGGL(qmpc_loop_front_kernel, dim3(blocks), dim3(64), 0, s, LP, d_states, h->d_in, h->d_loop_row, (int)batch);
     HIP_TRY(hipGetLastError());
     const qmpc_status st = launch_solve(h, batch, h->d_in, h->d_forces, h->d_info, nullptr, nullptr, s, /*timed=*/false);
     if (st != QMPC_OK) return st;
-    hipLaunchKernelGGL(qmpc_loop_post_kernel, dim3(blocks), dim3(64), 0, s, h->dev, LP, d_states, (const double*)h->d_forces,
-                       (const qmpc_info*)h->d_info, d_trace_forces, d_trace_contacts, (const int*)h->d_loop_row, (int)batch);
+    if (convex)
+      hipLaunchKernelGGL(qmpc_loop_post_kernel<true>, dim3(blocks), dim3(64), 0, s, h->dev, LP, d_states, (const double*)h->d_forces,
+                         (const qmpc_info*)h->d_info, d_trace_forces, d_trace_contacts, (const int*)h->d_loop_row, (int)batch);
+    else
+      hipLaunchKernelGGL(qmpc_loop_post_kernel<false>, dim3(blocks), dim3(64), 0, s, h->dev, LP, d_states, (const double*)h->d_forces,
+                         (const qmpc_info*)h->d_info, d_trace_forces, d_trace_contacts, (const int*)h->d_loop_row, (int)batch);
     HIP_TRY(hipGetLastError());
     if (g) {
       hipLaunchKernelGGL(qmpc_loop_joint_kernel, dim3((unsigned)(((size_t)batch * 4 + 255) / 256)), dim3(256), 0, s, G,
@@ -886,7 +897,7 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
     // the reference-mode kernels exist with everything in LDS (0) and with the gains in the workspace (1): launch_solve's rule
     const int var = ref ? ((batch > 1024 || h->lds_bytes > 40 * 1024 || h->variant >= 2) ? 1 : 0) : pick_variant(h, batch);
     const size_t lds = var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes);
-    HIP_TRY(qmpc_fused_launch(var, ref ? 1 : 0, (int)batch, lds, s, &h->dev, sizeof h->dev, &LP, d_states, h->d_in, h->d_forces,
+    HIP_TRY(qmpc_fused_launch(var, ref ? 1 : 0, convex ? 1 : 0, (int)batch, lds, s, &h->dev, sizeof h->dev, &LP, d_states, h->d_in, h->d_forces,
                               h->d_info, d_trace_forces, d_trace_contacts, (int)ticks, var >= 1 ? h->d_gws : nullptr, g,
                               d_joint_pos, d_cmd, d_trace_cmd));
     return QMPC_OK;
@@ -936,7 +947,7 @@ qmpc_status qmpc_loop_run_joint_device(qmpc_handle* h, const qmpc_loop_params* l
 qmpc_status qmpc_loop_run(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* states,
                           int32_t ticks, double* trace_forces, double* trace_contacts) {
   if (!h || !lp || batch < 0 || ticks < 0 || (batch > 0 && !states)) return QMPC_BAD_ARGUMENT;
-  if (h->params.model != QMPC_MODEL_QUAT) return QMPC_BAD_ARGUMENT;
+  if (h->params.model != QMPC_MODEL_QUAT && h->params.model != QMPC_MODEL_CONVEX) return QMPC_BAD_ARGUMENT;
   if (batch == 0 || ticks == 0) return QMPC_OK;
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
   HIP_TRY(hipSetDevice(h->device));

@@ -19,6 +19,8 @@
 #include "qmpc_device.h"      // DevParams; included after qmpc_kernels.hip by qmpc_hip.hip
 #include "qmpc_loop_math.h"
 
+#include <type_traits>
+
 namespace qmpc {
 
 __device__ inline double loop_filter(qmpc_loop_filter& f, double v) {   // MovingWindowFilter.hpp:28-62
@@ -159,44 +161,67 @@ __device__ inline double loop_fsm_update(qmpc_loop_leg& L, double dt, double gai
 }
 
 // ---- front end of one tick: feedback, Raibert, goal_update, foot_update, record ---------------
-__device__ inline void loop_front_one(const qmpc_loop_params& LP, qmpc_loop_state& s, qmpc_input& in) {
+// feedback the controller reads (BaseInterface::fbk_update): R, R_z, foot_pos_body, contact flags
+__device__ inline void loop_feedback(const qmpc_loop_params& LP, const qmpc_loop_state& s, double* R, double* Rz,
+                                     double* foot_body, double* flag) {
 #pragma clang fp contract(off)
-  // feedback the controller reads (BaseInterface::fbk_update): R, R_z, foot_pos_body, contact flags
-  double R[9], Rz[9];
   qmpc_loop::quat_to_rot(s.quat, R);
   qmpc_loop::rot_to_rot_z(R, Rz);
-  double foot_body[12], flag[4];
   for (int l = 0; l < 4; ++l) {
     const double d[3] = {s.foot_pos_world[3 * l] - s.pos_world[0], s.foot_pos_world[3 * l + 1] - s.pos_world[1],
                          s.foot_pos_world[3 * l + 2] - s.pos_world[2]};
     for (int a = 0; a < 3; ++a) foot_body[3 * l + a] = R[a] * d[0] + R[3 + a] * d[1] + R[6 + a] * d[2];
     flag[l] = (s.foot_pos_world[3 * l + 2] <= LP.contact_height) ? 1.0 : 0.0;
   }
-  // Raibert foothold targets (BaseInterface.cpp:266-288), with last tick's ctrl.torso_lin_vel_d_rel
-  double tgt_world[12];
-  {
-    double vrel[3];
-    for (int r = 0; r < 3; ++r) vrel[r] = Rz[r] * s.lin_vel_world[0] + Rz[3 + r] * s.lin_vel_world[1] + Rz[6 + r] * s.lin_vel_world[2];
-    const double k = sqrt(fabs(s.pos_world[2]) / 9.81);
-    double d[3] = {0.0, 0.0, 0.0};
-    d[0] = k * (vrel[0] - s.lin_vel_d_rel[0]) + (1.0 / LP.gait_freq) / 2.0 * s.lin_vel_d_rel[0];
-    if (d[0] < -0.5) d[0] = -0.5;
-    if (d[0] > 0.5) d[0] = 0.5;
-    d[1] = k * (vrel[1] - s.lin_vel_d_rel[1]) + (1.0 / LP.gait_freq) / 2.0 * s.lin_vel_d_rel[1];
-    if (d[1] < -0.3) d[1] = -0.3;
-    if (d[1] > 0.3) d[1] = 0.3;
-    double dabs[3];
-    for (int r = 0; r < 3; ++r) dabs[r] = Rz[3 * r] * d[0] + Rz[3 * r + 1] * d[1] + Rz[3 * r + 2] * d[2];
-    for (int l = 0; l < 4; ++l) {
-      double ab[3];
-      for (int r = 0; r < 3; ++r)
-        ab[r] = Rz[3 * r] * LP.default_foot_pos_rel[3 * l] + Rz[3 * r + 1] * LP.default_foot_pos_rel[3 * l + 1] +
-                Rz[3 * r + 2] * LP.default_foot_pos_rel[3 * l + 2];
-      ab[0] += dabs[0];
-      ab[1] += dabs[1];
-      for (int r = 0; r < 3; ++r) tgt_world[3 * l + r] = ab[r] + s.pos_world[r];
-    }
+}
+// Raibert foothold targets (BaseInterface.cpp:266-288), with last tick's ctrl.torso_lin_vel_d_rel
+__device__ inline void loop_raibert(const qmpc_loop_params& LP, const qmpc_loop_state& s, const double* Rz, double* tgt_world) {
+#pragma clang fp contract(off)
+  double vrel[3];
+  for (int r = 0; r < 3; ++r) vrel[r] = Rz[r] * s.lin_vel_world[0] + Rz[3 + r] * s.lin_vel_world[1] + Rz[6 + r] * s.lin_vel_world[2];
+  const double k = sqrt(fabs(s.pos_world[2]) / 9.81);
+  double d[3] = {0.0, 0.0, 0.0};
+  d[0] = k * (vrel[0] - s.lin_vel_d_rel[0]) + (1.0 / LP.gait_freq) / 2.0 * s.lin_vel_d_rel[0];
+  if (d[0] < -0.5) d[0] = -0.5;
+  if (d[0] > 0.5) d[0] = 0.5;
+  d[1] = k * (vrel[1] - s.lin_vel_d_rel[1]) + (1.0 / LP.gait_freq) / 2.0 * s.lin_vel_d_rel[1];
+  if (d[1] < -0.3) d[1] = -0.3;
+  if (d[1] > 0.3) d[1] = 0.3;
+  double dabs[3];
+  for (int r = 0; r < 3; ++r) dabs[r] = Rz[3 * r] * d[0] + Rz[3 * r + 1] * d[1] + Rz[3 * r + 2] * d[2];
+  for (int l = 0; l < 4; ++l) {
+    double ab[3];
+    for (int r = 0; r < 3; ++r)
+      ab[r] = Rz[3 * r] * LP.default_foot_pos_rel[3 * l] + Rz[3 * r + 1] * LP.default_foot_pos_rel[3 * l + 1] +
+              Rz[3 * r + 2] * LP.default_foot_pos_rel[3 * l + 2];
+    ab[0] += dabs[0];
+    ab[1] += dabs[1];
+    for (int r = 0; r < 3; ++r) tgt_world[3 * l + r] = ab[r] + s.pos_world[r];
   }
+}
+// foot_update (QuatMpc.cpp:278-305, ConvexMpc.cpp:200-222) and the published foot targets (QuatMpc.cpp:270)
+__device__ inline void loop_foot_update(const qmpc_loop_params& LP, qmpc_loop_state& s, const double* tgt_world, const double* flag) {
+#pragma clang fp contract(off)
+  if (s.movement_mode == 0.0) {
+    for (int l = 0; l < 4; ++l) {
+      loop_fsm_reset(s.leg[l], l);
+      s.contacts[l] = 1.0;
+    }
+  } else {
+    for (int l = 0; l < 4; ++l)
+      s.gait_counter[l] = loop_fsm_update(s.leg[l], 5.0 / 1000.0, LP.gait_freq, &s.foot_pos_world[3 * l], &tgt_world[3 * l],
+                                          flag[l] != 0.0);
+    for (int l = 0; l < 4; ++l) s.contacts[l] = s.leg[l].state;
+  }
+  for (int l = 0; l < 4; ++l)
+    for (int a = 0; a < 3; ++a) s.foot_target_world[3 * l + a] = s.leg[l].fsm_pos[a];
+}
+
+__device__ inline void loop_front_one(const qmpc_loop_params& LP, qmpc_loop_state& s, qmpc_input& in) {
+#pragma clang fp contract(off)
+  double R[9], Rz[9], foot_body[12], flag[4], tgt_world[12];
+  loop_feedback(LP, s, R, Rz, foot_body, flag);
+  loop_raibert(LP, s, Rz, tgt_world);
   // goal_update (QuatMpc.cpp:68-107)
   double vel_f[3], pos_f[3], wd[3];
   {
@@ -221,20 +246,7 @@ __device__ inline void loop_front_one(const qmpc_loop_params& LP, qmpc_loop_stat
     for (int r = 0; r < 3; ++r) pb[r] = R[r] * dp[0] + R[3 + r] * dp[1] + R[6 + r] * dp[2];
     for (int a = 0; a < 3; ++a) pos_f[a] = loop_filter(s.pos_filter[a], pb[a]);
   }
-  // foot_update (QuatMpc.cpp:278-305)
-  if (s.movement_mode == 0.0) {
-    for (int l = 0; l < 4; ++l) {
-      loop_fsm_reset(s.leg[l], l);
-      s.contacts[l] = 1.0;
-    }
-  } else {
-    for (int l = 0; l < 4; ++l)
-      s.gait_counter[l] = loop_fsm_update(s.leg[l], 5.0 / 1000.0, LP.gait_freq, &s.foot_pos_world[3 * l], &tgt_world[3 * l],
-                                          flag[l] != 0.0);
-    for (int l = 0; l < 4; ++l) s.contacts[l] = s.leg[l].state;
-  }
-  for (int l = 0; l < 4; ++l)
-    for (int a = 0; a < 3; ++a) s.foot_target_world[3 * l + a] = s.leg[l].fsm_pos[a];   // QuatMpc.cpp:270
+  loop_foot_update(LP, s, tgt_world, flag);
   // record (QuatMpc.cpp:112-176,231-246): torso_quat_d += 1/2 G(quat_d) w_d 5 ms, normalised
   {
     double* qd = s.quat_d;
@@ -265,7 +277,53 @@ __device__ inline void loop_front_one(const qmpc_loop_params& LP, qmpc_loop_stat
   }
   for (int a = 0; a < 12; ++a) in.foot_pos_body[a] = foot_body[a];
 }
+// ---- the same for the sibling controller, ConvexMpc (ConvexMpc.cpp:41-79,92-118,156-167,200-222) -------------------
+// feedback: torso_euler (Utils::quat_to_euler), torso_ang_vel_world = R w, foot_pos_abs_com = R foot_pos_body
+// (BaseInterface.cpp:197-199,217-223); goal_update: the desired position is the joystick's (body_x, body_y, height) --
+// kept in pos_d_world[0:2], which this controller never integrates -- and velx ramps at 1 m/s^2; the gait FSM, the
+// Raibert targets and the published foot targets are those of QuatMpc.
+__device__ inline void loop_front_convex_one(const qmpc_loop_params& LP, qmpc_loop_state& s, qmpc_convex_input& in) {
+#pragma clang fp contract(off)
+  double R[9], Rz[9], foot_body[12], flag[4], tgt_world[12];
+  loop_feedback(LP, s, R, Rz, foot_body, flag);
+  loop_raibert(LP, s, Rz, tgt_world);
+  // goal_update (ConvexMpc.cpp:51-79)
+  s.pos_d_world[2] = s.joy[2];
+  if (s.lin_vel_d_rel[0] < s.joy[0]) s.lin_vel_d_rel[0] += 1.0 * 5.0 / 1000.0;
+  else if (s.lin_vel_d_rel[0] > s.joy[0]) s.lin_vel_d_rel[0] -= 1.0 * 5.0 / 1000.0;
+  s.lin_vel_d_rel[1] = s.joy[1];
+  s.lin_vel_d_rel[2] = 0.0;
+  double vw[3];
+  for (int r = 0; r < 3; ++r)
+    vw[r] = Rz[3 * r] * s.lin_vel_d_rel[0] + Rz[3 * r + 1] * s.lin_vel_d_rel[1] + Rz[3 * r + 2] * s.lin_vel_d_rel[2];
+  loop_foot_update(LP, s, tgt_world, flag);
+  // record (ConvexMpc.cpp:92-118,156-167)
+  qmpc_loop::quat_to_euler(s.quat, in.euler);
+  for (int r = 0; r < 3; ++r) {
+    in.pos_world[r] = s.pos_world[r];
+    in.ang_vel_world[r] = R[3 * r] * s.ang_vel_body[0] + R[3 * r + 1] * s.ang_vel_body[1] + R[3 * r + 2] * s.ang_vel_body[2];
+    in.lin_vel_world[r] = s.lin_vel_world[r];
+    in.pos_d_world[r] = s.pos_d_world[r];
+    in.lin_vel_d_world[r] = vw[r];
+  }
+  for (int l = 0; l < 4; ++l) {
+    for (int r = 0; r < 3; ++r)
+      in.foot_pos_abs_com[3 * l + r] = R[3 * r] * foot_body[3 * l] + R[3 * r + 1] * foot_body[3 * l + 1] + R[3 * r + 2] * foot_body[3 * l + 2];
+    in.contacts[l] = (s.contacts[l] != 0.0) ? 1.0 : 0.0;
+  }
+  in.yaw_rate_d = s.joy[5];
+  for (int a = 0; a < 13; ++a) in.reserved[a] = 0.0;
+}
+
 #ifndef QMPC_FUSED_TU
+__global__ __launch_bounds__(64) void qmpc_loop_front_convex_kernel(qmpc_loop_params LP, qmpc_loop_state* __restrict__ st,
+                                                                    qmpc_convex_input* __restrict__ rec, int* __restrict__ row,
+                                                                    int batch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && row) *row += 1;
+  if (i >= batch) return;
+  loop_front_convex_one(LP, st[i], rec[i]);
+}
 __global__ __launch_bounds__(64) void qmpc_loop_front_kernel(qmpc_loop_params LP, qmpc_loop_state* __restrict__ st,
                                                              qmpc_input* __restrict__ rec, int* __restrict__ row,
                                                              int batch) {
@@ -278,6 +336,8 @@ __global__ __launch_bounds__(64) void qmpc_loop_front_kernel(qmpc_loop_params LP
 
 // ---- back end of one tick: outputs (QuatMpc.cpp:263-273), plant step, swing feet -----------------
 // forces: the 12 forces of this robot's solve; trace_f / trace_c: this robot's slots in the trace row of this tick (or null)
+// WORLD: the solve returns WORLD-frame forces (ConvexMpc); optimized_input = R' u (ConvexMpc.cpp:188-190)
+template <bool WORLD = false>
 __device__ inline void loop_post_one(const DevParams& P, const qmpc_loop_params& LP, qmpc_loop_state& s,
                                      const double* __restrict__ forces, const qmpc_info& inf, double* __restrict__ trace_f,
                                      double* __restrict__ trace_c) {
@@ -285,15 +345,25 @@ __device__ inline void loop_post_one(const DevParams& P, const qmpc_loop_params&
   const int status = inf.status;
   s.status = (double)status;
   s.iterations = (double)inf.iterations;
-  if (status == QMPC_OK || status == QMPC_MAX_ITER ||   // otherwise the previous forces stay (host/QuatMpcHip.h):
-      (P.mode == QMPC_MODE_REFERENCE && status == QMPC_LINESEARCH_FAIL))   // the reference applies its last iterate
-    for (int a = 0; a < 12; ++a) s.forces_body[a] = forces[a];
+  const bool accepted = status == QMPC_OK || status == QMPC_MAX_ITER ||   // otherwise the previous forces stay (host classes);
+                        (P.mode == QMPC_MODE_REFERENCE && status == QMPC_LINESEARCH_FAIL);   // the reference applies its last iterate
   double R[9];
   qmpc_loop::quat_to_rot(s.quat, R);
-  for (int l = 0; l < 4; ++l)
-    for (int r = 0; r < 3; ++r)
-      s.grf_world[3 * l + r] = R[3 * r] * s.forces_body[3 * l] + R[3 * r + 1] * s.forces_body[3 * l + 1] +
-                               R[3 * r + 2] * s.forces_body[3 * l + 2];
+  if (WORLD) {
+    if (accepted)
+      for (int l = 0; l < 4; ++l)
+        for (int r = 0; r < 3; ++r) {
+          s.grf_world[3 * l + r] = forces[3 * l + r];
+          s.forces_body[3 * l + r] = R[r] * forces[3 * l] + R[3 + r] * forces[3 * l + 1] + R[6 + r] * forces[3 * l + 2];
+        }
+  } else {
+    if (accepted)
+      for (int a = 0; a < 12; ++a) s.forces_body[a] = forces[a];
+    for (int l = 0; l < 4; ++l)
+      for (int r = 0; r < 3; ++r)
+        s.grf_world[3 * l + r] = R[3 * r] * s.forces_body[3 * l] + R[3 * r + 1] * s.forces_body[3 * l + 1] +
+                                 R[3 * r + 2] * s.forces_body[3 * l + 2];
+  }
   if (trace_f) for (int a = 0; a < 12; ++a) trace_f[a] = s.forces_body[a];
   if (trace_c) for (int a = 0; a < 4; ++a) trace_c[a] = s.contacts[a];
   // plant: rigid body under the applied forces, feet fixed during the step
@@ -311,6 +381,7 @@ __device__ inline void loop_post_one(const DevParams& P, const qmpc_loop_params&
   s.tick += 1.0;
 }
 #ifndef QMPC_FUSED_TU
+template <bool WORLD>
 __global__ __launch_bounds__(64) void qmpc_loop_post_kernel(DevParams P, qmpc_loop_params LP, qmpc_loop_state* __restrict__ st,
                                                             const double* __restrict__ forces,
                                                             const qmpc_info* __restrict__ info, double* __restrict__ trace_f,
@@ -319,8 +390,8 @@ __global__ __launch_bounds__(64) void qmpc_loop_post_kernel(DevParams P, qmpc_lo
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= batch) return;
   const size_t slot = (trace_f || trace_c) ? (size_t)(*row) * batch + i : 0;
-  loop_post_one(P, LP, st[i], forces + 12 * (size_t)i, info[i], trace_f ? trace_f + 12 * slot : nullptr,
-                trace_c ? trace_c + 4 * slot : nullptr);
+  loop_post_one<WORLD>(P, LP, st[i], forces + 12 * (size_t)i, info[i], trace_f ? trace_f + 12 * slot : nullptr,
+                       trace_c ? trace_c + 4 * slot : nullptr);
 }
 #endif
 
@@ -340,7 +411,8 @@ struct FusedJoint {          // the joint level closing every tick (JOINT instan
   qmpc_joint_command* trace;
 };
 // REF: the reference's own solver mode (AL-iLQR, <= 10 iterations; one wave per SIMD like qmpc_ref_kernel, VAR 0 / 1)
-template <int VAR, bool JOINT, bool REF>
+// CONVEX: the sibling controller's problem (ConvexModel; converged mode only)
+template <int VAR, bool JOINT, bool REF, bool CONVEX = false>
 __global__ __launch_bounds__(64, REF ? 1 : QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_loop_fused_kernel(
     DevParams P, qmpc_loop_params LP, qmpc_loop_state* __restrict__ st, qmpc_input* __restrict__ rec,
     double* __restrict__ forces, qmpc_info* __restrict__ info, double* __restrict__ trace_f, double* __restrict__ trace_c,
@@ -349,13 +421,16 @@ __global__ __launch_bounds__(64, REF ? 1 : QMPC_SOLVE_WAVES(QuatModel, VAR)) voi
   const int b = blockIdx.x;
   if (b >= batch) return;
   const int lane = threadIdx.x;
-  typedef QuatModel MD;
+  typedef typename std::conditional<CONVEX, ConvexModel, QuatModel>::type MD;
   constexpr bool PROF = false;
   const qmpc_input* in_ = rec;
   double *traj_u = nullptr, *traj_x = nullptr;
   long long* prof_out = nullptr;
   for (int t = 0; t < ticks; ++t) {
-    if (lane == 0) loop_front_one(LP, st[b], rec[b]);
+    if (lane == 0) {
+      if (CONVEX) loop_front_convex_one(LP, st[b], reinterpret_cast<qmpc_convex_input*>(rec)[b]);
+      else loop_front_one(LP, st[b], rec[b]);
+    }
     __syncthreads();                      // the record (global memory) is visible to the wave
     if (REF) {
       [&]() {                             // `return` in the body (rejected input) ends this tick's solve only
@@ -369,8 +444,8 @@ __global__ __launch_bounds__(64, REF ? 1 : QMPC_SOLVE_WAVES(QuatModel, VAR)) voi
     __syncthreads();
     if (lane == 0) {
       const size_t slot = (size_t)t * batch + b;
-      loop_post_one(P, LP, st[b], forces + 12 * (size_t)b, info[b], trace_f ? trace_f + 12 * slot : nullptr,
-                    trace_c ? trace_c + 4 * slot : nullptr);
+      loop_post_one<CONVEX>(P, LP, st[b], forces + 12 * (size_t)b, info[b], trace_f ? trace_f + 12 * slot : nullptr,
+                            trace_c ? trace_c + 4 * slot : nullptr);
     }
     __syncthreads();
     if (JOINT) {                          // the joint level of the tick (qmpc_joint.hip): one lane per leg

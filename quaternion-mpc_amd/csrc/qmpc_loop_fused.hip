@@ -16,19 +16,19 @@
 using namespace qmpc_fused_tu;
 
 // called from qmpc_hip.hip (declared there); hidden: not part of the C ABI
-template <bool JOINT, bool REF>
+template <bool JOINT, bool REF, bool CONVEX = false>
 static const void* fused_kernel(int var) {
-  if (REF) return var >= 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1, JOINT, true>)
-                           : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0, JOINT, true>);
-  return var == 2 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<2, JOINT, false>)
-                  : (var == 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1, JOINT, false>)
-                              : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0, JOINT, false>));
+  if (REF) return var >= 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1, JOINT, true, false>)
+                           : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0, JOINT, true, false>);
+  return var == 2 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<2, JOINT, false, CONVEX>)
+                  : (var == 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1, JOINT, false, CONVEX>)
+                              : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0, JOINT, false, CONVEX>));
 }
 
 __attribute__((visibility("hidden"))) hipError_t qmpc_fused_set_lds(int var, int bytes) {
-  const void* k[4] = {fused_kernel<false, false>(var), fused_kernel<true, false>(var), fused_kernel<false, true>(var),
-                      fused_kernel<true, true>(var)};
-  for (int i = 0; i < 4; ++i) {
+  const void* k[6] = {fused_kernel<false, false>(var), fused_kernel<true, false>(var), fused_kernel<false, true>(var),
+                      fused_kernel<true, true>(var),   fused_kernel<false, false, true>(var), fused_kernel<true, false, true>(var)};
+  for (int i = 0; i < 6; ++i) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
   }
@@ -36,7 +36,8 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_fused_set_lds(int var, int
 }
 
 // var: 0 everything in LDS, 1 gains in the workspace, 2 gains and slack arrays there (converged mode only)
-__attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int reference_mode, int batch, size_t lds, hipStream_t s,
+__attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int reference_mode, int convex, int batch, size_t lds,
+                                                                   hipStream_t s,
                                                                    const void* dev_params, size_t dev_params_size,
                                                                    const qmpc_loop_params* lp, qmpc_loop_state* st,
                                                                    qmpc_input* rec, double* forces, qmpc_info* info,
@@ -61,7 +62,17 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int 
                      info, trace_f, trace_c, ticks, batch, gws, JL)
 #define QMPC_LAUNCH_FUSED_J(V, R) \
   do { if (geom) QMPC_LAUNCH_FUSED(V, true, R); else QMPC_LAUNCH_FUSED(V, false, R); } while (0)
-  if (reference_mode) {
+#define QMPC_LAUNCH_FUSED_CJ(V) \
+  do { if (geom) QMPC_LAUNCH_FUSED4(V, true); else QMPC_LAUNCH_FUSED4(V, false); } while (0)
+#define QMPC_LAUNCH_FUSED4(V, J) \
+  hipLaunchKernelGGL((qmpc_loop_fused_kernel<V, J, false, true>), dim3((unsigned)batch), dim3(kWave), lds, s, P, LP, st, rec, \
+                     forces, info, trace_f, trace_c, ticks, batch, gws, JL)
+  if (convex) {
+    if (reference_mode) return hipErrorInvalidValue;
+    if (var == 2) QMPC_LAUNCH_FUSED_CJ(2);
+    else if (var == 1) QMPC_LAUNCH_FUSED_CJ(1);
+    else QMPC_LAUNCH_FUSED_CJ(0);
+  } else if (reference_mode) {
     if (var >= 1) QMPC_LAUNCH_FUSED_J(1, true);
     else QMPC_LAUNCH_FUSED_J(0, true);
   } else {
@@ -70,6 +81,8 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int 
     else QMPC_LAUNCH_FUSED_J(0, false);
   }
 #undef QMPC_LAUNCH_FUSED_J
+#undef QMPC_LAUNCH_FUSED_CJ
+#undef QMPC_LAUNCH_FUSED4
 #undef QMPC_LAUNCH_FUSED
   return hipGetLastError();
 }

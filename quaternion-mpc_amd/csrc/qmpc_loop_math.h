@@ -34,6 +34,19 @@ QMPC_HD void quat_to_rot(const double* q, double* R) {
   R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
 }
 
+// roll, pitch, yaw of q = (w, x, y, z): Utils::quat_to_euler (legged_ctrl/src/utils/Utils.cpp:7-33), fbk.torso_euler
+QMPC_HD void quat_to_euler(const double* q, double* e) {
+  QMPC_NO_CONTRACT
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  const double yy = y * y;
+  e[0] = atan2(2.0 * (w * x + y * z), 1.0 - 2.0 * (x * x + yy));
+  double t2 = 2.0 * (w * y - z * x);
+  t2 = t2 > 1.0 ? 1.0 : t2;
+  t2 = t2 < -1.0 ? -1.0 : t2;
+  e[1] = asin(t2);
+  e[2] = atan2(2.0 * (w * z + x * y), 1.0 - 2.0 * (yy + z * z));
+}
+
 // yaw-only rotation next to the full one (fbk.torso_rot_mat_z beside fbk.torso_rot_mat)
 QMPC_HD void rot_to_rot_z(const double* R, double* Rz) {
   const double yaw = atan2(R[3], R[0]);

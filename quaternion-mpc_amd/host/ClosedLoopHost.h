@@ -11,18 +11,44 @@
 #pragma once
 
 #include "../csrc/qmpc_loop_math.h"
+#include <type_traits>
+
+#include "ConvexMpcHip.h"
 #include "JointCommandsHip.h"
 #include "QuatMpcHip.h"
 #include "SwingTrajectoryHip.h"
 
 namespace legged {
 
+// what the test harness drives, whichever controller sits inside
 template <class State>
-class ClosedLoopHostT {
+class ClosedLoopHostBase {
  public:
+  virtual ~ClosedLoopHostBase() {}
+  virtual bool tick() = 0;
+  virtual void export_state(qmpc_loop_state* o) const = 0;
+  virtual void joint_commands(double* joint_pos_io, qmpc_joint_feedback* fb, qmpc_joint_command* cmd) = 0;
+  virtual qmpc_status device_status() const = 0;
+  State state;
+};
+
+// Mpc: QuatMpcHipT<State> (default) or ConvexMpcHipT<State> -- the two controllers share goal_update / foot_update /
+// grf_update, leg_FSM and the outputs the plant consumes (ctrl.optimized_input[0:12], body frame)
+template <class State, class Mpc = QuatMpcHipT<State>>
+class ClosedLoopHostT : public ClosedLoopHostBase<State> {
+ public:
+  using ClosedLoopHostBase<State>::state;
+  static constexpr bool kConvex = std::is_same<Mpc, ConvexMpcHipT<State>>::value;
   ClosedLoopHostT(const QmpcApi& api, const qmpc_loop_params& lp, const qmpc_loop_state& init, int horizon, int device,
                   int mode = QMPC_MODE_CONVERGED, int drop_ang_vel = 1)
       : lp_(lp) {
+    if (kConvex) {                     // gazebo_go1_convex_mpc.yaml: 5 ms, the Euler-angle state's weights, mu 0.6, fz_max 200
+      state.param.mpc_update_period = 5.0;
+      const double q[13] = {3.0, 3.0, 3.0, 1.0, 1.0, 20.0, 0.0, 0.0, 3.0, 2.0, 3.0, 2.0, 0.0};
+      for (int i = 0; i < 13; ++i) state.param.q_weights[i] = q[i];
+      state.param.mu = 0.6;
+      state.param.fz_max = 200.0;
+    }
     state.param.mpc_horizon = horizon;
     state.param.gait_freq = lp.gait_freq;
     for (int l = 0; l < NUM_LEG; ++l)
@@ -39,13 +65,12 @@ class ClosedLoopHostT {
     for (int a = 0; a < 3; ++a) state.ctrl.torso_lin_vel_d_rel[a] = init.lin_vel_d_rel[a];
     refresh_feedback();
     state.estimator_init = true;
-    mpc = new QuatMpcHipT<State>(state, api, device, mode, drop_ang_vel);      // takes torso_pos_d_world from the feedback (QuatMpc.cpp:13-20)
-    double I[9];
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) I[3 * r + c] = 1.2 * state.param.trunk_inertia(r, c);   // QuatMpc.cpp:182
-    qmpc_loop::inv3(I, Iinv_);
+    make_mpc(api, device, mode, drop_ang_vel);            // QuatMpc takes torso_pos_d_world from the feedback (QuatMpc.cpp:13-20)
+    if (kConvex) { state.joy.body_x = init.pos_d_world[0]; state.joy.body_y = init.pos_d_world[1]; }
+    qmpc_loop::inv3(mpc->params().inertia, Iinv_);          // the plant of the device loop uses the handle's mass / inertia
   }
-  ~ClosedLoopHostT() { delete mpc; }
+  ~ClosedLoopHostT() override { delete mpc; }
+  qmpc_status device_status() const override { return mpc->last_status(); }
 
   // what BaseInterface::fbk_update derives from the estimator for the fields the tick reads
   void refresh_feedback() {
@@ -68,9 +93,20 @@ class ClosedLoopHostT {
       }
       state.fbk.foot_contact_flag[l] = (feet_[3 * l + 2] <= lp_.contact_height) ? 1.0 : 0.0;
     }
+    // what ConvexMpc reads on top (BaseInterface.cpp:197-199,217-223)
+    double e[3];
+    qmpc_loop::quat_to_euler(&x_[3], e);
+    for (int a = 0; a < 3; ++a) {
+      state.fbk.torso_euler[a] = e[a];
+      state.fbk.torso_ang_vel_world[a] = R[3 * a] * x_[10] + R[3 * a + 1] * x_[11] + R[3 * a + 2] * x_[12];
+    }
+    for (int l = 0; l < NUM_LEG; ++l)
+      for (int a = 0; a < 3; ++a)
+        state.fbk.foot_pos_abs_com(a, l) = R[3 * a] * state.fbk.foot_pos_body(0, l) + R[3 * a + 1] * state.fbk.foot_pos_body(1, l) +
+                                           R[3 * a + 2] * state.fbk.foot_pos_body(2, l);
   }
 
-  bool tick() {
+  bool tick() override {
     refresh_feedback();
     raibert_foot_targets(state);
     mpc->goal_update(state);
@@ -78,7 +114,7 @@ class ClosedLoopHostT {
     const bool ok = mpc->grf_update(state);
     double u[12];
     for (int a = 0; a < 12; ++a) u[a] = state.ctrl.optimized_input[a];
-    qmpc_loop::plant_step(x_, u, feet_, NUM_LEG, state.param.robot_mass, Iinv_, lp_.dt);
+    qmpc_loop::plant_step(x_, u, feet_, NUM_LEG, mpc->params().mass, Iinv_, lp_.dt);
     if (state.ctrl.movement_mode != 0)
       for (int l = 0; l < NUM_LEG; ++l)
         if (!state.ctrl.plan_contacts[l])
@@ -91,7 +127,7 @@ class ClosedLoopHostT {
   // plant's feet (hip branch: joint_pos_io, the angles of the previous call; out of reach keeps them), measured
   // velocities = J^-1 R'(foot velocity - torso velocity), swing feet moving at their FSM target velocity; then
   // BaseInterface::tau_ctrl_update on that feedback.  Fills the records the device entry point produces.
-  void joint_commands(double* joint_pos_io, qmpc_joint_feedback* fb, qmpc_joint_command* cmd) {
+  void joint_commands(double* joint_pos_io, qmpc_joint_feedback* fb, qmpc_joint_command* cmd) override {
     refresh_feedback();
     double R[9];
     qmpc_loop::quat_to_rot(&x_[3], R);
@@ -131,7 +167,7 @@ class ClosedLoopHostT {
   }
 
   // the state in the device loop's record layout (filter internals are private to the host class: left zero)
-  void export_state(qmpc_loop_state* o) const {
+  void export_state(qmpc_loop_state* o) const override {
     std::memset(o, 0, sizeof *o);
     for (int a = 0; a < 3; ++a) { o->pos_world[a] = x_[a]; o->lin_vel_world[a] = x_[7 + a]; o->ang_vel_body[a] = x_[10 + a]; }
     for (int a = 0; a < 4; ++a) o->quat[a] = x_[3 + a];
@@ -140,7 +176,7 @@ class ClosedLoopHostT {
     o->joy[3] = state.joy.roll_rate; o->joy[4] = state.joy.pitch_rate; o->joy[5] = state.joy.yaw_rate;
     o->movement_mode = state.ctrl.movement_mode;
     o->sin_ang_vel = state.joy.sin_ang_vel ? 1.0 : 0.0;
-    o->attitude_traj_count = mpc->attitude_sweep_count();
+    o->attitude_traj_count = sweep_count();
     for (int a = 0; a < 3; ++a) { o->pos_d_world[a] = state.ctrl.torso_pos_d_world[a]; o->lin_vel_d_rel[a] = state.ctrl.torso_lin_vel_d_rel[a]; }
     o->pos_d_init = 1.0;
     o->quat_d[0] = state.ctrl.torso_quat_d.w(); o->quat_d[1] = state.ctrl.torso_quat_d.x();
@@ -173,10 +209,24 @@ class ClosedLoopHostT {
     o->tick = (double)ticks_;
   }
 
-  State state;
-  QuatMpcHipT<State>* mpc = nullptr;
+  Mpc* mpc = nullptr;
 
  private:
+  template <class M = Mpc>
+  typename std::enable_if<std::is_same<M, ConvexMpcHipT<State>>::value>::type make_mpc(const QmpcApi& api, int device, int, int) {
+    mpc = new Mpc(state, api, device);
+  }
+  template <class M = Mpc>
+  typename std::enable_if<!std::is_same<M, ConvexMpcHipT<State>>::value>::type make_mpc(const QmpcApi& api, int device, int mode,
+                                                                                       int drop_ang_vel) {
+    mpc = new Mpc(state, api, device, mode, drop_ang_vel);
+  }
+  template <class M = Mpc>
+  typename std::enable_if<std::is_same<M, ConvexMpcHipT<State>>::value, double>::type sweep_count() const { return 0.0; }
+  template <class M = Mpc>
+  typename std::enable_if<!std::is_same<M, ConvexMpcHipT<State>>::value, double>::type sweep_count() const {
+    return mpc->attitude_sweep_count();
+  }
   qmpc_loop_params lp_;
   JointCommandsHipT<State> joints_;
   double x_[13];

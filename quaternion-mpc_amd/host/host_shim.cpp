@@ -165,7 +165,7 @@ void qh_fake_script(const double* forces12, int call_status, int inst_status) {
 // ---- closed loop on the host: the parity reference of qmpc_loop_run (one instance) ----------------
 struct LoopHarness {
   Harness base;                      // owns the dlopen handle
-  legged::ClosedLoopHostT<LeggedStateLite>* loop = nullptr;
+  legged::ClosedLoopHostBase<LeggedStateLite>* loop = nullptr;
 };
 // lib_path NULL / "": the scripted test double (qh_fake_script) stands in for the device
 void* qh_loop_create_opts(const char* lib_path, int horizon, int mode, int drop_ang_vel, const qmpc_loop_params* lp,
@@ -183,13 +183,21 @@ void* qh_loop_create_opts(const char* lib_path, int horizon, int mode, int drop_
   h->loop = new legged::ClosedLoopHostT<LeggedStateLite>(api, *lp, *init, horizon, 0, mode, drop_ang_vel);
   return h;
 }
+// the sibling controller in the same loop: ConvexMpcHipT (gazebo_go1_convex_mpc.yaml values)
+void* qh_loop_create_convex(const char* lib_path, int horizon, const qmpc_loop_params* lp, const qmpc_loop_state* init) {
+  LoopHarness* h = new LoopHarness();
+  legged::QmpcApi api;
+  if (!(lib_path && lib_path[0]) || !bind_api(&h->base, lib_path, api)) { delete h; return nullptr; }
+  h->loop = new legged::ClosedLoopHostT<LeggedStateLite, legged::ConvexMpcHipT<LeggedStateLite>>(api, *lp, *init, horizon, 0);
+  return h;
+}
 void* qh_loop_create_mode(const char* lib_path, int horizon, int mode, const qmpc_loop_params* lp, const qmpc_loop_state* init) {
   return qh_loop_create_opts(lib_path, horizon, mode, 1, lp, init);
 }
 void* qh_loop_create(const char* lib_path, int horizon, const qmpc_loop_params* lp, const qmpc_loop_state* init) {
   return qh_loop_create_mode(lib_path, horizon, QMPC_MODE_CONVERGED, lp, init);
 }
-int qh_loop_device_status(void* p) { return (int)static_cast<LoopHarness*>(p)->loop->mpc->last_status(); }
+int qh_loop_device_status(void* p) { return (int)static_cast<LoopHarness*>(p)->loop->device_status(); }
 int qh_loop_tick(void* p) { return static_cast<LoopHarness*>(p)->loop->tick() ? 1 : 0; }
 // joy.{velx, vely, body_height, roll_rate, pitch_rate, yaw_rate} and ctrl.movement_mode from the next tick on
 void qh_loop_set_command(void* p, const double* joy, double movement_mode) {

@@ -13,12 +13,15 @@ from conftest import load_pkg  # noqa: E402
 pkg = load_pkg()
 robots, ticks, horizon = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0          # 0 converged, 1 reference (AL-iLQR, <= 10 iterations)
+convex = len(sys.argv) > 5 and sys.argv[5] == "convex"       # the sibling controller (ConvexMpc handle)
 lib = pkg.load_library()
 lp = pkg.default_loop_params(lib)
 rng = np.random.default_rng(5)
 cmds = np.zeros((robots, 7))
 cmds[:, 0] = rng.uniform(-0.5, 0.5, robots); cmds[:, 1] = rng.uniform(-0.2, 0.2, robots)
 cmds[:, 2] = rng.uniform(0.26, 0.32, robots); cmds[:, 5] = rng.uniform(-0.5, 0.5, robots)
+if convex:
+    cmds[:, 0] *= 0.6                        # ConvexMpc's gains (yaml) are tuned for gentler walking
 cmds[:, 6] = (rng.random(robots) < 0.85).astype(float)
 cmds[cmds[:, 6] == 0, :2] = 0.0
 cmds[cmds[:, 6] == 0, 5] = 0.0
@@ -26,7 +29,7 @@ stand = cmds.copy(); stand[:, 6] = 0.0
 st = pkg.loop_states(stand, lp, height=0.3, yaw=rng.uniform(-3, 3, robots), lib=lib)
 if robots > 2:
     st["quat"][2] = np.nan                   # a robot whose records are rejected every tick (QMPC_NAN_INPUT): it keeps ticking
-s = pkg.Solver(pkg.default_params(horizon, mode, lib), robots, device=0, lib=lib)
+s = pkg.Solver((pkg.default_convex_params if convex else pkg.default_params)(horizon, mode, lib), robots, device=0, lib=lib)
 st = s.loop_run(st, 6, lp)
 st["movement_mode"] = cmds[:, 6]
 st, tf, tc = s.loop_run(st, ticks, lp, trace=True)

@@ -883,10 +883,15 @@ def test_closed_loop_argument_checks_and_failed_instances(pkg, lib):
         s.loop_run(st0, 3, lp)
     assert e.value.code == pkg.BATCH_TOO_LARGE
     s.close()
-    sc = pkg.Solver(pkg.default_convex_params(20, pkg.MODE_CONVERGED, lib), 4, device=0, lib=lib)
+    sc = pkg.Solver(pkg.default_biped8_params(16, pkg.MODE_CONVERGED, lib), 4, device=0, lib=lib)
     with pytest.raises(pkg.QmpcError) as e:
-        sc.loop_run(st0, 3, lp)
+        sc.loop_run(st0, 3, lp)                       # the loop is QuatMpc's and ConvexMpc's: no 8-contact-point robot
     assert e.value.code == pkg.BAD_ARGUMENT
+    sc.close()
+    sc = pkg.Solver(pkg.default_convex_params(10, pkg.MODE_REFERENCE, lib), 4, device=0, lib=lib)
+    with pytest.raises(pkg.QmpcError) as e:
+        sc.loop_run(st0, 3, lp)                       # ConvexMpc's loop runs the converged mode only
+    assert e.value.code == pkg.UNSUPPORTED
     sc.close()
     s = pkg.Solver(pkg.default_params(10, pkg.MODE_CONVERGED, lib), 4, device=0, lib=lib)
     assert s.loop_run(st0, 0, lp).tobytes() == st0.tobytes()            # zero ticks: untouched
@@ -1068,6 +1073,56 @@ def test_attitude_sweep_closed_loop_matches_host_classes(pkg, lib):
     assert worst_f <= 1e-6
 
 
+def test_convex_mpc_closed_loop_matches_host_classes(pkg, lib):
+    """The sibling controller in the same device-resident loop: ConvexMpc (Euler-angle SRBD, world-frame forces;
+    ConvexMpc.cpp:41-79,92-118,156-167,186-196,200-222) -- its goal_update (velocity ramp, joystick position goal), the
+    feedback it reads (torso_euler, torso_ang_vel_world, foot_pos_abs_com), the shared gait FSM / Raibert targets, the
+    solve on a ConvexMpc handle and R' u into the plant -- against ConvexMpcHipT in host/ClosedLoopHost.h, tick for tick."""
+    import __graft_entry__ as g
+
+    host = C.CDLL(str(g.build_host()))
+    vp = C.c_void_p
+    host.qh_loop_create_convex.argtypes = [C.c_char_p, C.c_int, vp, vp]; host.qh_loop_create_convex.restype = vp
+    for f in ("qh_loop_tick", "qh_loop_destroy", "qh_loop_device_status"):
+        getattr(host, f).argtypes = [vp]
+    host.qh_loop_export.argtypes = [vp, vp]
+    host.qh_loop_set_command.argtypes = [vp, vp, C.c_double]
+    T0, T, N = 6, 120, 10
+    lp = pkg.default_loop_params(lib)
+    cmds = np.array(LOOP_COMMANDS[:5])
+    cmds[:, 3:5] = 0.0                        # this controller has no roll / pitch rate command
+    yaws = [0.0, 0.4, -1.0, 2.0, 0.7]
+    stand = cmds.copy(); stand[:, 6] = 0.0
+    st_init = pkg.loop_states(stand, lp, height=0.3, yaw=yaws, lib=lib)
+    B = len(st_init)
+    s = pkg.Solver(pkg.default_convex_params(N, pkg.MODE_CONVERGED, lib), B, device=0, lib=lib)
+    st0 = s.loop_run(st_init, T0, lp)
+    st0["movement_mode"] = cmds[:, 6]
+    st, tf, tc = s.loop_run(st0, T, lp, trace=True)
+    s.close()
+    assert (st["tick"] == T0 + T).all() and (st["status"] == 0).all()
+    worst_f = worst_x = 0.0
+    for i in range(B):
+        h = host.qh_loop_create_convex(str(pkg.LIB_PATH).encode(), N, C.addressof(lp), st_init[i:i + 1].ctypes.data)
+        assert h and host.qh_loop_device_status(h) == 0
+        e = np.zeros(1, dtype=pkg.LOOP_STATE_DTYPE)
+        for t in range(T0):
+            assert host.qh_loop_tick(h) == 1
+        host.qh_loop_set_command(h, np.ascontiguousarray(cmds[i, :6]).ctypes.data, float(cmds[i, 6]))
+        for t in range(T):
+            assert host.qh_loop_tick(h) == 1, (i, t)
+            host.qh_loop_export(h, e.ctypes.data)
+            assert np.array_equal(e[0]["contacts"], tc[t, i]), (i, t)
+            worst_f = max(worst_f, float(np.abs(e[0]["forces_body"] - tf[t, i]).max()))
+        for k in ("pos_world", "quat", "lin_vel_world", "ang_vel_body", "foot_pos_world", "lin_vel_d_rel", "foot_target_world"):
+            worst_x = max(worst_x, float(np.abs(st[i][k] - e[0][k]).max()))
+        host.qh_loop_destroy(h)
+    print(f"ConvexMpc closed loop, {B} robots x {T} ticks: worst force difference {worst_f:.2e} N, worst state difference {worst_x:.2e}")
+    assert worst_f <= 1e-6 and worst_x <= 1e-8
+    assert (np.abs(st["pos_world"][:, 2] - cmds[:, 2]) < 0.05).all()
+    assert st[1]["pos_world"][0] * np.cos(yaws[1]) + st[1]["pos_world"][1] * np.sin(yaws[1]) > 0.03      # it walks
+
+
 def test_reference_mode_closed_loop_matches_host_classes(pkg, lib):
     """The closed loop with the reference's OWN solver mode (AL-iLQR, <= 10 iterations, last iterate applied whatever its
     status, QuatMpc.cpp:21-26,256) -- i.e. what a robot running the reference controller would do -- on the device
@@ -1116,9 +1171,11 @@ def test_reference_mode_closed_loop_matches_host_classes(pkg, lib):
     assert st[1]["pos_world"][0] * np.cos(yaws[1]) + st[1]["pos_world"][1] * np.sin(yaws[1]) > 0.015
 
 
-@pytest.mark.parametrize("robots,ticks,horizon,mode", [(96, 90, 10, 0), (3000, 12, 10, 0), (40, 60, 20, 0), (64, 90, 10, 1)],
-                         ids=["96 robots N=10", "3000 robots (several rounds per SIMD)", "N=20", "reference mode"])
-def test_persistent_loop_kernel_equals_the_per_tick_sequence(robots, ticks, horizon, mode):
+@pytest.mark.parametrize("robots,ticks,horizon,mode,model",
+                         [(96, 90, 10, 0, "quat"), (3000, 12, 10, 0, "quat"), (40, 60, 20, 0, "quat"), (64, 90, 10, 1, "quat"),
+                          (64, 90, 10, 0, "convex")],
+                         ids=["96 robots N=10", "3000 robots (several rounds per SIMD)", "N=20", "reference mode", "ConvexMpc"])
+def test_persistent_loop_kernel_equals_the_per_tick_sequence(robots, ticks, horizon, mode, model):
     """qmpc_loop_run* has two launch forms: three kernels per tick (graph replay) and ONE persistent kernel in which a
     wave owns a robot for all ticks (the default up to 2048 robots: the per-tick tails of different robots average out,
     +28 % at 1024 robots, +51 % at N=20; profiles/r02_loop_bench.txt).  Same arithmetic in the same order: final
@@ -1131,7 +1188,7 @@ def test_persistent_loop_kernel_equals_the_per_tick_sequence(robots, ticks, hori
     out = {}
     for fused in ("0", "1"):
         env = dict(os.environ, QMPC_LOOP_FUSED=fused)
-        r = subprocess.run([sys.executable, str(worker), str(robots), str(ticks), str(horizon), str(mode)], env=env, capture_output=True,
+        r = subprocess.run([sys.executable, str(worker), str(robots), str(ticks), str(horizon), str(mode), model], env=env, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         out[fused] = [l for l in r.stdout.splitlines() if l.startswith("SHA")][0]
