@@ -1,8 +1,10 @@
 // qmpc_loop.hip -- device-resident closed loop around the MPC solve: the step before the
-// path (goal, gait FSM, swing quintic, Raibert footholds, record packing), the path (qmpc_solve_kernel) and a
-// single-rigid-body plant, chained per tick on one stream with every instance's state kept in HBM
-// (qmpc_loop_state, include/qmpc.h).  One thread per instance in the front / post kernels: they are a few hundred
-// flops of branchy scalar logic per tick, against ~10^6 for the solve.
+// path (goal, gait FSM, swing quintic, Raibert footholds, record packing), the path (the solve) and a
+// single-rigid-body plant, with every robot's state kept in HBM (qmpc_loop_state, include/qmpc.h).  Two launch forms
+// of the same per-robot functions (loop_front_one / loop_front_convex_one, the solve body, loop_post_one):
+//   per tick   front kernel -> qmpc_solve_kernel -> post kernel on one stream (one thread per robot in the front / post
+//              kernels: a few hundred flops of branchy scalar logic per tick, against ~10^6 for the solve);
+//   persistent qmpc_loop_fused_kernel, at the end of this file: a wave owns one robot for all ticks.
 //
 // Reference arithmetic mirrored here (legged_ctrl/):
 //   src/mpc/QuatMpc.cpp:68-107        goal_update              (host twin: host/QuatMpcHip.h)
@@ -12,6 +14,7 @@
 //   src/interfaces/BaseInterface.cpp:266-288  Raibert foothold targets
 //   include/utils/MovingWindowFilter.hpp:14-63  Neumaier moving average (host twin: host/MovingWindowFilter.h)
 //   src/mpc/QuatMpc.cpp:112-176,231-246,263-273  record packing, outputs
+//   src/mpc/ConvexMpc.cpp:51-79,92-118,156-167,186-196,200-222   the sibling controller's tick (host twin: host/ConvexMpcHip.h)
 // Floating-point contraction is switched off in the controller-side functions: the contact schedule must be
 // bit-exact against the host classes (compare-and-add state machine), and g++ does not fuse on the host.
 #pragma once
