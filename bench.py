@@ -413,11 +413,33 @@ def main():
             sl.loop_run_device(B, d_st.data_ptr(), ticks, lp, stream=stream.cuda_stream)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            # the same robots once more with the loop's own options: warm start + a low initial barrier (same forces, about
+            # half the iterations)
+            pw = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
+            pw.drop_ang_vel = 0
+            pw.ipm_mu0 = 1e-6
+            lpw = pkg.default_loop_params(lib)
+            lpw.warm_start = 1.0
+            sw = pkg.Solver(pw, B, device=local, lib=lib)
+            d_sw = torch.from_numpy(st.view(np.uint8).reshape(B, -1).copy()).cuda()
+            sw.loop_run_device(B, d_sw.data_ptr(), 40, lpw, stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            t0w = time.perf_counter()
+            sw.loop_run_device(B, d_sw.data_ptr(), ticks, lpw, stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            dtw = time.perf_counter() - t0w
+            finw = np.ascontiguousarray(d_sw.cpu().numpy()).view(pkg.LOOP_STATE_DTYPE).reshape(B)
+            sw.close()
             sl.close()
             fin = np.ascontiguousarray(d_st.cpu().numpy()).view(pkg.LOOP_STATE_DTYPE).reshape(B)
             out["closed_loop"] = {"value": B * ticks / dt, "unit": "robot-ticks/s", "ticks": ticks, "robots": B,
                                   "ms_per_tick": 1e3 * dt / ticks, "solver_ok": int((fin["status"] == 0).sum()),
                                   "mean_iterations": float(fin["iterations"].mean()),
+                                  "warm_start": {"value": B * ticks / dtw, "unit": "robot-ticks/s", "ms_per_tick": 1e3 * dtw / ticks,
+                                                 "solver_ok": int((finw["status"] == 0).sum()),
+                                                 "mean_iterations": float(finw["iterations"].mean()),
+                                                 "position_difference_to_cold_start_m": float(np.abs(finw["pos_world"] - fin["pos_world"]).max()),
+                                                 "note": "qmpc_loop_params.warm_start = 1, params.ipm_mu0 = 1e-6"},
                                   "launch_form": ("persistent wave-per-robot kernel" if B <= 2048 and os.environ.get("QMPC_LOOP_FUSED") != "0"
                                                   else "three kernels per tick (graph replay)"),
                                   "note": "secondary: qmpc_loop_run_device (goal + gait FSM + swing quintic + Raibert + "

@@ -392,6 +392,12 @@ typedef struct qmpc_loop_params {
   double default_foot_pos_rel[12];  /* param.default_foot_pos_rel, [3*leg+axis]         */
   double dt;                        /* tick: the reference's hard-wired 5 ms (QuatMpc.cpp:97-98,132,294) */
   double contact_height;            /* plant: foot_contact_flag = foot z <= this [m]    */
+  double warm_start;                /* 0 (default): every solve starts from u_ref like the reference (QuatMpc.cpp:253).
+                                       != 0: from the second tick of a call on, the solve starts from the previous
+                                       tick's solution shifted by one knot (swing legs 0, a leg that has just landed
+                                       from u_ref); converged mode; the call then always runs the persistent kernel,
+                                       whose LDS keeps that solution.  Same KKT points, about half the iterations when
+                                       combined with a low params.ipm_mu0 (1e-6): DESIGN.md 3e */
 } qmpc_loop_params;
 void qmpc_default_loop_params(qmpc_loop_params* p);
 /* Host-side initialiser (no GPU involved): robot standing at `height` over its default footholds, at rest,

@@ -165,7 +165,7 @@ class LoopParams(C.Structure):
     """struct qmpc_loop_params."""
 
     _fields_ = [("gait_freq", C.c_double), ("default_foot_pos_rel", C.c_double * 12), ("dt", C.c_double),
-                ("contact_height", C.c_double)]
+                ("contact_height", C.c_double), ("warm_start", C.c_double)]
 
 
 # struct qmpc_info: 2 x int32 + 4 doubles = 40 B

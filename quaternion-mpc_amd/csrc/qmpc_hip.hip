@@ -891,7 +891,8 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   // tails, and the fused kernel pays for its register pressure).
   // QMPC_LOOP_FUSED=0 / 1 forces one or the other (experiments, tests).
   static const int fused_env = [] { const char* e = std::getenv("QMPC_LOOP_FUSED"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-  const bool fused = fused_env >= 0 ? fused_env == 1 : batch <= 2048;      // measured: +25 % (256), +28 % (1024), +8 % (2048), -3 % (4096)
+  const bool warm = lp->warm_start != 0.0 && h->params.mode == QMPC_MODE_CONVERGED;   // needs the persistent kernel's LDS
+  const bool fused = warm || (fused_env >= 0 ? fused_env == 1 : batch <= 2048);      // measured: +25 % (256), +28 % (1024), +8 % (2048), -3 % (4096)
   if (fused) {
     const bool ref = h->params.mode == QMPC_MODE_REFERENCE;
     // the reference-mode kernels exist with everything in LDS (0) and with the gains in the workspace (1): launch_solve's rule

@@ -964,6 +964,7 @@ __global__ __launch_bounds__(64, QMPC_SOLVE_WAVES(MD, VAR)) void qmpc_solve_kern
   const int b = blockIdx.x;
   if (b >= batch) return;
   const int lane = threadIdx.x;
+  constexpr int warm_t = 0;            // a plain solve always starts from u_ref (QuatMpc.cpp:253)
 #include "qmpc_solve_body.inc"
 }
 

@@ -429,6 +429,7 @@ __global__ __launch_bounds__(64, REF ? 1 : QMPC_SOLVE_WAVES(QuatModel, VAR)) voi
   const qmpc_input* in_ = rec;
   double *traj_u = nullptr, *traj_x = nullptr;
   long long* prof_out = nullptr;
+  bool prev_ok = false;
   for (int t = 0; t < ticks; ++t) {
     if (lane == 0) {
       if (CONVEX) loop_front_convex_one(LP, st[b], reinterpret_cast<qmpc_convex_input*>(rec)[b]);
@@ -441,10 +442,12 @@ __global__ __launch_bounds__(64, REF ? 1 : QMPC_SOLVE_WAVES(QuatModel, VAR)) voi
       }();
     } else {
       [&]() {
+        const int warm_t = (LP.warm_start != 0.0 && prev_ok) ? t : 0;   // t > 0 and the last solve left a usable U in LDS
 #include "qmpc_solve_body.inc"
       }();
     }
     __syncthreads();
+    prev_ok = info[b].status == QMPC_OK || info[b].status == QMPC_MAX_ITER;   // uniform: every lane reads the same word
     if (lane == 0) {
       const size_t slot = (size_t)t * batch + b;
       loop_post_one<CONVEX>(P, LP, st[b], forces + 12 * (size_t)b, info[b], trace_f ? trace_f + 12 * slot : nullptr,

@@ -1123,6 +1123,55 @@ def test_convex_mpc_closed_loop_matches_host_classes(pkg, lib):
     assert st[1]["pos_world"][0] * np.cos(yaws[1]) + st[1]["pos_world"][1] * np.sin(yaws[1]) > 0.03      # it walks
 
 
+@pytest.mark.parametrize("model", ["quat", "convex"])
+def test_warm_started_closed_loop_reaches_the_same_forces(pkg, lib, model):
+    """qmpc_loop_params.warm_start: from the second tick of a call on, the solve starts from the previous tick's
+    solution (shifted by a knot, kept in the persistent kernel's LDS) instead of u_ref.  A different starting point of
+    the SAME problem: every tick must land on the same forces as the cold-started loop (which is checked against the host
+    classes) -- to the solver's tolerance, tick after tick, through swing / stance changes -- in about half the
+    iterations once the initial barrier is lowered with it."""
+    lp = pkg.default_loop_params(lib)
+    rng = np.random.default_rng(17)
+    B, T = 48, 300
+    cmds = np.zeros((B, 7))
+    k = 0.6 if model == "convex" else 1.0
+    cmds[:, 0] = k * rng.uniform(-0.5, 0.5, B); cmds[:, 1] = rng.uniform(-0.2, 0.2, B); cmds[:, 2] = rng.uniform(0.26, 0.32, B)
+    cmds[:, 5] = rng.uniform(-0.5, 0.5, B); cmds[:, 6] = (rng.random(B) < 0.85).astype(float)
+    cmds[cmds[:, 6] == 0, :2] = 0.0
+    cmds[cmds[:, 6] == 0, 5] = 0.0
+    stand = cmds.copy(); stand[:, 6] = 0.0
+    st_init = pkg.loop_states(stand, lp, height=0.3, yaw=rng.uniform(-3, 3, B), lib=lib)
+    runs = {}
+    for name, warm, mu0 in (("cold", 0.0, None), ("warm", 1.0, None), ("warm, mu0 = 1e-6", 1.0, 1e-6)):
+        p = (pkg.default_convex_params if model == "convex" else pkg.default_params)(10, pkg.MODE_CONVERGED, lib)
+        p.drop_ang_vel = 0
+        if mu0:
+            p.ipm_mu0 = mu0
+        lpw = pkg.default_loop_params(lib)
+        lpw.warm_start = warm
+        s = pkg.Solver(p, B, device=0, lib=lib)
+        st = s.loop_run(st_init, 8, lpw)
+        st["movement_mode"] = cmds[:, 6]
+        it = []
+        fs, cs = [], []
+        for seg in range(T // 50):                     # iteration counts along the way (the last tick of every segment)
+            st, tf, tc = s.loop_run(st, 50, lpw, trace=True)
+            fs.append(tf); cs.append(tc); it.append(st["iterations"].copy())
+            assert (st["status"] == 0).all(), (name, seg)
+        s.close()
+        runs[name] = (np.concatenate(fs), np.concatenate(cs), np.mean(it), st)
+    f0, c0, it0, st0 = runs["cold"]
+    for name in ("warm", "warm, mu0 = 1e-6"):
+        f1, c1, it1, st1 = runs[name]
+        assert np.array_equal(c0, c1), name                              # the same contact schedule
+        d = float(np.abs(f1 - f0).max())
+        print(f"{model}: {name}: worst force difference to the cold-started loop over {T} ticks {d:.2e} N, "
+              f"mean iterations {it1:.2f} (cold {it0:.2f})")
+        assert d < 1e-5, (name, d)
+        assert np.abs(st1["pos_world"] - st0["pos_world"]).max() < 1e-7
+    assert runs["warm, mu0 = 1e-6"][2] < 0.7 * it0
+
+
 def test_reference_mode_closed_loop_matches_host_classes(pkg, lib):
     """The closed loop with the reference's OWN solver mode (AL-iLQR, <= 10 iterations, last iterate applied whatever its
     status, QuatMpc.cpp:21-26,256) -- i.e. what a robot running the reference controller would do -- on the device

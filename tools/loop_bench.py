@@ -21,11 +21,13 @@ ap.add_argument("--robots", type=int, default=1024)
 ap.add_argument("--ticks", type=int, default=200)
 ap.add_argument("--horizon", type=int, default=10)
 ap.add_argument("--mu0", type=float, default=0.0, help="initial barrier parameter (0: the default of qmpc_default_params, 1e-2)")
+ap.add_argument("--warm", action="store_true", help="qmpc_loop_params.warm_start = 1")
 ap.add_argument("--quirk", action="store_true", help="params.drop_ang_vel = 1: the reference's x_init without angular velocity")
 ap.add_argument("--mode", type=int, default=0, help="0 converged, 1 reference (AL-iLQR, <= 10 iterations)")
 a = ap.parse_args()
 lib = pkg.load_library()
 lp = pkg.default_loop_params(lib)
+lp.warm_start = 1.0 if a.warm else 0.0
 rng = np.random.default_rng(11)
 B = a.robots
 cmds = np.zeros((B, 7))
@@ -52,7 +54,7 @@ s.wait()
 dt = time.perf_counter() - t0
 out = d_st.cpu().numpy().view(pkg.LOOP_STATE_DTYPE).reshape(B)
 import os
-print(f"closed loop{' (reference mode)' if a.mode else ''}, {B} robots with random commands, {a.ticks} ticks, N={a.horizon}{f', mu0={a.mu0:g}' if a.mu0 > 0 else ''}{', drop_ang_vel=1' if a.quirk else ''}, "
+print(f"closed loop{' (reference mode)' if a.mode else ''}, {B} robots with random commands, {a.ticks} ticks, N={a.horizon}{f', mu0={a.mu0:g}' if a.mu0 > 0 else ''}{', drop_ang_vel=1' if a.quirk else ''}{', warm start' if a.warm else ''}, "
       f"{ {'0': 'per-tick launches (QMPC_LOOP_FUSED=0)', '1': 'persistent kernel (QMPC_LOOP_FUSED=1)'}.get(os.environ.get('QMPC_LOOP_FUSED'), 'library default') }: {dt * 1e3 / a.ticks:.3f} ms per tick, "
       f"{B * a.ticks / dt:.4g} robot-ticks/s; last-tick status != OK {int((out['status'] != 0).sum())}, mean iterations "
       f"{out['iterations'].mean():.2f} (max {int(out['iterations'].max())}); checksum {float(out['pos_world'].sum()):.12f}")
