@@ -21,13 +21,13 @@ ap.add_argument("--robots", type=int, default=1024)
 ap.add_argument("--ticks", type=int, default=200)
 ap.add_argument("--horizon", type=int, default=10)
 ap.add_argument("--mu0", type=float, default=0.0, help="initial barrier parameter (0: the default of qmpc_default_params, 1e-2)")
-ap.add_argument("--warm", action="store_true", help="qmpc_loop_params.warm_start = 1")
+ap.add_argument("--warm", type=int, default=0, nargs="?", const=1, help="qmpc_loop_params.warm_start")
 ap.add_argument("--quirk", action="store_true", help="params.drop_ang_vel = 1: the reference's x_init without angular velocity")
 ap.add_argument("--mode", type=int, default=0, help="0 converged, 1 reference (AL-iLQR, <= 10 iterations)")
 a = ap.parse_args()
 lib = pkg.load_library()
 lp = pkg.default_loop_params(lib)
-lp.warm_start = 1.0 if a.warm else 0.0
+lp.warm_start = float(a.warm)
 rng = np.random.default_rng(11)
 B = a.robots
 cmds = np.zeros((B, 7))
