@@ -217,6 +217,17 @@ qmpc_status qmpc_solve_traj(qmpc_handle* h, int32_t batch, const qmpc_input* in,
                             double* forces_body, qmpc_info* info,
                             double* traj_u, double* traj_x);
 
+/* Warm-started solve (QuatMpc handle, converged mode): every instance starts from u_init [batch][N][12] -- the caller's
+ * previous solution of the same robot, e.g. the traj_u of last tick's call; it is shifted by one knot inside, swing legs
+ * are pinned to 0 and a leg that has just landed starts from u_ref -- instead of u_ref (QuatMpc.cpp:253).  u_init NULL =
+ * a cold solve.  traj_u [batch][N][12] (may be NULL; may be the same buffer as u_init) receives the new solution.  The
+ * KKT point is the one qmpc_solve finds; with params.ipm_mu0 lowered to 1e-6 it takes about half the iterations for a
+ * robot in its gait.  Host buffers / device buffers (stream-ordered). */
+qmpc_status qmpc_solve_warm(qmpc_handle* h, int32_t batch, const qmpc_input* in, const double* u_init,
+                            double* forces_body, qmpc_info* info, double* traj_u);
+qmpc_status qmpc_solve_warm_device(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, const double* d_u_init,
+                                   double* d_forces_body, qmpc_info* d_info, double* d_traj_u, void* stream);
+
 /* Stream-ordered, DEVICE buffers (inputs already resident in HBM).  `stream`
  * is a hipStream_t passed as void* (NULL = the handle's own stream).  Nothing
  * is synchronised; pair with qmpc_wait or your own stream sync. */

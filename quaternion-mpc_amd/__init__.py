@@ -277,6 +277,10 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.qmpc_loop_run_joint_device.restype = i32
     lib.qmpc_loop_joint_commands.argtypes = [vp, C.POINTER(LegGeometry), i32, vp, vp, vp, vp]
     lib.qmpc_loop_joint_commands.restype = i32
+    lib.qmpc_solve_warm.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    lib.qmpc_solve_warm.restype = i32
+    lib.qmpc_solve_warm_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+    lib.qmpc_solve_warm_device.restype = i32
     lib.qmpc_loop_joint_init.argtypes = [vp, i32]
     lib.qmpc_loop_joint_init.restype = None
     lib.qmpc_default_biped8_params.argtypes = [C.POINTER(Params), i32, i32]
@@ -362,6 +366,8 @@ EXPORTED_SYMBOLS = (
     "qmpc_loop_joint_init",
     "qmpc_loop_run_joint_device",
     "qmpc_loop_joint_commands",
+    "qmpc_solve_warm",
+    "qmpc_solve_warm_device",
 )
 
 
@@ -481,6 +487,19 @@ class Solver:
         if st != OK:
             raise QmpcError(st, "qmpc_solve")
         return forces, info
+
+    def solve_warm(self, inputs: np.ndarray, u_init: np.ndarray | None = None):
+        """Warm-started solve: (forces [B,12], info, traj_u [B,N,12]); u_init = a previous traj_u (None: cold)."""
+        inputs = np.ascontiguousarray(inputs, dtype=INPUT_DTYPE)
+        B, N = inputs.shape[0], self.params.horizon
+        forces = np.zeros((B, NU))
+        info = np.zeros(B, dtype=INFO_DTYPE)
+        tu = np.zeros((B, N, NU))
+        ui = None if u_init is None else np.ascontiguousarray(u_init, dtype=np.float64).reshape(B, N, NU)
+        st = self.lib.qmpc_solve_warm(self._h, B, _ptr(inputs), _ptr(ui), _ptr(forces), _ptr(info), _ptr(tu))
+        if st != OK:
+            raise QmpcError(st, "qmpc_solve_warm")
+        return forces, info, tu
 
     def solve_device(self, batch: int, d_in: int, d_forces: int, d_info: int, stream: int = 0):
         """Device pointers (ints), stream-ordered, no synchronisation."""

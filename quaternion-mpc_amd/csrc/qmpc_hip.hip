@@ -29,6 +29,10 @@ hipError_t qmpc_fused_launch(int var, int reference_mode, int convex, int batch,
                              qmpc_info* info, double* trace_f, double* trace_c, int ticks, double* gws,
                              const qmpc_leg_geometry* geom, double* joint_pos, qmpc_joint_command* cmd,
                              qmpc_joint_command* trace_cmd);
+hipError_t qmpc_warm_set_lds(int bytes);
+hipError_t qmpc_warm_launch(int var, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
+                            const qmpc_input* in, const double* u_init, double* forces, qmpc_info* info, double* traj_u,
+                            double* gws);
 
 struct qmpc_handle {
   qmpc_params params;
@@ -257,6 +261,7 @@ static qmpc_status create_resources(qmpc_handle* h, int N, int nl, int nu) {
   }
   if (params->model != QMPC_MODEL_QUAT8)
     for (int v = 0; v < 3; ++v) HIP_TRY(qmpc_fused_set_lds(v, 160 * 1024));     // the closed loop's persistent kernels
+  if (params->model == QMPC_MODEL_QUAT) HIP_TRY(qmpc_warm_set_lds(160 * 1024));
   if (params->mode == QMPC_MODE_REFERENCE) {
     if (params->model == QMPC_MODEL_QUAT8) {
       QMPC_SET_LDS((qmpc_ref_kernel<Quat8Model, 1>), h->lds_bytes_g);     // never everything in LDS
@@ -475,6 +480,45 @@ static qmpc_status solve_host(qmpc_handle* h, int32_t batch, const qmpc_input* i
   if (traj_u) HIP_TRY(hipMemcpyAsync(traj_u, h->d_traj_u, sizeof(double) * nu * N * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   if (traj_x) HIP_TRY(hipMemcpyAsync(traj_x, h->d_traj_x, sizeof(double) * nx * (N + 1) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   if (blocking) HIP_TRY(hipStreamSynchronize(h->stream));
+  return QMPC_OK;
+}
+
+// ---- warm-started solve (converged mode, QuatMpc): every instance starts from u_init shifted by one knot ----------------
+qmpc_status qmpc_solve_warm_device(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, const double* d_u_init,
+                                   double* d_forces_body, qmpc_info* d_info, double* d_traj_u, void* stream) {
+  if (!h || batch < 0 || (batch > 0 && (!d_in || !d_forces_body))) return QMPC_BAD_ARGUMENT;
+  if (h->params.model != QMPC_MODEL_QUAT || h->params.mode != QMPC_MODE_CONVERGED) return QMPC_BAD_ARGUMENT;
+  if (batch == 0) return QMPC_OK;
+  if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
+  HIP_TRY(hipSetDevice(h->device));
+  const int var = pick_variant(h, batch);
+  const size_t lds = var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes);
+  HIP_TRY(qmpc_warm_launch(var, (int)batch, lds, stream ? (hipStream_t)stream : h->stream, &h->dev, sizeof h->dev, d_in, d_u_init,
+                           d_forces_body, d_info, d_traj_u, var >= 1 ? h->d_gws : nullptr));
+  return QMPC_OK;
+}
+
+qmpc_status qmpc_solve_warm(qmpc_handle* h, int32_t batch, const qmpc_input* in, const double* u_init, double* forces_body,
+                            qmpc_info* info, double* traj_u) {
+  if (!h || batch < 0 || (batch > 0 && (!in || !forces_body))) return QMPC_BAD_ARGUMENT;
+  if (h->params.model != QMPC_MODEL_QUAT || h->params.mode != QMPC_MODE_CONVERGED) return QMPC_BAD_ARGUMENT;
+  if (batch == 0) return QMPC_OK;
+  if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
+  HIP_TRY(hipSetDevice(h->device));
+  const int N = h->params.horizon;
+  const size_t nu = sizeof(double) * 12 * N * (size_t)batch;
+  // the device trajectory buffer doubles as the staging of u_init (read before it is overwritten: one wave per instance
+  // loads its slice into LDS first)
+  if (!h->d_traj_u) HIP_TRY(hipMalloc(&h->d_traj_u, sizeof(double) * 12 * N * (size_t)h->max_batch));
+  HIP_TRY(hipMemcpyAsync(h->d_in, in, sizeof(qmpc_input) * (size_t)batch, hipMemcpyHostToDevice, h->stream));
+  if (u_init) HIP_TRY(hipMemcpyAsync(h->d_traj_u, u_init, nu, hipMemcpyHostToDevice, h->stream));
+  const qmpc_status st = qmpc_solve_warm_device(h, batch, h->d_in, u_init ? h->d_traj_u : nullptr, h->d_forces, h->d_info,
+                                                h->d_traj_u, h->stream);
+  if (st != QMPC_OK) return st;
+  HIP_TRY(hipMemcpyAsync(forces_body, h->d_forces, sizeof(double) * 12 * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+  if (info) HIP_TRY(hipMemcpyAsync(info, h->d_info, sizeof(qmpc_info) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+  if (traj_u) HIP_TRY(hipMemcpyAsync(traj_u, h->d_traj_u, nu, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return QMPC_OK;
 }
 

@@ -463,6 +463,30 @@ __global__ __launch_bounds__(64, REF ? 1 : QMPC_SOLVE_WAVES(QuatModel, VAR)) voi
   }
 }
 
+
+// ---- a single warm-started solve (qmpc_solve_warm*): the drop-in class's per-tick call ---------------------------------
+// Same body; the start is u_init (the caller's previous solution of the same robot, e.g. last tick's traj_u) shifted by
+// one knot instead of u_ref.  u_init == nullptr: a plain cold solve.  In this translation unit for the reason given above.
+template <int VAR>
+__global__ __launch_bounds__(64, QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_solve_warm_kernel(
+    DevParams P, const qmpc_input* __restrict__ in_, const double* __restrict__ u_init, double* __restrict__ forces,
+    qmpc_info* __restrict__ info, double* __restrict__ traj_u, int batch, double* __restrict__ gws) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int b = blockIdx.x;
+  if (b >= batch) return;
+  const int lane = threadIdx.x;
+  typedef QuatModel MD;
+  constexpr bool PROF = false;
+  double* traj_x = nullptr;
+  long long* prof_out = nullptr;
+  const int warm_t = u_init ? 1 : 0;
+  if (u_init) {
+    const Layout Lw = make_layout(P.N, VAR >= 1, MD::NL, VAR == 2);
+    for (int i = lane; i < P.N * 12; i += kWave) sm[Lw.U + i] = u_init[(size_t)b * P.N * 12 + i];
+    __syncthreads();
+  }
+#include "qmpc_solve_body.inc"
+}
 #endif
 
 }  // namespace qmpc

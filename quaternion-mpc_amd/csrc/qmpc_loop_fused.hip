@@ -86,3 +86,26 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int 
 #undef QMPC_LAUNCH_FUSED
   return hipGetLastError();
 }
+
+__attribute__((visibility("hidden"))) hipError_t qmpc_warm_set_lds(int bytes) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_warm_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_warm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_warm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  return e;
+}
+
+__attribute__((visibility("hidden"))) hipError_t qmpc_warm_launch(int var, int batch, size_t lds, hipStream_t s, const void* dev_params,
+                                                                  size_t dev_params_size, const qmpc_input* in, const double* u_init,
+                                                                  double* forces, qmpc_info* info, double* traj_u, double* gws) {
+  if (dev_params_size != sizeof(DevParams)) return hipErrorInvalidValue;
+  DevParams P;
+  std::memcpy(&P, dev_params, sizeof P);
+#define QMPC_LAUNCH_WARM(V) \
+  hipLaunchKernelGGL(qmpc_solve_warm_kernel<V>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in, u_init, forces, info, traj_u, \
+                     batch, gws)
+  if (var == 2) QMPC_LAUNCH_WARM(2);
+  else if (var == 1) QMPC_LAUNCH_WARM(1);
+  else QMPC_LAUNCH_WARM(0);
+#undef QMPC_LAUNCH_WARM
+  return hipGetLastError();
+}

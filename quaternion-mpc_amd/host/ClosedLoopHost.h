@@ -29,6 +29,7 @@ class ClosedLoopHostBase {
   virtual void export_state(qmpc_loop_state* o) const = 0;
   virtual void joint_commands(double* joint_pos_io, qmpc_joint_feedback* fb, qmpc_joint_command* cmd) = 0;
   virtual qmpc_status device_status() const = 0;
+  virtual void set_warm_start(bool on) = 0;
   State state;
 };
 
@@ -71,6 +72,7 @@ class ClosedLoopHostT : public ClosedLoopHostBase<State> {
   }
   ~ClosedLoopHostT() override { delete mpc; }
   qmpc_status device_status() const override { return mpc->last_status(); }
+  void set_warm_start(bool on) override { warm(on); }
 
   // what BaseInterface::fbk_update derives from the estimator for the fields the tick reads
   void refresh_feedback() {
@@ -221,6 +223,10 @@ class ClosedLoopHostT : public ClosedLoopHostBase<State> {
                                                                                        int drop_ang_vel) {
     mpc = new Mpc(state, api, device, mode, drop_ang_vel);
   }
+  template <class M = Mpc>
+  typename std::enable_if<std::is_same<M, ConvexMpcHipT<State>>::value>::type warm(bool) {}
+  template <class M = Mpc>
+  typename std::enable_if<!std::is_same<M, ConvexMpcHipT<State>>::value>::type warm(bool on) { mpc->set_warm_start(on); }
   template <class M = Mpc>
   typename std::enable_if<std::is_same<M, ConvexMpcHipT<State>>::value, double>::type sweep_count() const { return 0.0; }
   template <class M = Mpc>

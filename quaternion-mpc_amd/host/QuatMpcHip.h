@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <vector>
 
 #include "../../include/qmpc.h"
 #include "LeggedContactFSMHip.h"
@@ -32,6 +33,8 @@ struct QmpcApi {
   qmpc_status (*create)(const qmpc_params*, int32_t, int32_t, qmpc_handle**) = nullptr;
   qmpc_status (*solve)(qmpc_handle*, int32_t, const qmpc_input*, double*, qmpc_info*) = nullptr;
   void (*destroy)(qmpc_handle*) = nullptr;
+  // optional: the warm-started solve (QuatMpcHipT::set_warm_start)
+  qmpc_status (*solve_warm)(qmpc_handle*, int32_t, const qmpc_input*, const double*, double*, qmpc_info*, double*) = nullptr;
   // ConvexMpc entry points (only ConvexMpcHipT needs them)
   void (*default_convex_params)(qmpc_params*, int32_t, int32_t) = nullptr;
   qmpc_status (*convex_solve)(qmpc_handle*, int32_t, const qmpc_convex_input*, double*, qmpc_info*) = nullptr;
@@ -229,7 +232,15 @@ class QuatMpcHipT : public LeggedMpcHipT<State> {
     double u[12] = {0};
     qmpc_info info;
     info.status = QMPC_NO_DEVICE;
-    last_status_ = handle_ ? api_.solve(handle_, 1, &in, u, &info) : QMPC_NO_DEVICE;
+    if (warm_start_ && api_.solve_warm && handle_) {
+      // start from last tick's solution (shifted by a knot inside the library) instead of u_ref: same KKT point, about
+      // half the iterations with a low params.ipm_mu0; not what the reference does (QuatMpc.cpp:253), hence opt-in
+      if (u_prev_.size() != (size_t)(12 * horizon)) u_prev_.assign((size_t)(12 * horizon), 0.0);
+      last_status_ = api_.solve_warm(handle_, 1, &in, have_prev_ ? u_prev_.data() : nullptr, u, &info, u_prev_.data());
+      have_prev_ = last_status_ == QMPC_OK && (info.status == QMPC_OK || info.status == QMPC_MAX_ITER);
+    } else {
+      last_status_ = handle_ ? api_.solve(handle_, 1, &in, u, &info) : QMPC_NO_DEVICE;
+    }
     last_info_ = info;
     const auto t_end = std::chrono::high_resolution_clock::now();
     state.fbk.mpc_time = std::chrono::duration<double, std::milli>(t_end - t_start).count();   // :257-261
@@ -270,6 +281,8 @@ class QuatMpcHipT : public LeggedMpcHipT<State> {
   bool terrain_update(State&) override { return true; }   // commented out upstream (:307-338)
 
   qmpc_status last_status() const { return last_status_; }
+  // warm-started solves from now on (needs QmpcApi::solve_warm); false drops the kept solution
+  void set_warm_start(bool on) { warm_start_ = on; have_prev_ = false; }
   double attitude_sweep_count() const { return attitude_traj_count; }   // ticks spent in the sin_ang_vel test mode
   const qmpc_info& last_info() const { return last_info_; }
   const qmpc_params& params() const { return params_; }
@@ -288,6 +301,8 @@ class QuatMpcHipT : public LeggedMpcHipT<State> {
   double torso_lin_vel_d_body_filtered[3] = {0, 0, 0};
   double torso_pos_d_body_filtered[3] = {0, 0, 0};
   double attitude_traj_count = 0;
+  bool warm_start_ = false, have_prev_ = false;
+  std::vector<double> u_prev_;
   double h = 10.0;
   int horizon = 20;
 };

@@ -127,6 +127,7 @@ bool bind_api(Harness* h, const char* lib_path, legged::QmpcApi& api) {
     api.create = reinterpret_cast<decltype(api.create)>(dlsym(h->dl, "qmpc_create"));
     api.solve = reinterpret_cast<decltype(api.solve)>(dlsym(h->dl, "qmpc_solve"));
     api.destroy = reinterpret_cast<decltype(api.destroy)>(dlsym(h->dl, "qmpc_destroy"));
+    api.solve_warm = reinterpret_cast<decltype(api.solve_warm)>(dlsym(h->dl, "qmpc_solve_warm"));
     api.default_convex_params =
         reinterpret_cast<decltype(api.default_convex_params)>(dlsym(h->dl, "qmpc_default_convex_params"));
     api.convex_solve = reinterpret_cast<decltype(api.convex_solve)>(dlsym(h->dl, "qmpc_convex_solve"));
@@ -245,6 +246,7 @@ void qh_leg_inverse(int batch, const double* foot_pos_body, const double* cur_jo
   for (size_t t = 0; t < (size_t)batch * 4; ++t)
     qmpc_joint::leg_inverse(&foot_pos_body[3 * t], cur_joint_pos[3 * t], jc.geom.rho_fix[t & 3], &joint_pos[3 * t]);
 }
+void qh_loop_set_warm_start(void* p, int on) { static_cast<LoopHarness*>(p)->loop->set_warm_start(on != 0); }
 void qh_loop_set_sin_ang_vel(void* p, int on) { static_cast<LoopHarness*>(p)->loop->state.joy.sin_ang_vel = on != 0; }
 void qh_loop_export(void* p, qmpc_loop_state* out) { static_cast<LoopHarness*>(p)->loop->export_state(out); }
 void qh_loop_destroy(void* p) {

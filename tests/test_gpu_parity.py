@@ -1172,6 +1172,79 @@ def test_warm_started_closed_loop_reaches_the_same_forces(pkg, lib, model):
     assert runs["warm, mu0 = 1e-6"][2] < 0.7 * it0
 
 
+def test_warm_started_solve_and_drop_in(pkg, lib):
+    """qmpc_solve_warm: the plain solve started from a previous solution of the same robot (shifted by a knot inside)
+    instead of u_ref.  (i) Same KKT point as the cold solve, fewer iterations, for states one tick apart; cold when u_init
+    is NULL; swing legs stay exactly 0.  (ii) The drop-in class with set_warm_start(true) in the host closed loop equals
+    the warm-started DEVICE loop tick for tick -- the device keeps the solution in LDS, the host class hands last tick's
+    traj_u back through the C ABI: the same numbers -- which gives the warm-started loop its own parity reference."""
+    import __graft_entry__ as g
+
+    p = pkg.default_params(10, pkg.MODE_CONVERGED, lib)
+    p.ipm_mu0 = 1e-6
+    rec = pkg.random_go1_trot_states(256, config_id=2)
+    s = pkg.Solver(p, 256, device=0, lib=lib)
+    f0, i0, tu0 = s.solve_warm(rec, None)                          # cold
+    fc, ic = s.solve(rec)
+    assert np.array_equal(f0, fc) and np.array_equal(i0["iterations"], ic["iterations"])
+    rec2 = rec.copy()                                               # "the next tick": slightly moved states
+    rec2["lin_vel_body"] += 0.01
+    rec2["pos_ref_body"] += 0.002
+    f1c, i1c = s.solve(rec2)
+    f1w, i1w, tu1 = s.solve_warm(rec2, tu0)
+    s.close()
+    ok = (i1c["status"] == 0) & (i1w["status"] == 0)
+    assert ok.mean() > 0.98
+    d = float(np.abs(f1w - f1c)[ok].max())
+    print(f"warm vs cold solve of the next tick: force difference {d:.2e} N, iterations {i1w['iterations'][ok].mean():.2f} vs "
+          f"{i1c['iterations'][ok].mean():.2f}")
+    assert d < 1e-6 and i1w["iterations"][ok].mean() < i1c["iterations"][ok].mean()
+    assert (f1w.reshape(-1, 4, 3)[rec2["contacts"] == 0] == 0).all() and (tu1.reshape(256, 10, 4, 3).transpose(0, 2, 1, 3)[rec2["contacts"] == 0] == 0).all()
+
+    host = C.CDLL(str(g.build_host()))
+    vp = C.c_void_p
+    host.qh_loop_create_opts.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, vp, vp]; host.qh_loop_create_opts.restype = vp
+    for f in ("qh_loop_tick", "qh_loop_destroy"):
+        getattr(host, f).argtypes = [vp]
+    host.qh_loop_export.argtypes = [vp, vp]
+    host.qh_loop_set_command.argtypes = [vp, vp, C.c_double]
+    host.qh_loop_set_warm_start.argtypes = [vp, C.c_int]
+    T0, T, N = 6, 120, 10
+    lp = pkg.default_loop_params(lib)
+    lp.warm_start = 1.0
+    cmds = np.array(LOOP_COMMANDS[:4])
+    yaws = [0.0, 0.4, -1.0, 2.0]
+    stand = cmds.copy(); stand[:, 6] = 0.0
+    st_init = pkg.loop_states(stand, lp, height=0.3, yaw=yaws, lib=lib)
+    B = len(st_init)
+    pw = pkg.default_params(N, pkg.MODE_CONVERGED, lib)       # the default barrier start: the host class creates its handle
+    s = pkg.Solver(pw, B, device=0, lib=lib)                   # from the same defaults
+    st0 = s.loop_run(st_init, T0, lp)
+    st0["movement_mode"] = cmds[:, 6]
+    st, tf, tc = s.loop_run(st0, T, lp, trace=True)
+    s.close()
+    worst_f, its = 0.0, []
+    for i in range(B):
+        h = host.qh_loop_create_opts(str(pkg.LIB_PATH).encode(), N, pkg.MODE_CONVERGED, 1, C.addressof(lp), st_init[i:i + 1].ctypes.data)
+        assert h
+        e = np.zeros(1, dtype=pkg.LOOP_STATE_DTYPE)
+        host.qh_loop_set_warm_start(h, 1)
+        for t in range(T0):
+            host.qh_loop_tick(h)
+        host.qh_loop_set_warm_start(h, 1)          # the device call above started cold at its first tick: drop the kept solution
+        host.qh_loop_set_command(h, np.ascontiguousarray(cmds[i, :6]).ctypes.data, float(cmds[i, 6]))
+        for t in range(T):
+            assert host.qh_loop_tick(h) == 1, (i, t)
+            host.qh_loop_export(h, e.ctypes.data)
+            assert np.array_equal(e[0]["contacts"], tc[t, i]), (i, t)
+            worst_f = max(worst_f, float(np.abs(e[0]["forces_body"] - tf[t, i]).max()))
+        assert e[0]["iterations"] == st[i]["iterations"]
+        host.qh_loop_destroy(h)
+    print(f"warm-started loop, device (solution kept in LDS) vs host classes (traj_u through qmpc_solve_warm), {B} robots x {T} ticks: "
+          f"worst force difference {worst_f:.2e} N")
+    assert worst_f <= 1e-6
+
+
 def test_reference_mode_closed_loop_matches_host_classes(pkg, lib):
     """The closed loop with the reference's OWN solver mode (AL-iLQR, <= 10 iterations, last iterate applied whatever its
     status, QuatMpc.cpp:21-26,256) -- i.e. what a robot running the reference controller would do -- on the device
