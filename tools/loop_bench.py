@@ -23,6 +23,7 @@ ap.add_argument("--horizon", type=int, default=10)
 ap.add_argument("--mu0", type=float, default=0.0, help="initial barrier parameter (0: the default of qmpc_default_params, 1e-2)")
 ap.add_argument("--warm", type=int, default=0, nargs="?", const=1, help="qmpc_loop_params.warm_start")
 ap.add_argument("--quirk", action="store_true", help="params.drop_ang_vel = 1: the reference's x_init without angular velocity")
+ap.add_argument("--tol-step", type=float, default=0.0, help="params.tol_step (0: the default 1e-8 N)")
 ap.add_argument("--mode", type=int, default=0, help="0 converged, 1 reference (AL-iLQR, <= 10 iterations)")
 a = ap.parse_args()
 lib = pkg.load_library()
@@ -41,6 +42,8 @@ prm = pkg.default_params(a.horizon, a.mode, lib)
 prm.drop_ang_vel = 1 if a.quirk else 0     # default: the MPC sees the body's angular velocity
 if a.mu0 > 0.0:
     prm.ipm_mu0 = a.mu0
+if a.tol_step > 0.0:
+    prm.tol_step = a.tol_step
 s = pkg.Solver(prm, B, device=0, lib=lib)
 st = s.loop_run(st, 8, lp)
 st["movement_mode"] = cmds[:, 6]
@@ -54,7 +57,7 @@ s.wait()
 dt = time.perf_counter() - t0
 out = d_st.cpu().numpy().view(pkg.LOOP_STATE_DTYPE).reshape(B)
 import os
-print(f"closed loop{' (reference mode)' if a.mode else ''}, {B} robots with random commands, {a.ticks} ticks, N={a.horizon}{f', mu0={a.mu0:g}' if a.mu0 > 0 else ''}{', drop_ang_vel=1' if a.quirk else ''}{', warm start' if a.warm else ''}, "
+print(f"closed loop{' (reference mode)' if a.mode else ''}, {B} robots with random commands, {a.ticks} ticks, N={a.horizon}{f', mu0={a.mu0:g}' if a.mu0 > 0 else ''}{f', tol_step={a.tol_step:g}' if a.tol_step > 0 else ''}{', drop_ang_vel=1' if a.quirk else ''}{', warm start' if a.warm else ''}, "
       f"{ {'0': 'per-tick launches (QMPC_LOOP_FUSED=0)', '1': 'persistent kernel (QMPC_LOOP_FUSED=1)'}.get(os.environ.get('QMPC_LOOP_FUSED'), 'library default') }: {dt * 1e3 / a.ticks:.3f} ms per tick, "
       f"{B * a.ticks / dt:.4g} robot-ticks/s; last-tick status != OK {int((out['status'] != 0).sum())}, mean iterations "
       f"{out['iterations'].mean():.2f} (max {int(out['iterations'].max())}); checksum {float(out['pos_world'].sum()):.12f}")
