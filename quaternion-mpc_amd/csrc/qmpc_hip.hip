@@ -55,6 +55,8 @@ struct qmpc_handle {
   int* d_loop_row;        // trace row counter of the closed loop (qmpc_loop_run*)
   double* d_leg;          // staging of the host-buffer leg calls (grown on demand, freed with the handle)
   size_t leg_cap;         // its capacity in doubles
+  double* d_loop;         // staging of qmpc_loop_run (states and traces; grown on demand, freed with the handle)
+  size_t loop_cap;        // its capacity in doubles
   double* d_gws;          // [max_batch][N*(156+84)] workspace of the global-gains variant
   int variant;            // 0: auto, 1: LDS gains, 2: global gains (env QMPC_VARIANT)
 };
@@ -324,6 +326,7 @@ void qmpc_destroy(qmpc_handle* h) {
   if (h->d_gws) (void)hipFree(h->d_gws);
   if (h->d_leg) (void)hipFree(h->d_leg);
   if (h->d_loop_row) (void)hipFree(h->d_loop_row);
+  if (h->d_loop) (void)hipFree(h->d_loop);
   if (h->d_info) (void)hipFree(h->d_info);
   if (h->d_traj_u) (void)hipFree(h->d_traj_u);
   if (h->d_traj_x) (void)hipFree(h->d_traj_x);
@@ -996,14 +999,22 @@ qmpc_status qmpc_loop_run(qmpc_handle* h, const qmpc_loop_params* lp, int32_t ba
   if (batch == 0 || ticks == 0) return QMPC_OK;
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
   HIP_TRY(hipSetDevice(h->device));
-  qmpc_loop_state* d_st = nullptr;
-  double *d_tf = nullptr, *d_tc = nullptr;
+  // staging that belongs to the handle and only grows: [states | force trace | contact trace]
   const size_t B = (size_t)batch, T = (size_t)ticks;
+  const size_t n_st = (sizeof(qmpc_loop_state) / sizeof(double)) * B, n_tf = trace_forces ? 12 * B * T : 0,
+               n_tc = trace_contacts ? 4 * B * T : 0;
+  if (h->loop_cap < n_st + n_tf + n_tc) {
+    if (h->d_loop) (void)hipFree(h->d_loop);
+    h->d_loop = nullptr;
+    h->loop_cap = 0;
+    HIP_TRY(hipMalloc(&h->d_loop, sizeof(double) * (n_st + n_tf + n_tc)));
+    h->loop_cap = n_st + n_tf + n_tc;
+  }
+  qmpc_loop_state* d_st = reinterpret_cast<qmpc_loop_state*>(h->d_loop);
+  double* d_tf = trace_forces ? h->d_loop + n_st : nullptr;
+  double* d_tc = trace_contacts ? h->d_loop + n_st + n_tf : nullptr;
   qmpc_status rs = QMPC_OK;
   do {
-    if (hipMalloc(&d_st, sizeof(qmpc_loop_state) * B) != hipSuccess) { rs = QMPC_HIP_ERROR; break; }
-    if (trace_forces && hipMalloc(&d_tf, sizeof(double) * 12 * B * T) != hipSuccess) { rs = QMPC_HIP_ERROR; break; }
-    if (trace_contacts && hipMalloc(&d_tc, sizeof(double) * 4 * B * T) != hipSuccess) { rs = QMPC_HIP_ERROR; break; }
     if (hipMemcpyAsync(d_st, states, sizeof(qmpc_loop_state) * B, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rs = QMPC_HIP_ERROR; break; }
     rs = qmpc_loop_run_device(h, lp, batch, d_st, ticks, d_tf, d_tc, nullptr);
     if (rs != QMPC_OK) break;
@@ -1012,9 +1023,6 @@ qmpc_status qmpc_loop_run(qmpc_handle* h, const qmpc_loop_params* lp, int32_t ba
     if (d_tc && hipMemcpyAsync(trace_contacts, d_tc, sizeof(double) * 4 * B * T, hipMemcpyDeviceToHost, h->stream) != hipSuccess) { rs = QMPC_HIP_ERROR; break; }
     if (hipStreamSynchronize(h->stream) != hipSuccess) rs = QMPC_HIP_ERROR;
   } while (0);
-  if (d_st) (void)hipFree(d_st);
-  if (d_tf) (void)hipFree(d_tf);
-  if (d_tc) (void)hipFree(d_tc);
   return rs;
 }
 
