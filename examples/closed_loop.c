@@ -3,7 +3,8 @@
  * Raibert footholds, record packing -> MPC solve -> rigid-body plant) runs on the GPU with the robots' state in HBM.
  *   gcc -O2 -I include examples/closed_loop.c -o examples/closed_loop quaternion-mpc_amd/csrc/libqmpc_hip.so \
  *       -Wl,-rpath,'$ORIGIN/../quaternion-mpc_amd/csrc' -lm
- * usage: closed_loop [robots=64] [ticks=400]     (one tick = 5 ms)
+ * usage: closed_loop [robots=64] [ticks=400] [warm=0]     (one tick = 5 ms; warm=1: every solve starts from the previous
+ *        tick's solution and a low initial barrier -- the same forces in about half the iterations)
  * Prints where the robots ended up; exits non-zero if a robot fell, a solve failed, or there is no GPU (there is no
  * CPU fallback: qmpc_create then returns QMPC_NO_DEVICE). */
 #include <math.h>
@@ -15,10 +16,12 @@
 int main(int argc, char** argv) {
   const int robots = (argc > 1) ? atoi(argv[1]) : 64;
   const int ticks = (argc > 2) ? atoi(argv[2]) : 400;
+  const int warm = (argc > 3) ? atoi(argv[3]) : 0;
   qmpc_params p;
   qmpc_default_params(&p, /*horizon=*/10, QMPC_MODE_CONVERGED);
   p.drop_ang_vel = 0;   /* the MPC sees the body's angular velocity: the reference's x_init leaves it out (QuatMpc.cpp:242-245),
                            which an ideal rigid-body plant without leg damping does not forgive for long */
+  if (warm) p.ipm_mu0 = 1e-6;   /* goes with lp.warm_start below */
   qmpc_handle* h = NULL;
   qmpc_status st = qmpc_create(&p, robots, /*device=*/0, &h);
   if (st != QMPC_OK) {
@@ -27,6 +30,7 @@ int main(int argc, char** argv) {
   }
   qmpc_loop_params lp;
   qmpc_default_loop_params(&lp);
+  lp.warm_start = warm ? 1.0 : 0.0;
   qmpc_loop_state* s = calloc((size_t)robots, sizeof *s);
   for (int i = 0; i < robots; ++i) {
     /* joy: velx, vely, body_height, roll_rate, pitch_rate, yaw_rate -- a fan of headings and speeds */

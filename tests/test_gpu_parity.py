@@ -1550,6 +1550,10 @@ def test_closed_loop_c_example_runs_on_the_gpu(pkg, lib, tmp_path):
     assert "0 not upright" in r.stdout
     assert r.stdout.count("torque command") == 4 and "stance" in r.stdout      # the joint level of the last tick
     print(r.stdout)
+    rw = subprocess.run([str(exe), "32", "300", "1"], capture_output=True, text=True, timeout=300)    # warm-started
+    assert rw.returncode == 0 and "0 not upright" in rw.stdout, rw.stdout + rw.stderr
+    pos = lambda out: [l.split("position")[1].split(")")[0] for l in out.splitlines() if l.startswith("robot") and "position" in l]
+    assert pos(rw.stdout) == pos(r.stdout)                  # the same robots end in the same places (3 decimals printed)
 
 
 def test_c_example_runs_on_the_gpu(pkg, lib, tmp_path):
