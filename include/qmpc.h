@@ -119,7 +119,9 @@ typedef struct qmpc_params {
   int32_t linesearch_max;         /* reference mode: max halvings              */
   /* parity switches for the reference's quirks */
   int32_t drop_ang_vel;     /* 1: x_init[10:13]=0 (comma-initialiser bug at
-                               QuatMpc.cpp:242-245); 0: use ang_vel_body       */
+                               QuatMpc.cpp:242-245); 0: use ang_vel_body.  The default (1) is the
+                               reference's behaviour; a closed loop around an ideal plant needs 0
+                               beyond a few seconds                */
   int32_t model;            /* qmpc_model: which controller's problem the handle
                                solves (0 = QuatMpc, 1 = ConvexMpc)              */
 } qmpc_params;
@@ -422,10 +424,11 @@ void qmpc_loop_state_init(qmpc_loop_state* s, const qmpc_loop_params* lp, const 
  * and record, R' u into the plant -- with host/ClosedLoopHost.h over ConvexMpcHipT as the parity reference. */
 qmpc_status qmpc_loop_run(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* states,
                           int32_t ticks, double* trace_forces, double* trace_contacts);
-/* The same with DEVICE buffers, stream-ordered (NULL = the handle's stream).  Up to 2048 robots (converged mode) the
- * whole loop is ONE launch of a persistent kernel in which a wavefront owns a robot for all ticks (both solver
- * modes); beyond, the per-tick kernel sequence is captured once into a hipGraph and replayed `ticks` times.  The two
- * forms give the same bits (QMPC_LOOP_FUSED=0 / 1 forces one). */
+/* The same with DEVICE buffers, stream-ordered (NULL = the handle's stream).  Up to 2048 robots, and always with
+ * lp->warm_start, the whole loop is ONE launch of a persistent kernel in which a wavefront owns a robot for all ticks
+ * (both controllers, both solver modes); beyond, the per-tick kernel sequence is captured once into a hipGraph and
+ * replayed `ticks` times.  The two forms give the same bits (QMPC_LOOP_FUSED=0 / 1 forces one).
+ * For roll-outs longer than a few seconds set params.drop_ang_vel = 0 (see qmpc_params). */
 qmpc_status qmpc_loop_run_device(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* d_states,
                                  int32_t ticks, double* d_trace_forces, double* d_trace_contacts, void* stream);
 int32_t qmpc_sizeof_loop_state(void);
@@ -443,8 +446,9 @@ qmpc_status qmpc_loop_joint_commands(qmpc_handle* h, const qmpc_leg_geometry* g,
                                      const qmpc_loop_state* states, double* joint_pos, qmpc_joint_feedback* fb,
                                      qmpc_joint_command* cmd);
 /* The closed loop down to the motors: qmpc_loop_run_device with the joint level closing every tick (inside the
- * persistent kernel, or as the fourth kernel of the captured per-tick graph).  d_joint_pos [batch][12] in/out as above; d_cmd [batch] receives the commands of the LAST tick,
- * d_trace_cmd [ticks][batch] those of every tick (either may be NULL, not both). */
+ * persistent kernel, or as the fourth kernel of the captured per-tick graph).  d_joint_pos [batch][12] in/out as above;
+ * d_cmd [batch] receives the commands of the LAST tick, d_trace_cmd [ticks][batch] those of every tick (either may be
+ * NULL, not both). */
 qmpc_status qmpc_loop_run_joint_device(qmpc_handle* h, const qmpc_loop_params* lp, const qmpc_leg_geometry* g,
                                        int32_t batch, qmpc_loop_state* d_states, double* d_joint_pos, int32_t ticks,
                                        qmpc_joint_command* d_cmd, qmpc_joint_command* d_trace_cmd, void* stream);
