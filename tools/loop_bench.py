@@ -24,6 +24,7 @@ ap.add_argument("--mu0", type=float, default=0.0, help="initial barrier paramete
 ap.add_argument("--warm", type=int, default=0, nargs="?", const=1, help="qmpc_loop_params.warm_start")
 ap.add_argument("--quirk", action="store_true", help="params.drop_ang_vel = 1: the reference's x_init without angular velocity")
 ap.add_argument("--tol-step", type=float, default=0.0, help="params.tol_step (0: the default 1e-8 N)")
+ap.add_argument("--model", choices=["quat", "convex"], default="quat", help="which controller's tick (handle model)")
 ap.add_argument("--mode", type=int, default=0, help="0 converged, 1 reference (AL-iLQR, <= 10 iterations)")
 a = ap.parse_args()
 lib = pkg.load_library()
@@ -32,14 +33,16 @@ lp.warm_start = float(a.warm)
 rng = np.random.default_rng(11)
 B = a.robots
 cmds = np.zeros((B, 7))
-cmds[:, 0] = rng.uniform(-0.5, 0.5, B); cmds[:, 1] = rng.uniform(-0.2, 0.2, B); cmds[:, 2] = rng.uniform(0.26, 0.32, B)
+cmds[:, 0] = (0.6 if a.model == "convex" else 1.0) * rng.uniform(-0.5, 0.5, B); cmds[:, 1] = rng.uniform(-0.2, 0.2, B)
+cmds[:, 2] = rng.uniform(0.26, 0.32, B)
 cmds[:, 5] = rng.uniform(-0.5, 0.5, B); cmds[:, 6] = (rng.random(B) < 0.9).astype(float)
 cmds[cmds[:, 6] == 0, :2] = 0.0
 cmds[cmds[:, 6] == 0, 5] = 0.0
 stand = cmds.copy(); stand[:, 6] = 0.0
 st = pkg.loop_states(stand, lp, height=0.3, yaw=rng.uniform(-3.1, 3.1, B), lib=lib)
-prm = pkg.default_params(a.horizon, a.mode, lib)
-prm.drop_ang_vel = 1 if a.quirk else 0     # default: the MPC sees the body's angular velocity
+prm = (pkg.default_convex_params if a.model == "convex" else pkg.default_params)(a.horizon, a.mode, lib)
+if a.model == "quat":
+    prm.drop_ang_vel = 1 if a.quirk else 0     # default: the MPC sees the body's angular velocity
 if a.mu0 > 0.0:
     prm.ipm_mu0 = a.mu0
 if a.tol_step > 0.0:
@@ -57,7 +60,7 @@ s.wait()
 dt = time.perf_counter() - t0
 out = d_st.cpu().numpy().view(pkg.LOOP_STATE_DTYPE).reshape(B)
 import os
-print(f"closed loop{' (reference mode)' if a.mode else ''}, {B} robots with random commands, {a.ticks} ticks, N={a.horizon}{f', mu0={a.mu0:g}' if a.mu0 > 0 else ''}{f', tol_step={a.tol_step:g}' if a.tol_step > 0 else ''}{', drop_ang_vel=1' if a.quirk else ''}{', warm start' if a.warm else ''}, "
+print(f"closed loop{' (ConvexMpc)' if a.model == 'convex' else ''}{' (reference mode)' if a.mode else ''}, {B} robots with random commands, {a.ticks} ticks, N={a.horizon}{f', mu0={a.mu0:g}' if a.mu0 > 0 else ''}{f', tol_step={a.tol_step:g}' if a.tol_step > 0 else ''}{', drop_ang_vel=1' if a.quirk else ''}{', warm start' if a.warm else ''}, "
       f"{ {'0': 'per-tick launches (QMPC_LOOP_FUSED=0)', '1': 'persistent kernel (QMPC_LOOP_FUSED=1)'}.get(os.environ.get('QMPC_LOOP_FUSED'), 'library default') }: {dt * 1e3 / a.ticks:.3f} ms per tick, "
       f"{B * a.ticks / dt:.4g} robot-ticks/s; last-tick status != OK {int((out['status'] != 0).sum())}, mean iterations "
       f"{out['iterations'].mean():.2f} (max {int(out['iterations'].max())}); checksum {float(out['pos_world'].sum()):.12f}")
