@@ -408,8 +408,8 @@ typedef struct qmpc_loop_params {
   double warm_start;                /* 0 (default): every solve starts from u_ref like the reference (QuatMpc.cpp:253).
                                        != 0: from the second tick of a call on, the solve starts from the previous
                                        tick's solution shifted by one knot (swing legs 0, a leg that has just landed
-                                       from u_ref); converged mode; the call then always runs the persistent kernel,
-                                       whose LDS keeps that solution.  Same KKT points, about half the iterations when
+                                       from u_ref); converged mode.  The persistent kernel keeps that solution in LDS,
+                                       the per-tick form in the handle's trajectory buffer.  Same KKT points, about half the iterations when
                                        combined with a low params.ipm_mu0 (1e-6): DESIGN.md 3e */
 } qmpc_loop_params;
 void qmpc_default_loop_params(qmpc_loop_params* p);
@@ -424,8 +424,8 @@ void qmpc_loop_state_init(qmpc_loop_state* s, const qmpc_loop_params* lp, const 
  * and record, R' u into the plant -- with host/ClosedLoopHost.h over ConvexMpcHipT as the parity reference. */
 qmpc_status qmpc_loop_run(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* states,
                           int32_t ticks, double* trace_forces, double* trace_contacts);
-/* The same with DEVICE buffers, stream-ordered (NULL = the handle's stream).  Up to 2048 robots, and always with
- * lp->warm_start, the whole loop is ONE launch of a persistent kernel in which a wavefront owns a robot for all ticks
+/* The same with DEVICE buffers, stream-ordered (NULL = the handle's stream).  Up to 2048 robots (4096 with
+ * lp->warm_start) the whole loop is ONE launch of a persistent kernel in which a wavefront owns a robot for all ticks
  * (both controllers, both solver modes); beyond, the per-tick kernel sequence is captured once into a hipGraph and
  * replayed `ticks` times.  The two forms give the same bits (QMPC_LOOP_FUSED=0 / 1 forces one).
  * For roll-outs longer than a few seconds set params.drop_ang_vel = 0 (see qmpc_params). */

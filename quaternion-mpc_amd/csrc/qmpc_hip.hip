@@ -30,9 +30,9 @@ hipError_t qmpc_fused_launch(int var, int reference_mode, int convex, int batch,
                              const qmpc_leg_geometry* geom, double* joint_pos, qmpc_joint_command* cmd,
                              qmpc_joint_command* trace_cmd);
 hipError_t qmpc_warm_set_lds(int bytes);
-hipError_t qmpc_warm_launch(int var, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
+hipError_t qmpc_warm_launch(int var, int convex, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
                             const qmpc_input* in, const double* u_init, double* forces, qmpc_info* info, double* traj_u,
-                            double* gws);
+                            double* gws, int check_prev);
 
 struct qmpc_handle {
   qmpc_params params;
@@ -263,7 +263,7 @@ static qmpc_status create_resources(qmpc_handle* h, int N, int nl, int nu) {
   }
   if (params->model != QMPC_MODEL_QUAT8)
     for (int v = 0; v < 3; ++v) HIP_TRY(qmpc_fused_set_lds(v, 160 * 1024));     // the closed loop's persistent kernels
-  if (params->model == QMPC_MODEL_QUAT) HIP_TRY(qmpc_warm_set_lds(160 * 1024));
+  if (params->model != QMPC_MODEL_QUAT8) HIP_TRY(qmpc_warm_set_lds(160 * 1024));
   if (params->mode == QMPC_MODE_REFERENCE) {
     if (params->model == QMPC_MODEL_QUAT8) {
       QMPC_SET_LDS((qmpc_ref_kernel<Quat8Model, 1>), h->lds_bytes_g);     // never everything in LDS
@@ -496,8 +496,8 @@ qmpc_status qmpc_solve_warm_device(qmpc_handle* h, int32_t batch, const qmpc_inp
   HIP_TRY(hipSetDevice(h->device));
   const int var = pick_variant(h, batch);
   const size_t lds = var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes);
-  HIP_TRY(qmpc_warm_launch(var, (int)batch, lds, stream ? (hipStream_t)stream : h->stream, &h->dev, sizeof h->dev, d_in, d_u_init,
-                           d_forces_body, d_info, d_traj_u, var >= 1 ? h->d_gws : nullptr));
+  HIP_TRY(qmpc_warm_launch(var, 0, (int)batch, lds, stream ? (hipStream_t)stream : h->stream, &h->dev, sizeof h->dev, d_in, d_u_init,
+                           d_forces_body, d_info, d_traj_u, var >= 1 ? h->d_gws : nullptr, 0));
   return QMPC_OK;
 }
 
@@ -905,15 +905,27 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   LegGeom G;
   std::memset(&G, 0, sizeof G);
   if (g) std::memcpy(&G, g, sizeof G);
-  auto one_tick = [&]() -> qmpc_status {
+  // warm start in the per-tick form: the solution travels from tick to tick through the handle's trajectory buffer (the
+  // persistent kernel keeps it in LDS); the first tick of a call starts cold
+  const bool warm = lp->warm_start != 0.0 && h->params.mode == QMPC_MODE_CONVERGED;
+  if (warm && !h->d_traj_u)
+    HIP_TRY(hipMalloc(&h->d_traj_u, sizeof(double) * 12 * (size_t)h->params.horizon * (size_t)h->max_batch));
+  auto one_tick = [&](bool first) -> qmpc_status {
     if (convex)
       hipLaunchKernelGGL(qmpc_loop_front_convex_kernel, dim3(blocks), dim3(64), 0, s, LP, d_states,
                          reinterpret_cast<qmpc_convex_input*>(h->d_in), h->d_loop_row, (int)batch);
     else
       hipLaunchKernelGGL(qmpc_loop_front_kernel, dim3(blocks), dim3(64), 0, s, LP, d_states, h->d_in, h->d_loop_row, (int)batch);
     HIP_TRY(hipGetLastError());
-    const qmpc_status st = launch_solve(h, batch, h->d_in, h->d_forces, h->d_info, nullptr, nullptr, s, /*timed=*/false);
-    if (st != QMPC_OK) return st;
+    if (warm) {
+      const int var = pick_variant(h, batch);
+      const size_t lds = var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes);
+      HIP_TRY(qmpc_warm_launch(var, convex ? 1 : 0, (int)batch, lds, s, &h->dev, sizeof h->dev, h->d_in, first ? nullptr : h->d_traj_u,
+                               h->d_forces, h->d_info, h->d_traj_u, var >= 1 ? h->d_gws : nullptr, /*check_prev=*/1));
+    } else {
+      const qmpc_status st = launch_solve(h, batch, h->d_in, h->d_forces, h->d_info, nullptr, nullptr, s, /*timed=*/false);
+      if (st != QMPC_OK) return st;
+    }
     if (convex)
       hipLaunchKernelGGL(qmpc_loop_post_kernel<true>, dim3(blocks), dim3(64), 0, s, h->dev, LP, d_states, (const double*)h->d_forces,
                          (const qmpc_info*)h->d_info, d_trace_forces, d_trace_contacts, (const int*)h->d_loop_row, (int)batch);
@@ -938,8 +950,9 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   // tails, and the fused kernel pays for its register pressure).
   // QMPC_LOOP_FUSED=0 / 1 forces one or the other (experiments, tests).
   static const int fused_env = [] { const char* e = std::getenv("QMPC_LOOP_FUSED"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-  const bool warm = lp->warm_start != 0.0 && h->params.mode == QMPC_MODE_CONVERGED;   // needs the persistent kernel's LDS
-  const bool fused = warm || (fused_env >= 0 ? fused_env == 1 : batch <= 2048);      // measured: +25 % (256), +28 % (1024), +8 % (2048), -3 % (4096)
+  // measured, persistent vs per-tick: +25 % (256), +28 % (1024), +8 % (2048), -3 % (4096); with the warm start, whose
+  // iteration counts spread more: +61 % (1024), +33 % (2048), +8 % (4096), -14 % (16384)
+  const bool fused = fused_env >= 0 ? fused_env == 1 : batch <= (warm ? 4096 : 2048);
   if (fused) {
     const bool ref = h->params.mode == QMPC_MODE_REFERENCE;
     // the reference-mode kernels exist with everything in LDS (0) and with the gains in the workspace (1): launch_solve's rule
@@ -955,8 +968,14 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   bool captured = false;
-  if (ticks > 1 && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-    const qmpc_status st = one_tick();
+  int t_start = 0;
+  if (warm) {                            // the cold first tick is not the tick the graph repeats
+    const qmpc_status st = one_tick(true);
+    if (st != QMPC_OK) return st;
+    t_start = 1;
+  }
+  if (ticks - t_start > 1 && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+    const qmpc_status st = one_tick(false);
     const hipError_t ee = hipStreamEndCapture(s, &graph);
     if (st == QMPC_OK && ee == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess)
       captured = true;
@@ -964,11 +983,11 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
       (void)hipGetLastError();
   }
   qmpc_status rs = QMPC_OK;
-  for (int t = 0; t < ticks && rs == QMPC_OK; ++t) {
+  for (int t = t_start; t < ticks && rs == QMPC_OK; ++t) {
     if (captured) {
       if (hipGraphLaunch(exec, s) != hipSuccess) rs = QMPC_HIP_ERROR;
     } else {
-      rs = one_tick();
+      rs = one_tick(!warm);
     }
   }
   if (exec) {

@@ -465,22 +465,25 @@ __global__ __launch_bounds__(64, REF ? 1 : QMPC_SOLVE_WAVES(QuatModel, VAR)) voi
 
 
 // ---- a single warm-started solve (qmpc_solve_warm*): the drop-in class's per-tick call ---------------------------------
-// Same body; the start is u_init (the caller's previous solution of the same robot, e.g. last tick's traj_u) shifted by
-// one knot instead of u_ref.  u_init == nullptr: a plain cold solve.  In this translation unit for the reason given above.
-template <int VAR>
+// Same body; the start is u_init (the caller's previous solution of the same robot, e.g. last tick's traj_u; it may be the
+// buffer traj_u is written to) shifted by one knot instead of u_ref.  u_init == nullptr: a plain cold solve.  In this translation unit for the reason given above.
+template <int VAR, bool CONVEX = false>
 __global__ __launch_bounds__(64, QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_solve_warm_kernel(
-    DevParams P, const qmpc_input* __restrict__ in_, const double* __restrict__ u_init, double* __restrict__ forces,
-    qmpc_info* __restrict__ info, double* __restrict__ traj_u, int batch, double* __restrict__ gws) {
+    DevParams P, const qmpc_input* __restrict__ in_, const double* u_init, double* __restrict__ forces,
+    qmpc_info* __restrict__ info, double* traj_u, int batch, double* __restrict__ gws, int check_prev) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int b = blockIdx.x;
   if (b >= batch) return;
   const int lane = threadIdx.x;
-  typedef QuatModel MD;
+  typedef typename std::conditional<CONVEX, ConvexModel, QuatModel>::type MD;
   constexpr bool PROF = false;
   double* traj_x = nullptr;
   long long* prof_out = nullptr;
-  const int warm_t = u_init ? 1 : 0;
-  if (u_init) {
+  // check_prev (the closed loop's per-tick form): info[b] still holds the status of the robot's previous solve; a failed
+  // one left no usable solution behind, so this one starts cold -- the rule of the persistent kernel
+  const bool usable = u_init && (!check_prev || info[b].status == QMPC_OK || info[b].status == QMPC_MAX_ITER);
+  const int warm_t = usable ? 1 : 0;
+  if (usable) {
     const Layout Lw = make_layout(P.N, VAR >= 1, MD::NL, VAR == 2);
     for (int i = lane; i < P.N * 12; i += kWave) sm[Lw.U + i] = u_init[(size_t)b * P.N * 12 + i];
     __syncthreads();

@@ -88,24 +88,35 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int 
 }
 
 __attribute__((visibility("hidden"))) hipError_t qmpc_warm_set_lds(int bytes) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_warm_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_warm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_warm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  return e;
+  const void* k[6] = {reinterpret_cast<const void*>(qmpc_solve_warm_kernel<0, false>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<1, false>),
+                      reinterpret_cast<const void*>(qmpc_solve_warm_kernel<2, false>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<0, true>),
+                      reinterpret_cast<const void*>(qmpc_solve_warm_kernel<1, true>),  reinterpret_cast<const void*>(qmpc_solve_warm_kernel<2, true>)};
+  for (int i = 0; i < 6; ++i) {
+    const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
-__attribute__((visibility("hidden"))) hipError_t qmpc_warm_launch(int var, int batch, size_t lds, hipStream_t s, const void* dev_params,
-                                                                  size_t dev_params_size, const qmpc_input* in, const double* u_init,
-                                                                  double* forces, qmpc_info* info, double* traj_u, double* gws) {
+__attribute__((visibility("hidden"))) hipError_t qmpc_warm_launch(int var, int convex, int batch, size_t lds, hipStream_t s,
+                                                                  const void* dev_params, size_t dev_params_size,
+                                                                  const qmpc_input* in, const double* u_init, double* forces,
+                                                                  qmpc_info* info, double* traj_u, double* gws, int check_prev) {
   if (dev_params_size != sizeof(DevParams)) return hipErrorInvalidValue;
   DevParams P;
   std::memcpy(&P, dev_params, sizeof P);
-#define QMPC_LAUNCH_WARM(V) \
-  hipLaunchKernelGGL(qmpc_solve_warm_kernel<V>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in, u_init, forces, info, traj_u, \
-                     batch, gws)
-  if (var == 2) QMPC_LAUNCH_WARM(2);
-  else if (var == 1) QMPC_LAUNCH_WARM(1);
-  else QMPC_LAUNCH_WARM(0);
+#define QMPC_LAUNCH_WARM(V, C) \
+  hipLaunchKernelGGL((qmpc_solve_warm_kernel<V, C>), dim3((unsigned)batch), dim3(kWave), lds, s, P, in, u_init, forces, info, \
+                     traj_u, batch, gws, check_prev)
+  if (convex) {
+    if (var == 2) QMPC_LAUNCH_WARM(2, true);
+    else if (var == 1) QMPC_LAUNCH_WARM(1, true);
+    else QMPC_LAUNCH_WARM(0, true);
+  } else {
+    if (var == 2) QMPC_LAUNCH_WARM(2, false);
+    else if (var == 1) QMPC_LAUNCH_WARM(1, false);
+    else QMPC_LAUNCH_WARM(0, false);
+  }
 #undef QMPC_LAUNCH_WARM
   return hipGetLastError();
 }

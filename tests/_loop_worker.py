@@ -14,8 +14,10 @@ pkg = load_pkg()
 robots, ticks, horizon = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0          # 0 converged, 1 reference (AL-iLQR, <= 10 iterations)
 convex = len(sys.argv) > 5 and sys.argv[5] == "convex"       # the sibling controller (ConvexMpc handle)
+warm = len(sys.argv) > 6 and sys.argv[6] == "warm"           # qmpc_loop_params.warm_start
 lib = pkg.load_library()
 lp = pkg.default_loop_params(lib)
+lp.warm_start = 1.0 if warm else 0.0
 rng = np.random.default_rng(5)
 cmds = np.zeros((robots, 7))
 cmds[:, 0] = rng.uniform(-0.5, 0.5, robots); cmds[:, 1] = rng.uniform(-0.2, 0.2, robots)

@@ -1295,13 +1295,16 @@ def test_reference_mode_closed_loop_matches_host_classes(pkg, lib):
 
 @pytest.mark.parametrize("robots,ticks,horizon,mode,model",
                          [(96, 90, 10, 0, "quat"), (3000, 12, 10, 0, "quat"), (40, 60, 20, 0, "quat"), (64, 90, 10, 1, "quat"),
-                          (64, 90, 10, 0, "convex")],
-                         ids=["96 robots N=10", "3000 robots (several rounds per SIMD)", "N=20", "reference mode", "ConvexMpc"])
+                          (64, 90, 10, 0, "convex"), (96, 90, 10, 0, "quat warm"), (2500, 12, 10, 0, "quat warm"),
+                          (64, 90, 10, 0, "convex warm")],
+                         ids=["96 robots N=10", "3000 robots (several rounds per SIMD)", "N=20", "reference mode", "ConvexMpc",
+                              "warm start", "warm start, 2500 robots", "ConvexMpc, warm start"])
 def test_persistent_loop_kernel_equals_the_per_tick_sequence(robots, ticks, horizon, mode, model):
     """qmpc_loop_run* has two launch forms: three kernels per tick (graph replay) and ONE persistent kernel in which a
     wave owns a robot for all ticks (the default up to 2048 robots: the per-tick tails of different robots average out,
     +28 % at 1024 robots, +51 % at N=20; profiles/r02_loop_bench.txt).  Same arithmetic in the same order: final
-    states and traces must be BIT-identical, including a robot whose records are rejected at every tick."""
+    states and traces must be BIT-identical, including a robot whose records are rejected at every tick -- and with the
+    warm start, where the solution travels through LDS in one form and through the handle's trajectory buffer in the other."""
     import os
     import subprocess
     import sys
@@ -1310,7 +1313,8 @@ def test_persistent_loop_kernel_equals_the_per_tick_sequence(robots, ticks, hori
     out = {}
     for fused in ("0", "1"):
         env = dict(os.environ, QMPC_LOOP_FUSED=fused)
-        r = subprocess.run([sys.executable, str(worker), str(robots), str(ticks), str(horizon), str(mode), model], env=env, capture_output=True,
+        r = subprocess.run([sys.executable, str(worker), str(robots), str(ticks), str(horizon), str(mode)] + model.split(), env=env,
+                           capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         out[fused] = [l for l in r.stdout.splitlines() if l.startswith("SHA")][0]
