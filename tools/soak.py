@@ -33,6 +33,8 @@ ap.add_argument("--closed-loop", action="store_true")
 ap.add_argument("--robots", type=int, default=4096)
 ap.add_argument("--ticks", type=int, default=1000)
 ap.add_argument("--check", type=int, default=4, help="closed loop: robots replayed on the host classes")
+ap.add_argument("--warm", action="store_true", help="closed loop: qmpc_loop_params.warm_start = 1 on the device, set_warm_start(true) "
+                "on the host classes")
 ap.add_argument("--feed-ang-vel", action="store_true", help="closed loop: params.drop_ang_vel = 0 (the MPC sees the angular "
                 "velocity; with the reference's quirk the ideal plant is undamped and robots lose balance after 6-9 s)")
 a = ap.parse_args()
@@ -48,7 +50,9 @@ if a.closed_loop:
         getattr(host, fn).argtypes = [vp]
     host.qh_loop_export.argtypes = [vp, vp]
     host.qh_loop_set_command.argtypes = [vp, vp, C.c_double]
+    host.qh_loop_set_warm_start.argtypes = [vp, C.c_int]
     lp = pkg.default_loop_params(lib)
+    lp.warm_start = 1.0 if a.warm else 0.0
     rng = np.random.default_rng(11)
     B = a.robots
     cmds = np.zeros((B, 7))
@@ -79,8 +83,10 @@ if a.closed_loop:
         h = host.qh_loop_create_opts(str(pkg.LIB_PATH).encode(), a.horizon, pkg.MODE_CONVERGED, 0 if a.feed_ang_vel else 1,
                                      C.addressof(lp), st_init[i:i + 1].ctypes.data)
         e = np.zeros(1, dtype=pkg.LOOP_STATE_DTYPE)
+        host.qh_loop_set_warm_start(h, 1 if a.warm else 0)
         for _ in range(8):
             host.qh_loop_tick(h)
+        host.qh_loop_set_warm_start(h, 1 if a.warm else 0)      # a new device call starts cold: drop the kept solution
         host.qh_loop_set_command(h, np.ascontiguousarray(cmds[i, :6]).ctypes.data, float(cmds[i, 6]))
         for t in range(a.ticks):
             host.qh_loop_tick(h)
@@ -89,7 +95,7 @@ if a.closed_loop:
             worst_f = max(worst_f, float(np.abs(e[0]["forces_body"] - tf[t, i]).max()))
         host.qh_loop_destroy(h)
     dist = np.linalg.norm(st["pos_world"][:, :2] - st0["pos_world"][:, :2], axis=1)[~down]
-    print(f"closed-loop soak{' (angular velocity fed to the MPC)' if a.feed_ang_vel else ''}: {B} robots x {a.ticks} ticks ({a.ticks * 0.005:.1f} s of robot time) in {dt:.1f} s = "
+    print(f"closed-loop soak{' (angular velocity fed to the MPC)' if a.feed_ang_vel else ''}{' (warm start)' if a.warm else ''}: {B} robots x {a.ticks} ticks ({a.ticks * 0.005:.1f} s of robot time) in {dt:.1f} s = "
           f"{B * a.ticks / dt:.3g} robot-ticks/s incl. traces; robots down {fell}, last-tick solver status != OK {nonok}; "
           f"distance walked median {np.median(dist):.3f} m, max {dist.max():.3f} m; {min(a.check, B)} robots replayed on the host "
           f"classes: contact-flag differences {cdiff}, worst force difference {worst_f:.3e} N")
