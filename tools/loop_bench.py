@@ -25,6 +25,7 @@ ap.add_argument("--warm", type=int, default=0, nargs="?", const=1, help="qmpc_lo
 ap.add_argument("--quirk", action="store_true", help="params.drop_ang_vel = 1: the reference's x_init without angular velocity")
 ap.add_argument("--tol-step", type=float, default=0.0, help="params.tol_step (0: the default 1e-8 N)")
 ap.add_argument("--model", choices=["quat", "convex"], default="quat", help="which controller's tick (handle model)")
+ap.add_argument("--sigma-fast", type=float, default=0.0, help="params.ipm_sigma_fast (0: the default)")
 ap.add_argument("--mode", type=int, default=0, help="0 converged, 1 reference (AL-iLQR, <= 10 iterations)")
 a = ap.parse_args()
 lib = pkg.load_library()
@@ -47,6 +48,8 @@ if a.mu0 > 0.0:
     prm.ipm_mu0 = a.mu0
 if a.tol_step > 0.0:
     prm.tol_step = a.tol_step
+if a.sigma_fast > 0.0:
+    prm.ipm_sigma_fast = a.sigma_fast
 s = pkg.Solver(prm, B, device=0, lib=lib)
 st = s.loop_run(st, 8, lp)
 st["movement_mode"] = cmds[:, 6]
@@ -60,7 +63,7 @@ s.wait()
 dt = time.perf_counter() - t0
 out = d_st.cpu().numpy().view(pkg.LOOP_STATE_DTYPE).reshape(B)
 import os
-print(f"closed loop{' (ConvexMpc)' if a.model == 'convex' else ''}{' (reference mode)' if a.mode else ''}, {B} robots with random commands, {a.ticks} ticks, N={a.horizon}{f', mu0={a.mu0:g}' if a.mu0 > 0 else ''}{f', tol_step={a.tol_step:g}' if a.tol_step > 0 else ''}{', drop_ang_vel=1' if a.quirk else ''}{', warm start' if a.warm else ''}, "
+print(f"closed loop{' (ConvexMpc)' if a.model == 'convex' else ''}{' (reference mode)' if a.mode else ''}, {B} robots with random commands, {a.ticks} ticks, N={a.horizon}{f', mu0={a.mu0:g}' if a.mu0 > 0 else ''}{f', tol_step={a.tol_step:g}' if a.tol_step > 0 else ''}{f', sigma_fast={a.sigma_fast:g}' if a.sigma_fast > 0 else ''}{', drop_ang_vel=1' if a.quirk else ''}{', warm start' if a.warm else ''}, "
       f"{ {'0': 'per-tick launches (QMPC_LOOP_FUSED=0)', '1': 'persistent kernel (QMPC_LOOP_FUSED=1)'}.get(os.environ.get('QMPC_LOOP_FUSED'), 'library default') }: {dt * 1e3 / a.ticks:.3f} ms per tick, "
       f"{B * a.ticks / dt:.4g} robot-ticks/s; last-tick status != OK {int((out['status'] != 0).sum())}, mean iterations "
       f"{out['iterations'].mean():.2f} (max {int(out['iterations'].max())}); checksum {float(out['pos_world'].sum()):.12f}")
