@@ -72,7 +72,7 @@ struct qmpc_handle {
 
 extern "C" {
 
-const char* qmpc_version(void) { return "qmpc-hip 0.1 (gfx950, wave-per-instance IPM/Riccati, fp64 MFMA)"; }
+const char* qmpc_version(void) { return "qmpc-hip 0.2 (gfx950, wave-per-instance IPM/Riccati, fp64 MFMA; persistent closed loop)"; }
 int32_t qmpc_sizeof_input(void) { return (int32_t)sizeof(qmpc_input); }
 int32_t qmpc_sizeof_params(void) { return (int32_t)sizeof(qmpc_params); }
 int32_t qmpc_sizeof_info(void) { return (int32_t)sizeof(qmpc_info); }
