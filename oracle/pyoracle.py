@@ -120,6 +120,22 @@ def solve(params: Params, inputs: np.ndarray, threads: int = 1, want_traj: bool 
     return forces, info
 
 
+def solve_warm(params: Params, inputs: np.ndarray, u_init):
+    """Every instance started from u_init [B][N][12] shifted by one knot (None: cold).  (forces, info, traj_u)"""
+    inputs = np.ascontiguousarray(inputs, dtype=INPUT_DTYPE)
+    B, N = inputs.shape[0], params.horizon
+    forces = np.zeros((B, 12))
+    info = np.zeros(B, dtype=INFO_DTYPE)
+    tu = np.zeros((B, N, 12))
+    ui = None if u_init is None else np.ascontiguousarray(u_init, dtype=np.float64).reshape(B, N, 12)
+    L = lib()
+    L.qo_solve_one_warm.argtypes = [C.c_void_p] * 6
+    for b in range(B):
+        L.qo_solve_one_warm(C.addressof(params), inputs[b:b + 1].ctypes.data, None if ui is None else ui[b].ctypes.data,
+                            forces[b].ctypes.data, info[b:b + 1].ctypes.data, tu[b].ctypes.data)
+    return forces, info, tu
+
+
 def solve_verbose(params: Params, inp: np.ndarray):
     inp = np.ascontiguousarray(inp, dtype=INPUT_DTYPE)
     f = np.zeros(12)

@@ -208,6 +208,8 @@ static void options_from_params(const qmpc_params* p, qo_options* o, int verbose
   o->ipm_tau = p->ipm_tau;
 }
 
+static __thread const double* warm_u_init = NULL;   /* qo_solve_one_warm: the previous solution [N][m], or NULL */
+
 static int solve_one_v(const qmpc_params* p, const in_view* in, const void* rec, size_t rec_bytes,
                        double* forces, qmpc_info* info, double* traj_u, double* traj_x, int verbose,
                        double* dual, double* slack) {
@@ -240,6 +242,17 @@ static int solve_one_v(const qmpc_params* p, const in_view* in, const void* rec,
   /* initial guess: SetInput(u_ref) on all knots (QuatMpc.cpp:253); the state
    * guess x_ref (:250-252) is overwritten by the solver's initial rollout */
   for (int k = 0; k < N; ++k) memcpy(&U[m * k], prob->uref[0], sizeof(double) * m);
+  if (warm_u_init) {
+    /* warm start (qmpc_solve_warm, qmpc_loop_params.warm_start): the previous solution shifted by one knot, the last knot
+     * repeated; swing legs are pinned to 0, a leg that has just landed (previous force exactly 0) starts from u_ref */
+    for (int j = 0; j < m; ++j) {
+      const int stance = in->contacts[j / 3] != 0.0;
+      for (int k = 0; k < N; ++k) {
+        const double prev = warm_u_init[m * ((k + 1 < N) ? k + 1 : k) + j];
+        U[m * k + j] = !stance ? 0.0 : (prev != 0.0 ? prev : prob->uref[0][j]);
+      }
+    }
+  }
   qo_result r;
   qo_altro_solve(prob, &o, X, U, &r);
   memcpy(forces, U, sizeof(double) * m); /* GetInput(u, 0), QuatMpc.cpp:264-265 */
@@ -264,6 +277,16 @@ int qo_solve8_one(const qmpc_params* p, const qmpc_input8* in, double* forces, q
                   double* traj_u, double* traj_x, int verbose) {
   const in_view v = view8(in);
   return solve_one_v(p, &v, in, sizeof *in, forces, info, traj_u, traj_x, verbose, NULL, NULL);
+}
+
+/* One instance started from u_init [N][12] (NULL: from u_ref, i.e. qo_solve_one) */
+int qo_solve_one_warm(const qmpc_params* p, const qmpc_input* in, const double* u_init, double* forces, qmpc_info* info,
+                      double* traj_u) {
+  const in_view v = view4(in);
+  warm_u_init = u_init;
+  const int st = solve_one_v(p, &v, in, sizeof *in, forces, info, traj_u, NULL, 0, NULL, NULL);
+  warm_u_init = NULL;
+  return st;
 }
 
 /* One instance with the multipliers and slacks of the cone rows, [N][6 nleg] each (certificate fixtures only) */

@@ -25,6 +25,10 @@ int qo_solve_one(const qmpc_params* p, const qmpc_input* in, double* forces, qmp
 
 /* As qo_solve_one, plus the multipliers and slacks of the cone rows at the returned point, [N][24] each
  * (swing-leg rows report 0).  Used by tests/golden/make_kkt_fixtures.py only. */
+/* started from the previous solution u_init [N][12] shifted by one knot (NULL: qo_solve_one); restates the product's
+ * qmpc_solve_warm */
+int qo_solve_one_warm(const qmpc_params* p, const qmpc_input* in, const double* u_init, double* forces, qmpc_info* info,
+                      double* traj_u);
 int qo_solve_one_dual(const qmpc_params* p, const qmpc_input* in, double* forces, qmpc_info* info,
                       double* traj_u, double* traj_x, double* dual, double* slack);
 int qo_solve8_one_dual(const qmpc_params* p, const qmpc_input8* in, double* forces, qmpc_info* info,

@@ -1172,6 +1172,35 @@ def test_warm_started_closed_loop_reaches_the_same_forces(pkg, lib, model):
     assert runs["warm, mu0 = 1e-6"][2] < 0.7 * it0
 
 
+def test_warm_started_solve_matches_oracle(pkg, lib, oracle):
+    """qmpc_solve_warm against the oracle's restatement of the same start (oracle/qo_quatmpc.c: previous solution shifted
+    by a knot, swing legs 0, landed legs from u_ref): same status, same iteration counts, forces and trajectories within
+    1e-6 N -- like the cold solve.  The previous solutions come from states whose contact pattern differs on a third of
+    the instances (legs landing and lifting between the two ticks)."""
+    p = pkg.default_params(10, pkg.MODE_CONVERGED, lib)
+    p.ipm_mu0 = 1e-6
+    rec = pkg.random_go1_trot_states(384, config_id=2)
+    s = pkg.Solver(p, 384, device=0, lib=lib)
+    _, i0, tu0 = s.solve_warm(rec, None)
+    rec2 = rec.copy()
+    rec2["lin_vel_body"] += 0.01
+    rec2["pos_ref_body"] += 0.002
+    flip = np.arange(384) % 3 == 0                                   # other legs in contact than a tick ago
+    rec2["contacts"][flip] = 1.0 - rec2["contacts"][flip]
+    rec2["contacts"][flip & (rec2["contacts"].sum(1) == 0)] = 1.0     # (never airborne)
+    f, info, tu = s.solve_warm(rec2, tu0)
+    s.close()
+    fo, io, tuo = oracle.solve_warm(p, rec2, tu0)
+    assert np.array_equal(info["status"], io["status"])
+    ok = io["status"] == 0
+    same_it = float((info["iterations"] == io["iterations"])[ok].mean())
+    print(f"warm solve vs oracle: {int(ok.sum())}/384 converged, iteration counts equal on {100 * same_it:.1f} %, "
+          f"forces {np.abs(f - fo)[ok].max():.2e} N, trajectories {np.abs(tu - tuo)[ok].max():.2e} N")
+    assert ok.mean() > 0.95 and same_it > 0.97
+    assert np.abs(f - fo)[ok].max() < 1e-6 and np.abs(tu - tuo)[ok].max() < 1e-6
+    assert (f.reshape(-1, 4, 3)[rec2["contacts"] == 0] == 0).all()
+
+
 def test_warm_started_solve_and_drop_in(pkg, lib):
     """qmpc_solve_warm: the plain solve started from a previous solution of the same robot (shifted by a knot inside)
     instead of u_ref.  (i) Same KKT point as the cold solve, fewer iterations, for states one tick apart; cold when u_init
