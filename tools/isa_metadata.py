@@ -9,12 +9,12 @@ from pathlib import Path
 
 REPO = Path(__file__).resolve().parents[1]
 CSRC = REPO / "quaternion-mpc_amd" / "csrc"
-print("ISA metadata of the final build (hipcc --offload-arch=gfx950 -O2 -S --cuda-device-only; .amdgpu_metadata notes), one row per kernel")
+print("ISA metadata of the final build (hipcc --offload-arch=gfx950 -O2 -mllvm -disable-machine-licm -mllvm -disable-machine-sink -S --cuda-device-only; .amdgpu_metadata notes), one row per kernel")
 print("columns: kernel | vgpr_count | agpr_count | sgpr_count | vgpr_spill_count | sgpr_spill_count | private_segment_fixed_size (scratch bytes) | group_segment_fixed_size (static LDS)")
 for tu in ("qmpc_hip.hip", "qmpc_loop_fused.hip"):
     with tempfile.TemporaryDirectory() as d:
         asm = Path(d) / "tu.s"
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-S", "--cuda-device-only", "-o", str(asm),
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-mllvm", "-disable-machine-licm", "-mllvm", "-disable-machine-sink", "-std=c++17", "-S", "--cuda-device-only", "-o", str(asm),
                         str(CSRC / tu)], check=True, stderr=subprocess.DEVNULL)
         txt = asm.read_text()
     print(f"---- translation unit {tu}")
