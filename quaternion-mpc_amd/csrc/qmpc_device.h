@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "../../include/qmpc.h"
+#include "qmpc_params_dev.h"
 
 namespace qmpc {
 
@@ -25,29 +26,6 @@ constexpr int LD = 16;          // leading dimension of every LDS matrix: [12][1
 constexpr int MAT = 12 * LD;    // 192 doubles = 3 MFMA fragments of 64 lanes
 
 typedef double d4 __attribute__((ext_vector_type(4)));
-
-// Device copy of qmpc_params plus derived constants (host fills it).
-struct DevParams {
-  int N;
-  int mode;
-  int iterations_max;
-  int drop_ang_vel;
-  double h;        // (double)(float h)
-  double hh;       // (double)(h/2) with h float
-  double h_ref;
-  double mass;
-  double inv_mass;
-  double Iinv[9];
-  double Q[13];
-  double R[12];
-  double w;
-  double mu;
-  double fz_max;
-  double tol_feas, tol_step, mu0, mu_final, sigma, sigma_fast, tau;
-  // reference mode (AL-iLQR, QuatMpc.cpp:21-26 + upstream ALTRO defaults)
-  double penalty_initial, penalty_scaling, penalty_max, tol_stat, tol_cost_int;
-  int linesearch_max;
-};
 
 // ---- per-instance LDS layout (offsets in doubles) ---------------------------
 struct Layout {

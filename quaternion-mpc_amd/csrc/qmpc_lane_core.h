@@ -1,0 +1,1079 @@
+// qmpc_lane_core.h -- the lane-per-instance solver core: ONE GPU lane owns ONE MPC instance, so a wavefront
+// advances 64 independent solves in lock step with no cross-lane traffic at all, and the per-instance working set
+// (trajectory, slacks / multipliers, feedback gains) streams through an HBM workspace laid out structure-of-arrays
+// over the lanes ("stacked horizon matrices", coalesced 512-byte accesses per wave instruction).  This is the
+// large-batch form of the converged mode of include/qmpc.h; the wave-per-instance kernels (qmpc_kernels.hip) remain
+// the low-latency form for batches that do not fill the chip with lanes.
+//
+// Same problem, same interior-point iteration as qmpc_solve_body.inc (reference: QuatMpc.cpp:109-276 poses it,
+// AltroUtils.cpp:363-439 / :9-22,78-110 are the dynamics and their midpoint linearisation): centring rule, Tapia
+// flags on weakly active rows, analytic slack residual, rotated per-contact-point blocks.  What differs is how the
+// Newton system of a knot is eliminated.  The 3 NL inputs act on the state only through the 6-dimensional wrench
+//     Bbar_k = M_k Wr,   Wr = [c_l I ; Bw0_l] (6 x 3NL, the same for every knot),   M_k (12 x 6),
+// and the input Hessian is block diagonal apart from that coupling, Quu = D + Wr' (M' P M) Wr with D = blkdiag(D_l),
+// D_l = R_l + sum_i w_i a_i a_i' (3 x 3 per contact point).  With S6 = M'PM = L L', G = Wr D^-1 Wr' = sum_l V_l D_l^-1 V_l'
+// and H = I + L' G L = C C' (eigenvalues >= 1) the push-through identity gives
+//     du_l = -D_l^-1 (Wr_l' zeta + g_l),   zeta = L H^-1 (L^-1 (Y dx + y) - L' r6),   Y = M'P Abar, y = M'p,
+//     P  <- Abar'P Abar + lxx - Yt'Yt + Yh'Yh,        Yt = L^-1 Y,  Yh = C^-1 Yt,
+// i.e. NL independent 3 x 3 solves (in the rotated frame that keeps 1e14 : 1e-6 weight ratios accurate, DESIGN.md
+// section 2) and two 6 x 6 Cholesky factorisations instead of a 3NL x 3NL Gauss-Jordan; Abar's block structure
+// ([[I,0,hI,0],[0,A1,0,A3],[0,0,I,0],[0,0,0,I]]) is exploited in every product.  About 5.5 kflop per knot and
+// iteration instead of the 35 kflop of the dense recursion -- and what is stored between the backward and the
+// forward pass is the 6 x 13 wrench-space gain, not 3NL x 13.
+//
+// The file is plain C++ on purpose: hipcc compiles it into qmpc_lane_kernel (qmpc_lane.hip), g++ compiles the very
+// same text into the CPU numerics test of the core (tests/lane_core_host.cpp; test infrastructure, never a product
+// path -- the product has no CPU fallback).
+#pragma once
+
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "qmpc_params_dev.h"
+
+#if defined(__HIPCC__)
+#define QL_FN __device__ __forceinline__
+#define QL_DEVICE 1
+#else
+#define QL_FN inline
+#define QL_DEVICE 0
+#endif
+
+namespace qmpc {
+namespace lane {
+
+QL_FN double ql_rcp(double x) {
+#if QL_DEVICE
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+QL_FN double ql_rsqrt(double x) {
+#if QL_DEVICE
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  return r;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+
+// ---- sizes, record offsets (qmpc_input / qmpc_input8) and per-lane constant slots -------------------------------
+template <int NL>
+struct LDim {
+  static constexpr int NU = 3 * NL, NC = 6 * NL;
+  static constexpr int REC = 32 + 4 * NL;
+  static constexpr int R_FOOT = 19, R_CON = 19 + 3 * NL, R_POS = 19 + 4 * NL, R_QD = R_POS + 9;
+  // constants of one instance (LDS on the device: slot i of lane `lane` = cs[64 i + lane])
+  static constexpr int C_CR = 0, C_FOOT = 18, C_GB = C_FOOT + 3 * NL, C_WD0 = C_GB + 3, C_REF = C_WD0 + 3,
+                       C_RC0 = C_REF + 13, C_TOTAL = C_RC0 + 6;
+  static constexpr int GAIN = 78;     // wrench-space gain [Xg | zeta0], 6 x 13
+};
+
+// workspace offsets in ELEMENTS of one lane's column (element e of lane s lives at ws[e * stride + s])
+struct WsOff {
+  int X, U, dU, S, LAM, G, total;
+};
+template <int NL>
+QL_FN WsOff make_wsoff(int N) {
+  WsOff o;
+  int p = 0;
+  o.X = p; p += 13 * (N + 1);
+  o.U = p; p += 3 * NL * N;
+  o.dU = p; p += 3 * NL * N;
+  o.S = p; p += 6 * NL * N;
+  o.LAM = p; p += 6 * NL * N;
+  o.G = p; p += LDim<NL>::GAIN * N;
+  o.total = p;
+  return o;
+}
+inline size_t lane_ws_elements(int N, int nl) { return nl == 8 ? (size_t)make_wsoff<8>(N).total : (size_t)make_wsoff<4>(N).total; }
+
+struct Ctx {
+  double* ws;      // this lane's column of the workspace
+  size_t wstride;  // lanes in the workspace
+  double* cs;      // this lane's constants
+  int cstride;
+  QL_FN double& W(int e) const { return ws[(size_t)e * wstride]; }
+  QL_FN double& C(int i) const { return cs[i * cstride]; }
+};
+
+// per-instance scalars (registers)
+struct LaneState {
+  unsigned con;        // stance mask
+  int nc;              // stance count
+  int status, iters, it;
+  bool active;
+  double rho;          // slack residual scale: rc_i = rho * rc0_i (rc shrinks by (1 - alpha_p) per step, 0 after a full one)
+  double target;       // sigma * mu of the iteration whose step is pending
+  double mu, last_ap, last_ad, last_step;
+  double ap, ad;       // step lengths of the pending step
+  double uz;           // u_ref z-component of a stance contact point
+};
+
+// ---- small dense helpers (everything is unrolled into registers) --------------------------------------------------
+// symmetric 12 x 12 in 78 entries, upper triangle row-major
+constexpr int SI_(int i, int j) { return i * 12 - i * (i - 1) / 2 + (j - i); }
+constexpr int SI(int i, int j) { return i <= j ? SI_(i, j) : SI_(j, i); }
+// symmetric 6 x 6 in 21 entries
+constexpr int S6_(int i, int j) { return i * 6 - i * (i - 1) / 2 + (j - i); }
+constexpr int S6I(int i, int j) { return i <= j ? S6_(i, j) : S6_(j, i); }
+// lower triangle of a 6 x 6, row-major: (i,j), j <= i
+constexpr int LI(int i, int j) { return i * (i + 1) / 2 + j; }
+
+QL_FN void rdblk(const double* P, int a, int b, double M[9]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) M[3 * r + c] = P[SI(3 * a + r, 3 * b + c)];
+}
+// a < b: all nine entries; a == b: the upper triangle
+QL_FN void wrblk(double* P, int a, int b, const double M[9]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      if (a != b || r <= c) P[SI(3 * a + r, 3 * b + c)] = M[3 * r + c];
+}
+// C = A B, C = A' B (3 x 3 row-major)
+QL_FN void mm(const double A[9], const double B[9], double C[9]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+}
+QL_FN void mtm(const double A[9], const double B[9], double C[9]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) C[3 * r + c] = A[r] * B[c] + A[3 + r] * B[3 + c] + A[6 + r] * B[6 + c];
+}
+
+// G(q) (4 x 3), QuaternionUtils.cpp:48-52
+QL_FN void quatG(const double* q, double G[12]) {
+  const double s = q[0], x = q[1], y = q[2], z = q[3];
+  G[0] = -x; G[1] = -y; G[2] = -z;
+  G[3] = s;  G[4] = -z; G[5] = y;
+  G[6] = z;  G[7] = s;  G[8] = -x;
+  G[9] = -y; G[10] = x; G[11] = s;
+}
+// Omega(w) v (AltroUtils.cpp:408-410 without the 1/2)
+QL_FN void omega_mul(const double* w, const double* v, double* o) {
+  o[0] = -w[0] * v[1] - w[1] * v[2] - w[2] * v[3];
+  o[1] = w[0] * v[0] + w[2] * v[2] - w[1] * v[3];
+  o[2] = w[1] * v[0] - w[2] * v[1] + w[0] * v[3];
+  o[3] = w[2] * v[0] + w[1] * v[1] - w[0] * v[2];
+}
+
+// Bw0_l = Iinv skew(r_l) (AltroUtils.cpp:431-434) for a stance contact point
+QL_FN void leg_bw0(const DevParams& P, const double r[3], double B[9]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double i0 = P.Iinv[3 * a], i1 = P.Iinv[3 * a + 1], i2 = P.Iinv[3 * a + 2];
+    B[3 * a] = i1 * r[2] - i2 * r[1];
+    B[3 * a + 1] = i2 * r[0] - i0 * r[2];
+    B[3 * a + 2] = i0 * r[1] - i1 * r[0];
+  }
+}
+
+// explicit midpoint step (AltroUtils.cpp:9-22 on :363-392) given the force sum F and the angular acceleration wd
+QL_FN void srbd_step_fw(const DevParams& P, const double gb[3], const double* x, const double F[3], const double wd[3],
+                        double* xn) {
+  double vd[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) vd[a] = F[a] * P.inv_mass + gb[a];
+  double G[12];
+  quatG(&x[3], G);
+  double qm[4], wm[3];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    qm[r] = x[3 + r] + P.hh * (0.5 * (G[3 * r] * x[10] + G[3 * r + 1] * x[11] + G[3 * r + 2] * x[12]));
+#pragma unroll
+  for (int a = 0; a < 3; ++a) wm[a] = x[10 + a] + P.hh * wd[a];
+  quatG(qm, G);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    xn[a] = x[a] + P.h * (x[7 + a] + P.hh * vd[a]);
+    xn[7 + a] = x[7 + a] + P.h * vd[a];
+    xn[10 + a] = x[10 + a] + P.h * wd[a];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    xn[3 + r] = x[3 + r] + P.h * (0.5 * (G[3 * r] * wm[0] + G[3 * r + 1] * wm[1] + G[3 * r + 2] * wm[2]));
+}
+
+// reference state of knot k (QuatMpc.cpp:148-176) from refp = pos(3) vel(3) acc(3) quat_d(4)
+QL_FN void xref_at(const DevParams& P, const Ctx& c, int base, int k, double* xr) {
+  const double t = (double)k * P.h_ref;
+  const double h_ms = P.h_ref * 1000.0;
+  double rp[13];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) rp[i] = c.C(base + i);
+  xr[0] = rp[0] + rp[3] * k * h_ms / 1000.0 + 0.5 * rp[6] * t * t;
+  xr[1] = rp[1] + rp[4] * k * h_ms / 1000.0 + 0.5 * rp[7] * t * t;
+  xr[2] = rp[2] + 0.5 * rp[8] * t * t;
+  xr[3] = rp[9]; xr[4] = rp[10]; xr[5] = rp[11]; xr[6] = rp[12];
+  xr[7] = rp[3] + rp[6] * t; xr[8] = rp[4] + rp[7] * t; xr[9] = rp[5] + rp[8] * t;
+  xr[10] = 0.0; xr[11] = 0.0; xr[12] = 0.0;
+}
+
+// ---- one contact point at one knot: barrier weights, rotated frame, factorised 3 x 3 block ---------------------------
+// (the arithmetic of rotation_prepass in qmpc_kernels.hip, followed by the L D L' factorisation that the Gauss-Jordan
+// pivots 3l, 3l+1, 3l+2 perform there)
+struct LegBlk {
+  double T[9];                  // frame, T[3a+b] = (q_b)_a
+  double l10, l20, l21;         // unit lower factor of Db = T' D_l T
+  double id0, id1, id2;         // inverse pivots
+  double gq[3];                 // T' g_l
+};
+template <int NL>
+QL_FN void leg_block(const DevParams& P, const Ctx& c, int l, const double sv[6], const double lv[6], unsigned kap,
+                     double rho, double target, const double u[3], double uz, LegBlk& o) {
+  typedef LDim<NL> D;
+  double cr[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) cr[i] = c.C(D::C_CR + i);
+  double w[6], gi[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const double is = ql_rcp(sv[i]);
+    const double rc = rho * c.C(D::C_RC0 + i);
+    w[i] = lv[i] * is;
+    gi[i] = (target + lv[i] * rc) * is - (((kap >> i) & 1u) ? lv[i] : 0.0);
+  }
+  // heaviest row i1, second heaviest non-(anti)parallel row i2 (rows 4,5 are antiparallel)
+  int i1 = 0;
+  double w1 = w[0];
+#pragma unroll
+  for (int i = 1; i < 6; ++i) if (w[i] > w1) { w1 = w[i]; i1 = i; }
+  int i2 = -1;
+  double w2 = -1.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const bool skip = (i == i1) || ((i1 >= 4) && (i >= 4));
+    if (!skip && w[i] > w2) { w2 = w[i]; i2 = i; }
+  }
+  double a1[3] = {0, 0, 0}, a2[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      a1[a] = (i == i1) ? cr[3 * i + a] : a1[a];
+      a2[a] = (i == i2) ? cr[3 * i + a] : a2[a];
+    }
+  const double in1 = ql_rsqrt(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
+  double q1[3], q2[3], q3[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) q1[a] = a1[a] * in1;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const double dp = a2[0] * q1[0] + a2[1] * q1[1] + a2[2] * q1[2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) a2[a] -= dp * q1[a];
+  }
+  const double in2 = ql_rsqrt(a2[0] * a2[0] + a2[1] * a2[1] + a2[2] * a2[2]);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) q2[a] = a2[a] * in2;
+  q3[0] = q1[1] * q2[2] - q1[2] * q2[1];
+  q3[1] = q1[2] * q2[0] - q1[0] * q2[2];
+  q3[2] = q1[0] * q2[1] - q1[1] * q2[0];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { o.T[3 * a] = q1[a]; o.T[3 * a + 1] = q2[a]; o.T[3 * a + 2] = q3[a]; }
+  const double* T = o.T;
+  const int l4 = l & 3;     // R holds 12 weights: input j uses R[j % 12]
+  const double Rl[3] = {P.R[3 * l4], P.R[3 * l4 + 1], P.R[3 * l4 + 2]};
+  const double ru[3] = {Rl[0] * u[0], Rl[1] * u[1], Rl[2] * (u[2] - uz)};
+  // Db (upper triangle: 00 01 02 11 12 22) and the rotated gradient
+  double d00, d01, d02, d11, d12, d22;
+  {
+    double tr[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tr[i] = T[i] * Rl[i / 3];
+    d00 = tr[0] * T[0] + tr[3] * T[3] + tr[6] * T[6];
+    d01 = tr[0] * T[1] + tr[3] * T[4] + tr[6] * T[7];
+    d02 = tr[0] * T[2] + tr[3] * T[5] + tr[6] * T[8];
+    d11 = tr[1] * T[1] + tr[4] * T[4] + tr[7] * T[7];
+    d12 = tr[1] * T[2] + tr[4] * T[5] + tr[7] * T[8];
+    d22 = tr[2] * T[2] + tr[5] * T[5] + tr[8] * T[8];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) o.gq[a] = T[a] * ru[0] + T[3 + a] * ru[1] + T[6 + a] * ru[2];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double at[3];  // rotated row
+#pragma unroll
+    for (int b = 0; b < 3; ++b) at[b] = T[b] * cr[3 * i] + T[3 + b] * cr[3 * i + 1] + T[6 + b] * cr[3 * i + 2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) o.gq[a] += gi[i] * at[a];
+    const double w0 = w[i] * at[0], w1_ = w[i] * at[1];
+    d00 += w0 * at[0]; d01 += w0 * at[1]; d02 += w0 * at[2];
+    d11 += w1_ * at[1]; d12 += w1_ * at[2];
+    d22 += w[i] * at[2] * at[2];
+  }
+  // L D L' in the pivot order of the frame (heaviest direction first)
+  o.id0 = ql_rcp(d00);
+  o.l10 = d01 * o.id0;
+  o.l20 = d02 * o.id0;
+  const double e11 = d11 - o.l10 * d01;
+  o.id1 = ql_rcp(e11);
+  const double e21 = d12 - o.l20 * d01;
+  o.l21 = e21 * o.id1;
+  const double e22 = d22 - o.l20 * d02 - o.l21 * e21;
+  o.id2 = ql_rcp(e22);
+}
+
+// load the six slack / multiplier pairs of contact point l at knot k; the Tapia flag rides in the sign of the slack
+template <int NL>
+QL_FN unsigned load_rows(const Ctx& c, const WsOff& O, int k, int l, double sv[6], double lv[6]) {
+  unsigned kap = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const double s = c.W(O.S + 6 * NL * k + 6 * l + i);
+    lv[i] = c.W(O.LAM + 6 * NL * k + 6 * l + i);
+    kap |= (s < 0.0) ? (1u << i) : 0u;
+    sv[i] = fabs(s);
+  }
+  return kap;
+}
+
+// ---- set-up: record -> constants, initial guess U = u_ref (QuatMpc.cpp:253), slacks and multipliers ------------------
+template <int NL>
+QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const double* rec, LaneState& st) {
+  typedef LDim<NL> D;
+  const int N = P.N;
+  bool bad = false;
+  double raw[D::REC];
+#pragma unroll
+  for (int i = 0; i < D::REC; ++i) { raw[i] = rec[i]; bad = bad || !isfinite(raw[i]); }
+  st.con = 0; st.nc = 0;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) if (raw[D::R_CON + l] != 0.0) { st.con |= 1u << l; st.nc++; }
+  st.status = bad ? QMPC_NAN_INPUT : (st.nc == 0 ? QMPC_NO_CONTACT : QMPC_OK);
+  st.iters = 0; st.it = 0;
+  st.active = st.status == QMPC_OK;
+  st.rho = 1.0; st.mu = 0.0; st.target = 0.0; st.last_ap = 0.0; st.last_ad = 0.0; st.last_step = 1e300;
+  st.ap = 1.0; st.ad = 1.0; st.uz = 0.0;
+  if (!st.active) return;
+  // C_mat * R (QuatMpc.cpp:47-52,203)
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      const double C0 = (r == 0) ? 1.0 : (r == 1 ? -1.0 : 0.0);
+      const double C1 = (r == 2) ? 1.0 : (r == 3 ? -1.0 : 0.0);
+      const double C2 = (r < 4) ? -P.mu : (r == 4 ? 1.0 : -1.0);
+      c.C(D::C_CR + 3 * r + cc) = C0 * raw[4 + cc] + C1 * raw[4 + 3 + cc] + C2 * raw[4 + 6 + cc];
+    }
+#pragma unroll
+  for (int i = 0; i < 3 * NL; ++i) c.C(D::C_FOOT + i) = raw[D::R_FOOT + i];
+  double gb[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { gb[a] = raw[4 + 6 + a] * (-9.81); c.C(D::C_GB + a) = gb[a]; }   // R'(0,0,-9.81)
+  {
+    // wd0 = Iinv (c x 5.204 g_body)  (AltroUtils.cpp:373-374,391)
+    const double com[3] = {0.0223, 0.002, -0.0005};
+    const double fg[3] = {5.204 * gb[0], 5.204 * gb[1], 5.204 * gb[2]};
+    const double mg[3] = {com[1] * fg[2] - com[2] * fg[1], com[2] * fg[0] - com[0] * fg[2], com[0] * fg[1] - com[1] * fg[0]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c.C(D::C_WD0 + a) = P.Iinv[3 * a] * mg[0] + P.Iinv[3 * a + 1] * mg[1] + P.Iinv[3 * a + 2] * mg[2];
+  }
+#pragma unroll
+  for (int i = 0; i < 13; ++i) c.C(D::C_REF + i) = (i < 9) ? raw[D::R_POS + i] : raw[D::R_QD + i - 9];
+  // x_init (QuatMpc.cpp:231-246; the angular velocity is dropped by the ';' at :242 unless drop_ang_vel = 0)
+  {
+    double x0[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+      double v = 0.0;
+      if (i >= 3 && i < 7) v = raw[i - 3];
+      else if (i >= 7 && i < 10) v = raw[13 + i - 7];
+      else if (i >= 10) v = P.drop_ang_vel ? 0.0 : raw[16 + i - 10];
+      x0[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 13; ++i) c.W(O.X + i) = x0[i];
+  }
+  // u_ref (QuatMpc.cpp:118-125): weight shared by the stance points; cone values there are the same at every knot
+  st.uz = 1.0 * P.mass * 9.81 / (double)st.nc;
+  double s0[6], l0[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double c0 = c.C(D::C_CR + 3 * i) * 0.0 + c.C(D::C_CR + 3 * i + 1) * 0.0 + c.C(D::C_CR + 3 * i + 2) * st.uz;
+    if (i == 4) c0 += -P.fz_max;
+    s0[i] = fmax(-c0, 1.0);
+    l0[i] = P.mu0 / s0[i];
+    c.C(D::C_RC0 + i) = c0 + s0[i];
+  }
+  double slsum = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) slsum += s0[i] * l0[i];
+  for (int k = 0; k < N; ++k)
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const bool on = (st.con >> l) & 1u;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) c.W(O.U + 3 * NL * k + 3 * l + a) = (on && a == 2) ? st.uz : 0.0;
+      if (on) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          c.W(O.S + 6 * NL * k + 6 * l + i) = s0[i];
+          c.W(O.LAM + 6 * NL * k + 6 * l + i) = l0[i];
+        }
+      }
+    }
+  st.mu = slsum / 6.0;      // mean of s*lambda over the enabled rows (every stance point and knot carries the same six)
+}
+
+// ---- pass A: apply the pending step (none at the first iteration) and roll the states out open loop -----------------
+// Slack / multiplier directions are recomputed from the stored trial increment dU exactly as pass C formed them (the
+// cone rows are linear in u), so nothing but dU has to be kept between the passes.  A shortened primal step scales
+// the increment; rc <- (1 - alpha_p) rc, exactly 0 after a full step.
+template <int NL>
+QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, LaneState& st, bool first) {
+  typedef LDim<NL> D;
+  const int N = P.N;
+  double gb[3], wd0[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { gb[a] = c.C(D::C_GB + a); wd0[a] = c.C(D::C_WD0 + a); }
+  double x[13], xn[13];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) x[i] = c.W(O.X + i);
+  const double ap = st.ap, ad = st.ad;
+  const bool full = ap >= 1.0;
+  const bool tapia = (ap >= 0.99) && (ad >= 0.99);
+  double slsum = 0.0;
+  for (int k = 0; k < N; ++k) {
+    double F[3] = {0, 0, 0}, wd[3] = {wd0[0], wd0[1], wd0[2]};
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (!((st.con >> l) & 1u)) continue;
+      double u[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+      if (!first) {
+        double du[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) du[a] = c.W(O.dU + 3 * NL * k + 3 * l + a);
+        double sv[6], lv[6];
+        const unsigned kap = load_rows<NL>(c, O, k, l, sv, lv);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const double jd = c.C(D::C_CR + 3 * i) * du[0] + c.C(D::C_CR + 3 * i + 1) * du[1] + c.C(D::C_CR + 3 * i + 2) * du[2];
+          const double kp = ((kap >> i) & 1u) ? 1.0 : 0.0;
+          const double dsv = -(jd + st.rho * c.C(D::C_RC0 + i));
+          const double dlv = (st.target - (1.0 + kp) * sv[i] * lv[i] - lv[i] * dsv) * ql_rcp(sv[i]);
+          const double s1 = sv[i] + ap * dsv;
+          const double l1 = lv[i] + ad * dlv;
+          // Tapia indicators (see ipm_apply in qmpc_kernels.hip): both ratios near 1/2 on a full Newton step
+          const bool sig = tapia && (s1 < 0.6 * sv[i]) && (l1 < 0.6 * lv[i]) &&
+                           (kp != 0.0 || ((s1 > 0.4 * sv[i]) && (l1 > 0.4 * lv[i])));
+          c.W(O.S + 6 * NL * k + 6 * l + i) = sig ? -s1 : s1;
+          c.W(O.LAM + 6 * NL * k + 6 * l + i) = l1;
+          slsum += s1 * l1;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          u[a] += full ? du[a] : ap * du[a];
+          c.W(O.U + 3 * NL * k + 3 * l + a) = u[a];
+        }
+      }
+      double B[9], r[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) r[a] = c.C(D::C_FOOT + 3 * l + a);
+      leg_bw0(P, r, B);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        F[a] += u[a];
+        wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
+      }
+    }
+    srbd_step_fw(P, gb, x, F, wd, xn);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) { x[i] = xn[i]; c.W(O.X + 13 * (k + 1) + i) = xn[i]; }
+  }
+  if (!first) {
+    st.mu = slsum / (double)(6 * N * st.nc);
+    st.rho = full ? 0.0 : (1.0 - ap) * st.rho;
+  }
+}
+
+// ---- pass B: expansions + Riccati backward pass in the wrench form; writes the 6 x 13 gains -------------------------
+// returns false when S6 = M'PM loses positive definiteness (QMPC_NOT_PD)
+template <int NL>
+QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneState& st) {
+  typedef LDim<NL> D;
+  const int N = P.N;
+  double Pm[78], pv[12];      // cost-to-go  1/2 dx'P dx + p'dx
+  bool ok = true;
+  const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
+  for (int k = N; k >= 0; --k) {
+    double x[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) x[i] = c.W(O.X + 13 * k + i);
+    // ---- cost expansion at knot k: gradient lx (12), attitude block lxx (3 x 3) ----
+    double lx[12], lxx[9];
+    {
+      double xr[13];
+      xref_at(P, c, D::C_REF, k, xr);
+      double lxf[13];
+#pragma unroll
+      for (int i = 0; i < 13; ++i) lxf[i] = P.Q[i] * (x[i] - xr[i]);
+      const double dq = xr[3] * x[3] + xr[4] * x[4] + xr[5] * x[5] + xr[6] * x[6];
+      const double sg = (dq >= 0.0) ? 1.0 : -1.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lxf[3 + r] += -sg * P.w * xr[3 + r];
+      const double qh = -(x[3] * lxf[3] + x[4] * lxf[4] + x[5] * lxf[5] + x[6] * lxf[6]);
+      double G[12];
+      quatG(&x[3], G);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lx[a] = lxf[a];
+        lx[6 + a] = lxf[7 + a];
+        lx[9 + a] = lxf[10 + a];
+        lx[3 + a] = G[a] * lxf[3] + G[3 + a] * lxf[4] + G[6 + a] * lxf[5] + G[9 + a] * lxf[6];
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          double s = (a == b) ? qh : 0.0;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) s += G[3 * t + a] * P.Q[3 + t] * G[3 * t + b];
+          lxx[3 * a + b] = s;
+        }
+    }
+    if (k == N) {
+#pragma unroll
+      for (int i = 0; i < 78; ++i) Pm[i] = 0.0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        Pm[SI(a, a)] = P.Q[a];
+        Pm[SI(6 + a, 6 + a)] = P.Q[7 + a];
+        Pm[SI(9 + a, 9 + a)] = P.Q[10 + a];
+#pragma unroll
+        for (int b = a; b < 3; ++b) Pm[SI(3 + a, 3 + b)] = lxx[3 * a + b];
+      }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) pv[i] = lx[i];
+      continue;
+    }
+    // ---- contact points: G = sum_l V_l D_l^-1 V_l' (6 x 6), r6 = sum_l V_l D_l^-1 g_l; wd for the expansion ----
+    double G6[21], r6[6];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) G6[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r6[i] = 0.0;
+    double wd[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) wd[a] = c.C(D::C_WD0 + a);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (!((st.con >> l) & 1u)) continue;
+      double u[3], r[3], B[9];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { u[a] = c.W(O.U + 3 * NL * k + 3 * l + a); r[a] = c.C(D::C_FOOT + 3 * l + a); }
+      leg_bw0(P, r, B);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
+      double sv[6], lv[6];
+      const unsigned kap = load_rows<NL>(c, O, k, l, sv, lv);
+      LegBlk lb;
+      leg_block<NL>(P, c, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
+      // V = [T ; Bw0 T] (6 x 3), Vt = V L^-T (columns), G += sum_j id_j vt_j vt_j', r6 += sum_j vt_j id_j y_j, y = L^-1 gq
+      double V[18];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) V[i] = lb.T[i];
+      mm(B, lb.T, &V[9]);
+      const double y0 = lb.gq[0], y1 = lb.gq[1] - lb.l10 * y0, y2 = lb.gq[2] - lb.l20 * y0 - lb.l21 * y1;
+      const double z0 = lb.id0 * y0, z1 = lb.id1 * y1, z2 = lb.id2 * y2;
+      double v0[6], v1[6], v2[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        v0[i] = V[3 * i];
+        v1[i] = V[3 * i + 1] - lb.l10 * v0[i];
+        v2[i] = V[3 * i + 2] - lb.l20 * v0[i] - lb.l21 * v1[i];
+        r6[i] += v0[i] * z0 + v1[i] * z1 + v2[i] * z2;
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const double a0 = lb.id0 * v0[i], a1 = lb.id1 * v1[i], a2 = lb.id2 * v2[i];
+#pragma unroll
+        for (int j = i; j < 6; ++j) G6[S6I(i, j)] += a0 * v0[j] + a1 * v1[j] + a2 * v2[j];
+      }
+    }
+    // ---- dynamics expansion (AltroUtils.cpp:78-110,153-168 in compact form): A1 = Abar_phiphi, A3 = Abar_phiw,
+    //      Wt = (h h / 4) Gn'Gm  (the attitude rows of M) ----
+    double A1[9], A3[9], Wt[9];
+    {
+      double xn[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xn[i] = c.W(O.X + 13 * (k + 1) + 3 + i);
+      double G0[12], Gm[12], Gn[12];
+      quatG(&x[3], G0);
+      double qm[4], wm[3];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        qm[r] = x[3 + r] + P.hh * (0.5 * (G0[3 * r] * x[10] + G0[3 * r + 1] * x[11] + G0[3 * r + 2] * x[12]));
+#pragma unroll
+      for (int a = 0; a < 3; ++a) wm[a] = x[10 + a] + P.hh * wd[a];
+      quatG(qm, Gm);
+      quatG(xn, Gn);
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        double g[4], gm[4], t0[4], t1[4], t2[4], ag[4], aw[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { g[r] = G0[3 * r + cc]; gm[r] = Gm[3 * r + cc]; }
+        omega_mul(&x[10], g, t0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t1[r] = g[r] + (0.5 * P.hh) * t0[r];
+        omega_mul(wm, t1, t2);
+        omega_mul(wm, g, t0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ag[r] = g[r] + P.hh * t2[r];
+          aw[r] = P.hh * ((0.5 * P.hh) * t0[r] + gm[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          A1[3 * r + cc] = Gn[r] * ag[0] + Gn[3 + r] * ag[1] + Gn[6 + r] * ag[2] + Gn[9 + r] * ag[3];
+          A3[3 * r + cc] = Gn[r] * aw[0] + Gn[3 + r] * aw[1] + Gn[6 + r] * aw[2] + Gn[9 + r] * aw[3];
+          Wt[3 * r + cc] = ((0.5 * P.hh) * P.h) * (Gn[r] * gm[0] + Gn[3 + r] * gm[1] + Gn[6 + r] * gm[2] + Gn[9 + r] * gm[3]);
+        }
+      }
+    }
+    // ---- MP = M'P (6 x 12) and y = M'p from the OLD cost-to-go; S6 = MP M; Y = MP Abar in place ----
+    double Y[6][13];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        Y[a][j] = m1 * Pm[SI(a, j)] + m2 * Pm[SI(6 + a, j)];
+        Y[3 + a][j] = Wt[a] * Pm[SI(3, j)] + Wt[3 + a] * Pm[SI(4, j)] + Wt[6 + a] * Pm[SI(5, j)] + P.h * Pm[SI(9 + a, j)];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      Y[a][12] = m1 * pv[a] + m2 * pv[6 + a];
+      Y[3 + a][12] = Wt[a] * pv[3] + Wt[3 + a] * pv[4] + Wt[6 + a] * pv[5] + P.h * pv[9 + a];
+    }
+    double S6[21];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        if (i <= a) S6[S6I(i, a)] = m1 * Y[i][a] + m2 * Y[i][6 + a];
+        if (i <= 3 + a)
+          S6[S6I(i, 3 + a)] = Y[i][3] * Wt[a] + Y[i][4] * Wt[3 + a] + Y[i][5] * Wt[6 + a] + P.h * Y[i][9 + a];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double f0 = Y[i][3], f1 = Y[i][4], f2 = Y[i][5];
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        Y[i][9 + cc] += f0 * A3[cc] + f1 * A3[3 + cc] + f2 * A3[6 + cc];
+        Y[i][6 + cc] += P.h * Y[i][cc];
+      }
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) Y[i][3 + cc] = f0 * A1[cc] + f1 * A1[3 + cc] + f2 * A1[6 + cc];
+    }
+    // ---- P <- Abar' P Abar, p <- Abar' p  in place on the symmetric storage ----
+    {
+      double F[9], W[9], t1[9], t2[9], t3[9], Rb[9];
+      rdblk(Pm, 1, 1, F);
+      rdblk(Pm, 1, 3, W);
+      mm(F, A3, t1);            // P_ff A3
+      mtm(A3, W, t2);           // A3' P_fw
+      rdblk(Pm, 3, 3, Rb);
+      mtm(A3, t1, t3);
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) Rb[3 * r + cc] += t3[3 * r + cc] + t2[3 * r + cc] + t2[3 * cc + r];
+      wrblk(Pm, 3, 3, Rb);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) W[i] += t1[i];
+      mtm(A1, W, Rb);
+      wrblk(Pm, 1, 3, Rb);      // A1'(P_ff A3 + P_fw)
+      mm(F, A1, t3);
+      mtm(A1, t3, Rb);
+      wrblk(Pm, 1, 1, Rb);      // A1' P_ff A1
+    }
+    {
+      double Bq[9], Vq[9], t4[9], Cq[9], Dq[9], Rb[9];
+      rdblk(Pm, 0, 1, Bq);      // P_pf
+      rdblk(Pm, 1, 2, Vq);      // P_fv
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) t4[3 * r + cc] = P.h * Bq[3 * cc + r] + Vq[3 * r + cc];
+      rdblk(Pm, 0, 3, Cq);      // P_pw
+      rdblk(Pm, 2, 3, Dq);      // P_vw
+      mtm(t4, A3, Rb);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Dq[i] += P.h * Cq[i] + Rb[i];
+      wrblk(Pm, 2, 3, Dq);
+      mtm(A1, t4, Rb);
+      wrblk(Pm, 1, 2, Rb);
+      mm(Bq, A3, Rb);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Cq[i] += Rb[i];
+      wrblk(Pm, 0, 3, Cq);
+      mm(Bq, A1, Rb);
+      wrblk(Pm, 0, 1, Rb);
+    }
+    {
+      double E[9], Vv[9], Rb[9];
+      rdblk(Pm, 0, 0, E);
+      rdblk(Pm, 0, 2, Vv);
+      rdblk(Pm, 2, 2, Rb);
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) Rb[3 * r + cc] += P.h * (Vv[3 * r + cc] + Vv[3 * cc + r]) + (P.h * P.h) * E[3 * r + cc];
+      wrblk(Pm, 2, 2, Rb);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Vv[i] += P.h * E[i];
+      wrblk(Pm, 0, 2, Vv);
+    }
+    {
+      const double f0 = pv[3], f1 = pv[4], f2 = pv[5];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        pv[9 + a] += A3[a] * f0 + A3[3 + a] * f1 + A3[6 + a] * f2;
+        pv[6 + a] += P.h * pv[a];
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) pv[3 + a] = A1[a] * f0 + A1[3 + a] * f1 + A1[6 + a] * f2;
+    }
+    // stage cost
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      Pm[SI(a, a)] += P.Q[a];
+      Pm[SI(6 + a, 6 + a)] += P.Q[7 + a];
+      Pm[SI(9 + a, 9 + a)] += P.Q[10 + a];
+#pragma unroll
+      for (int b = a; b < 3; ++b) Pm[SI(3 + a, 3 + b)] += lxx[3 * a + b];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pv[i] += lx[i];
+    // ---- S6 = L L' ----
+    double L[21], iL[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double d = S6[S6I(j, j)];
+#pragma unroll
+      for (int t = 0; t < j; ++t) d -= L[LI(j, t)] * L[LI(j, t)];
+      ok = ok && (d > 0.0);
+      const double inv = ql_rsqrt(d);
+      iL[j] = inv;
+      L[LI(j, j)] = d * inv;
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i) {
+        double s = S6[S6I(j, i)];
+#pragma unroll
+        for (int t = 0; t < j; ++t) s -= L[LI(i, t)] * L[LI(j, t)];
+        L[LI(i, j)] = s * inv;
+      }
+    }
+    // Yt = L^-1 [Y | y]
+#pragma unroll
+    for (int cc = 0; cc < 13; ++cc)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        double s = Y[i][cc];
+#pragma unroll
+        for (int t = 0; t < i; ++t) s -= L[LI(i, t)] * Y[t][cc];
+        Y[i][cc] = s * iL[i];
+      }
+    // H = I + L' G L = C C'
+    double Cc[21], iC[6];
+    {
+      double GL[6][6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = j; t < 6; ++t) s += G6[S6I(i, t)] * L[LI(t, j)];
+          GL[i][j] = s;
+        }
+      double H[21];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+          double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+          for (int t = i; t < 6; ++t) s += L[LI(t, i)] * GL[t][j];
+          H[S6I(i, j)] = s;
+        }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        double d = H[S6I(j, j)];
+#pragma unroll
+        for (int t = 0; t < j; ++t) d -= Cc[LI(j, t)] * Cc[LI(j, t)];
+        const double inv = ql_rsqrt(d);
+        iC[j] = inv;
+        Cc[LI(j, j)] = d * inv;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+          double s = H[S6I(j, i)];
+#pragma unroll
+          for (int t = 0; t < j; ++t) s -= Cc[LI(i, t)] * Cc[LI(j, t)];
+          Cc[LI(i, j)] = s * inv;
+        }
+      }
+    }
+    // P_aug -= Yt' [Yt | yt];  then column 12 becomes b = yt - L' r6
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+#pragma unroll
+      for (int j = i; j < 12; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) s += Y[t][i] * Y[t][j];
+        Pm[SI(i, j)] -= s;
+      }
+      double s = 0.0;
+#pragma unroll
+      for (int t = 0; t < 6; ++t) s += Y[t][i] * Y[t][12];
+      pv[i] -= s;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      double s = Y[i][12];
+#pragma unroll
+      for (int t = i; t < 6; ++t) s -= L[LI(t, i)] * r6[t];
+      Y[i][12] = s;
+    }
+    // Yh = C^-1 [Yt | b];  P_aug += Yh' Yh
+#pragma unroll
+    for (int cc = 0; cc < 13; ++cc)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        double s = Y[i][cc];
+#pragma unroll
+        for (int t = 0; t < i; ++t) s -= Cc[LI(i, t)] * Y[t][cc];
+        Y[i][cc] = s * iC[i];
+      }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+#pragma unroll
+      for (int j = i; j < 12; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) s += Y[t][i] * Y[t][j];
+        Pm[SI(i, j)] += s;
+      }
+      double s = 0.0;
+#pragma unroll
+      for (int t = 0; t < 6; ++t) s += Y[t][i] * Y[t][12];
+      pv[i] += s;
+    }
+    // gains [Xg | zeta0] = L C^-T Yh
+#pragma unroll
+    for (int cc = 0; cc < 13; ++cc) {
+#pragma unroll
+      for (int i = 5; i >= 0; --i) {
+        double s = Y[i][cc];
+#pragma unroll
+        for (int t = i + 1; t < 6; ++t) s -= Cc[LI(t, i)] * Y[t][cc];
+        Y[i][cc] = s * iC[i];
+      }
+#pragma unroll
+      for (int i = 5; i >= 0; --i) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t <= i; ++t) s += L[LI(i, t)] * Y[t][cc];
+        Y[i][cc] = s;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int cc = 0; cc < 13; ++cc) c.W(O.G + D::GAIN * k + 13 * i + cc) = Y[i][cc];
+  }
+  return ok;
+}
+
+// ---- pass C: closed-loop trial rollout (alpha = 1) + slack / multiplier directions + step lengths ----------------------
+template <int NL>
+QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, LaneState& st) {
+  typedef LDim<NL> D;
+  const int N = P.N;
+  double gb[3], wd0[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { gb[a] = c.C(D::C_GB + a); wd0[a] = c.C(D::C_WD0 + a); }
+  double xc[13], xn[13];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) xc[i] = c.W(O.X + i);
+  double ap = 1.0, ad = 1.0, stp = 0.0;
+  for (int k = 0; k < N; ++k) {
+    // dx = xc (-) X_k in error coordinates (inverse Cayley map, QuaternionUtils.cpp:16-18)
+    double dx[12];
+    {
+      double xo[13];
+#pragma unroll
+      for (int i = 0; i < 13; ++i) xo[i] = c.W(O.X + 13 * k + i);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        dx[a] = xc[a] - xo[a];
+        dx[6 + a] = xc[7 + a] - xo[7 + a];
+        dx[9 + a] = xc[10 + a] - xo[10 + a];
+      }
+      double G[12];
+      quatG(&xo[3], G);
+      const double isc = ql_rcp(xo[3] * xc[3] + xo[4] * xc[4] + xo[5] * xc[5] + xo[6] * xc[6]);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) dx[3 + a] = (G[a] * xc[3] + G[3 + a] * xc[4] + G[6 + a] * xc[5] + G[9 + a] * xc[6]) * isc;
+    }
+    double zeta[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      double s = c.W(O.G + D::GAIN * k + 13 * i + 12);
+#pragma unroll
+      for (int j = 0; j < 12; ++j) s += c.W(O.G + D::GAIN * k + 13 * i + j) * dx[j];
+      zeta[i] = s;
+    }
+    double F[3] = {0, 0, 0}, wd[3] = {wd0[0], wd0[1], wd0[2]};
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (!((st.con >> l) & 1u)) continue;
+      double u[3], r[3], B[9];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { u[a] = c.W(O.U + 3 * NL * k + 3 * l + a); r[a] = c.C(D::C_FOOT + 3 * l + a); }
+      leg_bw0(P, r, B);
+      double sv[6], lv[6];
+      const unsigned kap = load_rows<NL>(c, O, k, l, sv, lv);
+      LegBlk lb;
+      leg_block<NL>(P, c, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
+      // rhs = T'(zeta_f + Bw0' zeta_t) + gq;  du = -T Db^-1 rhs
+      double t[3], rh[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) t[a] = zeta[a] + B[a] * zeta[3] + B[3 + a] * zeta[4] + B[6 + a] * zeta[5];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) rh[a] = lb.T[a] * t[0] + lb.T[3 + a] * t[1] + lb.T[6 + a] * t[2] + lb.gq[a];
+      const double y0 = rh[0], y1 = rh[1] - lb.l10 * y0, y2 = rh[2] - lb.l20 * y0 - lb.l21 * y1;
+      const double z2 = y2 * lb.id2;
+      const double z1 = y1 * lb.id1 - lb.l21 * z2;
+      const double z0 = y0 * lb.id0 - lb.l10 * z1 - lb.l20 * z2;
+      double du[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        du[a] = -(lb.T[3 * a] * z0 + lb.T[3 * a + 1] * z1 + lb.T[3 * a + 2] * z2);
+        c.W(O.dU + 3 * NL * k + 3 * l + a) = du[a];
+        stp = fmax(stp, fabs(du[a]));
+        u[a] += du[a];
+      }
+      // directions and fraction-to-the-boundary ratios (ipm_directions in qmpc_kernels.hip)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const double jd = c.C(D::C_CR + 3 * i) * du[0] + c.C(D::C_CR + 3 * i + 1) * du[1] + c.C(D::C_CR + 3 * i + 2) * du[2];
+        const double kp = ((kap >> i) & 1u) ? 1.0 : 0.0;
+        const double dsv = -(jd + st.rho * c.C(D::C_RC0 + i));
+        const double dlv = (st.target - (1.0 + kp) * sv[i] * lv[i] - lv[i] * dsv) * ql_rcp(sv[i]);
+        if (dsv < 0.0) ap = fmin(ap, -P.tau * sv[i] * ql_rcp(dsv));
+        if (dlv < 0.0) ad = fmin(ad, -P.tau * lv[i] * ql_rcp(dlv));
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        F[a] += u[a];
+        wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
+      }
+    }
+    srbd_step_fw(P, gb, xc, F, wd, xn);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) xc[i] = xn[i];
+  }
+  st.ap = ap; st.ad = ad;
+  st.last_ap = ap; st.last_ad = ad;
+  st.last_step = stp;
+}
+
+// largest |rc0|: the slack residual of every enabled row is rho * rc0_i
+template <int NL>
+QL_FN double rc0_max(const Ctx& c) {
+  double m = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) m = fmax(m, fabs(c.C(LDim<NL>::C_RC0 + i)));
+  return m;
+}
+
+// ---- one interior-point iteration of one lane: the control flow of qmpc_solve_body.inc ------------------------------
+// returns true while the instance needs more iterations
+template <int NL>
+QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, LaneState& st) {
+  st.it += 1;
+  pass_A<NL>(P, c, O, st, st.it == 1);
+  const double resid = st.rho * rc0_max<NL>(c);
+  if (st.mu <= P.mu_final && resid <= P.tol_feas && st.last_step <= P.tol_step) { st.status = QMPC_OK; return false; }
+  if (st.it > P.iterations_max) { st.status = QMPC_MAX_ITER; return false; }
+  double sg = P.sigma;
+  const double amin = fmin(st.last_ap, st.last_ad);
+  if (st.it > 1 && amin >= 0.99) sg = P.sigma_fast;
+  else if (st.it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
+  else if (st.it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
+  st.target = sg * st.mu;
+  if (!pass_B<NL>(P, c, O, st)) { st.status = QMPC_NOT_PD; return false; }
+  pass_C<NL>(P, c, O, st);
+  st.iters = st.it;
+  return true;
+}
+
+// ---- outputs: GetInput(u, 0) (QuatMpc.cpp:264-265) and the info record -----------------------------------------------
+template <int NL>
+QL_FN void lane_finish(const DevParams& P, const Ctx& c, const WsOff& O, const LaneState& st, double* forces,
+                       qmpc_info* info) {
+  typedef LDim<NL> D;
+  const int N = P.N;
+  const bool solved = st.status != QMPC_NAN_INPUT && st.status != QMPC_NO_CONTACT;
+#pragma unroll
+  for (int j = 0; j < 3 * NL; ++j) forces[j] = (solved && ((st.con >> (j / 3)) & 1u)) ? c.W(O.U + j) : 0.0;
+  if (!info) return;
+  double J = 0.0, viol = 0.0;
+  if (solved) {
+    for (int k = 0; k <= N; ++k) {
+      double xr[13];
+      xref_at(P, c, D::C_REF, k, xr);
+      double dq = 0.0;
+#pragma unroll
+      for (int i = 0; i < 13; ++i) {
+        const double xv = c.W(O.X + 13 * k + i);
+        const double e = xv - xr[i];
+        J += 0.5 * P.Q[i] * e * e;
+        if (i >= 3 && i < 7) dq += xr[i] * xv;
+      }
+      J += P.w * (1.0 - fabs(dq));
+      if (k == N) break;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        if (!((st.con >> l) & 1u)) continue;
+        double u[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+        const double e2 = u[2] - st.uz;
+        J += 0.5 * P.R[(3 * l) % 12] * u[0] * u[0] + 0.5 * P.R[(3 * l + 1) % 12] * u[1] * u[1] +
+             0.5 * P.R[(3 * l + 2) % 12] * e2 * e2;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          double cv = c.C(D::C_CR + 3 * i) * u[0] + c.C(D::C_CR + 3 * i + 1) * u[1] + c.C(D::C_CR + 3 * i + 2) * u[2];
+          if (i == 4) cv += -P.fz_max;
+          viol = fmax(viol, fmax(cv, 0.0));
+        }
+      }
+    }
+  }
+  qmpc_info r = {st.status, st.iters, J, viol, solved ? st.last_step : 0.0, solved ? st.mu : 0.0};
+  *info = r;
+}
+
+}  // namespace lane
+}  // namespace qmpc

@@ -1,0 +1,35 @@
+// lane_core_host.cpp -- TEST INFRASTRUCTURE: g++ build of the lane-per-instance solver core
+// (quaternion-mpc_amd/csrc/qmpc_lane_core.h, the text hipcc compiles into qmpc_lane_kernel), one instance after the
+// other with unit strides.  It exists so that the numerics of the wrench-form elimination can be checked against the
+// oracle on a machine without a GPU (tests/test_lane_core_cpu.py); nothing in the product loads it.
+#include <cstdlib>
+#include <vector>
+
+#include "../../quaternion-mpc_amd/csrc/qmpc_lane_core.h"
+
+using namespace qmpc;
+using namespace qmpc::lane;
+
+template <int NL>
+static int solve_all(const DevParams& P, int batch, const double* rec, double* forces, qmpc_info* info) {
+  const WsOff O = make_wsoff<NL>(P.N);
+  std::vector<double> ws((size_t)O.total), cs((size_t)LDim<NL>::C_TOTAL);
+  for (int b = 0; b < batch; ++b) {
+    Ctx c = {ws.data(), 1, cs.data(), 1};
+    LaneState st;
+    lane_setup<NL>(P, c, O, rec + (size_t)b * LDim<NL>::REC, st);
+    if (st.active)
+      while (lane_iteration<NL>(P, c, O, st)) {}
+    lane_finish<NL>(P, c, O, st, forces + (size_t)b * 3 * NL, info ? info + b : nullptr);
+  }
+  return 0;
+}
+
+extern "C" int lane_host_solve(const qmpc_params* p, int batch, const double* rec, double* forces, qmpc_info* info) {
+  DevParams P;
+  const int st = fill_dev_params(p, &P);
+  if (st != QMPC_OK) return st;
+  if (p->model == QMPC_MODEL_QUAT8) return solve_all<8>(P, batch, rec, forces, info);
+  if (p->model == QMPC_MODEL_QUAT) return solve_all<4>(P, batch, rec, forces, info);
+  return QMPC_BAD_ARGUMENT;
+}
