@@ -195,7 +195,8 @@ class QmpcError(RuntimeError):
 
 def load_library(path: os.PathLike | None = None) -> C.CDLL:
     """dlopen the HIP library.  Raises (never falls back) when it is absent."""
-    p = Path(path) if path else LIB_PATH
+    # QMPC_LIB: a diagnostic build of the same library (tools/.prof/, phase counters compiled in)
+    p = Path(path) if path else Path(os.environ.get("QMPC_LIB") or LIB_PATH)
     # torch bundles its own libamdhip64.so.7; whichever HIP runtime is loaded
     # first serves the whole process.  Let torch (our device-memory / stream /
     # RCCL plumbing) load its runtime first so both sides share one.

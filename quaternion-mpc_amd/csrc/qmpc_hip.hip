@@ -13,6 +13,7 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +34,13 @@ hipError_t qmpc_warm_set_lds(int bytes);
 hipError_t qmpc_warm_launch(int var, int convex, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
                             const qmpc_input* in, const double* u_init, double* forces, qmpc_info* info, double* traj_u,
                             double* gws, int check_prev);
+
+// qmpc_lane.hip (third translation unit): the lane-per-instance kernel of large batches
+size_t qmpc_lane_ws_bytes(int N, int nl, unsigned slots);
+size_t qmpc_lane_scratch_bytes(int batch);
+int qmpc_lane_param_slots();
+hipError_t qmpc_lane_launch(int nl, int pslot, int batch, hipStream_t s, const void* dev_params, size_t dev_params_size, const void* in,
+                            double* forces, qmpc_info* info, double* ws, unsigned slots, int* scratch);
 
 struct qmpc_handle {
   qmpc_params params;
@@ -58,8 +66,17 @@ struct qmpc_handle {
   double* d_loop;         // staging of qmpc_loop_run (states and traces; grown on demand, freed with the handle)
   size_t loop_cap;        // its capacity in doubles
   double* d_gws;          // [max_batch][N*(156+84)] workspace of the global-gains variant
-  int variant;            // 0: auto, 1: LDS gains, 2: global gains (env QMPC_VARIANT)
+  int variant;            // 0: auto, 1: LDS gains, 2: global gains, 3: + slack arrays, 4: lane per instance (env QMPC_VARIANT)
+  double* d_lane_ws;      // structure-of-arrays workspace of the lane-per-instance kernel: [elements][lane_slots], on first use
+  unsigned lane_slots;    // resident lanes it is sized for
+  int* d_lane_scratch;    // counting sort of the batch on the stance mask: hist | cursor | perm[max_batch]
+  int lane_min_batch;     // batches from this size on take the lane-per-instance kernel (env QMPC_LANE_MIN)
+  int lane_sort;          // 1: order the batch by stance mask first (env QMPC_LANE_SORT)
+  int lane_pslot;         // this handle's slot in the lane kernel's constant-memory parameter table
 };
+
+constexpr unsigned kLaneMaxSlots = 1024 * 64;   // one wavefront per SIMD of the chip
+constexpr int kLaneMinBatch = 1 << 30;           // auto switch-over (set from measurements; QMPC_LANE_MIN overrides)
 
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
@@ -262,6 +279,12 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
   {
     const char* v = std::getenv("QMPC_VARIANT");
     h->variant = v ? std::atoi(v) : 0;
+    const char* lm = std::getenv("QMPC_LANE_MIN");
+    h->lane_min_batch = lm ? std::atoi(lm) : kLaneMinBatch;
+    const char* ls = std::getenv("QMPC_LANE_SORT");
+    h->lane_sort = ls ? std::atoi(ls) : 1;
+    static std::atomic<int> next_slot{0};     // handles share the table round-robin (a slot is rewritten before every launch)
+    h->lane_pslot = next_slot.fetch_add(1) % qmpc_lane_param_slots();
   }
   const qmpc_status rs = create_resources(h, N, nl, nu);
   if (rs != QMPC_OK) { qmpc_destroy(h); return rs; }   // release whatever was created
@@ -275,6 +298,8 @@ void qmpc_destroy(qmpc_handle* h) {
   if (h->d_in) (void)hipFree(h->d_in);
   if (h->d_forces) (void)hipFree(h->d_forces);
   if (h->d_gws) (void)hipFree(h->d_gws);
+  if (h->d_lane_ws) (void)hipFree(h->d_lane_ws);
+  if (h->d_lane_scratch) (void)hipFree(h->d_lane_scratch);
   if (h->d_leg) (void)hipFree(h->d_leg);
   if (h->d_loop_row) (void)hipFree(h->d_loop_row);
   if (h->d_loop) (void)hipFree(h->d_loop);
@@ -310,6 +335,28 @@ static int pick_variant(const qmpc_handle* h, int32_t batch) {
 }
 static bool use_global_gains(const qmpc_handle* h, int32_t batch) { return pick_variant(h, batch) >= 1; }
 
+// Large batches of the converged mode go to the lane-per-instance kernel (qmpc_lane.hip): one lane per instance, the
+// working set streamed through a structure-of-arrays HBM workspace sized by the RESIDENT lanes (<= 1024 wavefronts).
+// It returns forces and info only; calls that ask for trajectories keep the wave-per-instance kernels.
+static bool use_lane(const qmpc_handle* h, int32_t batch, const double* d_tu, const double* d_tx) {
+  if (h->params.mode != QMPC_MODE_CONVERGED || h->params.model == QMPC_MODEL_CONVEX || d_tu || d_tx) return false;
+  if (h->variant == 4) return true;
+  return h->variant == 0 && batch >= h->lane_min_batch;
+}
+static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces, qmpc_info* d_info,
+                               hipStream_t s) {
+  const int nl = model_nl(h->params.model);
+  if (!h->d_lane_ws) {
+    const unsigned want = (unsigned)(((size_t)h->max_batch + 63) / 64) * 64;
+    h->lane_slots = want < kLaneMaxSlots ? want : kLaneMaxSlots;
+    HIP_TRY(hipMalloc(&h->d_lane_ws, qmpc_lane_ws_bytes(h->params.horizon, nl, h->lane_slots)));
+    HIP_TRY(hipMalloc(&h->d_lane_scratch, qmpc_lane_scratch_bytes(h->max_batch)));
+  }
+  HIP_TRY(qmpc_lane_launch(nl, h->lane_pslot, (int)batch, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, h->d_lane_ws, h->lane_slots,
+                           h->lane_sort ? h->d_lane_scratch : nullptr));
+  return QMPC_OK;
+}
+
 static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces,
                                 qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s, bool timed = true) {
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;   // the gains workspace is sized by max_batch
@@ -332,6 +379,15 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
     }
 #undef QMPC_LAUNCH_REF
     HIP_TRY(hipGetLastError());
+    if (timed) {
+      HIP_TRY(hipEventRecord(h->ev1, s));
+      h->timed = true;
+    }
+    return QMPC_OK;
+  }
+  if (use_lane(h, batch, d_tu, d_tx)) {
+    const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s);
+    if (ls != QMPC_OK) return ls;
     if (timed) {
       HIP_TRY(hipEventRecord(h->ev1, s));
       h->timed = true;

@@ -1,0 +1,325 @@
+// qmpc_lane.hip -- third translation unit of libqmpc_hip.so: the lane-per-instance solve kernel for large batches
+// (qmpc_lane_core.h has the algorithm and the reference citations) and its launcher.
+//
+// Mapping.  A 64-lane workgroup (one wavefront) is persistent: it owns one block of the HBM workspace for the whole
+// launch and walks the batch in strides of the resident lane count, so the workspace is sized by the number of RESIDENT
+// lanes (at most 1024 wavefronts x 64), not by the batch.  A block is laid out [element][lane]: every wave-level load /
+// store is one contiguous 512-byte row, consecutive elements are consecutive rows (one base register, immediate
+// offsets), and a wave streams through one contiguous region (DRAM pages, TLB).  The cost-to-go matrix of the backward
+// pass lives in LDS (78 rows of 512 bytes per wave: 4 waves per CU use 156 of the 160 KB), the per-instance constants in
+// registers.  There is no cross-lane operation anywhere in the solve; lanes whose instance has converged idle until the
+// slowest instance of the wave is done.
+//
+// Contact patterns.  The per-contact-point code is guarded by a per-lane stance test; the hardware skips a guarded
+// region when no lane of the wave needs it.  A counting sort on the stance mask (qmpc_lane_sort_*) orders the batch so
+// that a wave's 64 instances share their pattern (trot pairs do half the per-point work of a four-stance instance).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "qmpc_lane_core.h"
+
+namespace qmpc {
+namespace lane {
+
+constexpr int kLaneWave = 64;
+constexpr int kParamSlots = 64;
+
+// Parameter blocks live in constant memory, one slot per handle: every pass reads what it needs with scalar loads and
+// nothing of it occupies registers across the passes.
+__constant__ DevParams ql_params[kParamSlots];
+
+#define QL_PRIV_AS __attribute__((address_space(5)))
+
+// The three passes (and set-up / outputs) are compiled as SEPARATE functions: each gets the register file to itself --
+// inlined into one kernel body the allocator spilled several hundred registers around the backward pass.  The
+// instance's constants and scalars are handed over through the lane's private memory (read once per pass); wave-uniform
+// arguments arrive in vector registers by the calling convention and are made scalar again with v_readfirstlane.
+// struct <-> private memory, word by word (the implicit copy operations of a class do not take address-space pointers)
+template <class T>
+__device__ __forceinline__ void priv_load(T& dst, QL_PRIV_AS const T* src) {
+  static_assert(sizeof(T) % 4 == 0, "dword copy");
+  QL_PRIV_AS const unsigned* s = (QL_PRIV_AS const unsigned*)src;
+  unsigned* d = reinterpret_cast<unsigned*>(&dst);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i) d[i] = s[i];
+}
+template <class T>
+__device__ __forceinline__ void priv_store(QL_PRIV_AS T* dst, const T& src) {
+  static_assert(sizeof(T) % 4 == 0, "dword copy");
+  QL_PRIV_AS unsigned* d = (QL_PRIV_AS unsigned*)dst;
+  const unsigned* s = reinterpret_cast<const unsigned*>(&src);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i) d[i] = s[i];
+}
+
+struct PassArgs {
+  int pslot;
+  unsigned ws_lo, ws_hi;     // this wave's workspace block
+  unsigned lane8;            // 8 x lane
+};
+template <int NL>
+__device__ __forceinline__ Ctx pass_ctx(const PassArgs& a) {
+  extern __shared__ __attribute__((aligned(16))) double ql_lds[];
+  const unsigned lo = __builtin_amdgcn_readfirstlane(a.ws_lo), hi = __builtin_amdgcn_readfirstlane(a.ws_hi);
+  QL_GLOBAL_AS double* ws = reinterpret_cast<QL_GLOBAL_AS double*>(((unsigned long long)hi << 32) | lo);
+  Ctx c = {ws, 8u * kLaneWave, a.lane8, (QL_LDS_AS double*)ql_lds, 8u * kLaneWave, a.lane8};
+  return c;
+}
+template <int NL>
+__device__ __noinline__ void call_setup(PassArgs a, unsigned long long rec, QL_PRIV_AS LaneK<NL>* Kp, QL_PRIV_AS LaneState* sp) {
+  const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
+  const Ctx c = pass_ctx<NL>(a);
+  const WsOff O = make_wsoff<NL>(P.N);
+  LaneK<NL> K;
+  LaneState st;
+  lane_setup<NL>(P, c, O, reinterpret_cast<const double*>(rec), K, st);
+  priv_store(Kp, K);
+  priv_store(sp, st);
+}
+template <int NL>
+__device__ __noinline__ void call_A(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS LaneState* sp) {
+  const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
+  const Ctx c = pass_ctx<NL>(a);
+  const WsOff O = make_wsoff<NL>(P.N);
+  LaneK<NL> K;
+  priv_load(K, Kp);
+  LaneState st;
+  priv_load(st, (QL_PRIV_AS const LaneState*)sp);
+  st.it += 1;
+  pass_A<NL>(P, c, O, K, st, st.it == 1);
+  priv_store(sp, st);
+}
+template <int NL>
+__device__ __noinline__ bool call_B(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS LaneState* sp) {
+  const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
+  const Ctx c = pass_ctx<NL>(a);
+  const WsOff O = make_wsoff<NL>(P.N);
+  LaneK<NL> K;
+  priv_load(K, Kp);
+  LaneState st;
+  priv_load(st, (QL_PRIV_AS const LaneState*)sp);
+  const bool ok = pass_B<NL>(P, c, O, K, st);
+#if defined(QL_PROFILE)
+  priv_store(sp, st);
+#endif
+  return ok;
+}
+template <int NL>
+__device__ __noinline__ void call_C(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS LaneState* sp) {
+  const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
+  const Ctx c = pass_ctx<NL>(a);
+  const WsOff O = make_wsoff<NL>(P.N);
+  LaneK<NL> K;
+  priv_load(K, Kp);
+  LaneState st;
+  priv_load(st, (QL_PRIV_AS const LaneState*)sp);
+  pass_C<NL>(P, c, O, K, st);
+  st.iters = st.it;
+  priv_store(sp, st);
+}
+template <int NL>
+__device__ __noinline__ void call_finish(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp,
+                                         unsigned long long forces, unsigned long long info) {
+  const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
+  const Ctx c = pass_ctx<NL>(a);
+  const WsOff O = make_wsoff<NL>(P.N);
+  LaneK<NL> K;
+  priv_load(K, Kp);
+  LaneState st;
+  priv_load(st, sp);
+  lane_finish<NL>(P, c, O, K, st, reinterpret_cast<double*>(forces), reinterpret_cast<qmpc_info*>(info));
+}
+
+template <int NL>
+__global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const double* __restrict__ in,
+                                                              double* __restrict__ forces, qmpc_info* __restrict__ info,
+                                                              int batch, double* __restrict__ ws, unsigned slots,
+                                                              const int* __restrict__ perm, long long* __restrict__ prof) {
+  typedef LDim<NL> D;
+  const int lane = threadIdx.x;
+  const DevParams& P = ql_params[pslot];
+  const size_t block_elems = (size_t)make_wsoff<NL>(P.N).total * kLaneWave;
+  const unsigned long long wsb = reinterpret_cast<unsigned long long>(ws + (size_t)blockIdx.x * block_elems);
+  const PassArgs a = {pslot, (unsigned)wsb, (unsigned)(wsb >> 32), 8u * (unsigned)lane};
+  LaneK<NL> K;
+  LaneState st;
+  QL_PRIV_AS LaneK<NL>* Kp = (QL_PRIV_AS LaneK<NL>*)&K;
+  QL_PRIV_AS LaneState* sp = (QL_PRIV_AS LaneState*)&st;
+  for (long long base = (long long)blockIdx.x * kLaneWave; base < batch; base += slots) {
+    const long long pos = base + lane;
+    const bool valid = pos < batch;
+    const int b = valid ? (perm ? perm[pos] : (int)pos) : 0;
+    bool active = false;
+    if (valid) {
+      call_setup<NL>(a, reinterpret_cast<unsigned long long>(in + (size_t)b * D::REC), Kp, sp);
+      active = st.active;
+    }
+#if defined(QL_PROFILE)
+    for (int i = 0; i < LP_COUNT; ++i) st.t[i] = 0;
+    st.last = clock64();
+    int rounds = 0;
+#endif
+    while (__any(active)) {
+      if (active) {
+        // one interior-point iteration (the control flow of lane_iteration in qmpc_lane_core.h)
+        call_A<NL>(a, Kp, sp);
+        double resid;
+        {
+          double cr[18], s0[6], rc0[6];
+          cone_rows(P, K.rot, cr);
+          initial_rows(P, cr, st.uz, s0, rc0);
+          double m = 0.0;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) m = fmax(m, fabs(rc0[i]));
+          resid = st.rho * m;
+        }
+        if (st.mu <= P.mu_final && resid <= P.tol_feas && st.last_step <= P.tol_step) { st.status = QMPC_OK; active = false; }
+        else if (st.it > P.iterations_max) { st.status = QMPC_MAX_ITER; active = false; }
+        else {
+          double sg = P.sigma;
+          const double amin = fmin(st.last_ap, st.last_ad);
+          if (st.it > 1 && amin >= 0.99) sg = P.sigma_fast;
+          else if (st.it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
+          else if (st.it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
+          st.target = sg * st.mu;
+          if (!call_B<NL>(a, Kp, sp)) { st.status = QMPC_NOT_PD; active = false; }
+          else call_C<NL>(a, Kp, sp);
+        }
+      }
+#if defined(QL_PROFILE)
+      rounds++;
+#endif
+    }
+    if (valid)
+      call_finish<NL>(a, Kp, sp, reinterpret_cast<unsigned long long>(forces + (size_t)b * D::NU),
+                      info ? reinterpret_cast<unsigned long long>(info + b) : 0ull);
+#if defined(QL_PROFILE)
+    if (prof && base < (long long)slots) {      // first round of every wave; lane 0's clock, every lane's own iteration count
+      if (lane == 0) {
+        for (int i = 0; i < LP_COUNT; ++i) prof[16 * blockIdx.x + i] = st.t[i];
+        prof[16 * blockIdx.x + 15] = st.it;      // lane 0's own iterations: its clock stops when its instance is done
+        prof[16 * blockIdx.x + 14] = rounds;
+      }
+    }
+#endif
+  }
+}
+
+// ---- counting sort of the batch on the stance mask (keys 0 .. 2^NL - 1) ---------------------------------------------------
+// scratch layout (ints): hist[256] | cursor[256] | perm[batch]
+template <int NL>
+__global__ __launch_bounds__(256) void qmpc_lane_sort_count(const double* __restrict__ in, int batch, int* __restrict__ scratch) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= batch) return;
+  const double* rec = in + (size_t)b * LDim<NL>::REC + LDim<NL>::R_CON;
+  unsigned key = 0;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) key |= (rec[l] != 0.0) ? (1u << l) : 0u;
+  atomicAdd(&scratch[key], 1);
+}
+__global__ __launch_bounds__(64) void qmpc_lane_sort_scan(int* __restrict__ scratch) {
+  if (threadIdx.x != 0) return;
+  int run = 0;
+  for (int k = 0; k < 256; ++k) {
+    const int n = scratch[k];
+    scratch[256 + k] = run;
+    run += n;
+  }
+}
+template <int NL>
+__global__ __launch_bounds__(256) void qmpc_lane_sort_scatter(const double* __restrict__ in, int batch, int* __restrict__ scratch) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= batch) return;
+  const double* rec = in + (size_t)b * LDim<NL>::REC + LDim<NL>::R_CON;
+  unsigned key = 0;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) key |= (rec[l] != 0.0) ? (1u << l) : 0u;
+  const int at = atomicAdd(&scratch[256 + key], 1);
+  scratch[512 + at] = b;
+}
+
+}  // namespace lane
+}  // namespace qmpc
+
+using namespace qmpc;
+using namespace qmpc::lane;
+
+// called from qmpc_hip.hip (declared there); hidden: not part of the C ABI
+__attribute__((visibility("hidden"))) size_t qmpc_lane_ws_bytes(int N, int nl, unsigned slots) {
+  return sizeof(double) * lane_ws_elements(N, nl) * (size_t)slots;
+}
+__attribute__((visibility("hidden"))) size_t qmpc_lane_scratch_bytes(int batch) { return sizeof(int) * (512 + (size_t)batch); }
+
+// slots: resident lanes (multiple of 64); scratch: qmpc_lane_scratch_bytes(batch) bytes, or null for no sort
+// pslot: the handle's slot in the constant-memory parameter table (qmpc_lane_param_slots() of them); the block is copied
+// there stream-ordered before every launch, so qmpc_set_params takes effect like for the other kernels
+__attribute__((visibility("hidden"))) int qmpc_lane_param_slots() { return kParamSlots; }
+__attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int pslot, int batch, hipStream_t s, const void* dev_params,
+                                                                   size_t dev_params_size, const void* in, double* forces,
+                                                                   qmpc_info* info, double* ws, unsigned slots, int* scratch) {
+  if (dev_params_size != sizeof(DevParams) || (nl != 4 && nl != 8) || slots % kLaneWave || pslot < 0 || pslot >= kParamSlots)
+    return hipErrorInvalidValue;
+  DevParams P;
+  memcpy(&P, dev_params, sizeof P);
+  {
+    const hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(ql_params), dev_params, sizeof(DevParams), sizeof(DevParams) * (size_t)pslot,
+                                                hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+  }
+  const double* rec = static_cast<const double*>(in);
+  const int* perm = nullptr;
+  if (scratch) {
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(int) * 512, s);
+    if (e != hipSuccess) return e;
+    const unsigned blocks = (unsigned)((batch + 255) / 256);
+    if (nl == 8) {
+      hipLaunchKernelGGL(qmpc_lane_sort_count<8>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch);
+      hipLaunchKernelGGL(qmpc_lane_sort_scan, dim3(1), dim3(64), 0, s, scratch);
+      hipLaunchKernelGGL(qmpc_lane_sort_scatter<8>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch);
+    } else {
+      hipLaunchKernelGGL(qmpc_lane_sort_count<4>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch);
+      hipLaunchKernelGGL(qmpc_lane_sort_scan, dim3(1), dim3(64), 0, s, scratch);
+      hipLaunchKernelGGL(qmpc_lane_sort_scatter<4>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch);
+    }
+    perm = scratch + 512;
+  }
+  const unsigned need = (unsigned)(((size_t)batch + kLaneWave - 1) / kLaneWave);
+  const unsigned waves = need < slots / kLaneWave ? need : slots / kLaneWave;
+  const unsigned used = waves * kLaneWave;     // lanes of this launch: batch stride and workspace stride
+  const size_t lds = sizeof(double) * kLaneWave * LDim<4>::PLDS;
+  long long* prof = nullptr;
+#if defined(QL_PROFILE)
+  static long long* d_prof = nullptr;      // diagnostic build only: per-wave phase cycles of the first round, printed after the launch
+  if (!d_prof && hipMalloc(&d_prof, sizeof(long long) * 16 * 1024) != hipSuccess) return hipErrorOutOfMemory;
+  prof = d_prof;
+  (void)hipMemsetAsync(d_prof, 0, sizeof(long long) * 16 * 1024, s);
+#endif
+  if (nl == 8)
+    hipLaunchKernelGGL(qmpc_lane_kernel<8>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, perm, prof);
+  else
+    hipLaunchKernelGGL(qmpc_lane_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, perm, prof);
+#if defined(QL_PROFILE)
+  {
+    static long long hp[16 * 1024];
+    if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(hp, d_prof, sizeof hp, hipMemcpyDeviceToHost) == hipSuccess) {
+      static const char* names[LP_COUNT] = {"A", "B.head", "B.legs", "B.expand", "B.MP", "B.congr", "B.fact", "B.upd", "B.gain",
+                                            "C.head", "C.legs", "C.step"};
+      const unsigned nw = waves < 1024 ? waves : 1024;
+      double tot = 0.0, sum[LP_COUNT] = {0}, rounds = 0.0, wrounds = 0.0;
+      for (unsigned w = 0; w < nw; ++w) {
+        for (int i = 0; i < LP_COUNT; ++i) sum[i] += (double)hp[16 * w + i];
+        rounds += (double)hp[16 * w + 15];
+        wrounds += (double)hp[16 * w + 14];
+      }
+      for (int i = 0; i < LP_COUNT; ++i) tot += sum[i];
+      std::fprintf(stderr, "lane profile: batch %d N %d waves %u, rounds per wave %.1f (lane 0: %.1f iterations), cycles per knot-iteration %.0f\n",
+                   batch, P.N, waves, wrounds / nw, rounds / nw, tot / rounds / P.N);
+      for (int i = 0; i < LP_COUNT; ++i)
+        std::fprintf(stderr, "  %-9s %7.0f cycles per knot-iteration  %5.1f %%\n", names[i], sum[i] / rounds / P.N, 100.0 * sum[i] / tot);
+    }
+  }
+#endif
+  return hipGetLastError();
+}

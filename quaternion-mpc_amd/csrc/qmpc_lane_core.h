@@ -21,6 +21,11 @@
 // iteration instead of the 35 kflop of the dense recursion -- and what is stored between the backward and the
 // forward pass is the 6 x 13 wrench-space gain, not 3NL x 13.
 //
+// Where things live (device): the cost-to-go matrix P of the backward pass (78 doubles) in LDS, one 512-byte row per
+// entry; the instance's constants (rotation, contact points, references: 37 doubles, 49 for the 8-point model) in
+// registers for the whole solve; everything indexed by knot in the HBM workspace, laid out [wave][element][lane]: a
+// wavefront's working set is one contiguous block and consecutive elements are consecutive 512-byte rows.
+//
 // The file is plain C++ on purpose: hipcc compiles it into qmpc_lane_kernel (qmpc_lane.hip), g++ compiles the very
 // same text into the CPU numerics test of the core (tests/lane_core_host.cpp; test infrastructure, never a product
 // path -- the product has no CPU fallback).
@@ -34,9 +39,11 @@
 
 #if defined(__HIPCC__)
 #define QL_FN __device__ __forceinline__
+#define QL_HD __host__ __device__ __forceinline__
 #define QL_DEVICE 1
 #else
 #define QL_FN inline
+#define QL_HD inline
 #define QL_DEVICE 0
 #endif
 
@@ -70,18 +77,25 @@ struct LDim {
   static constexpr int NU = 3 * NL, NC = 6 * NL;
   static constexpr int REC = 32 + 4 * NL;
   static constexpr int R_FOOT = 19, R_CON = 19 + 3 * NL, R_POS = 19 + 4 * NL, R_QD = R_POS + 9;
-  // constants of one instance (LDS on the device: slot i of lane `lane` = cs[64 i + lane])
-  static constexpr int C_CR = 0, C_FOOT = 18, C_GB = C_FOOT + 3 * NL, C_WD0 = C_GB + 3, C_REF = C_WD0 + 3,
-                       C_RC0 = C_REF + 13, C_TOTAL = C_RC0 + 6;
+  static constexpr int PLDS = 78;     // entries of the symmetric cost-to-go matrix kept in lane-private LDS rows
   static constexpr int GAIN = 78;     // wrench-space gain [Xg | zeta0], 6 x 13
 };
 
-// workspace offsets in ELEMENTS of one lane's column (element e of lane s lives at ws[e * stride + s])
+// constants of one instance (registers)
+template <int NL>
+struct LaneK {
+  double rot[9];         // body -> world rotation, row-major (cone rows are C_mat * R, QuatMpc.cpp:47-52,203)
+  double foot[3 * NL];   // contact points in the body frame
+  double wd0[3];         // Iinv (c x 5.204 g_body)   (AltroUtils.cpp:373-374,391)
+  double refp[13];       // reference parameters: pos vel acc quat_d
+};
+
+// workspace offsets in ELEMENTS of one lane's column (element e of lane s of a wave lives at wave_base[64 e + s])
 struct WsOff {
   int X, U, dU, S, LAM, G, total;
 };
 template <int NL>
-QL_FN WsOff make_wsoff(int N) {
+QL_HD WsOff make_wsoff(int N) {
   WsOff o;
   int p = 0;
   o.X = p; p += 13 * (N + 1);
@@ -95,17 +109,52 @@ QL_FN WsOff make_wsoff(int N) {
 }
 inline size_t lane_ws_elements(int N, int nl) { return nl == 8 ? (size_t)make_wsoff<8>(N).total : (size_t)make_wsoff<4>(N).total; }
 
+// Addresses: a wave-uniform base (scalar registers, constant for the whole solve) plus one 32-bit per-lane byte offset
+// whose element part is a small multiple of the row size -- consecutive elements differ by an immediate.  On the device
+// the pointers carry their address spaces (global / LDS), so that the accesses stay global_load / ds_read when the
+// passes are compiled as separate functions.
+#if QL_DEVICE
+#define QL_GLOBAL_AS __attribute__((address_space(1)))
+#define QL_LDS_AS __attribute__((address_space(3)))
+#else
+#define QL_GLOBAL_AS
+#define QL_LDS_AS
+#endif
 struct Ctx {
-  double* ws;      // this lane's column of the workspace
-  size_t wstride;  // lanes in the workspace
-  double* cs;      // this lane's constants
-  int cstride;
-  QL_FN double& W(int e) const { return ws[(size_t)e * wstride]; }
-  QL_FN double& C(int i) const { return cs[i * cstride]; }
+  QL_GLOBAL_AS double* ws;   // this wave's block of the workspace: [element][lane]
+  unsigned wrow;             // bytes per workspace row (8 x lanes per wave)
+  unsigned woff;             // this lane's byte offset inside a row
+  QL_LDS_AS double* pl;      // lane-private rows for the cost-to-go matrix (LDS): [entry][lane]
+  unsigned prow, poff;
+  QL_FN QL_GLOBAL_AS double& W(int e) const {
+    return *reinterpret_cast<QL_GLOBAL_AS double*>(reinterpret_cast<QL_GLOBAL_AS char*>(ws) + ((unsigned)e * wrow + woff));
+  }
+  QL_FN QL_LDS_AS double& PL(int i) const {
+    return *reinterpret_cast<QL_LDS_AS double*>(reinterpret_cast<QL_LDS_AS char*>(pl) + ((unsigned)i * prow + poff));
+  }
 };
+
+// optional phase-level cycle accounting (diagnostic builds: -DQL_PROFILE; tools/lane_prof.sh)
+enum { LP_A = 0, LP_B_HEAD, LP_B_LEGS, LP_B_EXPAND, LP_B_MP, LP_B_CONGR, LP_B_FACT, LP_B_UPD, LP_B_GAIN, LP_C_HEAD, LP_C_LEGS,
+       LP_C_STEP, LP_COUNT };
+// compiler-level memory fence: values read from the lane-private rows before it are re-read after it instead of being
+// kept in registers across a phase boundary (the point of keeping P in LDS is to get it OUT of the register file)
+#if QL_DEVICE
+#define QL_FENCE() asm volatile("" ::: "memory")
+#else
+#define QL_FENCE() do { } while (0)
+#endif
+#if defined(QL_PROFILE) && QL_DEVICE
+#define QL_TICK(st, ph) do { const long long now_ = clock64(); (st).t[ph] += now_ - (st).last; (st).last = now_; } while (0)
+#else
+#define QL_TICK(st, ph) do { } while (0)
+#endif
 
 // per-instance scalars (registers)
 struct LaneState {
+#if defined(QL_PROFILE) && QL_DEVICE
+  long long t[LP_COUNT], last;
+#endif
   unsigned con;        // stance mask
   int nc;              // stance count
   int status, iters, it;
@@ -127,19 +176,19 @@ constexpr int S6I(int i, int j) { return i <= j ? S6_(i, j) : S6_(j, i); }
 // lower triangle of a 6 x 6, row-major: (i,j), j <= i
 constexpr int LI(int i, int j) { return i * (i + 1) / 2 + j; }
 
-QL_FN void rdblk(const double* P, int a, int b, double M[9]) {
+QL_FN void rdblk(const Ctx& cx, int a, int b, double M[9]) {
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) M[3 * r + c] = P[SI(3 * a + r, 3 * b + c)];
+    for (int c = 0; c < 3; ++c) M[3 * r + c] = cx.PL(SI(3 * a + r, 3 * b + c));
 }
 // a < b: all nine entries; a == b: the upper triangle
-QL_FN void wrblk(double* P, int a, int b, const double M[9]) {
+QL_FN void wrblk(const Ctx& cx, int a, int b, const double M[9]) {
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-      if (a != b || r <= c) P[SI(3 * a + r, 3 * b + c)] = M[3 * r + c];
+      if (a != b || r <= c) cx.PL(SI(3 * a + r, 3 * b + c)) = M[3 * r + c];
 }
 // C = A B, C = A' B (3 x 3 row-major)
 QL_FN void mm(const double A[9], const double B[9], double C[9]) {
@@ -209,18 +258,39 @@ QL_FN void srbd_step_fw(const DevParams& P, const double gb[3], const double* x,
 }
 
 // reference state of knot k (QuatMpc.cpp:148-176) from refp = pos(3) vel(3) acc(3) quat_d(4)
-QL_FN void xref_at(const DevParams& P, const Ctx& c, int base, int k, double* xr) {
+QL_FN void xref_at(const DevParams& P, const double rp[13], int k, double* xr) {
   const double t = (double)k * P.h_ref;
   const double h_ms = P.h_ref * 1000.0;
-  double rp[13];
-#pragma unroll
-  for (int i = 0; i < 13; ++i) rp[i] = c.C(base + i);
   xr[0] = rp[0] + rp[3] * k * h_ms / 1000.0 + 0.5 * rp[6] * t * t;
   xr[1] = rp[1] + rp[4] * k * h_ms / 1000.0 + 0.5 * rp[7] * t * t;
   xr[2] = rp[2] + 0.5 * rp[8] * t * t;
   xr[3] = rp[9]; xr[4] = rp[10]; xr[5] = rp[11]; xr[6] = rp[12];
   xr[7] = rp[3] + rp[6] * t; xr[8] = rp[4] + rp[7] * t; xr[9] = rp[5] + rp[8] * t;
   xr[10] = 0.0; xr[11] = 0.0; xr[12] = 0.0;
+}
+
+// cone rows a_i' = (C_mat R)_i  (QuatMpc.cpp:47-52,203): (1,0,-mu),(-1,0,-mu),(0,1,-mu),(0,-1,-mu),(0,0,1),(0,0,-1) times R
+QL_FN void cone_rows(const DevParams& P, const double rot[9], double cr[18]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double m = P.mu * rot[6 + a];
+    cr[a] = rot[a] - m;
+    cr[3 + a] = -rot[a] - m;
+    cr[6 + a] = rot[3 + a] - m;
+    cr[9 + a] = -rot[3 + a] - m;
+    cr[12 + a] = rot[6 + a];
+    cr[15 + a] = -rot[6 + a];
+  }
+}
+// slack residual of row i at the initial guess u = u_ref (the same at every knot and stance point): c0 + max(-c0, 1)
+QL_FN void initial_rows(const DevParams& P, const double cr[18], double uz, double s0[6], double rc0[6]) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double c0 = cr[3 * i + 2] * uz;
+    if (i == 4) c0 += -P.fz_max;
+    s0[i] = fmax(-c0, 1.0);
+    rc0[i] = c0 + s0[i];
+  }
 }
 
 // ---- one contact point at one knot: barrier weights, rotated frame, factorised 3 x 3 block ---------------------------
@@ -232,18 +302,13 @@ struct LegBlk {
   double id0, id1, id2;         // inverse pivots
   double gq[3];                 // T' g_l
 };
-template <int NL>
-QL_FN void leg_block(const DevParams& P, const Ctx& c, int l, const double sv[6], const double lv[6], unsigned kap,
-                     double rho, double target, const double u[3], double uz, LegBlk& o) {
-  typedef LDim<NL> D;
-  double cr[18];
-#pragma unroll
-  for (int i = 0; i < 18; ++i) cr[i] = c.C(D::C_CR + i);
+QL_FN void leg_block(const DevParams& P, const double cr[18], const double rc0[6], int l, const double sv[6],
+                     const double lv[6], unsigned kap, double rho, double target, const double u[3], double uz, LegBlk& o) {
   double w[6], gi[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const double is = ql_rcp(sv[i]);
-    const double rc = rho * c.C(D::C_RC0 + i);
+    const double rc = rho * rc0[i];
     w[i] = lv[i] * is;
     gi[i] = (target + lv[i] * rc) * is - (((kap >> i) & 1u) ? lv[i] : 0.0);
   }
@@ -344,7 +409,7 @@ QL_FN unsigned load_rows(const Ctx& c, const WsOff& O, int k, int l, double sv[6
 
 // ---- set-up: record -> constants, initial guess U = u_ref (QuatMpc.cpp:253), slacks and multipliers ------------------
 template <int NL>
-QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const double* rec, LaneState& st) {
+QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const double* rec, LaneK<NL>& K, LaneState& st) {
   typedef LDim<NL> D;
   const int N = P.N;
   bool bad = false;
@@ -360,31 +425,21 @@ QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const do
   st.rho = 1.0; st.mu = 0.0; st.target = 0.0; st.last_ap = 0.0; st.last_ad = 0.0; st.last_step = 1e300;
   st.ap = 1.0; st.ad = 1.0; st.uz = 0.0;
   if (!st.active) return;
-  // C_mat * R (QuatMpc.cpp:47-52,203)
 #pragma unroll
-  for (int r = 0; r < 6; ++r)
+  for (int i = 0; i < 9; ++i) K.rot[i] = raw[4 + i];
 #pragma unroll
-    for (int cc = 0; cc < 3; ++cc) {
-      const double C0 = (r == 0) ? 1.0 : (r == 1 ? -1.0 : 0.0);
-      const double C1 = (r == 2) ? 1.0 : (r == 3 ? -1.0 : 0.0);
-      const double C2 = (r < 4) ? -P.mu : (r == 4 ? 1.0 : -1.0);
-      c.C(D::C_CR + 3 * r + cc) = C0 * raw[4 + cc] + C1 * raw[4 + 3 + cc] + C2 * raw[4 + 6 + cc];
-    }
-#pragma unroll
-  for (int i = 0; i < 3 * NL; ++i) c.C(D::C_FOOT + i) = raw[D::R_FOOT + i];
-  double gb[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) { gb[a] = raw[4 + 6 + a] * (-9.81); c.C(D::C_GB + a) = gb[a]; }   // R'(0,0,-9.81)
+  for (int i = 0; i < 3 * NL; ++i) K.foot[i] = raw[D::R_FOOT + i];
   {
-    // wd0 = Iinv (c x 5.204 g_body)  (AltroUtils.cpp:373-374,391)
+    // wd0 = Iinv (c x 5.204 g_body), g_body = R'(0,0,-9.81)  (AltroUtils.cpp:368-374,391)
+    const double gb[3] = {raw[4 + 6] * (-9.81), raw[4 + 7] * (-9.81), raw[4 + 8] * (-9.81)};
     const double com[3] = {0.0223, 0.002, -0.0005};
     const double fg[3] = {5.204 * gb[0], 5.204 * gb[1], 5.204 * gb[2]};
     const double mg[3] = {com[1] * fg[2] - com[2] * fg[1], com[2] * fg[0] - com[0] * fg[2], com[0] * fg[1] - com[1] * fg[0]};
 #pragma unroll
-    for (int a = 0; a < 3; ++a) c.C(D::C_WD0 + a) = P.Iinv[3 * a] * mg[0] + P.Iinv[3 * a + 1] * mg[1] + P.Iinv[3 * a + 2] * mg[2];
+    for (int a = 0; a < 3; ++a) K.wd0[a] = P.Iinv[3 * a] * mg[0] + P.Iinv[3 * a + 1] * mg[1] + P.Iinv[3 * a + 2] * mg[2];
   }
 #pragma unroll
-  for (int i = 0; i < 13; ++i) c.C(D::C_REF + i) = (i < 9) ? raw[D::R_POS + i] : raw[D::R_QD + i - 9];
+  for (int i = 0; i < 13; ++i) K.refp[i] = (i < 9) ? raw[D::R_POS + i] : raw[D::R_QD + i - 9];
   // x_init (QuatMpc.cpp:231-246; the angular velocity is dropped by the ';' at :242 unless drop_ang_vel = 0)
   {
     double x0[13];
@@ -402,13 +457,12 @@ QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const do
   // u_ref (QuatMpc.cpp:118-125): weight shared by the stance points; cone values there are the same at every knot
   st.uz = 1.0 * P.mass * 9.81 / (double)st.nc;
   double s0[6], l0[6];
+  {
+    double cr[18], rc0[6];
+    cone_rows(P, K.rot, cr);
+    initial_rows(P, cr, st.uz, s0, rc0);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    double c0 = c.C(D::C_CR + 3 * i) * 0.0 + c.C(D::C_CR + 3 * i + 1) * 0.0 + c.C(D::C_CR + 3 * i + 2) * st.uz;
-    if (i == 4) c0 += -P.fz_max;
-    s0[i] = fmax(-c0, 1.0);
-    l0[i] = P.mu0 / s0[i];
-    c.C(D::C_RC0 + i) = c0 + s0[i];
+    for (int i = 0; i < 6; ++i) l0[i] = P.mu0 / s0[i];
   }
   double slsum = 0.0;
 #pragma unroll
@@ -435,12 +489,16 @@ QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const do
 // cone rows are linear in u), so nothing but dU has to be kept between the passes.  A shortened primal step scales
 // the increment; rc <- (1 - alpha_p) rc, exactly 0 after a full step.
 template <int NL>
-QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, LaneState& st, bool first) {
-  typedef LDim<NL> D;
+QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st, bool first) {
   const int N = P.N;
-  double gb[3], wd0[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) { gb[a] = c.C(D::C_GB + a); wd0[a] = c.C(D::C_WD0 + a); }
+  const double gb[3] = {K.rot[6] * (-9.81), K.rot[7] * (-9.81), K.rot[8] * (-9.81)};
+  const double* wd0 = K.wd0;
+  double cr[18], rc0[6];
+  {
+    double s0[6];
+    cone_rows(P, K.rot, cr);
+    initial_rows(P, cr, st.uz, s0, rc0);
+  }
   double x[13], xn[13];
 #pragma unroll
   for (int i = 0; i < 13; ++i) x[i] = c.W(O.X + i);
@@ -464,9 +522,9 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, LaneState& s
         const unsigned kap = load_rows<NL>(c, O, k, l, sv, lv);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          const double jd = c.C(D::C_CR + 3 * i) * du[0] + c.C(D::C_CR + 3 * i + 1) * du[1] + c.C(D::C_CR + 3 * i + 2) * du[2];
+          const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
           const double kp = ((kap >> i) & 1u) ? 1.0 : 0.0;
-          const double dsv = -(jd + st.rho * c.C(D::C_RC0 + i));
+          const double dsv = -(jd + st.rho * rc0[i]);
           const double dlv = (st.target - (1.0 + kp) * sv[i] * lv[i] - lv[i] * dsv) * ql_rcp(sv[i]);
           const double s1 = sv[i] + ap * dsv;
           const double l1 = lv[i] + ad * dlv;
@@ -485,7 +543,7 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, LaneState& s
       }
       double B[9], r[3];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) r[a] = c.C(D::C_FOOT + 3 * l + a);
+      for (int a = 0; a < 3; ++a) r[a] = K.foot[3 * l + a];
       leg_bw0(P, r, B);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -501,69 +559,93 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, LaneState& s
     st.mu = slsum / (double)(6 * N * st.nc);
     st.rho = full ? 0.0 : (1.0 - ap) * st.rho;
   }
+  QL_TICK(st, LP_A);
 }
 
 // ---- pass B: expansions + Riccati backward pass in the wrench form; writes the 6 x 13 gains -------------------------
-// returns false when S6 = M'PM loses positive definiteness (QMPC_NOT_PD)
+// Per knot (k = N-1 .. 0), with P, p the cost-to-go of knot k+1 in registers:
+//   1. contact points        G = sum_l V_l D_l^-1 V_l' (6 x 6),  r6 = sum_l V_l D_l^-1 g_l
+//   2. dynamics expansion    A1 = Abar_phiphi, A3 = Abar_phiw, Wt = (h h / 4) Gn'Gm
+//   3. S6 = M'PM straight from P;  S6 = L L',  H = I + L'GL = C C',  Z = L^-T (I - H^-1) L^-1 = Wr Quu^-1 Wr'
+//   4. P <- Abar'P Abar, p <- Abar'p in place;  Y = M'P_old Abar = Mt'P with Mt = Abar^-1 M (only its attitude block
+//      What = A1^-1 (Wt - h A3) differs from M), y = Mt'p, y' = y - S6 r6
+//   5. column by column:  z_j = Z y_j,  gain column  xg_j = y_j - S6 z_j  (= (I + S6 G)^-1 y_j) stored at once,
+//      P[i][j] -= y_i . z_j;  gradient column with y' and z + r6
+//   6. stage cost of knot k (the state is re-read: keeping its expansion live through 3-5 would cost 18 registers)
+// The order keeps at most P (90) + Y (78) + Z, S6 (42) + a dozen temporaries live -- the 512-register budget of a
+// wave that owns its SIMD.  Returns false when S6 loses positive definiteness (QMPC_NOT_PD).
 template <int NL>
-QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneState& st) {
+QL_FN void cost_expansion(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, int k, double lx[12],
+                          double lxx[6]) {
+  double x[13];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) x[i] = c.W(O.X + 13 * k + i);
+  double xr[13];
+  xref_at(P, K.refp, k, xr);
+  double lxf[13];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) lxf[i] = P.Q[i] * (x[i] - xr[i]);
+  const double dq = xr[3] * x[3] + xr[4] * x[4] + xr[5] * x[5] + xr[6] * x[6];
+  const double sg = (dq >= 0.0) ? 1.0 : -1.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) lxf[3 + r] += -sg * P.w * xr[3 + r];
+  const double qh = -(x[3] * lxf[3] + x[4] * lxf[4] + x[5] * lxf[5] + x[6] * lxf[6]);
+  double G[12];
+  quatG(&x[3], G);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lx[a] = lxf[a];
+    lx[6 + a] = lxf[7 + a];
+    lx[9 + a] = lxf[10 + a];
+    lx[3 + a] = G[a] * lxf[3] + G[3 + a] * lxf[4] + G[6 + a] * lxf[5] + G[9 + a] * lxf[6];
+  }
+  // attitude block (upper triangle 00 01 02 11 12 22)
+  int q = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = a; b < 3; ++b) {
+      double s = (a == b) ? qh : 0.0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s += G[3 * t + a] * P.Q[3 + t] * G[3 * t + b];
+      lxx[q++] = s;
+    }
+}
+
+template <int NL>
+QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st) {
   typedef LDim<NL> D;
   const int N = P.N;
-  double Pm[78], pv[12];      // cost-to-go  1/2 dx'P dx + p'dx
+  double pv[12];      // cost-to-go  1/2 dx'P dx + p'dx: P in the lane-private rows c.PL(), p in registers
+  double cr[18], rc0[6];
+  {
+    double s0[6];
+    cone_rows(P, K.rot, cr);
+    initial_rows(P, cr, st.uz, s0, rc0);
+  }
   bool ok = true;
   const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
-  for (int k = N; k >= 0; --k) {
-    double x[13];
+  {
+    double lx[12], lxx[6];
+    cost_expansion<NL>(P, c, O, K, N, lx, lxx);
 #pragma unroll
-    for (int i = 0; i < 13; ++i) x[i] = c.W(O.X + 13 * k + i);
-    // ---- cost expansion at knot k: gradient lx (12), attitude block lxx (3 x 3) ----
-    double lx[12], lxx[9];
-    {
-      double xr[13];
-      xref_at(P, c, D::C_REF, k, xr);
-      double lxf[13];
+    for (int i = 0; i < 78; ++i) c.PL(i) = 0.0;
+    int q = 0;
 #pragma unroll
-      for (int i = 0; i < 13; ++i) lxf[i] = P.Q[i] * (x[i] - xr[i]);
-      const double dq = xr[3] * x[3] + xr[4] * x[4] + xr[5] * x[5] + xr[6] * x[6];
-      const double sg = (dq >= 0.0) ? 1.0 : -1.0;
+    for (int a = 0; a < 3; ++a) {
+      c.PL(SI(a, a)) = P.Q[a];
+      c.PL(SI(6 + a, 6 + a)) = P.Q[7 + a];
+      c.PL(SI(9 + a, 9 + a)) = P.Q[10 + a];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lxf[3 + r] += -sg * P.w * xr[3 + r];
-      const double qh = -(x[3] * lxf[3] + x[4] * lxf[4] + x[5] * lxf[5] + x[6] * lxf[6]);
-      double G[12];
-      quatG(&x[3], G);
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        lx[a] = lxf[a];
-        lx[6 + a] = lxf[7 + a];
-        lx[9 + a] = lxf[10 + a];
-        lx[3 + a] = G[a] * lxf[3] + G[3 + a] * lxf[4] + G[6 + a] * lxf[5] + G[9 + a] * lxf[6];
-      }
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          double s = (a == b) ? qh : 0.0;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) s += G[3 * t + a] * P.Q[3 + t] * G[3 * t + b];
-          lxx[3 * a + b] = s;
-        }
+      for (int b = a; b < 3; ++b) c.PL(SI(3 + a, 3 + b)) = lxx[q++];
     }
-    if (k == N) {
 #pragma unroll
-      for (int i = 0; i < 78; ++i) Pm[i] = 0.0;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        Pm[SI(a, a)] = P.Q[a];
-        Pm[SI(6 + a, 6 + a)] = P.Q[7 + a];
-        Pm[SI(9 + a, 9 + a)] = P.Q[10 + a];
-#pragma unroll
-        for (int b = a; b < 3; ++b) Pm[SI(3 + a, 3 + b)] = lxx[3 * a + b];
-      }
-#pragma unroll
-      for (int i = 0; i < 12; ++i) pv[i] = lx[i];
-      continue;
-    }
-    // ---- contact points: G = sum_l V_l D_l^-1 V_l' (6 x 6), r6 = sum_l V_l D_l^-1 g_l; wd for the expansion ----
+    for (int i = 0; i < 12; ++i) pv[i] = lx[i];
+  }
+  for (int k = N - 1; k >= 0; --k) {
+    QL_FENCE();
+    QL_TICK(st, LP_B_HEAD);
+    // ---- 1. contact points; wd for the expansion ----
     double G6[21], r6[6];
 #pragma unroll
     for (int i = 0; i < 21; ++i) G6[i] = 0.0;
@@ -571,20 +653,20 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneSt
     for (int i = 0; i < 6; ++i) r6[i] = 0.0;
     double wd[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) wd[a] = c.C(D::C_WD0 + a);
+    for (int a = 0; a < 3; ++a) wd[a] = K.wd0[a];
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       if (!((st.con >> l) & 1u)) continue;
       double u[3], r[3], B[9];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) { u[a] = c.W(O.U + 3 * NL * k + 3 * l + a); r[a] = c.C(D::C_FOOT + 3 * l + a); }
+      for (int a = 0; a < 3; ++a) { u[a] = c.W(O.U + 3 * NL * k + 3 * l + a); r[a] = K.foot[3 * l + a]; }
       leg_bw0(P, r, B);
 #pragma unroll
       for (int a = 0; a < 3; ++a) wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
       double sv[6], lv[6];
       const unsigned kap = load_rows<NL>(c, O, k, l, sv, lv);
       LegBlk lb;
-      leg_block<NL>(P, c, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
+      leg_block(P, cr, rc0, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
       // V = [T ; Bw0 T] (6 x 3), Vt = V L^-T (columns), G += sum_j id_j vt_j vt_j', r6 += sum_j vt_j id_j y_j, y = L^-1 gq
       double V[18];
 #pragma unroll
@@ -607,11 +689,14 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneSt
         for (int j = i; j < 6; ++j) G6[S6I(i, j)] += a0 * v0[j] + a1 * v1[j] + a2 * v2[j];
       }
     }
-    // ---- dynamics expansion (AltroUtils.cpp:78-110,153-168 in compact form): A1 = Abar_phiphi, A3 = Abar_phiw,
-    //      Wt = (h h / 4) Gn'Gm  (the attitude rows of M) ----
+    QL_FENCE();
+    QL_TICK(st, LP_B_LEGS);
+    // ---- 2. dynamics expansion (AltroUtils.cpp:78-110,153-168 in compact form) ----
     double A1[9], A3[9], Wt[9];
     {
-      double xn[4];
+      double x[13], xn[4];
+#pragma unroll
+      for (int i = 3; i < 13; ++i) x[i] = c.W(O.X + 13 * k + i);
 #pragma unroll
       for (int i = 0; i < 4; ++i) xn[i] = c.W(O.X + 13 * (k + 1) + 3 + i);
       double G0[12], Gm[12], Gn[12];
@@ -647,100 +732,202 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneSt
         }
       }
     }
-    // ---- MP = M'P (6 x 12) and y = M'p from the OLD cost-to-go; S6 = MP M; Y = MP Abar in place ----
-    double Y[6][13];
+    QL_FENCE();
+    QL_TICK(st, LP_B_EXPAND);
+    // ---- 3. S6 = M'PM from the symmetric storage; factorisations; Z ----
+    double S6[21], Z[21];
+    {
+      // ff = m1^2 Ppp + m1 m2 (Ppv + Pvp) + m2^2 Pvv
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
+      for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        Y[a][j] = m1 * Pm[SI(a, j)] + m2 * Pm[SI(6 + a, j)];
-        Y[3 + a][j] = Wt[a] * Pm[SI(3, j)] + Wt[3 + a] * Pm[SI(4, j)] + Wt[6 + a] * Pm[SI(5, j)] + P.h * Pm[SI(9 + a, j)];
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      Y[a][12] = m1 * pv[a] + m2 * pv[6 + a];
-      Y[3 + a][12] = Wt[a] * pv[3] + Wt[3 + a] * pv[4] + Wt[6 + a] * pv[5] + P.h * pv[9 + a];
-    }
-    double S6[21];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
+        for (int b = a; b < 3; ++b)
+          S6[S6I(a, b)] = (m1 * m1) * c.PL(SI(a, b)) + (m1 * m2) * (c.PL(SI(a, 6 + b)) + c.PL(SI(6 + a, b))) + (m2 * m2) * c.PL(SI(6 + a, 6 + b));
+      // ft = (m1 Ppf + m2 Pvf) Wt + h (m1 Ppw + m2 Pvw);  tt = Wt'Pff Wt + h (Wt'Pfw + Pwf Wt) + h^2 Pww
+      double Fw[9];   // Pff Wt
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        if (i <= a) S6[S6I(i, a)] = m1 * Y[i][a] + m2 * Y[i][6 + a];
-        if (i <= 3 + a)
-          S6[S6I(i, 3 + a)] = Y[i][3] * Wt[a] + Y[i][4] * Wt[3 + a] + Y[i][5] * Wt[6 + a] + P.h * Y[i][9 + a];
-      }
-    }
+        double q0 = m1 * c.PL(SI(a, 3)) + m2 * c.PL(SI(6 + a, 3)), q1 = m1 * c.PL(SI(a, 4)) + m2 * c.PL(SI(6 + a, 4)),
+               q2 = m1 * c.PL(SI(a, 5)) + m2 * c.PL(SI(6 + a, 5));
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const double f0 = Y[i][3], f1 = Y[i][4], f2 = Y[i][5];
+        for (int b = 0; b < 3; ++b)
+          S6[S6I(a, 3 + b)] = q0 * Wt[b] + q1 * Wt[3 + b] + q2 * Wt[6 + b] + P.h * (m1 * c.PL(SI(a, 9 + b)) + m2 * c.PL(SI(6 + a, 9 + b)));
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc) {
-        Y[i][9 + cc] += f0 * A3[cc] + f1 * A3[3 + cc] + f2 * A3[6 + cc];
-        Y[i][6 + cc] += P.h * Y[i][cc];
+        for (int b = 0; b < 3; ++b) Fw[3 * a + b] = c.PL(SI(3 + a, 3)) * Wt[b] + c.PL(SI(3 + a, 4)) * Wt[3 + b] + c.PL(SI(3 + a, 5)) * Wt[6 + b];
       }
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc) Y[i][3 + cc] = f0 * A1[cc] + f1 * A1[3 + cc] + f2 * A1[6 + cc];
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = a; b < 3; ++b) {
+          double s = (P.h * P.h) * c.PL(SI(9 + a, 9 + b));
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            s += Wt[3 * t + a] * Fw[3 * t + b] + P.h * (Wt[3 * t + a] * c.PL(SI(3 + t, 9 + b)) + c.PL(SI(9 + a, 3 + t)) * Wt[3 * t + b]);
+          S6[S6I(3 + a, 3 + b)] = s;
+        }
+      double L[21], iL[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        double d = S6[S6I(j, j)];
+#pragma unroll
+        for (int t = 0; t < j; ++t) d -= L[LI(j, t)] * L[LI(j, t)];
+        ok = ok && (d > 0.0);
+        const double inv = ql_rsqrt(d);
+        iL[j] = inv;
+        L[LI(j, j)] = d * inv;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+          double s = S6[S6I(j, i)];
+#pragma unroll
+          for (int t = 0; t < j; ++t) s -= L[LI(i, t)] * L[LI(j, t)];
+          L[LI(i, j)] = s * inv;
+        }
+      }
+      // H = I + L' G L = C C'
+      double Cc[21], iC[6];
+      {
+        double GL[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int t = j; t < 6; ++t) s += G6[S6I(i, t)] * L[LI(t, j)];
+            GL[i][j] = s;
+          }
+        double H[21];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = i; j < 6; ++j) {
+            double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int t = i; t < 6; ++t) s += L[LI(t, i)] * GL[t][j];
+            H[S6I(i, j)] = s;
+          }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          double d = H[S6I(j, j)];
+#pragma unroll
+          for (int t = 0; t < j; ++t) d -= Cc[LI(j, t)] * Cc[LI(j, t)];
+          const double inv = ql_rsqrt(d);
+          iC[j] = inv;
+          Cc[LI(j, j)] = d * inv;
+#pragma unroll
+          for (int i = j + 1; i < 6; ++i) {
+            double s = H[S6I(j, i)];
+#pragma unroll
+            for (int t = 0; t < j; ++t) s -= Cc[LI(i, t)] * Cc[LI(j, t)];
+            Cc[LI(i, j)] = s * inv;
+          }
+        }
+      }
+      // Ci = C^-1 (lower), E = I - Ci'Ci;  Li = L^-1 (lower), Z = Li' E Li
+      double Ci[21], Li[21];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        Ci[LI(j, j)] = iC[j];
+        Li[LI(j, j)] = iL[j];
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+          double s = 0.0, s2 = 0.0;
+#pragma unroll
+          for (int t = j; t < i; ++t) { s -= Cc[LI(i, t)] * Ci[LI(t, j)]; s2 -= L[LI(i, t)] * Li[LI(t, j)]; }
+          Ci[LI(i, j)] = s * iC[i];
+          Li[LI(i, j)] = s2 * iL[i];
+        }
+      }
+      double E[21];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+          double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+          for (int t = j; t < 6; ++t) s -= Ci[LI(t, i)] * Ci[LI(t, j)];
+          E[S6I(i, j)] = s;
+        }
+      double EL[6][6];   // E Li (Li lower: column j has rows >= j)
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = j; t < 6; ++t) s += E[S6I(i, t)] * Li[LI(t, j)];
+          EL[i][j] = s;
+        }
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = i; t < 6; ++t) s += Li[LI(t, i)] * EL[t][j];
+          Z[S6I(i, j)] = s;
+        }
     }
-    // ---- P <- Abar' P Abar, p <- Abar' p  in place on the symmetric storage ----
+    QL_FENCE();
+    QL_TICK(st, LP_B_FACT);
+    // ---- 4. P <- Abar' P Abar, p <- Abar' p  in place on the symmetric storage; What = A1^-1 (Wt - h A3) ----
     {
       double F[9], W[9], t1[9], t2[9], t3[9], Rb[9];
-      rdblk(Pm, 1, 1, F);
-      rdblk(Pm, 1, 3, W);
+      rdblk(c, 1, 1, F);
+      rdblk(c, 1, 3, W);
       mm(F, A3, t1);            // P_ff A3
       mtm(A3, W, t2);           // A3' P_fw
-      rdblk(Pm, 3, 3, Rb);
+      rdblk(c, 3, 3, Rb);
       mtm(A3, t1, t3);
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) Rb[3 * r + cc] += t3[3 * r + cc] + t2[3 * r + cc] + t2[3 * cc + r];
-      wrblk(Pm, 3, 3, Rb);
+      wrblk(c, 3, 3, Rb);
 #pragma unroll
       for (int i = 0; i < 9; ++i) W[i] += t1[i];
       mtm(A1, W, Rb);
-      wrblk(Pm, 1, 3, Rb);      // A1'(P_ff A3 + P_fw)
+      wrblk(c, 1, 3, Rb);      // A1'(P_ff A3 + P_fw)
       mm(F, A1, t3);
       mtm(A1, t3, Rb);
-      wrblk(Pm, 1, 1, Rb);      // A1' P_ff A1
+      wrblk(c, 1, 1, Rb);      // A1' P_ff A1
     }
     {
       double Bq[9], Vq[9], t4[9], Cq[9], Dq[9], Rb[9];
-      rdblk(Pm, 0, 1, Bq);      // P_pf
-      rdblk(Pm, 1, 2, Vq);      // P_fv
+      rdblk(c, 0, 1, Bq);      // P_pf
+      rdblk(c, 1, 2, Vq);      // P_fv
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) t4[3 * r + cc] = P.h * Bq[3 * cc + r] + Vq[3 * r + cc];
-      rdblk(Pm, 0, 3, Cq);      // P_pw
-      rdblk(Pm, 2, 3, Dq);      // P_vw
+      rdblk(c, 0, 3, Cq);      // P_pw
+      rdblk(c, 2, 3, Dq);      // P_vw
       mtm(t4, A3, Rb);
 #pragma unroll
       for (int i = 0; i < 9; ++i) Dq[i] += P.h * Cq[i] + Rb[i];
-      wrblk(Pm, 2, 3, Dq);
+      wrblk(c, 2, 3, Dq);
       mtm(A1, t4, Rb);
-      wrblk(Pm, 1, 2, Rb);
+      wrblk(c, 1, 2, Rb);
       mm(Bq, A3, Rb);
 #pragma unroll
       for (int i = 0; i < 9; ++i) Cq[i] += Rb[i];
-      wrblk(Pm, 0, 3, Cq);
+      wrblk(c, 0, 3, Cq);
       mm(Bq, A1, Rb);
-      wrblk(Pm, 0, 1, Rb);
+      wrblk(c, 0, 1, Rb);
     }
     {
       double E[9], Vv[9], Rb[9];
-      rdblk(Pm, 0, 0, E);
-      rdblk(Pm, 0, 2, Vv);
-      rdblk(Pm, 2, 2, Rb);
+      rdblk(c, 0, 0, E);
+      rdblk(c, 0, 2, Vv);
+      rdblk(c, 2, 2, Rb);
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) Rb[3 * r + cc] += P.h * (Vv[3 * r + cc] + Vv[3 * cc + r]) + (P.h * P.h) * E[3 * r + cc];
-      wrblk(Pm, 2, 2, Rb);
+      wrblk(c, 2, 2, Rb);
 #pragma unroll
       for (int i = 0; i < 9; ++i) Vv[i] += P.h * E[i];
-      wrblk(Pm, 0, 2, Vv);
+      wrblk(c, 0, 2, Vv);
     }
     {
       const double f0 = pv[3], f1 = pv[4], f2 = pv[5];
@@ -752,166 +939,123 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneSt
 #pragma unroll
       for (int a = 0; a < 3; ++a) pv[3 + a] = A1[a] * f0 + A1[3 + a] * f1 + A1[6 + a] * f2;
     }
-    // stage cost
+    double Wh[9];       // A1^-1 (Wt - h A3) by cofactors (A1 = I + O(h |w|))
+    {
+      const double c00 = A1[4] * A1[8] - A1[5] * A1[7], c01 = A1[5] * A1[6] - A1[3] * A1[8], c02 = A1[3] * A1[7] - A1[4] * A1[6];
+      const double idet = ql_rcp(A1[0] * c00 + A1[1] * c01 + A1[2] * c02);
+      const double Ai[9] = {c00 * idet, (A1[2] * A1[7] - A1[1] * A1[8]) * idet, (A1[1] * A1[5] - A1[2] * A1[4]) * idet,
+                            c01 * idet, (A1[0] * A1[8] - A1[2] * A1[6]) * idet, (A1[2] * A1[3] - A1[0] * A1[5]) * idet,
+                            c02 * idet, (A1[1] * A1[6] - A1[0] * A1[7]) * idet, (A1[0] * A1[4] - A1[1] * A1[3]) * idet};
+      double Dm[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Dm[i] = Wt[i] - P.h * A3[i];
+      mm(Ai, Dm, Wh);
+    }
+    QL_FENCE();
+    QL_TICK(st, LP_B_CONGR);
+    // ---- 5. Y = Mt' P (rows f: mf P_p. + m2 P_v. ; rows t: What' P_f. + h P_w.), column by column ----
+    const double mf = m1 - P.h * m2;
+    double Y[12][6];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        Y[j][a] = mf * c.PL(SI(a, j)) + m2 * c.PL(SI(6 + a, j));
+        Y[j][3 + a] = Wh[a] * c.PL(SI(3, j)) + Wh[3 + a] * c.PL(SI(4, j)) + Wh[6 + a] * c.PL(SI(5, j)) + P.h * c.PL(SI(9 + a, j));
+      }
+    }
+    double yg[6];     // y' = Mt'p - S6 r6
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      Pm[SI(a, a)] += P.Q[a];
-      Pm[SI(6 + a, 6 + a)] += P.Q[7 + a];
-      Pm[SI(9 + a, 9 + a)] += P.Q[10 + a];
-#pragma unroll
-      for (int b = a; b < 3; ++b) Pm[SI(3 + a, 3 + b)] += lxx[3 * a + b];
-    }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) pv[i] += lx[i];
-    // ---- S6 = L L' ----
-    double L[21], iL[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      double d = S6[S6I(j, j)];
-#pragma unroll
-      for (int t = 0; t < j; ++t) d -= L[LI(j, t)] * L[LI(j, t)];
-      ok = ok && (d > 0.0);
-      const double inv = ql_rsqrt(d);
-      iL[j] = inv;
-      L[LI(j, j)] = d * inv;
-#pragma unroll
-      for (int i = j + 1; i < 6; ++i) {
-        double s = S6[S6I(j, i)];
-#pragma unroll
-        for (int t = 0; t < j; ++t) s -= L[LI(i, t)] * L[LI(j, t)];
-        L[LI(i, j)] = s * inv;
-      }
-    }
-    // Yt = L^-1 [Y | y]
-#pragma unroll
-    for (int cc = 0; cc < 13; ++cc)
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        double s = Y[i][cc];
-#pragma unroll
-        for (int t = 0; t < i; ++t) s -= L[LI(i, t)] * Y[t][cc];
-        Y[i][cc] = s * iL[i];
-      }
-    // H = I + L' G L = C C'
-    double Cc[21], iC[6];
-    {
-      double GL[6][6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          double s = 0.0;
-#pragma unroll
-          for (int t = j; t < 6; ++t) s += G6[S6I(i, t)] * L[LI(t, j)];
-          GL[i][j] = s;
-        }
-      double H[21];
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 6; ++j) {
-          double s = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-          for (int t = i; t < 6; ++t) s += L[LI(t, i)] * GL[t][j];
-          H[S6I(i, j)] = s;
-        }
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        double d = H[S6I(j, j)];
-#pragma unroll
-        for (int t = 0; t < j; ++t) d -= Cc[LI(j, t)] * Cc[LI(j, t)];
-        const double inv = ql_rsqrt(d);
-        iC[j] = inv;
-        Cc[LI(j, j)] = d * inv;
-#pragma unroll
-        for (int i = j + 1; i < 6; ++i) {
-          double s = H[S6I(j, i)];
-#pragma unroll
-          for (int t = 0; t < j; ++t) s -= Cc[LI(i, t)] * Cc[LI(j, t)];
-          Cc[LI(i, j)] = s * inv;
-        }
-      }
-    }
-    // P_aug -= Yt' [Yt | yt];  then column 12 becomes b = yt - L' r6
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-#pragma unroll
-      for (int j = i; j < 12; ++j) {
-        double s = 0.0;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) s += Y[t][i] * Y[t][j];
-        Pm[SI(i, j)] -= s;
-      }
-      double s = 0.0;
-#pragma unroll
-      for (int t = 0; t < 6; ++t) s += Y[t][i] * Y[t][12];
-      pv[i] -= s;
+      yg[a] = mf * pv[a] + m2 * pv[6 + a];
+      yg[3 + a] = Wh[a] * pv[3] + Wh[3 + a] * pv[4] + Wh[6 + a] * pv[5] + P.h * pv[9 + a];
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      double s = Y[i][12];
+      double s = yg[i];
 #pragma unroll
-      for (int t = i; t < 6; ++t) s -= L[LI(t, i)] * r6[t];
-      Y[i][12] = s;
+      for (int t = 0; t < 6; ++t) s -= S6[S6I(i, t)] * r6[t];
+      yg[i] = s;
     }
-    // Yh = C^-1 [Yt | b];  P_aug += Yh' Yh
+    QL_FENCE();
+    QL_TICK(st, LP_B_MP);
 #pragma unroll
-    for (int cc = 0; cc < 13; ++cc)
+    for (int j = 0; j < 13; ++j) {
+      QL_FENCE();
+      double yj[6], z[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) yj[i] = (j < 12) ? Y[j < 12 ? j : 0][i] : yg[i];
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        double s = Y[i][cc];
-#pragma unroll
-        for (int t = 0; t < i; ++t) s -= Cc[LI(i, t)] * Y[t][cc];
-        Y[i][cc] = s * iC[i];
-      }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-#pragma unroll
-      for (int j = i; j < 12; ++j) {
         double s = 0.0;
 #pragma unroll
-        for (int t = 0; t < 6; ++t) s += Y[t][i] * Y[t][j];
-        Pm[SI(i, j)] += s;
+        for (int t = 0; t < 6; ++t) s += Z[S6I(i, t)] * yj[t];
+        z[i] = s;
       }
-      double s = 0.0;
 #pragma unroll
-      for (int t = 0; t < 6; ++t) s += Y[t][i] * Y[t][12];
-      pv[i] += s;
+      for (int i = 0; i < 6; ++i) {
+        double s = yj[i];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) s -= S6[S6I(i, t)] * z[t];
+        c.W(O.G + D::GAIN * k + 13 * i + j) = s;
+      }
+      if (j < 12) {
+#pragma unroll
+        for (int i = 0; i <= j; ++i) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < 6; ++t) s += Y[i][t] * z[t];
+          c.PL(SI(i, j < 12 ? j : 0)) -= s;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) z[t] += r6[t];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < 6; ++t) s += Y[i][t] * z[t];
+          pv[i] -= s;
+        }
+      }
     }
-    // gains [Xg | zeta0] = L C^-T Yh
+    QL_FENCE();
+    QL_TICK(st, LP_B_UPD);
+    // ---- 6. stage cost of knot k ----
+    {
+      double lx[12], lxx[6];
+      cost_expansion<NL>(P, c, O, K, k, lx, lxx);
+      int q = 0;
 #pragma unroll
-    for (int cc = 0; cc < 13; ++cc) {
+      for (int a = 0; a < 3; ++a) {
+        c.PL(SI(a, a)) += P.Q[a];
+        c.PL(SI(6 + a, 6 + a)) += P.Q[7 + a];
+        c.PL(SI(9 + a, 9 + a)) += P.Q[10 + a];
 #pragma unroll
-      for (int i = 5; i >= 0; --i) {
-        double s = Y[i][cc];
-#pragma unroll
-        for (int t = i + 1; t < 6; ++t) s -= Cc[LI(t, i)] * Y[t][cc];
-        Y[i][cc] = s * iC[i];
+        for (int b = a; b < 3; ++b) c.PL(SI(3 + a, 3 + b)) += lxx[q++];
       }
 #pragma unroll
-      for (int i = 5; i >= 0; --i) {
-        double s = 0.0;
-#pragma unroll
-        for (int t = 0; t <= i; ++t) s += L[LI(i, t)] * Y[t][cc];
-        Y[i][cc] = s;
-      }
+      for (int i = 0; i < 12; ++i) pv[i] += lx[i];
     }
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int cc = 0; cc < 13; ++cc) c.W(O.G + D::GAIN * k + 13 * i + cc) = Y[i][cc];
+    QL_FENCE();
+    QL_TICK(st, LP_B_GAIN);
   }
   return ok;
 }
 
 // ---- pass C: closed-loop trial rollout (alpha = 1) + slack / multiplier directions + step lengths ----------------------
 template <int NL>
-QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, LaneState& st) {
+QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st) {
   typedef LDim<NL> D;
   const int N = P.N;
-  double gb[3], wd0[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) { gb[a] = c.C(D::C_GB + a); wd0[a] = c.C(D::C_WD0 + a); }
+  const double gb[3] = {K.rot[6] * (-9.81), K.rot[7] * (-9.81), K.rot[8] * (-9.81)};
+  const double* wd0 = K.wd0;
+  double cr[18], rc0[6];
+  {
+    double s0[6];
+    cone_rows(P, K.rot, cr);
+    initial_rows(P, cr, st.uz, s0, rc0);
+  }
   double xc[13], xn[13];
 #pragma unroll
   for (int i = 0; i < 13; ++i) xc[i] = c.W(O.X + i);
@@ -943,18 +1087,19 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, LaneState& s
       for (int j = 0; j < 12; ++j) s += c.W(O.G + D::GAIN * k + 13 * i + j) * dx[j];
       zeta[i] = s;
     }
+    QL_TICK(st, LP_C_HEAD);
     double F[3] = {0, 0, 0}, wd[3] = {wd0[0], wd0[1], wd0[2]};
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       if (!((st.con >> l) & 1u)) continue;
       double u[3], r[3], B[9];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) { u[a] = c.W(O.U + 3 * NL * k + 3 * l + a); r[a] = c.C(D::C_FOOT + 3 * l + a); }
+      for (int a = 0; a < 3; ++a) { u[a] = c.W(O.U + 3 * NL * k + 3 * l + a); r[a] = K.foot[3 * l + a]; }
       leg_bw0(P, r, B);
       double sv[6], lv[6];
       const unsigned kap = load_rows<NL>(c, O, k, l, sv, lv);
       LegBlk lb;
-      leg_block<NL>(P, c, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
+      leg_block(P, cr, rc0, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
       // rhs = T'(zeta_f + Bw0' zeta_t) + gq;  du = -T Db^-1 rhs
       double t[3], rh[3];
 #pragma unroll
@@ -976,9 +1121,9 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, LaneState& s
       // directions and fraction-to-the-boundary ratios (ipm_directions in qmpc_kernels.hip)
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        const double jd = c.C(D::C_CR + 3 * i) * du[0] + c.C(D::C_CR + 3 * i + 1) * du[1] + c.C(D::C_CR + 3 * i + 2) * du[2];
+        const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
         const double kp = ((kap >> i) & 1u) ? 1.0 : 0.0;
-        const double dsv = -(jd + st.rho * c.C(D::C_RC0 + i));
+        const double dsv = -(jd + st.rho * rc0[i]);
         const double dlv = (st.target - (1.0 + kp) * sv[i] * lv[i] - lv[i] * dsv) * ql_rcp(sv[i]);
         if (dsv < 0.0) ap = fmin(ap, -P.tau * sv[i] * ql_rcp(dsv));
         if (dlv < 0.0) ad = fmin(ad, -P.tau * lv[i] * ql_rcp(dlv));
@@ -989,31 +1134,33 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, LaneState& s
         wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
       }
     }
+    QL_TICK(st, LP_C_LEGS);
     srbd_step_fw(P, gb, xc, F, wd, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) xc[i] = xn[i];
+    QL_TICK(st, LP_C_STEP);
   }
   st.ap = ap; st.ad = ad;
   st.last_ap = ap; st.last_ad = ad;
   st.last_step = stp;
 }
 
-// largest |rc0|: the slack residual of every enabled row is rho * rc0_i
-template <int NL>
-QL_FN double rc0_max(const Ctx& c) {
-  double m = 0.0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) m = fmax(m, fabs(c.C(LDim<NL>::C_RC0 + i)));
-  return m;
-}
-
 // ---- one interior-point iteration of one lane: the control flow of qmpc_solve_body.inc ------------------------------
 // returns true while the instance needs more iterations
 template <int NL>
-QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, LaneState& st) {
+QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st) {
   st.it += 1;
-  pass_A<NL>(P, c, O, st, st.it == 1);
-  const double resid = st.rho * rc0_max<NL>(c);
+  pass_A<NL>(P, c, O, K, st, st.it == 1);
+  double resid;     // largest |rc|: the slack residual of every enabled row is rho * rc0_i
+  {
+    double cr[18], s0[6], rc0[6];
+    cone_rows(P, K.rot, cr);
+    initial_rows(P, cr, st.uz, s0, rc0);
+    double m = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) m = fmax(m, fabs(rc0[i]));
+    resid = st.rho * m;
+  }
   if (st.mu <= P.mu_final && resid <= P.tol_feas && st.last_step <= P.tol_step) { st.status = QMPC_OK; return false; }
   if (st.it > P.iterations_max) { st.status = QMPC_MAX_ITER; return false; }
   double sg = P.sigma;
@@ -1022,17 +1169,16 @@ QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, Lane
   else if (st.it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
   else if (st.it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
   st.target = sg * st.mu;
-  if (!pass_B<NL>(P, c, O, st)) { st.status = QMPC_NOT_PD; return false; }
-  pass_C<NL>(P, c, O, st);
+  if (!pass_B<NL>(P, c, O, K, st)) { st.status = QMPC_NOT_PD; return false; }
+  pass_C<NL>(P, c, O, K, st);
   st.iters = st.it;
   return true;
 }
 
 // ---- outputs: GetInput(u, 0) (QuatMpc.cpp:264-265) and the info record -----------------------------------------------
 template <int NL>
-QL_FN void lane_finish(const DevParams& P, const Ctx& c, const WsOff& O, const LaneState& st, double* forces,
-                       qmpc_info* info) {
-  typedef LDim<NL> D;
+QL_FN void lane_finish(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, const LaneState& st,
+                       double* forces, qmpc_info* info) {
   const int N = P.N;
   const bool solved = st.status != QMPC_NAN_INPUT && st.status != QMPC_NO_CONTACT;
 #pragma unroll
@@ -1040,9 +1186,11 @@ QL_FN void lane_finish(const DevParams& P, const Ctx& c, const WsOff& O, const L
   if (!info) return;
   double J = 0.0, viol = 0.0;
   if (solved) {
+    double cr[18];
+    cone_rows(P, K.rot, cr);
     for (int k = 0; k <= N; ++k) {
       double xr[13];
-      xref_at(P, c, D::C_REF, k, xr);
+      xref_at(P, K.refp, k, xr);
       double dq = 0.0;
 #pragma unroll
       for (int i = 0; i < 13; ++i) {
@@ -1064,7 +1212,7 @@ QL_FN void lane_finish(const DevParams& P, const Ctx& c, const WsOff& O, const L
              0.5 * P.R[(3 * l + 2) % 12] * e2 * e2;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          double cv = c.C(D::C_CR + 3 * i) * u[0] + c.C(D::C_CR + 3 * i + 1) * u[1] + c.C(D::C_CR + 3 * i + 2) * u[2];
+          double cv = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
           if (i == 4) cv += -P.fz_max;
           viol = fmax(viol, fmax(cv, 0.0));
         }

@@ -13,14 +13,15 @@ using namespace qmpc::lane;
 template <int NL>
 static int solve_all(const DevParams& P, int batch, const double* rec, double* forces, qmpc_info* info) {
   const WsOff O = make_wsoff<NL>(P.N);
-  std::vector<double> ws((size_t)O.total), cs((size_t)LDim<NL>::C_TOTAL);
+  std::vector<double> ws((size_t)O.total), pl((size_t)LDim<NL>::PLDS);
   for (int b = 0; b < batch; ++b) {
-    Ctx c = {ws.data(), 1, cs.data(), 1};
+    Ctx c = {ws.data(), 8, 0, pl.data(), 8, 0};
+    LaneK<NL> K;
     LaneState st;
-    lane_setup<NL>(P, c, O, rec + (size_t)b * LDim<NL>::REC, st);
+    lane_setup<NL>(P, c, O, rec + (size_t)b * LDim<NL>::REC, K, st);
     if (st.active)
-      while (lane_iteration<NL>(P, c, O, st)) {}
-    lane_finish<NL>(P, c, O, st, forces + (size_t)b * 3 * NL, info ? info + b : nullptr);
+      while (lane_iteration<NL>(P, c, O, K, st)) {}
+    lane_finish<NL>(P, c, O, K, st, forces + (size_t)b * 3 * NL, info ? info + b : nullptr);
   }
   return 0;
 }
