@@ -76,7 +76,7 @@ struct qmpc_handle {
 };
 
 constexpr unsigned kLaneMaxSlots = 1024 * 64;   // one wavefront per SIMD of the chip
-constexpr int kLaneMinBatch = 1 << 30;           // auto switch-over (set from measurements; QMPC_LANE_MIN overrides)
+constexpr int kLaneMinBatch = 24576;          // measured switch-over against the wave-per-instance kernels (QMPC_LANE_MIN overrides)
 
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
@@ -347,7 +347,8 @@ static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* 
                                hipStream_t s) {
   const int nl = model_nl(h->params.model);
   if (!h->d_lane_ws) {
-    const unsigned want = (unsigned)(((size_t)h->max_batch + 63) / 64) * 64;
+    // one workspace block per wavefront; a wavefront may run with 32 of its lanes (qmpc_lane.hip), hence max_batch / 32
+    const unsigned want = (unsigned)(((size_t)h->max_batch + 31) / 32) * 64;
     h->lane_slots = want < kLaneMaxSlots ? want : kLaneMaxSlots;
     HIP_TRY(hipMalloc(&h->d_lane_ws, qmpc_lane_ws_bytes(h->params.horizon, nl, h->lane_slots)));
     HIP_TRY(hipMalloc(&h->d_lane_scratch, qmpc_lane_scratch_bytes(h->max_batch)));

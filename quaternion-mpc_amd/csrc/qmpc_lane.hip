@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "qmpc_lane_core.h"
@@ -136,7 +137,8 @@ template <int NL>
 __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const double* __restrict__ in,
                                                               double* __restrict__ forces, qmpc_info* __restrict__ info,
                                                               int batch, double* __restrict__ ws, unsigned slots,
-                                                              const int* __restrict__ perm, long long* __restrict__ prof) {
+                                                              int lanes, const int* __restrict__ perm,
+                                                              long long* __restrict__ prof) {
   typedef LDim<NL> D;
   const int lane = threadIdx.x;
   const DevParams& P = ql_params[pslot];
@@ -147,9 +149,10 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
   LaneState st;
   QL_PRIV_AS LaneK<NL>* Kp = (QL_PRIV_AS LaneK<NL>*)&K;
   QL_PRIV_AS LaneState* sp = (QL_PRIV_AS LaneState*)&st;
-  for (long long base = (long long)blockIdx.x * kLaneWave; base < batch; base += slots) {
+  // `lanes` (64, or 32 when the batch would otherwise leave SIMDs without a wavefront) lanes of a wave take instances
+  for (long long base = (long long)blockIdx.x * lanes; base < batch; base += slots) {
     const long long pos = base + lane;
-    const bool valid = pos < batch;
+    const bool valid = lane < lanes && pos < batch;
     const int b = valid ? (perm ? perm[pos] : (int)pos) : 0;
     bool active = false;
     if (valid) {
@@ -285,9 +288,12 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
     }
     perm = scratch + 512;
   }
-  const unsigned need = (unsigned)(((size_t)batch + kLaneWave - 1) / kLaneWave);
+  // batches that would occupy at most half of the chip's SIMDs with full wavefronts run with 32 lanes per wavefront
+  static const int lanes_env = std::getenv("QMPC_LANE_WIDTH") ? std::atoi(std::getenv("QMPC_LANE_WIDTH")) : 0;
+  const int lanes = lanes_env == 32 || lanes_env == 64 ? lanes_env : ((size_t)batch * 2 <= slots ? 32 : 64);
+  const unsigned need = (unsigned)(((size_t)batch + lanes - 1) / lanes);
   const unsigned waves = need < slots / kLaneWave ? need : slots / kLaneWave;
-  const unsigned used = waves * kLaneWave;     // lanes of this launch: batch stride and workspace stride
+  const unsigned used = waves * (unsigned)lanes;     // instances in flight: the batch stride
   const size_t lds = sizeof(double) * kLaneWave * LDim<4>::PLDS;
   long long* prof = nullptr;
 #if defined(QL_PROFILE)
@@ -297,9 +303,9 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
   (void)hipMemsetAsync(d_prof, 0, sizeof(long long) * 16 * 1024, s);
 #endif
   if (nl == 8)
-    hipLaunchKernelGGL(qmpc_lane_kernel<8>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, perm, prof);
+    hipLaunchKernelGGL(qmpc_lane_kernel<8>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm, prof);
   else
-    hipLaunchKernelGGL(qmpc_lane_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, perm, prof);
+    hipLaunchKernelGGL(qmpc_lane_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm, prof);
 #if defined(QL_PROFILE)
   {
     static long long hp[16 * 1024];

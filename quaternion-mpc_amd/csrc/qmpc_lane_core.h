@@ -78,7 +78,11 @@ struct LDim {
   static constexpr int REC = 32 + 4 * NL;
   static constexpr int R_FOOT = 19, R_CON = 19 + 3 * NL, R_POS = 19 + 4 * NL, R_QD = R_POS + 9;
   static constexpr int PLDS = 78;     // entries of the symmetric cost-to-go matrix kept in lane-private LDS rows
-  static constexpr int GAIN = 78;     // wrench-space gain [Xg | zeta0], 6 x 13
+  // wrench-space gain of a knot: the feedback part Xg (6 x 12) in SINGLE precision, two entries per 8-byte element
+  // (element 3 j + i/2 holds rows i, i+1 of column j) -- it multiplies the state increment of the rollout, so its rounding
+  // changes the Newton direction by 6e-8 of the step and not the fixed point -- followed by the feed-forward zeta0 (6) in
+  // double precision
+  static constexpr int GAIN = 36 + 6;
 };
 
 // constants of one instance (registers)
@@ -139,6 +143,13 @@ enum { LP_A = 0, LP_B_HEAD, LP_B_LEGS, LP_B_EXPAND, LP_B_MP, LP_B_CONGR, LP_B_FA
        LP_C_STEP, LP_COUNT };
 // compiler-level memory fence: values read from the lane-private rows before it are re-read after it instead of being
 // kept in registers across a phase boundary (the point of keeping P in LDS is to get it OUT of the register file)
+// true when ANY active lane of the wave has the predicate: a scalar branch, so that loads placed under it are issued
+// for the whole wave ahead of the per-lane work (lanes that do not need the data ignore what they read)
+#if QL_DEVICE
+#define QL_ANY(x) (__any((int)(x)) != 0)
+#else
+#define QL_ANY(x) (x)
+#endif
 #if QL_DEVICE
 #define QL_FENCE() asm volatile("" ::: "memory")
 #else
@@ -202,6 +213,25 @@ QL_FN void mtm(const double A[9], const double B[9], double C[9]) {
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c < 3; ++c) C[3 * r + c] = A[r] * B[c] + A[3 + r] * B[3 + c] + A[6 + r] * B[6 + c];
+}
+
+// two floats in one 8-byte workspace element
+QL_FN double pack2f(float a, float b) {
+  unsigned long long u;
+  unsigned ua, ub;
+  __builtin_memcpy(&ua, &a, 4);
+  __builtin_memcpy(&ub, &b, 4);
+  u = ((unsigned long long)ub << 32) | ua;
+  double d;
+  __builtin_memcpy(&d, &u, 8);
+  return d;
+}
+QL_FN void unpack2f(double d, float& a, float& b) {
+  unsigned long long u;
+  __builtin_memcpy(&u, &d, 8);
+  const unsigned ua = (unsigned)u, ub = (unsigned)(u >> 32);
+  __builtin_memcpy(&a, &ua, 4);
+  __builtin_memcpy(&b, &ub, 4);
 }
 
 // G(q) (4 x 3), QuaternionUtils.cpp:48-52
@@ -407,6 +437,60 @@ QL_FN unsigned load_rows(const Ctx& c, const WsOff& O, int k, int l, double sv[6
   return kap;
 }
 
+// Rows of every contact point of ONE knot, held in registers one knot AHEAD of their use: a pass fills the buffer for
+// its first knot, and as soon as a contact point has been worked on, the same registers are re-loaded with that
+// point's rows of the next knot -- the loads then have the rest of the knot to land, and the single wavefront of a SIMD
+// does not sit through a memory latency per contact point.  Fetched when any lane of the wave has the point in stance.
+template <int NL>
+struct RowBuf {
+  double u[NL][3], du[NL][3], s[NL][6], lam[NL][6];
+};
+template <int NL, bool WITH_DU, bool WITH_ROWS>
+QL_FN void prefetch_leg(const Ctx& c, const WsOff& O, unsigned con, int k, int l, RowBuf<NL>& R) {
+  if (!QL_ANY((con >> l) & 1u)) return;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) R.u[l][a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+  if (WITH_DU)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) R.du[l][a] = c.W(O.dU + 3 * NL * k + 3 * l + a);
+  if (WITH_ROWS)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      R.s[l][i] = c.W(O.S + 6 * NL * k + 6 * l + i);
+      R.lam[l][i] = c.W(O.LAM + 6 * NL * k + 6 * l + i);
+    }
+}
+// slacks, multipliers and Tapia flags (sign of the stored slack) of contact point l out of the buffer
+template <int NL>
+QL_FN unsigned take_rows(const RowBuf<NL>& R, int l, double sv[6], double lv[6]) {
+  unsigned kap = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const double sx = R.s[l][i];
+    lv[i] = R.lam[l][i];
+    kap |= (sx < 0.0) ? (1u << i) : 0u;
+    sv[i] = fabs(sx);
+  }
+  return kap;
+}
+
+// QL_PF_x = 0 (diagnostics): pass x fetches the rows of a contact point where it uses them instead of a knot ahead
+#ifndef QL_PF_A
+#define QL_PF_A 1
+#endif
+#ifndef QL_PF_B
+#define QL_PF_B 1
+#endif
+#ifndef QL_PF_C
+#define QL_PF_C 1
+#endif
+#ifndef QL_PF_CH      // old state and gains of pass C one knot ahead
+#define QL_PF_CH 1
+#endif
+#ifndef QL_CR_PER_KNOT    // pass B rebuilds the cone rows per knot instead of keeping 24 registers through the factorisations
+#define QL_CR_PER_KNOT 1
+#endif
+
 // ---- set-up: record -> constants, initial guess U = u_ref (QuatMpc.cpp:253), slacks and multipliers ------------------
 template <int NL>
 QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const double* rec, LaneK<NL>& K, LaneState& st) {
@@ -506,20 +590,24 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   const bool full = ap >= 1.0;
   const bool tapia = (ap >= 0.99) && (ad >= 0.99);
   double slsum = 0.0;
+  RowBuf<NL> R;       // rows, inputs and trial increments of the contact points, one knot ahead (not at the first iteration:
+                      // nothing is pending then and every input is at its reference)
+  if (!first && QL_PF_A)
+#pragma unroll
+    for (int l = 0; l < NL; ++l) prefetch_leg<NL, true, true>(c, O, st.con, 0, l, R);
   for (int k = 0; k < N; ++k) {
+    const int kn = (k + 1 < N) ? k + 1 : k;
     double F[3] = {0, 0, 0}, wd[3] = {wd0[0], wd0[1], wd0[2]};
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-      if (!((st.con >> l) & 1u)) continue;
-      double u[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+      if (!first && !QL_PF_A) prefetch_leg<NL, true, true>(c, O, st.con, k, l, R);
+      if ((st.con >> l) & 1u) {
+      double u[3] = {0.0, 0.0, st.uz};
       if (!first) {
-        double du[3];
+        double du[3], sv[6], lv[6];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) du[a] = c.W(O.dU + 3 * NL * k + 3 * l + a);
-        double sv[6], lv[6];
-        const unsigned kap = load_rows<NL>(c, O, k, l, sv, lv);
+        for (int a = 0; a < 3; ++a) { u[a] = R.u[l][a]; du[a] = R.du[l][a]; }
+        const unsigned kap = take_rows<NL>(R, l, sv, lv);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
           const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
@@ -550,6 +638,8 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
         F[a] += u[a];
         wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
       }
+      }
+      if (!first && QL_PF_A) prefetch_leg<NL, true, true>(c, O, st.con, kn, l, R);
     }
     srbd_step_fw(P, gb, x, F, wd, xn);
 #pragma unroll
@@ -618,11 +708,15 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   const int N = P.N;
   double pv[12];      // cost-to-go  1/2 dx'P dx + p'dx: P in the lane-private rows c.PL(), p in registers
   double cr[18], rc0[6];
-  {
+  if (!QL_CR_PER_KNOT) {
     double s0[6];
     cone_rows(P, K.rot, cr);
     initial_rows(P, cr, st.uz, s0, rc0);
   }
+  RowBuf<NL> R;       // rows of the contact points, one knot ahead
+  if (QL_PF_B)
+#pragma unroll
+    for (int l = 0; l < NL; ++l) prefetch_leg<NL, false, true>(c, O, st.con, N - 1, l, R);
   bool ok = true;
   const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
   {
@@ -654,17 +748,24 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     double wd[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) wd[a] = K.wd0[a];
+    const int kn = (k > 0) ? k - 1 : 0;
+    if (QL_CR_PER_KNOT) {      // rebuilt per knot: 24 registers that need not live through the factorisations
+      double s0[6];
+      cone_rows(P, K.rot, cr);
+      initial_rows(P, cr, st.uz, s0, rc0);
+    }
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-      if (!((st.con >> l) & 1u)) continue;
+      if (!QL_PF_B) prefetch_leg<NL, false, true>(c, O, st.con, k, l, R);
+      if ((st.con >> l) & 1u) {
       double u[3], r[3], B[9];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) { u[a] = c.W(O.U + 3 * NL * k + 3 * l + a); r[a] = K.foot[3 * l + a]; }
+      for (int a = 0; a < 3; ++a) { u[a] = R.u[l][a]; r[a] = K.foot[3 * l + a]; }
       leg_bw0(P, r, B);
 #pragma unroll
       for (int a = 0; a < 3; ++a) wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
       double sv[6], lv[6];
-      const unsigned kap = load_rows<NL>(c, O, k, l, sv, lv);
+      const unsigned kap = take_rows<NL>(R, l, sv, lv);
       LegBlk lb;
       leg_block(P, cr, rc0, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
       // V = [T ; Bw0 T] (6 x 3), Vt = V L^-T (columns), G += sum_j id_j vt_j vt_j', r6 += sum_j vt_j id_j y_j, y = L^-1 gq
@@ -688,6 +789,8 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
 #pragma unroll
         for (int j = i; j < 6; ++j) G6[S6I(i, j)] += a0 * v0[j] + a1 * v1[j] + a2 * v2[j];
       }
+      }
+      if (QL_PF_B) prefetch_leg<NL, false, true>(c, O, st.con, kn, l, R);
     }
     QL_FENCE();
     QL_TICK(st, LP_B_LEGS);
@@ -992,12 +1095,20 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
         for (int t = 0; t < 6; ++t) s += Z[S6I(i, t)] * yj[t];
         z[i] = s;
       }
+      double xg[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         double s = yj[i];
 #pragma unroll
         for (int t = 0; t < 6; ++t) s -= S6[S6I(i, t)] * z[t];
-        c.W(O.G + D::GAIN * k + 13 * i + j) = s;
+        xg[i] = s;
+      }
+      if (j < 12) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) c.W(O.G + D::GAIN * k + 3 * (j < 12 ? j : 0) + i) = pack2f((float)xg[2 * i], (float)xg[2 * i + 1]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) c.W(O.G + D::GAIN * k + 36 + i) = xg[i];
       }
       if (j < 12) {
 #pragma unroll
@@ -1059,14 +1170,30 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   double xc[13], xn[13];
 #pragma unroll
   for (int i = 0; i < 13; ++i) xc[i] = c.W(O.X + i);
+  // one knot ahead: old state, gains, rows of the contact points
+  double xo[13], gn[D::GAIN];
+  RowBuf<NL> R;
+  if (QL_PF_CH) {
+#pragma unroll
+    for (int i = 0; i < 13; ++i) xo[i] = xc[i];
+#pragma unroll
+    for (int i = 0; i < D::GAIN; ++i) gn[i] = c.W(O.G + i);
+  }
+  if (QL_PF_C)
+#pragma unroll
+    for (int l = 0; l < NL; ++l) prefetch_leg<NL, false, true>(c, O, st.con, 0, l, R);
   double ap = 1.0, ad = 1.0, stp = 0.0;
   for (int k = 0; k < N; ++k) {
+    const int kn = (k + 1 < N) ? k + 1 : k;      // the last knot re-reads itself
     // dx = xc (-) X_k in error coordinates (inverse Cayley map, QuaternionUtils.cpp:16-18)
     double dx[12];
-    {
-      double xo[13];
+    if (!QL_PF_CH) {
 #pragma unroll
       for (int i = 0; i < 13; ++i) xo[i] = c.W(O.X + 13 * k + i);
+#pragma unroll
+      for (int i = 0; i < D::GAIN; ++i) gn[i] = c.W(O.G + D::GAIN * k + i);
+    }
+    {
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         dx[a] = xc[a] - xo[a];
@@ -1081,23 +1208,35 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     }
     double zeta[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      double s = c.W(O.G + D::GAIN * k + 13 * i + 12);
+    for (int i = 0; i < 6; ++i) zeta[i] = gn[36 + i];
 #pragma unroll
-      for (int j = 0; j < 12; ++j) s += c.W(O.G + D::GAIN * k + 13 * i + j) * dx[j];
-      zeta[i] = s;
+    for (int j = 0; j < 12; ++j)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float g0, g1;
+        unpack2f(gn[3 * j + i], g0, g1);
+        zeta[2 * i] += (double)g0 * dx[j];
+        zeta[2 * i + 1] += (double)g1 * dx[j];
+      }
+    // next knot's old state and gains into the registers just consumed
+    if (QL_PF_CH) {
+#pragma unroll
+      for (int i = 0; i < 13; ++i) xo[i] = c.W(O.X + 13 * kn + i);
+#pragma unroll
+      for (int i = 0; i < D::GAIN; ++i) gn[i] = c.W(O.G + D::GAIN * kn + i);
     }
     QL_TICK(st, LP_C_HEAD);
     double F[3] = {0, 0, 0}, wd[3] = {wd0[0], wd0[1], wd0[2]};
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-      if (!((st.con >> l) & 1u)) continue;
+      if (!QL_PF_C) prefetch_leg<NL, false, true>(c, O, st.con, k, l, R);
+      if ((st.con >> l) & 1u) {
       double u[3], r[3], B[9];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) { u[a] = c.W(O.U + 3 * NL * k + 3 * l + a); r[a] = K.foot[3 * l + a]; }
+      for (int a = 0; a < 3; ++a) { u[a] = R.u[l][a]; r[a] = K.foot[3 * l + a]; }
       leg_bw0(P, r, B);
       double sv[6], lv[6];
-      const unsigned kap = load_rows<NL>(c, O, k, l, sv, lv);
+      const unsigned kap = take_rows<NL>(R, l, sv, lv);
       LegBlk lb;
       leg_block(P, cr, rc0, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
       // rhs = T'(zeta_f + Bw0' zeta_t) + gq;  du = -T Db^-1 rhs
@@ -1133,6 +1272,8 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
         F[a] += u[a];
         wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
       }
+      }
+      if (QL_PF_C) prefetch_leg<NL, false, true>(c, O, st.con, kn, l, R);
     }
     QL_TICK(st, LP_C_LEGS);
     srbd_step_fw(P, gb, xc, F, wd, xn);
