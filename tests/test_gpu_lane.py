@@ -1,0 +1,151 @@
+"""GPU suite (-m gpu): the lane-per-instance kernel of large batches (csrc/qmpc_lane.hip, qmpc_lane_core.h) through the C ABI,
+against the CPU oracle and against the wave-per-instance kernels.
+
+The lane kernel solves the same problem with the same interior-point iteration; the Newton system of a knot is eliminated
+in the wrench form (qmpc_lane_core.h), so iterates agree with the oracle to rounding and iteration counts are the same
+except where a stopping test sits on its threshold.  Tolerances: forces 1e-6 N (measured 5e-11), status words equal,
+iteration counts equal on >= 97 % of the instances; swing-leg forces exactly 0."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    return pkg.load_library()
+
+
+def _forced(monkeypatch, variant):
+    monkeypatch.setenv("QMPC_VARIANT", str(variant))     # read by qmpc_create
+
+
+def _edge_records(pkg, rec):
+    """rec with a stand pose in front, one record without stance legs and one with a NaN: status paths of the set-up"""
+    rec = np.concatenate([pkg.go1_stand_input(), rec])
+    rec["contacts"][5] = 0.0
+    rec["lin_vel_body"][9, 1] = np.nan
+    return rec
+
+
+@pytest.mark.parametrize("N,B", [(10, 4096), (20, 1024), (5, 700), (1, 130), (32, 256)])
+def test_lane_kernel_matches_oracle(pkg, lib, oracle, monkeypatch, N, B):
+    _forced(monkeypatch, 4)
+    p = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
+    rec = _edge_records(pkg, pkg.random_go1_trot_states(B - 1, config_id=2 if N != 20 else 3))
+    s = pkg.Solver(p, B, device=0, lib=lib)
+    f, info = s.solve(rec)
+    s.close()
+    fo, io = oracle.solve(p, rec, threads=8)
+    assert np.array_equal(info["status"], io["status"])
+    assert info["status"][5] == pkg.NO_CONTACT and info["status"][9] == pkg.NAN_INPUT
+    assert (np.delete(info["status"], [5, 9]) == 0).all()
+    assert np.abs(f - fo).max() < 1e-6
+    assert np.abs(f[np.repeat(rec["contacts"] == 0, 3, axis=1)]).max() == 0.0
+    assert np.abs(f[[5, 9]]).max() == 0.0
+    di = np.abs(info["iterations"].astype(int) - io["iterations"].astype(int))
+    # long horizons have instances with 50+ iterations whose paths part (both reach the same point): counts within one on 98 %
+    assert (di == 0).mean() >= 0.97 and (di <= 1).mean() >= 0.98
+    ok = info["status"] == 0
+    assert np.abs(info["cost"][ok] - io["cost"][ok]).max() < 1e-9 * max(1.0, np.abs(io["cost"][ok]).max())
+    assert info["max_violation"].max() < 1e-8
+
+
+def test_lane_kernel_equals_wave_kernel_on_the_same_batch(pkg, lib, monkeypatch):
+    """Both kernel families on one batch (device buffers): same status words, forces within 1e-7 N, and the lane kernel's
+    result of an instance does not depend on where in the batch (which lane, which wavefront) it is solved."""
+    B, N = 8192, 10
+    p = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
+    rec = pkg.random_go1_trot_states(B, config_id=2)
+    out = {}
+    for v in (4, 0):
+        _forced(monkeypatch, v)
+        s = pkg.Solver(p, B, device=0, lib=lib)
+        out[v] = s.solve(rec)
+        if v == 4:
+            perm = np.random.default_rng(3).permutation(B)
+            fp, ip = s.solve(rec[perm])
+            assert np.array_equal(fp, out[4][0][perm]) and np.array_equal(ip["iterations"], out[4][1]["iterations"][perm])
+            f2, _ = s.solve(rec)
+            assert np.array_equal(f2, out[4][0])                     # deterministic
+            fs, _ = s.solve(rec[:100])                               # a ragged, partly filled wavefront
+            assert np.array_equal(fs, out[4][0][:100])
+        s.close()
+    assert np.array_equal(out[4][1]["status"], out[0][1]["status"])
+    assert np.abs(out[4][0] - out[0][0]).max() < 1e-7
+
+
+def test_lane_kernel_8_point_model(pkg, lib, oracle, monkeypatch):
+    _forced(monkeypatch, 4)
+    N, B = 16, 512
+    p = pkg.default_biped8_params(N, pkg.MODE_CONVERGED, lib)
+    rec = pkg.random_biped8_states(B, config_id=5)
+    s = pkg.Solver(p, B, device=0, lib=lib)
+    f, info = s.solve8(rec)
+    s.close()
+    fo, io = oracle.solve8(p, rec, threads=8)
+    assert np.array_equal(info["status"], io["status"]) and (info["status"] == 0).all()
+    assert np.abs(f - fo).max() < 1e-5                                # corner forces of a foot: DESIGN.md 3d
+    feet = rec["foot_pos_body"].reshape(B, 8, 3)
+    w = lambda x: np.concatenate([x.reshape(B, 8, 3).sum(1), np.cross(feet, x.reshape(B, 8, 3)).sum(1)], axis=1)
+    assert np.abs(w(f) - w(fo)).max() < 1e-7
+    assert np.abs(f[np.repeat(rec["contacts"] == 0, 3, axis=1)]).max() == 0.0
+
+
+@pytest.mark.parametrize("name,gen,dp,N,cfg,nu", [("quat_n10", "random_go1_trot_states", "default_params", 10, 2, 12),
+                                                   ("quat_n20", "random_go1_trot_states", "default_params", 20, 3, 12),
+                                                   ("biped8_n16", "random_biped8_states", "default_biped8_params", 16, 5, 24)])
+def test_lane_kernel_reaches_the_certified_points(pkg, lib, monkeypatch, name, gen, dp, N, cfg, nu):
+    """First-knot forces of the algorithm-independent KKT fixtures (tests/test_kkt_certificate.py), no oracle involved."""
+    from pathlib import Path
+    _forced(monkeypatch, 4)
+    U = np.load(Path(__file__).parent / "golden" / "kkt_fixtures.npz")[name + "_U"]
+    rec = getattr(pkg, gen)(U.shape[0], config_id=cfg)
+    s = pkg.Solver(getattr(pkg, dp)(N, pkg.MODE_CONVERGED, lib), U.shape[0], device=0, lib=lib)
+    f, info = (s.solve8 if nu == 24 else s.solve)(rec)
+    s.close()
+    assert (info["status"] == 0).all()
+    assert np.abs(f - U[:, 0, :]).max() < (1e-5 if nu == 24 else 1e-6)
+
+
+def test_lane_kernel_parameters_follow_the_handle(pkg, lib, oracle, monkeypatch):
+    """The lane kernel reads its parameter block from constant memory, one slot per handle: two handles with different
+    parameters, used alternately, and qmpc_set_params between two solves."""
+    _forced(monkeypatch, 4)
+    rec = pkg.random_go1_trot_states(256, config_id=2)
+    pa = pkg.default_params(10, pkg.MODE_CONVERGED, lib)
+    pb = pkg.default_params(10, pkg.MODE_CONVERGED, lib)
+    pb.mu, pb.fz_max, pb.w = 0.5, 80.0, 20.0
+    sa, sb = pkg.Solver(pa, 256, device=0, lib=lib), pkg.Solver(pb, 256, device=0, lib=lib)
+    fa, _ = sa.solve(rec); fb, _ = sb.solve(rec); fa2, _ = sa.solve(rec)
+    assert np.array_equal(fa, fa2)
+    assert np.abs(fa - oracle.solve(pa, rec, threads=8)[0]).max() < 1e-6
+    assert np.abs(fb - oracle.solve(pb, rec, threads=8)[0]).max() < 1e-6
+    sa.set_params(pb)
+    assert np.array_equal(sa.solve(rec)[0], fb)
+    sa.close(); sb.close()
+
+
+def test_config4_workload_on_one_gpu(pkg, lib, oracle):
+    """BASELINE config 4's own workload -- 262144 Go1 instances, N = 10, generator seed 0x5EED0000 + 4 -- on ONE GPU (the
+    8-GPU run shards it in blocks of 32768): four rounds of the resident lanes of the lane kernel.  Size-independent
+    properties + a 64-instance sample against the oracle."""
+    B, N = 262144, 10
+    p = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
+    rec = pkg.random_go1_trot_states(B, config_id=4)
+    s = pkg.Solver(p, B, device=0, lib=lib)
+    f, info = s.solve(rec)
+    assert (info["status"] == 0).all(), np.unique(info["status"], return_counts=True)
+    assert info["max_violation"].max() < 1e-8
+    assert np.abs(f[np.repeat(rec["contacts"] == 0, 3, axis=1)]).max() == 0.0
+    R = rec["rot"].reshape(B, 3, 3)
+    fw = np.einsum("bij,blj->bli", R, f.reshape(B, 4, 3))
+    assert (fw[..., 2] >= -1e-8).all() and (fw[..., 2] <= p.fz_max + 1e-8).all()
+    assert (np.abs(fw[..., 0]) <= p.mu * fw[..., 2] + 1e-7).all() and (np.abs(fw[..., 1]) <= p.mu * fw[..., 2] + 1e-7).all()
+    # the shard a rank of the 8-GPU run would solve gives the same bits
+    fsh, _ = s.solve(rec[3 * 32768:4 * 32768])
+    assert np.array_equal(fsh, f[3 * 32768:4 * 32768])
+    sub = np.arange(0, B, B // 64)[:64]
+    fo, io = oracle.solve(p, rec[sub], threads=8)
+    assert (io["status"] == 0).all() and np.abs(f[sub] - fo).max() < 1e-6
+    s.close()

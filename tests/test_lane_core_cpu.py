@@ -1,0 +1,80 @@
+"""CPU suite: numerics of the lane-per-instance solver core (quaternion-mpc_amd/csrc/qmpc_lane_core.h).
+
+The core is plain C++ that hipcc compiles into qmpc_lane_kernel; tests/native/lane_core_host.cpp compiles THE SAME TEXT
+with g++ (one instance after the other, unit strides) so that the wrench-form elimination, the single-precision feedback
+gains and the control flow can be checked against the oracle without a GPU.  Test infrastructure only: the product has no
+CPU path."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+HERE = Path(__file__).resolve().parent
+SRC = HERE / "native" / "lane_core_host.cpp"
+LIB = HERE / "native" / "liblane_core_host.so"
+CORE = HERE.parent / "quaternion-mpc_amd" / "csrc"
+
+
+@pytest.fixture(scope="module")
+def lane(pkg):
+    deps = [SRC, CORE / "qmpc_lane_core.h", CORE / "qmpc_params_dev.h", HERE.parent / "include" / "qmpc.h"]
+    if not LIB.exists() or any(LIB.stat().st_mtime < d.stat().st_mtime for d in deps):
+        # no contraction: the oracle is compiled without it as well
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                        "-o", str(LIB), str(SRC)], check=True)
+    lib = C.CDLL(str(LIB))
+    lib.lane_host_solve.restype = C.c_int
+
+    def solve(p, rec, nu=12):
+        rec = np.ascontiguousarray(rec)
+        B = rec.shape[0]
+        f = np.zeros((B, nu))
+        info = np.zeros(B, dtype=pkg.INFO_DTYPE)
+        rc = lib.lane_host_solve(C.byref(p), B, rec.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p),
+                                 info.ctypes.data_as(C.c_void_p))
+        assert rc == 0, rc
+        return f, info
+    return solve
+
+
+@pytest.mark.parametrize("N,B,cfg", [(10, 192, 2), (20, 64, 3), (1, 32, 2), (32, 24, 2)])
+def test_lane_core_matches_oracle(pkg, oracle, lane, N, B, cfg):
+    p = oracle.default_params(N, 0)
+    rec = np.concatenate([pkg.go1_stand_input(), pkg.random_go1_trot_states(B - 1, config_id=cfg)])
+    rec["contacts"][3] = 0.0
+    rec["quat"][6, 0] = np.inf
+    f, info = lane(p, rec)
+    fo, io = oracle.solve(p, rec, threads=8)
+    assert np.array_equal(info["status"], io["status"])
+    assert info["status"][3] == pkg.NO_CONTACT and info["status"][6] == pkg.NAN_INPUT
+    assert np.abs(f - fo).max() < 1e-6           # measured 3e-10
+    di = np.abs(info["iterations"].astype(int) - io["iterations"].astype(int))
+    assert (di == 0).mean() >= 0.95 and (di <= 1).mean() >= 0.97
+    assert np.abs(f[np.repeat(rec["contacts"] == 0, 3, axis=1)]).max() == 0.0
+    ok = info["status"] == 0
+    assert np.abs(info["cost"][ok] - io["cost"][ok]).max() < 1e-9 * max(1.0, np.abs(io["cost"][ok]).max())
+
+
+def test_lane_core_8_point_model(pkg, oracle, lane):
+    p = oracle.default_biped8_params(16, 0)
+    rec = pkg.random_biped8_states(48, config_id=5)
+    f, info = lane(p, rec, nu=24)
+    fo, io = oracle.solve8(p, rec, threads=8)
+    assert np.array_equal(info["status"], io["status"]) and (info["status"] == 0).all()
+    assert np.abs(f - fo).max() < 1e-5 and np.array_equal(info["iterations"], io["iterations"])
+
+
+@pytest.mark.parametrize("name,gen,dp,N,cfg,nu", [("quat_n10", "random_go1_trot_states", "default_params", 10, 2, 12),
+                                                   ("quat_n20", "random_go1_trot_states", "default_params", 20, 3, 12),
+                                                   ("biped8_n16", "random_biped8_states", "default_biped8_params", 16, 5, 24)])
+def test_lane_core_reaches_the_certified_points(pkg, oracle, lane, name, gen, dp, N, cfg, nu):
+    """The algorithm-independent KKT fixtures (tests/test_kkt_certificate.py): the lane core's first-knot forces are the
+    certified points' (the lane kernel returns forces only, not the whole input trajectory)."""
+    fx = np.load(HERE / "golden" / "kkt_fixtures.npz")
+    U = fx[name + "_U"]
+    rec = getattr(pkg, gen)(U.shape[0], config_id=cfg)
+    f, info = lane(getattr(oracle, dp)(N, 0), rec, nu=nu)
+    assert (info["status"] == 0).all()
+    assert np.abs(f - U[:, 0, :]).max() < (1e-5 if nu == 24 else 1e-6)
