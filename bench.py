@@ -145,16 +145,49 @@ def traffic_from_profiles(B, N, model):
     """HBM traffic per launch from the newest committed PMC pass of THIS workload (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs, tools/pmc_traffic.py; PMC counters cannot be collected from inside the timed
     process).  Returns (bytes or None, source description)."""
-    if not (B == 1024 and N == 10 and model == "quat"):
-        return None, "no committed PMC pass for this workload (profiles/ holds B=1024 and B=32768, N=10, quat)"
+    if model != "quat":
+        return None, "no committed PMC pass for this model"
+    pat = "r*_pmc_traffic.json" if (B == 1024 and N == 10) else f"r*_pmc_traffic_b{B}_n{N}.json"
     try:
-        latest = sorted((REPO / "profiles").glob("r*_pmc_traffic.json"),
+        latest = sorted((REPO / "profiles").glob(pat),
                         key=lambda q: [int(t) for t in re.findall(r"\d+", q.name)])[-1]
         pm = json.loads(latest.read_text())
         src = f"profiles/{latest.name}: {pm.get('source', '')}; {pm.get('calibration_note', 'FETCH_SIZE uncalibrated for 8-byte-per-lane reads')}"
         return pm.get("traffic_bytes_per_launch_calibrated", pm["traffic_bytes_per_launch"]), src
     except (OSError, ValueError, KeyError, IndexError):
-        return None, "profiles/*_pmc_traffic.json not found"
+        return None, f"no committed PMC pass for this workload (profiles/{pat})"
+
+
+def self_launch(n: int, argv, module: str = "torch.distributed.run", extra_env=None) -> int:
+    """Re-run this script under the torch.distributed launcher with one rank per GPU (127.0.0.1 rendezvous: the container
+    hostname may not resolve).  Returns the launcher's exit code; the ranks' stdout (rank 0 prints the JSON line) passes
+    through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", module, "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra_env or {})
+    return subprocess.call(cmd, env=env)
+
+
+def sq_from_profiles(B, N, model):
+    """MFMA-busy and issue fractions of the dominant kernel from the newest committed SQ counter pass of this workload
+    (tools/pmc_sq.sh / tools/pmc_lane.sh: rocprofv3 --pmc in runs of their own)."""
+    tag = f"b{B}_n{N}"
+    cands = sorted((REPO / "profiles").glob(f"r*_sq_summary_{tag}.json"), key=lambda q: [int(t) for t in re.findall(r"\d+", q.name)])
+    if model != "quat" or not cands:
+        return None
+    try:
+        d = json.loads(cands[-1].read_text())
+        d["source"] = f"profiles/{cands[-1].name}"
+        return d
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -175,6 +208,8 @@ def main():
                     help="skip the secondary figure of the reference's own solver mode (AL-iLQR, 10 iterations) on the device")
     ap.add_argument("--no-closed-loop", action="store_true",
                     help="skip the secondary device-resident closed-loop figure (N=1, quat only)")
+    ap.add_argument("--no-large-batch", action="store_true",
+                    help="skip the secondary legs on the large-batch configurations (B=32768 N=10, B=65536 N=20; N=1, quat only)")
     ap.add_argument("--no-config4", action="store_true",
                     help="multi-rank runs: skip the extra leg on BASELINE config 4 (262144 instances over the ranks)")
     ap.add_argument("--check", action="store_true", help="also compare a sample against the oracle")
@@ -186,15 +221,28 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (one rank per GPU of this node, RCCL over xGMI)
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: WORLD_SIZE={world} != --gpus {args.gpus}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+        sys.exit(2)
     multi = world > 1 or args.force_dist        # the collective path is on
+    if os.environ.get("QMPC_BENCH_DRYRUN"):
+        # launcher check without GPUs (tests/test_bench_cpu.py): rendezvous over gloo, one collective, one JSON line
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "sum_of_ranks": float(t.item())}), flush=True)
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the product path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
@@ -283,6 +331,13 @@ def main():
         return {"elapsed": elapsed, "kernel_ms": kernel_ms, "info": info, "forces": forces, "rec": rec,
                 "solver": solver, "d_in": d_in}
 
+    def kernel_name(batch):
+        """dominant kernel of a launch of `batch` instances (qmpc_hip.hip: launch_solve)"""
+        lane_min = int(os.environ.get("QMPC_LANE_MIN", "24576"))
+        var = os.environ.get("QMPC_VARIANT", "0")
+        lane = args.model != "convex" and (var == "4" or (var == "0" and batch >= lane_min))
+        return "qmpc_lane_kernel (lane per instance)" if lane else "qmpc_solve_kernel (wave per instance)"
+
     leg = timed_leg(B, config_id, args.steps, args.warmup)
     elapsed, kernel_ms, info, rec = leg["elapsed"], leg["kernel_ms"], leg["info"], leg["rec"]
     solver, d_in, d_f = leg["solver"], leg["d_in"], leg["forces"]
@@ -330,12 +385,17 @@ def main():
             "rates": {"device_resident": {"value": value, "unit": "solves/s", "ms_per_step": 1e3 * elapsed / args.steps}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "qmpc_solve_kernel", "kernel_ms": kernel_ms,
+                         "kernel": kernel_name(B), "kernel_ms": kernel_ms,
                          "algorithmic_flops_per_launch": w_alg * B,
                          "algorithmic_bytes_per_launch": B * (8 * (64 if biped else 48) + 8 * NU + 40),
                          "note": "FP64 MFMA/vector roof (78.6 TF); algorithmic work W_alg=159*N kFLOP/solve (SURVEY 8d); "
                                  "compulsory HBM traffic is 460 B/solve, i.e. not the binding roof"},
         }
+        sq = sq_from_profiles(B, N, args.model)
+        if sq is not None:
+            out["roofline"]["mfma_busy"] = sq.get("mfma_busy")
+            out["roofline"]["issue_frac"] = sq.get("issue_frac")
+            out["roofline"]["sq_source"] = sq.get("source")
         if config4 is not None:
             out["config4"] = config4
         if args.check:
@@ -357,6 +417,34 @@ def main():
                 "value": B * reps / dt, "unit": "solves/s", "ms_per_call": 1e3 * dt / reps,
                 "note": "qmpc_solve with pageable host buffers: H2D of the records + kernel + D2H of forces and status, blocking"}
             out["host_buffer_call"] = out["rates"]["host_buffer_call"]
+            out["value_host_inclusive"] = out["rates"]["host_buffer_call"]["value"]     # SURVEY 8d's own definition of the metric
+        if world == 1 and args.model == "quat" and not args.no_large_batch and B == 1024 and N == 10:
+            # secondary: the large-batch configurations of BASELINE.json on this GPU (the lane-per-instance kernel):
+            # the per-GPU share of config 4 (32768 instances, N=10) and config 3 (65536 instances, N=20); never `value`
+            out["large_batch"] = []
+            for (Bl, Nl, cfg, what) in ((32768, 10, 4, "per-GPU share of BASELINE config 4 (262144 instances over 8 GPUs)"),
+                                        (65536, 20, 3, "BASELINE config 3")):
+                pl_ = pkg.default_params(Nl, pkg.MODE_CONVERGED, lib)
+                kl = max(3, min(10, args.steps))
+                lg = timed_leg(Bl, cfg, kl, 2, prm=pl_, model="quat")
+                lg["solver"].close()
+                w_l = W_ALG_KFLOP_PER_KNOT * 1e3 * Nl
+                ach = w_l * Bl / (lg["kernel_ms"] * 1e-3) / 1e12
+                tr, tr_src = traffic_from_profiles(Bl, Nl, "quat")
+                ent = {"workload": f"Batch={Bl} random Go1 states, N={Nl}, seed 0x5EED0000+{cfg}: {what}",
+                       "value": Bl * kl / lg["elapsed"], "unit": "solves/s", "steps": kl, "ms_per_step": 1e3 * lg["elapsed"] / kl,
+                       "kernel": kernel_name(Bl), "kernel_ms": lg["kernel_ms"],
+                       "converged": int((lg["info"]["status"] == 0).sum()), "mean_iterations": float(lg["info"]["iterations"].mean()),
+                       "roofline": {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": ach / FP64_PEAK_TFLOPS, "traffic": tr, "traffic_source": tr_src,
+                                    "hbm_GBps": (tr / (lg["kernel_ms"] * 1e-3) / 1e9) if tr else None,
+                                    "hbm_frac_of_8TBps": (tr / (lg["kernel_ms"] * 1e-3) / 8e12) if tr else None}}
+                sql = sq_from_profiles(Bl, Nl, "quat")
+                if sql is not None:
+                    ent["roofline"]["issue_frac"] = sql.get("issue_frac")
+                    ent["roofline"]["sq_source"] = sql.get("source")
+                out["large_batch"].append(ent)
+                del lg
         if world == 1 and not args.no_in_flight:
             out["two_in_flight"] = two_in_flight(pkg, lib, params, args, d_in, NU)
         if world == 1 and args.model in ("quat", "convex") and not args.no_reference_mode:

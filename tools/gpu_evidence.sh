@@ -21,9 +21,9 @@ timeout 600 python bench.py --no-cpu-baseline --model biped8 --horizon 16 --batc
 timeout 300 python tools/latency_b1.py > "$out/latency_b1.txt" 2>/dev/null
 timeout 300 python tools/inflight_bench.py > "$out/inflight.txt" 2>/dev/null
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$out/prof" -- python "$root/bench.py" --no-cpu-baseline --no-in-flight --no-closed-loop --no-reference-mode > "$out/prof_bench.json" 2> "$out/prof_bench.err"
-timeout 600 rocprofv3 --pmc FETCH_SIZE -f csv -d "$out/pmc_fetch" -- python "$root/bench.py" --no-cpu-baseline --no-in-flight --no-closed-loop --no-reference-mode --steps 10 > /dev/null 2> "$out/pmc_fetch.err"
-timeout 600 rocprofv3 --pmc WRITE_SIZE -f csv -d "$out/pmc_write" -- python "$root/bench.py" --no-cpu-baseline --no-in-flight --no-closed-loop --no-reference-mode --steps 10 > /dev/null 2> "$out/pmc_write.err"
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$out/prof" -- python "$root/bench.py" --no-cpu-baseline --no-in-flight --no-large-batch --no-closed-loop --no-reference-mode > "$out/prof_bench.json" 2> "$out/prof_bench.err"
+timeout 600 rocprofv3 --pmc FETCH_SIZE -f csv -d "$out/pmc_fetch" -- python "$root/bench.py" --no-cpu-baseline --no-in-flight --no-large-batch --no-closed-loop --no-reference-mode --steps 10 > /dev/null 2> "$out/pmc_fetch.err"
+timeout 600 rocprofv3 --pmc WRITE_SIZE -f csv -d "$out/pmc_write" -- python "$root/bench.py" --no-cpu-baseline --no-in-flight --no-large-batch --no-closed-loop --no-reference-mode --steps 10 > /dev/null 2> "$out/pmc_write.err"
 cd "$root"
 find "$out" -name "*.csv" -size +8M -delete
 ls -R "$out" | head -50
