@@ -1154,6 +1154,62 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   return ok;
 }
 
+// contact points are worked on in PAIRS inside one basic block, so that the two independent dependency chains (weights
+// -> frame -> 3 x 3 factorisation: three reciprocals and two reciprocal square roots in series) interleave in the single
+// wavefront of a SIMD.  Diagonal pairs for four legs -- a trotting robot has exactly one pair in stance -- and the two
+// halves of a foot edge for the 8-point model.
+template <int NL>
+constexpr int pair_leg(int pr, int j) { return NL == 4 ? (j == 0 ? pr : 3 - pr) : 2 * pr + j; }
+
+// pass C's work on one contact point, free of memory operations and branches (the caller discards the result of a point
+// that is not in stance)
+struct LegOutC {
+  double du[3], u[3], B[9];
+  double ap, ad, stp;
+};
+template <int NL>
+QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr[18], const double rc0[6], const RowBuf<NL>& R,
+                         int l, const double zeta[6], const LaneState& st, LegOutC& o) {
+  double u[3], r[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { u[a] = R.u[l][a]; r[a] = K.foot[3 * l + a]; }
+  leg_bw0(P, r, o.B);
+  const double* B = o.B;
+  double sv[6], lv[6];
+  const unsigned kap = take_rows<NL>(R, l, sv, lv);
+  LegBlk lb;
+  leg_block(P, cr, rc0, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
+  // rhs = T'(zeta_f + Bw0' zeta_t) + gq;  du = -T Db^-1 rhs
+  double t[3], rh[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) t[a] = zeta[a] + B[a] * zeta[3] + B[3 + a] * zeta[4] + B[6 + a] * zeta[5];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) rh[a] = lb.T[a] * t[0] + lb.T[3 + a] * t[1] + lb.T[6 + a] * t[2] + lb.gq[a];
+  const double y0 = rh[0], y1 = rh[1] - lb.l10 * y0, y2 = rh[2] - lb.l20 * y0 - lb.l21 * y1;
+  const double z2 = y2 * lb.id2;
+  const double z1 = y1 * lb.id1 - lb.l21 * z2;
+  const double z0 = y0 * lb.id0 - lb.l10 * z1 - lb.l20 * z2;
+  double stp = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    o.du[a] = -(lb.T[3 * a] * z0 + lb.T[3 * a + 1] * z1 + lb.T[3 * a + 2] * z2);
+    stp = fmax(stp, fabs(o.du[a]));
+    o.u[a] = u[a] + o.du[a];
+  }
+  // directions and fraction-to-the-boundary ratios (ipm_directions in qmpc_kernels.hip)
+  double ap = 1.0, ad = 1.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const double jd = cr[3 * i] * o.du[0] + cr[3 * i + 1] * o.du[1] + cr[3 * i + 2] * o.du[2];
+    const double kp = ((kap >> i) & 1u) ? 1.0 : 0.0;
+    const double dsv = -(jd + st.rho * rc0[i]);
+    const double dlv = (st.target - (1.0 + kp) * sv[i] * lv[i] - lv[i] * dsv) * ql_rcp(sv[i]);
+    if (dsv < 0.0) ap = fmin(ap, -P.tau * sv[i] * ql_rcp(dsv));
+    if (dlv < 0.0) ad = fmin(ad, -P.tau * lv[i] * ql_rcp(dlv));
+  }
+  o.ap = ap; o.ad = ad; o.stp = stp;
+}
+
 // ---- pass C: closed-loop trial rollout (alpha = 1) + slack / multiplier directions + step lengths ----------------------
 template <int NL>
 QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st) {
@@ -1228,52 +1284,34 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     QL_TICK(st, LP_C_HEAD);
     double F[3] = {0, 0, 0}, wd[3] = {wd0[0], wd0[1], wd0[2]};
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
-      if (!QL_PF_C) prefetch_leg<NL, false, true>(c, O, st.con, k, l, R);
-      if ((st.con >> l) & 1u) {
-      double u[3], r[3], B[9];
+    for (int pr = 0; pr < NL / 2; ++pr) {
+      const int la = pair_leg<NL>(pr, 0), lb = pair_leg<NL>(pr, 1);
+      const bool on_a = (st.con >> la) & 1u, on_b = (st.con >> lb) & 1u;
+      if (!QL_PF_C) { prefetch_leg<NL, false, true>(c, O, st.con, k, la, R); prefetch_leg<NL, false, true>(c, O, st.con, k, lb, R); }
+      if (QL_ANY(on_a || on_b)) {
+        LegOutC oa, ob;
+        leg_compute_C<NL>(P, K, cr, rc0, R, la, zeta, st, oa);
+        leg_compute_C<NL>(P, K, cr, rc0, R, lb, zeta, st, ob);
+        if (on_a) {
 #pragma unroll
-      for (int a = 0; a < 3; ++a) { u[a] = R.u[l][a]; r[a] = K.foot[3 * l + a]; }
-      leg_bw0(P, r, B);
-      double sv[6], lv[6];
-      const unsigned kap = take_rows<NL>(R, l, sv, lv);
-      LegBlk lb;
-      leg_block(P, cr, rc0, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
-      // rhs = T'(zeta_f + Bw0' zeta_t) + gq;  du = -T Db^-1 rhs
-      double t[3], rh[3];
+          for (int a = 0; a < 3; ++a) {
+            c.W(O.dU + 3 * NL * k + 3 * la + a) = oa.du[a];
+            F[a] += oa.u[a];
+            wd[a] += oa.B[3 * a] * oa.u[0] + oa.B[3 * a + 1] * oa.u[1] + oa.B[3 * a + 2] * oa.u[2];
+          }
+          ap = fmin(ap, oa.ap); ad = fmin(ad, oa.ad); stp = fmax(stp, oa.stp);
+        }
+        if (on_b) {
 #pragma unroll
-      for (int a = 0; a < 3; ++a) t[a] = zeta[a] + B[a] * zeta[3] + B[3 + a] * zeta[4] + B[6 + a] * zeta[5];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) rh[a] = lb.T[a] * t[0] + lb.T[3 + a] * t[1] + lb.T[6 + a] * t[2] + lb.gq[a];
-      const double y0 = rh[0], y1 = rh[1] - lb.l10 * y0, y2 = rh[2] - lb.l20 * y0 - lb.l21 * y1;
-      const double z2 = y2 * lb.id2;
-      const double z1 = y1 * lb.id1 - lb.l21 * z2;
-      const double z0 = y0 * lb.id0 - lb.l10 * z1 - lb.l20 * z2;
-      double du[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        du[a] = -(lb.T[3 * a] * z0 + lb.T[3 * a + 1] * z1 + lb.T[3 * a + 2] * z2);
-        c.W(O.dU + 3 * NL * k + 3 * l + a) = du[a];
-        stp = fmax(stp, fabs(du[a]));
-        u[a] += du[a];
+          for (int a = 0; a < 3; ++a) {
+            c.W(O.dU + 3 * NL * k + 3 * lb + a) = ob.du[a];
+            F[a] += ob.u[a];
+            wd[a] += ob.B[3 * a] * ob.u[0] + ob.B[3 * a + 1] * ob.u[1] + ob.B[3 * a + 2] * ob.u[2];
+          }
+          ap = fmin(ap, ob.ap); ad = fmin(ad, ob.ad); stp = fmax(stp, ob.stp);
+        }
       }
-      // directions and fraction-to-the-boundary ratios (ipm_directions in qmpc_kernels.hip)
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
-        const double kp = ((kap >> i) & 1u) ? 1.0 : 0.0;
-        const double dsv = -(jd + st.rho * rc0[i]);
-        const double dlv = (st.target - (1.0 + kp) * sv[i] * lv[i] - lv[i] * dsv) * ql_rcp(sv[i]);
-        if (dsv < 0.0) ap = fmin(ap, -P.tau * sv[i] * ql_rcp(dsv));
-        if (dlv < 0.0) ad = fmin(ad, -P.tau * lv[i] * ql_rcp(dlv));
-      }
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        F[a] += u[a];
-        wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
-      }
-      }
-      if (QL_PF_C) prefetch_leg<NL, false, true>(c, O, st.con, kn, l, R);
+      if (QL_PF_C) { prefetch_leg<NL, false, true>(c, O, st.con, kn, la, R); prefetch_leg<NL, false, true>(c, O, st.con, kn, lb, R); }
     }
     QL_TICK(st, LP_C_LEGS);
     srbd_step_fw(P, gb, xc, F, wd, xn);
