@@ -150,7 +150,7 @@ enum { LP_A = 0, LP_B_HEAD, LP_B_LEGS, LP_B_EXPAND, LP_B_MP, LP_B_CONGR, LP_B_FA
 #else
 #define QL_ANY(x) (x)
 #endif
-#if QL_DEVICE
+#if QL_DEVICE && !defined(QL_NO_FENCE)
 #define QL_FENCE() asm volatile("" ::: "memory")
 #else
 #define QL_FENCE() do { } while (0)
@@ -1084,7 +1084,9 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     QL_TICK(st, LP_B_MP);
 #pragma unroll
     for (int j = 0; j < 13; ++j) {
+#if defined(QL_COL_FENCE)
       QL_FENCE();
+#endif
       double yj[6], z[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) yj[i] = (j < 12) ? Y[j < 12 ? j : 0][i] : yg[i];

@@ -3,7 +3,7 @@
 cases=${1:-10:1024,10:32768,10:65536}
 for v in tools/.prof/var_*.so; do
   n=$(basename $v .so)
-  QMPC_LIB=$PWD/$v timeout 200 python tools/lane_bench.py --skip-wave --reps 3 --sample 16 --cases $cases 2>/dev/null | python3 -c "
+  QMPC_LIB=$PWD/$v timeout 200 python tools/lane_bench.py --skip-wave --reps 5 --sample 16 --cases $cases 2>/dev/null | python3 -c "
 import sys,json
 out=[]
 for l in sys.stdin:
