@@ -331,6 +331,7 @@ struct LegBlk {
   double l10, l20, l21;         // unit lower factor of Db = T' D_l T
   double id0, id1, id2;         // inverse pivots
   double gq[3];                 // T' g_l
+  double is[6];                 // 1 / s_i (the directions of pass C divide by the slacks again)
 };
 QL_FN void leg_block(const DevParams& P, const double cr[18], const double rc0[6], int l, const double sv[6],
                      const double lv[6], unsigned kap, double rho, double target, const double u[3], double uz, LegBlk& o) {
@@ -338,6 +339,7 @@ QL_FN void leg_block(const DevParams& P, const double cr[18], const double rc0[6
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const double is = ql_rcp(sv[i]);
+    o.is[i] = is;
     const double rc = rho * rc0[i];
     w[i] = lv[i] * is;
     gi[i] = (target + lv[i] * rc) * is - (((kap >> i) & 1u) ? lv[i] : 0.0);
@@ -1167,7 +1169,7 @@ constexpr int pair_leg(int pr, int j) { return NL == 4 ? (j == 0 ? pr : 3 - pr) 
 // that is not in stance)
 struct LegOutC {
   double du[3], u[3], B[9];
-  double ap, ad, stp;
+  double rp, dn, dd, stp;     // largest -ds_i / s_i; the row with the largest -dlam_i / lam_i as numerator / denominator
 };
 template <int NL>
 QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr[18], const double rc0[6], const RowBuf<NL>& R,
@@ -1199,17 +1201,22 @@ QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr
     o.u[a] = u[a] + o.du[a];
   }
   // directions and fraction-to-the-boundary ratios (ipm_directions in qmpc_kernels.hip)
-  double ap = 1.0, ad = 1.0;
+  // The step lengths are min(1, tau / max_i(-ds_i / s_i)) and min(1, tau / max_i(-dlam_i / lam_i)): the maxima are
+  // tracked without a division per row (1 / s_i is at hand; the multiplier ratios are compared by cross-multiplication)
+  // and the two divisions happen once, at the end of the pass.
+  double rp = 0.0, dn = 0.0, dd = 1.0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const double jd = cr[3 * i] * o.du[0] + cr[3 * i + 1] * o.du[1] + cr[3 * i + 2] * o.du[2];
     const double kp = ((kap >> i) & 1u) ? 1.0 : 0.0;
     const double dsv = -(jd + st.rho * rc0[i]);
-    const double dlv = (st.target - (1.0 + kp) * sv[i] * lv[i] - lv[i] * dsv) * ql_rcp(sv[i]);
-    if (dsv < 0.0) ap = fmin(ap, -P.tau * sv[i] * ql_rcp(dsv));
-    if (dlv < 0.0) ad = fmin(ad, -P.tau * lv[i] * ql_rcp(dlv));
+    const double dlv = (st.target - (1.0 + kp) * sv[i] * lv[i] - lv[i] * dsv) * lb.is[i];
+    rp = fmax(rp, -dsv * lb.is[i]);
+    const bool better = (-dlv) * dd > dn * lv[i];       // -dlam_i / lam_i > dn / dd   (lam_i, dd > 0)
+    dn = better ? -dlv : dn;
+    dd = better ? lv[i] : dd;
   }
-  o.ap = ap; o.ad = ad; o.stp = stp;
+  o.rp = rp; o.dn = dn; o.dd = dd; o.stp = stp;
 }
 
 // ---- pass C: closed-loop trial rollout (alpha = 1) + slack / multiplier directions + step lengths ----------------------
@@ -1240,7 +1247,7 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   if (QL_PF_C)
 #pragma unroll
     for (int l = 0; l < NL; ++l) prefetch_leg<NL, false, true>(c, O, st.con, 0, l, R);
-  double ap = 1.0, ad = 1.0, stp = 0.0;
+  double rp = 0.0, dn = 0.0, dd = 1.0, stp = 0.0;
   for (int k = 0; k < N; ++k) {
     const int kn = (k + 1 < N) ? k + 1 : k;      // the last knot re-reads itself
     // dx = xc (-) X_k in error coordinates (inverse Cayley map, QuaternionUtils.cpp:16-18)
@@ -1301,7 +1308,8 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
             F[a] += oa.u[a];
             wd[a] += oa.B[3 * a] * oa.u[0] + oa.B[3 * a + 1] * oa.u[1] + oa.B[3 * a + 2] * oa.u[2];
           }
-          ap = fmin(ap, oa.ap); ad = fmin(ad, oa.ad); stp = fmax(stp, oa.stp);
+          rp = fmax(rp, oa.rp); stp = fmax(stp, oa.stp);
+          { const bool better = oa.dn * dd > dn * oa.dd; dn = better ? oa.dn : dn; dd = better ? oa.dd : dd; }
         }
         if (on_b) {
 #pragma unroll
@@ -1310,7 +1318,8 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
             F[a] += ob.u[a];
             wd[a] += ob.B[3 * a] * ob.u[0] + ob.B[3 * a + 1] * ob.u[1] + ob.B[3 * a + 2] * ob.u[2];
           }
-          ap = fmin(ap, ob.ap); ad = fmin(ad, ob.ad); stp = fmax(stp, ob.stp);
+          rp = fmax(rp, ob.rp); stp = fmax(stp, ob.stp);
+          { const bool better = ob.dn * dd > dn * ob.dd; dn = better ? ob.dn : dn; dd = better ? ob.dd : dd; }
         }
       }
       if (QL_PF_C) { prefetch_leg<NL, false, true>(c, O, st.con, kn, la, R); prefetch_leg<NL, false, true>(c, O, st.con, kn, lb, R); }
@@ -1321,6 +1330,8 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     for (int i = 0; i < 13; ++i) xc[i] = xn[i];
     QL_TICK(st, LP_C_STEP);
   }
+  const double ap = (rp > P.tau) ? P.tau / rp : 1.0;
+  const double ad = (dn * 1.0 > P.tau * dd) ? P.tau * dd / dn : 1.0;
   st.ap = ap; st.ad = ad;
   st.last_ap = ap; st.last_ad = ad;
   st.last_step = stp;

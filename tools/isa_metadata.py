@@ -11,13 +11,14 @@ REPO = Path(__file__).resolve().parents[1]
 CSRC = REPO / "quaternion-mpc_amd" / "csrc"
 print("ISA metadata of the final build (hipcc --offload-arch=gfx950 -O2 -mllvm -disable-machine-licm -mllvm -disable-machine-sink -S --cuda-device-only; .amdgpu_metadata notes), one row per kernel")
 print("columns: kernel | vgpr_count | agpr_count | sgpr_count | vgpr_spill_count | sgpr_spill_count | private_segment_fixed_size (scratch bytes) | group_segment_fixed_size (static LDS)")
-for tu in ("qmpc_hip.hip", "qmpc_loop_fused.hip"):
+WAVE = ["-mllvm", "-disable-machine-licm", "-mllvm", "-disable-machine-sink"]
+for tu, extra in (("qmpc_hip.hip", WAVE), ("qmpc_loop_fused.hip", WAVE), ("qmpc_lane.hip", ["-mllvm", "-disable-lsr"])):
     with tempfile.TemporaryDirectory() as d:
         asm = Path(d) / "tu.s"
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-mllvm", "-disable-machine-licm", "-mllvm", "-disable-machine-sink", "-std=c++17", "-S", "--cuda-device-only", "-o", str(asm),
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", *extra, "-std=c++17", "-S", "--cuda-device-only", "-o", str(asm),
                         str(CSRC / tu)], check=True, stderr=subprocess.DEVNULL)
         txt = asm.read_text()
-    print(f"---- translation unit {tu}")
+    print(f"---- translation unit {tu}" + (" (flags: -O2 -mllvm -disable-lsr; the kernel calls its passes as functions: the per-function figures follow the kernel rows)" if "lane" in tu else ""))
     for m in re.finditer(r"- \.agpr_count:.*?\.wavefront_size:\s+\d+", txt, re.S):
         blk = m.group(0)
         g = lambda k: re.search(r"\." + k + r":\s+(\S+)", blk).group(1)
@@ -25,3 +26,10 @@ for tu in ("qmpc_hip.hip", "qmpc_loop_fused.hip"):
         name = re.sub(r"\(.*", "", name).replace("void ", "")
         print(f"{name} | {g('vgpr_count')} | {g('agpr_count')} | {g('sgpr_count')} | {g('vgpr_spill_count')} | {g('sgpr_spill_count')} | "
               f"{g('private_segment_fixed_size')} | {g('group_segment_fixed_size')}")
+    if "lane" in tu:      # non-inlined device functions: registers and scratch from the .set directives of the listing
+        for fn in re.findall(r"^\t\.set (\.L_ZN4qmpc4lane\w+)\.num_vgpr, (\d+)", txt, re.M):
+            sym = fn[0]
+            get = lambda k: re.search(re.escape(sym) + r"\." + k + r", (\d+)", txt).group(1)
+            name = subprocess.run(["/usr/bin/c++filt", sym[2:]], capture_output=True, text=True).stdout.strip()
+            name = re.sub(r"\(.*", "", name).replace("void ", "").replace("bool ", "")
+            print(f"  function {name} | vgpr {get('num_vgpr')} | agpr {get('num_agpr')} | sgpr {get('numbered_sgpr')} | scratch {get('private_seg_size')} B")
