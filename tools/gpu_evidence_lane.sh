@@ -17,3 +17,11 @@ bash tools/pmc_lane.sh $tag/lane_b65536_n20 20:65536 > /dev/null 2>&1
 find "$out" -name "*.csv" -size +2M -delete
 find "$out" -name "*_agent_info.csv" -delete
 ls -R "$out" | head -40
+timeout 900 python -m pytest tests -m gpu -q > "$out/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$out/pytest_gpu.log"
+timeout 300 python bench.py --no-cpu-baseline --no-in-flight --no-closed-loop --no-reference-mode --batch 32768 --steps 10 --warmup 2 > "$out/bench_n10_b32768.json" 2>/dev/null
+timeout 300 python bench.py --no-cpu-baseline --no-in-flight --no-closed-loop --no-reference-mode --horizon 20 --batch 65536 --steps 6 --warmup 2 > "$out/bench_n20_b65536.json" 2>/dev/null
+timeout 300 python bench.py --no-cpu-baseline --no-in-flight --no-closed-loop --no-reference-mode --batch 65536 --steps 10 --warmup 2 > "$out/bench_n10_b65536.json" 2>/dev/null
+timeout 600 python bench.py --no-cpu-baseline --no-in-flight --model biped8 --horizon 16 --batch 65536 --steps 3 --warmup 1 --check > "$out/bench_biped8_n16_b65536.json" 2>/dev/null
+timeout 300 python tools/lane_bench.py --reps 3 --sample 64 --cases 10:16384,10:24576,10:32768,10:65536,10:262144,20:32768,20:65536 > "$out/lane_vs_wave.txt" 2>&1
+timeout 300 python tools/lane_bench.py --model biped8 --reps 2 --sample 32 --cases 16:32768,16:65536 >> "$out/lane_vs_wave.txt" 2>&1
+tail -3 "$out/pytest_gpu.log"
