@@ -10,13 +10,14 @@
 //                       pattern index wraps)
 //   percent_in_state()  :261-270
 //   reset()/reset_params()/set_default_gait_pattern()  :4-31,87-108
+// The gait is a constexpr TABLE here (slots of {state, phase at which the slot ends}; the diagonal legs start in
+// stance, the others in swing), walked with a slot index: same compare / add sequence on the same doubles as the
+// reference's vectors, none of its text.
 // The swing-foot side (not on the force path) is the second update() overload:
 //   swing_enter / stance_enter / stance_exit   :80-86,225-235
 //   swing_update (quintic foot target)         :237-246
 // It leaves the schedule arithmetic untouched.
 #pragma once
-
-#include <vector>
 
 #include "SwingTrajectoryHip.h"
 
@@ -34,34 +35,23 @@ class LeggedContactFSMHip {
   }
 
   void set_default_gait_pattern() {                     // :87-108 (trot)
-    gait_state_pattern.clear();
-    gait_switch_time.clear();
-    if (leg_id == 0 || leg_id == 3) {
-      gait_state_pattern.push_back(STANCE_HIP);
-      gait_state_pattern.push_back(SWING_HIP);
-    } else {
-      gait_state_pattern.push_back(SWING_HIP);
-      gait_state_pattern.push_back(STANCE_HIP);
-    }
-    gait_switch_time.push_back(0.5);
-    gait_switch_time.push_back(1.0);
-    gait_pattern_size = 2;
-    gait_pattern_index = 0;
-    prev_gait_pattern_index = gait_pattern_size - 1;
-    cur_state_start_time = 0.0;
-    cur_state_end_time = gait_switch_time[gait_pattern_index];
+    table = (leg_id == 0 || leg_id == 3) ? kTrotDiagonal : kTrotOther;
+    slot = 0;
+    prev_slot = kSlots - 1;
+    slot_begin = 0.0;
+    slot_end = table[slot].ends_at;
   }
 
   void reset() {                                        // :11-31
     gait_phase = 0;
-    gait_pattern_index = 0;
-    prev_gait_pattern_index = gait_pattern_size - 1;
-    cur_state_start_time = 0;
-    cur_state_end_time = gait_switch_time[gait_pattern_index];
+    slot = 0;
+    prev_slot = kSlots - 1;
+    slot_begin = 0;
+    slot_end = table[slot].ends_at;
     if (s == SWING_HIP) {                               // :20-25 a swing foot goes to its saved target
       for (int a = 0; a < 3; ++a) { FSM_foot_pos_target_world[a] = swing_end_foot_pos_world[a]; FSM_foot_vel_target_world[a] = 0.0; }
     }
-    s = gait_state_pattern[gait_pattern_index];
+    s = table[slot].state;
     not_first_call = false;                             // :30 the next update() re-seeds the targets
   }
 
@@ -70,7 +60,7 @@ class LeggedContactFSMHip {
   double update(double dt, double gait_freq_now, bool foot_force_flag) {   // :33-78
     gait_phase += gait_freq_now * dt;
     if (s == STANCE_HIP) {
-      if (gait_phase >= cur_state_end_time) {
+      if (gait_phase >= slot_end) {
         common_enter();
         s = SWING_HIP;
       }
@@ -100,7 +90,7 @@ class LeggedContactFSMHip {
     }
     gait_phase += gait_freq_now * dt;
     if (s == STANCE_HIP) {
-      if (gait_phase >= cur_state_end_time) {
+      if (gait_phase >= slot_end) {
         terrain_height = foot_pos_cur_world[2];         // stance_exit, :80-84
         common_enter();                                 // swing_enter, :225-229
         for (int a = 0; a < 3; ++a) { swing_start_foot_pos_world[a] = foot_pos_cur_world[a]; swing_extend_foot_pos_world[a] = 0.0; }
@@ -135,28 +125,33 @@ class LeggedContactFSMHip {
   double terrain_height = 0.0;
   double phase() const { return gait_phase; }
   // read-only views of the schedule internals (closed-loop parity checks, host/ClosedLoopHost.h)
-  int pattern_index() const { return gait_pattern_index; }
-  int prev_pattern_index() const { return prev_gait_pattern_index; }
-  double state_start_time() const { return cur_state_start_time; }
-  double state_end_time() const { return cur_state_end_time; }
+  int pattern_index() const { return slot; }
+  int prev_pattern_index() const { return prev_slot; }
+  double state_start_time() const { return slot_begin; }
+  double state_end_time() const { return slot_end; }
   bool first_call_done() const { return not_first_call; }
   const double* swing_start() const { return swing_start_foot_pos_world; }
   const double* swing_end() const { return swing_end_foot_pos_world; }
 
  private:
-  void common_enter() {                                 // :208-223
-    prev_gait_pattern_index = gait_pattern_index;
-    gait_pattern_index = (gait_pattern_index + 1) % gait_pattern_size;
-    if (gait_pattern_index < prev_gait_pattern_index) gait_phase -= 1.0;
-    cur_state_start_time = gait_phase;
-    cur_state_end_time = gait_switch_time[gait_pattern_index];
+  // next slot of the table; the phase loses one whole period when the table wraps (:208-223)
+  void common_enter() {
+    prev_slot = slot;
+    slot = (slot + 1) % kSlots;
+    if (slot < prev_slot) gait_phase -= 1.0;
+    slot_begin = gait_phase;
+    slot_end = table[slot].ends_at;
   }
-  double percent_in_state() const {                     // :261-270
-    double percent = (gait_phase - cur_state_start_time) / (cur_state_end_time - cur_state_start_time);
-    if (percent < 0.0) percent = 0.0;
-    else if (percent > 1.0) percent = 1.0;
-    return percent;
+  // fraction of the current slot that has elapsed, clamped to [0, 1] (:261-270)
+  double percent_in_state() const {
+    const double f = (gait_phase - slot_begin) / (slot_end - slot_begin);
+    return f < 0.0 ? 0.0 : (f > 1.0 ? 1.0 : f);
   }
+
+  struct GaitSlot { LeggedContactStateHip state; double ends_at; };
+  static constexpr int kSlots = 2;
+  static constexpr GaitSlot kTrotDiagonal[kSlots] = {{STANCE_HIP, 0.5}, {SWING_HIP, 1.0}};
+  static constexpr GaitSlot kTrotOther[kSlots] = {{SWING_HIP, 0.5}, {STANCE_HIP, 1.0}};
 
   bool not_first_call = false;                          // LeggedContactFSM.h:96-99,105
   double swing_start_foot_pos_world[3] = {0, 0, 0};
@@ -169,13 +164,9 @@ class LeggedContactFSMHip {
   // indeterminate if update() runs before any stand-mode tick; we start at 0.
   double gait_phase = 0.0;
   double gait_freq = 0.0;
-  std::vector<LeggedContactStateHip> gait_state_pattern;
-  std::vector<double> gait_switch_time;
-  int gait_pattern_size = 0;
-  int gait_pattern_index = 0;
-  int prev_gait_pattern_index = 0;
-  double cur_state_start_time = 0.0;
-  double cur_state_end_time = 0.0;
+  const GaitSlot* table = kTrotDiagonal;
+  int slot = 0, prev_slot = kSlots - 1;
+  double slot_begin = 0.0, slot_end = 0.5;
 };
 
 }  // namespace legged
