@@ -421,7 +421,9 @@ void qmpc_loop_state_init(qmpc_loop_state* s, const qmpc_loop_params* lp, const 
  * trace_contacts [ticks][batch][4] may be NULL.  The handle is a QuatMpc handle (QMPC_MODEL_QUAT, either solver mode) or a
  * ConvexMpc handle (QMPC_MODEL_CONVEX, converged mode): the latter runs ConvexMpc's tick -- its goal_update
  * (ConvexMpc.cpp:51-79; pos_d_world[0:2] hold joy.body_x / body_y, roll / pitch rate commands are ignored), its feedback
- * and record, R' u into the plant -- with host/ClosedLoopHost.h over ConvexMpcHipT as the parity reference. */
+ * and record, R' u into the plant -- with host/ClosedLoopHost.h over ConvexMpcHipT as the parity reference.  The device
+ * tick of ConvexMpc carries the controller period as the literal 5 ms (as the QuatMpc tick does upstream): a ConvexMpc
+ * handle whose knot spacing params.h is not 5 ms is refused with QMPC_UNSUPPORTED. */
 qmpc_status qmpc_loop_run(qmpc_handle* h, const qmpc_loop_params* lp, int32_t batch, qmpc_loop_state* states,
                           int32_t ticks, double* trace_forces, double* trace_contacts);
 /* The same with DEVICE buffers, stream-ordered (NULL = the handle's stream).  Up to 2048 robots (4096 with

@@ -328,7 +328,9 @@ static int pick_variant(const qmpc_handle* h, int32_t batch) {
   const bool no_lds_variant = h->params.model == QMPC_MODEL_QUAT8 || h->lds_bytes > 160 * 1024;
   if (h->variant == 1) return no_lds_variant ? 1 : 0;
   if (h->variant == 2) return 1;
-  if (h->variant == 3) return 2;
+  // variant 2's set-up scratch (one record) aliases X..U..Xc: it needs (N + 1) * 13 >= the record length, or a warm start
+  // loaded into U before the set-up would be overwritten
+  if (h->variant == 3) return ((h->params.horizon + 1) * 13 >= 32 + 4 * model_nl(h->params.model)) ? 2 : 1;
   if (h->params.model == QMPC_MODEL_QUAT8) return (batch > 768 && h->lds_bytes_g > 40 * 1024) ? 2 : 1;  // 3 per CU in LDS
   if (h->lds_bytes > 40 * 1024) return (big && h->lds_bytes_g > 20 * 1024) ? 2 : 1;   // < 4 instances per CU otherwise
   return big ? 1 : 0;
@@ -901,13 +903,15 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   if (h->params.model != QMPC_MODEL_QUAT && h->params.model != QMPC_MODEL_CONVEX) return QMPC_BAD_ARGUMENT;
   const bool convex = h->params.model == QMPC_MODEL_CONVEX;
   if (convex && h->params.mode != QMPC_MODE_CONVERGED) return QMPC_UNSUPPORTED;
+  // the device tick of ConvexMpc carries the controller period as the literal 5 ms (velocity ramp, gait clock): a handle
+  // with another knot spacing would silently part from the host class and the reference (ConvexMpc.cpp:9,62,208)
+  if (convex && h->params.h != (float)(5.0 / 1000.0)) return QMPC_UNSUPPORTED;
   if (batch == 0 || ticks == 0) return QMPC_OK;
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   if (!h->d_loop_row) HIP_TRY(hipMalloc(&h->d_loop_row, sizeof(int)));
-  const int minus1 = -1;
-  HIP_TRY(hipMemcpyAsync(h->d_loop_row, &minus1, sizeof(int), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(h->d_loop_row, 0xFF, sizeof(int), s));     // row counter = -1, stream-ordered (no host staging)
   const unsigned blocks = (unsigned)((batch + 63) / 64);
   const qmpc_loop_params LP = *lp;
   LegGeom G;

@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256) void qmpc_leg_inverse_kernel(LegGeom G, const 
 
 // Joint-level feedback and commands of the robots of a closed loop, from their states after a tick.  The plant's legs
 // are massless: the measured joint angles are the inverse kinematics of the plant's foot positions (hip branch: the
-// angle of the previous tick; a foot out of reach keeps the previous angles), the joint velocities J^-1 R'(foot
-// velocity - torso velocity) with swing feet moving at their FSM target velocity and stance feet at rest.
+// angle of the previous tick; a foot out of reach keeps the previous angles), the joint velocities J^-1 (R'(foot
+// velocity - torso velocity) - w x foot_body) with swing feet moving at their FSM target velocity and stance feet at rest.
 // One thread per (robot, leg); the loop state is an 820-double record, of which a leg reads ~45.  `cmd` receives the
 // commands of this call, `trace` (with the loop's tick counter `row`) one row per tick; either may be null.
 // leg l of robot s: joint_pos_io / fb_out / cmd / trace point at THIS robot's records (fb_out, cmd, trace may be null)
@@ -89,6 +89,13 @@ __device__ inline void loop_joint_leg(const LegGeom& G, const qmpc_loop_state& s
     for (int a = 0; a < 3; ++a) {
       pb[a] = R[a] * d[0] + R[3 + a] * d[1] + R[6 + a] * d[2];
       vb[a] = R[a] * fv[0] + R[3 + a] * fv[1] + R[6 + a] * fv[2];
+    }
+    // foot_world = p + R foot_body  =>  d/dt foot_body = R'(v_foot - v_torso) - w x foot_body   (the relation the reference
+    // uses the other way round: BaseInterface.cpp:229-231)
+    {
+      const double* w = s.ang_vel_body;
+      const double wx[3] = {w[1] * pb[2] - w[2] * pb[1], w[2] * pb[0] - w[0] * pb[2], w[0] * pb[1] - w[1] * pb[0]};
+      for (int a = 0; a < 3; ++a) vb[a] -= wx[a];
     }
     for (int a = 0; a < 3; ++a) qprev[a] = joint_pos_io[3 * l + a];
     qmpc_joint::leg_inverse(pb, qprev[0], G.rho_fix[l], q);

@@ -46,7 +46,7 @@ __device__ inline double loop_filter(qmpc_loop_filter& f, double v) {   // Movin
   return (f.sum + f.correction) / (double)QMPC_LOOP_WINDOW;
 }
 
-// QuinticCurve::get_foot_swing_target (Utils.cpp:236-293): matrix entries and powers of t in FLOAT (t, T are float
+// QuinticCurve::get_foot_swing_target (Utils.cpp:236-293): matrix entries in FLOAT (products of the float argument T), powers of t in double (t, T are float
 // arguments upstream), the 6x6 solve in double (Gaussian elimination with partial pivoting, three right-hand sides)
 __device__ inline void loop_swing_target(float t, float T, const double* start, const double* fin, double* out) {
 #pragma clang fp contract(off)
@@ -75,7 +75,8 @@ __device__ inline void loop_swing_target(float t, float T, const double* start, 
     }
   }
   const double td = t;
-  const float t2 = t * t, t3 = t * t * t, t4 = t * t * t * t, t5 = t * t * t * t * t;
+  // the polynomial is evaluated left to right with DOUBLE coefficients times the float t (Utils.cpp:263-265: `a_z(2) * t * t`),
+  // i.e. every power of t is formed in double; only the entries of the condition matrix are float products of T
   for (int ax = 0; ax < 3; ++ax) {
     double c[6];
     for (int i = 5; i >= 0; --i) {
@@ -83,9 +84,9 @@ __device__ inline void loop_swing_target(float t, float T, const double* start, 
       for (int j = i + 1; j < 6; ++j) s -= Cm[i][j] * c[j];
       c[i] = s / Cm[i][i];
     }
-    out[ax] = c[0] + c[1] * td + c[2] * t2 + c[3] * t3 + c[4] * t4 + c[5] * t5;
-    out[3 + ax] = c[1] + 2 * c[2] * td + 3 * c[3] * t2 + 4 * c[4] * t3 + 5 * c[5] * t4;
-    out[6 + ax] = 2 * c[2] + 6 * c[3] * td + 12 * c[4] * t2 + 20 * c[5] * t3;
+    out[ax] = c[0] + c[1] * td + c[2] * td * td + c[3] * td * td * td + c[4] * td * td * td * td + c[5] * td * td * td * td * td;
+    out[3 + ax] = c[1] + 2 * c[2] * td + 3 * c[3] * td * td + 4 * c[4] * td * td * td + 5 * c[5] * td * td * td * td;
+    out[6 + ax] = 2 * c[2] + 6 * c[3] * td + 12 * c[4] * td * td + 20 * c[5] * td * td * td;
   }
 }
 

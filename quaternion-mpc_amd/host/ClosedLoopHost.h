@@ -141,6 +141,11 @@ class ClosedLoopHostT : public ClosedLoopHostBase<State> {
         fv[a] = (swing ? mpc->leg_FSM[l].FSM_foot_vel_target_world[a] : 0.0) - x_[7 + a];
       }
       for (int a = 0; a < 3; ++a) vb[a] = R[a] * fv[0] + R[3 + a] * fv[1] + R[6 + a] * fv[2];
+      {   // d/dt foot_body = R'(v_foot - v_torso) - w x foot_body   (BaseInterface.cpp:229-231 read the other way round)
+        const double* w = &x_[10];
+        const double wx[3] = {w[1] * pb[2] - w[2] * pb[1], w[2] * pb[0] - w[0] * pb[2], w[0] * pb[1] - w[1] * pb[0]};
+        for (int a = 0; a < 3; ++a) vb[a] -= wx[a];
+      }
       qmpc_joint::leg_inverse(pb, joint_pos_io[3 * l], joints_.geom.rho_fix[l], q);
       if ((q[0] != q[0]) || (q[1] != q[1]) || (q[2] != q[2]))
         for (int a = 0; a < 3; ++a) q[a] = joint_pos_io[3 * l + a];

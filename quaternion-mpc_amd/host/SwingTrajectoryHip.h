@@ -34,13 +34,14 @@ class QuinticCurveHip {
                               {start[2], fin[2], 0.1, -0.1, 0.1, 0.0}};
     double a[3][6];
     solve3(C, con, a);
-    const double td = t;                                          // powers of t are formed in float upstream
-    const float t2 = t * t, t3 = t * t * t, t4 = t * t * t * t, t5 = t * t * t * t * t;
+    const double td = t;
+    // the polynomial is evaluated left to right with DOUBLE coefficients times the float t (Utils.cpp:263-265: `a_z(2) * t * t`),
+    // i.e. every power of t is formed in double; only the entries of the condition matrix are float products of T
     for (int ax = 0; ax < 3; ++ax) {
       const double* c = a[ax];
-      out[ax] = c[0] + c[1] * td + c[2] * t2 + c[3] * t3 + c[4] * t4 + c[5] * t5;
-      out[3 + ax] = c[1] + 2 * c[2] * td + 3 * c[3] * t2 + 4 * c[4] * t3 + 5 * c[5] * t4;
-      out[6 + ax] = 2 * c[2] + 6 * c[3] * td + 12 * c[4] * t2 + 20 * c[5] * t3;
+      out[ax] = c[0] + c[1] * td + c[2] * td * td + c[3] * td * td * td + c[4] * td * td * td * td + c[5] * td * td * td * td * td;
+      out[3 + ax] = c[1] + 2 * c[2] * td + 3 * c[3] * td * td + 4 * c[4] * td * td * td + 5 * c[5] * td * td * td * td;
+      out[6 + ax] = 2 * c[2] + 6 * c[3] * td + 12 * c[4] * td * td + 20 * c[5] * td * td * td;
     }
   }
 

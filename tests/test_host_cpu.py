@@ -297,8 +297,9 @@ def test_convex_pack_input_and_schedule(host, pkg):
 
 # ---- the step before the force path: swing trajectory, Raibert foothold, FSM targets -------
 def _py_quintic(t, T, start, fin):
-    """Independent restatement of QuinticCurve::get_foot_swing_target (Utils.cpp:236-293): matrix entries and the
-    powers of t in float32 (t, T are float arguments upstream), the 6x6 solve in double."""
+    """Independent restatement of QuinticCurve::get_foot_swing_target (Utils.cpp:236-293): matrix entries in float32
+    (products of the float argument T), the 6x6 solve in double, and the polynomial left to right with double
+    coefficients (`a_z(2) * t * t` at :263-265 is ((a_z(2) * t) * t) in double: no power of t is formed in float)."""
     f = np.float32
     t, T = f(t), f(T)
     C = np.array([[1, 0, 0, 0, 0, 0],
@@ -316,12 +317,12 @@ def _py_quintic(t, T, start, fin):
     cons = [[start[0], fin[0], 0, 0, (start[0] + fin[0]) / 2, vx], [start[1], fin[1], 0, 0, (start[1] + fin[1]) / 2, vy],
             [start[2], fin[2], 0.1, -0.1, 0.1, 0.0]]
     out = np.zeros(9)
-    td = float(t); t2 = float(t * t); t3 = float(t * t * t); t4 = float(t * t * t * t); t5 = float(t * t * t * t * t)
+    td = float(t)
     for ax in range(3):
         a = np.linalg.solve(C, np.array(cons[ax], dtype=float))
-        out[ax] = a[0] + a[1] * td + a[2] * t2 + a[3] * t3 + a[4] * t4 + a[5] * t5
-        out[3 + ax] = a[1] + 2 * a[2] * td + 3 * a[3] * t2 + 4 * a[4] * t3 + 5 * a[5] * t4
-        out[6 + ax] = 2 * a[2] + 6 * a[3] * td + 12 * a[4] * t2 + 20 * a[5] * t3
+        out[ax] = a[0] + a[1] * td + a[2] * td * td + a[3] * td * td * td + a[4] * td * td * td * td + a[5] * td * td * td * td * td
+        out[3 + ax] = a[1] + 2 * a[2] * td + 3 * a[3] * td * td + 4 * a[4] * td * td * td + 5 * a[5] * td * td * td * td
+        out[6 + ax] = 2 * a[2] + 6 * a[3] * td + 12 * a[4] * td * td + 20 * a[5] * td * td * td
     return out
 
 
