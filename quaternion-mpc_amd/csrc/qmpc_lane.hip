@@ -117,7 +117,7 @@ __device__ __noinline__ void call_C(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
   LaneState st;
   priv_load(st, (QL_PRIV_AS const LaneState*)sp);
   pass_C<NL>(P, c, O, K, st);
-  st.iters = st.it;
+  if (!st.bad_step) st.iters = st.it;
   priv_store(sp, st);
 }
 template <int NL>
@@ -188,7 +188,10 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
           else if (st.it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
           st.target = sg * st.mu;
           if (!call_B<NL>(a, Kp, sp)) { st.status = QMPC_NOT_PD; active = false; }
-          else call_C<NL>(a, Kp, sp);
+          else {
+            call_C<NL>(a, Kp, sp);
+            if (st.bad_step) { st.status = QMPC_NOT_PD; active = false; }     // a non-finite trial step is not applied
+          }
         }
       }
 #if defined(QL_PROFILE)

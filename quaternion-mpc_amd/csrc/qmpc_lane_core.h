@@ -174,6 +174,7 @@ struct LaneState {
   double target;       // sigma * mu of the iteration whose step is pending
   double mu, last_ap, last_ad, last_step;
   double ap, ad;       // step lengths of the pending step
+  int bad_step;        // the trial increment of the last forward pass was not finite (it is NOT applied: QMPC_NOT_PD)
   double uz;           // u_ref z-component of a stance contact point
 };
 
@@ -509,7 +510,7 @@ QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const do
   st.iters = 0; st.it = 0;
   st.active = st.status == QMPC_OK;
   st.rho = 1.0; st.mu = 0.0; st.target = 0.0; st.last_ap = 0.0; st.last_ad = 0.0; st.last_step = 1e300;
-  st.ap = 1.0; st.ad = 1.0; st.uz = 0.0;
+  st.ap = 1.0; st.ad = 1.0; st.uz = 0.0; st.bad_step = 0;
   if (!st.active) return;
 #pragma unroll
   for (int i = 0; i < 9; ++i) K.rot[i] = raw[4 + i];
@@ -1170,6 +1171,7 @@ constexpr int pair_leg(int pr, int j) { return NL == 4 ? (j == 0 ? pr : 3 - pr) 
 struct LegOutC {
   double du[3], u[3], B[9];
   double rp, dn, dd, stp;     // largest -ds_i / s_i; the row with the largest -dlam_i / lam_i as numerator / denominator
+  bool bad;                   // a component of du is not finite (fmax / fmin drop NaNs silently)
 };
 template <int NL>
 QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr[18], const double rc0[6], const RowBuf<NL>& R,
@@ -1194,12 +1196,15 @@ QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr
   const double z1 = y1 * lb.id1 - lb.l21 * z2;
   const double z0 = y0 * lb.id0 - lb.l10 * z1 - lb.l20 * z2;
   double stp = 0.0;
+  bool bad = false;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     o.du[a] = -(lb.T[3 * a] * z0 + lb.T[3 * a + 1] * z1 + lb.T[3 * a + 2] * z2);
     stp = fmax(stp, fabs(o.du[a]));
+    bad = bad || !(fabs(o.du[a]) <= 1e300);
     o.u[a] = u[a] + o.du[a];
   }
+  o.bad = bad;
   // directions and fraction-to-the-boundary ratios (ipm_directions in qmpc_kernels.hip)
   // The step lengths are min(1, tau / max_i(-ds_i / s_i)) and min(1, tau / max_i(-dlam_i / lam_i)): the maxima are
   // tracked without a division per row (1 / s_i is at hand; the multiplier ratios are compared by cross-multiplication)
@@ -1248,6 +1253,7 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
 #pragma unroll
     for (int l = 0; l < NL; ++l) prefetch_leg<NL, false, true>(c, O, st.con, 0, l, R);
   double rp = 0.0, dn = 0.0, dd = 1.0, stp = 0.0;
+  bool bad = false;
   for (int k = 0; k < N; ++k) {
     const int kn = (k + 1 < N) ? k + 1 : k;      // the last knot re-reads itself
     // dx = xc (-) X_k in error coordinates (inverse Cayley map, QuaternionUtils.cpp:16-18)
@@ -1308,7 +1314,7 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
             F[a] += oa.u[a];
             wd[a] += oa.B[3 * a] * oa.u[0] + oa.B[3 * a + 1] * oa.u[1] + oa.B[3 * a + 2] * oa.u[2];
           }
-          rp = fmax(rp, oa.rp); stp = fmax(stp, oa.stp);
+          rp = fmax(rp, oa.rp); stp = fmax(stp, oa.stp); bad = bad || oa.bad;
           { const bool better = oa.dn * dd > dn * oa.dd; dn = better ? oa.dn : dn; dd = better ? oa.dd : dd; }
         }
         if (on_b) {
@@ -1318,7 +1324,7 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
             F[a] += ob.u[a];
             wd[a] += ob.B[3 * a] * ob.u[0] + ob.B[3 * a + 1] * ob.u[1] + ob.B[3 * a + 2] * ob.u[2];
           }
-          rp = fmax(rp, ob.rp); stp = fmax(stp, ob.stp);
+          rp = fmax(rp, ob.rp); stp = fmax(stp, ob.stp); bad = bad || ob.bad;
           { const bool better = ob.dn * dd > dn * ob.dd; dn = better ? ob.dn : dn; dd = better ? ob.dd : dd; }
         }
       }
@@ -1332,6 +1338,7 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   }
   const double ap = (rp > P.tau) ? P.tau / rp : 1.0;
   const double ad = (dn * 1.0 > P.tau * dd) ? P.tau * dd / dn : 1.0;
+  st.bad_step = (bad || !(ap > 0.0) || !(ad > 0.0)) ? 1 : 0;      // also a NaN step length (0 * inf in the ratios)
   st.ap = ap; st.ad = ad;
   st.last_ap = ap; st.last_ad = ad;
   st.last_step = stp;
@@ -1363,6 +1370,7 @@ QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, cons
   st.target = sg * st.mu;
   if (!pass_B<NL>(P, c, O, K, st)) { st.status = QMPC_NOT_PD; return false; }
   pass_C<NL>(P, c, O, K, st);
+  if (st.bad_step) { st.status = QMPC_NOT_PD; return false; }     // the last finite iterate stays in the workspace
   st.iters = st.it;
   return true;
 }

@@ -149,3 +149,76 @@ def test_config4_workload_on_one_gpu(pkg, lib, oracle):
     fo, io = oracle.solve(p, rec[sub], threads=8)
     assert (io["status"] == 0).all() and np.abs(f[sub] - fo).max() < 1e-6
     s.close()
+
+
+def _random_params(pkg, lib, rng, t):
+    N = int(rng.choice([6, 10, 14, 20]))
+    p = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
+    p.mu = float(rng.uniform(0.3, 1.0))
+    p.fz_max = float(rng.uniform(60, 300))
+    p.w = float(rng.uniform(1, 100))
+    p.mass = float(rng.uniform(9, 16))
+    for i in range(13):
+        p.q_weights[i] = float(p.q_weights[i] * rng.uniform(0.3, 3.0))
+    for i in range(12):
+        p.r_weights[i] = float(10 ** rng.uniform(-6.5, -4))
+    p.drop_ang_vel = int(t % 2)
+    hs = float(rng.choice([0.005, 0.01, 0.02]))
+    if N * hs > 0.3:
+        hs = 0.015
+    p.h, p.h_ref = hs, hs
+    return p
+
+
+def test_lane_kernel_randomised_parameter_sets(pkg, lib, oracle, monkeypatch):
+    """Friction, force limit, weights (per-axis R included), mass, knot spacing, horizon and the angular-velocity quirk at
+    random (the draw of test_gpu_parity.py::test_randomised_parameter_sets_match_oracle): the lane kernel follows the oracle
+    for every set; so it does with zero velocity weights (S6 = M'PM stays positive definite through the position and
+    attitude weights) and with an iteration cap that truncates every solve."""
+    _forced(monkeypatch, 4)
+    rng = np.random.default_rng(77)
+    for t in range(8):
+        p = _random_params(pkg, lib, rng, t)
+        rec = pkg.random_go1_trot_states(192, config_id=40 + t)
+        s = pkg.Solver(p, 192, device=0, lib=lib)
+        f, info = s.solve(rec)
+        s.close()
+        fo, io = oracle.solve(p, rec, threads=8)
+        assert (io["status"] == 0).all() and (info["status"] == 0).all(), (t, np.unique(info["status"]))
+        assert np.abs(f - fo).max() < 1e-6, t
+    rec = pkg.random_go1_trot_states(128, config_id=2)
+    p = pkg.default_params(10, pkg.MODE_CONVERGED, lib)
+    for i in (7, 8, 9, 10, 11, 12):
+        p.q_weights[i] = 0.0
+    s = pkg.Solver(p, 128, device=0, lib=lib)
+    f, info = s.solve(rec)
+    fo, io = oracle.solve(p, rec, threads=8)
+    assert (info["status"] == 0).all() and (io["status"] == 0).all() and np.abs(f - fo).max() < 1e-6
+    p = pkg.default_params(10, pkg.MODE_CONVERGED, lib)
+    p.iterations_max = 6
+    s.set_params(p)
+    f, info = s.solve(rec)
+    s.close()
+    fo, io = oracle.solve(p, rec, threads=8)
+    assert (info["status"] == pkg.MAX_ITER).all() and (io["status"] == pkg.MAX_ITER).all()
+    assert (info["iterations"] == 6).all() and np.abs(f - fo).max() < 1e-6        # the truncated iterates agree as well
+
+
+def test_lane_kernel_outside_the_envelope(pkg, lib, oracle, monkeypatch):
+    """20 ms knots x N = 20 on strongly tilted states: a third of the instances fail on either side.  The lane
+    kernel must fail at the same RATE, report every failure through the status word, return FINITE forces (a non-finite
+    trial step is never applied) and agree with the oracle wherever both converge."""
+    _forced(monkeypatch, 4)
+    p = pkg.default_params(20, pkg.MODE_CONVERGED, lib)
+    p.h, p.h_ref = 0.02, 0.02
+    rec = pkg.random_go1_trot_states(256, config_id=41)
+    s = pkg.Solver(p, 256, device=0, lib=lib)
+    f, info = s.solve(rec)
+    s.close()
+    fo, io = oracle.solve(p, rec, threads=8)
+    ok_g, ok_o = info["status"] == 0, io["status"] == 0
+    both = ok_g & ok_o
+    assert set(np.unique(info["status"])) <= {pkg.OK, pkg.MAX_ITER, pkg.NOT_PD}
+    assert abs(ok_g.mean() - ok_o.mean()) < 0.08 and both.mean() > 0.45
+    assert np.abs(f - fo)[both].max() < 1e-5
+    assert np.isfinite(f).all()

@@ -78,3 +78,17 @@ def test_lane_core_reaches_the_certified_points(pkg, oracle, lane, name, gen, dp
     f, info = lane(getattr(oracle, dp)(N, 0), rec, nu=nu)
     assert (info["status"] == 0).all()
     assert np.abs(f - U[:, 0, :]).max() < (1e-5 if nu == 24 else 1e-6)
+
+
+def test_lane_core_outside_the_envelope_returns_finite_forces(pkg, oracle, lane):
+    """Long look-ahead on tilted states: failures are reported, never returned as NaN forces (a non-finite
+    trial step is not applied), and the converged instances agree with the oracle."""
+    p = oracle.default_params(20, 0)
+    p.h, p.h_ref = 0.02, 0.02
+    rec = pkg.random_go1_trot_states(96, config_id=41)
+    f, info = lane(p, rec)
+    fo, io = oracle.solve(p, rec, threads=8)
+    both = (info["status"] == 0) & (io["status"] == 0)
+    assert np.isfinite(f).all() and set(np.unique(info["status"])) <= {pkg.OK, pkg.MAX_ITER, pkg.NOT_PD}
+    assert both.mean() > 0.4 and np.abs(f - fo)[both].max() < 1e-5
+    assert abs((info["status"] == 0).mean() - (io["status"] == 0).mean()) < 0.1
