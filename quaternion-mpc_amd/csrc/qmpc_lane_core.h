@@ -440,53 +440,46 @@ QL_FN unsigned load_rows(const Ctx& c, const WsOff& O, int k, int l, double sv[6
   return kap;
 }
 
-// Rows of every contact point of ONE knot, held in registers one knot AHEAD of their use: a pass fills the buffer for
-// its first knot, and as soon as a contact point has been worked on, the same registers are re-loaded with that
-// point's rows of the next knot -- the loads then have the rest of the knot to land, and the single wavefront of a SIMD
-// does not sit through a memory latency per contact point.  Fetched when any lane of the wave has the point in stance.
-template <int NL>
-struct RowBuf {
-  double u[NL][3], du[NL][3], s[NL][6], lam[NL][6];
+// The backward pass has no registers for the rows of all contact points: it keeps ONE point ahead.  While contact
+// point l of knot k is worked on, the rows of the NEXT stance point in processing order (the next point of the same
+// knot, or the first point of knot k-1) are already on their way.  `order` is the wave-uniform list of points that any
+// lane has in stance; the address of the next point is a scalar computation.
+struct LegAhead {
+  double u[3], du[3], s[6], lam[6];
 };
-template <int NL, bool WITH_DU, bool WITH_ROWS>
-QL_FN void prefetch_leg(const Ctx& c, const WsOff& O, unsigned con, int k, int l, RowBuf<NL>& R) {
-  if (!QL_ANY((con >> l) & 1u)) return;
+template <int NL, bool WITH_DU = false>
+QL_FN void fetch_ahead(const Ctx& c, const WsOff& O, int k, int l, LegAhead& R) {     // k, l wave-uniform run-time values
 #pragma unroll
-  for (int a = 0; a < 3; ++a) R.u[l][a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+  for (int a = 0; a < 3; ++a) R.u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
   if (WITH_DU)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) R.du[l][a] = c.W(O.dU + 3 * NL * k + 3 * l + a);
-  if (WITH_ROWS)
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      R.s[l][i] = c.W(O.S + 6 * NL * k + 6 * l + i);
-      R.lam[l][i] = c.W(O.LAM + 6 * NL * k + 6 * l + i);
-    }
-}
-// slacks, multipliers and Tapia flags (sign of the stored slack) of contact point l out of the buffer
-template <int NL>
-QL_FN unsigned take_rows(const RowBuf<NL>& R, int l, double sv[6], double lv[6]) {
-  unsigned kap = 0;
+    for (int a = 0; a < 3; ++a) R.du[a] = c.W(O.dU + 3 * NL * k + 3 * l + a);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    const double sx = R.s[l][i];
-    lv[i] = R.lam[l][i];
-    kap |= (sx < 0.0) ? (1u << i) : 0u;
-    sv[i] = fabs(sx);
+    R.s[i] = c.W(O.S + 6 * NL * k + 6 * l + i);
+    R.lam[i] = c.W(O.LAM + 6 * NL * k + 6 * l + i);
   }
-  return kap;
+}
+// wave-uniform stance mask: bit l set when any lane of the wavefront has contact point l in stance
+template <int NL>
+QL_FN unsigned any_stance(unsigned con) {
+  unsigned m = 0;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) m |= QL_ANY((con >> l) & 1u) ? (1u << l) : 0u;
+  return m;
+}
+QL_FN int first_bit(unsigned m) {
+  int l = 0;
+  while (!((m >> l) & 1u)) ++l;
+  return l;
+}
+// first stance point after l, or -1
+QL_FN int next_bit(unsigned m, int l) {
+  for (int j = l + 1; j < 32; ++j)
+    if ((m >> j) & 1u) return j;
+  return -1;
 }
 
-// QL_PF_x = 0 (diagnostics): pass x fetches the rows of a contact point where it uses them instead of a knot ahead
-#ifndef QL_PF_A
-#define QL_PF_A 1
-#endif
-#ifndef QL_PF_B
-#define QL_PF_B 1
-#endif
-#ifndef QL_PF_C
-#define QL_PF_C 1
-#endif
 #ifndef QL_PF_CH      // old state and gains of pass C one knot ahead
 #define QL_PF_CH 1
 #endif
@@ -593,24 +586,32 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   const bool full = ap >= 1.0;
   const bool tapia = (ap >= 0.99) && (ad >= 0.99);
   double slsum = 0.0;
-  RowBuf<NL> R;       // rows, inputs and trial increments of the contact points, one knot ahead (not at the first iteration:
-                      // nothing is pending then and every input is at its reference)
-  if (!first && QL_PF_A)
-#pragma unroll
-    for (int l = 0; l < NL; ++l) prefetch_leg<NL, true, true>(c, O, st.con, 0, l, R);
+  const unsigned order = any_stance<NL>(st.con);
+  LegAhead R;         // rows, inputs and trial increments of the NEXT contact point in processing order (not at the first
+                      // iteration: nothing is pending then and every input is at its reference)
+  if (!first) fetch_ahead<NL, true>(c, O, 0, first_bit(order), R);
   for (int k = 0; k < N; ++k) {
     const int kn = (k + 1 < N) ? k + 1 : k;
     double F[3] = {0, 0, 0}, wd[3] = {wd0[0], wd0[1], wd0[2]};
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-      if (!first && !QL_PF_A) prefetch_leg<NL, true, true>(c, O, st.con, k, l, R);
-      if ((st.con >> l) & 1u) {
-      double u[3] = {0.0, 0.0, st.uz};
+      if (!((order >> l) & 1u)) continue;       // wave-uniform
+      double u[3] = {0.0, 0.0, st.uz}, du[3] = {0, 0, 0}, sv[6], lv[6];
+      unsigned kap = 0;
       if (!first) {
-        double du[3], sv[6], lv[6];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { u[a] = R.u[l][a]; du[a] = R.du[l][a]; }
-        const unsigned kap = take_rows<NL>(R, l, sv, lv);
+        for (int a = 0; a < 3; ++a) { u[a] = R.u[a]; du[a] = R.du[a]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          lv[i] = R.lam[i];
+          kap |= (R.s[i] < 0.0) ? (1u << i) : 0u;
+          sv[i] = fabs(R.s[i]);
+        }
+        const int ln = next_bit(order, l);
+        fetch_ahead<NL, true>(c, O, ln >= 0 ? k : kn, ln >= 0 ? ln : first_bit(order), R);
+      }
+      if ((st.con >> l) & 1u) {
+      if (!first) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
           const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
@@ -642,7 +643,6 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
         wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
       }
       }
-      if (!first && QL_PF_A) prefetch_leg<NL, true, true>(c, O, st.con, kn, l, R);
     }
     srbd_step_fw(P, gb, x, F, wd, xn);
 #pragma unroll
@@ -716,10 +716,9 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     cone_rows(P, K.rot, cr);
     initial_rows(P, cr, st.uz, s0, rc0);
   }
-  RowBuf<NL> R;       // rows of the contact points, one knot ahead
-  if (QL_PF_B)
-#pragma unroll
-    for (int l = 0; l < NL; ++l) prefetch_leg<NL, false, true>(c, O, st.con, N - 1, l, R);
+  const unsigned order = any_stance<NL>(st.con);      // at least one bit: the lanes of this call have a stance point
+  LegAhead R;         // rows of the NEXT contact point in processing order
+  fetch_ahead<NL>(c, O, N - 1, first_bit(order), R);
   bool ok = true;
   const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
   {
@@ -759,16 +758,28 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     }
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-      if (!QL_PF_B) prefetch_leg<NL, false, true>(c, O, st.con, k, l, R);
-      if ((st.con >> l) & 1u) {
-      double u[3], r[3], B[9];
+      if (!((order >> l) & 1u)) continue;       // wave-uniform
+      double u[3], sv[6], lv[6];
+      unsigned kap = 0;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) { u[a] = R.u[l][a]; r[a] = K.foot[3 * l + a]; }
+      for (int a = 0; a < 3; ++a) u[a] = R.u[a];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        lv[i] = R.lam[i];
+        kap |= (R.s[i] < 0.0) ? (1u << i) : 0u;
+        sv[i] = fabs(R.s[i]);
+      }
+      {     // the next point's rows into the registers just copied out
+        const int ln = next_bit(order, l);
+        fetch_ahead<NL>(c, O, ln >= 0 ? k : kn, ln >= 0 ? ln : first_bit(order), R);
+      }
+      if ((st.con >> l) & 1u) {
+      double r[3], B[9];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) r[a] = K.foot[3 * l + a];
       leg_bw0(P, r, B);
 #pragma unroll
       for (int a = 0; a < 3; ++a) wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
-      double sv[6], lv[6];
-      const unsigned kap = take_rows<NL>(R, l, sv, lv);
       LegBlk lb;
       leg_block(P, cr, rc0, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
       // V = [T ; Bw0 T] (6 x 3), Vt = V L^-T (columns), G += sum_j id_j vt_j vt_j', r6 += sum_j vt_j id_j y_j, y = L^-1 gq
@@ -793,7 +804,6 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
         for (int j = i; j < 6; ++j) G6[S6I(i, j)] += a0 * v0[j] + a1 * v1[j] + a2 * v2[j];
       }
       }
-      if (QL_PF_B) prefetch_leg<NL, false, true>(c, O, st.con, kn, l, R);
     }
     QL_FENCE();
     QL_TICK(st, LP_B_LEGS);
@@ -1174,15 +1184,21 @@ struct LegOutC {
   bool bad;                   // a component of du is not finite (fmax / fmin drop NaNs silently)
 };
 template <int NL>
-QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr[18], const double rc0[6], const RowBuf<NL>& R,
+QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr[18], const double rc0[6], const LegAhead& R,
                          int l, const double zeta[6], const LaneState& st, LegOutC& o) {
   double u[3], r[3];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) { u[a] = R.u[l][a]; r[a] = K.foot[3 * l + a]; }
+  for (int a = 0; a < 3; ++a) { u[a] = R.u[a]; r[a] = K.foot[3 * l + a]; }
   leg_bw0(P, r, o.B);
   const double* B = o.B;
   double sv[6], lv[6];
-  const unsigned kap = take_rows<NL>(R, l, sv, lv);
+  unsigned kap = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    lv[i] = R.lam[i];
+    kap |= (R.s[i] < 0.0) ? (1u << i) : 0u;
+    sv[i] = fabs(R.s[i]);
+  }
   LegBlk lb;
   leg_block(P, cr, rc0, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
   // rhs = T'(zeta_f + Bw0' zeta_t) + gq;  du = -T Db^-1 rhs
@@ -1242,16 +1258,26 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   for (int i = 0; i < 13; ++i) xc[i] = c.W(O.X + i);
   // one knot ahead: old state, gains, rows of the contact points
   double xo[13], gn[D::GAIN];
-  RowBuf<NL> R;
+  // the pairs of contact points that any lane has in stance, and the rows of the NEXT such pair in processing order
+  unsigned porder = 0;
+  {
+    const unsigned order = any_stance<NL>(st.con);
+#pragma unroll
+    for (int pr = 0; pr < NL / 2; ++pr)
+      porder |= (((order >> pair_leg<NL>(pr, 0)) | (order >> pair_leg<NL>(pr, 1))) & 1u) << pr;
+  }
+  LegAhead Ra, Rb;
   if (QL_PF_CH) {
 #pragma unroll
     for (int i = 0; i < 13; ++i) xo[i] = xc[i];
 #pragma unroll
     for (int i = 0; i < D::GAIN; ++i) gn[i] = c.W(O.G + i);
   }
-  if (QL_PF_C)
-#pragma unroll
-    for (int l = 0; l < NL; ++l) prefetch_leg<NL, false, true>(c, O, st.con, 0, l, R);
+  {
+    const int p0 = first_bit(porder);
+    fetch_ahead<NL>(c, O, 0, NL == 4 ? p0 : 2 * p0, Ra);
+    fetch_ahead<NL>(c, O, 0, NL == 4 ? 3 - p0 : 2 * p0 + 1, Rb);
+  }
   double rp = 0.0, dn = 0.0, dd = 1.0, stp = 0.0;
   bool bad = false;
   for (int k = 0; k < N; ++k) {
@@ -1302,11 +1328,16 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     for (int pr = 0; pr < NL / 2; ++pr) {
       const int la = pair_leg<NL>(pr, 0), lb = pair_leg<NL>(pr, 1);
       const bool on_a = (st.con >> la) & 1u, on_b = (st.con >> lb) & 1u;
-      if (!QL_PF_C) { prefetch_leg<NL, false, true>(c, O, st.con, k, la, R); prefetch_leg<NL, false, true>(c, O, st.con, k, lb, R); }
-      if (QL_ANY(on_a || on_b)) {
+      if ((porder >> pr) & 1u) {       // wave-uniform
         LegOutC oa, ob;
-        leg_compute_C<NL>(P, K, cr, rc0, R, la, zeta, st, oa);
-        leg_compute_C<NL>(P, K, cr, rc0, R, lb, zeta, st, ob);
+        leg_compute_C<NL>(P, K, cr, rc0, Ra, la, zeta, st, oa);
+        leg_compute_C<NL>(P, K, cr, rc0, Rb, lb, zeta, st, ob);
+        {     // the next pair's rows into the registers just consumed
+          const int pn = next_bit(porder, pr);
+          const int kq = pn >= 0 ? k : kn, pq = pn >= 0 ? pn : first_bit(porder);
+          fetch_ahead<NL>(c, O, kq, NL == 4 ? pq : 2 * pq, Ra);
+          fetch_ahead<NL>(c, O, kq, NL == 4 ? 3 - pq : 2 * pq + 1, Rb);
+        }
         if (on_a) {
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
@@ -1328,7 +1359,6 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
           { const bool better = ob.dn * dd > dn * ob.dd; dn = better ? ob.dn : dn; dd = better ? ob.dd : dd; }
         }
       }
-      if (QL_PF_C) { prefetch_leg<NL, false, true>(c, O, st.con, kn, la, R); prefetch_leg<NL, false, true>(c, O, st.con, kn, lb, R); }
     }
     QL_TICK(st, LP_C_LEGS);
     srbd_step_fw(P, gb, xc, F, wd, xn);
