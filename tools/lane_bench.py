@@ -74,7 +74,9 @@ def main():
             _, _, msn = run("4", p, rec, a.reps, biped, {"QMPC_LANE_SORT": "0"})
             row["lane_nosort_ms"] = msn
         if not a.skip_wave:
-            fw, iw, msw = run("0", p, rec, a.reps, biped)
+            # variant 0 = the library's automatic choice, which is the lane kernel from QMPC_LANE_MIN instances on:
+            # raise the threshold so that this leg really times the wave-per-instance kernels
+            fw, iw, msw = run("0", p, rec, a.reps, biped, {"QMPC_LANE_MIN": str(1 << 30)})
             row["wave_ms"] = msw
             row["wave_solves_per_s"] = B / msw * 1e3
             row["speedup"] = msw / msl
