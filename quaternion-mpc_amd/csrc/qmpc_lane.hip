@@ -31,7 +31,6 @@ constexpr int kParamSlots = 64;
 // nothing of it occupies registers across the passes.
 __constant__ DevParams ql_params[kParamSlots];
 
-#define QL_PRIV_AS __attribute__((address_space(5)))
 
 // The three passes (and set-up / outputs) are compiled as SEPARATE functions: each gets the register file to itself --
 // inlined into one kernel body the allocator spilled several hundred registers around the backward pass.  The
@@ -89,7 +88,7 @@ __device__ __noinline__ void call_A(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
   LaneState st;
   priv_load(st, (QL_PRIV_AS const LaneState*)sp);
   st.it += 1;
-  pass_A<NL>(P, c, O, K, st, st.it == 1);
+  pass_A<NL>(P, c, O, K, st, st.it == 1, (FootPtr)Kp->foot);
   priv_store(sp, st);
 }
 template <int NL>
@@ -101,7 +100,7 @@ __device__ __noinline__ bool call_B(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
   priv_load(K, Kp);
   LaneState st;
   priv_load(st, (QL_PRIV_AS const LaneState*)sp);
-  const bool ok = pass_B<NL>(P, c, O, K, st);
+  const bool ok = pass_B<NL>(P, c, O, K, st, (FootPtr)Kp->foot);
 #if defined(QL_PROFILE)
   priv_store(sp, st);
 #endif
@@ -116,7 +115,7 @@ __device__ __noinline__ void call_C(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
   priv_load(K, Kp);
   LaneState st;
   priv_load(st, (QL_PRIV_AS const LaneState*)sp);
-  pass_C<NL>(P, c, O, K, st);
+  pass_C<NL>(P, c, O, K, st, (FootPtr)Kp->foot);
   if (!st.bad_step) st.iters = st.it;
   priv_store(sp, st);
 }

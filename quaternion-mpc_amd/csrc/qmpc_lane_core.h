@@ -120,10 +120,18 @@ inline size_t lane_ws_elements(int N, int nl) { return nl == 8 ? (size_t)make_ws
 #if QL_DEVICE
 #define QL_GLOBAL_AS __attribute__((address_space(1)))
 #define QL_LDS_AS __attribute__((address_space(3)))
+#define QL_PRIV_AS __attribute__((address_space(5)))
 #else
 #define QL_GLOBAL_AS
 #define QL_LDS_AS
+#define QL_PRIV_AS
 #endif
+// The contact points' positions are read from the instance's constants in the lane's PRIVATE memory together with the
+// rows of the point (LegAhead), three doubles at a time, instead of living in 6 NL registers through every pass: where
+// the compiler parked them in scratch by itself it re-loaded them at the top of each point's block, behind the
+// prefetches just issued (the memory counter is in order: waiting for the re-load waited for the prefetch).
+constexpr bool kFootAhead = true;
+typedef QL_PRIV_AS const double* FootPtr;
 struct Ctx {
   QL_GLOBAL_AS double* ws;   // this wave's block of the workspace: [element][lane]
   unsigned wrow;             // bytes per workspace row (8 x lanes per wave)
@@ -135,6 +143,16 @@ struct Ctx {
   }
   QL_FN QL_LDS_AS double& PL(int i) const {
     return *reinterpret_cast<QL_LDS_AS double*>(reinterpret_cast<QL_LDS_AS char*>(pl) + ((unsigned)i * prow + poff));
+  }
+  // Recompute the lane's row offset (three VALU instructions) instead of keeping it live: where the register file is full
+  // the compiler parks this value in scratch and re-loads it before every group of workspace accesses -- a round trip to
+  // L2 that also waits for every load issued before it (the memory counters are in order), i.e. for the prefetches.
+  QL_FN void relane() {
+#if QL_DEVICE
+    unsigned x;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 3, %0" : "=v"(x));
+    woff = x;
+#endif
   }
 };
 
@@ -445,10 +463,16 @@ QL_FN unsigned load_rows(const Ctx& c, const WsOff& O, int k, int l, double sv[6
 // knot, or the first point of knot k-1) are already on their way.  `order` is the wave-uniform list of points that any
 // lane has in stance; the address of the next point is a scalar computation.
 struct LegAhead {
-  double u[3], du[3], s[6], lam[6];
+  double u[3], du[3], s[6], lam[6], foot[3];
 };
+QL_FN void fetch_foot(FootPtr fp, int l, LegAhead& R) {
+  if (kFootAhead)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) R.foot[a] = fp[3 * l + a];
+}
 template <int NL, bool WITH_DU = false>
-QL_FN void fetch_ahead(const Ctx& c, const WsOff& O, int k, int l, LegAhead& R) {     // k, l wave-uniform run-time values
+QL_FN void fetch_ahead(const Ctx& c, const WsOff& O, int k, int l, LegAhead& R, FootPtr fp) {     // k, l wave-uniform run-time values
+  fetch_foot(fp, l, R);
 #pragma unroll
   for (int a = 0; a < 3; ++a) R.u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
   if (WITH_DU)
@@ -569,7 +593,7 @@ QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const do
 // cone rows are linear in u), so nothing but dU has to be kept between the passes.  A shortened primal step scales
 // the increment; rc <- (1 - alpha_p) rc, exactly 0 after a full step.
 template <int NL>
-QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st, bool first) {
+QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st, bool first, FootPtr fp) {
   const int N = P.N;
   const double gb[3] = {K.rot[6] * (-9.81), K.rot[7] * (-9.81), K.rot[8] * (-9.81)};
   const double* wd0 = K.wd0;
@@ -589,15 +613,22 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   const unsigned order = any_stance<NL>(st.con);
   LegAhead R;         // rows, inputs and trial increments of the NEXT contact point in processing order (not at the first
                       // iteration: nothing is pending then and every input is at its reference)
-  if (!first) fetch_ahead<NL, true>(c, O, 0, first_bit(order), R);
+  if (!first) fetch_ahead<NL, true>(c, O, 0, first_bit(order), R, fp);
+  else fetch_foot(fp, first_bit(order), R);
   for (int k = 0; k < N; ++k) {
     const int kn = (k + 1 < N) ? k + 1 : k;
     double F[3] = {0, 0, 0}, wd[3] = {wd0[0], wd0[1], wd0[2]};
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       if (!((order >> l) & 1u)) continue;       // wave-uniform
-      double u[3] = {0.0, 0.0, st.uz}, du[3] = {0, 0, 0}, sv[6], lv[6];
+      double u[3] = {0.0, 0.0, st.uz}, du[3] = {0, 0, 0}, sv[6], lv[6], r[3];
       unsigned kap = 0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) r[a] = kFootAhead ? R.foot[a] : K.foot[3 * l + a];
+      if (first) {
+        const int ln = next_bit(order, l);
+        fetch_foot(fp, ln >= 0 ? ln : first_bit(order), R);
+      }
       if (!first) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) { u[a] = R.u[a]; du[a] = R.du[a]; }
@@ -608,7 +639,7 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
           sv[i] = fabs(R.s[i]);
         }
         const int ln = next_bit(order, l);
-        fetch_ahead<NL, true>(c, O, ln >= 0 ? k : kn, ln >= 0 ? ln : first_bit(order), R);
+        fetch_ahead<NL, true>(c, O, ln >= 0 ? k : kn, ln >= 0 ? ln : first_bit(order), R, fp);
       }
       if ((st.con >> l) & 1u) {
       if (!first) {
@@ -633,9 +664,7 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
           c.W(O.U + 3 * NL * k + 3 * l + a) = u[a];
         }
       }
-      double B[9], r[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) r[a] = K.foot[3 * l + a];
+      double B[9];
       leg_bw0(P, r, B);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -706,7 +735,8 @@ QL_FN void cost_expansion(const DevParams& P, const Ctx& c, const WsOff& O, cons
 }
 
 template <int NL>
-QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st) {
+QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const LaneK<NL>& K, LaneState& st, FootPtr fp) {
+  Ctx c = c_in;
   typedef LDim<NL> D;
   const int N = P.N;
   double pv[12];      // cost-to-go  1/2 dx'P dx + p'dx: P in the lane-private rows c.PL(), p in registers
@@ -718,7 +748,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   }
   const unsigned order = any_stance<NL>(st.con);      // at least one bit: the lanes of this call have a stance point
   LegAhead R;         // rows of the NEXT contact point in processing order
-  fetch_ahead<NL>(c, O, N - 1, first_bit(order), R);
+  fetch_ahead<NL>(c, O, N - 1, first_bit(order), R, fp);
   bool ok = true;
   const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
   {
@@ -740,6 +770,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   }
   for (int k = N - 1; k >= 0; --k) {
     QL_FENCE();
+    c.relane();
     QL_TICK(st, LP_B_HEAD);
     // ---- 1. contact points; wd for the expansion ----
     double G6[21], r6[6];
@@ -759,10 +790,10 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       if (!((order >> l) & 1u)) continue;       // wave-uniform
-      double u[3], sv[6], lv[6];
+      double u[3], sv[6], lv[6], r[3];
       unsigned kap = 0;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) u[a] = R.u[a];
+      for (int a = 0; a < 3; ++a) { u[a] = R.u[a]; r[a] = kFootAhead ? R.foot[a] : K.foot[3 * l + a]; }
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         lv[i] = R.lam[i];
@@ -771,12 +802,13 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
       }
       {     // the next point's rows into the registers just copied out
         const int ln = next_bit(order, l);
-        fetch_ahead<NL>(c, O, ln >= 0 ? k : kn, ln >= 0 ? ln : first_bit(order), R);
+        c.relane();
+        // (the first point of the NEXT knot is fetched after the main phase: 18 doubles fewer live through it, and the
+        // cost expansion and the head of the next knot are time enough for the rows to arrive)
+        if (ln >= 0) fetch_ahead<NL>(c, O, k, ln, R, fp);
       }
       if ((st.con >> l) & 1u) {
-      double r[3], B[9];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) r[a] = K.foot[3 * l + a];
+      double B[9];
       leg_bw0(P, r, B);
 #pragma unroll
       for (int a = 0; a < 3; ++a) wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
@@ -806,6 +838,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
       }
     }
     QL_FENCE();
+    c.relane();
     QL_TICK(st, LP_B_LEGS);
     // ---- 2. dynamics expansion (AltroUtils.cpp:78-110,153-168 in compact form) ----
     double A1[9], A3[9], Wt[9];
@@ -849,6 +882,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
       }
     }
     QL_FENCE();
+    c.relane();
     QL_TICK(st, LP_B_EXPAND);
     // ---- 3. S6 = M'PM from the symmetric storage; factorisations; Z ----
     double S6[21], Z[21];
@@ -985,6 +1019,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
         }
     }
     QL_FENCE();
+    c.relane();
     QL_TICK(st, LP_B_FACT);
     // ---- 4. P <- Abar' P Abar, p <- Abar' p  in place on the symmetric storage; What = A1^-1 (Wt - h A3) ----
     {
@@ -1068,6 +1103,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
       mm(Ai, Dm, Wh);
     }
     QL_FENCE();
+    c.relane();
     QL_TICK(st, LP_B_CONGR);
     // ---- 5. Y = Mt' P (rows f: mf P_p. + m2 P_v. ; rows t: What' P_f. + h P_w.), column by column ----
     const double mf = m1 - P.h * m2;
@@ -1094,6 +1130,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
       yg[i] = s;
     }
     QL_FENCE();
+    c.relane();
     QL_TICK(st, LP_B_MP);
 #pragma unroll
     for (int j = 0; j < 13; ++j) {
@@ -1101,6 +1138,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
       QL_FENCE();
 #endif
       double yj[6], z[6];
+      c.relane();
 #pragma unroll
       for (int i = 0; i < 6; ++i) yj[i] = (j < 12) ? Y[j < 12 ? j : 0][i] : yg[i];
 #pragma unroll
@@ -1146,7 +1184,9 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
       }
     }
     QL_FENCE();
+    c.relane();
     QL_TICK(st, LP_B_UPD);
+    fetch_ahead<NL>(c, O, kn, first_bit(order), R, fp);
     // ---- 6. stage cost of knot k ----
     {
       double lx[12], lxx[6];
@@ -1164,6 +1204,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
       for (int i = 0; i < 12; ++i) pv[i] += lx[i];
     }
     QL_FENCE();
+    c.relane();
     QL_TICK(st, LP_B_GAIN);
   }
   return ok;
@@ -1188,7 +1229,7 @@ QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr
                          int l, const double zeta[6], const LaneState& st, LegOutC& o) {
   double u[3], r[3];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) { u[a] = R.u[a]; r[a] = K.foot[3 * l + a]; }
+  for (int a = 0; a < 3; ++a) { u[a] = R.u[a]; r[a] = kFootAhead ? R.foot[a] : K.foot[3 * l + a]; }
   leg_bw0(P, r, o.B);
   const double* B = o.B;
   double sv[6], lv[6];
@@ -1242,7 +1283,7 @@ QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr
 
 // ---- pass C: closed-loop trial rollout (alpha = 1) + slack / multiplier directions + step lengths ----------------------
 template <int NL>
-QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st) {
+QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st, FootPtr fp) {
   typedef LDim<NL> D;
   const int N = P.N;
   const double gb[3] = {K.rot[6] * (-9.81), K.rot[7] * (-9.81), K.rot[8] * (-9.81)};
@@ -1275,8 +1316,8 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   }
   {
     const int p0 = first_bit(porder);
-    fetch_ahead<NL>(c, O, 0, NL == 4 ? p0 : 2 * p0, Ra);
-    fetch_ahead<NL>(c, O, 0, NL == 4 ? 3 - p0 : 2 * p0 + 1, Rb);
+    fetch_ahead<NL>(c, O, 0, NL == 4 ? p0 : 2 * p0, Ra, fp);
+    fetch_ahead<NL>(c, O, 0, NL == 4 ? 3 - p0 : 2 * p0 + 1, Rb, fp);
   }
   double rp = 0.0, dn = 0.0, dd = 1.0, stp = 0.0;
   bool bad = false;
@@ -1335,8 +1376,8 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
         {     // the next pair's rows into the registers just consumed
           const int pn = next_bit(porder, pr);
           const int kq = pn >= 0 ? k : kn, pq = pn >= 0 ? pn : first_bit(porder);
-          fetch_ahead<NL>(c, O, kq, NL == 4 ? pq : 2 * pq, Ra);
-          fetch_ahead<NL>(c, O, kq, NL == 4 ? 3 - pq : 2 * pq + 1, Rb);
+          fetch_ahead<NL>(c, O, kq, NL == 4 ? pq : 2 * pq, Ra, fp);
+          fetch_ahead<NL>(c, O, kq, NL == 4 ? 3 - pq : 2 * pq + 1, Rb, fp);
         }
         if (on_a) {
 #pragma unroll
@@ -1379,7 +1420,7 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
 template <int NL>
 QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st) {
   st.it += 1;
-  pass_A<NL>(P, c, O, K, st, st.it == 1);
+  pass_A<NL>(P, c, O, K, st, st.it == 1, (FootPtr)K.foot);
   double resid;     // largest |rc|: the slack residual of every enabled row is rho * rc0_i
   {
     double cr[18], s0[6], rc0[6];
@@ -1398,8 +1439,8 @@ QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, cons
   else if (st.it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
   else if (st.it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
   st.target = sg * st.mu;
-  if (!pass_B<NL>(P, c, O, K, st)) { st.status = QMPC_NOT_PD; return false; }
-  pass_C<NL>(P, c, O, K, st);
+  if (!pass_B<NL>(P, c, O, K, st, (FootPtr)K.foot)) { st.status = QMPC_NOT_PD; return false; }
+  pass_C<NL>(P, c, O, K, st, (FootPtr)K.foot);
   if (st.bad_step) { st.status = QMPC_NOT_PD; return false; }     // the last finite iterate stays in the workspace
   st.iters = st.it;
   return true;
