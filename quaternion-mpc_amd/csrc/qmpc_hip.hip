@@ -39,8 +39,9 @@ hipError_t qmpc_warm_launch(int var, int convex, int batch, size_t lds, hipStrea
 size_t qmpc_lane_ws_bytes(int N, int nl, unsigned slots);
 size_t qmpc_lane_scratch_bytes(int batch);
 int qmpc_lane_param_slots();
+hipError_t qmpc_lane_upload_params(int pslot, hipStream_t s, const void* dev_params, size_t dev_params_size);
 hipError_t qmpc_lane_launch(int nl, int pslot, int batch, hipStream_t s, const void* dev_params, size_t dev_params_size, const void* in,
-                            double* forces, qmpc_info* info, double* ws, unsigned slots, int* scratch);
+                            double* forces, qmpc_info* info, double* ws, unsigned slots, int* scratch, int upload_params);
 
 struct qmpc_handle {
   qmpc_params params;
@@ -73,6 +74,7 @@ struct qmpc_handle {
   int lane_min_batch;     // batches from this size on take the lane-per-instance kernel (env QMPC_LANE_MIN)
   int lane_sort;          // 1: order the batch by stance mask first (env QMPC_LANE_SORT)
   int lane_pslot;         // this handle's slot in the lane kernel's constant-memory parameter table
+  bool lane_params_resident;   // set while a stream capture repeats launches with unchanged parameters (closed loop)
 };
 
 constexpr unsigned kLaneMaxSlots = 1024 * 64;   // one wavefront per SIMD of the chip
@@ -345,8 +347,8 @@ static bool use_lane(const qmpc_handle* h, int32_t batch, const double* d_tu, co
   if (h->variant == 4) return true;
   return h->variant == 0 && batch >= h->lane_min_batch;
 }
-static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces, qmpc_info* d_info,
-                               hipStream_t s) {
+// workspace of the lane kernel, allocated at first use (never inside a stream capture: qmpc_loop_run calls this first)
+static qmpc_status ensure_lane_buffers(qmpc_handle* h) {
   const int nl = model_nl(h->params.model);
   if (!h->d_lane_ws) {
     // one workspace block per wavefront; a wavefront may run with 32 of its lanes (qmpc_lane.hip), hence max_batch / 32
@@ -355,8 +357,15 @@ static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* 
     HIP_TRY(hipMalloc(&h->d_lane_ws, qmpc_lane_ws_bytes(h->params.horizon, nl, h->lane_slots)));
     HIP_TRY(hipMalloc(&h->d_lane_scratch, qmpc_lane_scratch_bytes(h->max_batch)));
   }
+  return QMPC_OK;
+}
+static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces, qmpc_info* d_info,
+                               hipStream_t s) {
+  const int nl = model_nl(h->params.model);
+  const qmpc_status es = ensure_lane_buffers(h);
+  if (es != QMPC_OK) return es;
   HIP_TRY(qmpc_lane_launch(nl, h->lane_pslot, (int)batch, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, h->d_lane_ws, h->lane_slots,
-                           h->lane_sort ? h->d_lane_scratch : nullptr));
+                           h->lane_sort ? h->d_lane_scratch : nullptr, h->lane_params_resident ? 0 : 1));
   return QMPC_OK;
 }
 
@@ -981,6 +990,19 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   hipGraphExec_t exec = nullptr;
   bool captured = false;
   int t_start = 0;
+  // Large cold-start batches solve with the lane-per-instance kernel: its workspace is allocated and its parameter block
+  // uploaded HERE, once, on the stream -- neither belongs inside the capture below (an allocation is not capturable,
+  // and the parameters do not change between the ticks of a call).
+  struct ResidentGuard {
+    qmpc_handle* h;
+    ~ResidentGuard() { h->lane_params_resident = false; }
+  } resident_guard{h};
+  if (!warm && use_lane(h, batch, nullptr, nullptr)) {
+    const qmpc_status es = ensure_lane_buffers(h);
+    if (es != QMPC_OK) return es;
+    HIP_TRY(qmpc_lane_upload_params(h->lane_pslot, s, &h->dev, sizeof h->dev));
+    h->lane_params_resident = true;
+  }
   if (warm) {                            // the cold first tick is not the tick the graph repeats
     const qmpc_status st = one_tick(true);
     if (st != QMPC_OK) return st;

@@ -277,14 +277,21 @@ __attribute__((visibility("hidden"))) size_t qmpc_lane_scratch_bytes(int batch) 
 // pslot: the handle's slot in the constant-memory parameter table (qmpc_lane_param_slots() of them); the block is copied
 // there stream-ordered before every launch, so qmpc_set_params takes effect like for the other kernels
 __attribute__((visibility("hidden"))) int qmpc_lane_param_slots() { return kParamSlots; }
+__attribute__((visibility("hidden"))) hipError_t qmpc_lane_upload_params(int pslot, hipStream_t s, const void* dev_params,
+                                                                          size_t dev_params_size) {
+  if (dev_params_size != sizeof(DevParams) || pslot < 0 || pslot >= kParamSlots) return hipErrorInvalidValue;
+  return hipMemcpyToSymbolAsync(HIP_SYMBOL(ql_params), dev_params, sizeof(DevParams), sizeof(DevParams) * (size_t)pslot,
+                                hipMemcpyHostToDevice, s);
+}
 __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int pslot, int batch, hipStream_t s, const void* dev_params,
                                                                    size_t dev_params_size, const void* in, double* forces,
-                                                                   qmpc_info* info, double* ws, unsigned slots, int* scratch) {
+                                                                   qmpc_info* info, double* ws, unsigned slots, int* scratch,
+                                                                   int upload_params) {
   if (dev_params_size != sizeof(DevParams) || (nl != 4 && nl != 8) || slots % kLaneWave || pslot < 0 || pslot >= kParamSlots)
     return hipErrorInvalidValue;
   DevParams P;
   memcpy(&P, dev_params, sizeof P);
-  {
+  if (upload_params) {     // 0: the caller uploaded them on this stream already and repeats the launch (captured closed loop)
     const hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(ql_params), dev_params, sizeof(DevParams), sizeof(DevParams) * (size_t)pslot,
                                                 hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return e;

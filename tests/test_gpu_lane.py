@@ -222,3 +222,53 @@ def test_lane_kernel_outside_the_envelope(pkg, lib, oracle, monkeypatch):
     assert abs(ok_g.mean() - ok_o.mean()) < 0.08 and both.mean() > 0.45
     assert np.abs(f - fo)[both].max() < 1e-5
     assert np.isfinite(f).all()
+
+
+def test_closed_loop_with_the_lane_kernel(pkg, lib, monkeypatch):
+    """The device-resident closed loop in its per-tick form (more than 2048 robots) takes its solves from launch_solve, i.e.
+    from the lane kernel when that is selected: its workspace must exist and its parameters be uploaded BEFORE the tick
+    sequence is captured into a graph.  Same robots through the lane kernel and through the wave-per-instance kernels:
+    every solve converges in both, the states agree to the solvers' agreement (a closed loop amplifies 1e-10 N only
+    mildly over 40 ticks)."""
+    lp = pkg.default_loop_params(lib)
+    rng = np.random.default_rng(17)
+    B = 3072
+    cmds = np.zeros((B, 7))
+    cmds[:, 0] = rng.uniform(-0.5, 0.5, B); cmds[:, 1] = rng.uniform(-0.2, 0.2, B); cmds[:, 2] = rng.uniform(0.26, 0.32, B)
+    cmds[:, 5] = rng.uniform(-0.5, 0.5, B); cmds[:, 6] = (rng.random(B) < 0.9).astype(float)
+    cmds[cmds[:, 6] == 0, :2] = 0.0
+    cmds[cmds[:, 6] == 0, 5] = 0.0
+    stand = cmds.copy(); stand[:, 6] = 0.0
+    st0 = pkg.loop_states(stand, lp, height=0.3, yaw=rng.uniform(-3, 3, B), lib=lib)
+    out = {}
+    for v in (4, 0):
+        _forced(monkeypatch, v)
+        s = pkg.Solver(pkg.default_params(10, pkg.MODE_CONVERGED, lib), B, device=0, lib=lib)
+        st = s.loop_run(st0, 6, lp)
+        st["movement_mode"] = cmds[:, 6]
+        st = s.loop_run(st, 40, lp)
+        st = s.loop_run(st, 3, lp)          # a second call on the same handle: buffers and parameter slot are reused
+        s.close()
+        out[v] = st
+        assert (st["status"] == 0).all() and np.isfinite(st["pos_world"]).all()
+    assert np.array_equal(out[4]["tick"], out[0]["tick"])
+    assert np.array_equal(out[4]["contacts"], out[0]["contacts"])
+    dp = np.abs(out[4]["pos_world"] - out[0]["pos_world"]).max()
+    dv = np.abs(out[4]["lin_vel_world"] - out[0]["lin_vel_world"]).max() if "lin_vel_world" in out[0].dtype.names else 0.0
+    print(f"lane vs wave closed loop, {B} robots, 49 ticks: max position difference {dp:.2e} m, velocity {dv:.2e}")
+    assert dp < 1e-7
+
+
+def test_closed_loop_at_the_automatic_switch_over(pkg, lib):
+    """24576 robots: the batch size from which qmpc_solve* picks the lane kernel by itself; the loop must do the same."""
+    lp = pkg.default_loop_params(lib)
+    B = 24576
+    cmds = np.zeros((B, 7)); cmds[:, 0] = 0.3; cmds[:, 2] = 0.3
+    st0 = pkg.loop_states(cmds, lp, height=0.3, lib=lib)
+    s = pkg.Solver(pkg.default_params(10, pkg.MODE_CONVERGED, lib), B, device=0, lib=lib)
+    st = s.loop_run(st0, 4, lp)
+    st["movement_mode"] = 1.0
+    st = s.loop_run(st, 12, lp)
+    s.close()
+    assert (st["status"] == 0).all() and (st["tick"] == 16).all()
+    assert np.abs(st["pos_world"] - st["pos_world"][0]).max() < 1e-9      # identical robots, identical states
