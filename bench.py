@@ -533,6 +533,34 @@ def main():
                                   "note": "secondary: qmpc_loop_run_device (goal + gait FSM + swing quintic + Raibert + "
                                           "record packing -> solve -> rigid-body plant), robots with random commands, params.drop_ang_vel = 0, state "
                                           "resident in HBM; tools/loop_bench.py compares the two launch forms"}
+            if B == 1024 and N == 10 and not args.no_large_batch:
+                # ... and the Monte-Carlo scale: 65536 robots, per-tick launch form, the solves on the lane-per-instance
+                # kernel (cold start); 8 stand ticks, 30 ticks into the gait, 40 timed ticks
+                BL = 65536
+                cl = np.zeros((BL, 7))
+                cl[:, 0] = rng.uniform(-0.5, 0.5, BL); cl[:, 1] = rng.uniform(-0.2, 0.2, BL); cl[:, 2] = rng.uniform(0.26, 0.32, BL)
+                cl[:, 5] = rng.uniform(-0.5, 0.5, BL)
+                wl = rng.random(BL) < 0.9
+                cl[~wl, :2] = 0.0
+                cl[~wl, 5] = 0.0
+                stl = pkg.loop_states(cl, lp, height=0.3, yaw=rng.uniform(-3.1, 3.1, BL), lib=lib)
+                sll = pkg.Solver(pl, BL, device=local, lib=lib)
+                stl = sll.loop_run(stl, 8, lp)
+                stl["movement_mode"] = wl.astype(float)
+                d_stl = torch.from_numpy(stl.view(np.uint8).reshape(BL, -1).copy()).cuda()
+                sll.loop_run_device(BL, d_stl.data_ptr(), 30, lp, stream=stream.cuda_stream)
+                torch.cuda.synchronize()
+                tl = 40
+                t0l = time.perf_counter()
+                sll.loop_run_device(BL, d_stl.data_ptr(), tl, lp, stream=stream.cuda_stream)
+                torch.cuda.synchronize()
+                dtl = time.perf_counter() - t0l
+                finl = np.ascontiguousarray(d_stl.cpu().numpy()).view(pkg.LOOP_STATE_DTYPE).reshape(BL)
+                sll.close()
+                out["closed_loop"]["large"] = {"value": BL * tl / dtl, "unit": "robot-ticks/s", "robots": BL, "ticks": tl,
+                                               "ms_per_tick": 1e3 * dtl / tl, "solver_ok": int((finl["status"] == 0).sum()),
+                                               "mean_iterations": float(finl["iterations"].mean()),
+                                               "launch_form": "three kernels per tick (graph replay), solve = qmpc_lane_kernel"}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(pkg, N, config_id, model=args.model)
             f_cpu = cb.pop("_forces")

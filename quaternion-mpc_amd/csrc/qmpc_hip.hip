@@ -41,7 +41,8 @@ size_t qmpc_lane_scratch_bytes(int batch);
 int qmpc_lane_param_slots();
 hipError_t qmpc_lane_upload_params(int pslot, hipStream_t s, const void* dev_params, size_t dev_params_size);
 hipError_t qmpc_lane_launch(int nl, int pslot, int batch, hipStream_t s, const void* dev_params, size_t dev_params_size, const void* in,
-                            double* forces, qmpc_info* info, double* ws, unsigned slots, int* scratch, int upload_params);
+                            double* forces, qmpc_info* info, double* ws, unsigned slots, int* scratch, int upload_params,
+                            const double* u_init, double* traj_u, int check_prev);
 
 struct qmpc_handle {
   qmpc_params params;
@@ -341,9 +342,11 @@ static bool use_global_gains(const qmpc_handle* h, int32_t batch) { return pick_
 
 // Large batches of the converged mode go to the lane-per-instance kernel (qmpc_lane.hip): one lane per instance, the
 // working set streamed through a structure-of-arrays HBM workspace sized by the RESIDENT lanes (<= 1024 wavefronts).
-// It returns forces and info only; calls that ask for trajectories keep the wave-per-instance kernels.
+// It returns forces, info and (on request) the input trajectory; calls that ask for the state trajectory keep the
+// wave-per-instance kernels.
 static bool use_lane(const qmpc_handle* h, int32_t batch, const double* d_tu, const double* d_tx) {
-  if (h->params.mode != QMPC_MODE_CONVERGED || h->params.model == QMPC_MODEL_CONVEX || d_tu || d_tx) return false;
+  (void)d_tu;
+  if (h->params.mode != QMPC_MODE_CONVERGED || h->params.model == QMPC_MODEL_CONVEX || d_tx) return false;
   if (h->variant == 4) return true;
   return h->variant == 0 && batch >= h->lane_min_batch;
 }
@@ -359,13 +362,16 @@ static qmpc_status ensure_lane_buffers(qmpc_handle* h) {
   }
   return QMPC_OK;
 }
+// d_u_init / d_traj_u: previous solutions [batch][N][3 NL] to start from (null: cold) / where to leave this one (null:
+// not wanted); they may be the same buffer.  check_prev: d_info still holds the records of the previous solves
 static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces, qmpc_info* d_info,
-                               hipStream_t s) {
+                               hipStream_t s, const double* d_u_init = nullptr, double* d_traj_u = nullptr, int check_prev = 0) {
   const int nl = model_nl(h->params.model);
   const qmpc_status es = ensure_lane_buffers(h);
   if (es != QMPC_OK) return es;
   HIP_TRY(qmpc_lane_launch(nl, h->lane_pslot, (int)batch, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, h->d_lane_ws, h->lane_slots,
-                           h->lane_sort ? h->d_lane_scratch : nullptr, h->lane_params_resident ? 0 : 1));
+                           h->lane_sort ? h->d_lane_scratch : nullptr, h->lane_params_resident ? 0 : 1, d_u_init, d_traj_u,
+                           check_prev));
   return QMPC_OK;
 }
 
@@ -398,7 +404,7 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
     return QMPC_OK;
   }
   if (use_lane(h, batch, d_tu, d_tx)) {
-    const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s);
+    const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s, nullptr, d_tu);
     if (ls != QMPC_OK) return ls;
     if (timed) {
       HIP_TRY(hipEventRecord(h->ev1, s));
@@ -513,6 +519,8 @@ qmpc_status qmpc_solve_warm_device(qmpc_handle* h, int32_t batch, const qmpc_inp
   if (batch == 0) return QMPC_OK;
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
   HIP_TRY(hipSetDevice(h->device));
+  if (use_lane(h, batch, nullptr, nullptr))      // large batches: the lane-per-instance kernel, same start rule
+    return launch_lane(h, batch, d_in, d_forces_body, d_info, stream ? (hipStream_t)stream : h->stream, d_u_init, d_traj_u, 0);
   const int var = pick_variant(h, batch);
   const size_t lds = var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes);
   HIP_TRY(qmpc_warm_launch(var, 0, (int)batch, lds, stream ? (hipStream_t)stream : h->stream, &h->dev, sizeof h->dev, d_in, d_u_init,
@@ -938,7 +946,11 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
     else
       hipLaunchKernelGGL(qmpc_loop_front_kernel, dim3(blocks), dim3(64), 0, s, LP, d_states, h->d_in, h->d_loop_row, (int)batch);
     HIP_TRY(hipGetLastError());
-    if (warm) {
+    if (warm && !convex && use_lane(h, batch, nullptr, nullptr)) {
+      const qmpc_status st = launch_lane(h, batch, h->d_in, h->d_forces, h->d_info, s, first ? nullptr : h->d_traj_u, h->d_traj_u,
+                                         /*check_prev=*/1);
+      if (st != QMPC_OK) return st;
+    } else if (warm) {
       const int var = pick_variant(h, batch);
       const size_t lds = var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes);
       HIP_TRY(qmpc_warm_launch(var, convex ? 1 : 0, (int)batch, lds, s, &h->dev, sizeof h->dev, h->d_in, first ? nullptr : h->d_traj_u,
@@ -997,7 +1009,7 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
     qmpc_handle* h;
     ~ResidentGuard() { h->lane_params_resident = false; }
   } resident_guard{h};
-  if (!warm && use_lane(h, batch, nullptr, nullptr)) {
+  if (use_lane(h, batch, nullptr, nullptr)) {
     const qmpc_status es = ensure_lane_buffers(h);
     if (es != QMPC_OK) return es;
     HIP_TRY(qmpc_lane_upload_params(h->lane_pslot, s, &h->dev, sizeof h->dev));

@@ -58,6 +58,7 @@ struct PassArgs {
   int pslot;
   unsigned ws_lo, ws_hi;     // this wave's workspace block
   unsigned lane8;            // 8 x lane
+  unsigned warm;             // wave-uniform: the launch carries previous solutions (qmpc_solve_warm*, the warm-started loop)
 };
 template <int NL>
 __device__ __forceinline__ Ctx pass_ctx(const PassArgs& a) {
@@ -68,17 +69,19 @@ __device__ __forceinline__ Ctx pass_ctx(const PassArgs& a) {
   return c;
 }
 template <int NL>
-__device__ __noinline__ void call_setup(PassArgs a, unsigned long long rec, QL_PRIV_AS LaneK<NL>* Kp, QL_PRIV_AS LaneState* sp) {
+__device__ __noinline__ void call_setup(PassArgs a, unsigned long long rec, unsigned long long u_prev, QL_PRIV_AS LaneK<NL>* Kp,
+                                        QL_PRIV_AS LaneState* sp) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
   const WsOff O = make_wsoff<NL>(P.N);
   LaneK<NL> K;
   LaneState st;
-  lane_setup<NL>(P, c, O, reinterpret_cast<const double*>(rec), K, st);
+  lane_setup<NL>(P, c, O, reinterpret_cast<const double*>(rec), K, st, __builtin_amdgcn_readfirstlane(a.warm) != 0,
+                 reinterpret_cast<const double*>(u_prev));
   priv_store(Kp, K);
   priv_store(sp, st);
 }
-template <int NL>
+template <int NL, bool WARM>
 __device__ __noinline__ void call_A(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS LaneState* sp) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
@@ -88,10 +91,10 @@ __device__ __noinline__ void call_A(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
   LaneState st;
   priv_load(st, (QL_PRIV_AS const LaneState*)sp);
   st.it += 1;
-  pass_A<NL>(P, c, O, K, st, st.it == 1, (FootPtr)Kp->foot);
+  pass_A<NL, WARM>(P, c, O, K, st, st.it == 1, (FootPtr)Kp->foot);
   priv_store(sp, st);
 }
-template <int NL>
+template <int NL, bool WARM>
 __device__ __noinline__ bool call_B(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS LaneState* sp) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
@@ -100,13 +103,13 @@ __device__ __noinline__ bool call_B(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
   priv_load(K, Kp);
   LaneState st;
   priv_load(st, (QL_PRIV_AS const LaneState*)sp);
-  const bool ok = pass_B<NL>(P, c, O, K, st, (FootPtr)Kp->foot);
+  const bool ok = pass_B<NL, WARM>(P, c, O, K, st, (FootPtr)Kp->foot);
 #if defined(QL_PROFILE)
   priv_store(sp, st);
 #endif
   return ok;
 }
-template <int NL>
+template <int NL, bool WARM>
 __device__ __noinline__ void call_C(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS LaneState* sp) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
@@ -115,13 +118,13 @@ __device__ __noinline__ void call_C(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
   priv_load(K, Kp);
   LaneState st;
   priv_load(st, (QL_PRIV_AS const LaneState*)sp);
-  pass_C<NL>(P, c, O, K, st, (FootPtr)Kp->foot);
+  pass_C<NL, WARM>(P, c, O, K, st, (FootPtr)Kp->foot);
   if (!st.bad_step) st.iters = st.it;
   priv_store(sp, st);
 }
 template <int NL>
 __device__ __noinline__ void call_finish(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp,
-                                         unsigned long long forces, unsigned long long info) {
+                                         unsigned long long forces, unsigned long long info, unsigned long long traj_u) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
   const WsOff O = make_wsoff<NL>(P.N);
@@ -129,7 +132,8 @@ __device__ __noinline__ void call_finish(PassArgs a, QL_PRIV_AS const LaneK<NL>*
   priv_load(K, Kp);
   LaneState st;
   priv_load(st, sp);
-  lane_finish<NL>(P, c, O, K, st, reinterpret_cast<double*>(forces), reinterpret_cast<qmpc_info*>(info));
+  lane_finish<NL>(P, c, O, K, st, reinterpret_cast<double*>(forces), reinterpret_cast<qmpc_info*>(info),
+                  reinterpret_cast<double*>(traj_u));
 }
 
 template <int NL>
@@ -137,13 +141,16 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
                                                               double* __restrict__ forces, qmpc_info* __restrict__ info,
                                                               int batch, double* __restrict__ ws, unsigned slots,
                                                               int lanes, const int* __restrict__ perm,
-                                                              long long* __restrict__ prof) {
+                                                              long long* __restrict__ prof, const double* u_init, double* traj_u,
+                                                              int check_prev) {
   typedef LDim<NL> D;
   const int lane = threadIdx.x;
   const DevParams& P = ql_params[pslot];
   const size_t block_elems = (size_t)make_wsoff<NL>(P.N).total * kLaneWave;
   const unsigned long long wsb = reinterpret_cast<unsigned long long>(ws + (size_t)blockIdx.x * block_elems);
-  const PassArgs a = {pslot, (unsigned)wsb, (unsigned)(wsb >> 32), 8u * (unsigned)lane};
+  const PassArgs a = {pslot, (unsigned)wsb, (unsigned)(wsb >> 32), 8u * (unsigned)lane, u_init ? 1u : 0u};
+  const bool warm = u_init != nullptr;      // kernel argument: scalar
+  const size_t tstride = (size_t)P.N * D::NU;      // doubles per instance in u_init / traj_u
   LaneK<NL> K;
   LaneState st;
   QL_PRIV_AS LaneK<NL>* Kp = (QL_PRIV_AS LaneK<NL>*)&K;
@@ -155,7 +162,11 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
     const int b = valid ? (perm ? perm[pos] : (int)pos) : 0;
     bool active = false;
     if (valid) {
-      call_setup<NL>(a, reinterpret_cast<unsigned long long>(in + (size_t)b * D::REC), Kp, sp);
+      // the previous solution of this instance is usable unless its last solve failed (check_prev: info[b] still holds
+      // that solve's record -- the rule of qmpc_solve_warm_kernel)
+      const bool usable = u_init && (!check_prev || info[b].status == QMPC_OK || info[b].status == QMPC_MAX_ITER);
+      call_setup<NL>(a, reinterpret_cast<unsigned long long>(in + (size_t)b * D::REC),
+                     usable ? reinterpret_cast<unsigned long long>(u_init + (size_t)b * tstride) : 0ull, Kp, sp);
       active = st.active;
     }
 #if defined(QL_PROFILE)
@@ -166,17 +177,8 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
     while (__any(active)) {
       if (active) {
         // one interior-point iteration (the control flow of lane_iteration in qmpc_lane_core.h)
-        call_A<NL>(a, Kp, sp);
-        double resid;
-        {
-          double cr[18], s0[6], rc0[6];
-          cone_rows(P, K.rot, cr);
-          initial_rows(P, cr, st.uz, s0, rc0);
-          double m = 0.0;
-#pragma unroll
-          for (int i = 0; i < 6; ++i) m = fmax(m, fabs(rc0[i]));
-          resid = st.rho * m;
-        }
+        if (warm) call_A<NL, true>(a, Kp, sp); else call_A<NL, false>(a, Kp, sp);
+        const double resid = st.rho * st.rcmax;
         if (st.mu <= P.mu_final && resid <= P.tol_feas && st.last_step <= P.tol_step) { st.status = QMPC_OK; active = false; }
         else if (st.it > P.iterations_max) { st.status = QMPC_MAX_ITER; active = false; }
         else {
@@ -186,9 +188,9 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
           else if (st.it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
           else if (st.it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
           st.target = sg * st.mu;
-          if (!call_B<NL>(a, Kp, sp)) { st.status = QMPC_NOT_PD; active = false; }
+          if (!(warm ? call_B<NL, true>(a, Kp, sp) : call_B<NL, false>(a, Kp, sp))) { st.status = QMPC_NOT_PD; active = false; }
           else {
-            call_C<NL>(a, Kp, sp);
+            if (warm) call_C<NL, true>(a, Kp, sp); else call_C<NL, false>(a, Kp, sp);
             if (st.bad_step) { st.status = QMPC_NOT_PD; active = false; }     // a non-finite trial step is not applied
           }
         }
@@ -199,7 +201,8 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
     }
     if (valid)
       call_finish<NL>(a, Kp, sp, reinterpret_cast<unsigned long long>(forces + (size_t)b * D::NU),
-                      info ? reinterpret_cast<unsigned long long>(info + b) : 0ull);
+                      info ? reinterpret_cast<unsigned long long>(info + b) : 0ull,
+                      traj_u ? reinterpret_cast<unsigned long long>(traj_u + (size_t)b * tstride) : 0ull);
 #if defined(QL_PROFILE)
     if (prof && base < (long long)slots) {      // first round of every wave; lane 0's clock, every lane's own iteration count
       if (lane == 0) {
@@ -286,7 +289,8 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_upload_params(int psl
 __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int pslot, int batch, hipStream_t s, const void* dev_params,
                                                                    size_t dev_params_size, const void* in, double* forces,
                                                                    qmpc_info* info, double* ws, unsigned slots, int* scratch,
-                                                                   int upload_params) {
+                                                                   int upload_params, const double* u_init, double* traj_u,
+                                                                   int check_prev) {
   if (dev_params_size != sizeof(DevParams) || (nl != 4 && nl != 8) || slots % kLaneWave || pslot < 0 || pslot >= kParamSlots)
     return hipErrorInvalidValue;
   DevParams P;
@@ -328,9 +332,11 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
   (void)hipMemsetAsync(d_prof, 0, sizeof(long long) * 16 * 1024, s);
 #endif
   if (nl == 8)
-    hipLaunchKernelGGL(qmpc_lane_kernel<8>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm, prof);
+    hipLaunchKernelGGL(qmpc_lane_kernel<8>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm, prof,
+                       u_init, traj_u, check_prev);
   else
-    hipLaunchKernelGGL(qmpc_lane_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm, prof);
+    hipLaunchKernelGGL(qmpc_lane_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm, prof,
+                       u_init, traj_u, check_prev);
 #if defined(QL_PROFILE)
   {
     static long long hp[16 * 1024];

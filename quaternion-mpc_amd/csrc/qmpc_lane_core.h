@@ -96,7 +96,7 @@ struct LaneK {
 
 // workspace offsets in ELEMENTS of one lane's column (element e of lane s of a wave lives at wave_base[64 e + s])
 struct WsOff {
-  int X, U, dU, S, LAM, G, total;
+  int X, U, dU, S, LAM, G, RC, total;
 };
 template <int NL>
 QL_HD WsOff make_wsoff(int N) {
@@ -108,6 +108,7 @@ QL_HD WsOff make_wsoff(int N) {
   o.S = p; p += 6 * NL * N;
   o.LAM = p; p += 6 * NL * N;
   o.G = p; p += LDim<NL>::GAIN * N;
+  o.RC = p; p += 6 * NL * N;      // initial slack residuals per row: only a warm-started launch has them per knot
   o.total = p;
   return o;
 }
@@ -194,6 +195,7 @@ struct LaneState {
   double ap, ad;       // step lengths of the pending step
   int bad_step;        // the trial increment of the last forward pass was not finite (it is NOT applied: QMPC_NOT_PD)
   double uz;           // u_ref z-component of a stance contact point
+  double rcmax;        // largest |rc0_i| over the enabled rows (the feasibility residual is rho * rcmax)
 };
 
 // ---- small dense helpers (everything is unrolled into registers) --------------------------------------------------
@@ -462,17 +464,34 @@ QL_FN unsigned load_rows(const Ctx& c, const WsOff& O, int k, int l, double sv[6
 // point l of knot k is worked on, the rows of the NEXT stance point in processing order (the next point of the same
 // knot, or the first point of knot k-1) are already on their way.  `order` is the wave-uniform list of points that any
 // lane has in stance; the address of the next point is a scalar computation.
-struct LegAhead {
+// WARM: the launch is warm-started -- the rows' initial slack residuals travel with the rows while any lane's rho is not 0.
+// The passes exist in both forms: the six extra registers per point in flight cost the cold path 10-13 % otherwise.
+template <bool WARM>
+struct LegAheadT {
+  static constexpr bool kHasRc = true;
   double u[3], du[3], s[6], lam[6], foot[3];
+  double rc[6];
 };
-QL_FN void fetch_foot(FootPtr fp, int l, LegAhead& R) {
+template <>
+struct LegAheadT<false> {
+  static constexpr bool kHasRc = false;
+  double u[3], du[3], s[6], lam[6], foot[3];
+  static constexpr double rc[6] = {0, 0, 0, 0, 0, 0};
+};
+template <class RT>
+QL_FN void fetch_foot(FootPtr fp, int l, RT& R) {
   if (kFootAhead)
 #pragma unroll
     for (int a = 0; a < 3; ++a) R.foot[a] = fp[3 * l + a];
 }
-template <int NL, bool WITH_DU = false>
-QL_FN void fetch_ahead(const Ctx& c, const WsOff& O, int k, int l, LegAhead& R, FootPtr fp) {     // k, l wave-uniform run-time values
+template <int NL, bool WITH_DU = false, class RT>
+QL_FN void fetch_ahead(const Ctx& c, const WsOff& O, int k, int l, RT& R, FootPtr fp, bool rcrows = false) {     // k, l wave-uniform run-time values
   fetch_foot(fp, l, R);
+  if constexpr (RT::kHasRc) {
+    if (rcrows)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) R.rc[i] = c.W(O.RC + 6 * NL * k + 6 * l + i);
+  }
 #pragma unroll
   for (int a = 0; a < 3; ++a) R.u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
   if (WITH_DU)
@@ -512,8 +531,13 @@ QL_FN int next_bit(unsigned m, int l) {
 #endif
 
 // ---- set-up: record -> constants, initial guess U = u_ref (QuatMpc.cpp:253), slacks and multipliers ------------------
+// warm_launch (wave-uniform): the launch carries previous solutions; the rows' initial slack residuals are then kept per
+// knot (O.RC) for EVERY lane of the launch.  u_prev: this instance's previous inputs [N][3 NL] or null (cold start of
+// this instance).  The warm guess is the rule of qmpc_solve_body.inc: the previous solution shifted by one knot (the last
+// knot repeats), swing points pinned to 0, a component that was 0 (the point has just landed) starts from u_ref.
 template <int NL>
-QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const double* rec, LaneK<NL>& K, LaneState& st) {
+QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const double* rec, LaneK<NL>& K, LaneState& st,
+                      bool warm_launch = false, const double* u_prev = nullptr) {
   typedef LDim<NL> D;
   const int N = P.N;
   bool bad = false;
@@ -527,7 +551,7 @@ QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const do
   st.iters = 0; st.it = 0;
   st.active = st.status == QMPC_OK;
   st.rho = 1.0; st.mu = 0.0; st.target = 0.0; st.last_ap = 0.0; st.last_ad = 0.0; st.last_step = 1e300;
-  st.ap = 1.0; st.ad = 1.0; st.uz = 0.0; st.bad_step = 0;
+  st.ap = 1.0; st.ad = 1.0; st.uz = 0.0; st.bad_step = 0; st.rcmax = 0.0;
   if (!st.active) return;
 #pragma unroll
   for (int i = 0; i < 9; ++i) K.rot[i] = raw[4 + i];
@@ -565,8 +589,49 @@ QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const do
     double cr[18], rc0[6];
     cone_rows(P, K.rot, cr);
     initial_rows(P, cr, st.uz, s0, rc0);
+    st.rcmax = 0.0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) l0[i] = P.mu0 / s0[i];
+    for (int i = 0; i < 6; ++i) { l0[i] = P.mu0 / s0[i]; st.rcmax = fmax(st.rcmax, fabs(rc0[i])); }
+  }
+  if (warm_launch) {
+    double cr[18];
+    cone_rows(P, K.rot, cr);
+    double slsum = 0.0, rcmax = 0.0;
+    for (int k = 0; k < N; ++k) {
+      const int ks = (k + 1 < N) ? k + 1 : k;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        const bool on = (st.con >> l) & 1u;
+        double u[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const double ur = (a == 2) ? st.uz : 0.0;
+          double v = ur;
+          if (u_prev) {
+            const double prev = u_prev[3 * NL * ks + 3 * l + a];
+            v = (prev != 0.0) ? prev : ur;
+          }
+          u[a] = on ? v : 0.0;
+          c.W(O.U + 3 * NL * k + 3 * l + a) = u[a];
+        }
+        if (on) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            double c0 = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
+            if (i == 4) c0 += -P.fz_max;
+            const double sv = fmax(-c0, 1.0), lv = P.mu0 / sv, rc = c0 + sv;
+            c.W(O.S + 6 * NL * k + 6 * l + i) = sv;
+            c.W(O.LAM + 6 * NL * k + 6 * l + i) = lv;
+            c.W(O.RC + 6 * NL * k + 6 * l + i) = rc;
+            slsum += sv * lv;
+            rcmax = fmax(rcmax, fabs(rc));
+          }
+        }
+      }
+    }
+    st.mu = slsum / (double)(6 * N * st.nc);
+    st.rcmax = rcmax;
+    return;
   }
   double slsum = 0.0;
 #pragma unroll
@@ -592,8 +657,11 @@ QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const do
 // Slack / multiplier directions are recomputed from the stored trial increment dU exactly as pass C formed them (the
 // cone rows are linear in u), so nothing but dU has to be kept between the passes.  A shortened primal step scales
 // the increment; rc <- (1 - alpha_p) rc, exactly 0 after a full step.
-template <int NL>
+// WARM: a warm-started launch -- the inputs of the first iteration are read (they are not u_ref), and the rows' initial
+// slack residuals come from the workspace while any lane still carries a residual (rho != 0)
+template <int NL, bool WARM = false>
 QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st, bool first, FootPtr fp) {
+  constexpr bool warm = WARM;
   const int N = P.N;
   const double gb[3] = {K.rot[6] * (-9.81), K.rot[7] * (-9.81), K.rot[8] * (-9.81)};
   const double* wd0 = K.wd0;
@@ -611,9 +679,10 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   const bool tapia = (ap >= 0.99) && (ad >= 0.99);
   double slsum = 0.0;
   const unsigned order = any_stance<NL>(st.con);
-  LegAhead R;         // rows, inputs and trial increments of the NEXT contact point in processing order (not at the first
+  const bool rcrows = WARM && QL_ANY(st.rho != 0.0);
+  LegAheadT<WARM> R;         // rows, inputs and trial increments of the NEXT contact point in processing order (not at the first
                       // iteration: nothing is pending then and every input is at its reference)
-  if (!first) fetch_ahead<NL, true>(c, O, 0, first_bit(order), R, fp);
+  if (!first) fetch_ahead<NL, true>(c, O, 0, first_bit(order), R, fp, rcrows);
   else fetch_foot(fp, first_bit(order), R);
   for (int k = 0; k < N; ++k) {
     const int kn = (k + 1 < N) ? k + 1 : k;
@@ -625,9 +694,15 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
       unsigned kap = 0;
 #pragma unroll
       for (int a = 0; a < 3; ++a) r[a] = kFootAhead ? R.foot[a] : K.foot[3 * l + a];
+      double rcl[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) rcl[i] = rcrows ? R.rc[i] : rc0[i];
       if (first) {
         const int ln = next_bit(order, l);
         fetch_foot(fp, ln >= 0 ? ln : first_bit(order), R);
+        if (warm)      // the warm guess (once per solve: read in place)
+#pragma unroll
+          for (int a = 0; a < 3; ++a) u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
       }
       if (!first) {
 #pragma unroll
@@ -639,7 +714,7 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
           sv[i] = fabs(R.s[i]);
         }
         const int ln = next_bit(order, l);
-        fetch_ahead<NL, true>(c, O, ln >= 0 ? k : kn, ln >= 0 ? ln : first_bit(order), R, fp);
+        fetch_ahead<NL, true>(c, O, ln >= 0 ? k : kn, ln >= 0 ? ln : first_bit(order), R, fp, rcrows);
       }
       if ((st.con >> l) & 1u) {
       if (!first) {
@@ -647,7 +722,7 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
         for (int i = 0; i < 6; ++i) {
           const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
           const double kp = ((kap >> i) & 1u) ? 1.0 : 0.0;
-          const double dsv = -(jd + st.rho * rc0[i]);
+          const double dsv = -(jd + st.rho * rcl[i]);
           const double dlv = (st.target - (1.0 + kp) * sv[i] * lv[i] - lv[i] * dsv) * ql_rcp(sv[i]);
           const double s1 = sv[i] + ap * dsv;
           const double l1 = lv[i] + ad * dlv;
@@ -734,7 +809,7 @@ QL_FN void cost_expansion(const DevParams& P, const Ctx& c, const WsOff& O, cons
     }
 }
 
-template <int NL>
+template <int NL, bool WARM = false>
 QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const LaneK<NL>& K, LaneState& st, FootPtr fp) {
   Ctx c = c_in;
   typedef LDim<NL> D;
@@ -747,8 +822,9 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     initial_rows(P, cr, st.uz, s0, rc0);
   }
   const unsigned order = any_stance<NL>(st.con);      // at least one bit: the lanes of this call have a stance point
-  LegAhead R;         // rows of the NEXT contact point in processing order
-  fetch_ahead<NL>(c, O, N - 1, first_bit(order), R, fp);
+  const bool rcrows = WARM && QL_ANY(st.rho != 0.0);
+  LegAheadT<WARM> R;         // rows of the NEXT contact point in processing order
+  fetch_ahead<NL>(c, O, N - 1, first_bit(order), R, fp, rcrows);
   bool ok = true;
   const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
   {
@@ -794,6 +870,9 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
       unsigned kap = 0;
 #pragma unroll
       for (int a = 0; a < 3; ++a) { u[a] = R.u[a]; r[a] = kFootAhead ? R.foot[a] : K.foot[3 * l + a]; }
+      double rcl[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) rcl[i] = rcrows ? R.rc[i] : rc0[i];
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         lv[i] = R.lam[i];
@@ -805,7 +884,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
         c.relane();
         // (the first point of the NEXT knot is fetched after the main phase: 18 doubles fewer live through it, and the
         // cost expansion and the head of the next knot are time enough for the rows to arrive)
-        if (ln >= 0) fetch_ahead<NL>(c, O, k, ln, R, fp);
+        if (ln >= 0) fetch_ahead<NL>(c, O, k, ln, R, fp, rcrows);
       }
       if ((st.con >> l) & 1u) {
       double B[9];
@@ -813,7 +892,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
 #pragma unroll
       for (int a = 0; a < 3; ++a) wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
       LegBlk lb;
-      leg_block(P, cr, rc0, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
+      leg_block(P, cr, rcl, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
       // V = [T ; Bw0 T] (6 x 3), Vt = V L^-T (columns), G += sum_j id_j vt_j vt_j', r6 += sum_j vt_j id_j y_j, y = L^-1 gq
       double V[18];
 #pragma unroll
@@ -1186,7 +1265,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     QL_FENCE();
     c.relane();
     QL_TICK(st, LP_B_UPD);
-    fetch_ahead<NL>(c, O, kn, first_bit(order), R, fp);
+    fetch_ahead<NL>(c, O, kn, first_bit(order), R, fp, rcrows);
     // ---- 6. stage cost of knot k ----
     {
       double lx[12], lxx[6];
@@ -1224,9 +1303,12 @@ struct LegOutC {
   double rp, dn, dd, stp;     // largest -ds_i / s_i; the row with the largest -dlam_i / lam_i as numerator / denominator
   bool bad;                   // a component of du is not finite (fmax / fmin drop NaNs silently)
 };
-template <int NL>
-QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr[18], const double rc0[6], const LegAhead& R,
-                         int l, const double zeta[6], const LaneState& st, LegOutC& o) {
+template <int NL, class RT>
+QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr[18], const double rc0_[6], const RT& R,
+                         int l, const double zeta[6], const LaneState& st, LegOutC& o, bool rcrows) {
+  double rc0[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) rc0[i] = rcrows ? R.rc[i] : rc0_[i];
   double u[3], r[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) { u[a] = R.u[a]; r[a] = kFootAhead ? R.foot[a] : K.foot[3 * l + a]; }
@@ -1282,7 +1364,7 @@ QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr
 }
 
 // ---- pass C: closed-loop trial rollout (alpha = 1) + slack / multiplier directions + step lengths ----------------------
-template <int NL>
+template <int NL, bool WARM = false>
 QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st, FootPtr fp) {
   typedef LDim<NL> D;
   const int N = P.N;
@@ -1307,7 +1389,8 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     for (int pr = 0; pr < NL / 2; ++pr)
       porder |= (((order >> pair_leg<NL>(pr, 0)) | (order >> pair_leg<NL>(pr, 1))) & 1u) << pr;
   }
-  LegAhead Ra, Rb;
+  const bool rcrows = WARM && QL_ANY(st.rho != 0.0);
+  LegAheadT<WARM> Ra, Rb;
   if (QL_PF_CH) {
 #pragma unroll
     for (int i = 0; i < 13; ++i) xo[i] = xc[i];
@@ -1316,8 +1399,8 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   }
   {
     const int p0 = first_bit(porder);
-    fetch_ahead<NL>(c, O, 0, NL == 4 ? p0 : 2 * p0, Ra, fp);
-    fetch_ahead<NL>(c, O, 0, NL == 4 ? 3 - p0 : 2 * p0 + 1, Rb, fp);
+    fetch_ahead<NL>(c, O, 0, NL == 4 ? p0 : 2 * p0, Ra, fp, rcrows);
+    fetch_ahead<NL>(c, O, 0, NL == 4 ? 3 - p0 : 2 * p0 + 1, Rb, fp, rcrows);
   }
   double rp = 0.0, dn = 0.0, dd = 1.0, stp = 0.0;
   bool bad = false;
@@ -1371,13 +1454,13 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
       const bool on_a = (st.con >> la) & 1u, on_b = (st.con >> lb) & 1u;
       if ((porder >> pr) & 1u) {       // wave-uniform
         LegOutC oa, ob;
-        leg_compute_C<NL>(P, K, cr, rc0, Ra, la, zeta, st, oa);
-        leg_compute_C<NL>(P, K, cr, rc0, Rb, lb, zeta, st, ob);
+        leg_compute_C<NL>(P, K, cr, rc0, Ra, la, zeta, st, oa, rcrows);
+        leg_compute_C<NL>(P, K, cr, rc0, Rb, lb, zeta, st, ob, rcrows);
         {     // the next pair's rows into the registers just consumed
           const int pn = next_bit(porder, pr);
           const int kq = pn >= 0 ? k : kn, pq = pn >= 0 ? pn : first_bit(porder);
-          fetch_ahead<NL>(c, O, kq, NL == 4 ? pq : 2 * pq, Ra, fp);
-          fetch_ahead<NL>(c, O, kq, NL == 4 ? 3 - pq : 2 * pq + 1, Rb, fp);
+          fetch_ahead<NL>(c, O, kq, NL == 4 ? pq : 2 * pq, Ra, fp, rcrows);
+          fetch_ahead<NL>(c, O, kq, NL == 4 ? 3 - pq : 2 * pq + 1, Rb, fp, rcrows);
         }
         if (on_a) {
 #pragma unroll
@@ -1418,19 +1501,11 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
 // ---- one interior-point iteration of one lane: the control flow of qmpc_solve_body.inc ------------------------------
 // returns true while the instance needs more iterations
 template <int NL>
-QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st) {
+QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st, bool warm = false) {
   st.it += 1;
-  pass_A<NL>(P, c, O, K, st, st.it == 1, (FootPtr)K.foot);
-  double resid;     // largest |rc|: the slack residual of every enabled row is rho * rc0_i
-  {
-    double cr[18], s0[6], rc0[6];
-    cone_rows(P, K.rot, cr);
-    initial_rows(P, cr, st.uz, s0, rc0);
-    double m = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) m = fmax(m, fabs(rc0[i]));
-    resid = st.rho * m;
-  }
+  if (warm) pass_A<NL, true>(P, c, O, K, st, st.it == 1, (FootPtr)K.foot);
+  else pass_A<NL, false>(P, c, O, K, st, st.it == 1, (FootPtr)K.foot);
+  const double resid = st.rho * st.rcmax;     // largest |rc|: the slack residual of every enabled row is rho * rc0_i
   if (st.mu <= P.mu_final && resid <= P.tol_feas && st.last_step <= P.tol_step) { st.status = QMPC_OK; return false; }
   if (st.it > P.iterations_max) { st.status = QMPC_MAX_ITER; return false; }
   double sg = P.sigma;
@@ -1439,8 +1514,12 @@ QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, cons
   else if (st.it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
   else if (st.it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
   st.target = sg * st.mu;
-  if (!pass_B<NL>(P, c, O, K, st, (FootPtr)K.foot)) { st.status = QMPC_NOT_PD; return false; }
-  pass_C<NL>(P, c, O, K, st, (FootPtr)K.foot);
+  if (!(warm ? pass_B<NL, true>(P, c, O, K, st, (FootPtr)K.foot) : pass_B<NL, false>(P, c, O, K, st, (FootPtr)K.foot))) {
+    st.status = QMPC_NOT_PD;
+    return false;
+  }
+  if (warm) pass_C<NL, true>(P, c, O, K, st, (FootPtr)K.foot);
+  else pass_C<NL, false>(P, c, O, K, st, (FootPtr)K.foot);
   if (st.bad_step) { st.status = QMPC_NOT_PD; return false; }     // the last finite iterate stays in the workspace
   st.iters = st.it;
   return true;
@@ -1448,12 +1527,18 @@ QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, cons
 
 // ---- outputs: GetInput(u, 0) (QuatMpc.cpp:264-265) and the info record -----------------------------------------------
 template <int NL>
+// traj_u: this instance's [N][3 NL] input trajectory (the next tick's warm start), or null
 QL_FN void lane_finish(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, const LaneState& st,
-                       double* forces, qmpc_info* info) {
+                       double* forces, qmpc_info* info, double* traj_u = nullptr) {
   const int N = P.N;
   const bool solved = st.status != QMPC_NAN_INPUT && st.status != QMPC_NO_CONTACT;
 #pragma unroll
   for (int j = 0; j < 3 * NL; ++j) forces[j] = (solved && ((st.con >> (j / 3)) & 1u)) ? c.W(O.U + j) : 0.0;
+  if (traj_u)
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+      for (int j = 0; j < 3 * NL; ++j)
+        traj_u[3 * NL * k + j] = (solved && ((st.con >> (j / 3)) & 1u)) ? c.W(O.U + 3 * NL * k + j) : 0.0;
   if (!info) return;
   double J = 0.0, viol = 0.0;
   if (solved) {

@@ -11,17 +11,19 @@ using namespace qmpc;
 using namespace qmpc::lane;
 
 template <int NL>
-static int solve_all(const DevParams& P, int batch, const double* rec, double* forces, qmpc_info* info) {
+static int solve_all(const DevParams& P, int batch, const double* rec, double* forces, qmpc_info* info,
+                     bool warm = false, const double* u_init = nullptr, double* traj_u = nullptr) {
   const WsOff O = make_wsoff<NL>(P.N);
   std::vector<double> ws((size_t)O.total), pl((size_t)LDim<NL>::PLDS);
   for (int b = 0; b < batch; ++b) {
     Ctx c = {ws.data(), 8, 0, pl.data(), 8, 0};
     LaneK<NL> K;
     LaneState st;
-    lane_setup<NL>(P, c, O, rec + (size_t)b * LDim<NL>::REC, K, st);
+    const size_t ts = (size_t)P.N * 3 * NL;
+    lane_setup<NL>(P, c, O, rec + (size_t)b * LDim<NL>::REC, K, st, warm, u_init ? u_init + b * ts : nullptr);
     if (st.active)
-      while (lane_iteration<NL>(P, c, O, K, st)) {}
-    lane_finish<NL>(P, c, O, K, st, forces + (size_t)b * 3 * NL, info ? info + b : nullptr);
+      while (lane_iteration<NL>(P, c, O, K, st, warm)) {}
+    lane_finish<NL>(P, c, O, K, st, forces + (size_t)b * 3 * NL, info ? info + b : nullptr, traj_u ? traj_u + b * ts : nullptr);
   }
   return 0;
 }
@@ -32,5 +34,16 @@ extern "C" int lane_host_solve(const qmpc_params* p, int batch, const double* re
   if (st != QMPC_OK) return st;
   if (p->model == QMPC_MODEL_QUAT8) return solve_all<8>(P, batch, rec, forces, info);
   if (p->model == QMPC_MODEL_QUAT) return solve_all<4>(P, batch, rec, forces, info);
+  return QMPC_BAD_ARGUMENT;
+}
+
+// warm-started solve: u_init [batch][N][12] (null: every instance starts cold, but the launch keeps per-row residuals like
+// a warm one), traj_u out (may alias u_init)
+extern "C" int lane_host_solve_warm(const qmpc_params* p, int batch, const double* rec, const double* u_init, double* forces,
+                                    qmpc_info* info, double* traj_u) {
+  DevParams P;
+  const int st = fill_dev_params(p, &P);
+  if (st != QMPC_OK) return st;
+  if (p->model == QMPC_MODEL_QUAT) return solve_all<4>(P, batch, rec, forces, info, true, u_init, traj_u);
   return QMPC_BAD_ARGUMENT;
 }

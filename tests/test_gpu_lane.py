@@ -272,3 +272,76 @@ def test_closed_loop_at_the_automatic_switch_over(pkg, lib):
     s.close()
     assert (st["status"] == 0).all() and (st["tick"] == 16).all()
     assert np.abs(st["pos_world"] - st["pos_world"][0]).max() < 1e-9      # identical robots, identical states
+
+
+@pytest.mark.parametrize("N,mu0", [(10, 0.0), (10, 1e-6), (20, 1e-6)])
+def test_lane_kernel_warm_start_matches_oracle(pkg, lib, oracle, monkeypatch, N, mu0):
+    """qmpc_solve_warm on the lane kernel: previous solutions shifted by one knot, changed contact sets, instances without
+    a previous solution in the same launch (u_init = None starts everyone cold), trajectory output -- against the oracle's
+    restatement of the same start and against the wave-per-instance kernels."""
+    B = 192
+    rec = pkg.random_go1_trot_states(B, config_id=2)
+    rec2 = rec.copy()
+    rec2["lin_vel_body"] += 0.02
+    rec2["contacts"][::7] = rec2["contacts"][::7][:, ::-1]
+    rec2["contacts"][3::11] = 1.0
+    res = {}
+    for v in (4, 0):
+        _forced(monkeypatch, v)
+        p = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
+        if mu0:
+            p.ipm_mu0 = mu0
+        s = pkg.Solver(p, B, device=0, lib=lib)
+        f0, i0, tu0 = s.solve_warm(rec, None)
+        f1, i1, tu1 = s.solve_warm(rec2, tu0)
+        s.close()
+        res[v] = (f0, i0, tu0, f1, i1, tu1)
+    po = oracle.default_params(N, 0)
+    if mu0:
+        po.ipm_mu0 = mu0
+    fo0, io0, tuo0 = oracle.solve_warm(po, rec, None)
+    fo1, io1, tuo1 = oracle.solve_warm(po, rec2, res[4][2])
+    f0, i0, tu0, f1, i1, tu1 = res[4]
+    assert (i0["status"] == 0).all() and (i1["status"] == 0).all()
+    assert np.abs(f0 - fo0).max() < 1e-6 and np.abs(tu0.reshape(B, -1) - tuo0.reshape(B, -1)).max() < 1e-5
+    assert np.abs(f1 - fo1).max() < 1e-6, np.abs(f1 - fo1).max()
+    assert np.abs(tu1.reshape(B, -1) - tuo1.reshape(B, -1)).max() < 1e-5
+    di = np.abs(i1["iterations"].astype(int) - io1["iterations"].astype(int))
+    assert (di == 0).mean() >= 0.9 and (di <= 1).mean() >= 0.95, np.bincount(di)
+    assert np.abs(f1 - res[0][3]).max() < 1e-6 and np.abs(tu1.reshape(B, -1) - res[0][5].reshape(B, -1)).max() < 1e-5
+    assert np.abs(tu1.reshape(B, N, 12)[np.repeat(rec2["contacts"] == 0, 3, axis=1)[:, None, :].repeat(N, 1)]).max() == 0.0
+    print(f"N={N} mu0={mu0}: lane warm vs oracle {np.abs(f1 - fo1).max():.2e} N, vs wave kernel {np.abs(f1 - res[0][3]).max():.2e} N; "
+          f"iterations equal on {(di == 0).mean():.3f}")
+
+
+def test_warm_started_closed_loop_with_the_lane_kernel(pkg, lib, monkeypatch):
+    """The warm-started loop (qmpc_loop_params.warm_start, low initial barrier) on the lane kernel against the wave kernels:
+    same robots, same ticks, the first tick of each call cold, a failed previous solve ignored (check_prev)."""
+    lp = pkg.default_loop_params(lib)
+    lp.warm_start = 1.0
+    rng = np.random.default_rng(23)
+    B = 3072
+    cmds = np.zeros((B, 7))
+    cmds[:, 0] = rng.uniform(-0.5, 0.5, B); cmds[:, 1] = rng.uniform(-0.2, 0.2, B); cmds[:, 2] = rng.uniform(0.26, 0.32, B)
+    cmds[:, 5] = rng.uniform(-0.5, 0.5, B); cmds[:, 6] = (rng.random(B) < 0.9).astype(float)
+    cmds[cmds[:, 6] == 0, :2] = 0.0
+    cmds[cmds[:, 6] == 0, 5] = 0.0
+    stand = cmds.copy(); stand[:, 6] = 0.0
+    st0 = pkg.loop_states(stand, lp, height=0.3, yaw=rng.uniform(-3, 3, B), lib=lib)
+    out = {}
+    for v in (4, 0):
+        _forced(monkeypatch, v)
+        p = pkg.default_params(10, pkg.MODE_CONVERGED, lib)
+        p.ipm_mu0 = 1e-6
+        p.drop_ang_vel = 0
+        s = pkg.Solver(p, B, device=0, lib=lib)
+        st = s.loop_run(st0, 6, lp)
+        st["movement_mode"] = cmds[:, 6]
+        st = s.loop_run(st, 60, lp)
+        s.close()
+        out[v] = st
+        assert (st["status"] == 0).all() and np.isfinite(st["pos_world"]).all()
+    dp = np.abs(out[4]["pos_world"] - out[0]["pos_world"]).max()
+    print(f"warm-started loop, lane vs wave, {B} robots, 66 ticks: max position difference {dp:.2e} m; "
+          f"mean iterations {out[4]['iterations'].mean():.2f} / {out[0]['iterations'].mean():.2f}")
+    assert dp < 1e-7 and abs(out[4]["iterations"].mean() - out[0]["iterations"].mean()) < 0.2

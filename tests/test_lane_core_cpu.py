@@ -92,3 +92,51 @@ def test_lane_core_outside_the_envelope_returns_finite_forces(pkg, oracle, lane)
     assert np.isfinite(f).all() and set(np.unique(info["status"])) <= {pkg.OK, pkg.MAX_ITER, pkg.NOT_PD}
     assert both.mean() > 0.4 and np.abs(f - fo)[both].max() < 1e-5
     assert abs((info["status"] == 0).mean() - (io["status"] == 0).mean()) < 0.1
+
+
+def test_lane_core_warm_start_matches_oracle(pkg, oracle):
+    """The warm-started solve (qmpc_solve_warm*, the warm-started closed loop) on the lane core: the previous solution
+    shifted by one knot, a changed contact set (a leg lands, another lifts off), an instance without a usable previous
+    solution, the low initial barrier of the loop -- against the oracle's restatement of the same start."""
+    deps = [SRC, CORE / "qmpc_lane_core.h"]
+    if not LIB.exists() or any(LIB.stat().st_mtime < d.stat().st_mtime for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                        "-o", str(LIB), str(SRC)], check=True)
+    lib = C.CDLL(str(LIB))
+    lib.lane_host_solve_warm.restype = C.c_int
+
+    def warm(p, rec, u_init):
+        B, N = rec.shape[0], p.horizon
+        f = np.zeros((B, 12)); tu = np.zeros((B, N, 12))
+        info = np.zeros(B, dtype=pkg.INFO_DTYPE)
+        ui = None if u_init is None else np.ascontiguousarray(u_init)
+        rc = lib.lane_host_solve_warm(C.byref(p), B, np.ascontiguousarray(rec).ctypes.data_as(C.c_void_p),
+                                      None if ui is None else ui.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p),
+                                      info.ctypes.data_as(C.c_void_p), tu.ctypes.data_as(C.c_void_p))
+        assert rc == 0, rc
+        return f, info, tu
+
+    for N, mu0 in ((10, 0.0), (10, 1e-6), (20, 1e-6)):
+        p = oracle.default_params(N, 0)
+        if mu0:
+            p.ipm_mu0 = mu0
+        rec = pkg.random_go1_trot_states(96, config_id=2)
+        # cold launch through the warm entry: the same answers as the plain solve, and the trajectory to start from
+        f0, i0, tu = warm(p, rec, None)
+        fo0, io0, tuo = oracle.solve_warm(p, rec, None)
+        assert np.array_equal(i0["status"], io0["status"]) and np.abs(f0 - fo0).max() < 1e-6
+        assert np.abs(tu - tuo.reshape(tu.shape)).max() < 1e-6
+        # next tick: slightly different states, a changed contact set on some instances
+        rec2 = rec.copy()
+        rec2["lin_vel_body"] += 0.02
+        rec2["contacts"][::7] = rec2["contacts"][::7][:, ::-1]          # stance pair swapped: two legs land, two lift off
+        rec2["contacts"][3::11] = 1.0                                     # all four down
+        f1, i1, tu1 = warm(p, rec2, tuo.reshape(tu.shape))
+        fo1, io1, tuo1 = oracle.solve_warm(p, rec2, tuo)
+        assert np.array_equal(i1["status"], io1["status"]) and (i1["status"] == 0).all()
+        assert np.abs(f1 - fo1).max() < 1e-6, np.abs(f1 - fo1).max()
+        di = np.abs(i1["iterations"].astype(int) - io1["iterations"].astype(int))
+        assert (di == 0).mean() >= 0.9 and (di <= 1).mean() >= 0.95, np.bincount(di)
+        assert np.abs(tu1 - tuo1.reshape(tu1.shape)).max() < 1e-5
+        print(f"N={N} mu0={mu0}: warm iterations {i1['iterations'].mean():.2f} (cold {i0['iterations'].mean():.2f}), "
+              f"max force difference to the oracle {np.abs(f1 - fo1).max():.2e} N, iteration counts equal on {(di == 0).mean():.3f}")
