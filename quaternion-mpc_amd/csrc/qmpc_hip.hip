@@ -346,7 +346,7 @@ static bool use_global_gains(const qmpc_handle* h, int32_t batch) { return pick_
 // wave-per-instance kernels.
 static bool use_lane(const qmpc_handle* h, int32_t batch, const double* d_tu, const double* d_tx) {
   (void)d_tu;
-  if (h->params.mode != QMPC_MODE_CONVERGED || h->params.model == QMPC_MODEL_CONVEX || d_tx) return false;
+  if (h->params.mode != QMPC_MODE_CONVERGED || d_tx) return false;
   if (h->variant == 4) return true;
   return h->variant == 0 && batch >= h->lane_min_batch;
 }
@@ -366,7 +366,7 @@ static qmpc_status ensure_lane_buffers(qmpc_handle* h) {
 // not wanted); they may be the same buffer.  check_prev: d_info still holds the records of the previous solves
 static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces, qmpc_info* d_info,
                                hipStream_t s, const double* d_u_init = nullptr, double* d_traj_u = nullptr, int check_prev = 0) {
-  const int nl = model_nl(h->params.model);
+  const int nl = h->params.model == QMPC_MODEL_CONVEX ? -4 : model_nl(h->params.model);     // -4: ConvexMpc's model (qmpc_lane.hip)
   const qmpc_status es = ensure_lane_buffers(h);
   if (es != QMPC_OK) return es;
   HIP_TRY(qmpc_lane_launch(nl, h->lane_pslot, (int)batch, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, h->d_lane_ws, h->lane_slots,
@@ -946,7 +946,7 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
     else
       hipLaunchKernelGGL(qmpc_loop_front_kernel, dim3(blocks), dim3(64), 0, s, LP, d_states, h->d_in, h->d_loop_row, (int)batch);
     HIP_TRY(hipGetLastError());
-    if (warm && !convex && use_lane(h, batch, nullptr, nullptr)) {
+    if (warm && use_lane(h, batch, nullptr, nullptr)) {
       const qmpc_status st = launch_lane(h, batch, h->d_in, h->d_forces, h->d_info, s, first ? nullptr : h->d_traj_u, h->d_traj_u,
                                          /*check_prev=*/1);
       if (st != QMPC_OK) return st;

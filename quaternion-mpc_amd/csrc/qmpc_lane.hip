@@ -68,7 +68,7 @@ __device__ __forceinline__ Ctx pass_ctx(const PassArgs& a) {
   Ctx c = {ws, 8u * kLaneWave, a.lane8, (QL_LDS_AS double*)ql_lds, 8u * kLaneWave, a.lane8};
   return c;
 }
-template <int NL>
+template <int NL, int MD>
 __device__ __noinline__ void call_setup(PassArgs a, unsigned long long rec, unsigned long long u_prev, QL_PRIV_AS LaneK<NL>* Kp,
                                         QL_PRIV_AS LaneState* sp) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
@@ -76,12 +76,12 @@ __device__ __noinline__ void call_setup(PassArgs a, unsigned long long rec, unsi
   const WsOff O = make_wsoff<NL>(P.N);
   LaneK<NL> K;
   LaneState st;
-  lane_setup<NL>(P, c, O, reinterpret_cast<const double*>(rec), K, st, __builtin_amdgcn_readfirstlane(a.warm) != 0,
+  lane_setup<NL, MD>(P, c, O, reinterpret_cast<const double*>(rec), K, st, __builtin_amdgcn_readfirstlane(a.warm) != 0,
                  reinterpret_cast<const double*>(u_prev));
   priv_store(Kp, K);
   priv_store(sp, st);
 }
-template <int NL, bool WARM>
+template <int NL, bool WARM, int MD>
 __device__ __noinline__ void call_A(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS LaneState* sp) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
@@ -91,10 +91,10 @@ __device__ __noinline__ void call_A(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
   LaneState st;
   priv_load(st, (QL_PRIV_AS const LaneState*)sp);
   st.it += 1;
-  pass_A<NL, WARM>(P, c, O, K, st, st.it == 1, (FootPtr)Kp->foot);
+  pass_A<NL, WARM, MD>(P, c, O, K, st, st.it == 1, (FootPtr)Kp->foot);
   priv_store(sp, st);
 }
-template <int NL, bool WARM>
+template <int NL, bool WARM, int MD>
 __device__ __noinline__ bool call_B(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS LaneState* sp) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
@@ -103,13 +103,13 @@ __device__ __noinline__ bool call_B(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
   priv_load(K, Kp);
   LaneState st;
   priv_load(st, (QL_PRIV_AS const LaneState*)sp);
-  const bool ok = pass_B<NL, WARM>(P, c, O, K, st, (FootPtr)Kp->foot);
+  const bool ok = pass_B<NL, WARM, MD>(P, c, O, K, st, (FootPtr)Kp->foot);
 #if defined(QL_PROFILE)
   priv_store(sp, st);
 #endif
   return ok;
 }
-template <int NL, bool WARM>
+template <int NL, bool WARM, int MD>
 __device__ __noinline__ void call_C(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS LaneState* sp) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
@@ -118,11 +118,11 @@ __device__ __noinline__ void call_C(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
   priv_load(K, Kp);
   LaneState st;
   priv_load(st, (QL_PRIV_AS const LaneState*)sp);
-  pass_C<NL, WARM>(P, c, O, K, st, (FootPtr)Kp->foot);
+  pass_C<NL, WARM, MD>(P, c, O, K, st, (FootPtr)Kp->foot);
   if (!st.bad_step) st.iters = st.it;
   priv_store(sp, st);
 }
-template <int NL>
+template <int NL, int MD>
 __device__ __noinline__ void call_finish(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp,
                                          unsigned long long forces, unsigned long long info, unsigned long long traj_u) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
@@ -132,11 +132,11 @@ __device__ __noinline__ void call_finish(PassArgs a, QL_PRIV_AS const LaneK<NL>*
   priv_load(K, Kp);
   LaneState st;
   priv_load(st, sp);
-  lane_finish<NL>(P, c, O, K, st, reinterpret_cast<double*>(forces), reinterpret_cast<qmpc_info*>(info),
+  lane_finish<NL, MD>(P, c, O, K, st, reinterpret_cast<double*>(forces), reinterpret_cast<qmpc_info*>(info),
                   reinterpret_cast<double*>(traj_u));
 }
 
-template <int NL>
+template <int NL, int MD = MD_QUAT>
 __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const double* __restrict__ in,
                                                               double* __restrict__ forces, qmpc_info* __restrict__ info,
                                                               int batch, double* __restrict__ ws, unsigned slots,
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
       // the previous solution of this instance is usable unless its last solve failed (check_prev: info[b] still holds
       // that solve's record -- the rule of qmpc_solve_warm_kernel)
       const bool usable = u_init && (!check_prev || info[b].status == QMPC_OK || info[b].status == QMPC_MAX_ITER);
-      call_setup<NL>(a, reinterpret_cast<unsigned long long>(in + (size_t)b * D::REC),
+      call_setup<NL, MD>(a, reinterpret_cast<unsigned long long>(in + (size_t)b * D::REC),
                      usable ? reinterpret_cast<unsigned long long>(u_init + (size_t)b * tstride) : 0ull, Kp, sp);
       active = st.active;
     }
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
     while (__any(active)) {
       if (active) {
         // one interior-point iteration (the control flow of lane_iteration in qmpc_lane_core.h)
-        if (warm) call_A<NL, true>(a, Kp, sp); else call_A<NL, false>(a, Kp, sp);
+        if (warm) call_A<NL, true, MD>(a, Kp, sp); else call_A<NL, false, MD>(a, Kp, sp);
         const double resid = st.rho * st.rcmax;
         if (st.mu <= P.mu_final && resid <= P.tol_feas && st.last_step <= P.tol_step) { st.status = QMPC_OK; active = false; }
         else if (st.it > P.iterations_max) { st.status = QMPC_MAX_ITER; active = false; }
@@ -188,9 +188,9 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
           else if (st.it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
           else if (st.it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
           st.target = sg * st.mu;
-          if (!(warm ? call_B<NL, true>(a, Kp, sp) : call_B<NL, false>(a, Kp, sp))) { st.status = QMPC_NOT_PD; active = false; }
+          if (!(warm ? call_B<NL, true, MD>(a, Kp, sp) : call_B<NL, false, MD>(a, Kp, sp))) { st.status = QMPC_NOT_PD; active = false; }
           else {
-            if (warm) call_C<NL, true>(a, Kp, sp); else call_C<NL, false>(a, Kp, sp);
+            if (warm) call_C<NL, true, MD>(a, Kp, sp); else call_C<NL, false, MD>(a, Kp, sp);
             if (st.bad_step) { st.status = QMPC_NOT_PD; active = false; }     // a non-finite trial step is not applied
           }
         }
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
 #endif
     }
     if (valid)
-      call_finish<NL>(a, Kp, sp, reinterpret_cast<unsigned long long>(forces + (size_t)b * D::NU),
+      call_finish<NL, MD>(a, Kp, sp, reinterpret_cast<unsigned long long>(forces + (size_t)b * D::NU),
                       info ? reinterpret_cast<unsigned long long>(info + b) : 0ull,
                       traj_u ? reinterpret_cast<unsigned long long>(traj_u + (size_t)b * tstride) : 0ull);
 #if defined(QL_PROFILE)
@@ -220,20 +220,20 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
 // the global counters once per key it holds (a batch has a handful of distinct masks: per-thread global atomics on three
 // addresses took 0.65 ms per launch).
 template <int NL>
-__device__ __forceinline__ unsigned stance_key(const double* __restrict__ in, int b) {
-  const double* rec = in + (size_t)b * LDim<NL>::REC + LDim<NL>::R_CON;
+__device__ __forceinline__ unsigned stance_key(const double* __restrict__ in, int b, int con_off) {
+  const double* rec = in + (size_t)b * LDim<NL>::REC + con_off;
   unsigned key = 0;
 #pragma unroll
   for (int l = 0; l < NL; ++l) key |= (rec[l] != 0.0) ? (1u << l) : 0u;
   return key;
 }
 template <int NL>
-__global__ __launch_bounds__(256) void qmpc_lane_sort_count(const double* __restrict__ in, int batch, int* __restrict__ scratch) {
+__global__ __launch_bounds__(256) void qmpc_lane_sort_count(const double* __restrict__ in, int batch, int* __restrict__ scratch, int con_off) {
   __shared__ int hist[256];
   hist[threadIdx.x] = 0;
   __syncthreads();
   const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b < batch) atomicAdd(&hist[stance_key<NL>(in, b)], 1);
+  if (b < batch) atomicAdd(&hist[stance_key<NL>(in, b, con_off)], 1);
   __syncthreads();
   if (hist[threadIdx.x]) atomicAdd(&scratch[threadIdx.x], hist[threadIdx.x]);
 }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64) void qmpc_lane_sort_scan(int* __restrict__ scra
   }
 }
 template <int NL>
-__global__ __launch_bounds__(256) void qmpc_lane_sort_scatter(const double* __restrict__ in, int batch, int* __restrict__ scratch) {
+__global__ __launch_bounds__(256) void qmpc_lane_sort_scatter(const double* __restrict__ in, int batch, int* __restrict__ scratch, int con_off) {
   __shared__ int hist[256], base[256];
   hist[threadIdx.x] = 0;
   __syncthreads();
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void qmpc_lane_sort_scatter(const double* __re
   unsigned key = 0;
   int rank = 0;
   if (b < batch) {
-    key = stance_key<NL>(in, b);
+    key = stance_key<NL>(in, b, con_off);
     rank = atomicAdd(&hist[key], 1);
   }
   __syncthreads();
@@ -291,6 +291,10 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
                                                                    qmpc_info* info, double* ws, unsigned slots, int* scratch,
                                                                    int upload_params, const double* u_init, double* traj_u,
                                                                    int check_prev) {
+  // nl: 4 (QuatMpc), 8 (the 8-contact-point model) or -4 (ConvexMpc's model: four points, world-frame forces)
+  const bool convex = nl == -4;
+  if (convex) nl = 4;
+  const int con_off = convex ? 24 : (nl == 8 ? LDim<8>::R_CON : LDim<4>::R_CON);      // contacts[] inside a record
   if (dev_params_size != sizeof(DevParams) || (nl != 4 && nl != 8) || slots % kLaneWave || pslot < 0 || pslot >= kParamSlots)
     return hipErrorInvalidValue;
   DevParams P;
@@ -307,13 +311,13 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
     if (e != hipSuccess) return e;
     const unsigned blocks = (unsigned)((batch + 255) / 256);
     if (nl == 8) {
-      hipLaunchKernelGGL(qmpc_lane_sort_count<8>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch);
+      hipLaunchKernelGGL(qmpc_lane_sort_count<8>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch, con_off);
       hipLaunchKernelGGL(qmpc_lane_sort_scan, dim3(1), dim3(64), 0, s, scratch);
-      hipLaunchKernelGGL(qmpc_lane_sort_scatter<8>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch);
+      hipLaunchKernelGGL(qmpc_lane_sort_scatter<8>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch, con_off);
     } else {
-      hipLaunchKernelGGL(qmpc_lane_sort_count<4>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch);
+      hipLaunchKernelGGL(qmpc_lane_sort_count<4>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch, con_off);
       hipLaunchKernelGGL(qmpc_lane_sort_scan, dim3(1), dim3(64), 0, s, scratch);
-      hipLaunchKernelGGL(qmpc_lane_sort_scatter<4>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch);
+      hipLaunchKernelGGL(qmpc_lane_sort_scatter<4>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch, con_off);
     }
     perm = scratch + 512;
   }
@@ -334,6 +338,9 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
   if (nl == 8)
     hipLaunchKernelGGL(qmpc_lane_kernel<8>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm, prof,
                        u_init, traj_u, check_prev);
+  else if (convex)
+    hipLaunchKernelGGL((qmpc_lane_kernel<4, MD_CONVEX>), dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes,
+                       perm, prof, u_init, traj_u, check_prev);
   else
     hipLaunchKernelGGL(qmpc_lane_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm, prof,
                        u_init, traj_u, check_prev);

@@ -308,6 +308,106 @@ QL_FN void srbd_step_fw(const DevParams& P, const double gb[3], const double* x,
     xn[3 + r] = x[3 + r] + P.h * (0.5 * (G[3 * r] * wm[0] + G[3 * r + 1] * wm[1] + G[3 * r + 2] * wm[2]));
 }
 
+// ---- ConvexMpc's model on the same core (MD = 1; ConvexMpc.cpp:81-198, AltroUtils.cpp:224-359) ----------------------------
+// State in the workspace as in the record: [rpy, pos, ang_vel_world, lin_vel_world] (12 of the 13 rows of a knot), forces in
+// the WORLD frame.  Inside the recursion the blocks are ordered like the quaternion model's error state, [p, phi, v, w],
+// and the transition has the same shape: Abar = [[I,0,hI,0],[0,A1,0,A3],[0,0,I,0],[0,0,0,I]] with
+//   A1 = I + h [0 0 j0; 0 0 j1; 0 0 0],   A3 = h [c s hh j0; -s c hh j1; 0 0 1]      (c, s, j at the midpoint yaw),
+// and Bbar = M Wr_k with the wrench (F, t') where t' = Iw(yaw_m)^-1 sum r x u (the inertia at the MIDPOINT yaw goes into
+// the per-point map Bw0 = Iw_m^-1 [r]x, knot by knot), M's attitude block Wt = h hh Rz_m' Iw(yaw)^-1 Iw(yaw_m).
+enum { MD_QUAT = 0, MD_CONVEX = 1 };
+enum { CVR_YAW = 0, CVR_RATE, CVR_POS, CVR_VX = 5, CVR_VY = 6 };      // refp of the convex model (qmpc_device.h CR_*)
+// Iw(yaw)^-1 = Rz diag(1/I) Rz': W = {w00, w01, w11, wzz}
+QL_FN void cv_winv(const DevParams& P, double c, double s, double W[4]) {
+  const double a = P.Iinv[0], b = P.Iinv[4];
+  W[0] = c * c * a + s * s * b;
+  W[1] = c * s * (a - b);
+  W[2] = s * s * a + c * c * b;
+  W[3] = P.Iinv[8];
+}
+// B = Iw^-1 [r]x
+QL_FN void cv_leg_bw0(const double W[4], const double r[3], double B[9]) {
+  const double S[9] = {0.0, -r[2], r[1], r[2], 0.0, -r[0], -r[1], r[0], 0.0};
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    B[b] = W[0] * S[b] + W[1] * S[3 + b];
+    B[3 + b] = W[1] * S[b] + W[2] * S[3 + b];
+    B[6 + b] = W[3] * S[6 + b];
+  }
+}
+QL_FN void cv_cross_acc(const double r[3], const double u[3], double t[3]) {      // t += r x u
+  t[0] += r[1] * u[2] - r[2] * u[1];
+  t[1] += r[2] * u[0] - r[0] * u[2];
+  t[2] += r[0] * u[1] - r[1] * u[0];
+}
+// explicit midpoint of ct_srb_dynamics (AltroUtils.cpp:9-22 on :224-293) given the force sum F and the torque sum tau
+QL_FN void cv_step_fw(const DevParams& P, const double* x, const double F[3], const double tau[3], double* xn) {
+  double s0, c0, W[4];
+  sincos(x[2], &s0, &c0);
+  cv_winv(P, c0, s0, W);
+  const double vd[3] = {F[0] * P.inv_mass, F[1] * P.inv_mass, F[2] * P.inv_mass - 9.81};
+  const double wd0[3] = {W[0] * tau[0] + W[1] * tau[1], W[1] * tau[0] + W[2] * tau[1], W[3] * tau[2]};
+  const double yawm = x[2] + P.hh * x[8];
+  const double wm[3] = {x[6] + P.hh * wd0[0], x[7] + P.hh * wd0[1], x[8] + P.hh * wd0[2]};
+  double sm_, cm_;
+  sincos(yawm, &sm_, &cm_);
+  cv_winv(P, cm_, sm_, W);
+  const double wdm[3] = {W[0] * tau[0] + W[1] * tau[1], W[1] * tau[0] + W[2] * tau[1], W[3] * tau[2]};
+  xn[0] = x[0] + P.h * (cm_ * wm[0] + sm_ * wm[1]);
+  xn[1] = x[1] + P.h * (-sm_ * wm[0] + cm_ * wm[1]);
+  xn[2] = x[2] + P.h * wm[2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    xn[3 + a] = x[3 + a] + P.h * (x[9 + a] + P.hh * vd[a]);
+    xn[6 + a] = x[6 + a] + P.h * wdm[a];
+    xn[9 + a] = x[9 + a] + P.h * vd[a];
+  }
+  xn[12] = 0.0;
+}
+// reference state of knot k (ConvexMpc.cpp:95-106)
+QL_FN void cv_xref_at(const DevParams& P, const double rp[13], int k, double* xr) {
+  const double h_ms = P.h_ref * 1000.0;
+#pragma unroll
+  for (int i = 0; i < 13; ++i) xr[i] = 0.0;
+  xr[2] = rp[CVR_YAW] + rp[CVR_RATE] * h_ms / 1000.0 * k;
+  xr[3] = rp[CVR_POS]; xr[4] = rp[CVR_POS + 1]; xr[5] = rp[CVR_POS + 2];
+  xr[8] = rp[CVR_RATE];
+  xr[9] = rp[CVR_VX]; xr[10] = rp[CVR_VY];
+}
+// Iw(yaw_m)^-1 of knot state x (the per-point map of the linearisation at that knot)
+QL_FN void cv_winv_mid(const DevParams& P, double yaw, double wz, double W[4]) {
+  double sm_, cm_;
+  sincos(yaw + P.hh * wz, &sm_, &cm_);
+  cv_winv(P, cm_, sm_, W);
+}
+// A1, A3, Wt of a knot from its state and torque sum (AltroUtils.cpp:295-359 through the midpoint rule :78-110)
+QL_FN void cv_expansion(const DevParams& P, const double* x, const double tau[3], double A1[9], double A3[9], double Wt[9]) {
+  double s0, c0, W0[4], Wm[4];
+  sincos(x[2], &s0, &c0);
+  cv_winv(P, c0, s0, W0);
+  const double wm0 = x[6] + P.hh * (W0[0] * tau[0] + W0[1] * tau[1]);
+  const double wm1 = x[7] + P.hh * (W0[1] * tau[0] + W0[2] * tau[1]);
+  double sm_, cm_;
+  sincos(x[2] + P.hh * x[8], &sm_, &cm_);
+  cv_winv(P, cm_, sm_, Wm);
+  const double j0 = wm1 * cm_ - wm0 * sm_, j1 = -wm0 * cm_ - wm1 * sm_;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { A1[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+  A1[2] = P.h * j0; A1[5] = P.h * j1;
+  A3[0] = P.h * cm_;  A3[1] = P.h * sm_; A3[2] = P.h * P.hh * j0;
+  A3[3] = -P.h * sm_; A3[4] = P.h * cm_; A3[5] = P.h * P.hh * j1;
+  A3[6] = 0.0; A3[7] = 0.0; A3[8] = P.h;
+  // M1 = Rz_m' Iw(yaw)^-1 (upper-left 2 x 2; the rest is 1 / Izz),  Iw(yaw_m) = Rz_m diag(I) Rz_m'
+  const double m00 = cm_ * W0[0] + sm_ * W0[1], m01 = cm_ * W0[1] + sm_ * W0[2];
+  const double m10 = -sm_ * W0[0] + cm_ * W0[1], m11 = -sm_ * W0[1] + cm_ * W0[2];
+  const double ixx = 1.0 / P.Iinv[0], iyy = 1.0 / P.Iinv[4];
+  const double i00 = cm_ * cm_ * ixx + sm_ * sm_ * iyy, i01 = cm_ * sm_ * (ixx - iyy), i11 = sm_ * sm_ * ixx + cm_ * cm_ * iyy;
+  const double hhh = P.h * P.hh;
+  Wt[0] = hhh * (m00 * i00 + m01 * i01); Wt[1] = hhh * (m00 * i01 + m01 * i11); Wt[2] = 0.0;
+  Wt[3] = hhh * (m10 * i00 + m11 * i01); Wt[4] = hhh * (m10 * i01 + m11 * i11); Wt[5] = 0.0;
+  Wt[6] = 0.0; Wt[7] = 0.0; Wt[8] = hhh;
+}
+
 // reference state of knot k (QuatMpc.cpp:148-176) from refp = pos(3) vel(3) acc(3) quat_d(4)
 QL_FN void xref_at(const DevParams& P, const double rp[13], int k, double* xr) {
   const double t = (double)k * P.h_ref;
@@ -535,7 +635,7 @@ QL_FN int next_bit(unsigned m, int l) {
 // knot (O.RC) for EVERY lane of the launch.  u_prev: this instance's previous inputs [N][3 NL] or null (cold start of
 // this instance).  The warm guess is the rule of qmpc_solve_body.inc: the previous solution shifted by one knot (the last
 // knot repeats), swing points pinned to 0, a component that was 0 (the point has just landed) starts from u_ref.
-template <int NL>
+template <int NL, int MD = MD_QUAT>
 QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const double* rec, LaneK<NL>& K, LaneState& st,
                       bool warm_launch = false, const double* u_prev = nullptr) {
   typedef LDim<NL> D;
@@ -546,13 +646,31 @@ QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const do
   for (int i = 0; i < D::REC; ++i) { raw[i] = rec[i]; bad = bad || !isfinite(raw[i]); }
   st.con = 0; st.nc = 0;
 #pragma unroll
-  for (int l = 0; l < NL; ++l) if (raw[D::R_CON + l] != 0.0) { st.con |= 1u << l; st.nc++; }
+  for (int l = 0; l < NL; ++l) if (raw[(MD == MD_CONVEX ? 24 : D::R_CON) + l] != 0.0) { st.con |= 1u << l; st.nc++; }
   st.status = bad ? QMPC_NAN_INPUT : (st.nc == 0 ? QMPC_NO_CONTACT : QMPC_OK);
   st.iters = 0; st.it = 0;
   st.active = st.status == QMPC_OK;
   st.rho = 1.0; st.mu = 0.0; st.target = 0.0; st.last_ap = 0.0; st.last_ad = 0.0; st.last_step = 1e300;
   st.ap = 1.0; st.ad = 1.0; st.uz = 0.0; st.bad_step = 0; st.rcmax = 0.0;
   if (!st.active) return;
+  if constexpr (MD == MD_CONVEX) {
+    // qmpc_convex_input: euler 0..2, pos 3..5, ang_vel 6..8, lin_vel 9..11, foot 12..23, contacts 24..27, pos_d 28..30,
+    // lin_vel_d 31..33, yaw_rate_d 34.  World-frame forces: the pyramid acts on them directly (rot = I), gravity is
+    // (0,0,-9.81), no centre-of-mass torque
+#pragma unroll
+    for (int i = 0; i < 9; ++i) K.rot[i] = (i % 4 == 0) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < 3 * NL; ++i) K.foot[i] = raw[12 + i];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) K.wd0[a] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) K.refp[i] = 0.0;
+    K.refp[CVR_YAW] = raw[2]; K.refp[CVR_RATE] = raw[34];
+    K.refp[CVR_POS] = raw[28]; K.refp[CVR_POS + 1] = raw[29]; K.refp[CVR_POS + 2] = raw[30];
+    K.refp[CVR_VX] = raw[31]; K.refp[CVR_VY] = raw[32];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) c.W(O.X + i) = (i < 12) ? raw[i] : 0.0;      // x_init, ConvexMpc.cpp:156-167
+  } else {
 #pragma unroll
   for (int i = 0; i < 9; ++i) K.rot[i] = raw[4 + i];
 #pragma unroll
@@ -581,6 +699,7 @@ QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const do
     }
 #pragma unroll
     for (int i = 0; i < 13; ++i) c.W(O.X + i) = x0[i];
+  }
   }
   // u_ref (QuatMpc.cpp:118-125): weight shared by the stance points; cone values there are the same at every knot
   st.uz = 1.0 * P.mass * 9.81 / (double)st.nc;
@@ -659,7 +778,7 @@ QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const do
 // the increment; rc <- (1 - alpha_p) rc, exactly 0 after a full step.
 // WARM: a warm-started launch -- the inputs of the first iteration are read (they are not u_ref), and the rows' initial
 // slack residuals come from the workspace while any lane still carries a residual (rho != 0)
-template <int NL, bool WARM = false>
+template <int NL, bool WARM = false, int MD = MD_QUAT>
 QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st, bool first, FootPtr fp) {
   constexpr bool warm = WARM;
   const int N = P.N;
@@ -739,6 +858,11 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
           c.W(O.U + 3 * NL * k + 3 * l + a) = u[a];
         }
       }
+      if constexpr (MD == MD_CONVEX) {      // wd collects the torque sum
+#pragma unroll
+        for (int a = 0; a < 3; ++a) F[a] += u[a];
+        cv_cross_acc(r, u, wd);
+      } else {
       double B[9];
       leg_bw0(P, r, B);
 #pragma unroll
@@ -747,8 +871,10 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
         wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
       }
       }
+      }
     }
-    srbd_step_fw(P, gb, x, F, wd, xn);
+    if constexpr (MD == MD_CONVEX) cv_step_fw(P, x, F, wd, xn);
+    else srbd_step_fw(P, gb, x, F, wd, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) { x[i] = xn[i]; c.W(O.X + 13 * (k + 1) + i) = xn[i]; }
   }
@@ -771,12 +897,25 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
 //   6. stage cost of knot k (the state is re-read: keeping its expansion live through 3-5 would cost 18 registers)
 // The order keeps at most P (90) + Y (78) + Z, S6 (42) + a dozen temporaries live -- the 512-register budget of a
 // wave that owns its SIMD.  Returns false when S6 loses positive definiteness (QMPC_NOT_PD).
-template <int NL>
+template <int NL, int MD = MD_QUAT>
 QL_FN void cost_expansion(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, int k, double lx[12],
                           double lxx[6]) {
   double x[13];
 #pragma unroll
   for (int i = 0; i < 13; ++i) x[i] = c.W(O.X + 13 * k + i);
+  if constexpr (MD == MD_CONVEX) {       // quadratic in the state; blocks reordered [p, phi, v, w]
+    double xr[13];
+    cv_xref_at(P, K.refp, k, xr);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lx[a] = P.Q[3 + a] * (x[3 + a] - xr[3 + a]);
+      lx[3 + a] = P.Q[a] * (x[a] - xr[a]);
+      lx[6 + a] = P.Q[9 + a] * (x[9 + a] - xr[9 + a]);
+      lx[9 + a] = P.Q[6 + a] * (x[6 + a] - xr[6 + a]);
+    }
+    lxx[0] = P.Q[0]; lxx[1] = 0.0; lxx[2] = 0.0; lxx[3] = P.Q[1]; lxx[4] = 0.0; lxx[5] = P.Q[2];
+    return;
+  }
   double xr[13];
   xref_at(P, K.refp, k, xr);
   double lxf[13];
@@ -809,11 +948,13 @@ QL_FN void cost_expansion(const DevParams& P, const Ctx& c, const WsOff& O, cons
     }
 }
 
-template <int NL, bool WARM = false>
+template <int NL, bool WARM = false, int MD = MD_QUAT>
 QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const LaneK<NL>& K, LaneState& st, FootPtr fp) {
   Ctx c = c_in;
   typedef LDim<NL> D;
   const int N = P.N;
+  // where the position / velocity / angular-velocity weights sit in P.Q (the two models order their states differently)
+  constexpr int QPo = (MD == MD_CONVEX) ? 3 : 0, QVo = (MD == MD_CONVEX) ? 9 : 7, QWo = (MD == MD_CONVEX) ? 6 : 10;
   double pv[12];      // cost-to-go  1/2 dx'P dx + p'dx: P in the lane-private rows c.PL(), p in registers
   double cr[18], rc0[6];
   if (!QL_CR_PER_KNOT) {
@@ -829,15 +970,15 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
   const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
   {
     double lx[12], lxx[6];
-    cost_expansion<NL>(P, c, O, K, N, lx, lxx);
+    cost_expansion<NL, MD>(P, c, O, K, N, lx, lxx);
 #pragma unroll
     for (int i = 0; i < 78; ++i) c.PL(i) = 0.0;
     int q = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      c.PL(SI(a, a)) = P.Q[a];
-      c.PL(SI(6 + a, 6 + a)) = P.Q[7 + a];
-      c.PL(SI(9 + a, 9 + a)) = P.Q[10 + a];
+      c.PL(SI(a, a)) = P.Q[QPo + a];
+      c.PL(SI(6 + a, 6 + a)) = P.Q[QVo + a];
+      c.PL(SI(9 + a, 9 + a)) = P.Q[QWo + a];
 #pragma unroll
       for (int b = a; b < 3; ++b) c.PL(SI(3 + a, 3 + b)) = lxx[q++];
     }
@@ -858,6 +999,8 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
 #pragma unroll
     for (int a = 0; a < 3; ++a) wd[a] = K.wd0[a];
     const int kn = (k > 0) ? k - 1 : 0;
+    double Wk[4] = {0, 0, 0, 0};       // ConvexMpc's model: Iw^-1 at this knot's midpoint yaw
+    if constexpr (MD == MD_CONVEX) cv_winv_mid(P, c.W(O.X + 13 * k + 2), c.W(O.X + 13 * k + 8), Wk);
     if (QL_CR_PER_KNOT) {      // rebuilt per knot: 24 registers that need not live through the factorisations
       double s0[6];
       cone_rows(P, K.rot, cr);
@@ -888,9 +1031,14 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
       }
       if ((st.con >> l) & 1u) {
       double B[9];
+      if constexpr (MD == MD_CONVEX) {
+        cv_leg_bw0(Wk, r, B);          // the linearisation's per-point map; wd collects the raw torque sum for the expansion
+        cv_cross_acc(r, u, wd);
+      } else {
       leg_bw0(P, r, B);
 #pragma unroll
       for (int a = 0; a < 3; ++a) wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
+      }
       LegBlk lb;
       leg_block(P, cr, rcl, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
       // V = [T ; Bw0 T] (6 x 3), Vt = V L^-T (columns), G += sum_j id_j vt_j vt_j', r6 += sum_j vt_j id_j y_j, y = L^-1 gq
@@ -921,7 +1069,12 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     QL_TICK(st, LP_B_LEGS);
     // ---- 2. dynamics expansion (AltroUtils.cpp:78-110,153-168 in compact form) ----
     double A1[9], A3[9], Wt[9];
-    {
+    if constexpr (MD == MD_CONVEX) {
+      double x[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) x[i] = c.W(O.X + 13 * k + i);
+      cv_expansion(P, x, wd, A1, A3, Wt);
+    } else {
       double x[13], xn[4];
 #pragma unroll
       for (int i = 3; i < 13; ++i) x[i] = c.W(O.X + 13 * k + i);
@@ -1269,13 +1422,13 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     // ---- 6. stage cost of knot k ----
     {
       double lx[12], lxx[6];
-      cost_expansion<NL>(P, c, O, K, k, lx, lxx);
+      cost_expansion<NL, MD>(P, c, O, K, k, lx, lxx);
       int q = 0;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        c.PL(SI(a, a)) += P.Q[a];
-        c.PL(SI(6 + a, 6 + a)) += P.Q[7 + a];
-        c.PL(SI(9 + a, 9 + a)) += P.Q[10 + a];
+        c.PL(SI(a, a)) += P.Q[QPo + a];
+        c.PL(SI(6 + a, 6 + a)) += P.Q[QVo + a];
+        c.PL(SI(9 + a, 9 + a)) += P.Q[QWo + a];
 #pragma unroll
         for (int b = a; b < 3; ++b) c.PL(SI(3 + a, 3 + b)) += lxx[q++];
       }
@@ -1300,18 +1453,24 @@ constexpr int pair_leg(int pr, int j) { return NL == 4 ? (j == 0 ? pr : 3 - pr) 
 // that is not in stance)
 struct LegOutC {
   double du[3], u[3], B[9];
+  double r[3];                // the point's position (ConvexMpc's model: the rollout wants the raw torque r x u)
   double rp, dn, dd, stp;     // largest -ds_i / s_i; the row with the largest -dlam_i / lam_i as numerator / denominator
   bool bad;                   // a component of du is not finite (fmax / fmin drop NaNs silently)
 };
-template <int NL, class RT>
+template <int NL, int MD = MD_QUAT, class RT>
 QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr[18], const double rc0_[6], const RT& R,
-                         int l, const double zeta[6], const LaneState& st, LegOutC& o, bool rcrows) {
+                         int l, const double zeta[6], const LaneState& st, LegOutC& o, bool rcrows, const double* Wk = nullptr) {
   double rc0[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) rc0[i] = rcrows ? R.rc[i] : rc0_[i];
   double u[3], r[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) { u[a] = R.u[a]; r[a] = kFootAhead ? R.foot[a] : K.foot[3 * l + a]; }
+  if constexpr (MD == MD_CONVEX) {
+    cv_leg_bw0(Wk, r, o.B);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) o.r[a] = r[a];
+  } else
   leg_bw0(P, r, o.B);
   const double* B = o.B;
   double sv[6], lv[6];
@@ -1364,7 +1523,7 @@ QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr
 }
 
 // ---- pass C: closed-loop trial rollout (alpha = 1) + slack / multiplier directions + step lengths ----------------------
-template <int NL, bool WARM = false>
+template <int NL, bool WARM = false, int MD = MD_QUAT>
 QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st, FootPtr fp) {
   typedef LDim<NL> D;
   const int N = P.N;
@@ -1414,7 +1573,17 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
 #pragma unroll
       for (int i = 0; i < D::GAIN; ++i) gn[i] = c.W(O.G + D::GAIN * k + i);
     }
-    {
+    double Wk[4] = {0, 0, 0, 0};       // ConvexMpc's model: Iw^-1 at the OLD knot state's midpoint yaw (the linearisation point)
+    if constexpr (MD == MD_CONVEX) {
+      cv_winv_mid(P, xo[2], xo[8], Wk);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        dx[a] = xc[3 + a] - xo[3 + a];
+        dx[3 + a] = xc[a] - xo[a];
+        dx[6 + a] = xc[9 + a] - xo[9 + a];
+        dx[9 + a] = xc[6 + a] - xo[6 + a];
+      }
+    } else {
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         dx[a] = xc[a] - xo[a];
@@ -1454,8 +1623,8 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
       const bool on_a = (st.con >> la) & 1u, on_b = (st.con >> lb) & 1u;
       if ((porder >> pr) & 1u) {       // wave-uniform
         LegOutC oa, ob;
-        leg_compute_C<NL>(P, K, cr, rc0, Ra, la, zeta, st, oa, rcrows);
-        leg_compute_C<NL>(P, K, cr, rc0, Rb, lb, zeta, st, ob, rcrows);
+        leg_compute_C<NL, MD>(P, K, cr, rc0, Ra, la, zeta, st, oa, rcrows, Wk);
+        leg_compute_C<NL, MD>(P, K, cr, rc0, Rb, lb, zeta, st, ob, rcrows, Wk);
         {     // the next pair's rows into the registers just consumed
           const int pn = next_bit(porder, pr);
           const int kq = pn >= 0 ? k : kn, pq = pn >= 0 ? pn : first_bit(porder);
@@ -1467,8 +1636,9 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
           for (int a = 0; a < 3; ++a) {
             c.W(O.dU + 3 * NL * k + 3 * la + a) = oa.du[a];
             F[a] += oa.u[a];
-            wd[a] += oa.B[3 * a] * oa.u[0] + oa.B[3 * a + 1] * oa.u[1] + oa.B[3 * a + 2] * oa.u[2];
+            if constexpr (MD != MD_CONVEX) wd[a] += oa.B[3 * a] * oa.u[0] + oa.B[3 * a + 1] * oa.u[1] + oa.B[3 * a + 2] * oa.u[2];
           }
+          if constexpr (MD == MD_CONVEX) cv_cross_acc(oa.r, oa.u, wd);
           rp = fmax(rp, oa.rp); stp = fmax(stp, oa.stp); bad = bad || oa.bad;
           { const bool better = oa.dn * dd > dn * oa.dd; dn = better ? oa.dn : dn; dd = better ? oa.dd : dd; }
         }
@@ -1477,15 +1647,17 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
           for (int a = 0; a < 3; ++a) {
             c.W(O.dU + 3 * NL * k + 3 * lb + a) = ob.du[a];
             F[a] += ob.u[a];
-            wd[a] += ob.B[3 * a] * ob.u[0] + ob.B[3 * a + 1] * ob.u[1] + ob.B[3 * a + 2] * ob.u[2];
+            if constexpr (MD != MD_CONVEX) wd[a] += ob.B[3 * a] * ob.u[0] + ob.B[3 * a + 1] * ob.u[1] + ob.B[3 * a + 2] * ob.u[2];
           }
+          if constexpr (MD == MD_CONVEX) cv_cross_acc(ob.r, ob.u, wd);
           rp = fmax(rp, ob.rp); stp = fmax(stp, ob.stp); bad = bad || ob.bad;
           { const bool better = ob.dn * dd > dn * ob.dd; dn = better ? ob.dn : dn; dd = better ? ob.dd : dd; }
         }
       }
     }
     QL_TICK(st, LP_C_LEGS);
-    srbd_step_fw(P, gb, xc, F, wd, xn);
+    if constexpr (MD == MD_CONVEX) cv_step_fw(P, xc, F, wd, xn);
+    else srbd_step_fw(P, gb, xc, F, wd, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) xc[i] = xn[i];
     QL_TICK(st, LP_C_STEP);
@@ -1500,11 +1672,11 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
 
 // ---- one interior-point iteration of one lane: the control flow of qmpc_solve_body.inc ------------------------------
 // returns true while the instance needs more iterations
-template <int NL>
+template <int NL, int MD = MD_QUAT>
 QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st, bool warm = false) {
   st.it += 1;
-  if (warm) pass_A<NL, true>(P, c, O, K, st, st.it == 1, (FootPtr)K.foot);
-  else pass_A<NL, false>(P, c, O, K, st, st.it == 1, (FootPtr)K.foot);
+  if (warm) pass_A<NL, true, MD>(P, c, O, K, st, st.it == 1, (FootPtr)K.foot);
+  else pass_A<NL, false, MD>(P, c, O, K, st, st.it == 1, (FootPtr)K.foot);
   const double resid = st.rho * st.rcmax;     // largest |rc|: the slack residual of every enabled row is rho * rc0_i
   if (st.mu <= P.mu_final && resid <= P.tol_feas && st.last_step <= P.tol_step) { st.status = QMPC_OK; return false; }
   if (st.it > P.iterations_max) { st.status = QMPC_MAX_ITER; return false; }
@@ -1514,20 +1686,20 @@ QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, cons
   else if (st.it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
   else if (st.it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
   st.target = sg * st.mu;
-  if (!(warm ? pass_B<NL, true>(P, c, O, K, st, (FootPtr)K.foot) : pass_B<NL, false>(P, c, O, K, st, (FootPtr)K.foot))) {
+  if (!(warm ? pass_B<NL, true, MD>(P, c, O, K, st, (FootPtr)K.foot) : pass_B<NL, false, MD>(P, c, O, K, st, (FootPtr)K.foot))) {
     st.status = QMPC_NOT_PD;
     return false;
   }
-  if (warm) pass_C<NL, true>(P, c, O, K, st, (FootPtr)K.foot);
-  else pass_C<NL, false>(P, c, O, K, st, (FootPtr)K.foot);
+  if (warm) pass_C<NL, true, MD>(P, c, O, K, st, (FootPtr)K.foot);
+  else pass_C<NL, false, MD>(P, c, O, K, st, (FootPtr)K.foot);
   if (st.bad_step) { st.status = QMPC_NOT_PD; return false; }     // the last finite iterate stays in the workspace
   st.iters = st.it;
   return true;
 }
 
 // ---- outputs: GetInput(u, 0) (QuatMpc.cpp:264-265) and the info record -----------------------------------------------
-template <int NL>
 // traj_u: this instance's [N][3 NL] input trajectory (the next tick's warm start), or null
+template <int NL, int MD = MD_QUAT>
 QL_FN void lane_finish(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, const LaneState& st,
                        double* forces, qmpc_info* info, double* traj_u = nullptr) {
   const int N = P.N;
@@ -1546,16 +1718,17 @@ QL_FN void lane_finish(const DevParams& P, const Ctx& c, const WsOff& O, const L
     cone_rows(P, K.rot, cr);
     for (int k = 0; k <= N; ++k) {
       double xr[13];
-      xref_at(P, K.refp, k, xr);
+      if constexpr (MD == MD_CONVEX) cv_xref_at(P, K.refp, k, xr);
+      else xref_at(P, K.refp, k, xr);
       double dq = 0.0;
 #pragma unroll
-      for (int i = 0; i < 13; ++i) {
+      for (int i = 0; i < (MD == MD_CONVEX ? 12 : 13); ++i) {
         const double xv = c.W(O.X + 13 * k + i);
         const double e = xv - xr[i];
         J += 0.5 * P.Q[i] * e * e;
-        if (i >= 3 && i < 7) dq += xr[i] * xv;
+        if (MD != MD_CONVEX && i >= 3 && i < 7) dq += xr[i] * xv;
       }
-      J += P.w * (1.0 - fabs(dq));
+      if constexpr (MD != MD_CONVEX) J += P.w * (1.0 - fabs(dq));
       if (k == N) break;
 #pragma unroll
       for (int l = 0; l < NL; ++l) {

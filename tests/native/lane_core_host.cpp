@@ -10,7 +10,7 @@
 using namespace qmpc;
 using namespace qmpc::lane;
 
-template <int NL>
+template <int NL, int MD = MD_QUAT>
 static int solve_all(const DevParams& P, int batch, const double* rec, double* forces, qmpc_info* info,
                      bool warm = false, const double* u_init = nullptr, double* traj_u = nullptr) {
   const WsOff O = make_wsoff<NL>(P.N);
@@ -20,10 +20,10 @@ static int solve_all(const DevParams& P, int batch, const double* rec, double* f
     LaneK<NL> K;
     LaneState st;
     const size_t ts = (size_t)P.N * 3 * NL;
-    lane_setup<NL>(P, c, O, rec + (size_t)b * LDim<NL>::REC, K, st, warm, u_init ? u_init + b * ts : nullptr);
+    lane_setup<NL, MD>(P, c, O, rec + (size_t)b * LDim<NL>::REC, K, st, warm, u_init ? u_init + b * ts : nullptr);
     if (st.active)
-      while (lane_iteration<NL>(P, c, O, K, st, warm)) {}
-    lane_finish<NL>(P, c, O, K, st, forces + (size_t)b * 3 * NL, info ? info + b : nullptr, traj_u ? traj_u + b * ts : nullptr);
+      while (lane_iteration<NL, MD>(P, c, O, K, st, warm)) {}
+    lane_finish<NL, MD>(P, c, O, K, st, forces + (size_t)b * 3 * NL, info ? info + b : nullptr, traj_u ? traj_u + b * ts : nullptr);
   }
   return 0;
 }
@@ -34,6 +34,7 @@ extern "C" int lane_host_solve(const qmpc_params* p, int batch, const double* re
   if (st != QMPC_OK) return st;
   if (p->model == QMPC_MODEL_QUAT8) return solve_all<8>(P, batch, rec, forces, info);
   if (p->model == QMPC_MODEL_QUAT) return solve_all<4>(P, batch, rec, forces, info);
+  if (p->model == QMPC_MODEL_CONVEX) return solve_all<4, MD_CONVEX>(P, batch, rec, forces, info);
   return QMPC_BAD_ARGUMENT;
 }
 

@@ -345,3 +345,32 @@ def test_warm_started_closed_loop_with_the_lane_kernel(pkg, lib, monkeypatch):
     print(f"warm-started loop, lane vs wave, {B} robots, 66 ticks: max position difference {dp:.2e} m; "
           f"mean iterations {out[4]['iterations'].mean():.2f} / {out[0]['iterations'].mean():.2f}")
     assert dp < 1e-7 and abs(out[4]["iterations"].mean() - out[0]["iterations"].mean()) < 0.2
+
+
+@pytest.mark.parametrize("N,B", [(20, 320), (10, 192)])
+def test_lane_kernel_convex_model_matches_oracle(pkg, lib, oracle, monkeypatch, N, B):
+    """ConvexMpc's problem (Euler-angle model, world-frame forces) on the lane kernel: the same transition shape as the
+    quaternion model's error state, the inertia at the midpoint yaw in the per-point map -- against the oracle and the
+    wave-per-instance kernel, with a rejected record and a record without contacts in the batch."""
+    rec = pkg.random_go1_convex_states(B, config_id=12)
+    rec["contacts"][5] = 0.0
+    rec["euler"][9, 1] = np.nan
+    res = {}
+    for v in (4, 0):
+        _forced(monkeypatch, v)
+        s = pkg.Solver(pkg.default_convex_params(N, pkg.MODE_CONVERGED, lib), B, device=0, lib=lib)
+        res[v] = s.convex_solve(rec)
+        s.close()
+    f, info = res[4]
+    fo, io = oracle.convex_solve(oracle.default_convex_params(N, 0), rec, threads=8)
+    assert np.array_equal(info["status"], io["status"]) and np.array_equal(info["status"], res[0][1]["status"])
+    assert info["status"][5] == pkg.NO_CONTACT and info["status"][9] == pkg.NAN_INPUT
+    ok = info["status"] == 0
+    assert ok.sum() == B - 2
+    assert np.abs(f - fo).max() < 1e-6 and np.abs(f - res[0][0]).max() < 1e-6
+    di = np.abs(info["iterations"].astype(int) - io["iterations"].astype(int))
+    assert (di == 0).mean() >= 0.95 and (di <= 1).mean() >= 0.97, np.bincount(di)
+    assert np.abs(info["cost"][ok] - io["cost"][ok]).max() < 1e-9 * max(1.0, np.abs(io["cost"][ok]).max())
+    assert np.abs(f[np.repeat(rec["contacts"] == 0, 3, axis=1)]).max() == 0.0
+    print(f"convex N={N}: lane vs oracle {np.abs(f - fo).max():.2e} N, vs wave kernel {np.abs(f - res[0][0]).max():.2e} N, "
+          f"iterations equal on {(di == 0).mean():.3f}")

@@ -140,3 +140,19 @@ def test_lane_core_warm_start_matches_oracle(pkg, oracle):
         assert np.abs(tu1 - tuo1.reshape(tu1.shape)).max() < 1e-5
         print(f"N={N} mu0={mu0}: warm iterations {i1['iterations'].mean():.2f} (cold {i0['iterations'].mean():.2f}), "
               f"max force difference to the oracle {np.abs(f1 - fo1).max():.2e} N, iteration counts equal on {(di == 0).mean():.3f}")
+
+
+@pytest.mark.parametrize("N", [10, 20])
+def test_lane_core_convex_model_matches_oracle(pkg, oracle, lane, N):
+    """ConvexMpc's problem on the same core (MD_CONVEX): Euler-angle single rigid body, world-frame forces."""
+    p = oracle.default_convex_params(N, 0)
+    rec = pkg.random_go1_convex_states(96, config_id=12)
+    rec["contacts"][4] = 0.0
+    f, info = lane(p, rec)
+    fo, io = oracle.convex_solve(p, rec, threads=8)
+    assert np.array_equal(info["status"], io["status"]) and info["status"][4] == pkg.NO_CONTACT
+    assert np.abs(f - fo).max() < 1e-6           # measured 6e-11
+    di = np.abs(info["iterations"].astype(int) - io["iterations"].astype(int))
+    assert (di == 0).mean() >= 0.95 and (di <= 1).mean() >= 0.97
+    ok = info["status"] == 0
+    assert np.abs(info["cost"][ok] - io["cost"][ok]).max() < 1e-9 * max(1.0, np.abs(io["cost"][ok]).max())
