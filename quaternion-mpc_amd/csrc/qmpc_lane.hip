@@ -177,7 +177,10 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
     while (__any(active)) {
       if (active) {
         // one interior-point iteration (the control flow of lane_iteration in qmpc_lane_core.h)
-        if (warm) call_A<NL, true, MD>(a, Kp, sp); else call_A<NL, false, MD>(a, Kp, sp);
+        // The warm instantiations of the passes (per-row initial residuals travelling with the rows) are needed only while
+        // some lane still carries a slack residual: rho is exactly 0 after a lane's first full step, and from then on the
+        // cold passes compute the same thing with fewer registers (their rc0 is multiplied by rho = 0).
+        if (warm && __any(st.rho != 0.0)) call_A<NL, true, MD>(a, Kp, sp); else call_A<NL, false, MD>(a, Kp, sp);
         const double resid = st.rho * st.rcmax;
         if (st.mu <= P.mu_final && resid <= P.tol_feas && st.last_step <= P.tol_step) { st.status = QMPC_OK; active = false; }
         else if (st.it > P.iterations_max) { st.status = QMPC_MAX_ITER; active = false; }
@@ -188,9 +191,10 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
           else if (st.it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
           else if (st.it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
           st.target = sg * st.mu;
-          if (!(warm ? call_B<NL, true, MD>(a, Kp, sp) : call_B<NL, false, MD>(a, Kp, sp))) { st.status = QMPC_NOT_PD; active = false; }
+          const bool wrows = warm && __any(st.rho != 0.0);
+          if (!(wrows ? call_B<NL, true, MD>(a, Kp, sp) : call_B<NL, false, MD>(a, Kp, sp))) { st.status = QMPC_NOT_PD; active = false; }
           else {
-            if (warm) call_C<NL, true, MD>(a, Kp, sp); else call_C<NL, false, MD>(a, Kp, sp);
+            if (wrows) call_C<NL, true, MD>(a, Kp, sp); else call_C<NL, false, MD>(a, Kp, sp);
             if (st.bad_step) { st.status = QMPC_NOT_PD; active = false; }     // a non-finite trial step is not applied
           }
         }

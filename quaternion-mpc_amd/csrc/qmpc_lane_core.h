@@ -1675,7 +1675,8 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
 template <int NL, int MD = MD_QUAT>
 QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st, bool warm = false) {
   st.it += 1;
-  if (warm) pass_A<NL, true, MD>(P, c, O, K, st, st.it == 1, (FootPtr)K.foot);
+  // (the kernel takes the warm instantiations only while some lane of the wavefront still carries a slack residual)
+  if (warm && st.rho != 0.0) pass_A<NL, true, MD>(P, c, O, K, st, st.it == 1, (FootPtr)K.foot);
   else pass_A<NL, false, MD>(P, c, O, K, st, st.it == 1, (FootPtr)K.foot);
   const double resid = st.rho * st.rcmax;     // largest |rc|: the slack residual of every enabled row is rho * rc0_i
   if (st.mu <= P.mu_final && resid <= P.tol_feas && st.last_step <= P.tol_step) { st.status = QMPC_OK; return false; }
@@ -1686,6 +1687,7 @@ QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, cons
   else if (st.it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
   else if (st.it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
   st.target = sg * st.mu;
+  warm = warm && st.rho != 0.0;
   if (!(warm ? pass_B<NL, true, MD>(P, c, O, K, st, (FootPtr)K.foot) : pass_B<NL, false, MD>(P, c, O, K, st, (FootPtr)K.foot))) {
     st.status = QMPC_NOT_PD;
     return false;

@@ -374,3 +374,37 @@ def test_lane_kernel_convex_model_matches_oracle(pkg, lib, oracle, monkeypatch, 
     assert np.abs(f[np.repeat(rec["contacts"] == 0, 3, axis=1)]).max() == 0.0
     print(f"convex N={N}: lane vs oracle {np.abs(f - fo).max():.2e} N, vs wave kernel {np.abs(f - res[0][0]).max():.2e} N, "
           f"iterations equal on {(di == 0).mean():.3f}")
+
+
+def test_convex_closed_loop_with_the_lane_kernel(pkg, lib, monkeypatch):
+    """ConvexMpc's tick in the device-resident loop (per-tick form) with its solves on the lane kernel, cold and
+    warm-started, against the wave-per-instance kernels."""
+    rng = np.random.default_rng(29)
+    B = 3072
+    cmds = np.zeros((B, 7))
+    cmds[:, 0] = 0.6 * rng.uniform(-0.5, 0.5, B); cmds[:, 1] = rng.uniform(-0.2, 0.2, B); cmds[:, 2] = rng.uniform(0.26, 0.32, B)
+    cmds[:, 5] = rng.uniform(-0.5, 0.5, B); cmds[:, 6] = (rng.random(B) < 0.9).astype(float)
+    cmds[cmds[:, 6] == 0, :2] = 0.0
+    cmds[cmds[:, 6] == 0, 5] = 0.0
+    stand = cmds.copy(); stand[:, 6] = 0.0
+    for warm in (0.0, 1.0):
+        lp = pkg.default_loop_params(lib)
+        lp.warm_start = warm
+        st0 = pkg.loop_states(stand, lp, height=0.3, yaw=rng.uniform(-3, 3, B), lib=lib)
+        out = {}
+        for v in (4, 0):
+            _forced(monkeypatch, v)
+            p = pkg.default_convex_params(10, pkg.MODE_CONVERGED, lib)
+            if warm:
+                p.ipm_mu0 = 1e-6
+            s = pkg.Solver(p, B, device=0, lib=lib)
+            st = s.loop_run(st0, 6, lp)
+            st["movement_mode"] = cmds[:, 6]
+            st = s.loop_run(st, 40, lp)
+            s.close()
+            out[v] = st
+            assert (st["status"] == 0).all() and np.isfinite(st["pos_world"]).all()
+        dp = np.abs(out[4]["pos_world"] - out[0]["pos_world"]).max()
+        print(f"ConvexMpc loop, warm_start={warm}: lane vs wave max position difference {dp:.2e} m; "
+              f"mean iterations {out[4]['iterations'].mean():.2f} / {out[0]['iterations'].mean():.2f}")
+        assert dp < 1e-7 and np.array_equal(out[4]["contacts"], out[0]["contacts"])
