@@ -408,3 +408,33 @@ def test_convex_closed_loop_with_the_lane_kernel(pkg, lib, monkeypatch):
         print(f"ConvexMpc loop, warm_start={warm}: lane vs wave max position difference {dp:.2e} m; "
               f"mean iterations {out[4]['iterations'].mean():.2f} / {out[0]['iterations'].mean():.2f}")
         assert dp < 1e-7 and np.array_equal(out[4]["contacts"], out[0]["contacts"])
+
+
+def test_lane_kernel_warm_and_convex_beyond_the_resident_lanes(pkg, lib, oracle):
+    """70000 instances (more than the 65536 resident lanes: a second round of some wavefronts) through the automatic
+    selection: warm-started QuatMpc solves and ConvexMpc solves, each against the oracle on a sample and for
+    batch-position independence (a shard solved alone gives the same bits)."""
+    B, N = 70000, 10
+    rec = pkg.random_go1_trot_states(B, config_id=4)
+    p = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
+    s = pkg.Solver(p, B, device=0, lib=lib)
+    f0, i0, tu0 = s.solve_warm(rec, None)
+    rec2 = rec.copy()
+    rec2["lin_vel_body"] += 0.01
+    f1, i1, tu1 = s.solve_warm(rec2, tu0)
+    assert (i0["status"] == 0).all() and (i1["status"] == 0).all()
+    sub = np.arange(0, B, B // 48)[:48]
+    fo, io, tuo = oracle.solve_warm(oracle.default_params(N, 0), rec2[sub], tu0[sub])
+    assert np.abs(f1[sub] - fo).max() < 1e-6 and np.abs(tu1[sub].reshape(48, -1) - tuo.reshape(48, -1)).max() < 1e-5
+    fs, _, _ = s.solve_warm(rec2[40000:], tu0[40000:])
+    assert np.array_equal(fs, f1[40000:])
+    s.close()
+    recc = pkg.random_go1_convex_states(B, config_id=12)
+    sc = pkg.Solver(pkg.default_convex_params(N, pkg.MODE_CONVERGED, lib), B, device=0, lib=lib)
+    fc, ic = sc.convex_solve(recc)
+    assert (ic["status"] == 0).all()
+    fco, _ = oracle.convex_solve(oracle.default_convex_params(N, 0), recc[sub], threads=8)
+    assert np.abs(fc[sub] - fco).max() < 1e-6
+    fcs, _ = sc.convex_solve(recc[40000:])
+    assert np.array_equal(fcs, fc[40000:])
+    sc.close()
