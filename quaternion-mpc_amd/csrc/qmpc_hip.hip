@@ -42,7 +42,7 @@ int qmpc_lane_param_slots();
 hipError_t qmpc_lane_upload_params(int pslot, hipStream_t s, const void* dev_params, size_t dev_params_size);
 hipError_t qmpc_lane_launch(int nl, int pslot, int batch, hipStream_t s, const void* dev_params, size_t dev_params_size, const void* in,
                             double* forces, qmpc_info* info, double* ws, unsigned slots, int* scratch, int upload_params,
-                            const double* u_init, double* traj_u, int check_prev);
+                            const double* u_init, double* traj_u, int check_prev, int order_prev);
 
 struct qmpc_handle {
   qmpc_params params;
@@ -76,6 +76,7 @@ struct qmpc_handle {
   int lane_sort;          // 1: order the batch by stance mask first (env QMPC_LANE_SORT)
   int lane_pslot;         // this handle's slot in the lane kernel's constant-memory parameter table
   bool lane_params_resident;   // set while a stream capture repeats launches with unchanged parameters (closed loop)
+  bool lane_order_prev;        // closed loop: d_info holds every robot's previous record -- order the batch by its iteration count too
 };
 
 constexpr unsigned kLaneMaxSlots = 1024 * 64;   // one wavefront per SIMD of the chip
@@ -371,7 +372,7 @@ static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* 
   if (es != QMPC_OK) return es;
   HIP_TRY(qmpc_lane_launch(nl, h->lane_pslot, (int)batch, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, h->d_lane_ws, h->lane_slots,
                            h->lane_sort ? h->d_lane_scratch : nullptr, h->lane_params_resident ? 0 : 1, d_u_init, d_traj_u,
-                           check_prev));
+                           check_prev, h->lane_order_prev ? 1 : 0));
   return QMPC_OK;
 }
 
@@ -1007,13 +1008,15 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   // and the parameters do not change between the ticks of a call).
   struct ResidentGuard {
     qmpc_handle* h;
-    ~ResidentGuard() { h->lane_params_resident = false; }
+    ~ResidentGuard() { h->lane_params_resident = false; h->lane_order_prev = false; }
   } resident_guard{h};
   if (use_lane(h, batch, nullptr, nullptr)) {
     const qmpc_status es = ensure_lane_buffers(h);
     if (es != QMPC_OK) return es;
     HIP_TRY(qmpc_lane_upload_params(h->lane_pslot, s, &h->dev, sizeof h->dev));
     h->lane_params_resident = true;
+    static const bool order_env = [] { const char* e = std::getenv("QMPC_LANE_ORDER_PREV"); return !e || e[0] != '0'; }();
+    h->lane_order_prev = order_env;
   }
   if (warm) {                            // the cold first tick is not the tick the graph repeats
     const qmpc_status st = one_tick(true);

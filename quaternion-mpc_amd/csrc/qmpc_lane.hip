@@ -224,20 +224,29 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
 // the global counters once per key it holds (a batch has a handful of distinct masks: per-thread global atomics on three
 // addresses took 0.65 ms per launch).
 template <int NL>
-__device__ __forceinline__ unsigned stance_key(const double* __restrict__ in, int b, int con_off) {
+// prev (four-point models only; null: not used): the records of the instances' PREVIOUS solves -- in the closed loop a robot
+// needs about as many iterations as at its last tick, and a wavefront runs as long as the slowest of its lanes, so within a
+// stance pattern the batch is ordered by that count (16 classes: 3 ... 18 iterations)
+__device__ __forceinline__ unsigned stance_key(const double* __restrict__ in, int b, int con_off, const qmpc_info* __restrict__ prev) {
   const double* rec = in + (size_t)b * LDim<NL>::REC + con_off;
   unsigned key = 0;
 #pragma unroll
   for (int l = 0; l < NL; ++l) key |= (rec[l] != 0.0) ? (1u << l) : 0u;
+  if (NL == 4 && prev) {
+    int it = prev[b].iterations - 3;
+    it = it < 0 ? 0 : (it > 15 ? 15 : it);
+    key = (key << 4) | (unsigned)it;
+  }
   return key;
 }
 template <int NL>
-__global__ __launch_bounds__(256) void qmpc_lane_sort_count(const double* __restrict__ in, int batch, int* __restrict__ scratch, int con_off) {
+__global__ __launch_bounds__(256) void qmpc_lane_sort_count(const double* __restrict__ in, int batch, int* __restrict__ scratch, int con_off,
+                                                                const qmpc_info* __restrict__ prev) {
   __shared__ int hist[256];
   hist[threadIdx.x] = 0;
   __syncthreads();
   const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b < batch) atomicAdd(&hist[stance_key<NL>(in, b, con_off)], 1);
+  if (b < batch) atomicAdd(&hist[stance_key<NL>(in, b, con_off, prev)], 1);
   __syncthreads();
   if (hist[threadIdx.x]) atomicAdd(&scratch[threadIdx.x], hist[threadIdx.x]);
 }
@@ -251,7 +260,8 @@ __global__ __launch_bounds__(64) void qmpc_lane_sort_scan(int* __restrict__ scra
   }
 }
 template <int NL>
-__global__ __launch_bounds__(256) void qmpc_lane_sort_scatter(const double* __restrict__ in, int batch, int* __restrict__ scratch, int con_off) {
+__global__ __launch_bounds__(256) void qmpc_lane_sort_scatter(const double* __restrict__ in, int batch, int* __restrict__ scratch, int con_off,
+                                                                  const qmpc_info* __restrict__ prev) {
   __shared__ int hist[256], base[256];
   hist[threadIdx.x] = 0;
   __syncthreads();
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(256) void qmpc_lane_sort_scatter(const double* __re
   unsigned key = 0;
   int rank = 0;
   if (b < batch) {
-    key = stance_key<NL>(in, b, con_off);
+    key = stance_key<NL>(in, b, con_off, prev);
     rank = atomicAdd(&hist[key], 1);
   }
   __syncthreads();
@@ -294,7 +304,7 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
                                                                    size_t dev_params_size, const void* in, double* forces,
                                                                    qmpc_info* info, double* ws, unsigned slots, int* scratch,
                                                                    int upload_params, const double* u_init, double* traj_u,
-                                                                   int check_prev) {
+                                                                   int check_prev, int order_prev) {
   // nl: 4 (QuatMpc), 8 (the 8-contact-point model) or -4 (ConvexMpc's model: four points, world-frame forces)
   const bool convex = nl == -4;
   if (convex) nl = 4;
@@ -311,17 +321,18 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
   const double* rec = static_cast<const double*>(in);
   const int* perm = nullptr;
   if (scratch) {
+    const qmpc_info* prev = (order_prev && info) ? info : nullptr;      // the previous solves' records, still in the output buffer
     hipError_t e = hipMemsetAsync(scratch, 0, sizeof(int) * 512, s);
     if (e != hipSuccess) return e;
     const unsigned blocks = (unsigned)((batch + 255) / 256);
     if (nl == 8) {
-      hipLaunchKernelGGL(qmpc_lane_sort_count<8>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch, con_off);
+      hipLaunchKernelGGL(qmpc_lane_sort_count<8>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch, con_off, prev);
       hipLaunchKernelGGL(qmpc_lane_sort_scan, dim3(1), dim3(64), 0, s, scratch);
-      hipLaunchKernelGGL(qmpc_lane_sort_scatter<8>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch, con_off);
+      hipLaunchKernelGGL(qmpc_lane_sort_scatter<8>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch, con_off, prev);
     } else {
-      hipLaunchKernelGGL(qmpc_lane_sort_count<4>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch, con_off);
+      hipLaunchKernelGGL(qmpc_lane_sort_count<4>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch, con_off, prev);
       hipLaunchKernelGGL(qmpc_lane_sort_scan, dim3(1), dim3(64), 0, s, scratch);
-      hipLaunchKernelGGL(qmpc_lane_sort_scatter<4>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch, con_off);
+      hipLaunchKernelGGL(qmpc_lane_sort_scatter<4>, dim3(blocks), dim3(256), 0, s, rec, batch, scratch, con_off, prev);
     }
     perm = scratch + 512;
   }
