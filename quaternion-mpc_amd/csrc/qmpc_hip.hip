@@ -42,7 +42,7 @@ int qmpc_lane_param_slots();
 hipError_t qmpc_lane_upload_params(int pslot, hipStream_t s, const void* dev_params, size_t dev_params_size);
 hipError_t qmpc_lane_launch(int nl, int pslot, int batch, hipStream_t s, const void* dev_params, size_t dev_params_size, const void* in,
                             double* forces, qmpc_info* info, double* ws, unsigned slots, int* scratch, int upload_params,
-                            const double* u_init, double* traj_u, int check_prev, int order_prev);
+                            const double* u_init, double* traj_u, int check_prev, int order_prev, double* traj_x);
 
 struct qmpc_handle {
   qmpc_params params;
@@ -343,11 +343,10 @@ static bool use_global_gains(const qmpc_handle* h, int32_t batch) { return pick_
 
 // Large batches of the converged mode go to the lane-per-instance kernel (qmpc_lane.hip): one lane per instance, the
 // working set streamed through a structure-of-arrays HBM workspace sized by the RESIDENT lanes (<= 1024 wavefronts).
-// It returns forces, info and (on request) the input trajectory; calls that ask for the state trajectory keep the
-// wave-per-instance kernels.
+// It returns forces, info and (on request) the input and state trajectories.
 static bool use_lane(const qmpc_handle* h, int32_t batch, const double* d_tu, const double* d_tx) {
-  (void)d_tu;
-  if (h->params.mode != QMPC_MODE_CONVERGED || d_tx) return false;
+  (void)d_tu; (void)d_tx;
+  if (h->params.mode != QMPC_MODE_CONVERGED) return false;
   if (h->variant == 4) return true;
   return h->variant == 0 && batch >= h->lane_min_batch;
 }
@@ -366,13 +365,14 @@ static qmpc_status ensure_lane_buffers(qmpc_handle* h) {
 // d_u_init / d_traj_u: previous solutions [batch][N][3 NL] to start from (null: cold) / where to leave this one (null:
 // not wanted); they may be the same buffer.  check_prev: d_info still holds the records of the previous solves
 static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces, qmpc_info* d_info,
-                               hipStream_t s, const double* d_u_init = nullptr, double* d_traj_u = nullptr, int check_prev = 0) {
+                               hipStream_t s, const double* d_u_init = nullptr, double* d_traj_u = nullptr, int check_prev = 0,
+                               double* d_traj_x = nullptr) {
   const int nl = h->params.model == QMPC_MODEL_CONVEX ? -4 : model_nl(h->params.model);     // -4: ConvexMpc's model (qmpc_lane.hip)
   const qmpc_status es = ensure_lane_buffers(h);
   if (es != QMPC_OK) return es;
   HIP_TRY(qmpc_lane_launch(nl, h->lane_pslot, (int)batch, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, h->d_lane_ws, h->lane_slots,
                            h->lane_sort ? h->d_lane_scratch : nullptr, h->lane_params_resident ? 0 : 1, d_u_init, d_traj_u,
-                           check_prev, h->lane_order_prev ? 1 : 0));
+                           check_prev, h->lane_order_prev ? 1 : 0, d_traj_x));
   return QMPC_OK;
 }
 
@@ -405,7 +405,7 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
     return QMPC_OK;
   }
   if (use_lane(h, batch, d_tu, d_tx)) {
-    const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s, nullptr, d_tu);
+    const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s, nullptr, d_tu, 0, d_tx);
     if (ls != QMPC_OK) return ls;
     if (timed) {
       HIP_TRY(hipEventRecord(h->ev1, s));

@@ -124,7 +124,8 @@ __device__ __noinline__ void call_C(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
 }
 template <int NL, int MD>
 __device__ __noinline__ void call_finish(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp,
-                                         unsigned long long forces, unsigned long long info, unsigned long long traj_u) {
+                                         unsigned long long forces, unsigned long long info, unsigned long long traj_u,
+                                         unsigned long long traj_x) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
   const WsOff O = make_wsoff<NL>(P.N);
@@ -133,7 +134,7 @@ __device__ __noinline__ void call_finish(PassArgs a, QL_PRIV_AS const LaneK<NL>*
   LaneState st;
   priv_load(st, sp);
   lane_finish<NL, MD>(P, c, O, K, st, reinterpret_cast<double*>(forces), reinterpret_cast<qmpc_info*>(info),
-                  reinterpret_cast<double*>(traj_u));
+                  reinterpret_cast<double*>(traj_u), reinterpret_cast<double*>(traj_x));
 }
 
 template <int NL, int MD = MD_QUAT>
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
                                                               int batch, double* __restrict__ ws, unsigned slots,
                                                               int lanes, const int* __restrict__ perm,
                                                               long long* __restrict__ prof, const double* u_init, double* traj_u,
-                                                              int check_prev) {
+                                                              int check_prev, double* traj_x) {
   typedef LDim<NL> D;
   const int lane = threadIdx.x;
   const DevParams& P = ql_params[pslot];
@@ -206,7 +207,8 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
     if (valid)
       call_finish<NL, MD>(a, Kp, sp, reinterpret_cast<unsigned long long>(forces + (size_t)b * D::NU),
                       info ? reinterpret_cast<unsigned long long>(info + b) : 0ull,
-                      traj_u ? reinterpret_cast<unsigned long long>(traj_u + (size_t)b * tstride) : 0ull);
+                      traj_u ? reinterpret_cast<unsigned long long>(traj_u + (size_t)b * tstride) : 0ull,
+                      traj_x ? reinterpret_cast<unsigned long long>(traj_x + (size_t)b * (size_t)(P.N + 1) * (MD == MD_CONVEX ? 12 : 13)) : 0ull);
 #if defined(QL_PROFILE)
     if (prof && base < (long long)slots) {      // first round of every wave; lane 0's clock, every lane's own iteration count
       if (lane == 0) {
@@ -304,7 +306,7 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
                                                                    size_t dev_params_size, const void* in, double* forces,
                                                                    qmpc_info* info, double* ws, unsigned slots, int* scratch,
                                                                    int upload_params, const double* u_init, double* traj_u,
-                                                                   int check_prev, int order_prev) {
+                                                                   int check_prev, int order_prev, double* traj_x) {
   // nl: 4 (QuatMpc), 8 (the 8-contact-point model) or -4 (ConvexMpc's model: four points, world-frame forces)
   const bool convex = nl == -4;
   if (convex) nl = 4;
@@ -352,13 +354,13 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
 #endif
   if (nl == 8)
     hipLaunchKernelGGL(qmpc_lane_kernel<8>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm, prof,
-                       u_init, traj_u, check_prev);
+                       u_init, traj_u, check_prev, traj_x);
   else if (convex)
     hipLaunchKernelGGL((qmpc_lane_kernel<4, MD_CONVEX>), dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes,
-                       perm, prof, u_init, traj_u, check_prev);
+                       perm, prof, u_init, traj_u, check_prev, traj_x);
   else
     hipLaunchKernelGGL(qmpc_lane_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm, prof,
-                       u_init, traj_u, check_prev);
+                       u_init, traj_u, check_prev, traj_x);
 #if defined(QL_PROFILE)
   {
     static long long hp[16 * 1024];

@@ -1703,7 +1703,7 @@ QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, cons
 // traj_u: this instance's [N][3 NL] input trajectory (the next tick's warm start), or null
 template <int NL, int MD = MD_QUAT>
 QL_FN void lane_finish(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, const LaneState& st,
-                       double* forces, qmpc_info* info, double* traj_u = nullptr) {
+                       double* forces, qmpc_info* info, double* traj_u = nullptr, double* traj_x = nullptr) {
   const int N = P.N;
   const bool solved = st.status != QMPC_NAN_INPUT && st.status != QMPC_NO_CONTACT;
 #pragma unroll
@@ -1713,6 +1713,12 @@ QL_FN void lane_finish(const DevParams& P, const Ctx& c, const WsOff& O, const L
 #pragma unroll
       for (int j = 0; j < 3 * NL; ++j)
         traj_u[3 * NL * k + j] = (solved && ((st.con >> (j / 3)) & 1u)) ? c.W(O.U + 3 * NL * k + j) : 0.0;
+  if (traj_x) {      // [N + 1][13] (ConvexMpc's model: [N + 1][12])
+    constexpr int NX = (MD == MD_CONVEX) ? 12 : 13;
+    for (int k = 0; k <= N; ++k)
+#pragma unroll
+      for (int i = 0; i < NX; ++i) traj_x[NX * k + i] = solved ? c.W(O.X + 13 * k + i) : 0.0;
+  }
   if (!info) return;
   double J = 0.0, viol = 0.0;
   if (solved) {

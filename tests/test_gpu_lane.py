@@ -438,3 +438,30 @@ def test_lane_kernel_warm_and_convex_beyond_the_resident_lanes(pkg, lib, oracle)
     fcs, _ = sc.convex_solve(recc[40000:])
     assert np.array_equal(fcs, fc[40000:])
     sc.close()
+
+
+@pytest.mark.parametrize("model", ["quat", "convex", "biped8"])
+def test_lane_kernel_trajectory_outputs(pkg, lib, oracle, monkeypatch, model):
+    """qmpc_solve*_traj on the lane kernel: input and state trajectories against the oracle's and the wave kernels'."""
+    B = 96
+    gen, dp, N = {"quat": (pkg.random_go1_trot_states, pkg.default_params, 10),
+                  "convex": (pkg.random_go1_convex_states, pkg.default_convex_params, 20),
+                  "biped8": (pkg.random_biped8_states, pkg.default_biped8_params, 16)}[model]
+    rec = gen(B, config_id={"quat": 2, "convex": 12, "biped8": 5}[model])
+    res = {}
+    for v in (4, 0):
+        _forced(monkeypatch, v)
+        s = pkg.Solver(dp(N, pkg.MODE_CONVERGED, lib), B, device=0, lib=lib)
+        call = {"quat": s.solve, "convex": s.convex_solve, "biped8": s.solve8}[model]
+        res[v] = call(rec, want_traj=True)
+        s.close()
+    osolve, odp = {"quat": (oracle.solve, oracle.default_params), "convex": (oracle.convex_solve, oracle.default_convex_params),
+                   "biped8": (oracle.solve8, oracle.default_biped8_params)}[model]
+    fo, io, tuo, txo = osolve(odp(N, 0), rec, threads=8, want_traj=True)
+    f, info, tu, tx = res[4]
+    assert (info["status"] == 0).all()
+    assert np.abs(f - fo).max() < 1e-6
+    assert np.abs(tu.reshape(B, -1) - tuo.reshape(B, -1)).max() < 1e-5 and np.abs(tx.reshape(B, -1) - txo.reshape(B, -1)).max() < 1e-8
+    assert np.abs(tu.reshape(B, -1) - res[0][2].reshape(B, -1)).max() < 1e-5
+    assert np.abs(tx.reshape(B, -1) - res[0][3].reshape(B, -1)).max() < 1e-8
+    assert np.array_equal(tu.reshape(B, N, -1)[:, 0, :], f)
