@@ -93,7 +93,7 @@ constexpr int kLaneMinBatch = 24576;          // measured switch-over against th
 
 extern "C" {
 
-const char* qmpc_version(void) { return "qmpc-hip 0.2 (gfx950, wave-per-instance IPM/Riccati, fp64 MFMA; persistent closed loop)"; }
+const char* qmpc_version(void) { return "qmpc-hip 0.3 (gfx950, wave-per-instance IPM/Riccati with fp64 MFMA; lane-per-instance kernel for large batches; device-resident closed loop)"; }
 int32_t qmpc_sizeof_input(void) { return (int32_t)sizeof(qmpc_input); }
 int32_t qmpc_sizeof_params(void) { return (int32_t)sizeof(qmpc_params); }
 int32_t qmpc_sizeof_info(void) { return (int32_t)sizeof(qmpc_info); }
