@@ -76,10 +76,14 @@ struct qmpc_handle {
   int lane_sort;          // 1: order the batch by stance mask first (env QMPC_LANE_SORT)
   int lane_pslot;         // this handle's slot in the lane kernel's constant-memory parameter table
   bool lane_params_resident;   // set while a stream capture repeats launches with unchanged parameters (closed loop)
+  bool lane_loop_cold;         // set during a cold-started qmpc_loop_run*: the loop's own switch-over applies
+  int lane_min_loop_cold;
   bool lane_order_prev;        // closed loop: d_info holds every robot's previous record -- order the batch by its iteration count too
 };
 
 constexpr unsigned kLaneMaxSlots = 1024 * 64;   // one wavefront per SIMD of the chip
+constexpr int kLaneMinLoopCold = 18432;       // ... of the cold-started closed loop (its states need fewer iterations and spread less; measured:
+                                              // 16384 robots 3.95 vs 3.91 M robot-ticks/s, 20480: 4.81 vs 3.97 M; warm-started the general threshold holds)
 constexpr int kLaneMinBatch = 24576;          // measured switch-over against the wave-per-instance kernels (QMPC_LANE_MIN overrides)
 
 #define HIP_TRY(expr)                                                                      \
@@ -285,6 +289,7 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     h->variant = v ? std::atoi(v) : 0;
     const char* lm = std::getenv("QMPC_LANE_MIN");
     h->lane_min_batch = lm ? std::atoi(lm) : kLaneMinBatch;
+    h->lane_min_loop_cold = lm ? h->lane_min_batch : kLaneMinLoopCold;
     const char* ls = std::getenv("QMPC_LANE_SORT");
     h->lane_sort = ls ? std::atoi(ls) : 1;
     static std::atomic<int> next_slot{0};     // handles share the table round-robin (a slot is rewritten before every launch)
@@ -348,7 +353,7 @@ static bool use_lane(const qmpc_handle* h, int32_t batch, const double* d_tu, co
   (void)d_tu; (void)d_tx;
   if (h->params.mode != QMPC_MODE_CONVERGED) return false;
   if (h->variant == 4) return true;
-  return h->variant == 0 && batch >= h->lane_min_batch;
+  return h->variant == 0 && batch >= (h->lane_loop_cold ? h->lane_min_loop_cold : h->lane_min_batch);
 }
 // workspace of the lane kernel, allocated at first use (never inside a stream capture: qmpc_loop_run calls this first)
 static qmpc_status ensure_lane_buffers(qmpc_handle* h) {
@@ -1008,8 +1013,9 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   // and the parameters do not change between the ticks of a call).
   struct ResidentGuard {
     qmpc_handle* h;
-    ~ResidentGuard() { h->lane_params_resident = false; h->lane_order_prev = false; }
+    ~ResidentGuard() { h->lane_params_resident = false; h->lane_order_prev = false; h->lane_loop_cold = false; }
   } resident_guard{h};
+  h->lane_loop_cold = !warm;
   if (use_lane(h, batch, nullptr, nullptr)) {
     const qmpc_status es = ensure_lane_buffers(h);
     if (es != QMPC_OK) return es;
