@@ -465,3 +465,50 @@ def test_lane_kernel_trajectory_outputs(pkg, lib, oracle, monkeypatch, model):
     assert np.abs(tu.reshape(B, -1) - res[0][2].reshape(B, -1)).max() < 1e-5
     assert np.abs(tx.reshape(B, -1) - res[0][3].reshape(B, -1)).max() < 1e-8
     assert np.array_equal(tu.reshape(B, N, -1)[:, 0, :], f)
+
+
+def test_lane_kernel_convex_and_warm_randomised_parameter_sets(pkg, lib, oracle, monkeypatch):
+    """Random friction, force limit, weights, mass, inertia, knot spacing and horizon for ConvexMpc's problem on the lane
+    kernel, and the same draw of QuatMpc parameters for warm-started solves (previous solution of slightly different
+    states): the lane kernel follows the oracle for every set."""
+    _forced(monkeypatch, 4)
+    rng = np.random.default_rng(91)
+    for t in range(6):
+        N = int(rng.choice([6, 10, 20, 30]))
+        p = pkg.default_convex_params(N, pkg.MODE_CONVERGED, lib)
+        p.mu = float(rng.uniform(0.3, 1.0))
+        p.fz_max = float(rng.uniform(80, 300))
+        p.mass = float(rng.uniform(9, 16))
+        for i in range(12):
+            p.q_weights[i] = float(p.q_weights[i] * rng.uniform(0.3, 3.0))
+            p.r_weights[i] = float(10 ** rng.uniform(-6.5, -4.5))
+        for i in (0, 4, 8):
+            p.inertia[i] = float(p.inertia[i] * rng.uniform(0.6, 1.6))
+        hs = float(rng.choice([0.005, 0.01]))
+        p.h, p.h_ref = hs, hs
+        rec = pkg.random_go1_convex_states(128, config_id=60 + t)
+        s = pkg.Solver(p, 128, device=0, lib=lib)
+        f, info = s.convex_solve(rec)
+        s.close()
+        fo, io = oracle.convex_solve(p, rec, threads=8)
+        assert np.array_equal(info["status"], io["status"]), (t, np.unique(info["status"]), np.unique(io["status"]))
+        ok = info["status"] == 0
+        assert ok.mean() > 0.9 and np.abs(f[ok] - fo[ok]).max() < 1e-6, (t, np.abs(f[ok] - fo[ok]).max())
+        di = np.abs(info["iterations"][ok].astype(int) - io["iterations"][ok].astype(int))
+        assert (di <= 1).mean() >= 0.95, (t, np.bincount(di))
+    for t in range(4):
+        p = _random_params(pkg, lib, rng, t)
+        p.ipm_mu0 = float(rng.choice([1e-2, 1e-4, 1e-6]))
+        rec = pkg.random_go1_trot_states(128, config_id=70 + t)
+        rec2 = rec.copy()
+        rec2["lin_vel_body"] += rng.normal(0, 0.02, rec2["lin_vel_body"].shape)
+        s = pkg.Solver(p, 128, device=0, lib=lib)
+        _, _, tu = s.solve_warm(rec, None)
+        f, info, tu1 = s.solve_warm(rec2, tu)
+        s.close()
+        fo, io, tuo = oracle.solve_warm(p, rec2, tu)
+        assert np.array_equal(info["status"], io["status"]), t
+        ok = info["status"] == 0
+        assert ok.mean() > 0.9 and np.abs(f[ok] - fo[ok]).max() < 1e-6, (t, np.abs(f[ok] - fo[ok]).max())
+        di = np.abs(info["iterations"][ok].astype(int) - io["iterations"][ok].astype(int))
+        assert (di <= 1).mean() >= 0.95, (t, np.bincount(di))
