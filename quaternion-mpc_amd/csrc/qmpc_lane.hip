@@ -12,7 +12,12 @@
 //
 // Contact patterns.  The per-contact-point code is guarded by a per-lane stance test; the hardware skips a guarded
 // region when no lane of the wave needs it.  A counting sort on the stance mask (qmpc_lane_sort_*) orders the batch so
-// that a wave's 64 instances share their pattern (trot pairs do half the per-point work of a four-stance instance).
+// that a wave's 64 instances share their pattern (trot pairs do half the per-point work of a four-stance instance); in
+// the closed loop the order within a pattern follows every robot's iteration count at its last tick.
+//
+// Calls served: qmpc_solve* / qmpc_solve8* / qmpc_convex_solve* (with or without trajectory outputs), qmpc_solve_warm* and
+// the per-tick form of the device-resident closed loop (cold or warm-started), converged mode, from the switch-over batch
+// size of qmpc_hip.hip on.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>

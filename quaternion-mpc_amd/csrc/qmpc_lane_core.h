@@ -22,9 +22,16 @@
 // forward pass is the 6 x 13 wrench-space gain, not 3NL x 13.
 //
 // Where things live (device): the cost-to-go matrix P of the backward pass (78 doubles) in LDS, one 512-byte row per
-// entry; the instance's constants (rotation, contact points, references: 37 doubles, 49 for the 8-point model) in
-// registers for the whole solve; everything indexed by knot in the HBM workspace, laid out [wave][element][lane]: a
-// wavefront's working set is one contiguous block and consecutive elements are consecutive 512-byte rows.
+// entry; the instance's constants (rotation, references: 25 doubles) in registers for a pass, the contact points'
+// positions in the lane's private memory (they are fetched with a point's rows); everything indexed by knot in the HBM
+// workspace, laid out [wave][element][lane]: a wavefront's working set is one contiguous block and consecutive elements
+// are consecutive 512-byte rows.  One wavefront per SIMD has nobody to switch to: rows are prefetched one contact point
+// ahead into the registers just consumed (LegAhead), and nothing is allowed to spill inside the loops -- the memory
+// counter is in order, so a spill re-load behind a prefetch waits for the prefetch.
+//
+// Template parameters of the passes: NL (4 or 8 contact points), WARM (a warm-started launch: the rows' initial slack
+// residuals come from the workspace while any lane carries one), MD (MD_QUAT, or MD_CONVEX: ConvexMpc's Euler-angle model,
+// whose transition has the same block shape once the yaw-dependent inertia goes into the per-point map).
 //
 // The file is plain C++ on purpose: hipcc compiles it into qmpc_lane_kernel (qmpc_lane.hip), g++ compiles the very
 // same text into the CPU numerics test of the core (tests/lane_core_host.cpp; test infrastructure, never a product
