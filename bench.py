@@ -333,9 +333,9 @@ def main():
 
     def kernel_name(batch):
         """dominant kernel of a launch of `batch` instances (qmpc_hip.hip: launch_solve)"""
-        lane_min = int(os.environ.get("QMPC_LANE_MIN", "24576"))
+        lane_min = int(os.environ.get("QMPC_LANE_MIN", "21504" if args.model == "quat" else "18432"))
         var = os.environ.get("QMPC_VARIANT", "0")
-        lane = args.model != "convex" and (var == "4" or (var == "0" and batch >= lane_min))
+        lane = var == "4" or (var == "0" and batch >= lane_min)
         return "qmpc_lane_kernel (lane per instance)" if lane else "qmpc_solve_kernel (wave per instance)"
 
     leg = timed_leg(B, config_id, args.steps, args.warmup)

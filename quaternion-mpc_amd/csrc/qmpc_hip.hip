@@ -84,7 +84,11 @@ struct qmpc_handle {
 constexpr unsigned kLaneMaxSlots = 1024 * 64;   // one wavefront per SIMD of the chip
 constexpr int kLaneMinLoopCold = 18432;       // ... of the cold-started closed loop (its states need fewer iterations and spread less; measured:
                                               // 16384 robots 3.95 vs 3.91 M robot-ticks/s, 20480: 4.81 vs 3.97 M; warm-started the general threshold holds)
-constexpr int kLaneMinBatch = 24576;          // measured switch-over against the wave-per-instance kernels (QMPC_LANE_MIN overrides)
+// measured switch-over against the wave-per-instance kernels (QMPC_LANE_MIN overrides): QuatMpc N=10 20480: 2.62 vs 2.74 M,
+// 22528: 2.94 vs 2.78 M solves/s (N=20: equal at 20480); ConvexMpc and the 8-point model cross earlier (ConvexMpc N=10 / 20:
+// equal at 16384 / 20480; 8-point 16384: 0.78 vs 0.82 M, 20480: 0.97 vs 0.84 M)
+constexpr int kLaneMinBatch = 21504;
+constexpr int kLaneMinBatchOther = 18432;
 
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
@@ -288,7 +292,7 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     const char* v = std::getenv("QMPC_VARIANT");
     h->variant = v ? std::atoi(v) : 0;
     const char* lm = std::getenv("QMPC_LANE_MIN");
-    h->lane_min_batch = lm ? std::atoi(lm) : kLaneMinBatch;
+    h->lane_min_batch = lm ? std::atoi(lm) : (params->model == QMPC_MODEL_QUAT ? kLaneMinBatch : kLaneMinBatchOther);
     h->lane_min_loop_cold = lm ? h->lane_min_batch : kLaneMinLoopCold;
     const char* ls = std::getenv("QMPC_LANE_SORT");
     h->lane_sort = ls ? std::atoi(ls) : 1;

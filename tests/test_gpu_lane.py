@@ -260,7 +260,7 @@ def test_closed_loop_with_the_lane_kernel(pkg, lib, monkeypatch):
 
 
 def test_closed_loop_at_the_automatic_switch_over(pkg, lib):
-    """24576 robots: the batch size from which qmpc_solve* picks the lane kernel by itself; the loop must do the same."""
+    """24576 robots: beyond the batch size from which qmpc_solve* picks the lane kernel by itself; the loop must do the same."""
     lp = pkg.default_loop_params(lib)
     B = 24576
     cmds = np.zeros((B, 7)); cmds[:, 0] = 0.3; cmds[:, 2] = 0.3
