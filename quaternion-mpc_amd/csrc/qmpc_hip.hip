@@ -35,6 +35,13 @@ hipError_t qmpc_warm_launch(int var, int convex, int batch, size_t lds, hipStrea
                             const qmpc_input* in, const double* u_init, double* forces, qmpc_info* info, double* traj_u,
                             double* gws, int check_prev);
 
+// qmpc_wform.hip (fourth translation unit): the wave-per-instance kernel with the wrench-form elimination (small batches)
+size_t qmpc_wform_lds_bytes(int N);
+hipError_t qmpc_wform_set_lds(int bytes);
+hipError_t qmpc_wform_launch(int prof, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
+                             const qmpc_input* in, double* forces, qmpc_info* info, double* traj_u, double* traj_x,
+                             long long* prof_out);
+
 // qmpc_lane.hip (third translation unit): the lane-per-instance kernel of large batches
 size_t qmpc_lane_ws_bytes(int N, int nl, unsigned slots);
 size_t qmpc_lane_scratch_bytes(int batch);
@@ -62,6 +69,8 @@ struct qmpc_handle {
   size_t lds_bytes;       // LDS-resident gains
   size_t lds_bytes_g;     // gains in the global workspace
   size_t lds_bytes_s;     // gains and slack arrays in the global workspace
+  size_t lds_bytes_w;     // the wrench-form kernel (qmpc_wform.hip), everything in LDS
+  int wform;              // 1: batches that keep everything in LDS take the wrench-form kernel (env QMPC_WFORM, default 1)
   int* d_loop_row;        // trace row counter of the closed loop (qmpc_loop_run*)
   double* d_leg;          // staging of the host-buffer leg calls (grown on demand, freed with the handle)
   size_t leg_cap;         // its capacity in doubles
@@ -244,6 +253,7 @@ static qmpc_status create_resources(qmpc_handle* h, int N, int nl, int nu) {
   if (params->model != QMPC_MODEL_QUAT8)
     for (int v = 0; v < 3; ++v) HIP_TRY(qmpc_fused_set_lds(v, 160 * 1024));     // the closed loop's persistent kernels
   if (params->model != QMPC_MODEL_QUAT8) HIP_TRY(qmpc_warm_set_lds(160 * 1024));
+  if (params->model == QMPC_MODEL_QUAT) HIP_TRY(qmpc_wform_set_lds(160 * 1024));
   if (params->mode == QMPC_MODE_REFERENCE) {
     if (params->model == QMPC_MODEL_QUAT8) {
       QMPC_SET_LDS((qmpc_ref_kernel<Quat8Model, 1>), h->lds_bytes_g);     // never everything in LDS
@@ -291,6 +301,9 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
   {
     const char* v = std::getenv("QMPC_VARIANT");
     h->variant = v ? std::atoi(v) : 0;
+    const char* wf = std::getenv("QMPC_WFORM");
+    h->wform = wf ? std::atoi(wf) : 1;
+    h->lds_bytes_w = qmpc_wform_lds_bytes(N);
     const char* lm = std::getenv("QMPC_LANE_MIN");
     h->lane_min_batch = lm ? std::atoi(lm) : (params->model == QMPC_MODEL_QUAT ? kLaneMinBatch : kLaneMinBatchOther);
     h->lane_min_loop_cold = lm ? h->lane_min_batch : kLaneMinLoopCold;
@@ -385,6 +398,13 @@ static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* 
   return QMPC_OK;
 }
 
+// Batches that keep everything in LDS (one instance per SIMD at most) of QuatMpc's problem take the wrench-form kernel
+// (qmpc_wform.hip) when four instances fit a CU with its layout; QMPC_WFORM=0 keeps the round-1 kernel (A/B runs).
+static bool use_wform(const qmpc_handle* h, int32_t batch) {
+  return h->wform && h->params.model == QMPC_MODEL_QUAT && h->params.mode == QMPC_MODE_CONVERGED &&
+         h->lds_bytes_w <= 40 * 1024 && pick_variant(h, batch) == 0;
+}
+
 static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces,
                                 qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s, bool timed = true) {
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;   // the gains workspace is sized by max_batch
@@ -416,6 +436,14 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
   if (use_lane(h, batch, d_tu, d_tx)) {
     const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s, nullptr, d_tu, 0, d_tx);
     if (ls != QMPC_OK) return ls;
+    if (timed) {
+      HIP_TRY(hipEventRecord(h->ev1, s));
+      h->timed = true;
+    }
+    return QMPC_OK;
+  }
+  if (use_wform(h, batch)) {
+    HIP_TRY(qmpc_wform_launch(0, (int)batch, h->lds_bytes_w, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, d_tu, d_tx, nullptr));
     if (timed) {
       HIP_TRY(hipEventRecord(h->ev1, s));
       h->timed = true;
@@ -1117,7 +1145,10 @@ qmpc_status qmpc_debug_profile(qmpc_handle* h, int32_t batch, const qmpc_input* 
   HIP_TRY(hipMalloc(&d_prof, sizeof(long long) * 16 * (size_t)batch));
   HIP_TRY(hipMemsetAsync(d_prof, 0, sizeof(long long) * 16 * (size_t)batch, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_in, in, sizeof(qmpc_input) * (size_t)batch, hipMemcpyHostToDevice, h->stream));
-  if (use_global_gains(h, batch))
+  if (use_wform(h, batch))
+    HIP_TRY(qmpc_wform_launch(1, (int)batch, h->lds_bytes_w, h->stream, &h->dev, sizeof h->dev, h->d_in, h->d_forces, h->d_info,
+                              nullptr, nullptr, d_prof));
+  else if (use_global_gains(h, batch))
     hipLaunchKernelGGL((qmpc_solve_kernel<QuatModel, true, 1>), dim3((unsigned)batch), dim3(kWave), h->lds_bytes_g, h->stream,
                        h->dev, h->d_in, h->d_forces, h->d_info, (double*)nullptr, (double*)nullptr, (int)batch, d_prof,
                        h->d_gws);
