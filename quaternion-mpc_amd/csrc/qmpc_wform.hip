@@ -293,13 +293,24 @@ __device__ __forceinline__ double times_Abar(double x, const ColOps& co, const d
 }
 
 // One Gauss-Jordan step on pivot J < 6 of the pair (M | Rr) held in two fragment registers (rows 0..3 and 4..7):
-// row J is eliminated from every other row (the diagonal is divided out at the end)
+// row J is eliminated from every other row.  Returns -1 / pivot: the diagonal is divided out at the end, and a later step
+// does not touch an earlier pivot (its column is already zero in the later pivot rows).
+// PERM: the pivot row reaches the other row groups through v_permlane16/32_swap (VALU) instead of ds_bpermute (LDS)
+#ifndef QMPC_GJ_PERM
+#define QMPC_GJ_PERM 0
+#endif
 template <int J>
-__device__ __forceinline__ void gj6_step(double M[2], double Rr[2], int c, int g, double& minpiv) {
+__device__ __forceinline__ double gj6_step(double M[2], double Rr[2], int c, int g, double& minpiv) {
   constexpr int ej = J >> 2, gj = J & 3;
-  const int src = (gj << 4) | c;
-  const double mrow = __shfl(M[ej], src);      // row J, same column, all row groups
-  const double rrow = __shfl(Rr[ej], src);
+  double mrow, rrow;
+  if (QMPC_GJ_PERM) {
+    mrow = rowgroup_bcast<gj>(M[ej]);
+    rrow = rowgroup_bcast<gj>(Rr[ej]);
+  } else {
+    const int src = (gj << 4) | c;
+    mrow = __shfl(M[ej], src);      // row J, same column, all row groups
+    rrow = __shfl(Rr[ej], src);
+  }
   const double piv = read_lane(M[ej], (gj << 4) | J);
   minpiv = fmin(minpiv, piv);
   const double ninv = -fast_rcp(piv);
@@ -310,6 +321,7 @@ __device__ __forceinline__ void gj6_step(double M[2], double Rr[2], int c, int g
     M[e] = fma(f, mrow, M[e]);
     Rr[e] = fma(f, rrow, Rr[e]);
   }
+  return ninv;
 }
 
 // Riccati backward pass in the wrench form; writes per knot [Xw | xw] and [Xz | xz] (KD).  Returns nonzero when a pivot
@@ -371,34 +383,45 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
   }
   double minpiv = 1e300;
   const d4 z4 = {0.0, 0.0, 0.0, 0.0};
-  for (int k = N - 1; k >= 0; --k) {
-    // ---- per-knot operands (independent of the cost-to-go) ----
-    const double* ABk = sm + L.AB + kAB * k;
-    const double* GKk = sm + LW.GK + kGK * k;
-    const double* XTk = sm + L.XT + kXT * k;
-    double wt[3], at[3], Mf[3], Nf[2], Gf[2], R6f[2], xt[3];
+  // operands of a knot (independent of the cost-to-go): loaded one knot ahead, right after the first products are issued
+  struct KnotOps { double wt[3], at[3], Mf[3], Nf[2], Gf[2], R6f[2], xt[3]; };
+  auto load_ops = [&](int kk, KnotOps& o) {
+    const double* ABk = sm + L.AB + kAB * kk;
+    const double* GKk = sm + LW.GK + kGK * kk;
+    const double* XTk = sm + L.XT + kXT * kk;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       const double wv = ABk[(co.woff[t] >= 0) ? co.woff[t] : 0];
       const double av = ABk[(co.aoff[t] >= 0) ? co.aoff[t] : 0];
-      wt[t] = (co.woff[t] >= 0) ? wscale * wv : 0.0;
-      at[t] = (co.aoff[t] >= 0) ? av : 0.0;
+      o.wt[t] = (co.woff[t] >= 0) ? wscale * wv : 0.0;
+      o.at[t] = (co.aoff[t] >= 0) ? av : 0.0;
     }
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
       const double mv = ABk[(moff[e] >= 0) ? moff[e] : 0];
-      Mf[e] = (moff[e] >= 0) ? wscale * mv : Mc[e];
-      xt[e] = XTk[(xoff[e] >= 0) ? xoff[e] : 0];
+      o.Mf[e] = (moff[e] >= 0) ? wscale * mv : Mc[e];
+      o.xt[e] = XTk[(xoff[e] >= 0) ? xoff[e] : 0];
     }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const double nv = ABk[(noff[e] >= 0) ? noff[e] : 0];
-      Nf[e] = ((noff[e] >= 0) ? nv : 0.0) + Nc[e];
+      o.Nf[e] = ((noff[e] >= 0) ? nv : 0.0) + Nc[e];
       const double gv = GKk[(goff[e] >= 0) ? goff[e] : 0];
       const double rv = GKk[(roff[e] >= 0) ? roff[e] : 0];
-      Gf[e] = (goff[e] >= 0) ? gv : 0.0;
-      R6f[e] = (roff[e] >= 0) ? rv : 0.0;
+      o.Gf[e] = (goff[e] >= 0) ? gv : 0.0;
+      o.R6f[e] = (roff[e] >= 0) ? rv : 0.0;
     }
+  };
+  KnotOps ops, opn;
+  load_ops(N - 1, ops);
+  for (int k = N - 1; k >= 0; --k) {
+    const double* wt = ops.wt;
+    const double* at = ops.at;
+    const double* Mf = ops.Mf;
+    const double* Nf = ops.Nf;
+    const double* Gf = ops.Gf;
+    const double* R6f = ops.R6f;
+    const double* xt = ops.xt;
     prof.tick(PH_BUILD);
     // ---- 1. Yp = M' [P | p]  (6 x 13) ----
     double Yp[2];
@@ -406,6 +429,7 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
       const d4 a = mtm3(Mf, Pf, z4);
       Yp[0] = a[0]; Yp[1] = a[1];
     }
+    load_ops(k > 0 ? k - 1 : 0, opn);
     // ---- 2. S6 = Yp_fb M  (column operation) ----
     double S6[2];
     S6[0] = times_M(Yp[0], co, wt);
@@ -423,18 +447,15 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
     Wm[1] = S6[1] + times_M(Qf[1], co, wt);
     prof.tick(PH_MFMA);
     // ---- 5. W' X = -Q ----
-    gj6_step<0>(Wm, Qf, c, g, minpiv);
-    gj6_step<1>(Wm, Qf, c, g, minpiv);
-    gj6_step<2>(Wm, Qf, c, g, minpiv);
-    gj6_step<3>(Wm, Qf, c, g, minpiv);
-    gj6_step<4>(Wm, Qf, c, g, minpiv);
-    gj6_step<5>(Wm, Qf, c, g, minpiv);
+    const double n0 = gj6_step<0>(Wm, Qf, c, g, minpiv);
+    const double n1 = gj6_step<1>(Wm, Qf, c, g, minpiv);
+    const double n2 = gj6_step<2>(Wm, Qf, c, g, minpiv);
+    const double n3 = gj6_step<3>(Wm, Qf, c, g, minpiv);
+    const double n4 = gj6_step<4>(Wm, Qf, c, g, minpiv);
+    const double n5 = gj6_step<5>(Wm, Qf, c, g, minpiv);
     double Xf[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const double dg = __shfl(Wm[e], (g << 4) | ((4 * e + g) & 15));      // W'[r][r] lives in lane (g, r)
-      Xf[e] = rowok[e] ? -Qf[e] * fast_rcp(dg) : 0.0;
-    }
+    Xf[0] = Qf[0] * ((g == 0) ? n0 : (g == 1 ? n1 : (g == 2 ? n2 : n3)));      // X = -diag^-1 Q
+    Xf[1] = rowok[1] ? Qf[1] * ((g == 0) ? n4 : n5) : 0.0;
     prof.tick(PH_SOLVE);
     // ---- 6. Pi = [P | p] + Yp_fb' X ;  7. gains [Xz | xz] = Yp + S6 X ----
     double Pi[3];
@@ -466,6 +487,7 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
         if (kwo[e] >= 0) { KDk[kwo[e]] = Xf[e]; KDk[kzo[e]] = Zf[e]; }
       }
     }
+    ops = opn;
     prof.tick(PH_PUPD);
   }
   return !(minpiv > 0.0);   // also true for a NaN pivot
@@ -497,22 +519,57 @@ __device__ __forceinline__ void srbd_step_w(const DevParams& P, const double gb[
     xn[3 + r] = x[3 + r] + P.h * (0.5 * (G[3 * r] * wm[0] + G[3 * r + 1] * wm[1] + G[3 * r + 2] * wm[2]));
 }
 
-// wrench of every knot from the inputs U (+ scale dU): lane (k, i), i < 6
+// wrench of every knot from the inputs U (WITH_DU: U + dU), lane (k, i), i < 6
+template <bool WITH_DU>
 __device__ inline void wrench_from_inputs(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm, int lane) {
   const int N = P.N;
   for (int q = lane; q < 6 * N; q += kWave) {
     const int k = q / 6, i = q - 6 * k;
-    const double* u = sm + L.U + 12 * k;
-    double s0 = 0.0, s1 = 0.0;
-    if (i < 3) {
-      s0 = u[i] + u[6 + i];
-      s1 = u[3 + i] + u[9 + i];
-    } else {
-      const double* b = sm + L.bw0 + 12 * (i - 3);
+    double u[12];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) { s0 += b[j] * u[j]; s1 += b[6 + j] * u[6 + j]; }
+    for (int j = 0; j < 12; ++j) u[j] = sm[L.U + 12 * k + j] + (WITH_DU ? sm[L.dU + 12 * k + j] : 0.0);
+    const double* b = sm + L.bw0 + ((i >= 3) ? 12 * (i - 3) : 0);
+    double s0 = 0.0, s1 = 0.0, f0 = 0.0, f1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { s0 += b[j] * u[j]; s1 += b[6 + j] * u[6 + j]; }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      f0 += (i == a) ? u[a] + u[6 + a] : 0.0;
+      f1 += (i == a) ? u[3 + a] + u[9 + a] : 0.0;
     }
-    sm[LW.WR + q] = s0 + s1;
+    sm[LW.WR + q] = (i < 3) ? f0 + f1 : s0 + s1;
+  }
+  QSYNC();
+}
+
+// shortened primal step: scale the trial increment and re-roll the states open loop from the knots' wrenches
+__device__ inline void rollout_scaled_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm, double ap, int lane) {
+  typedef Dim<4> D;
+  const int N = P.N;
+  const double* cst = sm + L.cst;
+  for (int i = lane; i < N * D::NU; i += kWave) sm[L.dU + i] *= ap;
+  QSYNC();
+  wrench_from_inputs<true>(P, L, LW, sm, lane);
+  double gb[3], wd0[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { gb[a] = cst[D::C_GB + a]; wd0[a] = cst[D::C_WD0 + a]; }
+  double x[13], xn[13], w[6], wn[6];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) x[i] = cst[D::C_X0 + i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) w[i] = sm[LW.WR + i];
+  for (int k = 0; k < N; ++k) {
+    const int kn = (k + 1 < N) ? k + 1 : k;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wn[i] = sm[LW.WR + 6 * kn + i];
+    srbd_step_w(P, gb, wd0, x, w, xn);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) x[i] = xn[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) w[i] = wn[i];
+    if (lane == 0)
+#pragma unroll
+      for (int i = 0; i < 13; ++i) sm[L.Xc + 13 * (k + 1) + i] = xn[i];
   }
   QSYNC();
 }
@@ -666,7 +723,7 @@ __global__ __launch_bounds__(64, 1) void qmpc_solve_w_kernel(
   for (int i = lane; i < N * NU; i += kWave) sm[L.U + i] = sm[L.uref + (i % NU)];      // U = u_ref (QuatMpc.cpp:253)
   QSYNC();
   rollout_open<MD, false>(P, L, sm, lane);
-  wrench_from_inputs(P, L, LW, sm, lane);
+  wrench_from_inputs<false>(P, L, LW, sm, lane);
   expansions<MD>(P, L, sm, lane);
   double sl_part = 0.0, rc_part = 0.0;
   for (int i = lane; i < N * NC; i += kWave) {
@@ -712,14 +769,14 @@ __global__ __launch_bounds__(64, 1) void qmpc_solve_w_kernel(
     ipm_directions<D>(P, L, sm, sl, target, lane, &ap, &ad, &last_step);
     last_ap = ap; last_ad = ad;
     prof.tick(PH_DIRS);
-    if (ap < 1.0) rollout_scaled<MD, false>(P, L, sm, ap, lane);    // shortened primal step
+    if (ap < 1.0) rollout_scaled_w(P, L, LW, sm, ap, lane);    // shortened primal step
     prof.tick(PH_ROLL);
     ipm_apply<D>(P, L, sl, ap, ad, conmask, lane, kapbits, sl_part, rc_part);
     prof.tick(PH_APPLY);
     for (int i = lane; i < N * NU; i += kWave) sm[L.U + i] += sm[L.dU + i];
     for (int i = lane; i < (N + 1) * 13; i += kWave) sm[L.X + i] = sm[L.Xc + i];
     QSYNC();
-    wrench_from_inputs(P, L, LW, sm, lane);
+    wrench_from_inputs<false>(P, L, LW, sm, lane);
     prof.tick(PH_MISC);
     expansions<MD>(P, L, sm, lane);
     prof.tick(PH_EXPAND);
