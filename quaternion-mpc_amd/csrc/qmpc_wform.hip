@@ -247,6 +247,26 @@ __device__ inline void prepass_w(const DevParams& P, const Layout& L, const Layo
   QSYNC();
 }
 
+// diagnostics (PROF builds): a phase boundary pinned between the computation of (a, b) and their uses -- the values
+// pass through one volatile asm before the clock is read and through another one after it
+template <bool PROF>
+__device__ __forceinline__ void tick_dep(Prof<PROF>& prof, int ph, double& a, double& b) {
+  if (PROF) {
+    asm volatile("s_nop 0" : "+v"(a), "+v"(b));
+    prof.tick(ph);
+    asm volatile("s_nop 0" : "+v"(a), "+v"(b));
+  }
+}
+
+template <bool PROF>
+__device__ __forceinline__ void tick_dep1(Prof<PROF>& prof, int ph, double& a) {
+  if (PROF) {
+    asm volatile("s_nop 0" : "+v"(a));
+    prof.tick(ph);
+    asm volatile("s_nop 0" : "+v"(a));
+  }
+}
+
 // ---- pieces of the backward pass ------------------------------------------------------------------------------------
 // acc += X' Y over fragment rows 0..7 (two k-steps): the wrench-space products (K = 6; rows 6, 7 of both operands are 0)
 __device__ __forceinline__ d4 mtm2(const double X[2], const double Y[2], d4 acc) {
@@ -271,25 +291,31 @@ struct ColOps {
     }
   }
 };
+// acc += sum_t x[lane 3 + t of the row] * m[t]: three v_fmac_f64 with a DPP source (row_newbcast on src0 of the 64-bit
+// VOP2 form, gfx90a+).  The leading s_nop covers the VALU-write -> DPP-read hazard, which the compiler does not track
+// through inline asm.
+__device__ __forceinline__ double fma_bcast345(double acc, double x, const double m[3]) {
+  asm("s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %3 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %4 row_newbcast:5 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc)
+      : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]));
+  return acc;
+}
 // x M   (columns 0..5 of the result; M = [[m1 I, 0], [0, Wt], [m2 I, 0], [0, h I]]): lane c < 3 takes m1 x[c] + m2 x[c+6],
 // lane 3 + b takes sum_t x[3+t] Wt[t][b] + h x[9+b]; wt[t] = Wt[t][c-3] on lanes 3..5, 0 elsewhere
 __device__ __forceinline__ double times_M(double x, const ColOps& co, const double wt[3]) {
   double r = co.m1c * x;
   r = fma(co.m2c, dpp_mov<0x106>(x), r);       // row_shl:6: lane c reads lane c + 6
-  r = fma(wt[0], row_bcast<3>(x), r);
-  r = fma(wt[1], row_bcast<4>(x), r);
-  r = fma(wt[2], row_bcast<5>(x), r);
-  return r;
+  return fma_bcast345(r, x, wt);
 }
 // x Abar_aug  (Abar = [[I,0,hI,0],[0,A1,0,A3],[0,0,I,0],[0,0,0,I]], the gradient column 12 untouched):
 // at[t] = A1[t][c-3] on lanes 3..5, A3[t][c-9] on lanes 9..11, 0 elsewhere
 __device__ __forceinline__ double times_Abar(double x, const ColOps& co, const double at[3]) {
   double r = co.keep * x;
   r = fma(co.hsel, dpp_mov<0x116>(x), r);      // row_shr:6: lane c reads lane c - 6
-  r = fma(at[0], row_bcast<3>(x), r);
-  r = fma(at[1], row_bcast<4>(x), r);
-  r = fma(at[2], row_bcast<5>(x), r);
-  return r;
+  return fma_bcast345(r, x, at);
 }
 
 // One Gauss-Jordan step on pivot J < 6 of the pair (M | Rr) held in two fragment registers (rows 0..3 and 4..7):
@@ -334,12 +360,28 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
   const double wscale = (0.5 * P.hh) * P.h;        // Wt = (h^2 / 4) Gn'Gm
   ColOps co;
   co.init(P, c);
-  // fragment patterns, rows r_e = 4 e + g
+  // fragment patterns, rows r_e = 4 e + g.  Every per-knot operand is ONE LDS read at a lane-constant index that steps
+  // back by the record size per knot; lanes outside a pattern read a slot that holds 0.0 (index fixed), so no select
+  // follows the loads.  The Wt block of the M fragment and the A1 / A3 blocks of the N = Abar - I fragment are the
+  // column-operation multipliers wt[], at[] of the same lane.
+  const int zslot = L.cst + 63;
   double Mc[3], Nc[2], qadd[3];
-  int moff[3], noff[2], xoff[3], goff[2], roff[2], kwo[2], kzo[2];
+  double msel[3], nsel[3];          // 1.0 where the lane's fragment row takes wt[t] / at[t]: rows 3 + t
+  int ix_w[3], ix_a[3], ix_x[3], ix_g[2], st_w[3], st_a[3], st_x[3], st_g[2], kwo[2], kzo[2];
+  int xoffN[3];
   bool rowok[2];
   {
     const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const bool wv = co.woff[t] >= 0, av = co.aoff[t] >= 0;
+      ix_w[t] = wv ? L.AB + kAB * (N - 1) + co.woff[t] : zslot;  st_w[t] = wv ? kAB : 0;
+      ix_a[t] = av ? L.AB + kAB * (N - 1) + co.aoff[t] : zslot;  st_a[t] = av ? kAB : 0;
+    }
+    // row 3 + t lives in (e, g) = (0, 3), (1, 0), (1, 1)
+    msel[0] = nsel[0] = (g == 3) ? 1.0 : 0.0;
+    msel[1] = nsel[1] = (g == 0) ? 1.0 : 0.0;
+    msel[2] = nsel[2] = (g == 1) ? 1.0 : 0.0;
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
       const int r = 4 * e + g;
@@ -351,12 +393,14 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
         else if (r >= 9) v = (r - 9 == c - 3) ? P.h : 0.0;
       }
       Mc[e] = v;
-      moff[e] = (phi && c >= 3 && c < 6) ? 18 + 3 * (r - 3) + (c - 3) : -1;
       const bool cval = c < 12;
       qadd[e] = (cval && r == c && !phi) ? P.Q[(r < 3) ? r : r + 1] : 0.0;
-      xoff[e] = -1;
-      if (phi && c >= 3 && c < 6) xoff[e] = 3 * (r - 3) + (c - 3);
-      if (c == 12) xoff[e] = 9 + r;
+      int xo = -1;
+      if (phi && c >= 3 && c < 6) xo = 3 * (r - 3) + (c - 3);
+      if (c == 12) xo = 9 + r;
+      xoffN[e] = xo;
+      ix_x[e] = (xo >= 0) ? L.XT + kXT * (N - 1) + xo : zslot;
+      st_x[e] = (xo >= 0) ? kXT : 0;
     }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -364,12 +408,12 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
       const bool phi = (r >= 3 && r < 6);
       // N = Abar - I, rows 0..7 (rows 6, 7 are zero)
       Nc[e] = (r < 3 && c == r + 6) ? P.h : ((phi && r == c) ? -1.0 : 0.0);
-      noff[e] = -1;
-      if (phi && c >= 3 && c < 6) noff[e] = 3 * (r - 3) + (c - 3);
-      if (phi && c >= 9 && c < 12) noff[e] = 9 + 3 * (r - 3) + (c - 9);
       rowok[e] = r < 6;
-      goff[e] = (r < 6 && c < 6) ? S6I(r, c) : -1;
-      roff[e] = (r < 6 && c == 12) ? 21 + r : -1;
+      // G (columns 0..5) and r6 (column 12) share a register: as the A operand of G Yp the column 12 only feeds the
+      // unused output row 12
+      const int go = (r < 6 && c < 6) ? S6I(r, c) : ((r < 6 && c == 12) ? 21 + r : -1);
+      ix_g[e] = (go >= 0) ? LW.GK + kGK * (N - 1) + go : zslot;
+      st_g[e] = (go >= 0) ? kGK : 0;
       kwo[e] = (r < 6 && c < 13) ? 13 * r + c : -1;
       kzo[e] = (r < 6 && c < 13) ? 13 * (6 + r) + c : -1;
     }
@@ -379,57 +423,46 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
   {
     const double* XTk = sm + L.XT + kXT * N;
 #pragma unroll
-    for (int e = 0; e < 3; ++e) Pf[e] = qadd[e] + ((xoff[e] >= 0) ? XTk[xoff[e]] : 0.0);
+    for (int e = 0; e < 3; ++e) Pf[e] = qadd[e] + ((xoffN[e] >= 0) ? XTk[xoffN[e]] : 0.0);
   }
   double minpiv = 1e300;
   const d4 z4 = {0.0, 0.0, 0.0, 0.0};
   // operands of a knot (independent of the cost-to-go): loaded one knot ahead, right after the first products are issued
-  struct KnotOps { double wt[3], at[3], Mf[3], Nf[2], Gf[2], R6f[2], xt[3]; };
-  auto load_ops = [&](int kk, KnotOps& o) {
-    const double* ABk = sm + L.AB + kAB * kk;
-    const double* GKk = sm + LW.GK + kGK * kk;
-    const double* XTk = sm + L.XT + kXT * kk;
+  struct KnotOps { double wt[3], at[3], gr[2], xt[3]; };
+  auto load_ops = [&](KnotOps& o) {       // the knot the running indices point at; then one knot back
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-      const double wv = ABk[(co.woff[t] >= 0) ? co.woff[t] : 0];
-      const double av = ABk[(co.aoff[t] >= 0) ? co.aoff[t] : 0];
-      o.wt[t] = (co.woff[t] >= 0) ? wscale * wv : 0.0;
-      o.at[t] = (co.aoff[t] >= 0) ? av : 0.0;
+      o.wt[t] = sm[ix_w[t]]; o.at[t] = sm[ix_a[t]]; o.xt[t] = sm[ix_x[t]];
+      ix_w[t] -= st_w[t]; ix_a[t] -= st_a[t]; ix_x[t] -= st_x[t];
     }
 #pragma unroll
-    for (int e = 0; e < 3; ++e) {
-      const double mv = ABk[(moff[e] >= 0) ? moff[e] : 0];
-      o.Mf[e] = (moff[e] >= 0) ? wscale * mv : Mc[e];
-      o.xt[e] = XTk[(xoff[e] >= 0) ? xoff[e] : 0];
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const double nv = ABk[(noff[e] >= 0) ? noff[e] : 0];
-      o.Nf[e] = ((noff[e] >= 0) ? nv : 0.0) + Nc[e];
-      const double gv = GKk[(goff[e] >= 0) ? goff[e] : 0];
-      const double rv = GKk[(roff[e] >= 0) ? roff[e] : 0];
-      o.Gf[e] = (goff[e] >= 0) ? gv : 0.0;
-      o.R6f[e] = (roff[e] >= 0) ? rv : 0.0;
-    }
+    for (int e = 0; e < 2; ++e) { o.gr[e] = sm[ix_g[e]]; ix_g[e] -= st_g[e]; }
   };
   KnotOps ops, opn;
-  load_ops(N - 1, ops);
+  load_ops(ops);
   for (int k = N - 1; k >= 0; --k) {
-    const double* wt = ops.wt;
+    double wt[3], Mf[3], Nf[2], R6f[2];
     const double* at = ops.at;
-    const double* Mf = ops.Mf;
-    const double* Nf = ops.Nf;
-    const double* Gf = ops.Gf;
-    const double* R6f = ops.R6f;
+    const double* Gf = ops.gr;
     const double* xt = ops.xt;
-    prof.tick(PH_BUILD);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) wt[t] = wscale * ops.wt[t];
+    Mf[0] = fma(msel[0], wt[0], Mc[0]);
+    Mf[1] = fma(msel[1], wt[1], fma(msel[2], wt[2], Mc[1]));
+    Mf[2] = Mc[2];
+    Nf[0] = fma(nsel[0], at[0], Nc[0]);
+    Nf[1] = fma(nsel[1], at[1], fma(nsel[2], at[2], Nc[1]));
+    R6f[0] = (c == 12) ? ops.gr[0] : 0.0;
+    R6f[1] = (c == 12) ? ops.gr[1] : 0.0;
+    tick_dep(prof, PH_BUILD, Pf[0], Pf[1]);
     // ---- 1. Yp = M' [P | p]  (6 x 13) ----
     double Yp[2];
     {
       const d4 a = mtm3(Mf, Pf, z4);
       Yp[0] = a[0]; Yp[1] = a[1];
     }
-    load_ops(k > 0 ? k - 1 : 0, opn);
+    if (k > 0) load_ops(opn);
+    tick_dep(prof, PH_DRAIN, Yp[0], Yp[1]);
     // ---- 2. S6 = Yp_fb M  (column operation) ----
     double S6[2];
     S6[0] = times_M(Yp[0], co, wt);
@@ -445,7 +478,7 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
     }
     Wm[0] = S6[0] + times_M(Qf[0], co, wt);
     Wm[1] = S6[1] + times_M(Qf[1], co, wt);
-    prof.tick(PH_MFMA);
+    tick_dep(prof, PH_MFMA, Wm[0], Wm[1]);
     // ---- 5. W' X = -Q ----
     const double n0 = gj6_step<0>(Wm, Qf, c, g, minpiv);
     const double n1 = gj6_step<1>(Wm, Qf, c, g, minpiv);
@@ -456,7 +489,7 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
     double Xf[2];
     Xf[0] = Qf[0] * ((g == 0) ? n0 : (g == 1 ? n1 : (g == 2 ? n2 : n3)));      // X = -diag^-1 Q
     Xf[1] = rowok[1] ? Qf[1] * ((g == 0) ? n4 : n5) : 0.0;
-    prof.tick(PH_SOLVE);
+    tick_dep(prof, PH_SOLVE, Xf[0], Xf[1]);
     // ---- 6. Pi = [P | p] + Yp_fb' X ;  7. gains [Xz | xz] = Yp + S6 X ----
     double Pi[3];
     {
@@ -475,8 +508,7 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
 #pragma unroll
     for (int e = 0; e < 3; ++e) Uf[e] = times_Abar(Pi[e], co, at);
     {
-      const d4 ini = {Uf[0] + qadd[0] + ((xoff[0] >= 0) ? xt[0] : 0.0), Uf[1] + qadd[1] + ((xoff[1] >= 0) ? xt[1] : 0.0),
-                      Uf[2] + qadd[2] + ((xoff[2] >= 0) ? xt[2] : 0.0), 0.0};
+      const d4 ini = {Uf[0] + (qadd[0] + xt[0]), Uf[1] + (qadd[1] + xt[1]), Uf[2] + (qadd[2] + xt[2]), 0.0};
       const d4 a = mtm2(Nf, Uf, ini);
       Pf[0] = a[0]; Pf[1] = a[1]; Pf[2] = a[2];
     }
@@ -488,7 +520,7 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
       }
     }
     ops = opn;
-    prof.tick(PH_PUPD);
+    tick_dep(prof, PH_PUPD, Pf[0], Pf[1]);
   }
   return !(minpiv > 0.0);   // also true for a NaN pivot
 }
@@ -628,13 +660,13 @@ __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, con
     const double p3 = kd[9] * e[9] + kd[10] * e[10] + kd[11] * e[11];
     const double s = (p0 + p1) + (p2 + p3);
     if (zlane) ROT[zeta_slot(k, lane - 6)] = s;      // the costate of the contact points, for the input recovery
-    const double wn = cur.wk + s;
-    prof.tick(PH_R_GAIN);
+    double wn = cur.wk + s;
+    tick_dep1(prof, PH_R_GAIN, wn);
     if (k + 1 < N) roll_load_w(L, LW, sm, KD, k + 1, row, wi, nxt);      // one knot ahead
     double w[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) w[i] = read_lane(wn, i);
-    prof.tick(PH_R_BCAST);
+    tick_dep(prof, PH_R_BCAST, w[0], w[5]);
     srbd_step_w(P, gb, wd0, xc, w, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) xc[i] = xn[i];
@@ -642,7 +674,7 @@ __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, con
 #pragma unroll
       for (int i = 0; i < 13; ++i) sm[L.Xc + 13 * (k + 1) + i] = xn[i];
     cur = nxt;
-    prof.tick(PH_R_STEP);
+    tick_dep(prof, PH_R_STEP, xc[3], xc[10]);
   }
   QSYNC();
 }
@@ -720,6 +752,7 @@ __global__ __launch_bounds__(64, 1) void qmpc_solve_w_kernel(
   unsigned conmask = 0;
   for (int l = 0; l < MD::NL; ++l) conmask |= (sm[L.cst + D::C_CON + l] != 0.0) ? (1u << l) : 0u;
   conmask = __builtin_amdgcn_readfirstlane(conmask);
+  if (lane == 0) sm[L.cst + 63] = 0.0;      // the zero the masked operand reads of the backward pass point at
   for (int i = lane; i < N * NU; i += kWave) sm[L.U + i] = sm[L.uref + (i % NU)];      // U = u_ref (QuatMpc.cpp:253)
   QSYNC();
   rollout_open<MD, false>(P, L, sm, lane);
