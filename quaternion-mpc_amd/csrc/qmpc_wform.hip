@@ -294,7 +294,11 @@ struct ColOps {
 // acc += sum_t x[lane 3 + t of the row] * m[t]: three v_fmac_f64 with a DPP source (row_newbcast on src0 of the 64-bit
 // VOP2 form, gfx90a+).  The leading s_nop covers the VALU-write -> DPP-read hazard, which the compiler does not track
 // through inline asm.
+#ifndef QMPC_COL_FUSED
+#define QMPC_COL_FUSED 1
+#endif
 __device__ __forceinline__ double fma_bcast345(double acc, double x, const double m[3]) {
+#if QMPC_COL_FUSED
   asm("s_nop 1\n\t"
       "v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
       "v_fmac_f64_dpp %0, %1, %3 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
@@ -302,6 +306,11 @@ __device__ __forceinline__ double fma_bcast345(double acc, double x, const doubl
       : "+v"(acc)
       : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]));
   return acc;
+#else
+  acc = fma(m[0], row_bcast<3>(x), acc);
+  acc = fma(m[1], row_bcast<4>(x), acc);
+  return fma(m[2], row_bcast<5>(x), acc);
+#endif
 }
 // x M   (columns 0..5 of the result; M = [[m1 I, 0], [0, Wt], [m2 I, 0], [0, h I]]): lane c < 3 takes m1 x[c] + m2 x[c+6],
 // lane 3 + b takes sum_t x[3+t] Wt[t][b] + h x[9+b]; wt[t] = Wt[t][c-3] on lanes 3..5, 0 elsewhere
@@ -325,6 +334,9 @@ __device__ __forceinline__ double times_Abar(double x, const ColOps& co, const d
 #ifndef QMPC_GJ_PERM
 #define QMPC_GJ_PERM 0
 #endif
+#ifndef QMPC_GJ_FUSED
+#define QMPC_GJ_FUSED 0     // measured: 1.76 M against 1.82 M solves/s -- the 64-bit DPP form issues slower than mov + fma
+#endif
 template <int J>
 __device__ __forceinline__ double gj6_step(double M[2], double Rr[2], int c, int g, double& minpiv) {
   constexpr int ej = J >> 2, gj = J & 3;
@@ -340,6 +352,19 @@ __device__ __forceinline__ double gj6_step(double M[2], double Rr[2], int c, int
   const double piv = read_lane(M[ej], (gj << 4) | J);
   minpiv = fmin(minpiv, piv);
   const double ninv = -fast_rcp(piv);
+#if QMPC_GJ_FUSED
+  // X[r][c] += X[r][J] * (-row_J[c] / piv) as ONE v_fmac_f64 with a DPP source per fragment register; the DPP row mask
+  // (one bit per row group) leaves the pivot row itself untouched.  The right-hand side first: it reads the old column J.
+  const double nm = ninv * mrow, nr = ninv * rrow;
+  constexpr int m0 = (ej == 0) ? (0xf ^ (1 << gj)) : 0xf, m1 = (ej == 1) ? (0xf ^ (1 << gj)) : 0xf;
+  asm("s_nop 1\n\t"
+      "v_fmac_f64_dpp %2, %0, %5 row_newbcast:%6 row_mask:%7 bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %3, %1, %5 row_newbcast:%6 row_mask:%8 bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %0, %4 row_newbcast:%6 row_mask:%7 bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %1, %4 row_newbcast:%6 row_mask:%8 bank_mask:0xf"
+      : "+v"(M[0]), "+v"(M[1]), "+v"(Rr[0]), "+v"(Rr[1])
+      : "v"(nm), "v"(nr), "n"(J), "n"(m0), "n"(m1));
+#else
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const double col = row_bcast<J>(M[e]);
@@ -347,6 +372,7 @@ __device__ __forceinline__ double gj6_step(double M[2], double Rr[2], int c, int
     M[e] = fma(f, mrow, M[e]);
     Rr[e] = fma(f, rrow, Rr[e]);
   }
+#endif
   return ninv;
 }
 
@@ -639,9 +665,9 @@ __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, con
   if (lane == 0)
 #pragma unroll
     for (int i = 0; i < 13; ++i) sm[L.Xc + i] = xc[i];
-  RollLoadsW cur, nxt;
-  roll_load_w(L, LW, sm, KD, 0, row, wi, cur);
-  for (int k = 0; k < N; ++k) {
+  // one knot: gains / old state / Jacobian blocks in `cur`, the next knot's loaded into `nxt` meanwhile (the loop body is
+  // instantiated twice with the roles swapped: no register copies)
+  auto knot = [&](int k, const RollLoadsW& cur, RollLoadsW& nxt) {
     double dx[12], e[12];
     QuatModel::state_diff(cur.xo, xc, dx);
     // e = Abar dx
@@ -673,8 +699,13 @@ __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, con
     if (lane == 0)
 #pragma unroll
       for (int i = 0; i < 13; ++i) sm[L.Xc + 13 * (k + 1) + i] = xn[i];
-    cur = nxt;
     tick_dep(prof, PH_R_STEP, xc[3], xc[10]);
+  };
+  RollLoadsW ra, rb;
+  roll_load_w(L, LW, sm, KD, 0, row, wi, ra);
+  for (int k = 0; k < N; k += 2) {
+    knot(k, ra, rb);
+    if (k + 1 < N) knot(k + 1, rb, ra);
   }
   QSYNC();
 }
