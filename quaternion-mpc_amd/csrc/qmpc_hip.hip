@@ -251,7 +251,7 @@ static qmpc_status create_resources(qmpc_handle* h, int N, int nl, int nu) {
     QMPC_SET_LDS(qmpc_linearize_kernel<QuatModel>, h->lds_bytes_g);
   }
   if (params->model != QMPC_MODEL_QUAT8)
-    for (int v = 0; v < 3; ++v) HIP_TRY(qmpc_fused_set_lds(v, 160 * 1024));     // the closed loop's persistent kernels
+    for (int v = 0; v < 4; ++v) HIP_TRY(qmpc_fused_set_lds(v, 160 * 1024));     // the closed loop's persistent kernels
   if (params->model != QMPC_MODEL_QUAT8) HIP_TRY(qmpc_warm_set_lds(160 * 1024));
   if (params->model == QMPC_MODEL_QUAT) HIP_TRY(qmpc_wform_set_lds(160 * 1024));
   if (params->mode == QMPC_MODE_REFERENCE) {
@@ -404,6 +404,15 @@ static bool use_wform(const qmpc_handle* h, int32_t batch) {
   return h->wform && h->params.model == QMPC_MODEL_QUAT && h->params.mode == QMPC_MODE_CONVERGED &&
          h->lds_bytes_w <= 40 * 1024 && pick_variant(h, batch) == 0;
 }
+
+// variant of the converged-mode kernels that share a body (plain solve, warm-started solve, persistent loop kernel):
+// pick_variant's 0 / 1 / 2, or 3 = the wrench form where it applies -- the three launch forms must agree, they are
+// bit-identical only on the same body
+static int body_variant(const qmpc_handle* h, int32_t batch) { return use_wform(h, batch) ? 3 : pick_variant(h, batch); }
+static size_t variant_lds(const qmpc_handle* h, int var) {
+  return var == 3 ? h->lds_bytes_w : (var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes));
+}
+static double* variant_gws(const qmpc_handle* h, int var) { return (var == 1 || var == 2) ? h->d_gws : nullptr; }
 
 static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces,
                                 qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s, bool timed = true) {
@@ -559,10 +568,9 @@ qmpc_status qmpc_solve_warm_device(qmpc_handle* h, int32_t batch, const qmpc_inp
   HIP_TRY(hipSetDevice(h->device));
   if (use_lane(h, batch, nullptr, nullptr))      // large batches: the lane-per-instance kernel, same start rule
     return launch_lane(h, batch, d_in, d_forces_body, d_info, stream ? (hipStream_t)stream : h->stream, d_u_init, d_traj_u, 0);
-  const int var = pick_variant(h, batch);
-  const size_t lds = var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes);
-  HIP_TRY(qmpc_warm_launch(var, 0, (int)batch, lds, stream ? (hipStream_t)stream : h->stream, &h->dev, sizeof h->dev, d_in, d_u_init,
-                           d_forces_body, d_info, d_traj_u, var >= 1 ? h->d_gws : nullptr, 0));
+  const int var = body_variant(h, batch);
+  HIP_TRY(qmpc_warm_launch(var, 0, (int)batch, variant_lds(h, var), stream ? (hipStream_t)stream : h->stream, &h->dev, sizeof h->dev, d_in, d_u_init,
+                           d_forces_body, d_info, d_traj_u, variant_gws(h, var), 0));
   return QMPC_OK;
 }
 
@@ -989,10 +997,9 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
                                          /*check_prev=*/1);
       if (st != QMPC_OK) return st;
     } else if (warm) {
-      const int var = pick_variant(h, batch);
-      const size_t lds = var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes);
-      HIP_TRY(qmpc_warm_launch(var, convex ? 1 : 0, (int)batch, lds, s, &h->dev, sizeof h->dev, h->d_in, first ? nullptr : h->d_traj_u,
-                               h->d_forces, h->d_info, h->d_traj_u, var >= 1 ? h->d_gws : nullptr, /*check_prev=*/1));
+      const int var = body_variant(h, batch);
+      HIP_TRY(qmpc_warm_launch(var, convex ? 1 : 0, (int)batch, variant_lds(h, var), s, &h->dev, sizeof h->dev, h->d_in, first ? nullptr : h->d_traj_u,
+                               h->d_forces, h->d_info, h->d_traj_u, variant_gws(h, var), /*check_prev=*/1));
     } else {
       const qmpc_status st = launch_solve(h, batch, h->d_in, h->d_forces, h->d_info, nullptr, nullptr, s, /*timed=*/false);
       if (st != QMPC_OK) return st;
@@ -1027,10 +1034,9 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   if (fused) {
     const bool ref = h->params.mode == QMPC_MODE_REFERENCE;
     // the reference-mode kernels exist with everything in LDS (0) and with the gains in the workspace (1): launch_solve's rule
-    const int var = ref ? ((batch > 1024 || h->lds_bytes > 40 * 1024 || h->variant >= 2) ? 1 : 0) : pick_variant(h, batch);
-    const size_t lds = var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes);
-    HIP_TRY(qmpc_fused_launch(var, ref ? 1 : 0, convex ? 1 : 0, (int)batch, lds, s, &h->dev, sizeof h->dev, &LP, d_states, h->d_in, h->d_forces,
-                              h->d_info, d_trace_forces, d_trace_contacts, (int)ticks, var >= 1 ? h->d_gws : nullptr, g,
+    const int var = ref ? ((batch > 1024 || h->lds_bytes > 40 * 1024 || h->variant >= 2) ? 1 : 0) : body_variant(h, batch);
+    HIP_TRY(qmpc_fused_launch(var, ref ? 1 : 0, convex ? 1 : 0, (int)batch, variant_lds(h, var), s, &h->dev, sizeof h->dev, &LP, d_states, h->d_in, h->d_forces,
+                              h->d_info, d_trace_forces, d_trace_contacts, (int)ticks, variant_gws(h, var), g,
                               d_joint_pos, d_cmd, d_trace_cmd));
     return QMPC_OK;
   }

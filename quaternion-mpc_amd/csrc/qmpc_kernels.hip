@@ -954,7 +954,7 @@ __device__ inline double cost_plain(const DevParams& P, const Layout& L, double*
 // VAR 0: everything in LDS; 1: gains / rotation blocks in the global workspace gws (one slice per instance);
 // 2: the slack / multiplier arrays there as well
 #define QMPC_SOLVE_WAVES(MD, VAR) \
-  ((VAR) == 0 ? 1 : (MD::NL != 4 ? ((VAR) == 2 ? QMPC_NL8_WAVES : 1) : ((VAR) == 2 ? QMPC_V2_WAVES : 2)))
+  ((VAR) == 0 || (VAR) == 3 ? 1 : (MD::NL != 4 ? ((VAR) == 2 ? QMPC_NL8_WAVES : 1) : ((VAR) == 2 ? QMPC_V2_WAVES : 2)))
 template <class MD, bool PROF, int VAR>
 __global__ __launch_bounds__(64, QMPC_SOLVE_WAVES(MD, VAR)) void qmpc_solve_kernel(
     DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,

@@ -400,6 +400,9 @@ __global__ __launch_bounds__(64) void qmpc_loop_post_kernel(DevParams P, qmpc_lo
 #endif
 
 #ifdef QMPC_FUSED_TU      // compiled in its own translation unit (qmpc_loop_fused.hip)
+}  // namespace qmpc
+#include "qmpc_wform.h"     // VAR == 3: the solve in the wrench form (QuatMpc's problem, everything in LDS)
+namespace qmpc {
 // ---- the whole loop in ONE launch: a persistent wave per robot ------------------------------------------------
 // The robots of a batch do not interact, so nothing forces them to advance in lock-step: with one launch sequence per
 // tick every tick lasts as long as its slowest solve (mean / max of the iteration counts ~0.63 at 1024 robots), and
@@ -414,6 +417,7 @@ struct FusedJoint {          // the joint level closing every tick (JOINT instan
   qmpc_joint_command* cmd;
   qmpc_joint_command* trace;
 };
+// VAR: 0 / 1 / 2 as in qmpc_solve_kernel; 3: the wrench-form body (qmpc_wform_body.inc; QuatMpc's problem, converged mode)
 // REF: the reference's own solver mode (AL-iLQR, <= 10 iterations; one wave per SIMD like qmpc_ref_kernel, VAR 0 / 1)
 // CONVEX: the sibling controller's problem (ConvexModel; converged mode only)
 template <int VAR, bool JOINT, bool REF, bool CONVEX = false>
@@ -440,6 +444,11 @@ __global__ __launch_bounds__(64, REF ? 1 : QMPC_SOLVE_WAVES(QuatModel, VAR)) voi
     if (REF) {
       [&]() {                             // `return` in the body (rejected input) ends this tick's solve only
 #include "qmpc_ref_body.inc"
+      }();
+    } else if constexpr (VAR == 3) {
+      [&]() {
+        const int warm_t = (LP.warm_start != 0.0 && prev_ok) ? t : 0;   // t > 0 and the last solve left a usable U in LDS
+#include "qmpc_wform_body.inc"
       }();
     } else {
       [&]() {
@@ -485,11 +494,16 @@ __global__ __launch_bounds__(64, QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_sol
   const bool usable = u_init && (!check_prev || info[b].status == QMPC_OK || info[b].status == QMPC_MAX_ITER);
   const int warm_t = usable ? 1 : 0;
   if (usable) {
-    const Layout Lw = make_layout(P.N, VAR >= 1, MD::NL, VAR == 2);
+    LayoutW LWw;
+    const Layout Lw = (VAR == 3) ? make_layout_w(P.N, &LWw) : make_layout(P.N, VAR == 1 || VAR == 2, MD::NL, VAR == 2);
     for (int i = lane; i < P.N * 12; i += kWave) sm[Lw.U + i] = u_init[(size_t)b * P.N * 12 + i];
     __syncthreads();
   }
+  if constexpr (VAR == 3) {
+#include "qmpc_wform_body.inc"
+  } else {
 #include "qmpc_solve_body.inc"
+  }
 }
 #endif
 

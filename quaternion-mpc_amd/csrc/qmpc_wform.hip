@@ -29,723 +29,15 @@
 // a row of Xw, lanes 6..11 a row of Xz (their costates are parked for the input recovery, which runs lane-parallel
 // over (knot, contact point) after the rollout), six values are broadcast per knot instead of twelve.
 //
-// The shared sources are included under another namespace name (like qmpc_loop_fused.hip): a code object of its own,
-// so the round-1 kernels keep their code generation to the byte.
+// The algebra lives in qmpc_wform.h, the body of a solve in qmpc_wform_body.inc (shared with the closed loop's kernels);
+// this file is the plain solve kernel and its launcher.  The shared sources are included under another namespace name
+// (like qmpc_loop_fused.hip): a code object of its own, so the round-1 kernels keep their code generation to the byte.
 #define QMPC_FUSED_TU 1
 #define qmpc qmpc_wform_tu
 #include "qmpc_kernels.hip"
-#undef qmpc
+#include "qmpc_wform.h"
 
-#include <cstring>
-
-namespace qmpc_wform_tu {
-
-// ---- LDS layout: that of the all-LDS variant, the set-up scratch aliased onto the slack array, plus per knot the
-// wrench-space blocks G (21, symmetric) and r6 (6) of the contact points and the wrench Wr u_k (6) ------------------
-struct LayoutW {
-  int GK, WR;
-};
-constexpr int kGK = 27;
-__host__ __device__ inline Layout make_layout_w(int N, LayoutW* W) {
-  Layout L;
-  int o = 0;
-  auto take = [&](int n) { int r = o; o += n; return r; };
-  constexpr int nu = 12, nc = 24, nl = 4;
-  L.cst = take(64);
-  L.bw0 = take(3 * nu);
-  L.refp = take(13);
-  L.uref = take(nu);
-  L.X = take((N + 1) * 13);
-  L.U = take(N * nu);
-  L.Xc = take((N + 1) * 13);
-  L.dU = take(N * nu);
-  L.S = take(N * nc);
-  L.LAM = take(N * nc);
-  L.DS = take(N * nc);
-  L.DLAM = take(N * nc);
-  L.RC = take(N * nc);
-  L.AB = take(N * kAB);
-  L.XT = take((N + 1) * kXT);
-  L.KD = take(N * 13 * nu);       // per knot [Xw | xw] (rows 0..5) and [Xz | xz] (rows 6..11), 13 entries per row
-  L.ROT = take(N * 21 * nl);      // per (knot, point): T (9), l10 l20 l21, id0 id1 id2, gq (3), 3 spare (zeta, below)
-  W->GK = take(N * kGK);
-  W->WR = take(N * 6);
-  L.tile = L.S;                   // set-up scratch (one record): the slack arrays are initialised after it
-  L.total = (o + 1) & ~1;
-  return L;
-}
-// the costate zeta_k (6) of the trial rollout is parked in the spare slots of the knot's first two ROT records
-__device__ __forceinline__ int zeta_slot(int k, int i) { return 84 * k + 21 * (i / 3) + 18 + (i % 3); }
-
-constexpr int S6I_(int i, int j) { return i * 6 - i * (i - 1) / 2 + (j - i); }
-__host__ __device__ constexpr int S6I(int i, int j) { return i <= j ? S6I_(i, j) : S6I_(j, i); }
-
-// ---- pre-pass over (knot, contact point), one lane each: barrier weights, rotated frame, L D L' of the 3 x 3 block,
-// and the point's share of G = sum V D^-1 V', r6 = sum V D^-1 g (the arithmetic of rotation_prepass in
-// qmpc_kernels.hip followed by leg_block / pass B step 1 of qmpc_lane_core.h).  The four points of a knot sit in one
-// lane quad: their shares are summed with quad_perm moves and lane 0 of the quad stores the knot's 27 numbers. ----
-__device__ inline void prepass_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm, const double* sl,
-                                 double* ROT, double target, int lane) {
-  typedef Dim<4> D;
-  const int N = P.N;
-  const double* cst = sm + L.cst;
-  double cr[18];
-#pragma unroll
-  for (int i = 0; i < 18; ++i) cr[i] = cst[D::C_CR + i];
-  for (int q0 = 0; q0 < 4 * N; q0 += kWave) {
-    const int q = q0 + lane;
-    const bool live = q < 4 * N;
-    const int k = live ? (q >> 2) : 0, l = q & 3;
-    double* out = ROT + D::ROT * k + 21 * l;
-    double acc[kGK];
-#pragma unroll
-    for (int i = 0; i < kGK; ++i) acc[i] = 0.0;
-    const bool stance = live && cst[D::C_CON + l] != 0.0;
-    if (live && !stance) {
-      out[0] = 1; out[1] = 0; out[2] = 0; out[3] = 0; out[4] = 1; out[5] = 0; out[6] = 0; out[7] = 0; out[8] = 1;
-      out[9] = 0; out[10] = 0; out[11] = 0; out[12] = 1; out[13] = 1; out[14] = 1; out[15] = 0; out[16] = 0; out[17] = 0;
-    }
-    if (stance) {
-      const double R0 = P.R[3 * l], R1 = P.R[3 * l + 1], R2 = P.R[3 * l + 2];
-      double w[6], gi[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const double lam = sl[L.LAM + D::NC * k + 6 * l + i];
-        const double rc = sl[L.RC + D::NC * k + 6 * l + i];
-        const double s = sl[L.S + D::NC * k + 6 * l + i];
-        const double kap = sl[L.DS + D::NC * k + 6 * l + i];     // weakly-active flag (see ipm_apply)
-        const double is = fast_rcp(s);
-        w[i] = lam * is;
-        gi[i] = (target + lam * rc) * is - kap * lam;
-      }
-      // heaviest row i1, second heaviest non-(anti)parallel row i2 (rows 4,5 are antiparallel)
-      int i1 = 0;
-      double w1 = w[0];
-#pragma unroll
-      for (int i = 1; i < 6; ++i) if (w[i] > w1) { w1 = w[i]; i1 = i; }
-      int i2 = -1;
-      double w2 = -1.0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const bool skip = (i == i1) || ((i1 >= 4) && (i >= 4));
-        if (!skip && w[i] > w2) { w2 = w[i]; i2 = i; }
-      }
-      double a1[3] = {0, 0, 0}, a2[3] = {0, 0, 0};
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          a1[a] = (i == i1) ? cr[3 * i + a] : a1[a];
-          a2[a] = (i == i2) ? cr[3 * i + a] : a2[a];
-        }
-      const double in1 = fast_rsqrt(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
-      double q1[3], q2[3], q3[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) q1[a] = a1[a] * in1;
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const double dp = a2[0] * q1[0] + a2[1] * q1[1] + a2[2] * q1[2];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) a2[a] -= dp * q1[a];
-      }
-      const double in2 = fast_rsqrt(a2[0] * a2[0] + a2[1] * a2[1] + a2[2] * a2[2]);
-#pragma unroll
-      for (int a = 0; a < 3; ++a) q2[a] = a2[a] * in2;
-      q3[0] = q1[1] * q2[2] - q1[2] * q2[1];
-      q3[1] = q1[2] * q2[0] - q1[0] * q2[2];
-      q3[2] = q1[0] * q2[1] - q1[1] * q2[0];
-      double T[9];  // T[3a+b] = (q_b)_a
-#pragma unroll
-      for (int a = 0; a < 3; ++a) { T[3 * a] = q1[a]; T[3 * a + 1] = q2[a]; T[3 * a + 2] = q3[a]; }
-      const double Rl[3] = {R0, R1, R2};
-      const double* u = sm + L.U + D::NU * k + 3 * l;
-      const double* ur = sm + L.uref + 3 * l;
-      const double ru[3] = {R0 * (u[0] - ur[0]), R1 * (u[1] - ur[1]), R2 * (u[2] - ur[2])};
-      double gq[3];
-      double d00, d01, d02, d11, d12, d22;
-      {
-        double tr[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) tr[i] = T[i] * Rl[i / 3];
-        d00 = tr[0] * T[0] + tr[3] * T[3] + tr[6] * T[6];
-        d01 = tr[0] * T[1] + tr[3] * T[4] + tr[6] * T[7];
-        d02 = tr[0] * T[2] + tr[3] * T[5] + tr[6] * T[8];
-        d11 = tr[1] * T[1] + tr[4] * T[4] + tr[7] * T[7];
-        d12 = tr[1] * T[2] + tr[4] * T[5] + tr[7] * T[8];
-        d22 = tr[2] * T[2] + tr[5] * T[5] + tr[8] * T[8];
-      }
-#pragma unroll
-      for (int a = 0; a < 3; ++a) gq[a] = T[a] * ru[0] + T[3 + a] * ru[1] + T[6 + a] * ru[2];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        double at[3];  // rotated row
-#pragma unroll
-        for (int b = 0; b < 3; ++b) at[b] = T[b] * cr[3 * i] + T[3 + b] * cr[3 * i + 1] + T[6 + b] * cr[3 * i + 2];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) gq[a] += gi[i] * at[a];
-        const double w0 = w[i] * at[0], w1_ = w[i] * at[1];
-        d00 += w0 * at[0]; d01 += w0 * at[1]; d02 += w0 * at[2];
-        d11 += w1_ * at[1]; d12 += w1_ * at[2];
-        d22 += w[i] * at[2] * at[2];
-      }
-      // L D L' in the pivot order of the frame (heaviest direction first)
-      const double id0 = fast_rcp(d00);
-      const double l10 = d01 * id0, l20 = d02 * id0;
-      const double e11 = d11 - l10 * d01;
-      const double id1 = fast_rcp(e11);
-      const double e21 = d12 - l20 * d01;
-      const double l21 = e21 * id1;
-      const double e22 = d22 - l20 * d02 - l21 * e21;
-      const double id2 = fast_rcp(e22);
-#pragma unroll
-      for (int i = 0; i < 9; ++i) out[i] = T[i];
-      out[9] = l10; out[10] = l20; out[11] = l21; out[12] = id0; out[13] = id1; out[14] = id2;
-      out[15] = gq[0]; out[16] = gq[1]; out[17] = gq[2];
-      // V = [T ; Bw0_l T] (6 x 3); vt_j = columns of V L^-T; G += sum_j id_j vt_j vt_j', r6 += sum_j vt_j id_j y_j, y = L^-1 gq
-      double V[18];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) V[i] = T[i];
-      {
-        const double* bw = sm + L.bw0 + 3 * l;     // Bw0_l[a][c] = bw[12 a + c]
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int b = 0; b < 3; ++b)
-            V[9 + 3 * a + b] = bw[D::NU * a] * T[b] + bw[D::NU * a + 1] * T[3 + b] + bw[D::NU * a + 2] * T[6 + b];
-      }
-      const double y0 = gq[0], y1 = gq[1] - l10 * y0, y2 = gq[2] - l20 * y0 - l21 * y1;
-      const double z0 = id0 * y0, z1 = id1 * y1, z2 = id2 * y2;
-      double v0[6], v1[6], v2[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        v0[i] = V[3 * i];
-        v1[i] = V[3 * i + 1] - l10 * v0[i];
-        v2[i] = V[3 * i + 2] - l20 * v0[i] - l21 * v1[i];
-        acc[21 + i] = v0[i] * z0 + v1[i] * z1 + v2[i] * z2;
-      }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const double b0 = id0 * v0[i], b1 = id1 * v1[i], b2 = id2 * v2[i];
-#pragma unroll
-        for (int j = i; j < 6; ++j) acc[S6I(i, j)] = b0 * v0[j] + b1 * v1[j] + b2 * v2[j];
-      }
-    }
-    // sum over the quad (the four contact points of the knot)
-#pragma unroll
-    for (int i = 0; i < kGK; ++i) {
-      double v = acc[i];
-      v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
-      v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
-      acc[i] = v;
-    }
-    if (live && l == 0) {
-      double* gk = sm + LW.GK + kGK * k;
-#pragma unroll
-      for (int i = 0; i < kGK; ++i) gk[i] = acc[i];
-    }
-  }
-  QSYNC();
-}
-
-// diagnostics (PROF builds): a phase boundary pinned between the computation of (a, b) and their uses -- the values
-// pass through one volatile asm before the clock is read and through another one after it
-template <bool PROF>
-__device__ __forceinline__ void tick_dep(Prof<PROF>& prof, int ph, double& a, double& b) {
-  if (PROF) {
-    asm volatile("s_nop 0" : "+v"(a), "+v"(b));
-    prof.tick(ph);
-    asm volatile("s_nop 0" : "+v"(a), "+v"(b));
-  }
-}
-
-template <bool PROF>
-__device__ __forceinline__ void tick_dep1(Prof<PROF>& prof, int ph, double& a) {
-  if (PROF) {
-    asm volatile("s_nop 0" : "+v"(a));
-    prof.tick(ph);
-    asm volatile("s_nop 0" : "+v"(a));
-  }
-}
-
-// ---- pieces of the backward pass ------------------------------------------------------------------------------------
-// acc += X' Y over fragment rows 0..7 (two k-steps): the wrench-space products (K = 6; rows 6, 7 of both operands are 0)
-__device__ __forceinline__ d4 mtm2(const double X[2], const double Y[2], d4 acc) {
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[0], Y[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[1], Y[1], acc, 0, 0, 0);
-  return acc;
-}
-// per-lane multipliers of the two column operations (lane c = column c of the fragment)
-struct ColOps {
-  double m1c, m2c, keep, hsel;
-  int woff[3], aoff[3];
-  __device__ __forceinline__ void init(const DevParams& P, int c) {
-    const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
-    m1c = (c < 3) ? m1 : 0.0;
-    m2c = (c < 3) ? m2 : ((c < 6) ? P.h : 0.0);
-    keep = (c >= 3 && c < 6) ? 0.0 : 1.0;
-    hsel = (c >= 6 && c < 9) ? P.h : 0.0;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      woff[t] = (c >= 3 && c < 6) ? 18 + 3 * t + (c - 3) : -1;
-      aoff[t] = (c >= 3 && c < 6) ? 3 * t + (c - 3) : ((c >= 9 && c < 12) ? 9 + 3 * t + (c - 9) : -1);
-    }
-  }
-};
-// acc += sum_t x[lane 3 + t of the row] * m[t]: three v_fmac_f64 with a DPP source (row_newbcast on src0 of the 64-bit
-// VOP2 form, gfx90a+).  The leading s_nop covers the VALU-write -> DPP-read hazard, which the compiler does not track
-// through inline asm.
-#ifndef QMPC_COL_FUSED
-#define QMPC_COL_FUSED 1
-#endif
-__device__ __forceinline__ double fma_bcast345(double acc, double x, const double m[3]) {
-#if QMPC_COL_FUSED
-  asm("s_nop 1\n\t"
-      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %1, %3 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %1, %4 row_newbcast:5 row_mask:0xf bank_mask:0xf"
-      : "+v"(acc)
-      : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]));
-  return acc;
-#else
-  acc = fma(m[0], row_bcast<3>(x), acc);
-  acc = fma(m[1], row_bcast<4>(x), acc);
-  return fma(m[2], row_bcast<5>(x), acc);
-#endif
-}
-// x M   (columns 0..5 of the result; M = [[m1 I, 0], [0, Wt], [m2 I, 0], [0, h I]]): lane c < 3 takes m1 x[c] + m2 x[c+6],
-// lane 3 + b takes sum_t x[3+t] Wt[t][b] + h x[9+b]; wt[t] = Wt[t][c-3] on lanes 3..5, 0 elsewhere
-__device__ __forceinline__ double times_M(double x, const ColOps& co, const double wt[3]) {
-  double r = co.m1c * x;
-  r = fma(co.m2c, dpp_mov<0x106>(x), r);       // row_shl:6: lane c reads lane c + 6
-  return fma_bcast345(r, x, wt);
-}
-// x Abar_aug  (Abar = [[I,0,hI,0],[0,A1,0,A3],[0,0,I,0],[0,0,0,I]], the gradient column 12 untouched):
-// at[t] = A1[t][c-3] on lanes 3..5, A3[t][c-9] on lanes 9..11, 0 elsewhere
-__device__ __forceinline__ double times_Abar(double x, const ColOps& co, const double at[3]) {
-  double r = co.keep * x;
-  r = fma(co.hsel, dpp_mov<0x116>(x), r);      // row_shr:6: lane c reads lane c - 6
-  return fma_bcast345(r, x, at);
-}
-
-// One Gauss-Jordan step on pivot J < 6 of the pair (M | Rr) held in two fragment registers (rows 0..3 and 4..7):
-// row J is eliminated from every other row.  Returns -1 / pivot: the diagonal is divided out at the end, and a later step
-// does not touch an earlier pivot (its column is already zero in the later pivot rows).
-// PERM: the pivot row reaches the other row groups through v_permlane16/32_swap (VALU) instead of ds_bpermute (LDS)
-#ifndef QMPC_GJ_PERM
-#define QMPC_GJ_PERM 0
-#endif
-#ifndef QMPC_GJ_FUSED
-#define QMPC_GJ_FUSED 0     // measured: 1.76 M against 1.82 M solves/s -- the 64-bit DPP form issues slower than mov + fma
-#endif
-template <int J>
-__device__ __forceinline__ double gj6_step(double M[2], double Rr[2], int c, int g, double& minpiv) {
-  constexpr int ej = J >> 2, gj = J & 3;
-  double mrow, rrow;
-  if (QMPC_GJ_PERM) {
-    mrow = rowgroup_bcast<gj>(M[ej]);
-    rrow = rowgroup_bcast<gj>(Rr[ej]);
-  } else {
-    const int src = (gj << 4) | c;
-    mrow = __shfl(M[ej], src);      // row J, same column, all row groups
-    rrow = __shfl(Rr[ej], src);
-  }
-  const double piv = read_lane(M[ej], (gj << 4) | J);
-  minpiv = fmin(minpiv, piv);
-  const double ninv = -fast_rcp(piv);
-#if QMPC_GJ_FUSED
-  // X[r][c] += X[r][J] * (-row_J[c] / piv) as ONE v_fmac_f64 with a DPP source per fragment register; the DPP row mask
-  // (one bit per row group) leaves the pivot row itself untouched.  The right-hand side first: it reads the old column J.
-  const double nm = ninv * mrow, nr = ninv * rrow;
-  constexpr int m0 = (ej == 0) ? (0xf ^ (1 << gj)) : 0xf, m1 = (ej == 1) ? (0xf ^ (1 << gj)) : 0xf;
-  asm("s_nop 1\n\t"
-      "v_fmac_f64_dpp %2, %0, %5 row_newbcast:%6 row_mask:%7 bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %3, %1, %5 row_newbcast:%6 row_mask:%8 bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %0, %4 row_newbcast:%6 row_mask:%7 bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %1, %4 row_newbcast:%6 row_mask:%8 bank_mask:0xf"
-      : "+v"(M[0]), "+v"(M[1]), "+v"(Rr[0]), "+v"(Rr[1])
-      : "v"(nm), "v"(nr), "n"(J), "n"(m0), "n"(m1));
-#else
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const double col = row_bcast<J>(M[e]);
-    const double f = ((e == ej) && (g == gj)) ? 0.0 : col * ninv;
-    M[e] = fma(f, mrow, M[e]);
-    Rr[e] = fma(f, rrow, Rr[e]);
-  }
-#endif
-  return ninv;
-}
-
-// Riccati backward pass in the wrench form; writes per knot [Xw | xw] and [Xz | xz] (KD).  Returns nonzero when a pivot
-// of W' is not positive (P lost positive definiteness: QMPC_NOT_PD).
-template <bool PROF>
-__device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm, double* KD,
-                                      int lane, Prof<PROF>& prof) {
-  const int N = P.N;
-  const int c = lane & 15, g = lane >> 4;
-  const double wscale = (0.5 * P.hh) * P.h;        // Wt = (h^2 / 4) Gn'Gm
-  ColOps co;
-  co.init(P, c);
-  // fragment patterns, rows r_e = 4 e + g.  Every per-knot operand is ONE LDS read at a lane-constant index that steps
-  // back by the record size per knot; lanes outside a pattern read a slot that holds 0.0 (index fixed), so no select
-  // follows the loads.  The Wt block of the M fragment and the A1 / A3 blocks of the N = Abar - I fragment are the
-  // column-operation multipliers wt[], at[] of the same lane.
-  const int zslot = L.cst + 63;
-  double Mc[3], Nc[2], qadd[3];
-  double msel[3], nsel[3];          // 1.0 where the lane's fragment row takes wt[t] / at[t]: rows 3 + t
-  int ix_w[3], ix_a[3], ix_x[3], ix_g[2], st_w[3], st_a[3], st_x[3], st_g[2], kwo[2], kzo[2];
-  int xoffN[3];
-  bool rowok[2];
-  {
-    const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const bool wv = co.woff[t] >= 0, av = co.aoff[t] >= 0;
-      ix_w[t] = wv ? L.AB + kAB * (N - 1) + co.woff[t] : zslot;  st_w[t] = wv ? kAB : 0;
-      ix_a[t] = av ? L.AB + kAB * (N - 1) + co.aoff[t] : zslot;  st_a[t] = av ? kAB : 0;
-    }
-    // row 3 + t lives in (e, g) = (0, 3), (1, 0), (1, 1)
-    msel[0] = nsel[0] = (g == 3) ? 1.0 : 0.0;
-    msel[1] = nsel[1] = (g == 0) ? 1.0 : 0.0;
-    msel[2] = nsel[2] = (g == 1) ? 1.0 : 0.0;
-#pragma unroll
-    for (int e = 0; e < 3; ++e) {
-      const int r = 4 * e + g;
-      const bool phi = (r >= 3 && r < 6);
-      double v = 0.0;
-      if (c < 6) {
-        if (r < 3) v = (r == c) ? m1 : 0.0;
-        else if (r >= 6 && r < 9) v = (r - 6 == c) ? m2 : 0.0;
-        else if (r >= 9) v = (r - 9 == c - 3) ? P.h : 0.0;
-      }
-      Mc[e] = v;
-      const bool cval = c < 12;
-      qadd[e] = (cval && r == c && !phi) ? P.Q[(r < 3) ? r : r + 1] : 0.0;
-      int xo = -1;
-      if (phi && c >= 3 && c < 6) xo = 3 * (r - 3) + (c - 3);
-      if (c == 12) xo = 9 + r;
-      xoffN[e] = xo;
-      ix_x[e] = (xo >= 0) ? L.XT + kXT * (N - 1) + xo : zslot;
-      st_x[e] = (xo >= 0) ? kXT : 0;
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int r = 4 * e + g;
-      const bool phi = (r >= 3 && r < 6);
-      // N = Abar - I, rows 0..7 (rows 6, 7 are zero)
-      Nc[e] = (r < 3 && c == r + 6) ? P.h : ((phi && r == c) ? -1.0 : 0.0);
-      rowok[e] = r < 6;
-      // G (columns 0..5) and r6 (column 12) share a register: as the A operand of G Yp the column 12 only feeds the
-      // unused output row 12
-      const int go = (r < 6 && c < 6) ? S6I(r, c) : ((r < 6 && c == 12) ? 21 + r : -1);
-      ix_g[e] = (go >= 0) ? LW.GK + kGK * (N - 1) + go : zslot;
-      st_g[e] = (go >= 0) ? kGK : 0;
-      kwo[e] = (r < 6 && c < 13) ? 13 * r + c : -1;
-      kzo[e] = (r < 6 && c < 13) ? 13 * (6 + r) + c : -1;
-    }
-  }
-  // ---- terminal cost-to-go  P_aug = [lxx_N | lx_N] ----
-  double Pf[3];
-  {
-    const double* XTk = sm + L.XT + kXT * N;
-#pragma unroll
-    for (int e = 0; e < 3; ++e) Pf[e] = qadd[e] + ((xoffN[e] >= 0) ? XTk[xoffN[e]] : 0.0);
-  }
-  double minpiv = 1e300;
-  const d4 z4 = {0.0, 0.0, 0.0, 0.0};
-  // operands of a knot (independent of the cost-to-go): loaded one knot ahead, right after the first products are issued
-  struct KnotOps { double wt[3], at[3], gr[2], xt[3]; };
-  auto load_ops = [&](KnotOps& o) {       // the knot the running indices point at; then one knot back
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      o.wt[t] = sm[ix_w[t]]; o.at[t] = sm[ix_a[t]]; o.xt[t] = sm[ix_x[t]];
-      ix_w[t] -= st_w[t]; ix_a[t] -= st_a[t]; ix_x[t] -= st_x[t];
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) { o.gr[e] = sm[ix_g[e]]; ix_g[e] -= st_g[e]; }
-  };
-  KnotOps ops, opn;
-  load_ops(ops);
-  for (int k = N - 1; k >= 0; --k) {
-    double wt[3], Mf[3], Nf[2], R6f[2];
-    const double* at = ops.at;
-    const double* Gf = ops.gr;
-    const double* xt = ops.xt;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) wt[t] = wscale * ops.wt[t];
-    Mf[0] = fma(msel[0], wt[0], Mc[0]);
-    Mf[1] = fma(msel[1], wt[1], fma(msel[2], wt[2], Mc[1]));
-    Mf[2] = Mc[2];
-    Nf[0] = fma(nsel[0], at[0], Nc[0]);
-    Nf[1] = fma(nsel[1], at[1], fma(nsel[2], at[2], Nc[1]));
-    R6f[0] = (c == 12) ? ops.gr[0] : 0.0;
-    R6f[1] = (c == 12) ? ops.gr[1] : 0.0;
-    tick_dep(prof, PH_BUILD, Pf[0], Pf[1]);
-    // ---- 1. Yp = M' [P | p]  (6 x 13) ----
-    double Yp[2];
-    {
-      const d4 a = mtm3(Mf, Pf, z4);
-      Yp[0] = a[0]; Yp[1] = a[1];
-    }
-    if (k > 0) load_ops(opn);
-    tick_dep(prof, PH_DRAIN, Yp[0], Yp[1]);
-    // ---- 2. S6 = Yp_fb M  (column operation) ----
-    double S6[2];
-    S6[0] = times_M(Yp[0], co, wt);
-    S6[1] = times_M(Yp[1], co, wt);
-    // ---- 3. C = G Yp + [0 | r6] ;  4. Q = S6 C,  W' = S6 + Q_fb M ----
-    double Cf[2], Qf[2], Wm[2];
-    {
-      const d4 ini = {R6f[0], R6f[1], 0.0, 0.0};
-      const d4 a = mtm2(Gf, Yp, ini);
-      Cf[0] = a[0]; Cf[1] = a[1];
-      const d4 b = mtm2(S6, Cf, z4);
-      Qf[0] = b[0]; Qf[1] = b[1];
-    }
-    Wm[0] = S6[0] + times_M(Qf[0], co, wt);
-    Wm[1] = S6[1] + times_M(Qf[1], co, wt);
-    tick_dep(prof, PH_MFMA, Wm[0], Wm[1]);
-    // ---- 5. W' X = -Q ----
-    const double n0 = gj6_step<0>(Wm, Qf, c, g, minpiv);
-    const double n1 = gj6_step<1>(Wm, Qf, c, g, minpiv);
-    const double n2 = gj6_step<2>(Wm, Qf, c, g, minpiv);
-    const double n3 = gj6_step<3>(Wm, Qf, c, g, minpiv);
-    const double n4 = gj6_step<4>(Wm, Qf, c, g, minpiv);
-    const double n5 = gj6_step<5>(Wm, Qf, c, g, minpiv);
-    double Xf[2];
-    Xf[0] = Qf[0] * ((g == 0) ? n0 : (g == 1 ? n1 : (g == 2 ? n2 : n3)));      // X = -diag^-1 Q
-    Xf[1] = rowok[1] ? Qf[1] * ((g == 0) ? n4 : n5) : 0.0;
-    tick_dep(prof, PH_SOLVE, Xf[0], Xf[1]);
-    // ---- 6. Pi = [P | p] + Yp_fb' X ;  7. gains [Xz | xz] = Yp + S6 X ----
-    double Pi[3];
-    {
-      const d4 ini = {Pf[0], Pf[1], Pf[2], 0.0};
-      const d4 a = mtm2(Yp, Xf, ini);
-      Pi[0] = a[0]; Pi[1] = a[1]; Pi[2] = a[2];
-    }
-    double Zf[2];
-    {
-      const d4 ini = {Yp[0], Yp[1], 0.0, 0.0};
-      const d4 a = mtm2(S6, Xf, ini);
-      Zf[0] = a[0]; Zf[1] = a[1];
-    }
-    // ---- 8. [P | p]_k = [lxx | lx] + Abar' (Pi Abar_aug) ----
-    double Uf[3];
-#pragma unroll
-    for (int e = 0; e < 3; ++e) Uf[e] = times_Abar(Pi[e], co, at);
-    {
-      const d4 ini = {Uf[0] + (qadd[0] + xt[0]), Uf[1] + (qadd[1] + xt[1]), Uf[2] + (qadd[2] + xt[2]), 0.0};
-      const d4 a = mtm2(Nf, Uf, ini);
-      Pf[0] = a[0]; Pf[1] = a[1]; Pf[2] = a[2];
-    }
-    {
-      double* KDk = KD + 156 * k;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        if (kwo[e] >= 0) { KDk[kwo[e]] = Xf[e]; KDk[kzo[e]] = Zf[e]; }
-      }
-    }
-    ops = opn;
-    tick_dep(prof, PH_PUPD, Pf[0], Pf[1]);
-  }
-  return !(minpiv > 0.0);   // also true for a NaN pivot
-}
-
-// ---- explicit midpoint step given the wrench w = (sum of the forces, sum of Bw0_l u_l) (AltroUtils.cpp:9-22 on :363-392)
-__device__ __forceinline__ void srbd_step_w(const DevParams& P, const double gb[3], const double wd0[3], const double* x,
-                                            const double w[6], double* xn) {
-  double vd[3], wd[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) { vd[a] = w[a] * P.inv_mass + gb[a]; wd[a] = wd0[a] + w[3 + a]; }
-  double G[12];
-  quat_G(&x[3], G);
-  double qm[4], wm[3];
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-    qm[r] = x[3 + r] + P.hh * (0.5 * (G[3 * r] * x[10] + G[3 * r + 1] * x[11] + G[3 * r + 2] * x[12]));
-#pragma unroll
-  for (int a = 0; a < 3; ++a) wm[a] = x[10 + a] + P.hh * wd[a];
-  quat_G(qm, G);
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    xn[a] = x[a] + P.h * (x[7 + a] + P.hh * vd[a]);
-    xn[7 + a] = x[7 + a] + P.h * vd[a];
-    xn[10 + a] = x[10 + a] + P.h * wd[a];
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-    xn[3 + r] = x[3 + r] + P.h * (0.5 * (G[3 * r] * wm[0] + G[3 * r + 1] * wm[1] + G[3 * r + 2] * wm[2]));
-}
-
-// wrench of every knot from the inputs U (WITH_DU: U + dU), lane (k, i), i < 6
-template <bool WITH_DU>
-__device__ inline void wrench_from_inputs(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm, int lane) {
-  const int N = P.N;
-  for (int q = lane; q < 6 * N; q += kWave) {
-    const int k = q / 6, i = q - 6 * k;
-    double u[12];
-#pragma unroll
-    for (int j = 0; j < 12; ++j) u[j] = sm[L.U + 12 * k + j] + (WITH_DU ? sm[L.dU + 12 * k + j] : 0.0);
-    const double* b = sm + L.bw0 + ((i >= 3) ? 12 * (i - 3) : 0);
-    double s0 = 0.0, s1 = 0.0, f0 = 0.0, f1 = 0.0;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) { s0 += b[j] * u[j]; s1 += b[6 + j] * u[6 + j]; }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      f0 += (i == a) ? u[a] + u[6 + a] : 0.0;
-      f1 += (i == a) ? u[3 + a] + u[9 + a] : 0.0;
-    }
-    sm[LW.WR + q] = (i < 3) ? f0 + f1 : s0 + s1;
-  }
-  QSYNC();
-}
-
-// shortened primal step: scale the trial increment and re-roll the states open loop from the knots' wrenches
-__device__ inline void rollout_scaled_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm, double ap, int lane) {
-  typedef Dim<4> D;
-  const int N = P.N;
-  const double* cst = sm + L.cst;
-  for (int i = lane; i < N * D::NU; i += kWave) sm[L.dU + i] *= ap;
-  QSYNC();
-  wrench_from_inputs<true>(P, L, LW, sm, lane);
-  double gb[3], wd0[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) { gb[a] = cst[D::C_GB + a]; wd0[a] = cst[D::C_WD0 + a]; }
-  double x[13], xn[13], w[6], wn[6];
-#pragma unroll
-  for (int i = 0; i < 13; ++i) x[i] = cst[D::C_X0 + i];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) w[i] = sm[LW.WR + i];
-  for (int k = 0; k < N; ++k) {
-    const int kn = (k + 1 < N) ? k + 1 : k;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) wn[i] = sm[LW.WR + 6 * kn + i];
-    srbd_step_w(P, gb, wd0, x, w, xn);
-#pragma unroll
-    for (int i = 0; i < 13; ++i) x[i] = xn[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) w[i] = wn[i];
-    if (lane == 0)
-#pragma unroll
-      for (int i = 0; i < 13; ++i) sm[L.Xc + 13 * (k + 1) + i] = xn[i];
-  }
-  QSYNC();
-}
-
-// ---- closed-loop trial rollout (alpha = 1) in the wrench space: lane i < 6 owns row i of [Xw | xw], lanes 6..11 row
-// i - 6 of [Xz | xz]; the state is advanced by every lane redundantly, six wrench components are broadcast per knot ----
-struct RollLoadsW {
-  double xo[13], ab[18], kd[13], wk;
-};
-__device__ __forceinline__ void roll_load_w(const Layout& L, const LayoutW& LW, const double* sm, const double* KD, int k,
-                                            int row, int wi, RollLoadsW& r) {
-#pragma unroll
-  for (int i = 0; i < 13; ++i) r.xo[i] = sm[L.X + 13 * k + i];
-#pragma unroll
-  for (int i = 0; i < 18; ++i) r.ab[i] = sm[L.AB + kAB * k + i];
-  const double* kd = KD + 156 * k + 13 * row;
-#pragma unroll
-  for (int i = 0; i < 13; ++i) r.kd[i] = kd[i];
-  r.wk = sm[LW.WR + 6 * k + wi];
-}
-template <bool PROF>
-__device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm,
-                                        const double* KD, double* ROT, int lane, Prof<PROF>& prof) {
-  typedef Dim<4> D;
-  const int N = P.N;
-  const double* cst = sm + L.cst;
-  double gb[3], wd0[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) { gb[a] = cst[D::C_GB + a]; wd0[a] = cst[D::C_WD0 + a]; }
-  const int row = (lane < 12) ? lane : 0, wi = (lane < 6) ? lane : 0;
-  const bool zlane = lane >= 6 && lane < 12;
-  double xc[13], xn[13];
-#pragma unroll
-  for (int i = 0; i < 13; ++i) xc[i] = cst[D::C_X0 + i];
-  if (lane == 0)
-#pragma unroll
-    for (int i = 0; i < 13; ++i) sm[L.Xc + i] = xc[i];
-  // one knot: gains / old state / Jacobian blocks in `cur`, the next knot's loaded into `nxt` meanwhile (the loop body is
-  // instantiated twice with the roles swapped: no register copies)
-  auto knot = [&](int k, const RollLoadsW& cur, RollLoadsW& nxt) {
-    double dx[12], e[12];
-    QuatModel::state_diff(cur.xo, xc, dx);
-    // e = Abar dx
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      e[a] = dx[a] + P.h * dx[6 + a];
-      e[3 + a] = (cur.ab[3 * a] * dx[3] + cur.ab[3 * a + 1] * dx[4] + cur.ab[3 * a + 2] * dx[5]) +
-                 (cur.ab[9 + 3 * a] * dx[9] + cur.ab[9 + 3 * a + 1] * dx[10] + cur.ab[9 + 3 * a + 2] * dx[11]);
-      e[6 + a] = dx[6 + a];
-      e[9 + a] = dx[9 + a];
-    }
-    const double* kd = cur.kd;
-    const double p0 = kd[12] + kd[0] * e[0] + kd[1] * e[1] + kd[2] * e[2];
-    const double p1 = kd[3] * e[3] + kd[4] * e[4] + kd[5] * e[5];
-    const double p2 = kd[6] * e[6] + kd[7] * e[7] + kd[8] * e[8];
-    const double p3 = kd[9] * e[9] + kd[10] * e[10] + kd[11] * e[11];
-    const double s = (p0 + p1) + (p2 + p3);
-    if (zlane) ROT[zeta_slot(k, lane - 6)] = s;      // the costate of the contact points, for the input recovery
-    double wn = cur.wk + s;
-    tick_dep1(prof, PH_R_GAIN, wn);
-    if (k + 1 < N) roll_load_w(L, LW, sm, KD, k + 1, row, wi, nxt);      // one knot ahead
-    double w[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) w[i] = read_lane(wn, i);
-    tick_dep(prof, PH_R_BCAST, w[0], w[5]);
-    srbd_step_w(P, gb, wd0, xc, w, xn);
-#pragma unroll
-    for (int i = 0; i < 13; ++i) xc[i] = xn[i];
-    if (lane == 0)
-#pragma unroll
-      for (int i = 0; i < 13; ++i) sm[L.Xc + 13 * (k + 1) + i] = xn[i];
-    tick_dep(prof, PH_R_STEP, xc[3], xc[10]);
-  };
-  RollLoadsW ra, rb;
-  roll_load_w(L, LW, sm, KD, 0, row, wi, ra);
-  for (int k = 0; k < N; k += 2) {
-    knot(k, ra, rb);
-    if (k + 1 < N) knot(k + 1, rb, ra);
-  }
-  QSYNC();
-}
-
-// ---- input increments of the trial step, one lane per (knot, contact point):
-//      du_l = -T_l D~_l^-1 (V_l' zeta + gq_l),   V_l' zeta = T_l' (zeta_f + Bw0_l' zeta_t) ----
-__device__ inline void recover_inputs_w(const DevParams& P, const Layout& L, double* sm, const double* ROT, int lane) {
-  typedef Dim<4> D;
-  const int N = P.N;
-  const double* cst = sm + L.cst;
-  for (int q = lane; q < 4 * N; q += kWave) {
-    const int k = q >> 2, l = q & 3;
-    double du[3] = {0.0, 0.0, 0.0};
-    if (cst[D::C_CON + l] != 0.0) {
-      const double* rec = ROT + D::ROT * k + 21 * l;
-      double T[9], z[6];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) T[i] = rec[i];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) z[i] = ROT[zeta_slot(k, i)];
-      const double l10 = rec[9], l20 = rec[10], l21 = rec[11], id0 = rec[12], id1 = rec[13], id2 = rec[14];
-      const double* bw = sm + L.bw0 + 3 * l;
-      double f[3];
-#pragma unroll
-      for (int b = 0; b < 3; ++b) f[b] = z[b] + (bw[b] * z[3] + bw[D::NU + b] * z[4] + bw[2 * D::NU + b] * z[5]);
-      double t[3];
-#pragma unroll
-      for (int b = 0; b < 3; ++b) t[b] = rec[15 + b] + (T[b] * f[0] + T[3 + b] * f[1] + T[6 + b] * f[2]);
-      const double y0 = t[0], y1 = t[1] - l10 * y0, y2 = t[2] - l20 * y0 - l21 * y1;
-      const double x2 = id2 * y2;
-      const double x1 = id1 * y1 - l21 * x2;
-      const double x0 = id0 * y0 - l10 * x1 - l20 * x2;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) du[a] = -(T[3 * a] * x0 + T[3 * a + 1] * x1 + T[3 * a + 2] * x2);
-    }
-    double* o = sm + L.dU + D::NU * k + 3 * l;
-    o[0] = du[0]; o[1] = du[1]; o[2] = du[2];
-  }
-  QSYNC();
-}
+namespace qmpc {
 
 // ---- the solve kernel (QuatMpc's problem, four contact points, everything in LDS, one wave per SIMD) -----------------
 template <bool PROF>
@@ -756,122 +48,14 @@ __global__ __launch_bounds__(64, 1) void qmpc_solve_w_kernel(
   const int b = blockIdx.x;
   if (b >= batch) return;
   const int lane = threadIdx.x;
-  typedef QuatModel MD;
-  typedef MD::D D;
-  constexpr int NU = D::NU, NC = D::NC;
-  const int N = P.N;
-  LayoutW LW;
-  const Layout L = make_layout_w(N, &LW);
-  double* KD = sm + L.KD;
-  double* ROT = sm + L.ROT;
-  double* sl = sm;
-  const void* in = reinterpret_cast<const double*>(in_) + (size_t)b * D::REC;
-  int status = QMPC_OK;
-  Prof<PROF> prof;
-  prof.start();
-  setup_instance<MD>(P, L, sm, in, lane, &status);
-  if (status != QMPC_OK) {
-    if (lane < NU) forces[NU * (size_t)b + lane] = 0.0;
-    if (lane == 0 && info) {
-      qmpc_info r = {status, 0, 0.0, 0.0, 0.0, 0.0};
-      info[b] = r;
-    }
-    if (traj_u) for (int i = lane; i < N * NU; i += kWave) traj_u[(size_t)b * N * NU + i] = 0.0;
-    if (traj_x) for (int i = lane; i < (N + 1) * MD::NX; i += kWave) traj_x[(size_t)b * (N + 1) * MD::NX + i] = 0.0;
-    return;
-  }
-  unsigned conmask = 0;
-  for (int l = 0; l < MD::NL; ++l) conmask |= (sm[L.cst + D::C_CON + l] != 0.0) ? (1u << l) : 0u;
-  conmask = __builtin_amdgcn_readfirstlane(conmask);
-  if (lane == 0) sm[L.cst + 63] = 0.0;      // the zero the masked operand reads of the backward pass point at
-  for (int i = lane; i < N * NU; i += kWave) sm[L.U + i] = sm[L.uref + (i % NU)];      // U = u_ref (QuatMpc.cpp:253)
-  QSYNC();
-  rollout_open<MD, false>(P, L, sm, lane);
-  wrench_from_inputs<false>(P, L, LW, sm, lane);
-  expansions<MD>(P, L, sm, lane);
-  double sl_part = 0.0, rc_part = 0.0;
-  for (int i = lane; i < N * NC; i += kWave) {
-    const double c0 = cone_value<D>(P, L, sm, i);
-    const double s0 = fmax(-c0, 1.0);
-    const double lam0 = P.mu0 / s0;
-    sl[L.S + i] = s0;
-    sl[L.RC + i] = c0 + s0;
-    sl[L.LAM + i] = lam0;
-    sl[L.DS + i] = 0.0;
-    if (conmask & (1u << ((i % NC) / 6))) {
-      sl_part += s0 * lam0;
-      rc_part = fmax(rc_part, fabs(c0 + s0));
-    }
-  }
-  QSYNC();
-  prof.tick(PH_SETUP);
-  const double inv_rows = 1.0 / (double)(6 * N * __popc(conmask));
-  int it = 0, iters = 0;
-  unsigned kapbits = 0;
-  double mu = 0.0, resid = 0.0, last_step = 1e300, last_ap = 0.0, last_ad = 0.0;
-  status = QMPC_MAX_ITER;
-  for (it = 1; it <= P.iterations_max + 1; ++it) {
-    mu = wave_sum(sl_part) * inv_rows;
-    resid = wave_max(rc_part);
-    if (mu <= P.mu_final && resid <= P.tol_feas && last_step <= P.tol_step) { status = QMPC_OK; break; }
-    if (it > P.iterations_max) break;
-    double sg = P.sigma;
-    const double amin = fmin(last_ap, last_ad);
-    if (it > 1 && amin >= 0.99) sg = P.sigma_fast;
-    else if (it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
-    else if (it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
-    const double target = sg * mu;
-    prof.tick(PH_MISC);
-    prepass_w(P, L, LW, sm, sl, ROT, target, lane);
-    prof.tick(PH_PREPASS);
-    if (backward_pass_w<PROF>(P, L, LW, sm, KD, lane, prof)) { status = QMPC_NOT_PD; break; }
-    QSYNC();
-    double ap, ad;
-    rollout_closed_w<PROF>(P, L, LW, sm, KD, ROT, lane, prof);      // trial step
-    recover_inputs_w(P, L, sm, ROT, lane);
-    prof.tick(PH_ROLL);
-    ipm_directions<D>(P, L, sm, sl, target, lane, &ap, &ad, &last_step);
-    last_ap = ap; last_ad = ad;
-    prof.tick(PH_DIRS);
-    if (ap < 1.0) rollout_scaled_w(P, L, LW, sm, ap, lane);    // shortened primal step
-    prof.tick(PH_ROLL);
-    ipm_apply<D>(P, L, sl, ap, ad, conmask, lane, kapbits, sl_part, rc_part);
-    prof.tick(PH_APPLY);
-    for (int i = lane; i < N * NU; i += kWave) sm[L.U + i] += sm[L.dU + i];
-    for (int i = lane; i < (N + 1) * 13; i += kWave) sm[L.X + i] = sm[L.Xc + i];
-    QSYNC();
-    wrench_from_inputs<false>(P, L, LW, sm, lane);
-    prof.tick(PH_MISC);
-    expansions<MD>(P, L, sm, lane);
-    prof.tick(PH_EXPAND);
-    iters = it;
-  }
-  if (lane < NU) forces[NU * (size_t)b + lane] = sm[L.U + lane];
-  if (traj_u) for (int i = lane; i < N * NU; i += kWave) traj_u[(size_t)b * N * NU + i] = sm[L.U + i];
-  if (traj_x)
-    for (int i = lane; i < (N + 1) * MD::NX; i += kWave) traj_x[(size_t)b * (N + 1) * MD::NX + i] = sm[L.X + i];
-  if (info) {
-    const double J = cost_plain<MD>(P, L, sm, lane);
-    double viol = 0.0;
-    for (int i = lane; i < N * NC; i += kWave) {
-      const int l = (i % NC) / 6;
-      if (conmask & (1u << l)) viol = fmax(viol, fmax(cone_value<D>(P, L, sm, i), 0.0));
-    }
-    viol = wave_max(viol);
-    if (lane == 0) {
-      qmpc_info r = {status, iters, J, viol, last_step, mu};
-      info[b] = r;
-    }
-  }
-  if (PROF && prof_out && lane == 0) {
-    prof.tick(PH_MISC);
-#pragma unroll
-    for (int i = 0; i < PH_COUNT; ++i) prof_out[16 * (size_t)b + i] = prof.t[i];
-    prof_out[16 * (size_t)b + 15] = iters;
-  }
+  constexpr int warm_t = 0;            // a plain solve always starts from u_ref (QuatMpc.cpp:253)
+#include "qmpc_wform_body.inc"
 }
 
-}  // namespace qmpc_wform_tu
+}  // namespace qmpc
+#undef qmpc
+
+#include <cstring>
 
 using namespace qmpc_wform_tu;
 
