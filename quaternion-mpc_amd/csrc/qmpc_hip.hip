@@ -36,11 +36,12 @@ hipError_t qmpc_warm_launch(int var, int convex, int batch, size_t lds, hipStrea
                             double* gws, int check_prev);
 
 // qmpc_wform.hip (fourth translation unit): the wave-per-instance kernel with the wrench-form elimination (small batches)
-size_t qmpc_wform_lds_bytes(int N);
+size_t qmpc_wform_lds_bytes(int N, int kd_global);
+size_t qmpc_wform_slice_doubles(int N);
 hipError_t qmpc_wform_set_lds(int bytes);
-hipError_t qmpc_wform_launch(int prof, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
+hipError_t qmpc_wform_launch(int var, int prof, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
                              const qmpc_input* in, double* forces, qmpc_info* info, double* traj_u, double* traj_x,
-                             long long* prof_out);
+                             long long* prof_out, double* gws);
 
 // qmpc_lane.hip (third translation unit): the lane-per-instance kernel of large batches
 size_t qmpc_lane_ws_bytes(int N, int nl, unsigned slots);
@@ -70,6 +71,7 @@ struct qmpc_handle {
   size_t lds_bytes_g;     // gains in the global workspace
   size_t lds_bytes_s;     // gains and slack arrays in the global workspace
   size_t lds_bytes_w;     // the wrench-form kernel (qmpc_wform.hip), everything in LDS
+  size_t lds_bytes_wg;    // ... with its gains / per-point records / per-knot blocks in the global workspace
   int wform;              // 1: batches that keep everything in LDS take the wrench-form kernel (env QMPC_WFORM, default 1)
   int* d_loop_row;        // trace row counter of the closed loop (qmpc_loop_run*)
   double* d_leg;          // staging of the host-buffer leg calls (grown on demand, freed with the handle)
@@ -303,7 +305,8 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     h->variant = v ? std::atoi(v) : 0;
     const char* wf = std::getenv("QMPC_WFORM");
     h->wform = wf ? std::atoi(wf) : 1;
-    h->lds_bytes_w = qmpc_wform_lds_bytes(N);
+    h->lds_bytes_w = qmpc_wform_lds_bytes(N, 0);
+    h->lds_bytes_wg = qmpc_wform_lds_bytes(N, 1);
     const char* lm = std::getenv("QMPC_LANE_MIN");
     h->lane_min_batch = lm ? std::atoi(lm) : (params->model == QMPC_MODEL_QUAT ? kLaneMinBatch : kLaneMinBatchOther);
     h->lane_min_loop_cold = lm ? h->lane_min_batch : kLaneMinLoopCold;
@@ -398,12 +401,17 @@ static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* 
   return QMPC_OK;
 }
 
-// Batches that keep everything in LDS (one instance per SIMD at most) of QuatMpc's problem take the wrench-form kernel
-// (qmpc_wform.hip) when four instances fit a CU with its layout; QMPC_WFORM=0 keeps the round-1 kernel (A/B runs).
-static bool use_wform(const qmpc_handle* h, int32_t batch) {
-  return h->wform && h->params.model == QMPC_MODEL_QUAT && h->params.mode == QMPC_MODE_CONVERGED &&
-         h->lds_bytes_w <= 40 * 1024 && pick_variant(h, batch) == 0;
+// QuatMpc's problem in converged mode takes the wrench-form kernels (qmpc_wform.hip): with everything in LDS (3) where
+// the round-1 family would keep everything in LDS (one instance per SIMD at most) and four instances fit a CU with its
+// layout, with the gains in the workspace (5) for the mid-size batches below the lane kernel's threshold.
+// QMPC_WFORM=0 keeps the round-1 kernels (A/B runs); QMPC_WFORM=3 restricts it to the all-LDS form.
+static int wform_variant(const qmpc_handle* h, int32_t batch) {
+  if (!h->wform || h->params.model != QMPC_MODEL_QUAT || h->params.mode != QMPC_MODE_CONVERGED) return 0;
+  const int pv = pick_variant(h, batch);
+  if (pv == 0) return h->lds_bytes_w <= 40 * 1024 ? 3 : 0;
+  return (h->wform != 3 && h->lds_bytes_wg <= 80 * 1024) ? 5 : 0;
 }
+static bool use_wform(const qmpc_handle* h, int32_t batch) { return wform_variant(h, batch) == 3; }
 
 // variant of the converged-mode kernels that share a body (plain solve, warm-started solve, persistent loop kernel):
 // pick_variant's 0 / 1 / 2, or 3 = the wrench form where it applies -- the three launch forms must agree, they are
@@ -451,8 +459,9 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
     }
     return QMPC_OK;
   }
-  if (use_wform(h, batch)) {
-    HIP_TRY(qmpc_wform_launch(0, (int)batch, h->lds_bytes_w, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, d_tu, d_tx, nullptr));
+  if (const int wv = wform_variant(h, batch)) {
+    HIP_TRY(qmpc_wform_launch(wv, 0, (int)batch, wv == 5 ? h->lds_bytes_wg : h->lds_bytes_w, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info,
+                              d_tu, d_tx, nullptr, wv == 5 ? h->d_gws : nullptr));
     if (timed) {
       HIP_TRY(hipEventRecord(h->ev1, s));
       h->timed = true;
@@ -1152,8 +1161,8 @@ qmpc_status qmpc_debug_profile(qmpc_handle* h, int32_t batch, const qmpc_input* 
   HIP_TRY(hipMemsetAsync(d_prof, 0, sizeof(long long) * 16 * (size_t)batch, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_in, in, sizeof(qmpc_input) * (size_t)batch, hipMemcpyHostToDevice, h->stream));
   if (use_wform(h, batch))
-    HIP_TRY(qmpc_wform_launch(1, (int)batch, h->lds_bytes_w, h->stream, &h->dev, sizeof h->dev, h->d_in, h->d_forces, h->d_info,
-                              nullptr, nullptr, d_prof));
+    HIP_TRY(qmpc_wform_launch(3, 1, (int)batch, h->lds_bytes_w, h->stream, &h->dev, sizeof h->dev, h->d_in, h->d_forces, h->d_info,
+                              nullptr, nullptr, d_prof, nullptr));
   else if (use_global_gains(h, batch))
     hipLaunchKernelGGL((qmpc_solve_kernel<QuatModel, true, 1>), dim3((unsigned)batch), dim3(kWave), h->lds_bytes_g, h->stream,
                        h->dev, h->d_in, h->d_forces, h->d_info, (double*)nullptr, (double*)nullptr, (int)batch, d_prof,

@@ -448,6 +448,7 @@ __global__ __launch_bounds__(64, REF ? 1 : QMPC_SOLVE_WAVES(QuatModel, VAR)) voi
     } else if constexpr (VAR == 3) {
       [&]() {
         const int warm_t = (LP.warm_start != 0.0 && prev_ok) ? t : 0;   // t > 0 and the last solve left a usable U in LDS
+        constexpr int WVAR = 3;
 #include "qmpc_wform_body.inc"
       }();
     } else {
@@ -500,6 +501,7 @@ __global__ __launch_bounds__(64, QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_sol
     __syncthreads();
   }
   if constexpr (VAR == 3) {
+    constexpr int WVAR = 3;
 #include "qmpc_wform_body.inc"
   } else {
 #include "qmpc_solve_body.inc"

@@ -43,7 +43,10 @@ struct LayoutW {
   int GK, WR;
 };
 constexpr int kGK = 27;
-__host__ __device__ inline Layout make_layout_w(int N, LayoutW* W) {
+// workspace variant (kd_global): the gains KD, the per-point records ROT and the per-knot blocks GK live in a global
+// workspace slice of the instance, [KD | ROT | GK], instead of LDS (19 KB of LDS at N=10: two waves per SIMD)
+__host__ __device__ inline size_t wform_slice(int N) { return ((size_t)N * (13 * 12 + 21 * 4 + kGK) + 1 + 1) & ~(size_t)1; }
+__host__ __device__ inline Layout make_layout_w(int N, LayoutW* W, bool kd_global = false) {
   Layout L;
   int o = 0;
   auto take = [&](int n) { int r = o; o += n; return r; };
@@ -63,9 +66,13 @@ __host__ __device__ inline Layout make_layout_w(int N, LayoutW* W) {
   L.RC = take(N * nc);
   L.AB = take(N * kAB);
   L.XT = take((N + 1) * kXT);
-  L.KD = take(N * 13 * nu);       // per knot [Xw | xw] (rows 0..5) and [Xz | xz] (rows 6..11), 13 entries per row
-  L.ROT = take(N * 21 * nl);      // per (knot, point): T (9), l10 l20 l21, id0 id1 id2, gq (3), 3 spare (zeta, below)
-  W->GK = take(N * kGK);
+  if (kd_global) {
+    L.KD = 0; L.ROT = N * 13 * nu; W->GK = N * (13 * nu + 21 * nl);      // offsets inside the workspace slice
+  } else {
+    L.KD = take(N * 13 * nu);       // per knot [Xw | xw] (rows 0..5) and [Xz | xz] (rows 6..11), 13 entries per row
+    L.ROT = take(N * 21 * nl);      // per (knot, point): T (9), l10 l20 l21, id0 id1 id2, gq (3), 3 spare (zeta, below)
+    W->GK = take(N * kGK + 1);      // per knot G (21) r6 (6); one 0.0 behind the array (masked operand reads point at it)
+  }
   W->WR = take(N * 6);
   L.tile = L.S;                   // set-up scratch (one record): the slack arrays are initialised after it
   L.total = (o + 1) & ~1;
@@ -75,14 +82,14 @@ __host__ __device__ inline Layout make_layout_w(int N, LayoutW* W) {
 __device__ __forceinline__ int zeta_slot(int k, int i) { return 84 * k + 21 * (i / 3) + 18 + (i % 3); }
 
 constexpr int S6I_(int i, int j) { return i * 6 - i * (i - 1) / 2 + (j - i); }
-__host__ __device__ constexpr int S6I(int i, int j) { return i <= j ? S6I_(i, j) : S6I_(j, i); }
+__host__ __device__ constexpr int S6I(int i, int j) { return i <= j ? S6I_(i, j) : S6I_(j, i); }      // also at run time
 
 // ---- pre-pass over (knot, contact point), one lane each: barrier weights, rotated frame, L D L' of the 3 x 3 block,
 // and the point's share of G = sum V D^-1 V', r6 = sum V D^-1 g (the arithmetic of rotation_prepass in
 // qmpc_kernels.hip followed by leg_block / pass B step 1 of qmpc_lane_core.h).  The four points of a knot sit in one
 // lane quad: their shares are summed with quad_perm moves and lane 0 of the quad stores the knot's 27 numbers. ----
-__device__ inline void prepass_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm, const double* sl,
-                                 double* ROT, double target, int lane) {
+__device__ inline void prepass_w(const DevParams& P, const Layout& L, double* sm, const double* sl,
+                                 double* ROT, double* GK, double target, int lane) {
   typedef Dim<4> D;
   const int N = P.N;
   const double* cst = sm + L.cst;
@@ -236,7 +243,7 @@ __device__ inline void prepass_w(const DevParams& P, const Layout& L, const Layo
       acc[i] = v;
     }
     if (live && l == 0) {
-      double* gk = sm + LW.GK + kGK * k;
+      double* gk = GK + kGK * k;
 #pragma unroll
       for (int i = 0; i < kGK; ++i) gk[i] = acc[i];
     }
@@ -274,17 +281,71 @@ __device__ __forceinline__ d4 mtm2(const double X[2], const double Y[2], d4 acc)
 // per-lane multipliers of the two column operations (lane c = column c of the fragment)
 struct ColOps {
   double m1c, m2c, keep, hsel;
-  int woff[3], aoff[3];
   __device__ __forceinline__ void init(const DevParams& P, int c) {
     const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
     m1c = (c < 3) ? m1 : 0.0;
     m2c = (c < 3) ? m2 : ((c < 6) ? P.h : 0.0);
     keep = (c >= 3 && c < 6) ? 0.0 : 1.0;
     hsel = (c >= 6 && c < 9) ? P.h : 0.0;
+  }
+};
+// Lane patterns of the backward pass, computed ONCE per solve (they depend on the lane and the horizon only): fragment
+// rows r_e = 4 e + g.  Every per-knot operand is one LDS read at a lane-constant index that steps back by the record
+// size per knot; lanes outside a pattern read slots that hold 0.0 (fixed index, stride 0), so no select follows the
+// loads.  The three column multipliers wt[t] / at[t] of a lane sit 3 doubles apart in the knot's record (immediate
+// offsets of one index register); the Wt block of the M fragment and the A1 / A3 blocks of the N = Abar - I fragment
+// ARE those multipliers on the lanes whose fragment row is 3 + t.
+constexpr int kZeroSlots = 54;      // cst[54..63] hold 0.0 (cst[] is used up to slot 52)
+struct BwPat {
+  ColOps co;
+  double Mc[3], Nc[2], qadd[3], sel[3];     // sel[t]: 1.0 where the lane's fragment row is 3 + t
+  int ix_w, st_w, ix_a, st_a, ix_x[3], st_x[3], ix_g[2], st_g[2], kwo[2], xoffN[3];
+  bool c12;
+  __device__ __forceinline__ void init(const DevParams& P, const Layout& L, int lane) {
+    const int N = P.N;
+    const int c = lane & 15, g = lane >> 4;
+    co.init(P, c);
+    const int zs = L.cst + kZeroSlots;
+    const bool c35 = (c >= 3 && c < 6), c911 = (c >= 9 && c < 12);
+    c12 = c == 12;
+    const int abN = L.AB + kAB * (N - 1);
+    ix_w = c35 ? abN + 18 + (c - 3) : zs;   st_w = c35 ? kAB : 0;
+    ix_a = c35 ? abN + (c - 3) : (c911 ? abN + 9 + (c - 9) : zs);   st_a = (c35 || c911) ? kAB : 0;
+    sel[0] = (g == 3) ? 1.0 : 0.0;      // row 3 + t lives in (e, g) = (0, 3), (1, 0), (1, 1)
+    sel[1] = (g == 0) ? 1.0 : 0.0;
+    sel[2] = (g == 1) ? 1.0 : 0.0;
+    const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      woff[t] = (c >= 3 && c < 6) ? 18 + 3 * t + (c - 3) : -1;
-      aoff[t] = (c >= 3 && c < 6) ? 3 * t + (c - 3) : ((c >= 9 && c < 12) ? 9 + 3 * t + (c - 9) : -1);
+    for (int e = 0; e < 3; ++e) {
+      const int r = 4 * e + g;
+      const bool phi = (r >= 3 && r < 6);
+      double v = 0.0;
+      if (c < 6) {
+        if (r < 3) v = (r == c) ? m1 : 0.0;
+        else if (r >= 6 && r < 9) v = (r - 6 == c) ? m2 : 0.0;
+        else if (r >= 9) v = (r - 9 == c - 3) ? P.h : 0.0;
+      }
+      Mc[e] = v;
+      qadd[e] = (c < 12 && r == c && !phi) ? P.Q[(r < 3) ? r : r + 1] : 0.0;
+      const bool xv = (phi && c35) || c12;
+      const int xo = c12 ? 9 + r : 3 * (r - 3) + (c - 3);
+      xoffN[e] = xv ? xo : -1;
+      ix_x[e] = xv ? L.XT + kXT * (N - 1) + xo : zs;
+      st_x[e] = xv ? kXT : 0;
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int r = 4 * e + g;
+      const bool phi = (r >= 3 && r < 6);
+      // N = Abar - I, rows 0..7 (rows 6, 7 are zero)
+      Nc[e] = (r < 3 && c == r + 6) ? P.h : ((phi && r == c) ? -1.0 : 0.0);
+      // G (columns 0..5) and r6 (column 12) share a register: as the A operand of G Yp the column 12 only feeds the
+      // unused output row 12
+      const bool gv = r < 6 && (c < 6 || c12);
+      const int go = c12 ? 21 + r : S6I(r < 6 ? r : 0, c < 6 ? c : 0);
+      ix_g[e] = gv ? kGK * (N - 1) + go : kGK * N;      // relative to GK; GK[27 N] holds 0.0
+      st_g[e] = gv ? kGK : 0;
+      kwo[e] = (r < 6 && c < 13) ? 13 * r + c : -1;      // [Xw | xw] row r; [Xz | xz] row 6 + r is 78 doubles further
     }
   }
 };
@@ -376,71 +437,21 @@ __device__ __forceinline__ double gj6_step(double M[2], double Rr[2], int c, int
 // Riccati backward pass in the wrench form; writes per knot [Xw | xw] and [Xz | xz] (KD).  Returns nonzero when a pivot
 // of W' is not positive (P lost positive definiteness: QMPC_NOT_PD).
 template <bool PROF>
-__device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm, double* KD,
-                                      int lane, Prof<PROF>& prof) {
+__device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const BwPat& bp, double* sm, double* KD,
+                                      const double* GK, int lane, Prof<PROF>& prof) {
   const int N = P.N;
   const int c = lane & 15, g = lane >> 4;
   const double wscale = (0.5 * P.hh) * P.h;        // Wt = (h^2 / 4) Gn'Gm
-  ColOps co;
-  co.init(P, c);
-  // fragment patterns, rows r_e = 4 e + g.  Every per-knot operand is ONE LDS read at a lane-constant index that steps
-  // back by the record size per knot; lanes outside a pattern read a slot that holds 0.0 (index fixed), so no select
-  // follows the loads.  The Wt block of the M fragment and the A1 / A3 blocks of the N = Abar - I fragment are the
-  // column-operation multipliers wt[], at[] of the same lane.
-  const int zslot = L.cst + 63;
-  double Mc[3], Nc[2], qadd[3];
-  double msel[3], nsel[3];          // 1.0 where the lane's fragment row takes wt[t] / at[t]: rows 3 + t
-  int ix_w[3], ix_a[3], ix_x[3], ix_g[2], st_w[3], st_a[3], st_x[3], st_g[2], kwo[2], kzo[2];
-  int xoffN[3];
-  bool rowok[2];
-  {
-    const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const bool wv = co.woff[t] >= 0, av = co.aoff[t] >= 0;
-      ix_w[t] = wv ? L.AB + kAB * (N - 1) + co.woff[t] : zslot;  st_w[t] = wv ? kAB : 0;
-      ix_a[t] = av ? L.AB + kAB * (N - 1) + co.aoff[t] : zslot;  st_a[t] = av ? kAB : 0;
-    }
-    // row 3 + t lives in (e, g) = (0, 3), (1, 0), (1, 1)
-    msel[0] = nsel[0] = (g == 3) ? 1.0 : 0.0;
-    msel[1] = nsel[1] = (g == 0) ? 1.0 : 0.0;
-    msel[2] = nsel[2] = (g == 1) ? 1.0 : 0.0;
-#pragma unroll
-    for (int e = 0; e < 3; ++e) {
-      const int r = 4 * e + g;
-      const bool phi = (r >= 3 && r < 6);
-      double v = 0.0;
-      if (c < 6) {
-        if (r < 3) v = (r == c) ? m1 : 0.0;
-        else if (r >= 6 && r < 9) v = (r - 6 == c) ? m2 : 0.0;
-        else if (r >= 9) v = (r - 9 == c - 3) ? P.h : 0.0;
-      }
-      Mc[e] = v;
-      const bool cval = c < 12;
-      qadd[e] = (cval && r == c && !phi) ? P.Q[(r < 3) ? r : r + 1] : 0.0;
-      int xo = -1;
-      if (phi && c >= 3 && c < 6) xo = 3 * (r - 3) + (c - 3);
-      if (c == 12) xo = 9 + r;
-      xoffN[e] = xo;
-      ix_x[e] = (xo >= 0) ? L.XT + kXT * (N - 1) + xo : zslot;
-      st_x[e] = (xo >= 0) ? kXT : 0;
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int r = 4 * e + g;
-      const bool phi = (r >= 3 && r < 6);
-      // N = Abar - I, rows 0..7 (rows 6, 7 are zero)
-      Nc[e] = (r < 3 && c == r + 6) ? P.h : ((phi && r == c) ? -1.0 : 0.0);
-      rowok[e] = r < 6;
-      // G (columns 0..5) and r6 (column 12) share a register: as the A operand of G Yp the column 12 only feeds the
-      // unused output row 12
-      const int go = (r < 6 && c < 6) ? S6I(r, c) : ((r < 6 && c == 12) ? 21 + r : -1);
-      ix_g[e] = (go >= 0) ? LW.GK + kGK * (N - 1) + go : zslot;
-      st_g[e] = (go >= 0) ? kGK : 0;
-      kwo[e] = (r < 6 && c < 13) ? 13 * r + c : -1;
-      kzo[e] = (r < 6 && c < 13) ? 13 * (6 + r) + c : -1;
-    }
-  }
+  const ColOps& co = bp.co;
+  const double* Mc = bp.Mc;
+  const double* Nc = bp.Nc;
+  const double* qadd = bp.qadd;
+  const double* msel = bp.sel;
+  const double* nsel = bp.sel;
+  const int* xoffN = bp.xoffN;
+  const int* kwo = bp.kwo;
+  int ix_w = bp.ix_w, ix_a = bp.ix_a, ix_x[3] = {bp.ix_x[0], bp.ix_x[1], bp.ix_x[2]}, ix_g[2] = {bp.ix_g[0], bp.ix_g[1]};
+  const bool rowok1 = kwo[1] >= 0;
   // ---- terminal cost-to-go  P_aug = [lxx_N | lx_N] ----
   double Pf[3];
   {
@@ -455,11 +466,12 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
   auto load_ops = [&](KnotOps& o) {       // the knot the running indices point at; then one knot back
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-      o.wt[t] = sm[ix_w[t]]; o.at[t] = sm[ix_a[t]]; o.xt[t] = sm[ix_x[t]];
-      ix_w[t] -= st_w[t]; ix_a[t] -= st_a[t]; ix_x[t] -= st_x[t];
+      o.wt[t] = sm[ix_w + 3 * t]; o.at[t] = sm[ix_a + 3 * t]; o.xt[t] = sm[ix_x[t]];
+      ix_x[t] -= bp.st_x[t];
     }
+    ix_w -= bp.st_w; ix_a -= bp.st_a;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) { o.gr[e] = sm[ix_g[e]]; ix_g[e] -= st_g[e]; }
+    for (int e = 0; e < 2; ++e) { o.gr[e] = GK[ix_g[e]]; ix_g[e] -= bp.st_g[e]; }
   };
   KnotOps ops, opn;
   load_ops(ops);
@@ -475,8 +487,8 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
     Mf[2] = Mc[2];
     Nf[0] = fma(nsel[0], at[0], Nc[0]);
     Nf[1] = fma(nsel[1], at[1], fma(nsel[2], at[2], Nc[1]));
-    R6f[0] = (c == 12) ? ops.gr[0] : 0.0;
-    R6f[1] = (c == 12) ? ops.gr[1] : 0.0;
+    R6f[0] = bp.c12 ? ops.gr[0] : 0.0;
+    R6f[1] = bp.c12 ? ops.gr[1] : 0.0;
     tick_dep(prof, PH_BUILD, Pf[0], Pf[1]);
     // ---- 1. Yp = M' [P | p]  (6 x 13) ----
     double Yp[2];
@@ -511,7 +523,7 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
     const double n5 = gj6_step<5>(Wm, Qf, c, g, minpiv);
     double Xf[2];
     Xf[0] = Qf[0] * ((g == 0) ? n0 : (g == 1 ? n1 : (g == 2 ? n2 : n3)));      // X = -diag^-1 Q
-    Xf[1] = rowok[1] ? Qf[1] * ((g == 0) ? n4 : n5) : 0.0;
+    Xf[1] = rowok1 ? Qf[1] * ((g == 0) ? n4 : n5) : 0.0;
     tick_dep(prof, PH_SOLVE, Xf[0], Xf[1]);
     // ---- 6. Pi = [P | p] + Yp_fb' X ;  7. gains [Xz | xz] = Yp + S6 X ----
     double Pi[3];
@@ -539,7 +551,7 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
       double* KDk = KD + 156 * k;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        if (kwo[e] >= 0) { KDk[kwo[e]] = Xf[e]; KDk[kzo[e]] = Zf[e]; }
+        if (kwo[e] >= 0) { KDk[kwo[e]] = Xf[e]; KDk[kwo[e] + 78] = Zf[e]; }
       }
     }
     ops = opn;
@@ -645,7 +657,9 @@ __device__ __forceinline__ void roll_load_w(const Layout& L, const LayoutW& LW, 
   for (int i = 0; i < 13; ++i) r.kd[i] = kd[i];
   r.wk = sm[LW.WR + 6 * k + wi];
 }
-template <bool PROF>
+// PF: the next knot's gains / old state / Jacobian blocks are loaded one knot ahead into a second register set (90 more
+// registers: the one-wave-per-SIMD form); without it the loads sit at the top of the knot (two waves per SIMD hide them)
+template <bool PROF, bool PF>
 __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm,
                                         const double* KD, double* ROT, int lane, Prof<PROF>& prof) {
   typedef Dim<4> D;
@@ -664,7 +678,8 @@ __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, con
     for (int i = 0; i < 13; ++i) sm[L.Xc + i] = xc[i];
   // one knot: gains / old state / Jacobian blocks in `cur`, the next knot's loaded into `nxt` meanwhile (the loop body is
   // instantiated twice with the roles swapped: no register copies)
-  auto knot = [&](int k, const RollLoadsW& cur, RollLoadsW& nxt) {
+  auto knot = [&](int k, RollLoadsW& cur, RollLoadsW& nxt) {
+    if (!PF) roll_load_w(L, LW, sm, KD, k, row, wi, cur);
     double dx[12], e[12];
     QuatModel::state_diff(cur.xo, xc, dx);
     // e = Abar dx
@@ -685,7 +700,7 @@ __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, con
     if (zlane) ROT[zeta_slot(k, lane - 6)] = s;      // the costate of the contact points, for the input recovery
     double wn = cur.wk + s;
     tick_dep1(prof, PH_R_GAIN, wn);
-    if (k + 1 < N) roll_load_w(L, LW, sm, KD, k + 1, row, wi, nxt);      // one knot ahead
+    if (PF && k + 1 < N) roll_load_w(L, LW, sm, KD, k + 1, row, wi, nxt);      // one knot ahead
     double w[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) w[i] = read_lane(wn, i);
@@ -698,11 +713,16 @@ __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, con
       for (int i = 0; i < 13; ++i) sm[L.Xc + 13 * (k + 1) + i] = xn[i];
     tick_dep(prof, PH_R_STEP, xc[3], xc[10]);
   };
-  RollLoadsW ra, rb;
-  roll_load_w(L, LW, sm, KD, 0, row, wi, ra);
-  for (int k = 0; k < N; k += 2) {
-    knot(k, ra, rb);
-    if (k + 1 < N) knot(k + 1, rb, ra);
+  if (PF) {
+    RollLoadsW ra, rb;
+    roll_load_w(L, LW, sm, KD, 0, row, wi, ra);
+    for (int k = 0; k < N; k += 2) {
+      knot(k, ra, rb);
+      if (k + 1 < N) knot(k + 1, rb, ra);
+    }
+  } else {
+    RollLoadsW ra;
+    for (int k = 0; k < N; ++k) knot(k, ra, ra);
   }
   QSYNC();
 }

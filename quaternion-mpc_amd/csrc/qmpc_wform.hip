@@ -40,10 +40,13 @@
 namespace qmpc {
 
 // ---- the solve kernel (QuatMpc's problem, four contact points, everything in LDS, one wave per SIMD) -----------------
-template <bool PROF>
-__global__ __launch_bounds__(64, 1) void qmpc_solve_w_kernel(
+// WVAR 3: everything in LDS, one wave per SIMD (small batches); 5: gains, per-point records and per-knot blocks in the
+// global workspace (one slice per instance), two waves per SIMD (mid-size batches)
+template <bool PROF, int WVAR>
+__global__ __launch_bounds__(64, WVAR == 5 ? 2 : 1) void qmpc_solve_w_kernel(
     DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
-    double* __restrict__ traj_u, double* __restrict__ traj_x, int batch, long long* __restrict__ prof_out) {
+    double* __restrict__ traj_u, double* __restrict__ traj_x, int batch, long long* __restrict__ prof_out,
+    double* __restrict__ gws) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int b = blockIdx.x;
   if (b >= batch) return;
@@ -60,29 +63,36 @@ __global__ __launch_bounds__(64, 1) void qmpc_solve_w_kernel(
 using namespace qmpc_wform_tu;
 
 // called from qmpc_hip.hip (declared there); hidden: not part of the C ABI
-__attribute__((visibility("hidden"))) size_t qmpc_wform_lds_bytes(int N) {
+__attribute__((visibility("hidden"))) size_t qmpc_wform_lds_bytes(int N, int kd_global) {
   LayoutW LW;
-  return (size_t)make_layout_w(N, &LW).total * sizeof(double);
+  return (size_t)make_layout_w(N, &LW, kd_global != 0).total * sizeof(double);
 }
+__attribute__((visibility("hidden"))) size_t qmpc_wform_slice_doubles(int N) { return wform_slice(N); }
 __attribute__((visibility("hidden"))) hipError_t qmpc_wform_set_lds(int bytes) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_w_kernel<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(qmpc_solve_w_kernel<true>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  const void* k[4] = {reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 3>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 3>),
+                      reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 5>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 5>)};
+  for (int i = 0; i < 4; ++i) {
+    const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
-__attribute__((visibility("hidden"))) hipError_t qmpc_wform_launch(int prof, int batch, size_t lds, hipStream_t s,
+// var: 3 everything in LDS, 5 gains in the workspace gws
+__attribute__((visibility("hidden"))) hipError_t qmpc_wform_launch(int var, int prof, int batch, size_t lds, hipStream_t s,
                                                                    const void* dev_params, size_t dev_params_size,
                                                                    const qmpc_input* in, double* forces, qmpc_info* info,
-                                                                   double* traj_u, double* traj_x, long long* prof_out) {
+                                                                   double* traj_u, double* traj_x, long long* prof_out, double* gws) {
   if (dev_params_size != sizeof(DevParams)) return hipErrorInvalidValue;
   DevParams P;
   std::memcpy(&P, dev_params, sizeof P);
-  if (prof)
-    hipLaunchKernelGGL(qmpc_solve_w_kernel<true>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in, forces, info, traj_u,
-                       traj_x, batch, prof_out);
-  else
-    hipLaunchKernelGGL(qmpc_solve_w_kernel<false>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in, forces, info, traj_u,
-                       traj_x, batch, prof_out);
+#define QMPC_LAUNCH_W(PR, V) \
+  hipLaunchKernelGGL((qmpc_solve_w_kernel<PR, V>), dim3((unsigned)batch), dim3(kWave), lds, s, P, in, forces, info, traj_u, traj_x, \
+                     batch, prof_out, gws)
+  if (var == 5) {
+    if (prof) QMPC_LAUNCH_W(true, 5); else QMPC_LAUNCH_W(false, 5);
+  } else {
+    if (prof) QMPC_LAUNCH_W(true, 3); else QMPC_LAUNCH_W(false, 3);
+  }
+#undef QMPC_LAUNCH_W
   return hipGetLastError();
 }

@@ -8,7 +8,7 @@ lines = open(sys.argv[1]).read().split('\n')
 key = sys.argv[2]
 minsz = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 start = [i for i, l in enumerate(lines) if re.match(r'^_Z\S*:', l) and key in l][0]
-end = [i for i, l in enumerate(lines) if i > start and 's_endpgm' in l][0]
+ends = [i for i, l in enumerate(lines) if i > start and ".end_amdhsa_kernel" in l]; end = ends[0] if ends else len(lines)
 body = lines[start:end]
 blocks, cur, name = [], [], 'entry'
 for l in body:
