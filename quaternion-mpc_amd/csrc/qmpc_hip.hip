@@ -253,7 +253,7 @@ static qmpc_status create_resources(qmpc_handle* h, int N, int nl, int nu) {
     QMPC_SET_LDS(qmpc_linearize_kernel<QuatModel>, h->lds_bytes_g);
   }
   if (params->model != QMPC_MODEL_QUAT8)
-    for (int v = 0; v < 4; ++v) HIP_TRY(qmpc_fused_set_lds(v, 160 * 1024));     // the closed loop's persistent kernels
+    for (int v = 0; v < 6; ++v) if (v != 4) HIP_TRY(qmpc_fused_set_lds(v, 160 * 1024));     // the closed loop's persistent kernels
   if (params->model != QMPC_MODEL_QUAT8) HIP_TRY(qmpc_warm_set_lds(160 * 1024));
   if (params->model == QMPC_MODEL_QUAT) HIP_TRY(qmpc_wform_set_lds(160 * 1024));
   if (params->mode == QMPC_MODE_REFERENCE) {
@@ -416,11 +416,11 @@ static bool use_wform(const qmpc_handle* h, int32_t batch) { return wform_varian
 // variant of the converged-mode kernels that share a body (plain solve, warm-started solve, persistent loop kernel):
 // pick_variant's 0 / 1 / 2, or 3 = the wrench form where it applies -- the three launch forms must agree, they are
 // bit-identical only on the same body
-static int body_variant(const qmpc_handle* h, int32_t batch) { return use_wform(h, batch) ? 3 : pick_variant(h, batch); }
+static int body_variant(const qmpc_handle* h, int32_t batch) { const int wv = wform_variant(h, batch); return wv ? wv : pick_variant(h, batch); }
 static size_t variant_lds(const qmpc_handle* h, int var) {
-  return var == 3 ? h->lds_bytes_w : (var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes));
+  return var == 5 ? h->lds_bytes_wg : (var == 3 ? h->lds_bytes_w : (var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes)));
 }
-static double* variant_gws(const qmpc_handle* h, int var) { return (var == 1 || var == 2) ? h->d_gws : nullptr; }
+static double* variant_gws(const qmpc_handle* h, int var) { return (var == 1 || var == 2 || var == 5) ? h->d_gws : nullptr; }
 
 static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces,
                                 qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s, bool timed = true) {
@@ -1160,9 +1160,9 @@ qmpc_status qmpc_debug_profile(qmpc_handle* h, int32_t batch, const qmpc_input* 
   HIP_TRY(hipMalloc(&d_prof, sizeof(long long) * 16 * (size_t)batch));
   HIP_TRY(hipMemsetAsync(d_prof, 0, sizeof(long long) * 16 * (size_t)batch, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_in, in, sizeof(qmpc_input) * (size_t)batch, hipMemcpyHostToDevice, h->stream));
-  if (use_wform(h, batch))
-    HIP_TRY(qmpc_wform_launch(3, 1, (int)batch, h->lds_bytes_w, h->stream, &h->dev, sizeof h->dev, h->d_in, h->d_forces, h->d_info,
-                              nullptr, nullptr, d_prof, nullptr));
+  if (const int wv = wform_variant(h, batch))
+    HIP_TRY(qmpc_wform_launch(wv, 1, (int)batch, variant_lds(h, wv), h->stream, &h->dev, sizeof h->dev, h->d_in, h->d_forces, h->d_info,
+                              nullptr, nullptr, d_prof, variant_gws(h, wv)));
   else if (use_global_gains(h, batch))
     hipLaunchKernelGGL((qmpc_solve_kernel<QuatModel, true, 1>), dim3((unsigned)batch), dim3(kWave), h->lds_bytes_g, h->stream,
                        h->dev, h->d_in, h->d_forces, h->d_info, (double*)nullptr, (double*)nullptr, (int)batch, d_prof,

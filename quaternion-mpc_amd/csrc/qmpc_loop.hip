@@ -417,7 +417,8 @@ struct FusedJoint {          // the joint level closing every tick (JOINT instan
   qmpc_joint_command* cmd;
   qmpc_joint_command* trace;
 };
-// VAR: 0 / 1 / 2 as in qmpc_solve_kernel; 3: the wrench-form body (qmpc_wform_body.inc; QuatMpc's problem, converged mode)
+// VAR: 0 / 1 / 2 as in qmpc_solve_kernel; 3 / 5: the wrench-form body (qmpc_wform_body.inc; QuatMpc's problem, converged
+// mode) with everything in LDS / with its gains in the workspace
 // REF: the reference's own solver mode (AL-iLQR, <= 10 iterations; one wave per SIMD like qmpc_ref_kernel, VAR 0 / 1)
 // CONVEX: the sibling controller's problem (ConvexModel; converged mode only)
 template <int VAR, bool JOINT, bool REF, bool CONVEX = false>
@@ -445,10 +446,10 @@ __global__ __launch_bounds__(64, REF ? 1 : QMPC_SOLVE_WAVES(QuatModel, VAR)) voi
       [&]() {                             // `return` in the body (rejected input) ends this tick's solve only
 #include "qmpc_ref_body.inc"
       }();
-    } else if constexpr (VAR == 3) {
+    } else if constexpr (VAR == 3 || VAR == 5) {
       [&]() {
         const int warm_t = (LP.warm_start != 0.0 && prev_ok) ? t : 0;   // t > 0 and the last solve left a usable U in LDS
-        constexpr int WVAR = 3;
+        constexpr int WVAR = VAR;
 #include "qmpc_wform_body.inc"
       }();
     } else {
@@ -496,12 +497,12 @@ __global__ __launch_bounds__(64, QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_sol
   const int warm_t = usable ? 1 : 0;
   if (usable) {
     LayoutW LWw;
-    const Layout Lw = (VAR == 3) ? make_layout_w(P.N, &LWw) : make_layout(P.N, VAR == 1 || VAR == 2, MD::NL, VAR == 2);
+    const Layout Lw = (VAR == 3 || VAR == 5) ? make_layout_w(P.N, &LWw, VAR == 5) : make_layout(P.N, VAR == 1 || VAR == 2, MD::NL, VAR == 2);
     for (int i = lane; i < P.N * 12; i += kWave) sm[Lw.U + i] = u_init[(size_t)b * P.N * 12 + i];
     __syncthreads();
   }
-  if constexpr (VAR == 3) {
-    constexpr int WVAR = 3;
+  if constexpr (VAR == 3 || VAR == 5) {
+    constexpr int WVAR = VAR;
 #include "qmpc_wform_body.inc"
   } else {
 #include "qmpc_solve_body.inc"

@@ -21,6 +21,7 @@ static const void* fused_kernel(int var) {
   if (REF) return var >= 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1, JOINT, true, false>)
                            : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0, JOINT, true, false>);
   if (var == 3 && !CONVEX) return reinterpret_cast<const void*>(qmpc_loop_fused_kernel<3, JOINT, false, false>);
+  if (var == 5 && !CONVEX) return reinterpret_cast<const void*>(qmpc_loop_fused_kernel<5, JOINT, false, false>);
   return var == 2 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<2, JOINT, false, CONVEX>)
                   : (var == 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1, JOINT, false, CONVEX>)
                               : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0, JOINT, false, CONVEX>));
@@ -37,7 +38,7 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_fused_set_lds(int var, int
 }
 
 // var: 0 everything in LDS, 1 gains in the workspace, 2 gains and slack arrays there (converged mode only),
-// 3 the wrench form with everything in LDS (QuatMpc's problem, converged mode)
+// 3 / 5 the wrench form with everything in LDS / with its gains in the workspace (QuatMpc's problem, converged mode)
 __attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int reference_mode, int convex, int batch, size_t lds,
                                                                    hipStream_t s,
                                                                    const void* dev_params, size_t dev_params_size,
@@ -79,6 +80,7 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int 
     else QMPC_LAUNCH_FUSED_J(0, true);
   } else {
     if (var == 3) QMPC_LAUNCH_FUSED_J(3, false);
+    else if (var == 5) QMPC_LAUNCH_FUSED_J(5, false);
     else if (var == 2) QMPC_LAUNCH_FUSED_J(2, false);
     else if (var == 1) QMPC_LAUNCH_FUSED_J(1, false);
     else QMPC_LAUNCH_FUSED_J(0, false);
@@ -91,11 +93,11 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int 
 }
 
 __attribute__((visibility("hidden"))) hipError_t qmpc_warm_set_lds(int bytes) {
-  const void* k[7] = {reinterpret_cast<const void*>(qmpc_solve_warm_kernel<0, false>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<1, false>),
+  const void* k[8] = {reinterpret_cast<const void*>(qmpc_solve_warm_kernel<0, false>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<1, false>),
                       reinterpret_cast<const void*>(qmpc_solve_warm_kernel<2, false>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<0, true>),
                       reinterpret_cast<const void*>(qmpc_solve_warm_kernel<1, true>),  reinterpret_cast<const void*>(qmpc_solve_warm_kernel<2, true>),
-                      reinterpret_cast<const void*>(qmpc_solve_warm_kernel<3, false>)};
-  for (int i = 0; i < 7; ++i) {
+                      reinterpret_cast<const void*>(qmpc_solve_warm_kernel<3, false>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<5, false>)};
+  for (int i = 0; i < 8; ++i) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
   }
@@ -118,6 +120,7 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_warm_launch(int var, int c
     else QMPC_LAUNCH_WARM(0, true);
   } else {
     if (var == 3) QMPC_LAUNCH_WARM(3, false);
+    else if (var == 5) QMPC_LAUNCH_WARM(5, false);
     else if (var == 2) QMPC_LAUNCH_WARM(2, false);
     else if (var == 1) QMPC_LAUNCH_WARM(1, false);
     else QMPC_LAUNCH_WARM(0, false);

@@ -396,7 +396,7 @@ __device__ __forceinline__ double times_Abar(double x, const ColOps& co, const d
 #define QMPC_GJ_FUSED 0     // measured: 1.76 M against 1.82 M solves/s -- the 64-bit DPP form issues slower than mov + fma
 #endif
 template <int J>
-__device__ __forceinline__ double gj6_step(double M[2], double Rr[2], int c, int g, double& minpiv) {
+__device__ __forceinline__ double gj6_step(double M[2], double Rr[2], int c, int g, bool& pd) {
   constexpr int ej = J >> 2, gj = J & 3;
   double mrow, rrow;
   if (QMPC_GJ_PERM) {
@@ -408,7 +408,7 @@ __device__ __forceinline__ double gj6_step(double M[2], double Rr[2], int c, int
     rrow = __shfl(Rr[ej], src);
   }
   const double piv = read_lane(M[ej], (gj << 4) | J);
-  minpiv = fmin(minpiv, piv);
+  pd = pd && (piv > 0.0);          // false for a NaN pivot too (fmin / fmax would drop it silently)
   const double ninv = -fast_rcp(piv);
 #if QMPC_GJ_FUSED
   // X[r][c] += X[r][J] * (-row_J[c] / piv) as ONE v_fmac_f64 with a DPP source per fragment register; the DPP row mask
@@ -459,7 +459,7 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
 #pragma unroll
     for (int e = 0; e < 3; ++e) Pf[e] = qadd[e] + ((xoffN[e] >= 0) ? XTk[xoffN[e]] : 0.0);
   }
-  double minpiv = 1e300;
+  bool pd = true;
   const d4 z4 = {0.0, 0.0, 0.0, 0.0};
   // operands of a knot (independent of the cost-to-go): loaded one knot ahead, right after the first products are issued
   struct KnotOps { double wt[3], at[3], gr[2], xt[3]; };
@@ -515,12 +515,12 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
     Wm[1] = S6[1] + times_M(Qf[1], co, wt);
     tick_dep(prof, PH_MFMA, Wm[0], Wm[1]);
     // ---- 5. W' X = -Q ----
-    const double n0 = gj6_step<0>(Wm, Qf, c, g, minpiv);
-    const double n1 = gj6_step<1>(Wm, Qf, c, g, minpiv);
-    const double n2 = gj6_step<2>(Wm, Qf, c, g, minpiv);
-    const double n3 = gj6_step<3>(Wm, Qf, c, g, minpiv);
-    const double n4 = gj6_step<4>(Wm, Qf, c, g, minpiv);
-    const double n5 = gj6_step<5>(Wm, Qf, c, g, minpiv);
+    const double n0 = gj6_step<0>(Wm, Qf, c, g, pd);
+    const double n1 = gj6_step<1>(Wm, Qf, c, g, pd);
+    const double n2 = gj6_step<2>(Wm, Qf, c, g, pd);
+    const double n3 = gj6_step<3>(Wm, Qf, c, g, pd);
+    const double n4 = gj6_step<4>(Wm, Qf, c, g, pd);
+    const double n5 = gj6_step<5>(Wm, Qf, c, g, pd);
     double Xf[2];
     Xf[0] = Qf[0] * ((g == 0) ? n0 : (g == 1 ? n1 : (g == 2 ? n2 : n3)));      // X = -diag^-1 Q
     Xf[1] = rowok1 ? Qf[1] * ((g == 0) ? n4 : n5) : 0.0;
@@ -557,7 +557,7 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
     ops = opn;
     tick_dep(prof, PH_PUPD, Pf[0], Pf[1]);
   }
-  return !(minpiv > 0.0);   // also true for a NaN pivot
+  return !pd;
 }
 
 // ---- explicit midpoint step given the wrench w = (sum of the forces, sum of Bw0_l u_l) (AltroUtils.cpp:9-22 on :363-392)
@@ -729,10 +729,13 @@ __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, con
 
 // ---- input increments of the trial step, one lane per (knot, contact point):
 //      du_l = -T_l D~_l^-1 (V_l' zeta + gq_l),   V_l' zeta = T_l' (zeta_f + Bw0_l' zeta_t) ----
-__device__ inline void recover_inputs_w(const DevParams& P, const Layout& L, double* sm, const double* ROT, int lane) {
+// Returns nonzero (wave-uniform) when an increment is not finite: the trial step is then NOT applied (QMPC_NOT_PD, the
+// rule of the lane kernel) -- the step-length reductions that follow drop NaNs silently.
+__device__ inline int recover_inputs_w(const DevParams& P, const Layout& L, double* sm, const double* ROT, int lane) {
   typedef Dim<4> D;
   const int N = P.N;
   const double* cst = sm + L.cst;
+  bool bad = false;
   for (int q = lane; q < 4 * N; q += kWave) {
     const int k = q >> 2, l = q & 3;
     double du[3] = {0.0, 0.0, 0.0};
@@ -760,8 +763,10 @@ __device__ inline void recover_inputs_w(const DevParams& P, const Layout& L, dou
     }
     double* o = sm + L.dU + D::NU * k + 3 * l;
     o[0] = du[0]; o[1] = du[1]; o[2] = du[2];
+    bad = bad || !(isfinite(du[0]) && isfinite(du[1]) && isfinite(du[2]));
   }
   QSYNC();
+  return __any(bad ? 1 : 0);
 }
 
 
