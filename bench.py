@@ -331,12 +331,38 @@ def main():
         return {"elapsed": elapsed, "kernel_ms": kernel_ms, "info": info, "forces": forces, "rec": rec,
                 "solver": solver, "d_in": d_in}
 
-    def kernel_name(batch):
-        """dominant kernel of a launch of `batch` instances (qmpc_hip.hip: launch_solve)"""
-        lane_min = int(os.environ.get("QMPC_LANE_MIN", "21504" if args.model == "quat" else "18432"))
+    def kernel_name(batch, horizon=None):
+        """dominant kernel of a launch of `batch` instances (qmpc_hip.hip: launch_solve / wform_variant / use_lane)"""
+        hz = N if horizon is None else horizon
+        default_min = ("26624" if hz <= 12 else "16384") if args.model == "quat" else "18432"
+        lane_min = int(os.environ.get("QMPC_LANE_MIN", default_min))
         var = os.environ.get("QMPC_VARIANT", "0")
-        lane = var == "4" or (var == "0" and batch >= lane_min)
-        return "qmpc_lane_kernel (lane per instance)" if lane else "qmpc_solve_kernel (wave per instance)"
+        wf = int(os.environ.get("QMPC_WFORM", "1"))
+        if var == "4" or (var == "0" and batch >= lane_min):
+            return "qmpc_lane_kernel (lane per instance, wrench form)"
+        if args.model == "quat" and wf and var in ("0", "1"):
+            all_lds = batch <= 1024 and hz <= 10
+            if all_lds:
+                return "qmpc_solve_w_kernel<3> (wave per instance, wrench form, everything in LDS)"
+            if wf != 3:
+                return "qmpc_solve_w_kernel<5> (wave per instance, wrench form, gains in the workspace)"
+        return "qmpc_solve_kernel (wave per instance, dense 12x12 stage algebra)"
+
+    def roofline_object(kname, ach, tr, tr_src, kms, batch, compulsory):
+        """`frac` prices SURVEY 8d's algorithmic flops against the 78.6 TFLOP/s FP64 peak (the matrix and the vector FP64
+        rates of gfx950 are the same units).  `bound` says which instructions issue them in the dominant kernel: "mfma"
+        where FP64 MFMAs carry the stage products (the wave-per-instance kernels), "fp64_valu" for the lane-per-instance
+        kernel, whose ISA holds no matrix instruction (mfma_busy 0)."""
+        lane = kname.startswith("qmpc_lane_kernel")
+        o = {"bound": "fp64_valu" if lane else "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": ach / FP64_PEAK_TFLOPS, "traffic": tr, "traffic_source": tr_src, "kernel": kname, "kernel_ms": kms,
+             "algorithmic_bytes_per_launch": compulsory,
+             "hbm_GBps": (tr / (kms * 1e-3) / 1e9) if tr else None,
+             "hbm_frac_of_8TBps": (tr / (kms * 1e-3) / 8e12) if tr else None,
+             "traffic_to_compulsory": (tr / compulsory) if tr else None}
+        if lane:
+            o["storage"] = "f64 arithmetic; the 6 x 12 feedback gains are stored as packed f32 pairs (forces within 1e-6 N of the oracle)"
+        return o
 
     leg = timed_leg(B, config_id, args.steps, args.warmup)
     elapsed, kernel_ms, info, rec = leg["elapsed"], leg["kernel_ms"], leg["info"], leg["rec"]
@@ -383,14 +409,12 @@ def main():
                        "batch_per_gpu": B, "horizon": N, "parallelism": f"instance-sharded x{world}",
                        "instances": world * B, "converged": n_ok, "mean_iterations": mean_iters},
             "rates": {"device_resident": {"value": value, "unit": "solves/s", "ms_per_step": 1e3 * elapsed / args.steps}},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kernel_name(B), "kernel_ms": kernel_ms,
-                         "algorithmic_flops_per_launch": w_alg * B,
-                         "algorithmic_bytes_per_launch": B * (8 * (64 if biped else 48) + 8 * NU + 40),
-                         "note": "FP64 MFMA/vector roof (78.6 TF); algorithmic work W_alg=159*N kFLOP/solve (SURVEY 8d); "
-                                 "compulsory HBM traffic is 460 B/solve, i.e. not the binding roof"},
+            "roofline": roofline_object(kernel_name(B), achieved, traffic, traffic_src, kernel_ms, B,
+                                        B * (8 * (64 if biped else 48) + 8 * NU + 40)),
         }
+        out["roofline"]["algorithmic_flops_per_launch"] = w_alg * B
+        out["roofline"]["note"] = ("FP64 MFMA/vector roof (78.6 TF); algorithmic work W_alg=159*N kFLOP/solve (SURVEY 8d); "
+                                   "compulsory HBM traffic is 460 B/solve, i.e. not the binding roof")
         sq = sq_from_profiles(B, N, args.model)
         if sq is not None:
             out["roofline"]["mfma_busy"] = sq.get("mfma_busy")
@@ -453,14 +477,11 @@ def main():
                 tr, tr_src = traffic_from_profiles(Bl, Nl, "quat")
                 ent = {"workload": f"Batch={Bl} random Go1 states, N={Nl}, seed 0x5EED0000+{cfg}: {what}",
                        "value": Bl * kl / lg["elapsed"], "unit": "solves/s", "steps": kl, "ms_per_step": 1e3 * lg["elapsed"] / kl,
-                       "kernel": kernel_name(Bl), "kernel_ms": lg["kernel_ms"],
+                       "kernel": kernel_name(Bl, Nl), "kernel_ms": lg["kernel_ms"],
                        "converged": int((lg["info"]["status"] == 0).sum()), "mean_iterations": float(lg["info"]["iterations"].mean()),
                        "two_in_flight": {"value": Bl * 2 * kl / dt2, "unit": "solves/s", "ms_per_batch": 1e3 * dt2 / (2 * kl),
                                          "outputs_identical": same2},
-                       "roofline": {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": ach / FP64_PEAK_TFLOPS, "traffic": tr, "traffic_source": tr_src,
-                                    "hbm_GBps": (tr / (lg["kernel_ms"] * 1e-3) / 1e9) if tr else None,
-                                    "hbm_frac_of_8TBps": (tr / (lg["kernel_ms"] * 1e-3) / 8e12) if tr else None}}
+                       "roofline": roofline_object(kernel_name(Bl, Nl), ach, tr, tr_src, lg["kernel_ms"], Bl, Bl * (8 * 48 + 8 * 12 + 40))}
                 sql = sq_from_profiles(Bl, Nl, "quat")
                 if sql is not None:
                     ent["roofline"]["issue_frac"] = sql.get("issue_frac")

@@ -95,10 +95,13 @@ struct qmpc_handle {
 constexpr unsigned kLaneMaxSlots = 1024 * 64;   // one wavefront per SIMD of the chip
 constexpr int kLaneMinLoopCold = 18432;       // ... of the cold-started closed loop (its states need fewer iterations and spread less; measured:
                                               // 16384 robots 3.95 vs 3.91 M robot-ticks/s, 20480: 4.81 vs 3.97 M; warm-started the general threshold holds)
-// measured switch-over against the wave-per-instance kernels (QMPC_LANE_MIN overrides): QuatMpc N=10 20480: 2.62 vs 2.74 M,
-// 22528: 2.94 vs 2.78 M solves/s (N=20: equal at 20480); ConvexMpc and the 8-point model cross earlier (ConvexMpc N=10 / 20:
-// equal at 16384 / 20480; 8-point 16384: 0.78 vs 0.82 M, 20480: 0.97 vs 0.84 M)
-constexpr int kLaneMinBatch = 21504;
+// measured switch-over against the wave-per-instance kernels (QMPC_LANE_MIN overrides).  QuatMpc, round 4 (the wave side is the
+// wrench-form kernel with its gains in the workspace): N=10 24576: lane 3.20 vs wave 3.38 M solves/s, 28672: 3.61 vs 3.44;
+// N=20 16384: 1.03 vs 0.99, 24576: 1.49 vs 1.00 (long horizons run one wave per SIMD on either side).  ConvexMpc and the
+// 8-point model keep the round-1 wave kernels and cross earlier (ConvexMpc N=10 / 20: equal at 16384 / 20480; 8-point
+// 16384: 0.78 vs 0.82 M, 20480: 0.97 vs 0.84 M)
+constexpr int kLaneMinBatch = 26624;          // QuatMpc, horizons up to 12
+constexpr int kLaneMinBatchLong = 16384;      // QuatMpc, longer horizons
 constexpr int kLaneMinBatchOther = 18432;
 
 #define HIP_TRY(expr)                                                                      \
@@ -308,8 +311,8 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     h->lds_bytes_w = qmpc_wform_lds_bytes(N, 0);
     h->lds_bytes_wg = qmpc_wform_lds_bytes(N, 1);
     const char* lm = std::getenv("QMPC_LANE_MIN");
-    h->lane_min_batch = lm ? std::atoi(lm) : (params->model == QMPC_MODEL_QUAT ? kLaneMinBatch : kLaneMinBatchOther);
-    h->lane_min_loop_cold = lm ? h->lane_min_batch : kLaneMinLoopCold;
+    h->lane_min_batch = lm ? std::atoi(lm) : (params->model == QMPC_MODEL_QUAT ? (N <= 12 ? kLaneMinBatch : kLaneMinBatchLong) : kLaneMinBatchOther);
+    h->lane_min_loop_cold = lm ? h->lane_min_batch : (kLaneMinLoopCold < h->lane_min_batch ? kLaneMinLoopCold : h->lane_min_batch);
     const char* ls = std::getenv("QMPC_LANE_SORT");
     h->lane_sort = ls ? std::atoi(ls) : 1;
     static std::atomic<int> next_slot{0};     // handles share the table round-robin (a slot is rewritten before every launch)

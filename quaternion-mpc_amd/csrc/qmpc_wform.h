@@ -641,6 +641,70 @@ __device__ inline void rollout_scaled_w(const DevParams& P, const Layout& L, con
   QSYNC();
 }
 
+// ---- expansions at (X, U): four lanes per knot (three columns of the Jacobian blocks + the cost expansion) as in
+// expand_knot_part (qmpc_device.h; AltroUtils.cpp:78-110,153-168), with the angular acceleration taken from the knot's
+// wrench (WR) instead of being re-summed over the twelve inputs by every lane ------------------------------------------
+__device__ inline void expansions_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm, int lane) {
+  typedef Dim<4> D;
+  const int N = P.N;
+  const double* cst = sm + L.cst;
+  for (int q = lane; q < 4 * (N + 1); q += kWave) {
+    const int k = q >> 2, part = q & 3;
+    double x[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) x[i] = sm[L.X + 13 * k + i];
+    double* ABk = sm + L.AB + kAB * k;
+    double* XTk = sm + L.XT + kXT * k;
+    if (part < 3) {
+      if (k >= N) continue;
+      const int c = part;
+      double xn[4], wd[3];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xn[i] = sm[L.X + 13 * (k + 1) + 3 + i];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) wd[a] = cst[D::C_WD0 + a] + sm[LW.WR + 6 * k + 3 + a];
+      double G0[12], Gm[12], Gn[12];
+      quat_G(&x[3], G0);
+      double qm[4], wm[3];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        qm[r] = x[3 + r] + P.hh * (0.5 * (G0[3 * r] * x[10] + G0[3 * r + 1] * x[11] + G0[3 * r + 2] * x[12]));
+#pragma unroll
+      for (int a = 0; a < 3; ++a) wm[a] = x[10 + a] + P.hh * wd[a];
+      quat_G(qm, Gm);
+      quat_G(xn, Gn);
+      double g[4], gm[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {      // column c of G0 / Gm (c is lane-dependent: selects, no indexing)
+        g[r] = (c == 0) ? G0[3 * r] : (c == 1 ? G0[3 * r + 1] : G0[3 * r + 2]);
+        gm[r] = (c == 0) ? Gm[3 * r] : (c == 1 ? Gm[3 * r + 1] : Gm[3 * r + 2]);
+      }
+      double t0[4], t1[4], t2[4], ag[4], aw[4];
+      omega_mul(&x[10], g, t0);                                        // O0 g
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t1[r] = g[r] + (0.5 * P.hh) * t0[r];  // (I + (h/4) O0) g
+      omega_mul(wm, t1, t2);                                           // Om (.)
+      omega_mul(wm, g, t0);                                            // Om g
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ag[r] = g[r] + P.hh * t2[r];
+        aw[r] = P.hh * ((0.5 * P.hh) * t0[r] + gm[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        ABk[3 * r + c] = Gn[r] * ag[0] + Gn[3 + r] * ag[1] + Gn[6 + r] * ag[2] + Gn[9 + r] * ag[3];
+        ABk[9 + 3 * r + c] = Gn[r] * aw[0] + Gn[3 + r] * aw[1] + Gn[6 + r] * aw[2] + Gn[9 + r] * aw[3];
+        ABk[18 + 3 * r + c] = Gn[r] * gm[0] + Gn[3 + r] * gm[1] + Gn[6 + r] * gm[2] + Gn[9 + r] * gm[3];
+      }
+    } else {
+      // the cost expansion of knot k = 0..N (part 3 of expand_knot_part)
+      double u0[1] = {0.0};
+      expand_knot_part<4>(P, cst, sm + L.bw0, sm + L.refp, k, 3, x, u0, x, ABk, XTk);
+    }
+  }
+  QSYNC();
+}
+
 // ---- closed-loop trial rollout (alpha = 1) in the wrench space: lane i < 6 owns row i of [Xw | xw], lanes 6..11 row
 // i - 6 of [Xz | xz]; the state is advanced by every lane redundantly, six wrench components are broadcast per knot ----
 struct RollLoadsW {
