@@ -42,6 +42,9 @@ hipError_t qmpc_wform_set_lds(int bytes);
 hipError_t qmpc_wform_launch(int var, int prof, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
                              const qmpc_input* in, double* forces, qmpc_info* info, double* traj_u, double* traj_x,
                              long long* prof_out, double* gws);
+hipError_t qmpc_wform_launch_list(int var, int grid, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
+                                  const qmpc_input* in, double* forces, qmpc_info* info, double* traj_u, double* traj_x,
+                                  const int* sel, const int* sel_count, double* gws, const double* hstate, int hcap);
 
 // qmpc_lane.hip (third translation unit): the lane-per-instance kernel of large batches
 size_t qmpc_lane_ws_bytes(int N, int nl, unsigned slots);
@@ -50,7 +53,10 @@ int qmpc_lane_param_slots();
 hipError_t qmpc_lane_upload_params(int pslot, hipStream_t s, const void* dev_params, size_t dev_params_size);
 hipError_t qmpc_lane_launch(int nl, int pslot, int batch, hipStream_t s, const void* dev_params, size_t dev_params_size, const void* in,
                             double* forces, qmpc_info* info, double* ws, unsigned slots, int* scratch, int upload_params,
-                            const double* u_init, double* traj_u, int check_prev, int order_prev, double* traj_x);
+                            const double* u_init, double* traj_u, int check_prev, int order_prev, double* traj_x, int iter_cap,
+                            int* hcount, int* hsel, double* hstate, int hcap);
+size_t qmpc_lane_handoff_list_bytes(int batch);
+size_t qmpc_lane_handoff_record_doubles(int N);
 
 struct qmpc_handle {
   qmpc_params params;
@@ -90,6 +96,10 @@ struct qmpc_handle {
   bool lane_loop_cold;         // set during a cold-started qmpc_loop_run*: the loop's own switch-over applies
   int lane_min_loop_cold;
   bool lane_order_prev;        // closed loop: d_info holds every robot's previous record -- order the batch by its iteration count too
+  int* d_handoff;              // straggler hand-off: count | list of instances the capped lane launch left (on first use)
+  double* d_hstate;            // ... and their state records (hstate_cap of them)
+  int hstate_cap;
+  int lane_cap;                // straggler hand-off: iteration cap of the lane kernel in cold plain solves (0: off; env QMPC_LANE_CAP)
 };
 
 constexpr unsigned kLaneMaxSlots = 1024 * 64;   // one wavefront per SIMD of the chip
@@ -313,6 +323,15 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     const char* lm = std::getenv("QMPC_LANE_MIN");
     h->lane_min_batch = lm ? std::atoi(lm) : (params->model == QMPC_MODEL_QUAT ? (N <= 12 ? kLaneMinBatch : kLaneMinBatchLong) : kLaneMinBatchOther);
     h->lane_min_loop_cold = lm ? h->lane_min_batch : (kLaneMinLoopCold < h->lane_min_batch ? kLaneMinLoopCold : h->lane_min_batch);
+    // Straggler hand-off (cold plain solves of QuatMpc's problem on the lane kernel): a launch of the lane kernel lasts as
+    // long as its slowest instance -- 23 interior-point iterations at N=10 (mean 13.6), 31 at N=20 (mean 14.6) -- while
+    // only 8 % / 10 % of the instances are still running after 16 / 17.  The lane kernel stops there, leaves the state of
+    // those instances in a record each, and the wave-per-instance kernel, whose iteration takes a tenth of the time,
+    // CONTINUES them (launch_solve; qmpc_wform_body.inc `resume`).  The cap is a fixed function of the horizon, so the
+    // result of an instance depends neither on timing nor on the batch it is part of.  Measured (caps 14 .. 20 scanned):
+    // B=32768 N=10 4.14 -> 5.2 M solves/s, B=65536 N=10 6.8 -> 8.3 M, B=65536 N=20 3.25 -> 3.83 M, B=262144 N=10 9.1 -> 9.8 M.
+    const char* lc = std::getenv("QMPC_LANE_CAP");
+    h->lane_cap = lc ? std::atoi(lc) : 15 + N / 10;
     const char* ls = std::getenv("QMPC_LANE_SORT");
     h->lane_sort = ls ? std::atoi(ls) : 1;
     static std::atomic<int> next_slot{0};     // handles share the table round-robin (a slot is rewritten before every launch)
@@ -332,6 +351,8 @@ void qmpc_destroy(qmpc_handle* h) {
   if (h->d_gws) (void)hipFree(h->d_gws);
   if (h->d_lane_ws) (void)hipFree(h->d_lane_ws);
   if (h->d_lane_scratch) (void)hipFree(h->d_lane_scratch);
+  if (h->d_handoff) (void)hipFree(h->d_handoff);
+  if (h->d_hstate) (void)hipFree(h->d_hstate);
   if (h->d_leg) (void)hipFree(h->d_leg);
   if (h->d_loop_row) (void)hipFree(h->d_loop_row);
   if (h->d_loop) (void)hipFree(h->d_loop);
@@ -394,13 +415,23 @@ static qmpc_status ensure_lane_buffers(qmpc_handle* h) {
 // not wanted); they may be the same buffer.  check_prev: d_info still holds the records of the previous solves
 static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces, qmpc_info* d_info,
                                hipStream_t s, const double* d_u_init = nullptr, double* d_traj_u = nullptr, int check_prev = 0,
-                               double* d_traj_x = nullptr) {
+                               double* d_traj_x = nullptr, int iter_cap = 0) {
+  if (iter_cap > 0 && !h->d_handoff) {      // hand-off buffers, on first use (never inside a stream capture: plain solves only)
+    // state records (8 + 60 N doubles each) for a quarter of the capacity -- 8-10 % of a batch is handed over in the
+    // measured workloads; instances beyond that are solved from scratch by the wave kernel.  80 MB at 65536 x N=10.
+    const char* hd = std::getenv("QMPC_HANDOFF_DIV");      // experiments
+    const int div = hd ? std::atoi(hd) : 4;
+    h->hstate_cap = h->max_batch / div > 4096 ? h->max_batch / div : 4096;
+    HIP_TRY(hipMalloc(&h->d_handoff, qmpc_lane_handoff_list_bytes(h->max_batch)));
+    HIP_TRY(hipMalloc(&h->d_hstate, sizeof(double) * qmpc_lane_handoff_record_doubles(h->params.horizon) * (size_t)h->hstate_cap));
+  }
   const int nl = h->params.model == QMPC_MODEL_CONVEX ? -4 : model_nl(h->params.model);     // -4: ConvexMpc's model (qmpc_lane.hip)
   const qmpc_status es = ensure_lane_buffers(h);
   if (es != QMPC_OK) return es;
   HIP_TRY(qmpc_lane_launch(nl, h->lane_pslot, (int)batch, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, h->d_lane_ws, h->lane_slots,
                            h->lane_sort ? h->d_lane_scratch : nullptr, h->lane_params_resident ? 0 : 1, d_u_init, d_traj_u,
-                           check_prev, h->lane_order_prev ? 1 : 0, d_traj_x));
+                           check_prev, h->lane_order_prev ? 1 : 0, d_traj_x, iter_cap, iter_cap > 0 ? h->d_handoff : nullptr,
+                           iter_cap > 0 ? h->d_handoff + 64 : nullptr, iter_cap > 0 ? h->d_hstate : nullptr, h->hstate_cap));
   return QMPC_OK;
 }
 
@@ -426,7 +457,8 @@ static size_t variant_lds(const qmpc_handle* h, int var) {
 static double* variant_gws(const qmpc_handle* h, int var) { return (var == 1 || var == 2 || var == 5) ? h->d_gws : nullptr; }
 
 static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces,
-                                qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s, bool timed = true) {
+                                qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s, bool timed = true,
+                                bool handoff = true) {
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;   // the gains workspace is sized by max_batch
   if (timed) HIP_TRY(hipEventRecord(h->ev0, s));
   if (h->params.mode == QMPC_MODE_REFERENCE) {     // the reference's own AL-iLQR mode (qmpc_ref.hip)
@@ -454,8 +486,17 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
     return QMPC_OK;
   }
   if (use_lane(h, batch, d_tu, d_tx)) {
-    const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s, nullptr, d_tu, 0, d_tx);
+    // straggler hand-off (see qmpc_create): only where the library chose the lane kernel by itself (QMPC_VARIANT=4 forces
+    // the pure lane kernel) and there at every batch size (a shard of a batch gives the bits of the whole batch), with status
+    // records to select from
+    const int wv = (handoff && h->variant == 0 && h->wform && h->params.model == QMPC_MODEL_QUAT && d_info &&
+                    h->lane_cap > 0 && h->lane_cap < h->params.iterations_max)
+                       ? (h->lds_bytes_w <= 40 * 1024 ? 3 : (h->lds_bytes_wg <= 40 * 1024 ? 5 : 0)) : 0;
+    const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s, nullptr, d_tu, 0, d_tx, wv ? h->lane_cap : 0);
     if (ls != QMPC_OK) return ls;
+    if (wv)      // one workgroup per SIMD walks the list the lane kernel left (8-10 % of the batch in the measured workloads)
+      HIP_TRY(qmpc_wform_launch_list(wv, 1024, variant_lds(h, wv), s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, d_tu, d_tx,
+                                     h->d_handoff + 64, h->d_handoff, variant_gws(h, wv), h->d_hstate, h->hstate_cap));
     if (timed) {
       HIP_TRY(hipEventRecord(h->ev1, s));
       h->timed = true;
@@ -1013,7 +1054,7 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
       HIP_TRY(qmpc_warm_launch(var, convex ? 1 : 0, (int)batch, variant_lds(h, var), s, &h->dev, sizeof h->dev, h->d_in, first ? nullptr : h->d_traj_u,
                                h->d_forces, h->d_info, h->d_traj_u, variant_gws(h, var), /*check_prev=*/1));
     } else {
-      const qmpc_status st = launch_solve(h, batch, h->d_in, h->d_forces, h->d_info, nullptr, nullptr, s, /*timed=*/false);
+      const qmpc_status st = launch_solve(h, batch, h->d_in, h->d_forces, h->d_info, nullptr, nullptr, s, /*timed=*/false, /*handoff=*/false);
       if (st != QMPC_OK) return st;
     }
     if (convex)

@@ -142,16 +142,44 @@ __device__ __noinline__ void call_finish(PassArgs a, QL_PRIV_AS const LaneK<NL>*
                   reinterpret_cast<double*>(traj_u), reinterpret_cast<double*>(traj_x));
 }
 
+// Straggler hand-off (four-point QuatMpc, cold launches): the state of an instance that reached the iteration cap, for
+// the wave-per-instance kernel to CONTINUE from (qmpc_wform_body.inc) -- one record of 8 + 60 N doubles:
+// rho, last alpha_p, last alpha_d, last full step, iterations done, 3 spare; U [N][12]; slacks [N][24] (the Tapia flag in
+// the sign); multipliers [N][24].  The state is that of the top of the next iteration (the step applied, the barrier
+// parameter not yet evaluated), which is where the wave kernel's loop begins.
+template <int NL>
+__device__ __noinline__ void call_dump(PassArgs a, QL_PRIV_AS const LaneState* sp, unsigned long long out) {
+  const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
+  const Ctx c = pass_ctx<NL>(a);
+  const WsOff O = make_wsoff<NL>(P.N);
+  LaneState st;
+  priv_load(st, sp);
+  double* o = reinterpret_cast<double*>(out);
+  const int N = P.N;
+  o[0] = st.rho; o[1] = st.last_ap; o[2] = st.last_ad; o[3] = st.last_step; o[4] = (double)st.iters; o[5] = 0.0; o[6] = 0.0; o[7] = 0.0;
+  for (int i = 0; i < 3 * NL * N; ++i) o[8 + i] = c.W(O.U + i);
+  for (int i = 0; i < 6 * NL * N; ++i) {
+    const bool on = (st.con >> ((i % (6 * NL)) / 6)) & 1u;
+    o[8 + 3 * NL * N + i] = on ? c.W(O.S + i) : 1.0;
+    o[8 + 9 * NL * N + i] = on ? c.W(O.LAM + i) : 0.0;
+  }
+}
+
 template <int NL, int MD = MD_QUAT>
 __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const double* __restrict__ in,
                                                               double* __restrict__ forces, qmpc_info* __restrict__ info,
                                                               int batch, double* __restrict__ ws, unsigned slots,
                                                               int lanes, const int* __restrict__ perm,
                                                               long long* __restrict__ prof, const double* u_init, double* traj_u,
-                                                              int check_prev, double* traj_x) {
+                                                              int check_prev, double* traj_x, int iter_cap,
+                                                              int* __restrict__ hcount, int* __restrict__ hsel,
+                                                              double* __restrict__ hstate, int hcap) {
   typedef LDim<NL> D;
   const int lane = threadIdx.x;
   const DevParams& P = ql_params[pslot];
+  // iter_cap > 0: instances that have not converged after iter_cap iterations stop as QMPC_MAX_ITER with that count --
+  // the launcher hands them to the wave-per-instance kernel (straggler hand-off, qmpc_hip.hip)
+  const int itmax = (iter_cap > 0 && iter_cap < P.iterations_max) ? iter_cap : P.iterations_max;
   const size_t block_elems = (size_t)make_wsoff<NL>(P.N).total * kLaneWave;
   const unsigned long long wsb = reinterpret_cast<unsigned long long>(ws + (size_t)blockIdx.x * block_elems);
   const PassArgs a = {pslot, (unsigned)wsb, (unsigned)(wsb >> 32), 8u * (unsigned)lane, u_init ? 1u : 0u};
@@ -189,7 +217,7 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
         if (warm && __any(st.rho != 0.0)) call_A<NL, true, MD>(a, Kp, sp); else call_A<NL, false, MD>(a, Kp, sp);
         const double resid = st.rho * st.rcmax;
         if (st.mu <= P.mu_final && resid <= P.tol_feas && st.last_step <= P.tol_step) { st.status = QMPC_OK; active = false; }
-        else if (st.it > P.iterations_max) { st.status = QMPC_MAX_ITER; active = false; }
+        else if (st.it > itmax) { st.status = QMPC_MAX_ITER; active = false; }
         else {
           double sg = P.sigma;
           const double amin = fmin(st.last_ap, st.last_ad);
@@ -214,6 +242,13 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
                       info ? reinterpret_cast<unsigned long long>(info + b) : 0ull,
                       traj_u ? reinterpret_cast<unsigned long long>(traj_u + (size_t)b * tstride) : 0ull,
                       traj_x ? reinterpret_cast<unsigned long long>(traj_x + (size_t)b * (size_t)(P.N + 1) * (MD == MD_CONVEX ? 12 : 13)) : 0ull);
+    // hand-off: an instance stopped by the cap joins the list; its state travels with it while the buffer has room (the
+    // wave kernel starts the others from scratch)
+    if (NL == 4 && hcount && valid && itmax < P.iterations_max && st.status == QMPC_MAX_ITER) {
+      const int ord = atomicAdd(hcount, 1);
+      hsel[ord] = b;
+      if (ord < hcap) call_dump<NL>(a, sp, reinterpret_cast<unsigned long long>(hstate + (size_t)ord * (8 + 60 * (size_t)P.N)));
+    }
 #if defined(QL_PROFILE)
     if (prof && base < (long long)slots) {      // first round of every wave; lane 0's clock, every lane's own iteration count
       if (lane == 0) {
@@ -296,6 +331,9 @@ __attribute__((visibility("hidden"))) size_t qmpc_lane_ws_bytes(int N, int nl, u
   return sizeof(double) * lane_ws_elements(N, nl) * (size_t)slots;
 }
 __attribute__((visibility("hidden"))) size_t qmpc_lane_scratch_bytes(int batch) { return sizeof(int) * (512 + (size_t)batch); }
+// hand-off list of a capped launch: count | instance indices [batch]; the state records live in their own buffer
+__attribute__((visibility("hidden"))) size_t qmpc_lane_handoff_list_bytes(int batch) { return sizeof(int) * (64 + (size_t)batch); }
+__attribute__((visibility("hidden"))) size_t qmpc_lane_handoff_record_doubles(int N) { return 8 + 60 * (size_t)N; }
 
 // slots: resident lanes (multiple of 64); scratch: qmpc_lane_scratch_bytes(batch) bytes, or null for no sort
 // pslot: the handle's slot in the constant-memory parameter table (qmpc_lane_param_slots() of them); the block is copied
@@ -311,7 +349,8 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
                                                                    size_t dev_params_size, const void* in, double* forces,
                                                                    qmpc_info* info, double* ws, unsigned slots, int* scratch,
                                                                    int upload_params, const double* u_init, double* traj_u,
-                                                                   int check_prev, int order_prev, double* traj_x) {
+                                                                   int check_prev, int order_prev, double* traj_x, int iter_cap,
+                                                                   int* hcount, int* hsel, double* hstate, int hcap) {
   // nl: 4 (QuatMpc), 8 (the 8-contact-point model) or -4 (ConvexMpc's model: four points, world-frame forces)
   const bool convex = nl == -4;
   if (convex) nl = 4;
@@ -326,6 +365,10 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
     if (e != hipSuccess) return e;
   }
   const double* rec = static_cast<const double*>(in);
+  if (hcount) {
+    const hipError_t e = hipMemsetAsync(hcount, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+  }
   const int* perm = nullptr;
   if (scratch) {
     const qmpc_info* prev = (order_prev && info) ? info : nullptr;      // the previous solves' records, still in the output buffer
@@ -359,13 +402,13 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
 #endif
   if (nl == 8)
     hipLaunchKernelGGL(qmpc_lane_kernel<8>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm, prof,
-                       u_init, traj_u, check_prev, traj_x);
+                       u_init, traj_u, check_prev, traj_x, iter_cap, hcount, hsel, hstate, hcap);
   else if (convex)
     hipLaunchKernelGGL((qmpc_lane_kernel<4, MD_CONVEX>), dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes,
-                       perm, prof, u_init, traj_u, check_prev, traj_x);
+                       perm, prof, u_init, traj_u, check_prev, traj_x, iter_cap, hcount, hsel, hstate, hcap);
   else
     hipLaunchKernelGGL(qmpc_lane_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm, prof,
-                       u_init, traj_u, check_prev, traj_x);
+                       u_init, traj_u, check_prev, traj_x, iter_cap, hcount, hsel, hstate, hcap);
 #if defined(QL_PROFILE)
   {
     static long long hp[16 * 1024];

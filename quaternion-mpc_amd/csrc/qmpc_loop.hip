@@ -450,6 +450,8 @@ __global__ __launch_bounds__(64, REF ? 1 : QMPC_SOLVE_WAVES(QuatModel, VAR)) voi
       [&]() {
         const int warm_t = (LP.warm_start != 0.0 && prev_ok) ? t : 0;   // t > 0 and the last solve left a usable U in LDS
         constexpr int WVAR = VAR;
+        const int wslot = b;
+        constexpr const double* resume = nullptr;
 #include "qmpc_wform_body.inc"
       }();
     } else {
@@ -503,6 +505,8 @@ __global__ __launch_bounds__(64, QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_sol
   }
   if constexpr (VAR == 3 || VAR == 5) {
     constexpr int WVAR = VAR;
+    const int wslot = b;
+    constexpr const double* resume = nullptr;
 #include "qmpc_wform_body.inc"
   } else {
 #include "qmpc_solve_body.inc"

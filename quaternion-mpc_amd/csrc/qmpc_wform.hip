@@ -50,9 +50,38 @@ __global__ __launch_bounds__(64, WVAR == 5 ? 2 : 1) void qmpc_solve_w_kernel(
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int b = blockIdx.x;
   if (b >= batch) return;
+  const int wslot = b;                 // the instance's slice of the workspace
   const int lane = threadIdx.x;
   constexpr int warm_t = 0;            // a plain solve always starts from u_ref (QuatMpc.cpp:253)
+  constexpr const double* resume = nullptr;
 #include "qmpc_wform_body.inc"
+}
+
+// The same solve over a LIST of instances (sel[0 .. *sel_count), built on the device): the workgroups walk the list with
+// the grid as stride.  The straggler hand-off of large batches (qmpc_hip.hip: launch_solve): the lane-per-instance kernel
+// stops after a fixed number of iterations and the few instances it leaves unconverged are solved here, where one
+// interior-point iteration takes a tenth of the time.
+template <int WVAR>
+__global__ __launch_bounds__(64, WVAR == 5 ? 2 : 1) void qmpc_solve_w_list_kernel(
+    DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
+    double* __restrict__ traj_u, double* __restrict__ traj_x, const int* __restrict__ sel, const int* __restrict__ sel_count,
+    double* __restrict__ gws, const double* __restrict__ hstate, int hcap) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int lane = threadIdx.x;
+  constexpr bool PROF = false;
+  constexpr int warm_t = 0;
+  long long* prof_out = nullptr;
+  const int wslot = blockIdx.x;
+  const int count = *sel_count;
+  for (int i = blockIdx.x; i < count; i += gridDim.x) {
+    const int b = sel[i];
+    // the instance's state at the lane kernel's iteration cap (null: none was kept, start from scratch)
+    const double* resume = (hstate && i < hcap) ? hstate + (size_t)i * (8 + 60 * (size_t)P.N) : nullptr;
+    [&]() {                            // `return` in the body (rejected input) ends this instance only
+#include "qmpc_wform_body.inc"
+    }();
+    __syncthreads();
+  }
 }
 
 }  // namespace qmpc
@@ -69,9 +98,10 @@ __attribute__((visibility("hidden"))) size_t qmpc_wform_lds_bytes(int N, int kd_
 }
 __attribute__((visibility("hidden"))) size_t qmpc_wform_slice_doubles(int N) { return wform_slice(N); }
 __attribute__((visibility("hidden"))) hipError_t qmpc_wform_set_lds(int bytes) {
-  const void* k[4] = {reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 3>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 3>),
-                      reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 5>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 5>)};
-  for (int i = 0; i < 4; ++i) {
+  const void* k[6] = {reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 3>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 3>),
+                      reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 5>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 5>),
+                      reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<3>), reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<5>)};
+  for (int i = 0; i < 6; ++i) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
   }
@@ -94,5 +124,22 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_wform_launch(int var, int 
     if (prof) QMPC_LAUNCH_W(true, 3); else QMPC_LAUNCH_W(false, 3);
   }
 #undef QMPC_LAUNCH_W
+  return hipGetLastError();
+}
+// the instances sel[0 .. *sel_count) (device memory), `grid` workgroups walking the list
+__attribute__((visibility("hidden"))) hipError_t qmpc_wform_launch_list(int var, int grid, size_t lds, hipStream_t s, const void* dev_params,
+                                                                        size_t dev_params_size, const qmpc_input* in, double* forces,
+                                                                        qmpc_info* info, double* traj_u, double* traj_x, const int* sel,
+                                                                        const int* sel_count, double* gws, const double* hstate,
+                                                                        int hcap) {
+  if (dev_params_size != sizeof(DevParams)) return hipErrorInvalidValue;
+  DevParams P;
+  std::memcpy(&P, dev_params, sizeof P);
+  if (var == 5)
+    hipLaunchKernelGGL(qmpc_solve_w_list_kernel<5>, dim3((unsigned)grid), dim3(kWave), lds, s, P, in, forces, info, traj_u, traj_x, sel,
+                       sel_count, gws, hstate, hcap);
+  else
+    hipLaunchKernelGGL(qmpc_solve_w_list_kernel<3>, dim3((unsigned)grid), dim3(kWave), lds, s, P, in, forces, info, traj_u, traj_x, sel,
+                       sel_count, gws, hstate, hcap);
   return hipGetLastError();
 }
