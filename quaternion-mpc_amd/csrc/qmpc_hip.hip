@@ -406,8 +406,17 @@ static qmpc_status ensure_lane_buffers(qmpc_handle* h) {
     // one workspace block per wavefront; a wavefront may run with 32 of its lanes (qmpc_lane.hip), hence max_batch / 32
     const unsigned want = (unsigned)(((size_t)h->max_batch + 31) / 32) * 64;
     h->lane_slots = want < kLaneMaxSlots ? want : kLaneMaxSlots;
-    HIP_TRY(hipMalloc(&h->d_lane_ws, qmpc_lane_ws_bytes(h->params.horizon, nl, h->lane_slots)));
-    HIP_TRY(hipMalloc(&h->d_lane_scratch, qmpc_lane_scratch_bytes(h->max_batch)));
+    // both buffers or none: a handle with a workspace but no sort scratch would run unsorted for the rest of its life
+    double* ws = nullptr;
+    int* sc = nullptr;
+    if (hipMalloc(&ws, qmpc_lane_ws_bytes(h->params.horizon, nl, h->lane_slots)) != hipSuccess ||
+        hipMalloc(&sc, qmpc_lane_scratch_bytes(h->max_batch)) != hipSuccess) {
+      std::fprintf(stderr, "qmpc: lane-kernel workspace allocation failed: %s\n", hipGetErrorString(hipGetLastError()));
+      if (ws) (void)hipFree(ws);
+      return QMPC_HIP_ERROR;
+    }
+    h->d_lane_ws = ws;
+    h->d_lane_scratch = sc;
   }
   return QMPC_OK;
 }
@@ -416,18 +425,25 @@ static qmpc_status ensure_lane_buffers(qmpc_handle* h) {
 static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces, qmpc_info* d_info,
                                hipStream_t s, const double* d_u_init = nullptr, double* d_traj_u = nullptr, int check_prev = 0,
                                double* d_traj_x = nullptr, int iter_cap = 0) {
-  if (iter_cap > 0 && !h->d_handoff) {      // hand-off buffers, on first use (never inside a stream capture: plain solves only)
-    // state records (8 + 60 N doubles each) for a quarter of the capacity -- 8-10 % of a batch is handed over in the
-    // measured workloads; instances beyond that are solved from scratch by the wave kernel.  80 MB at 65536 x N=10.
-    const char* hd = std::getenv("QMPC_HANDOFF_DIV");      // experiments
-    const int div = hd ? std::atoi(hd) : 4;
-    h->hstate_cap = h->max_batch / div > 4096 ? h->max_batch / div : 4096;
-    HIP_TRY(hipMalloc(&h->d_handoff, qmpc_lane_handoff_list_bytes(h->max_batch)));
-    HIP_TRY(hipMalloc(&h->d_hstate, sizeof(double) * qmpc_lane_handoff_record_doubles(h->params.horizon) * (size_t)h->hstate_cap));
-  }
   const int nl = h->params.model == QMPC_MODEL_CONVEX ? -4 : model_nl(h->params.model);     // -4: ConvexMpc's model (qmpc_lane.hip)
   const qmpc_status es = ensure_lane_buffers(h);
   if (es != QMPC_OK) return es;
+  if (iter_cap > 0 && !h->d_handoff) {      // hand-off buffers, on first use (never inside a stream capture: plain solves only)
+    // One state record (8 + 60 N doubles) per instance of the handle's capacity: 8-10 % of a batch is handed over in the
+    // measured workloads, but WHICH record an instance gets is decided by an atomic counter, so only room for all of them
+    // keeps the results independent of timing (320 MB at 65536 x N=10, 1.3 GB at 262144 x N=10; held until qmpc_destroy,
+    // like the lane kernel's workspace).  If the memory is not there the hand-off is switched off for this handle.
+    h->hstate_cap = h->max_batch;
+    const size_t rec_bytes = sizeof(double) * qmpc_lane_handoff_record_doubles(h->params.horizon);
+    if (hipMalloc(&h->d_handoff, qmpc_lane_handoff_list_bytes(h->max_batch)) != hipSuccess ||
+        hipMalloc(&h->d_hstate, rec_bytes * (size_t)h->hstate_cap) != hipSuccess) {
+      (void)hipGetLastError();
+      if (h->d_handoff) (void)hipFree(h->d_handoff);
+      h->d_handoff = nullptr; h->d_hstate = nullptr;
+      h->lane_cap = 0;
+      iter_cap = 0;
+    }
+  }
   HIP_TRY(qmpc_lane_launch(nl, h->lane_pslot, (int)batch, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, h->d_lane_ws, h->lane_slots,
                            h->lane_sort ? h->d_lane_scratch : nullptr, h->lane_params_resident ? 0 : 1, d_u_init, d_traj_u,
                            check_prev, h->lane_order_prev ? 1 : 0, d_traj_x, iter_cap, iter_cap > 0 ? h->d_handoff : nullptr,
@@ -494,9 +510,13 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
                        ? (h->lds_bytes_w <= 40 * 1024 ? 3 : (h->lds_bytes_wg <= 40 * 1024 ? 5 : 0)) : 0;
     const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s, nullptr, d_tu, 0, d_tx, wv ? h->lane_cap : 0);
     if (ls != QMPC_OK) return ls;
-    if (wv)      // one workgroup per SIMD walks the list the lane kernel left (8-10 % of the batch in the measured workloads)
+    if (wv && h->d_handoff) {     // one workgroup per SIMD walks the list the lane kernel left (8-10 % of the batch in the measured workloads)
+      // QMPC_HANDOFF_RESTART=1 (experiments, tests): the wave kernel ignores the state records and solves the list from scratch
+      const char* hr = std::getenv("QMPC_HANDOFF_RESTART");
+      const bool restart = hr && std::atoi(hr) != 0;
       HIP_TRY(qmpc_wform_launch_list(wv, 1024, variant_lds(h, wv), s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, d_tu, d_tx,
-                                     h->d_handoff + 64, h->d_handoff, variant_gws(h, wv), h->d_hstate, h->hstate_cap));
+                                     h->d_handoff + 64, h->d_handoff, variant_gws(h, wv), restart ? nullptr : h->d_hstate, h->hstate_cap));
+    }
     if (timed) {
       HIP_TRY(hipEventRecord(h->ev1, s));
       h->timed = true;

@@ -151,6 +151,51 @@ def test_config4_workload_on_one_gpu(pkg, lib, oracle):
     s.close()
 
 
+@pytest.mark.parametrize("N,B", [(10, 32768), (20, 16384)])
+def test_straggler_hand_off_of_large_batches(pkg, lib, oracle, monkeypatch, N, B):
+    """Cold plain solves the library sends to the lane kernel by itself (qmpc_hip.hip: launch_solve): the lane kernel stops at
+    a fixed iteration cap and the wrench-form wave kernel CONTINUES the instances left from their state records.  Against
+    the pure lane kernel (QMPC_LANE_CAP=0): same status words, iteration counts equal on >= 99.9 %, forces within 1e-7 N;
+    against the oracle on a sample that over-represents the handed-over instances; a second call gives the same bits (the
+    cap is a function of the horizon, not of timing); edge records (no stance leg, NaN) keep their status words."""
+    p = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
+    rec = _edge_records(pkg, pkg.random_go1_trot_states(B - 1, config_id=4 if N == 10 else 3))
+    cap = 15 + N // 10
+    out = {}
+    for tag, env in (("pure", {"QMPC_LANE_CAP": "0"}), ("auto", {}), ("low cap", {"QMPC_LANE_CAP": "12"}),
+                     ("restart", {"QMPC_HANDOFF_RESTART": "1"})):       # the wave kernel ignores the records: from scratch
+        for k in ("QMPC_LANE_CAP", "QMPC_HANDOFF_RESTART"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = pkg.Solver(p, B, device=0, lib=lib)
+        f, info = s.solve(rec)
+        f2, info2 = s.solve(rec)
+        s.close()
+        assert np.array_equal(f, f2) and np.array_equal(info["iterations"], info2["iterations"]), tag
+        out[tag] = (f, info)
+    fp, ip = out["pure"]
+    handed = int((ip["iterations"] > cap).sum())
+    assert handed > B // 100, handed          # the workload does leave instances beyond the cap
+    for tag in ("auto", "low cap", "restart"):
+        f, info = out[tag]
+        assert np.array_equal(info["status"], ip["status"]), tag
+        same = float((info["iterations"] == ip["iterations"]).mean())
+        err = float(np.abs(f - fp).max())
+        print(f"hand-off ({tag}), N={N} B={B}: {handed} instances beyond the cap of {cap}; iteration counts equal on {100 * same:.3f} %, "
+              f"forces within {err:.2e} N of the pure lane kernel")
+        assert same > 0.999 and err < 1e-7
+    assert ip["status"][5] == pkg.NO_CONTACT and ip["status"][9] == pkg.NAN_INPUT
+    f, info = out["auto"]
+    slow = np.argsort(-ip["iterations"])[:96]                     # the handed-over ones ...
+    idx = np.unique(np.concatenate([slow, np.arange(0, B, B // 96)]))     # ... and a spread sample
+    idx = idx[(ip["status"][idx] == 0)]
+    fo, io = oracle.solve(p, rec[idx], threads=8)
+    assert (io["status"] == 0).all()
+    assert np.abs(f[idx] - fo).max() < 1e-6
+    assert float((info["iterations"][idx] == io["iterations"]).mean()) > 0.97
+
+
 def _random_params(pkg, lib, rng, t):
     N = int(rng.choice([6, 10, 14, 20]))
     p = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
