@@ -232,7 +232,21 @@ qmpc_status qmpc_solve_warm_device(qmpc_handle* h, int32_t batch, const qmpc_inp
 
 /* Stream-ordered, DEVICE buffers (inputs already resident in HBM).  `stream`
  * is a hipStream_t passed as void* (NULL = the handle's own stream).  Nothing
- * is synchronised; pair with qmpc_wait or your own stream sync. */
+ * is synchronised; pair with qmpc_wait or your own stream sync.
+ *
+ * ONE launch in flight per HANDLE (not per stream): the handle owns mutable device state -- the gains workspace of the
+ * mid-size kernels, the lane kernel's workspace / sort scratch, the hand-off list -- so a second qmpc_solve*_device on
+ * the same handle must be stream-ordered after the first (same stream, or an event).  Independent batches in flight
+ * take one handle each (bench.py: two_in_flight).
+ *
+ * Which kernel runs is chosen from the batch size (converged mode; QuatMpc N <= 12: everything in LDS up to 1024
+ * instances, gains in a workspace up to 26623, from 26624 on one LANE per instance with the stragglers handed back to the
+ * wave kernel; the thresholds of the other models and horizons are in qmpc_hip.hip).  The kernel families solve the same
+ * problem to the same KKT point but round differently: forces agree to ~1e-10 N across a threshold (tested to 1e-7 N),
+ * bit for bit within a family and for a shard of a batch against the whole batch.  Their device buffers are allocated on
+ * the first call that needs them, sized by max_batch, and held until qmpc_destroy: the lane kernel's workspace (<= 1024
+ * wavefronts x 0.84 MB at N=10: 0.86 GB) and the state records of the straggler hand-off (8 + 60 N doubles per instance
+ * of max_batch: 320 MB at 65536 x N=10) -- create the handle with the max_batch you mean to use. */
 qmpc_status qmpc_solve_device(qmpc_handle* h, int32_t batch, const qmpc_input* d_in,
                               double* d_forces_body, qmpc_info* d_info, void* stream);
 qmpc_status qmpc_wait(qmpc_handle* h);

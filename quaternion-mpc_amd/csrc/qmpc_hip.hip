@@ -133,6 +133,21 @@ int32_t qmpc_sizeof_convex_input(void) { return (int32_t)sizeof(qmpc_convex_inpu
 int32_t qmpc_sizeof_input8(void) { return (int32_t)sizeof(qmpc_input8); }
 static_assert(sizeof(qmpc_input8) == 8 * Dim<8>::REC && sizeof(qmpc_input) == 8 * Dim<4>::REC, "record sizes");
 static int model_nl(int model) { return model == QMPC_MODEL_QUAT8 ? 8 : 4; }
+// free list of the lane kernel's parameter slots (qmpc_lane.hip: ql_params[])
+static std::mutex g_lane_slot_mutex;
+static unsigned long long g_lane_slot_used = 0;
+static int lane_slot_acquire() {
+  std::lock_guard<std::mutex> lock(g_lane_slot_mutex);
+  const int n = qmpc_lane_param_slots();
+  for (int i = 0; i < n && i < 64; ++i)
+    if (!((g_lane_slot_used >> i) & 1ull)) { g_lane_slot_used |= 1ull << i; return i; }
+  return -1;
+}
+static void lane_slot_release(int slot) {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lock(g_lane_slot_mutex);
+  g_lane_slot_used &= ~(1ull << slot);
+}
 static_assert(sizeof(qmpc_convex_input) == sizeof(qmpc_input), "both records are 48 doubles");
 
 const char* qmpc_status_string(int32_t s) {
@@ -301,6 +316,7 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
   qmpc_handle* h = new (std::nothrow) qmpc_handle();
   if (!h) return QMPC_HIP_ERROR;
   std::memset(h, 0, sizeof *h);
+  h->lane_pslot = -1;
   h->params = *params;
   h->dev = d;
   h->device = device;
@@ -334,8 +350,10 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     h->lane_cap = lc ? std::atoi(lc) : 15 + N / 10;
     const char* ls = std::getenv("QMPC_LANE_SORT");
     h->lane_sort = ls ? std::atoi(ls) : 1;
-    static std::atomic<int> next_slot{0};     // handles share the table round-robin (a slot is rewritten before every launch)
-    h->lane_pslot = next_slot.fetch_add(1) % qmpc_lane_param_slots();
+    // the lane kernel reads its parameters from a constant-memory table with one slot per LIVE handle (a slot is rewritten
+    // before every launch of its handle, on that launch's stream): slots come from a free list and go back in
+    // qmpc_destroy; a handle created while all of them are taken keeps the wave-per-instance kernels
+    h->lane_pslot = lane_slot_acquire();
   }
   const qmpc_status rs = create_resources(h, N, nl, nu);
   if (rs != QMPC_OK) { qmpc_destroy(h); return rs; }   // release whatever was created
@@ -364,6 +382,7 @@ void qmpc_destroy(qmpc_handle* h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  lane_slot_release(h->lane_pslot);      // after the frees above (they wait for the device): no launch of this handle reads the slot any more
   delete h;
 }
 
@@ -395,7 +414,7 @@ static bool use_global_gains(const qmpc_handle* h, int32_t batch) { return pick_
 // It returns forces, info and (on request) the input and state trajectories.
 static bool use_lane(const qmpc_handle* h, int32_t batch, const double* d_tu, const double* d_tx) {
   (void)d_tu; (void)d_tx;
-  if (h->params.mode != QMPC_MODE_CONVERGED) return false;
+  if (h->params.mode != QMPC_MODE_CONVERGED || h->lane_pslot < 0) return false;
   if (h->variant == 4) return true;
   return h->variant == 0 && batch >= (h->lane_loop_cold ? h->lane_min_loop_cold : h->lane_min_batch);
 }

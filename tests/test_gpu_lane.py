@@ -151,6 +151,37 @@ def test_config4_workload_on_one_gpu(pkg, lib, oracle):
     s.close()
 
 
+def test_more_live_handles_than_parameter_slots(pkg, lib, oracle, monkeypatch):
+    """The lane kernel reads its parameters from a 64-slot constant-memory table, one slot per LIVE handle (free list,
+    returned in qmpc_destroy).  70 handles with different friction coefficients alive at once: every one solves its own
+    problem (the ones created after the table is full keep the wave-per-instance kernels), also after the early ones have
+    solved again; destroyed handles give their slots back."""
+    _forced(monkeypatch, 4)
+    rec = pkg.random_go1_trot_states(64, config_id=2)
+    mus = np.linspace(0.35, 0.9, 70)
+    solvers, want = [], []
+    for mu in mus:
+        p = pkg.default_params(10, pkg.MODE_CONVERGED, lib)
+        p.mu = float(mu)
+        solvers.append(pkg.Solver(p, 64, device=0, lib=lib))
+    for i in (0, 13, 63, 64, 69):
+        p = pkg.default_params(10, pkg.MODE_CONVERGED, lib)
+        p.mu = float(mus[i])
+        want.append((i, oracle.solve(p, rec, threads=8)[0]))
+    first = [s.solve(rec)[0] for s in solvers]
+    again = [s.solve(rec)[0] for s in solvers]
+    for i, fo in want:
+        assert np.abs(first[i] - fo).max() < 1e-6 and np.array_equal(first[i], again[i]), i
+    assert np.abs(first[0] - first[69]).max() > 1e-3            # different problems
+    for s in solvers:
+        s.close()
+    fresh = [pkg.Solver(pkg.default_params(10, pkg.MODE_CONVERGED, lib), 64, device=0, lib=lib) for _ in range(64)]
+    f0 = [s.solve(rec)[0] for s in fresh]
+    assert all(np.array_equal(f0[0], f) for f in f0)
+    for s in fresh:
+        s.close()
+
+
 @pytest.mark.parametrize("N,B", [(10, 32768), (20, 16384)])
 def test_straggler_hand_off_of_large_batches(pkg, lib, oracle, monkeypatch, N, B):
     """Cold plain solves the library sends to the lane kernel by itself (qmpc_hip.hip: launch_solve): the lane kernel stops at
