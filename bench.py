@@ -184,7 +184,8 @@ def sq_from_profiles(B, N, model):
         return None
     try:
         d = json.loads(cands[-1].read_text())
-        d["source"] = f"profiles/{cands[-1].name}"
+        # say which round and which kernel the pass was taken on (a pass older than the kernel it is quoted for is stale)
+        d["source"] = f"profiles/{cands[-1].name} (round {d.get('round', cands[-1].name[:3])}, kernel {d.get('kernel', 'see the file')})"
         return d
     except (OSError, ValueError):
         return None
@@ -339,7 +340,10 @@ def main():
         var = os.environ.get("QMPC_VARIANT", "0")
         wf = int(os.environ.get("QMPC_WFORM", "1"))
         if var == "4" or (var == "0" and batch >= lane_min):
-            return "qmpc_lane_kernel (lane per instance, wrench form)"
+            cap = int(os.environ.get("QMPC_LANE_CAP", str(15 + hz // 10)))
+            handoff = var == "0" and args.model == "quat" and wf and cap > 0
+            return "qmpc_lane_kernel (lane per instance, wrench form)" + (
+                f"; stragglers beyond {cap} iterations continued by qmpc_solve_w_list_kernel (one call)" if handoff else "")
         if args.model == "quat" and wf and var in ("0", "1"):
             all_lds = batch <= 1024 and hz <= 10
             if all_lds:
