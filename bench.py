@@ -486,6 +486,31 @@ def main():
                        "two_in_flight": {"value": Bl * 2 * kl / dt2, "unit": "solves/s", "ms_per_batch": 1e3 * dt2 / (2 * kl),
                                          "outputs_identical": same2},
                        "roofline": roofline_object(kernel_name(Bl, Nl), ach, tr, tr_src, lg["kernel_ms"], Bl, Bl * (8 * 48 + 8 * 12 + 40))}
+                # the reference's own solver mode on the same batch (AL-iLQR, <= 10 iterations; wave-per-instance kernels at
+                # every batch size: wrench form for N <= 12, the round-1 kernels beyond)
+                if not args.no_reference_mode:
+                    prl = pkg.default_params(Nl, pkg.MODE_REFERENCE, lib)
+                    srl = pkg.Solver(prl, Bl, device=local, lib=lib)
+                    frl = torch.zeros(Bl, 12, dtype=torch.float64, device="cuda")
+                    irl = torch.zeros(Bl, pkg.INFO_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+                    d_inl = torch.from_numpy(pkg.random_go1_trot_states(Bl, config_id=cfg).view(np.float64).reshape(Bl, -1).copy()).cuda()
+                    kms = []
+                    for r_ in range(4):
+                        srl.solve_device(Bl, d_inl.data_ptr(), frl.data_ptr(), irl.data_ptr())
+                        srl.wait()
+                        if r_:
+                            kms.append(srl.last_kernel_ms())
+                    inf_l = irl.cpu().numpy().view(pkg.INFO_DTYPE).reshape(Bl)
+                    srl.close()
+                    ent["reference_mode"] = {
+                        "value": Bl / (float(np.median(kms)) * 1e-3), "unit": "solves/s", "kernel_ms": float(np.median(kms)),
+                        "kernel": ("qmpc_ref_w_kernel<5> (wave per instance, wrench form, gains in the workspace)" if Nl <= 12
+                                   else "qmpc_ref_kernel (wave per instance, dense 12x12 stage algebra)"),
+                        "mean_iterations": float(inf_l["iterations"].mean()),
+                        "status_counts": {"converged": int((inf_l["status"] == 0).sum()), "iteration_cap": int((inf_l["status"] == 1).sum()),
+                                          "linesearch_fail": int((inf_l["status"] == 4).sum()), "not_pd": int((inf_l["status"] == 5).sum())},
+                        "note": "secondary: the reference's own operating mode (truncated AL-iLQR iterate) at this batch size; never `value`"}
+                    del frl, irl, d_inl
                 sql = sq_from_profiles(Bl, Nl, "quat")
                 if sql is not None:
                     ent["roofline"]["issue_frac"] = sql.get("issue_frac")

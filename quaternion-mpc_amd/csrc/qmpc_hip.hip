@@ -42,6 +42,8 @@ hipError_t qmpc_wform_set_lds(int bytes);
 hipError_t qmpc_wform_launch(int var, int prof, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
                              const qmpc_input* in, double* forces, qmpc_info* info, double* traj_u, double* traj_x,
                              long long* prof_out, double* gws);
+hipError_t qmpc_wform_ref_launch(int var, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
+                                 const qmpc_input* in, double* forces, qmpc_info* info, double* traj_u, double* traj_x, double* gws);
 hipError_t qmpc_wform_launch_list(int var, int grid, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
                                   const qmpc_input* in, double* forces, qmpc_info* info, double* traj_u, double* traj_x,
                                   const int* sel, const int* sel_count, double* gws, const double* hstate, int hcap);
@@ -491,6 +493,21 @@ static size_t variant_lds(const qmpc_handle* h, int var) {
 }
 static double* variant_gws(const qmpc_handle* h, int var) { return (var == 1 || var == 2 || var == 5) ? h->d_gws : nullptr; }
 
+// reference mode of QuatMpc's problem: the wrench-form kernels (3: everything in LDS, one instance per SIMD; 5: gains in the
+// workspace), with the rule of the round-1 reference kernels for which of the two; 0: keep the round-1 kernels.
+// Horizons up to 12 only: a TRUNCATED iterate does not damp the rounding of its Newton systems, and the 6 x 6 wrench-space
+// system (condition ~1e7, growing with the horizon) is solved to ~1e-9 of the step where the rotated 12 x 12 elimination
+// keeps every direction to its own scale.  Measured against the round-1 kernels (tools/refmode_bench.py): N=10 all status
+// words and iteration counts equal, forces within 4e-8 N, 0.91 -> 1.02 M solves/s at 1024 instances, 1.36 -> 1.83 M at 65536;
+// N=20 status words and iteration counts equal but only 65 % of the forces within 1e-6 N (median 6e-7), and no faster.
+static int ref_wform_variant(const qmpc_handle* h, int32_t batch) {
+  if (!h->wform || h->params.model != QMPC_MODEL_QUAT || h->params.mode != QMPC_MODE_REFERENCE) return 0;
+  if (h->params.horizon > 12) return 0;
+  const bool ws = batch > 1024 || h->lds_bytes_w > 40 * 1024 || h->variant >= 2;
+  if (!ws) return 3;
+  return h->lds_bytes_wg <= 80 * 1024 ? 5 : 0;
+}
+
 static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces,
                                 qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s, bool timed = true,
                                 bool handoff = true) {
@@ -498,6 +515,15 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
   if (timed) HIP_TRY(hipEventRecord(h->ev0, s));
   if (h->params.mode == QMPC_MODE_REFERENCE) {     // the reference's own AL-iLQR mode (qmpc_ref.hip)
     const bool ws = batch > 1024 || h->lds_bytes > 40 * 1024 || h->variant >= 2 || h->params.model == QMPC_MODEL_QUAT8;
+    if (const int wv = ref_wform_variant(h, batch)) {      // QuatMpc's problem: on the wrench-form algebra (qmpc_wform_ref_body.inc)
+      HIP_TRY(qmpc_wform_ref_launch(wv, (int)batch, variant_lds(h, wv), s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, d_tu, d_tx,
+                                    variant_gws(h, wv)));
+      if (timed) {
+        HIP_TRY(hipEventRecord(h->ev1, s));
+        h->timed = true;
+      }
+      return QMPC_OK;
+    }
     const size_t lds_r = ws ? h->lds_bytes_g : h->lds_bytes;
     double* gws_r = ws ? h->d_gws : nullptr;
 #define QMPC_LAUNCH_REF(kern) \
@@ -1126,7 +1152,8 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   if (fused) {
     const bool ref = h->params.mode == QMPC_MODE_REFERENCE;
     // the reference-mode kernels exist with everything in LDS (0) and with the gains in the workspace (1): launch_solve's rule
-    const int var = ref ? ((batch > 1024 || h->lds_bytes > 40 * 1024 || h->variant >= 2) ? 1 : 0) : body_variant(h, batch);
+    const int rwv = ref ? ref_wform_variant(h, batch) : 0;
+    const int var = ref ? (rwv ? rwv : ((batch > 1024 || h->lds_bytes > 40 * 1024 || h->variant >= 2) ? 1 : 0)) : body_variant(h, batch);
     HIP_TRY(qmpc_fused_launch(var, ref ? 1 : 0, convex ? 1 : 0, (int)batch, variant_lds(h, var), s, &h->dev, sizeof h->dev, &LP, d_states, h->d_in, h->d_forces,
                               h->d_info, d_trace_forces, d_trace_contacts, (int)ticks, variant_gws(h, var), g,
                               d_joint_pos, d_cmd, d_trace_cmd));

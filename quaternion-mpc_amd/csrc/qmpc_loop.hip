@@ -422,7 +422,7 @@ struct FusedJoint {          // the joint level closing every tick (JOINT instan
 // REF: the reference's own solver mode (AL-iLQR, <= 10 iterations; one wave per SIMD like qmpc_ref_kernel, VAR 0 / 1)
 // CONVEX: the sibling controller's problem (ConvexModel; converged mode only)
 template <int VAR, bool JOINT, bool REF, bool CONVEX = false>
-__global__ __launch_bounds__(64, REF ? 1 : QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_loop_fused_kernel(
+__global__ __launch_bounds__(64, (REF && VAR != 5) ? 1 : QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_loop_fused_kernel(
     DevParams P, qmpc_loop_params LP, qmpc_loop_state* __restrict__ st, qmpc_input* __restrict__ rec,
     double* __restrict__ forces, qmpc_info* __restrict__ info, double* __restrict__ trace_f, double* __restrict__ trace_c,
     int ticks, int batch, double* __restrict__ gws, FusedJoint JL) {
@@ -442,7 +442,13 @@ __global__ __launch_bounds__(64, REF ? 1 : QMPC_SOLVE_WAVES(QuatModel, VAR)) voi
       else loop_front_one(LP, st[b], rec[b]);
     }
     __syncthreads();                      // the record (global memory) is visible to the wave
-    if (REF) {
+    if constexpr (REF && (VAR == 3 || VAR == 5)) {
+      [&]() {                             // the reference's solver mode on the wrench-form algebra
+        constexpr int WVAR = VAR;
+        const int wslot = b;
+#include "qmpc_wform_ref_body.inc"
+      }();
+    } else if constexpr (REF) {
       [&]() {                             // `return` in the body (rejected input) ends this tick's solve only
 #include "qmpc_ref_body.inc"
       }();

@@ -18,6 +18,8 @@ using namespace qmpc_fused_tu;
 // called from qmpc_hip.hip (declared there); hidden: not part of the C ABI
 template <bool JOINT, bool REF, bool CONVEX = false>
 static const void* fused_kernel(int var) {
+  if (REF && var == 3) return reinterpret_cast<const void*>(qmpc_loop_fused_kernel<3, JOINT, true, false>);
+  if (REF && var == 5) return reinterpret_cast<const void*>(qmpc_loop_fused_kernel<5, JOINT, true, false>);
   if (REF) return var >= 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1, JOINT, true, false>)
                            : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0, JOINT, true, false>);
   if (var == 3 && !CONVEX) return reinterpret_cast<const void*>(qmpc_loop_fused_kernel<3, JOINT, false, false>);
@@ -76,7 +78,9 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int 
     else if (var == 1) QMPC_LAUNCH_FUSED_CJ(1);
     else QMPC_LAUNCH_FUSED_CJ(0);
   } else if (reference_mode) {
-    if (var >= 1) QMPC_LAUNCH_FUSED_J(1, true);
+    if (var == 3) QMPC_LAUNCH_FUSED_J(3, true);
+    else if (var == 5) QMPC_LAUNCH_FUSED_J(5, true);
+    else if (var >= 1) QMPC_LAUNCH_FUSED_J(1, true);
     else QMPC_LAUNCH_FUSED_J(0, true);
   } else {
     if (var == 3) QMPC_LAUNCH_FUSED_J(3, false);

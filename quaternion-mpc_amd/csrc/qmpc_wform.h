@@ -88,6 +88,9 @@ __host__ __device__ constexpr int S6I(int i, int j) { return i <= j ? S6I_(i, j)
 // and the point's share of G = sum V D^-1 V', r6 = sum V D^-1 g (the arithmetic of rotation_prepass in
 // qmpc_kernels.hip followed by leg_block / pass B step 1 of qmpc_lane_core.h).  The four points of a knot sit in one
 // lane quad: their shares are summed with quad_perm moves and lane 0 of the quad stores the knot's 27 numbers. ----
+// AL = true (reference mode, qmpc_wform_ref_body.inc): augmented-Lagrangian weights instead of barrier weights,
+//   w_i = rho [lam_i + rho c_i > 0],  g_i = max(lam_i + rho c_i, 0)   (SURVEY.md Appendix B), c_i in the RC slot, `target` = rho
+template <bool AL = false>
 __device__ inline void prepass_w(const DevParams& P, const Layout& L, double* sm, const double* sl,
                                  double* ROT, double* GK, double target, int lane) {
   typedef Dim<4> D;
@@ -116,11 +119,17 @@ __device__ inline void prepass_w(const DevParams& P, const Layout& L, double* sm
       for (int i = 0; i < 6; ++i) {
         const double lam = sl[L.LAM + D::NC * k + 6 * l + i];
         const double rc = sl[L.RC + D::NC * k + 6 * l + i];
-        const double s = sl[L.S + D::NC * k + 6 * l + i];
-        const double kap = sl[L.DS + D::NC * k + 6 * l + i];     // weakly-active flag (see ipm_apply)
-        const double is = fast_rcp(s);
-        w[i] = lam * is;
-        gi[i] = (target + lam * rc) * is - kap * lam;
+        if (AL) {
+          const double z = lam + target * rc;
+          w[i] = (z > 0.0) ? target : 0.0;
+          gi[i] = (z > 0.0) ? z : 0.0;
+        } else {
+          const double s = sl[L.S + D::NC * k + 6 * l + i];
+          const double kap = sl[L.DS + D::NC * k + 6 * l + i];     // weakly-active flag (see ipm_apply)
+          const double is = fast_rcp(s);
+          w[i] = lam * is;
+          gi[i] = (target + lam * rc) * is - kap * lam;
+        }
       }
       // heaviest row i1, second heaviest non-(anti)parallel row i2 (rows 4,5 are antiparallel)
       int i1 = 0;
@@ -437,8 +446,10 @@ __device__ __forceinline__ double gj6_step(double M[2], double Rr[2], int c, int
 // Riccati backward pass in the wrench form; writes per knot [Xw | xw] and [Xz | xz] (KD).  Returns nonzero when a pivot
 // of W' is not positive (P lost positive definiteness: QMPC_NOT_PD).
 template <bool PROF>
+// y0out (optional, 6 per knot): y0_k = M' p_{k+1}, the wrench-space costate BEFORE the stage solve -- the rotated input
+// gradient of contact point l is V_l' y0 + gq_l (the expected decrease of the reference mode's line search needs it)
 __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const BwPat& bp, double* sm, double* KD,
-                                      const double* GK, int lane, Prof<PROF>& prof) {
+                                      const double* GK, int lane, Prof<PROF>& prof, double* y0out = nullptr) {
   const int N = P.N;
   const int c = lane & 15, g = lane >> 4;
   const double wscale = (0.5 * P.hh) * P.h;        // Wt = (h^2 / 4) Gn'Gm
@@ -497,6 +508,10 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
       Yp[0] = a[0]; Yp[1] = a[1];
     }
     if (k > 0) load_ops(opn);
+    if (y0out && bp.c12) {
+      if (g < 4) y0out[6 * k + g] = Yp[0];
+      if (g < 2) y0out[6 * k + 4 + g] = Yp[1];
+    }
     tick_dep(prof, PH_DRAIN, Yp[0], Yp[1]);
     // ---- 2. S6 = Yp_fb M  (column operation) ----
     double S6[2];
@@ -725,7 +740,7 @@ __device__ __forceinline__ void roll_load_w(const Layout& L, const LayoutW& LW, 
 // registers: the one-wave-per-SIMD form); without it the loads sit at the top of the knot (two waves per SIMD hide them)
 template <bool PROF, bool PF>
 __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm,
-                                        const double* KD, double* ROT, int lane, Prof<PROF>& prof) {
+                                        const double* KD, double* ROT, int lane, Prof<PROF>& prof, double alpha = 1.0) {
   typedef Dim<4> D;
   const int N = P.N;
   const double* cst = sm + L.cst;
@@ -756,7 +771,7 @@ __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, con
       e[9 + a] = dx[9 + a];
     }
     const double* kd = cur.kd;
-    const double p0 = kd[12] + kd[0] * e[0] + kd[1] * e[1] + kd[2] * e[2];
+    const double p0 = alpha * kd[12] + kd[0] * e[0] + kd[1] * e[1] + kd[2] * e[2];      // alpha scales the feed-forward part
     const double p1 = kd[3] * e[3] + kd[4] * e[4] + kd[5] * e[5];
     const double p2 = kd[6] * e[6] + kd[7] * e[7] + kd[8] * e[8];
     const double p3 = kd[9] * e[9] + kd[10] * e[10] + kd[11] * e[11];
@@ -791,11 +806,53 @@ __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, con
   QSYNC();
 }
 
+// ---- expected decrease of a full step, sum_k d_k' Qu_k (the Armijo test of the reference mode's line search): one lane
+// per (knot, contact point); d_l = -D~_l^-1 (V_l' xz + gq_l) is the feed-forward part of the point's step, Qu_l = V_l' y0 + gq_l
+// its gradient (y0 from the backward pass, xz = column 12 of [Xz | xz]) ---------------------------------------------------
+__device__ inline double expected_decrease_w(const DevParams& P, const Layout& L, double* sm, const double* KD,
+                                             const double* ROT, const double* y0, int lane) {
+  typedef Dim<4> D;
+  const int N = P.N;
+  const double* cst = sm + L.cst;
+  double part = 0.0;
+  for (int q = lane; q < 4 * N; q += kWave) {
+    const int k = q >> 2, l = q & 3;
+    if (cst[D::C_CON + l] == 0.0) continue;
+    const double* rec = ROT + D::ROT * k + 21 * l;
+    double T[9], xz[6], yk[6];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) T[i] = rec[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { xz[i] = KD[156 * k + 13 * (6 + i) + 12]; yk[i] = y0[6 * k + i]; }
+    const double l10 = rec[9], l20 = rec[10], l21 = rec[11], id0 = rec[12], id1 = rec[13], id2 = rec[14];
+    const double* bw = sm + L.bw0 + 3 * l;
+    double fz[3], fy[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      fz[b] = xz[b] + (bw[b] * xz[3] + bw[D::NU + b] * xz[4] + bw[2 * D::NU + b] * xz[5]);
+      fy[b] = yk[b] + (bw[b] * yk[3] + bw[D::NU + b] * yk[4] + bw[2 * D::NU + b] * yk[5]);
+    }
+    double t[3], qu[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      t[b] = rec[15 + b] + (T[b] * fz[0] + T[3 + b] * fz[1] + T[6 + b] * fz[2]);
+      qu[b] = rec[15 + b] + (T[b] * fy[0] + T[3 + b] * fy[1] + T[6 + b] * fy[2]);
+    }
+    const double y0_ = t[0], y1_ = t[1] - l10 * y0_, y2_ = t[2] - l20 * y0_ - l21 * y1_;
+    const double x2 = id2 * y2_;
+    const double x1 = id1 * y1_ - l21 * x2;
+    const double x0 = id0 * y0_ - l10 * x1 - l20 * x2;
+    part -= x0 * qu[0] + x1 * qu[1] + x2 * qu[2];
+  }
+  return wave_sum(part);
+}
+
 // ---- input increments of the trial step, one lane per (knot, contact point):
 //      du_l = -T_l D~_l^-1 (V_l' zeta + gq_l),   V_l' zeta = T_l' (zeta_f + Bw0_l' zeta_t) ----
 // Returns nonzero (wave-uniform) when an increment is not finite: the trial step is then NOT applied (QMPC_NOT_PD, the
 // rule of the lane kernel) -- the step-length reductions that follow drop NaNs silently.
-__device__ inline int recover_inputs_w(const DevParams& P, const Layout& L, double* sm, const double* ROT, int lane) {
+__device__ inline int recover_inputs_w(const DevParams& P, const Layout& L, double* sm, const double* ROT, int lane,
+                                       double alpha = 1.0) {
   typedef Dim<4> D;
   const int N = P.N;
   const double* cst = sm + L.cst;
@@ -817,7 +874,7 @@ __device__ inline int recover_inputs_w(const DevParams& P, const Layout& L, doub
       for (int b = 0; b < 3; ++b) f[b] = z[b] + (bw[b] * z[3] + bw[D::NU + b] * z[4] + bw[2 * D::NU + b] * z[5]);
       double t[3];
 #pragma unroll
-      for (int b = 0; b < 3; ++b) t[b] = rec[15 + b] + (T[b] * f[0] + T[3 + b] * f[1] + T[6 + b] * f[2]);
+      for (int b = 0; b < 3; ++b) t[b] = alpha * rec[15 + b] + (T[b] * f[0] + T[3 + b] * f[1] + T[6 + b] * f[2]);
       const double y0 = t[0], y1 = t[1] - l10 * y0, y2 = t[2] - l20 * y0 - l21 * y1;
       const double x2 = id2 * y2;
       const double x1 = id1 * y1 - l21 * x2;

@@ -35,6 +35,7 @@
 #define QMPC_FUSED_TU 1
 #define qmpc qmpc_wform_tu
 #include "qmpc_kernels.hip"
+#include "qmpc_ref.hip"
 #include "qmpc_wform.h"
 
 namespace qmpc {
@@ -84,6 +85,19 @@ __global__ __launch_bounds__(64, WVAR == 5 ? 2 : 1) void qmpc_solve_w_list_kerne
   }
 }
 
+// The reference's own solver mode (AL-iLQR, <= 10 iterations) on the wrench-form algebra (qmpc_wform_ref_body.inc)
+template <int WVAR>
+__global__ __launch_bounds__(64, WVAR == 5 ? 2 : 1) void qmpc_ref_w_kernel(
+    DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
+    double* __restrict__ traj_u, double* __restrict__ traj_x, int batch, double* __restrict__ gws) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int b = blockIdx.x;
+  if (b >= batch) return;
+  const int wslot = b;
+  const int lane = threadIdx.x;
+#include "qmpc_wform_ref_body.inc"
+}
+
 }  // namespace qmpc
 #undef qmpc
 
@@ -98,10 +112,11 @@ __attribute__((visibility("hidden"))) size_t qmpc_wform_lds_bytes(int N, int kd_
 }
 __attribute__((visibility("hidden"))) size_t qmpc_wform_slice_doubles(int N) { return wform_slice(N); }
 __attribute__((visibility("hidden"))) hipError_t qmpc_wform_set_lds(int bytes) {
-  const void* k[6] = {reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 3>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 3>),
+  const void* k[8] = {reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 3>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 3>),
                       reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 5>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 5>),
-                      reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<3>), reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<5>)};
-  for (int i = 0; i < 6; ++i) {
+                      reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<3>), reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<5>),
+                      reinterpret_cast<const void*>(qmpc_ref_w_kernel<3>), reinterpret_cast<const void*>(qmpc_ref_w_kernel<5>)};
+  for (int i = 0; i < 8; ++i) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
   }
@@ -141,5 +156,18 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_wform_launch_list(int var,
   else
     hipLaunchKernelGGL(qmpc_solve_w_list_kernel<3>, dim3((unsigned)grid), dim3(kWave), lds, s, P, in, forces, info, traj_u, traj_x, sel,
                        sel_count, gws, hstate, hcap);
+  return hipGetLastError();
+}
+// reference mode; var: 3 everything in LDS, 5 gains in the workspace gws
+__attribute__((visibility("hidden"))) hipError_t qmpc_wform_ref_launch(int var, int batch, size_t lds, hipStream_t s, const void* dev_params,
+                                                                       size_t dev_params_size, const qmpc_input* in, double* forces,
+                                                                       qmpc_info* info, double* traj_u, double* traj_x, double* gws) {
+  if (dev_params_size != sizeof(DevParams)) return hipErrorInvalidValue;
+  DevParams P;
+  std::memcpy(&P, dev_params, sizeof P);
+  if (var == 5)
+    hipLaunchKernelGGL(qmpc_ref_w_kernel<5>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in, forces, info, traj_u, traj_x, batch, gws);
+  else
+    hipLaunchKernelGGL(qmpc_ref_w_kernel<3>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in, forces, info, traj_u, traj_x, batch, gws);
   return hipGetLastError();
 }

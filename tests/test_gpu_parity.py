@@ -826,6 +826,27 @@ def test_reference_mode_on_device_matches_oracle_reference_mode(pkg, lib, oracle
         assert (f.reshape(-1, 4, 3)[rec["contacts"] == 0] == 0).all()          # swing legs exactly 0
 
 
+def test_reference_mode_at_monte_carlo_scale(pkg, lib, oracle):
+    """The reference's own solver mode on a 65536-instance batch (N = 10; the wrench-form reference kernel with its gains in
+    the workspace): a 384-instance sample spread over the batch against the oracle's reference mode -- identical status words
+    and iteration counts, forces within 1e-6 N; every instance ends within the 10 iterations; swing legs exactly 0."""
+    B, N = 65536, 10
+    p = pkg.default_params(N, pkg.MODE_REFERENCE, lib)
+    rec = pkg.random_go1_trot_states(B, config_id=4)
+    s = pkg.Solver(p, B, device=0, lib=lib)
+    f, info = s.solve(rec)
+    s.close()
+    idx = np.arange(0, B, B // 384)[:384]
+    fo, io = oracle.solve(p, rec[idx], threads=8)
+    d = np.abs(f[idx] - fo).max(axis=1)
+    same = (info["status"][idx] == io["status"]) & (info["iterations"][idx] == io["iterations"])
+    print(f"reference mode at B={B}: {int(same.sum())}/384 sampled instances with identical status and iterations, forces worst {d.max():.2e} N; "
+          f"status counts {np.bincount(info['status'], minlength=6).tolist()}, iterations mean {info['iterations'].mean():.2f}")
+    assert same.all() and d.max() < 1e-6
+    assert (info["iterations"] <= 10).all() and np.isfinite(f).all()
+    assert (f.reshape(-1, 4, 3)[rec["contacts"] == 0] == 0).all()
+
+
 def test_reference_mode_edge_cases_and_convex_model(pkg, lib, oracle):
     """Reference mode: non-finite and no-contact records get their status and zero forces, trajectories come back,
     the 8-point model follows the oracle too, and ConvexMpc's problem (ConvexMpc.cpp:36-38: 5 iterations) follows
