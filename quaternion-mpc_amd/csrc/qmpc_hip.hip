@@ -101,6 +101,7 @@ struct qmpc_handle {
   int* d_handoff;              // straggler hand-off: count | list of instances the capped lane launch left (on first use)
   double* d_hstate;            // ... and their state records (hstate_cap of them)
   int hstate_cap;
+  int lane_ref_min;            // reference-mode batches from this size on take the lane kernel (env QMPC_LANE_REF_MIN)
   int lane_cap;                // straggler hand-off: iteration cap of the lane kernel in cold plain solves (0: off; env QMPC_LANE_CAP)
 };
 
@@ -115,6 +116,7 @@ constexpr int kLaneMinLoopCold = 18432;       // ... of the cold-started closed 
 constexpr int kLaneMinBatch = 26624;          // QuatMpc, horizons up to 12
 constexpr int kLaneMinBatchLong = 16384;      // QuatMpc, longer horizons
 constexpr int kLaneMinBatchOther = 18432;
+constexpr int kLaneRefMinBatch = 8192;        // reference mode (AL-iLQR): provisional, see profiles/r04_refmode_lane.txt
 
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
@@ -348,6 +350,8 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     // CONTINUES them (launch_solve; qmpc_wform_body.inc `resume`).  The cap is a fixed function of the horizon, so the
     // result of an instance depends neither on timing nor on the batch it is part of.  Measured (caps 14 .. 20 scanned):
     // B=32768 N=10 4.14 -> 5.2 M solves/s, B=65536 N=10 6.8 -> 8.3 M, B=65536 N=20 3.25 -> 3.83 M, B=262144 N=10 9.1 -> 9.8 M.
+    const char* lrm = std::getenv("QMPC_LANE_REF_MIN");
+    h->lane_ref_min = lrm ? std::atoi(lrm) : kLaneRefMinBatch;
     const char* lc = std::getenv("QMPC_LANE_CAP");
     h->lane_cap = lc ? std::atoi(lc) : 15 + N / 10;
     const char* ls = std::getenv("QMPC_LANE_SORT");
@@ -515,6 +519,18 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
   if (timed) HIP_TRY(hipEventRecord(h->ev0, s));
   if (h->params.mode == QMPC_MODE_REFERENCE) {     // the reference's own AL-iLQR mode (qmpc_ref.hip)
     const bool ws = batch > 1024 || h->lds_bytes > 40 * 1024 || h->variant >= 2 || h->params.model == QMPC_MODEL_QUAT8;
+    // Monte-Carlo scale (plain solves of QuatMpc's problem): one lane per instance, the AL variant of the lane passes
+    // (qmpc_lane_core.h: lane_solve_ref; qmpc_lane.hip: qmpc_lane_ref_kernel)
+    if (handoff && h->params.model == QMPC_MODEL_QUAT && h->lane_pslot >= 0 && !d_tx &&
+        (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min))) {
+      const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s, nullptr, d_tu, 0, nullptr, 0);
+      if (ls != QMPC_OK) return ls;
+      if (timed) {
+        HIP_TRY(hipEventRecord(h->ev1, s));
+        h->timed = true;
+      }
+      return QMPC_OK;
+    }
     if (const int wv = ref_wform_variant(h, batch)) {      // QuatMpc's problem: on the wrench-form algebra (qmpc_wform_ref_body.inc)
       HIP_TRY(qmpc_wform_ref_launch(wv, (int)batch, variant_lds(h, wv), s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, d_tu, d_tx,
                                     variant_gws(h, wv)));

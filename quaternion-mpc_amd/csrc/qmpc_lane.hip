@@ -142,6 +142,171 @@ __device__ __noinline__ void call_finish(PassArgs a, QL_PRIV_AS const LaneK<NL>*
                   reinterpret_cast<double*>(traj_u), reinterpret_cast<double*>(traj_x));
 }
 
+// ---- reference mode (qmpc_lane_core.h: "Reference mode on the lane passes"): the passes as separate functions, the
+// augmented-Lagrangian scalars of the lane handed over through its private memory like the other per-instance state ---------
+template <int NL>
+__device__ __noinline__ void call_setup_ref(PassArgs a, QL_PRIV_AS const LaneState* sp, QL_PRIV_AS LaneAL* alp) {
+  const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
+  const Ctx c = pass_ctx<NL>(a);
+  const WsOff O = make_wsoff<NL>(P.N);
+  LaneState st;
+  priv_load(st, sp);
+  LaneAL al;
+  lane_setup_ref<NL>(P, c, O, st, al);
+  priv_store(alp, al);
+}
+template <int NL, bool UPDATE>
+__device__ __noinline__ void call_M(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp, QL_PRIV_AS LaneAL* alp) {
+  const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
+  const Ctx c = pass_ctx<NL>(a);
+  const WsOff O = make_wsoff<NL>(P.N);
+  LaneK<NL> K;
+  priv_load(K, Kp);
+  LaneState st;
+  priv_load(st, sp);
+  LaneAL al;
+  priv_load(al, (QL_PRIV_AS const LaneAL*)alp);
+  pass_M<NL, UPDATE>(P, c, O, K, st, al);
+  priv_store(alp, al);
+}
+template <int NL>
+__device__ __noinline__ bool call_B_AL(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp, QL_PRIV_AS LaneAL* alp) {
+  const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
+  const Ctx c = pass_ctx<NL>(a);
+  const WsOff O = make_wsoff<NL>(P.N);
+  LaneK<NL> K;
+  priv_load(K, Kp);
+  LaneState st;
+  priv_load(st, sp);
+  LaneAL al;
+  priv_load(al, (QL_PRIV_AS const LaneAL*)alp);
+  const bool ok = pass_B<NL, false, MD_QUAT, true>(P, c, O, K, st, (FootPtr)Kp->foot, &al);
+  priv_store(alp, al);
+  return ok;
+}
+template <int NL>
+__device__ __noinline__ void call_C_AL(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp, QL_PRIV_AS LaneAL* alp) {
+  const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
+  const Ctx c = pass_ctx<NL>(a);
+  const WsOff O = make_wsoff<NL>(P.N);
+  LaneK<NL> K;
+  priv_load(K, Kp);
+  LaneState st;
+  priv_load(st, sp);
+  LaneAL al;
+  priv_load(al, (QL_PRIV_AS const LaneAL*)alp);
+  pass_C_AL<NL>(P, c, O, K, st, al, true);
+  priv_store(alp, al);
+}
+template <int NL>
+__device__ __noinline__ void call_A_AL(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp) {
+  const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
+  const Ctx c = pass_ctx<NL>(a);
+  const WsOff O = make_wsoff<NL>(P.N);
+  LaneK<NL> K;
+  priv_load(K, Kp);
+  LaneState st;
+  priv_load(st, sp);
+  pass_A_AL<NL>(P, c, O, K, st);
+}
+template <int NL>
+__device__ __noinline__ void call_S(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp, QL_PRIV_AS LaneAL* alp) {
+  const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
+  const Ctx c = pass_ctx<NL>(a);
+  const WsOff O = make_wsoff<NL>(P.N);
+  LaneK<NL> K;
+  priv_load(K, Kp);
+  LaneState st;
+  priv_load(st, sp);
+  LaneAL al;
+  priv_load(al, (QL_PRIV_AS const LaneAL*)alp);
+  pass_S<NL>(P, c, O, K, st, al);
+  priv_store(alp, al);
+}
+
+// The reference's own solver mode, one lane per instance: the steps of lane_solve_ref (qmpc_lane_core.h) in lock step.  A
+// lane whose line search has ended waits (masked off) while others of its wavefront try shorter steps.
+template <int NL>
+__global__ __launch_bounds__(kLaneWave) void qmpc_lane_ref_kernel(int pslot, const double* __restrict__ in, double* __restrict__ forces,
+                                                                  qmpc_info* __restrict__ info, int batch, double* __restrict__ ws,
+                                                                  unsigned slots, int lanes, const int* __restrict__ perm,
+                                                                  double* traj_u, double* traj_x) {
+  typedef LDim<NL> D;
+  const int lane = threadIdx.x;
+  const DevParams& P = ql_params[pslot];
+  const size_t block_elems = (size_t)make_wsoff<NL>(P.N).total * kLaneWave;
+  const unsigned long long wsb = reinterpret_cast<unsigned long long>(ws + (size_t)blockIdx.x * block_elems);
+  const PassArgs a = {pslot, (unsigned)wsb, (unsigned)(wsb >> 32), 8u * (unsigned)lane, 0u};
+  const size_t tstride = (size_t)P.N * D::NU;
+  LaneK<NL> K;
+  LaneState st;
+  LaneAL al;
+  QL_PRIV_AS LaneK<NL>* Kp = (QL_PRIV_AS LaneK<NL>*)&K;
+  QL_PRIV_AS LaneState* sp = (QL_PRIV_AS LaneState*)&st;
+  QL_PRIV_AS LaneAL* alp = (QL_PRIV_AS LaneAL*)&al;
+  for (long long base = (long long)blockIdx.x * lanes; base < batch; base += slots) {
+    const long long pos = base + lane;
+    const bool valid = lane < lanes && pos < batch;
+    const int b = valid ? (perm ? perm[pos] : (int)pos) : 0;
+    bool active = false;
+    if (valid) {
+      call_setup<NL, MD_QUAT>(a, reinterpret_cast<unsigned long long>(in + (size_t)b * D::REC), 0ull, Kp, sp);
+      active = st.active;
+    }
+    int iter = 0;
+    if (active) {
+      call_setup_ref<NL>(a, sp, alp);
+      call_A<NL, false, MD_QUAT>(a, Kp, sp);        // X <- rollout of U = u_ref (first iteration of the apply pass)
+      call_M<NL, false>(a, Kp, sp, alp);
+      st.status = QMPC_MAX_ITER;
+      st.last_step = 0.0;
+    }
+    while (__any(active)) {
+      bool searching = false;
+      if (active) {
+        ++iter;
+        if (!call_B_AL<NL>(a, Kp, sp, alp)) { st.status = QMPC_NOT_PD; --iter; active = false; }
+        else { al.alpha = 1.0; searching = true; }
+      }
+      bool accepted = false;
+      int ls = 0;
+      while (__any(searching)) {
+        if (searching) {
+          call_C_AL<NL>(a, Kp, sp, alp);
+          const double expected = al.alpha * al.dV1;
+          const double slack = 1e-12 * fmax(1.0, fabs(al.J));
+          if (isfinite(al.Jn) && al.Jn - al.J <= 1e-4 * expected + slack) { accepted = true; searching = false; }
+          else {
+            al.alpha *= 0.5;
+            if (++ls > P.linesearch_max) searching = false;
+          }
+        }
+      }
+      if (active && !accepted) { st.status = QMPC_LINESEARCH_FAIL; --iter; active = false; }
+      if (active) {
+        call_A_AL<NL>(a, Kp, sp);
+        st.last_step = al.stp;
+        const double dJ = al.J - al.Jn;
+        al.J = al.Jn; al.Jp = al.Jnp; al.viol = al.vn;
+        call_S<NL>(a, Kp, sp, alp);
+        if (al.stat < P.tol_stat && al.viol < P.tol_feas) { st.status = QMPC_OK; active = false; }
+        else {
+          if (al.stat < P.tol_stat || fabs(dJ) < P.tol_cost_int) call_M<NL, true>(a, Kp, sp, alp);
+          if (iter >= P.iterations_max) active = false;
+        }
+      }
+    }
+    if (valid) {
+      st.iters = iter;
+      if (st.active) st.mu = al.rho;       // the info record's last field is the penalty in this mode
+      call_finish<NL, MD_QUAT>(a, Kp, sp, reinterpret_cast<unsigned long long>(forces + (size_t)b * D::NU),
+                               info ? reinterpret_cast<unsigned long long>(info + b) : 0ull,
+                               traj_u ? reinterpret_cast<unsigned long long>(traj_u + (size_t)b * tstride) : 0ull,
+                               traj_x ? reinterpret_cast<unsigned long long>(traj_x + (size_t)b * (size_t)(P.N + 1) * 13) : 0ull);
+    }
+  }
+}
+
 // Straggler hand-off (four-point QuatMpc, cold launches): the state of an instance that reached the iteration cap, for
 // the wave-per-instance kernel to CONTINUE from (qmpc_wform_body.inc) -- one record of 8 + 60 N doubles:
 // rho, last alpha_p, last alpha_d, last full step, iterations done, 3 spare; U [N][12]; slacks [N][24] (the Tapia flag in
@@ -400,6 +565,12 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
   prof = d_prof;
   (void)hipMemsetAsync(d_prof, 0, sizeof(long long) * 16 * 1024, s);
 #endif
+  if (P.mode == QMPC_MODE_REFERENCE) {      // the reference's own solver mode (four-point QuatMpc): qmpc_lane_ref_kernel
+    if (nl != 4 || convex || u_init) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(qmpc_lane_ref_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm,
+                       traj_u, traj_x);
+    return hipGetLastError();
+  }
   if (nl == 8)
     hipLaunchKernelGGL(qmpc_lane_kernel<8>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm, prof,
                        u_init, traj_u, check_prev, traj_x, iter_cap, hcount, hsel, hstate, hcap);

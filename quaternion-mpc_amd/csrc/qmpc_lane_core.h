@@ -955,8 +955,23 @@ QL_FN void cost_expansion(const DevParams& P, const Ctx& c, const WsOff& O, cons
     }
 }
 
-template <int NL, bool WARM = false, int MD = MD_QUAT>
-QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const LaneK<NL>& K, LaneState& st, FootPtr fp) {
+// AL (reference mode, lane_iteration_ref below): the rows carry augmented-Lagrangian weights instead of barrier weights --
+//   z_i = lam_i + rho c_i,  w_i = rho [z_i > 0],  g_i = max(z_i, 0)      (c_i = a_i . u + b_i from the input)
+// fed to leg_block() as a slack of 1, a multiplier w_i and a residual z_i / rho (target 0) -- and the pass also returns the
+// expected decrease of a full step, dV1 = sum_k d_k' Qu_k = -sum_k Qu_k' Quu_k^-1 Qu_k, through the wrench form:
+//   Qu' Quu^-1 Qu = y0'G y0 + 2 y0'r6 + sum_l g_l' D_l^-1 g_l - q6' S6 (I + G S6)^-1 q6,   y0 = M'p, q6 = G y0 + r6.
+struct LaneAL {
+  double rho, irho;         // penalty and its reciprocal
+  double J, Jp, viol;       // AL merit, plain objective and largest violation of the current trajectory
+  double dV1;               // expected decrease of a full step (pass B)
+  double alpha;             // step length of the line-search trial
+  double Jn, Jnp, vn, stp;  // the trial's merit, plain objective, violation, largest input increment
+  double stat;              // stationarity |grad_U L_A|_inf (pass S)
+  int searching;            // this lane's line search is still running (its trial increments may be overwritten)
+};
+template <int NL, bool WARM = false, int MD = MD_QUAT, bool AL = false>
+QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const LaneK<NL>& K, LaneState& st, FootPtr fp,
+                  LaneAL* al = nullptr) {
   Ctx c = c_in;
   typedef LDim<NL> D;
   const int N = P.N;
@@ -974,6 +989,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
   LegAheadT<WARM> R;         // rows of the NEXT contact point in processing order
   fetch_ahead<NL>(c, O, N - 1, first_bit(order), R, fp, rcrows);
   bool ok = true;
+  double dV1 = 0.0;           // AL only
   const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
   {
     double lx[12], lxx[6];
@@ -1005,6 +1021,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     double wd[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) wd[a] = K.wd0[a];
+    double gam = 0.0;         // AL only: sum_l g_l' D_l^-1 g_l
     const int kn = (k > 0) ? k - 1 : 0;
     double Wk[4] = {0, 0, 0, 0};       // ConvexMpc's model: Iw^-1 at this knot's midpoint yaw
     if constexpr (MD == MD_CONVEX) cv_winv_mid(P, c.W(O.X + 13 * k + 2), c.W(O.X + 13 * k + 8), Wk);
@@ -1046,8 +1063,21 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
 #pragma unroll
       for (int a = 0; a < 3; ++a) wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
       }
+      if constexpr (AL) {
+        kap = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          double cv = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
+          if (i == 4) cv += -P.fz_max;
+          const double z = lv[i] + al->rho * cv;
+          const bool act = z > 0.0;
+          sv[i] = 1.0;
+          rcl[i] = act ? z * al->irho : 0.0;
+          lv[i] = act ? al->rho : 0.0;
+        }
+      }
       LegBlk lb;
-      leg_block(P, cr, rcl, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
+      leg_block(P, cr, rcl, l, sv, lv, kap, AL ? 1.0 : st.rho, AL ? 0.0 : st.target, u, st.uz, lb);
       // V = [T ; Bw0 T] (6 x 3), Vt = V L^-T (columns), G += sum_j id_j vt_j vt_j', r6 += sum_j vt_j id_j y_j, y = L^-1 gq
       double V[18];
 #pragma unroll
@@ -1055,6 +1085,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
       mm(B, lb.T, &V[9]);
       const double y0 = lb.gq[0], y1 = lb.gq[1] - lb.l10 * y0, y2 = lb.gq[2] - lb.l20 * y0 - lb.l21 * y1;
       const double z0 = lb.id0 * y0, z1 = lb.id1 * y1, z2 = lb.id2 * y2;
+      if constexpr (AL) gam += y0 * z0 + y1 * z1 + y2 * z2;
       double v0[6], v1[6], v2[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -1123,6 +1154,24 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     QL_FENCE();
     c.relane();
     QL_TICK(st, LP_B_EXPAND);
+    double q6[6] = {0, 0, 0, 0, 0, 0}, ak = 0.0;      // AL only: q6 = G y0 + r6,  ak = y0'G y0 + 2 y0'r6 + gam
+    if constexpr (AL) {
+      double y0v[6];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        y0v[a] = m1 * pv[a] + m2 * pv[6 + a];
+        y0v[3 + a] = Wt[a] * pv[3] + Wt[3 + a] * pv[4] + Wt[6 + a] * pv[5] + P.h * pv[9 + a];
+      }
+      ak = gam;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        double gy = 0.0;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) gy += G6[S6I(i, t)] * y0v[t];
+        q6[i] = gy + r6[i];
+        ak += y0v[i] * (gy + 2.0 * r6[i]);
+      }
+    }
     // ---- 3. S6 = M'PM from the symmetric storage; factorisations; Z ----
     double S6[21], Z[21];
     {
@@ -1413,6 +1462,17 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
       } else {
 #pragma unroll
         for (int t = 0; t < 6; ++t) z[t] += r6[t];
+        if constexpr (AL) {      // z + r6 = (I + G S6)^-1 q6
+          double t2 = 0.0;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            double sw = 0.0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) sw += S6[S6I(i, t)] * z[t];
+            t2 += q6[i] * sw;
+          }
+          dV1 -= ak - t2;
+        }
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
           double s = 0.0;
@@ -1446,6 +1506,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     c.relane();
     QL_TICK(st, LP_B_GAIN);
   }
+  if constexpr (AL) al->dV1 = dV1;
   return ok;
 }
 
@@ -1704,6 +1765,411 @@ QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, cons
   if (st.bad_step) { st.status = QMPC_NOT_PD; return false; }     // the last finite iterate stays in the workspace
   st.iters = st.it;
   return true;
+}
+
+// =====================================================================================================================
+// Reference mode on the lane passes (QMPC_MODE_REFERENCE; four- and eight-point quaternion model): the reference's OWN
+// operating mode -- the AL-iLQR scheme of its external solver with QuatMpc's settings, iterations_max = 10,
+// penalty_scaling = 20, backtracking line search, status ignored (QuatMpc.cpp:21-26,256; the
+// wave-per-instance form is qmpc_ref.hip, the CPU restatement oracle/qo_altro.c):
+//
+//   lambda <- 0, rho <- penalty_initial; U <- u_ref; X <- rollout; J <- AL merit
+//   repeat iter = 1 .. iterations_max:
+//     pass B<AL>     Riccati step with AL weights, expected decrease dV1
+//     pass C_AL      trial rollouts u = u + alpha d + K dx at alpha = 1, 1/2, ... until the merit decreases (Armijo, 1e-4)
+//     pass A_AL      apply the accepted increment, roll the states out
+//     pass S         stationarity |grad_U L_A|_inf at the new trajectory (costate recursion)
+//     converged: stationarity < tol and feasibility < tol
+//     if stationarity < tol or |dJ| < tol_cost_intermediate:  pass M<true>: lambda <- max(lambda + rho c, 0), rho <- rho * scaling, J
+//
+// Workspace use: LAM = lambda; S unused (kept at 1); dU = the increment of the line search's current trial; the cone values
+// c_i = a_i . u + b_i are recomputed from the inputs wherever they are needed.  A lane whose line search has ended keeps
+// its increments while the other lanes of its wavefront try shorter steps (`live`).
+// =====================================================================================================================
+
+// stage cost of knot k at state x (full coordinates) -- the terms of lane_finish / knot_cost
+QL_FN double al_state_cost(const DevParams& P, const double refp[13], int k, const double* x) {
+  double xr[13];
+  xref_at(P, refp, k, xr);
+  double J = 0.0, dq = 0.0;
+#pragma unroll
+  for (int i = 0; i < 13; ++i) {
+    const double e = x[i] - xr[i];
+    J += 0.5 * P.Q[i] * e * e;
+    if (i >= 3 && i < 7) dq += xr[i] * x[i];
+  }
+  return J + P.w * (1.0 - fabs(dq));
+}
+// input cost and AL terms of one stance point: returns the input cost, adds (max(lam + rho c, 0)^2 - lam^2) to alsum
+QL_FN double al_point_terms(const DevParams& P, const double cr[18], int l, const double u[3], double uz, const double lam[6],
+                            double rho, double& alsum, double& viol) {
+  const double e2 = u[2] - uz;
+  const double Ju = 0.5 * P.R[(3 * l) % 12] * u[0] * u[0] + 0.5 * P.R[(3 * l + 1) % 12] * u[1] * u[1] +
+                    0.5 * P.R[(3 * l + 2) % 12] * e2 * e2;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double cv = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
+    if (i == 4) cv += -P.fz_max;
+    double z = lam[i] + rho * cv;
+    if (z < 0.0) z = 0.0;
+    alsum += z * z - lam[i] * lam[i];
+    viol = fmax(viol, fmax(cv, 0.0));
+  }
+  return Ju;
+}
+
+// ---- pass M: AL merit, plain objective and violation of the CURRENT trajectory; UPDATE: the dual update first
+// (lambda <- max(lambda + rho c, 0), then rho <- min(rho * scaling, max)) -------------------------------------------------
+template <int NL, bool UPDATE>
+QL_FN void pass_M(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, const LaneState& st, LaneAL& al) {
+  const int N = P.N;
+  double cr[18];
+  cone_rows(P, K.rot, cr);
+  const double rho_old = al.rho;
+  if (UPDATE) {
+    al.rho = fmin(al.rho * P.penalty_scaling, P.penalty_max);
+    al.irho = 1.0 / al.rho;
+  }
+  double Jp = 0.0, alsum = 0.0, viol = 0.0;
+  for (int k = 0; k <= N; ++k) {
+    double x[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) x[i] = c.W(O.X + 13 * k + i);
+    Jp += al_state_cost(P, K.refp, k, x);
+    if (k == N) break;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (!((st.con >> l) & 1u)) continue;
+      double u[3], lam[6];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) lam[i] = c.W(O.LAM + 6 * NL * k + 6 * l + i);
+      if (UPDATE) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          double cv = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
+          if (i == 4) cv += -P.fz_max;
+          const double z = lam[i] + rho_old * cv;
+          lam[i] = (z > 0.0) ? z : 0.0;
+          c.W(O.LAM + 6 * NL * k + 6 * l + i) = lam[i];
+        }
+      }
+      Jp += al_point_terms(P, cr, l, u, st.uz, lam, al.rho, alsum, viol);
+    }
+  }
+  al.Jp = Jp;
+  al.viol = viol;
+  al.J = Jp + alsum / (2.0 * al.rho);
+}
+
+// ---- pass A_AL: apply the accepted increment of the line search and roll the states out open loop ----------------------
+template <int NL>
+QL_FN void pass_A_AL(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, const LaneState& st) {
+  const int N = P.N;
+  const double gb[3] = {K.rot[6] * (-9.81), K.rot[7] * (-9.81), K.rot[8] * (-9.81)};
+  double x[13], xn[13];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) x[i] = c.W(O.X + i);
+  for (int k = 0; k < N; ++k) {
+    double F[3] = {0, 0, 0}, wd[3] = {K.wd0[0], K.wd0[1], K.wd0[2]};
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (!((st.con >> l) & 1u)) continue;
+      double u[3], B[9];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        u[a] = c.W(O.U + 3 * NL * k + 3 * l + a) + c.W(O.dU + 3 * NL * k + 3 * l + a);
+        c.W(O.U + 3 * NL * k + 3 * l + a) = u[a];
+      }
+      leg_bw0(P, &K.foot[3 * l], B);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        F[a] += u[a];
+        wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
+      }
+    }
+    srbd_step_fw(P, gb, x, F, wd, xn);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) { x[i] = xn[i]; c.W(O.X + 13 * (k + 1) + i) = xn[i]; }
+  }
+}
+
+// ---- pass C_AL: one trial of the line search -- closed-loop rollout at step length al.alpha, the trial's increments
+// (stored while `live`), its merit, violation and largest increment ---------------------------------------------------------
+template <int NL>
+QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, const LaneState& st, LaneAL& al, bool live) {
+  typedef LDim<NL> D;
+  const int N = P.N;
+  const double gb[3] = {K.rot[6] * (-9.81), K.rot[7] * (-9.81), K.rot[8] * (-9.81)};
+  double cr[18];
+  cone_rows(P, K.rot, cr);
+  const double alpha = al.alpha;
+  double xc[13], xn[13];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) xc[i] = c.W(O.X + i);
+  double Jp = 0.0, alsum = 0.0, viol = 0.0, stp = 0.0;
+  bool bad = false;
+  for (int k = 0; k < N; ++k) {
+    Jp += al_state_cost(P, K.refp, k, xc);
+    double xo[13], dx[12];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) xo[i] = c.W(O.X + 13 * k + i);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      dx[a] = xc[a] - xo[a];
+      dx[6 + a] = xc[7 + a] - xo[7 + a];
+      dx[9 + a] = xc[10 + a] - xo[10 + a];
+    }
+    {
+      double G[12];
+      quatG(&xo[3], G);
+      const double isc = ql_rcp(xo[3] * xc[3] + xo[4] * xc[4] + xo[5] * xc[5] + xo[6] * xc[6]);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) dx[3 + a] = (G[a] * xc[3] + G[3 + a] * xc[4] + G[6 + a] * xc[5] + G[9 + a] * xc[6]) * isc;
+    }
+    double zeta[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) zeta[i] = alpha * c.W(O.G + D::GAIN * k + 36 + i);
+#pragma unroll
+    for (int j = 0; j < 12; ++j)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float g0, g1;
+        unpack2f(c.W(O.G + D::GAIN * k + 3 * j + i), g0, g1);
+        zeta[2 * i] += (double)g0 * dx[j];
+        zeta[2 * i + 1] += (double)g1 * dx[j];
+      }
+    double F[3] = {0, 0, 0}, wd[3] = {K.wd0[0], K.wd0[1], K.wd0[2]};
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (!((st.con >> l) & 1u)) continue;
+      double u[3], lam[6], sv[6], lv[6], rcl[6], B[9];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        lam[i] = c.W(O.LAM + 6 * NL * k + 6 * l + i);
+        double cv = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
+        if (i == 4) cv += -P.fz_max;
+        const double z = lam[i] + al.rho * cv;
+        const bool act = z > 0.0;
+        sv[i] = 1.0;
+        rcl[i] = act ? z * al.irho : 0.0;
+        lv[i] = act ? al.rho : 0.0;
+      }
+      leg_bw0(P, &K.foot[3 * l], B);
+      LegBlk lb;
+      leg_block(P, cr, rcl, l, sv, lv, 0u, 1.0, 0.0, u, st.uz, lb);
+      // rhs = T'(zeta_f + Bw0' zeta_t) + alpha gq;  du = -T Db^-1 rhs
+      double t[3], rh[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) t[a] = zeta[a] + B[a] * zeta[3] + B[3 + a] * zeta[4] + B[6 + a] * zeta[5];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) rh[a] = lb.T[a] * t[0] + lb.T[3 + a] * t[1] + lb.T[6 + a] * t[2] + alpha * lb.gq[a];
+      const double y0 = rh[0], y1 = rh[1] - lb.l10 * y0, y2 = rh[2] - lb.l20 * y0 - lb.l21 * y1;
+      const double z2 = y2 * lb.id2;
+      const double z1 = y1 * lb.id1 - lb.l21 * z2;
+      const double z0 = y0 * lb.id0 - lb.l10 * z1 - lb.l20 * z2;
+      double un[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double du = -(lb.T[3 * a] * z0 + lb.T[3 * a + 1] * z1 + lb.T[3 * a + 2] * z2);
+        stp = fmax(stp, fabs(du));
+        bad = bad || !(fabs(du) <= 1e300);
+        un[a] = u[a] + du;
+        if (live) c.W(O.dU + 3 * NL * k + 3 * l + a) = du;
+      }
+      Jp += al_point_terms(P, cr, l, un, st.uz, lam, al.rho, alsum, viol);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        F[a] += un[a];
+        wd[a] += B[3 * a] * un[0] + B[3 * a + 1] * un[1] + B[3 * a + 2] * un[2];
+      }
+    }
+    srbd_step_fw(P, gb, xc, F, wd, xn);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) xc[i] = xn[i];
+  }
+  Jp += al_state_cost(P, K.refp, N, xc);
+  al.Jnp = Jp;
+  al.vn = viol;
+  al.stp = stp;
+  al.Jn = bad ? (double)NAN : Jp + alsum / (2.0 * al.rho);
+}
+
+// ---- pass S: |grad_U L_A|_inf at (X, U) through the costate recursion  y_k = lx_k + Abar_k' y_{k+1},
+//      gu_l = R (u_l - uref_l) + Wr_l' (M_k' y_{k+1}) + sum_i max(lam_i + rho c_i, 0) a_i   (ref_stationarity of qmpc_ref.hip)
+template <int NL>
+QL_FN void pass_S(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, const LaneState& st, LaneAL& al) {
+  const int N = P.N;
+  const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
+  double cr[18];
+  cone_rows(P, K.rot, cr);
+  double y[12];
+  {
+    double lxx[6];
+    cost_expansion<NL, MD_QUAT>(P, c, O, K, N, y, lxx);
+  }
+  double g = 0.0;
+  for (int k = N - 1; k >= 0; --k) {
+    // the knot's angular acceleration (for the expansion) and its points' inputs
+    double wd[3] = {K.wd0[0], K.wd0[1], K.wd0[2]};
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (!((st.con >> l) & 1u)) continue;
+      double u[3], B[9];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+      leg_bw0(P, &K.foot[3 * l], B);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
+    }
+    // dynamics expansion (pass B step 2)
+    double A1[9], A3[9], Wt[9];
+    {
+      double x[13], xn[4];
+#pragma unroll
+      for (int i = 3; i < 13; ++i) x[i] = c.W(O.X + 13 * k + i);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xn[i] = c.W(O.X + 13 * (k + 1) + 3 + i);
+      double G0[12], Gm[12], Gn[12];
+      quatG(&x[3], G0);
+      double qm[4], wm[3];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        qm[r] = x[3 + r] + P.hh * (0.5 * (G0[3 * r] * x[10] + G0[3 * r + 1] * x[11] + G0[3 * r + 2] * x[12]));
+#pragma unroll
+      for (int a = 0; a < 3; ++a) wm[a] = x[10 + a] + P.hh * wd[a];
+      quatG(qm, Gm);
+      quatG(xn, Gn);
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        double gg[4], gm[4], t0[4], t1[4], t2[4], ag[4], aw[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { gg[r] = G0[3 * r + cc]; gm[r] = Gm[3 * r + cc]; }
+        omega_mul(&x[10], gg, t0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t1[r] = gg[r] + (0.5 * P.hh) * t0[r];
+        omega_mul(wm, t1, t2);
+        omega_mul(wm, gg, t0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ag[r] = gg[r] + P.hh * t2[r];
+          aw[r] = P.hh * ((0.5 * P.hh) * t0[r] + gm[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          A1[3 * r + cc] = Gn[r] * ag[0] + Gn[3 + r] * ag[1] + Gn[6 + r] * ag[2] + Gn[9 + r] * ag[3];
+          A3[3 * r + cc] = Gn[r] * aw[0] + Gn[3 + r] * aw[1] + Gn[6 + r] * aw[2] + Gn[9 + r] * aw[3];
+          Wt[3 * r + cc] = ((0.5 * P.hh) * P.h) * (Gn[r] * gm[0] + Gn[3 + r] * gm[1] + Gn[6 + r] * gm[2] + Gn[9 + r] * gm[3]);
+        }
+      }
+    }
+    // m6 = M' y_{k+1}
+    double m6[6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      m6[a] = m1 * y[a] + m2 * y[6 + a];
+      m6[3 + a] = Wt[a] * y[3] + Wt[3 + a] * y[4] + Wt[6 + a] * y[5] + P.h * y[9 + a];
+    }
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (!((st.con >> l) & 1u)) continue;
+      double u[3], B[9];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+      leg_bw0(P, &K.foot[3 * l], B);
+      double gu[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+        gu[a] = P.R[(3 * l + a) % 12] * (u[a] - ((a == 2) ? st.uz : 0.0)) + m6[a] + (B[a] * m6[3] + B[3 + a] * m6[4] + B[6 + a] * m6[5]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        double cv = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
+        if (i == 4) cv += -P.fz_max;
+        const double z = c.W(O.LAM + 6 * NL * k + 6 * l + i) + al.rho * cv;
+        if (z > 0.0) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) gu[a] += z * cr[3 * i + a];
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) g = fmax(g, fabs(gu[a]));
+    }
+    // y_k = lx_k + Abar' y_{k+1}
+    {
+      double lx[12], lxx[6];
+      cost_expansion<NL, MD_QUAT>(P, c, O, K, k, lx, lxx);
+      const double f0 = y[3], f1 = y[4], f2 = y[5];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        y[9 + a] += A3[a] * f0 + A3[3 + a] * f1 + A3[6 + a] * f2;
+        y[6 + a] += P.h * y[a];
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) y[3 + a] = A1[a] * f0 + A1[3 + a] * f1 + A1[6 + a] * f2;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) y[i] += lx[i];
+    }
+  }
+  al.stat = g;
+}
+
+// set-up of the multipliers for the reference mode (after lane_setup): lambda = 0, slacks at 1
+template <int NL>
+QL_FN void lane_setup_ref(const DevParams& P, const Ctx& c, const WsOff& O, const LaneState& st, LaneAL& al) {
+  const int N = P.N;
+  for (int k = 0; k < N; ++k)
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+      if ((st.con >> l) & 1u)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          c.W(O.S + 6 * NL * k + 6 * l + i) = 1.0;
+          c.W(O.LAM + 6 * NL * k + 6 * l + i) = 0.0;
+        }
+  al.rho = P.penalty_initial;
+  al.irho = 1.0 / al.rho;
+  al.J = 0.0; al.Jp = 0.0; al.viol = 0.0; al.dV1 = 0.0; al.alpha = 1.0; al.Jn = 0.0; al.Jnp = 0.0; al.vn = 0.0; al.stp = 0.0;
+  al.stat = 0.0; al.searching = 0;
+}
+
+// ---- the whole reference-mode solve of one lane (host build: tests; the kernel runs the same steps in lock step,
+// qmpc_lane.hip) -------------------------------------------------------------------------------------------------------------
+template <int NL>
+QL_FN void lane_solve_ref(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st) {
+  LaneAL al;
+  lane_setup_ref<NL>(P, c, O, st, al);
+  st.it = 1;
+  pass_A<NL, false, MD_QUAT>(P, c, O, K, st, true, (FootPtr)K.foot);      // X <- rollout of U = u_ref
+  pass_M<NL, false>(P, c, O, K, st, al);
+  int iter = 0;
+  st.status = QMPC_MAX_ITER;
+  st.last_step = 0.0;
+  for (iter = 1; iter <= P.iterations_max; ++iter) {
+    if (!pass_B<NL, false, MD_QUAT, true>(P, c, O, K, st, (FootPtr)K.foot, &al)) { st.status = QMPC_NOT_PD; --iter; break; }
+    al.alpha = 1.0;
+    bool accepted = false;
+    for (int ls = 0; ls <= P.linesearch_max; ++ls) {
+      pass_C_AL<NL>(P, c, O, K, st, al, true);
+      const double expected = al.alpha * al.dV1;
+      const double slack = 1e-12 * fmax(1.0, fabs(al.J));
+      if (isfinite(al.Jn) && al.Jn - al.J <= 1e-4 * expected + slack) { accepted = true; break; }
+      al.alpha *= 0.5;
+    }
+    if (!accepted) { st.status = QMPC_LINESEARCH_FAIL; --iter; break; }
+    pass_A_AL<NL>(P, c, O, K, st);
+    st.last_step = al.stp;
+    const double dJ = al.J - al.Jn;
+    al.J = al.Jn; al.Jp = al.Jnp; al.viol = al.vn;
+    pass_S<NL>(P, c, O, K, st, al);
+    if (al.stat < P.tol_stat && al.viol < P.tol_feas) { st.status = QMPC_OK; break; }
+    if (al.stat < P.tol_stat || fabs(dJ) < P.tol_cost_int) pass_M<NL, true>(P, c, O, K, st, al);
+  }
+  if (iter > P.iterations_max) iter = P.iterations_max;
+  st.iters = iter;
+  st.mu = al.rho;           // the info record's last field is the penalty in this mode
 }
 
 // ---- outputs: GetInput(u, 0) (QuatMpc.cpp:264-265) and the info record -----------------------------------------------
