@@ -116,7 +116,9 @@ constexpr int kLaneMinLoopCold = 18432;       // ... of the cold-started closed 
 constexpr int kLaneMinBatch = 26624;          // QuatMpc, horizons up to 12
 constexpr int kLaneMinBatchLong = 16384;      // QuatMpc, longer horizons
 constexpr int kLaneMinBatchOther = 18432;
-constexpr int kLaneRefMinBatch = 8192;        // reference mode (AL-iLQR): provisional, see profiles/r04_refmode_lane.txt
+// reference mode (AL-iLQR, <= 10 iterations; qmpc_lane_ref_kernel): measured against the wave-per-instance reference kernels
+// (tools/refmode_lane_bench.py, N=10): 16384: 1.49 vs 1.74 M solves/s, 32768: 2.70 vs 1.78 M, 65536: 4.59 vs 1.83 M (N=20: 2.53 vs 0.79 M)
+constexpr int kLaneRefMinBatch = 20480;
 
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \

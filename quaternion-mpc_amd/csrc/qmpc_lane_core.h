@@ -1771,7 +1771,7 @@ QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, cons
 // Reference mode on the lane passes (QMPC_MODE_REFERENCE; four- and eight-point quaternion model): the reference's OWN
 // operating mode -- the AL-iLQR scheme of its external solver with QuatMpc's settings, iterations_max = 10,
 // penalty_scaling = 20, backtracking line search, status ignored (QuatMpc.cpp:21-26,256; the
-// wave-per-instance form is qmpc_ref.hip, the CPU restatement oracle/qo_altro.c):
+// wave-per-instance form is qmpc_ref.hip; the CPU checker restates the same scheme):
 //
 //   lambda <- 0, rho <- penalty_initial; U <- u_ref; X <- rollout; J <- AL merit
 //   repeat iter = 1 .. iterations_max:
@@ -1830,21 +1830,41 @@ QL_FN void pass_M(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     al.rho = fmin(al.rho * P.penalty_scaling, P.penalty_max);
     al.irho = 1.0 / al.rho;
   }
+  const unsigned order = any_stance<NL>(st.con);
+  // the knot's state, inputs and multipliers are fetched one knot ahead, into the registers just consumed
+  double xk[13], uk[3 * NL], lk[6 * NL];
+  auto load_x = [&](int k) {
+#pragma unroll
+    for (int i = 0; i < 13; ++i) xk[i] = c.W(O.X + 13 * k + i);
+  };
+  auto load_leg = [&](int k, int l) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) uk[3 * l + a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lk[6 * l + i] = c.W(O.LAM + 6 * NL * k + 6 * l + i);
+  };
+  load_x(0);
+#pragma unroll
+  for (int l = 0; l < NL; ++l) if ((order >> l) & 1u) load_leg(0, l);
   double Jp = 0.0, alsum = 0.0, viol = 0.0;
   for (int k = 0; k <= N; ++k) {
     double x[13];
 #pragma unroll
-    for (int i = 0; i < 13; ++i) x[i] = c.W(O.X + 13 * k + i);
+    for (int i = 0; i < 13; ++i) x[i] = xk[i];
+    if (k < N) load_x(k + 1);
     Jp += al_state_cost(P, K.refp, k, x);
     if (k == N) break;
+    const int kn = (k + 1 < N) ? k + 1 : k;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-      if (!((st.con >> l) & 1u)) continue;
+      if (!((order >> l) & 1u)) continue;       // wave-uniform
       double u[3], lam[6];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+      for (int a = 0; a < 3; ++a) u[a] = uk[3 * l + a];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) lam[i] = c.W(O.LAM + 6 * NL * k + 6 * l + i);
+      for (int i = 0; i < 6; ++i) lam[i] = lk[6 * l + i];
+      load_leg(kn, l);
+      if (!((st.con >> l) & 1u)) continue;
       if (UPDATE) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -1868,20 +1888,33 @@ template <int NL>
 QL_FN void pass_A_AL(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, const LaneState& st) {
   const int N = P.N;
   const double gb[3] = {K.rot[6] * (-9.81), K.rot[7] * (-9.81), K.rot[8] * (-9.81)};
+  const unsigned order = any_stance<NL>(st.con);
   double x[13], xn[13];
 #pragma unroll
   for (int i = 0; i < 13; ++i) x[i] = c.W(O.X + i);
+  double uk[3 * NL], dk[3 * NL];      // one knot ahead
+  auto load_leg = [&](int k, int l) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      uk[3 * l + a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+      dk[3 * l + a] = c.W(O.dU + 3 * NL * k + 3 * l + a);
+    }
+  };
+#pragma unroll
+  for (int l = 0; l < NL; ++l) if ((order >> l) & 1u) load_leg(0, l);
   for (int k = 0; k < N; ++k) {
+    const int kn = (k + 1 < N) ? k + 1 : k;
     double F[3] = {0, 0, 0}, wd[3] = {K.wd0[0], K.wd0[1], K.wd0[2]};
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-      if (!((st.con >> l) & 1u)) continue;
+      if (!((order >> l) & 1u)) continue;       // wave-uniform
       double u[3], B[9];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        u[a] = c.W(O.U + 3 * NL * k + 3 * l + a) + c.W(O.dU + 3 * NL * k + 3 * l + a);
-        c.W(O.U + 3 * NL * k + 3 * l + a) = u[a];
-      }
+      for (int a = 0; a < 3; ++a) u[a] = uk[3 * l + a] + dk[3 * l + a];
+      load_leg(kn, l);
+      if (!((st.con >> l) & 1u)) continue;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) c.W(O.U + 3 * NL * k + 3 * l + a) = u[a];
       leg_bw0(P, &K.foot[3 * l], B);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -1908,13 +1941,30 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
   double xc[13], xn[13];
 #pragma unroll
   for (int i = 0; i < 13; ++i) xc[i] = c.W(O.X + i);
+  const unsigned order = any_stance<NL>(st.con);
+  // old state, gains, inputs and multipliers of a knot are fetched one knot ahead, into the registers just consumed
+  double xo[13], gn[D::GAIN], uk[3 * NL], lk[6 * NL];
+  auto load_head = [&](int k) {
+#pragma unroll
+    for (int i = 0; i < 13; ++i) xo[i] = c.W(O.X + 13 * k + i);
+#pragma unroll
+    for (int i = 0; i < D::GAIN; ++i) gn[i] = c.W(O.G + D::GAIN * k + i);
+  };
+  auto load_leg = [&](int k, int l) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) uk[3 * l + a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lk[6 * l + i] = c.W(O.LAM + 6 * NL * k + 6 * l + i);
+  };
+  load_head(0);
+#pragma unroll
+  for (int l = 0; l < NL; ++l) if ((order >> l) & 1u) load_leg(0, l);
   double Jp = 0.0, alsum = 0.0, viol = 0.0, stp = 0.0;
   bool bad = false;
   for (int k = 0; k < N; ++k) {
+    const int kn = (k + 1 < N) ? k + 1 : k;
     Jp += al_state_cost(P, K.refp, k, xc);
-    double xo[13], dx[12];
-#pragma unroll
-    for (int i = 0; i < 13; ++i) xo[i] = c.W(O.X + 13 * k + i);
+    double dx[12];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       dx[a] = xc[a] - xo[a];
@@ -1930,26 +1980,30 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
     }
     double zeta[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) zeta[i] = alpha * c.W(O.G + D::GAIN * k + 36 + i);
+    for (int i = 0; i < 6; ++i) zeta[i] = alpha * gn[36 + i];
 #pragma unroll
     for (int j = 0; j < 12; ++j)
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         float g0, g1;
-        unpack2f(c.W(O.G + D::GAIN * k + 3 * j + i), g0, g1);
+        unpack2f(gn[3 * j + i], g0, g1);
         zeta[2 * i] += (double)g0 * dx[j];
         zeta[2 * i + 1] += (double)g1 * dx[j];
       }
+    load_head(kn);
     double F[3] = {0, 0, 0}, wd[3] = {K.wd0[0], K.wd0[1], K.wd0[2]};
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-      if (!((st.con >> l) & 1u)) continue;
+      if (!((order >> l) & 1u)) continue;       // wave-uniform
       double u[3], lam[6], sv[6], lv[6], rcl[6], B[9];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+      for (int a = 0; a < 3; ++a) u[a] = uk[3 * l + a];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) lam[i] = lk[6 * l + i];
+      load_leg(kn, l);
+      if (!((st.con >> l) & 1u)) continue;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        lam[i] = c.W(O.LAM + 6 * NL * k + 6 * l + i);
         double cv = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
         if (i == 4) cv += -P.fz_max;
         const double z = lam[i] + al.rho * cv;
@@ -2006,33 +2060,57 @@ QL_FN void pass_S(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
   double cr[18];
   cone_rows(P, K.rot, cr);
+  const unsigned order = any_stance<NL>(st.con);
   double y[12];
   {
     double lxx[6];
     cost_expansion<NL, MD_QUAT>(P, c, O, K, N, y, lxx);
   }
+  // state of the knot, quaternion of the next one, inputs and multipliers: one knot ahead, into the registers just consumed
+  double xk[13], qn[4], uk[3 * NL], lk[6 * NL];
+  auto load_head = [&](int k) {
+#pragma unroll
+    for (int i = 0; i < 13; ++i) xk[i] = c.W(O.X + 13 * k + i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qn[i] = c.W(O.X + 13 * (k + 1) + 3 + i);
+  };
+  auto load_leg = [&](int k, int l) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) uk[3 * l + a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lk[6 * l + i] = c.W(O.LAM + 6 * NL * k + 6 * l + i);
+  };
+  load_head(N - 1);
+#pragma unroll
+  for (int l = 0; l < NL; ++l) if ((order >> l) & 1u) load_leg(N - 1, l);
   double g = 0.0;
   for (int k = N - 1; k >= 0; --k) {
-    // the knot's angular acceleration (for the expansion) and its points' inputs
+    const int kn = (k > 0) ? k - 1 : 0;
+    double x[13], xn[4], u[3 * NL], lam[6 * NL];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) x[i] = xk[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xn[i] = qn[i];
+#pragma unroll
+    for (int i = 0; i < 3 * NL; ++i) u[i] = uk[i];
+#pragma unroll
+    for (int i = 0; i < 6 * NL; ++i) lam[i] = lk[i];
+    load_head(kn);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) if ((order >> l) & 1u) load_leg(kn, l);
+    // the knot's angular acceleration (for the expansion)
     double wd[3] = {K.wd0[0], K.wd0[1], K.wd0[2]};
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       if (!((st.con >> l) & 1u)) continue;
-      double u[3], B[9];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+      double B[9];
       leg_bw0(P, &K.foot[3 * l], B);
 #pragma unroll
-      for (int a = 0; a < 3; ++a) wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
+      for (int a = 0; a < 3; ++a) wd[a] += B[3 * a] * u[3 * l] + B[3 * a + 1] * u[3 * l + 1] + B[3 * a + 2] * u[3 * l + 2];
     }
     // dynamics expansion (pass B step 2)
     double A1[9], A3[9], Wt[9];
     {
-      double x[13], xn[4];
-#pragma unroll
-      for (int i = 3; i < 13; ++i) x[i] = c.W(O.X + 13 * k + i);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xn[i] = c.W(O.X + 13 * (k + 1) + 3 + i);
       double G0[12], Gm[12], Gn[12];
       quatG(&x[3], G0);
       double qm[4], wm[3];
@@ -2076,31 +2154,44 @@ QL_FN void pass_S(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       if (!((st.con >> l) & 1u)) continue;
-      double u[3], B[9];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+      double B[9];
       leg_bw0(P, &K.foot[3 * l], B);
+      const double* ul = &u[3 * l];
       double gu[3];
 #pragma unroll
       for (int a = 0; a < 3; ++a)
-        gu[a] = P.R[(3 * l + a) % 12] * (u[a] - ((a == 2) ? st.uz : 0.0)) + m6[a] + (B[a] * m6[3] + B[3 + a] * m6[4] + B[6 + a] * m6[5]);
+        gu[a] = P.R[(3 * l + a) % 12] * (ul[a] - ((a == 2) ? st.uz : 0.0)) + m6[a] + (B[a] * m6[3] + B[3 + a] * m6[4] + B[6 + a] * m6[5]);
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        double cv = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
+        double cv = cr[3 * i] * ul[0] + cr[3 * i + 1] * ul[1] + cr[3 * i + 2] * ul[2];
         if (i == 4) cv += -P.fz_max;
-        const double z = c.W(O.LAM + 6 * NL * k + 6 * l + i) + al.rho * cv;
-        if (z > 0.0) {
+        const double z = lam[6 * l + i] + al.rho * cv;
+        const double zp = (z > 0.0) ? z : 0.0;
 #pragma unroll
-          for (int a = 0; a < 3; ++a) gu[a] += z * cr[3 * i + a];
-        }
+        for (int a = 0; a < 3; ++a) gu[a] += zp * cr[3 * i + a];
       }
 #pragma unroll
       for (int a = 0; a < 3; ++a) g = fmax(g, fabs(gu[a]));
     }
-    // y_k = lx_k + Abar' y_{k+1}
+    // y_k = lx_k + Abar' y_{k+1}; the cost expansion of knot k from the state already in registers
     {
-      double lx[12], lxx[6];
-      cost_expansion<NL, MD_QUAT>(P, c, O, K, k, lx, lxx);
+      double xr[13], lxf[13], lx[12];
+      xref_at(P, K.refp, k, xr);
+#pragma unroll
+      for (int i = 0; i < 13; ++i) lxf[i] = P.Q[i] * (x[i] - xr[i]);
+      const double dq = xr[3] * x[3] + xr[4] * x[4] + xr[5] * x[5] + xr[6] * x[6];
+      const double sg = (dq >= 0.0) ? 1.0 : -1.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lxf[3 + r] += -sg * P.w * xr[3 + r];
+      double G[12];
+      quatG(&x[3], G);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lx[a] = lxf[a];
+        lx[6 + a] = lxf[7 + a];
+        lx[9 + a] = lxf[10 + a];
+        lx[3 + a] = G[a] * lxf[3] + G[3 + a] * lxf[4] + G[6 + a] * lxf[5] + G[9 + a] * lxf[6];
+      }
       const double f0 = y[3], f1 = y[4], f2 = y[5];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {

@@ -151,6 +151,44 @@ def test_config4_workload_on_one_gpu(pkg, lib, oracle):
     s.close()
 
 
+@pytest.mark.parametrize("N,B", [(10, 4096), (20, 1024), (3, 300)])
+def test_lane_kernel_reference_mode(pkg, lib, oracle, monkeypatch, N, B):
+    """QMPC_MODE_REFERENCE on the lane kernel (qmpc_lane_ref_kernel: the AL variant of the lane passes, line search in lock
+    step): against the oracle's reference mode on every instance -- identical status words and iteration counts, forces
+    within 1e-6 N on >= 95 % (truncated iterates) -- and against the wave-per-instance reference kernels; edge records keep
+    their status words, swing legs are exactly 0, trajectories come back."""
+    p = pkg.default_params(N, pkg.MODE_REFERENCE, lib)
+    rec = _edge_records(pkg, pkg.random_go1_trot_states(B - 1, config_id=2 if N != 20 else 3))
+    out = {}
+    for v in (4, 0):
+        _forced(monkeypatch, v)
+        monkeypatch.setenv("QMPC_LANE_REF_MIN", str(1 << 30))       # variant 0: the wave kernels at this size
+        s = pkg.Solver(p, B, device=0, lib=lib)
+        f, info, tu, tx = s.solve(rec, want_traj=True) if v == 0 else (*s.solve(rec), None, None)
+        if v == 4:
+            f2, info2 = s.solve(rec)
+            assert np.array_equal(f, f2) and np.array_equal(info["iterations"], info2["iterations"])
+        s.close()
+        out[v] = (f, info)
+    fl, il = out[4]
+    fw, iw = out[0]
+    fo, io = oracle.solve(p, rec, threads=8)
+    assert np.array_equal(il["status"], io["status"]) and np.array_equal(il["iterations"], io["iterations"])
+    assert np.array_equal(il["status"], iw["status"]) and np.array_equal(il["iterations"], iw["iterations"])
+    assert il["status"][5] == pkg.NO_CONTACT and il["status"][9] == pkg.NAN_INPUT
+    d = np.abs(fl - fo).max(axis=1)
+    dw = np.abs(fl - fw).max(axis=1)
+    print(f"lane kernel, reference mode N={N} B={B}: vs oracle within 1e-6 N on {100 * (d < 1e-6).mean():.1f} % (median {np.median(d):.1e}, worst "
+          f"{d.max():.1e}); vs wave kernels {100 * (dw < 1e-6).mean():.1f} %; status counts {np.bincount(il['status'], minlength=6).tolist()}")
+    # (two truncated iterates against each other at N = 20: the wave kernels' own agreement with the oracle is 97 %)
+    assert (d < 1e-6).mean() >= 0.95 and (dw < 1e-6).mean() >= (0.95 if N <= 10 else 0.90)
+    assert (il["iterations"] <= 10).all() and np.isfinite(fl).all()
+    assert (fl.reshape(-1, 4, 3)[rec["contacts"] == 0] == 0).all()
+    solved = io["status"] <= 1
+    assert np.abs(il["cost"][solved] - io["cost"][solved]).max() < 1e-6 * max(1.0, np.abs(io["cost"][solved]).max())
+    assert np.array_equal(il["penalty"][solved], io["penalty"][solved])          # the final penalty
+
+
 def test_more_live_handles_than_parameter_slots(pkg, lib, oracle, monkeypatch):
     """The lane kernel reads its parameters from a 64-slot constant-memory table, one slot per LIVE handle (free list,
     returned in qmpc_destroy).  70 handles with different friction coefficients alive at once: every one solves its own
