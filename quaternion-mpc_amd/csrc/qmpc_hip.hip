@@ -119,6 +119,7 @@ constexpr int kLaneMinBatchOther = 18432;
 // reference mode (AL-iLQR, <= 10 iterations; qmpc_lane_ref_kernel): measured against the wave-per-instance reference kernels
 // (tools/refmode_lane_bench.py, N=10): 16384: 1.49 vs 1.74 M solves/s, 32768: 2.70 vs 1.78 M, 65536: 4.59 vs 1.83 M (N=20: 2.53 vs 0.79 M)
 constexpr int kLaneRefMinBatch = 20480;
+constexpr int kLaneRefMinBatchLong = 16384;   // horizons beyond 12 (N=20: 16384: 0.81 vs 0.76 M, 32768: 1.47 vs 0.78 M)
 
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
@@ -353,7 +354,7 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     // result of an instance depends neither on timing nor on the batch it is part of.  Measured (caps 14 .. 20 scanned):
     // B=32768 N=10 4.14 -> 5.2 M solves/s, B=65536 N=10 6.8 -> 8.3 M, B=65536 N=20 3.25 -> 3.83 M, B=262144 N=10 9.1 -> 9.8 M.
     const char* lrm = std::getenv("QMPC_LANE_REF_MIN");
-    h->lane_ref_min = lrm ? std::atoi(lrm) : kLaneRefMinBatch;
+    h->lane_ref_min = lrm ? std::atoi(lrm) : (N <= 12 ? kLaneRefMinBatch : kLaneRefMinBatchLong);
     const char* lc = std::getenv("QMPC_LANE_CAP");
     h->lane_cap = lc ? std::atoi(lc) : 15 + N / 10;
     const char* ls = std::getenv("QMPC_LANE_SORT");
