@@ -255,6 +255,16 @@ def test_straggler_hand_off_of_large_batches(pkg, lib, oracle, monkeypatch, N, B
               f"forces within {err:.2e} N of the pure lane kernel")
         assert same > 0.999 and err < 1e-7
     assert ip["status"][5] == pkg.NO_CONTACT and ip["status"][9] == pkg.NAN_INPUT
+    # trajectory outputs across the hand-off: handed-over instances get theirs from the wave kernel
+    for k in ("QMPC_LANE_CAP", "QMPC_HANDOFF_RESTART"):
+        monkeypatch.delenv(k, raising=False)
+    s = pkg.Solver(p, B, device=0, lib=lib)
+    ft, it_, tu, tx = s.solve(rec, want_traj=True)
+    s.close()
+    assert np.array_equal(ft, out["auto"][0]) and np.array_equal(tu[:, 0, :], ft)
+    hs = np.where(ip["iterations"] > cap)[0][:64]
+    x0 = tx[hs, 0, :]
+    assert np.abs(x0[:, 3:7] - rec["quat"][hs]).max() == 0.0 and np.isfinite(tx).all() and np.isfinite(tu).all()
     f, info = out["auto"]
     slow = np.argsort(-ip["iterations"])[:96]                     # the handed-over ones ...
     idx = np.unique(np.concatenate([slow, np.arange(0, B, B // 96)]))     # ... and a spread sample
