@@ -852,7 +852,7 @@ __device__ inline double expected_decrease_w(const DevParams& P, const Layout& L
 // Returns nonzero (wave-uniform) when an increment is not finite: the trial step is then NOT applied (QMPC_NOT_PD, the
 // rule of the lane kernel) -- the step-length reductions that follow drop NaNs silently.
 __device__ inline int recover_inputs_w(const DevParams& P, const Layout& L, double* sm, const double* ROT, int lane,
-                                       double alpha = 1.0) {
+                                       double alpha = 1.0, const double* zsrc = nullptr) {
   typedef Dim<4> D;
   const int N = P.N;
   const double* cst = sm + L.cst;
@@ -866,7 +866,7 @@ __device__ inline int recover_inputs_w(const DevParams& P, const Layout& L, doub
 #pragma unroll
       for (int i = 0; i < 9; ++i) T[i] = rec[i];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) z[i] = ROT[zeta_slot(k, i)];
+      for (int i = 0; i < 6; ++i) z[i] = zsrc ? zsrc[6 * k + i] : ROT[zeta_slot(k, i)];
       const double l10 = rec[9], l20 = rec[10], l21 = rec[11], id0 = rec[12], id1 = rec[13], id2 = rec[14];
       const double* bw = sm + L.bw0 + 3 * l;
       double f[3];
@@ -888,6 +888,206 @@ __device__ inline int recover_inputs_w(const DevParams& P, const Layout& L, doub
   }
   QSYNC();
   return __any(bad ? 1 : 0);
+}
+
+// ---- reference mode: FOUR trial step lengths of the backtracking line search per rollout ------------------------------
+// The closed-loop rollout of one trial keeps 12 of the 64 lanes busy (the rows of the wrench-space gains) and every lane
+// advances the same state.  The trials of one line search are independent of each other, so each 16-lane row of the
+// wavefront rolls its own step length alpha_g = alpha 2^-g out: rows 0..5 of a group own [Xw | xw], rows 6..11 [Xz | xz],
+// the knot's six wrench components are broadcast inside the row (DPP row_newbcast), the state cost of the group's
+// trajectory is summed on the way.  What a group leaves behind is its costates zeta (ZG, for the inputs) and its states:
+// group 0 in Xc itself, groups 1..3 in the S, DLAM and XT slots -- the reference mode uses neither S nor DLAM, and the cost
+// expansions in XT are dead between the backward pass and the expansions at the accepted point.
+// Returns the state cost sum_k l_k(x_k) of the lane's group.
+__device__ __forceinline__ int trial_states_slot(const Layout& L, int g) {      // knots 1..N of group g's trajectory
+  return g == 0 ? L.Xc + 13 : (g == 1 ? L.S : (g == 2 ? L.DLAM : L.XT));
+}
+__device__ inline double rollout_trials_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm,
+                                          const double* KD, double* ZG, double alpha_g, int lane) {
+  typedef Dim<4> D;
+  const int N = P.N;
+  const double* cst = sm + L.cst;
+  double gb[3], wd0[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { gb[a] = cst[D::C_GB + a]; wd0[a] = cst[D::C_WD0 + a]; }
+  const int r = lane & 15, g = lane >> 4;
+  const int row = (r < 12) ? r : 0, wi = (r < 6) ? r : 0;
+  double* zg = ZG + 6 * N * g;
+  double* xg = sm + trial_states_slot(L, g);
+  double xc[13], xn[13];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) xc[i] = cst[D::C_X0 + i];
+  if (lane == 15)
+#pragma unroll
+    for (int i = 0; i < 13; ++i) sm[L.Xc + i] = xc[i];
+  double Jx = QuatModel::knot_cost(P, sm + L.refp, sm + L.uref, 0, xc, nullptr);
+  for (int k = 0; k < N; ++k) {
+    RollLoadsW cur;
+    roll_load_w(L, LW, sm, KD, k, row, wi, cur);
+    double dx[12], e[12];
+    QuatModel::state_diff(cur.xo, xc, dx);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      e[a] = dx[a] + P.h * dx[6 + a];
+      e[3 + a] = (cur.ab[3 * a] * dx[3] + cur.ab[3 * a + 1] * dx[4] + cur.ab[3 * a + 2] * dx[5]) +
+                 (cur.ab[9 + 3 * a] * dx[9] + cur.ab[9 + 3 * a + 1] * dx[10] + cur.ab[9 + 3 * a + 2] * dx[11]);
+      e[6 + a] = dx[6 + a];
+      e[9 + a] = dx[9 + a];
+    }
+    const double* kd = cur.kd;
+    const double p0 = alpha_g * kd[12] + kd[0] * e[0] + kd[1] * e[1] + kd[2] * e[2];
+    const double p1 = kd[3] * e[3] + kd[4] * e[4] + kd[5] * e[5];
+    const double p2 = kd[6] * e[6] + kd[7] * e[7] + kd[8] * e[8];
+    const double p3 = kd[9] * e[9] + kd[10] * e[10] + kd[11] * e[11];
+    const double s = (p0 + p1) + (p2 + p3);
+    const double wn = cur.wk + s;
+    if (r >= 6 && r < 12) zg[6 * k + r - 6] = s;
+    double w[6];
+    w[0] = dpp_mov<0x150>(wn); w[1] = dpp_mov<0x151>(wn); w[2] = dpp_mov<0x152>(wn);      // row_newbcast:0..5
+    w[3] = dpp_mov<0x153>(wn); w[4] = dpp_mov<0x154>(wn); w[5] = dpp_mov<0x155>(wn);
+    srbd_step_w(P, gb, wd0, xc, w, xn);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) xc[i] = xn[i];
+    if (r == 15)
+#pragma unroll
+      for (int i = 0; i < 13; ++i) xg[13 * k + i] = xn[i];
+    Jx += QuatModel::knot_cost(P, sm + L.refp, sm + L.uref, k + 1, xc, nullptr);
+  }
+  QSYNC();
+  return Jx;
+}
+
+// the inputs' share of the four trials' merit, one lane per (knot, contact point): du_l(alpha_g) as in recover_inputs_w from
+// the group's costates, u = U + du, then the input cost, the augmented-Lagrangian terms max(lambda + rho c, 0)^2 - lambda^2
+// and the violation max(c, 0) of the point's cone rows (the arithmetic of ref_merit in qmpc_ref.hip).  Per-lane partial sums:
+// Ju = input cost, mer = Ju + (augmented-Lagrangian terms) / (2 rho), vi = violation.
+__device__ inline void trial_inputs_w(const DevParams& P, const Layout& L, const double* sm, const double* sl,
+                                      const double* ROT, const double* ZG, double alpha, double rho, int lane,
+                                      double Ju[4], double mer[4], double vi[4]) {
+  typedef Dim<4> D;
+  const int N = P.N;
+  const double* cst = sm + L.cst;
+  const double* cr = cst + D::C_CR;
+  double al[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { Ju[g] = 0.0; al[g] = 0.0; vi[g] = 0.0; }
+  for (int q = lane; q < 4 * N; q += kWave) {
+    const int k = q >> 2, l = q & 3;
+    const bool stance = cst[D::C_CON + l] != 0.0;
+    const double* rec = ROT + D::ROT * k + 21 * l;
+    const double* bw = sm + L.bw0 + 3 * l;
+    double u0[3], ur[3], Rw[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      u0[a] = sm[L.U + D::NU * k + 3 * l + a];
+      ur[a] = sm[L.uref + 3 * l + a];
+      Rw[a] = P.R[3 * l + a];
+    }
+    double T[9], lam[6];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) T[i] = stance ? rec[i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lam[i] = sl[L.LAM + D::NC * k + 6 * l + i];
+    const double l10 = rec[9], l20 = rec[10], l21 = rec[11], id0 = rec[12], id1 = rec[13], id2 = rec[14];
+    const double fzc = -P.fz_max * cst[D::C_CON + l];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const double ag = alpha * (g == 0 ? 1.0 : (g == 1 ? 0.5 : (g == 2 ? 0.25 : 0.125)));
+      double u[3] = {u0[0], u0[1], u0[2]};
+      if (stance) {
+        const double* z = ZG + 6 * N * g + 6 * k;
+        double f[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) f[b] = z[b] + (bw[b] * z[3] + bw[D::NU + b] * z[4] + bw[2 * D::NU + b] * z[5]);
+        double t[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) t[b] = ag * rec[15 + b] + (T[b] * f[0] + T[3 + b] * f[1] + T[6 + b] * f[2]);
+        const double y0 = t[0], y1 = t[1] - l10 * y0, y2 = t[2] - l20 * y0 - l21 * y1;
+        const double x2 = id2 * y2;
+        const double x1 = id1 * y1 - l21 * x2;
+        const double x0 = id0 * y0 - l10 * x1 - l20 * x2;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) u[a] = u0[a] + (-(T[3 * a] * x0 + T[3 * a + 1] * x1 + T[3 * a + 2] * x2));
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { const double e = u[a] - ur[a]; Ju[g] += 0.5 * Rw[a] * e * e; }
+      if (stance) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          double c = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
+          if (i == 4) c += fzc;
+          double zz = lam[i] + rho * c;
+          if (zz < 0.0) zz = 0.0;
+          al[g] += zz * zz - lam[i] * lam[i];
+          vi[g] = fmax(vi[g], fmax(c, 0.0));
+        }
+      }
+    }
+  }
+  const double i2r = 1.0 / (2.0 * rho);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) mer[g] = Ju[g] + al[g] * i2r;
+}
+
+// ---- reference mode: |grad_U L_A|_inf at (X, U) (ref_stationarity of qmpc_ref.hip) through the block structure of the
+// transition.  The costate y_k = lx_k + Abar_k' y_{k+1} is carried in registers by every lane (no exchange inside the
+// sweep); Bbar_k' y_{k+1} = Wr' (M_k' y_{k+1}) leaves a 6-vector per knot (mf = force part, mt = torque part) in `my`, and the
+// gradient rows are then formed one lane per (knot, input):
+//   gu = R (u - u_ref) + c_l mf_a + Bw0_l(:, a)' mt + sum_i max(lambda_i + rho c_i, 0) a_i.
+__device__ inline double stationarity_w(const DevParams& P, const Layout& L, double* sm, const double* sl, double* my,
+                                        double rho, unsigned conmask, int lane) {
+  typedef Dim<4> D;
+  const int N = P.N;
+  const double* cst = sm + L.cst;
+  const double* cr = cst + D::C_CR;
+  double y[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) y[i] = sm[L.XT + kXT * N + 9 + i];
+  const double cpf = P.h * (P.hh * P.inv_mass), cvf = P.h * P.inv_mass;
+  for (int k = N - 1; k >= 0; --k) {
+    const double* AB = sm + L.AB + kAB * k;
+    const double* lx = sm + L.XT + kXT * k + 9;
+    double m6[6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      m6[a] = cpf * y[a] + cvf * y[6 + a];
+      m6[3 + a] = P.h * ((0.5 * P.hh) * (AB[18 + a] * y[3] + AB[21 + a] * y[4] + AB[24 + a] * y[5]) + y[9 + a]);
+    }
+    if (lane < 6) {
+      double v = m6[0];
+#pragma unroll
+      for (int i = 1; i < 6; ++i) v = (lane == i) ? m6[i] : v;
+      my[6 * k + lane] = v;
+    }
+    double yn[12];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      yn[a] = lx[a] + y[a];
+      yn[3 + a] = lx[3 + a] + (AB[a] * y[3] + AB[3 + a] * y[4] + AB[6 + a] * y[5]);
+      yn[6 + a] = lx[6 + a] + (P.h * y[a] + y[6 + a]);
+      yn[9 + a] = lx[9 + a] + ((AB[9 + a] * y[3] + AB[12 + a] * y[4] + AB[15 + a] * y[5]) + y[9 + a]);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) y[i] = yn[i];
+  }
+  QSYNC();
+  double g = 0.0;
+  for (int q = lane; q < N * D::NU; q += kWave) {
+    const int k = q / D::NU, j = q - D::NU * k, l = j / 3, a = j - 3 * l;
+    if (!(conmask & (1u << l))) continue;
+    const double* m = my + 6 * k;
+    const double* bw = sm + L.bw0 + j;
+    double gu = P.R[j] * (sm[L.U + q] - sm[L.uref + j]) + cst[D::C_CON + l] * m[a] +
+                (bw[0] * m[3] + bw[D::NU] * m[4] + bw[2 * D::NU] * m[5]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int idx = D::NC * k + 6 * l + i;
+      const double z = sl[L.LAM + idx] + rho * sl[L.RC + idx];
+      gu += (z > 0.0) ? z * cr[3 * i + a] : 0.0;
+    }
+    g = fmax(g, fabs(gu));
+  }
+  return wave_max(g);
 }
 
 
