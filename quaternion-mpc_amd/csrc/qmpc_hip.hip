@@ -118,7 +118,7 @@ constexpr int kLaneMinBatchLong = 16384;      // QuatMpc, longer horizons
 constexpr int kLaneMinBatchOther = 18432;
 // reference mode (AL-iLQR, <= 10 iterations; qmpc_lane_ref_kernel): measured against the wave-per-instance reference kernels
 // (tools/refmode_lane_bench.py, N=10): 16384: 1.49 vs 1.74 M solves/s, 32768: 2.70 vs 1.78 M, 65536: 4.59 vs 1.83 M (N=20: 2.53 vs 0.79 M)
-constexpr int kLaneRefMinBatch = 20480;
+constexpr int kLaneRefMinBatch = 36864;      // N <= 12: the wave kernels try four step lengths per rollout (32768: 3.17 vs 2.81 M, 40960: 3.19 vs 3.46 M)
 constexpr int kLaneRefMinBatchLong = 16384;   // horizons beyond 12 (N=20: 16384: 0.81 vs 0.76 M, 32768: 1.47 vs 0.78 M)
 
 #define HIP_TRY(expr)                                                                      \
@@ -505,8 +505,9 @@ static double* variant_gws(const qmpc_handle* h, int var) { return (var == 1 || 
 // Horizons up to 12 only: a TRUNCATED iterate does not damp the rounding of its Newton systems, and the 6 x 6 wrench-space
 // system (condition ~1e7, growing with the horizon) is solved to ~1e-9 of the step where the rotated 12 x 12 elimination
 // keeps every direction to its own scale.  Measured against the round-1 kernels (tools/refmode_bench.py): N=10 all status
-// words and iteration counts equal, forces within 4e-8 N, 0.91 -> 1.02 M solves/s at 1024 instances, 1.36 -> 1.83 M at 65536;
-// N=20 status words and iteration counts equal but only 65 % of the forces within 1e-6 N (median 6e-7), and no faster.
+// words and iteration counts equal, forces within 4e-8 N; with four trial step lengths per rollout and the costate sweep in
+// row-parallel form 0.91 -> 1.95 M solves/s at 1024 instances, 1.24 -> 2.9 M at 8192.  N=20 (first version): status words and
+// iteration counts equal but only 65 % of the forces within 1e-6 N (median 6e-7).
 static int ref_wform_variant(const qmpc_handle* h, int32_t batch) {
   if (!h->wform || h->params.model != QMPC_MODEL_QUAT || h->params.mode != QMPC_MODE_REFERENCE) return 0;
   if (h->params.horizon > 12) return 0;

@@ -902,6 +902,7 @@ __device__ inline int recover_inputs_w(const DevParams& P, const Layout& L, doub
 __device__ __forceinline__ int trial_states_slot(const Layout& L, int g) {      // knots 1..N of group g's trajectory
   return g == 0 ? L.Xc + 13 : (g == 1 ? L.S : (g == 2 ? L.DLAM : L.XT));
 }
+template <bool PF>
 __device__ inline double rollout_trials_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm,
                                           const double* KD, double* ZG, double alpha_g, int lane) {
   typedef Dim<4> D;
@@ -921,9 +922,9 @@ __device__ inline double rollout_trials_w(const DevParams& P, const Layout& L, c
 #pragma unroll
     for (int i = 0; i < 13; ++i) sm[L.Xc + i] = xc[i];
   double Jx = QuatModel::knot_cost(P, sm + L.refp, sm + L.uref, 0, xc, nullptr);
-  for (int k = 0; k < N; ++k) {
-    RollLoadsW cur;
-    roll_load_w(L, LW, sm, KD, k, row, wi, cur);
+  // one knot; PF: the next knot's gains / old state / Jacobian blocks are loaded meanwhile into the other register set
+  auto knot = [&](int k, RollLoadsW& cur, RollLoadsW& nxt) {
+    if (!PF) roll_load_w(L, LW, sm, KD, k, row, wi, cur);
     double dx[12], e[12];
     QuatModel::state_diff(cur.xo, xc, dx);
 #pragma unroll
@@ -942,6 +943,7 @@ __device__ inline double rollout_trials_w(const DevParams& P, const Layout& L, c
     const double s = (p0 + p1) + (p2 + p3);
     const double wn = cur.wk + s;
     if (r >= 6 && r < 12) zg[6 * k + r - 6] = s;
+    if (PF && k + 1 < N) roll_load_w(L, LW, sm, KD, k + 1, row, wi, nxt);
     double w[6];
     w[0] = dpp_mov<0x150>(wn); w[1] = dpp_mov<0x151>(wn); w[2] = dpp_mov<0x152>(wn);      // row_newbcast:0..5
     w[3] = dpp_mov<0x153>(wn); w[4] = dpp_mov<0x154>(wn); w[5] = dpp_mov<0x155>(wn);
@@ -952,6 +954,17 @@ __device__ inline double rollout_trials_w(const DevParams& P, const Layout& L, c
 #pragma unroll
       for (int i = 0; i < 13; ++i) xg[13 * k + i] = xn[i];
     Jx += QuatModel::knot_cost(P, sm + L.refp, sm + L.uref, k + 1, xc, nullptr);
+  };
+  if (PF) {
+    RollLoadsW ra, rb;
+    roll_load_w(L, LW, sm, KD, 0, row, wi, ra);
+    for (int k = 0; k < N; k += 2) {
+      knot(k, ra, rb);
+      if (k + 1 < N) knot(k + 1, rb, ra);
+    }
+  } else {
+    RollLoadsW ra;
+    for (int k = 0; k < N; ++k) knot(k, ra, ra);
   }
   QSYNC();
   return Jx;
@@ -962,8 +975,8 @@ __device__ inline double rollout_trials_w(const DevParams& P, const Layout& L, c
 // and the violation max(c, 0) of the point's cone rows (the arithmetic of ref_merit in qmpc_ref.hip).  Per-lane partial sums:
 // Ju = input cost, mer = Ju + (augmented-Lagrangian terms) / (2 rho), vi = violation.
 __device__ inline void trial_inputs_w(const DevParams& P, const Layout& L, const double* sm, const double* sl,
-                                      const double* ROT, const double* ZG, double alpha, double rho, int lane,
-                                      double Ju[4], double mer[4], double vi[4]) {
+                                      const double* ROT, const double* ZG, const double* Rl, double alpha, double rho,
+                                      int lane, double Ju[4], double mer[4], double vi[4]) {
   typedef Dim<4> D;
   const int N = P.N;
   const double* cst = sm + L.cst;
@@ -981,7 +994,7 @@ __device__ inline void trial_inputs_w(const DevParams& P, const Layout& L, const
     for (int a = 0; a < 3; ++a) {
       u0[a] = sm[L.U + D::NU * k + 3 * l + a];
       ur[a] = sm[L.uref + 3 * l + a];
-      Rw[a] = P.R[3 * l + a];
+      Rw[a] = Rl[3 * l + a];      // input weights from LDS (a lane-dependent index into the kernel arguments is a waterfall loop)
     }
     double T[9], lam[6];
 #pragma unroll
@@ -1030,65 +1043,70 @@ __device__ inline void trial_inputs_w(const DevParams& P, const Layout& L, const
 }
 
 // ---- reference mode: |grad_U L_A|_inf at (X, U) (ref_stationarity of qmpc_ref.hip) through the block structure of the
-// transition.  The costate y_k = lx_k + Abar_k' y_{k+1} is carried in registers by every lane (no exchange inside the
-// sweep); Bbar_k' y_{k+1} = Wr' (M_k' y_{k+1}) leaves a 6-vector per knot (mf = force part, mt = torque part) in `my`, and the
-// gradient rows are then formed one lane per (knot, input):
-//   gu = R (u - u_ref) + c_l mf_a + Bw0_l(:, a)' mt + sum_i max(lambda_i + rho c_i, 0) a_i.
-__device__ inline double stationarity_w(const DevParams& P, const Layout& L, double* sm, const double* sl, double* my,
-                                        double rho, unsigned conmask, int lane) {
+// transition.  Lane c < 12 of every 16-lane row owns component c of the costate y_k = lx_k + Abar_k' y_{k+1}:
+//   position rows keep y,  attitude rows take A1' y_att,  velocity rows add h y_pos,  rate rows add A3' y_att
+// -- three row broadcasts and one row shift per knot, the lane's three coefficients come from LDS through per-lane
+// addresses (lanes without a term read a 0.0 slot).  Bbar_k' y_{k+1} = Wr' (M_k' y_{k+1}) leaves a 6-vector per knot in `my`
+// (lanes 0..2 the force part, 3..5 the torque part); the gradient rows are then formed one lane per (knot, contact point):
+//   gu = R (u - u_ref) + c_l mf + Bw0_l' mt + sum_i max(lambda_i + rho c_i, 0) a_i.
+#ifndef QMPC_STAT_ATTR
+#define QMPC_STAT_ATTR inline
+#endif
+__device__ QMPC_STAT_ATTR double stationarity_w(const DevParams& P, const Layout& L, double* sm, const double* sl, double* my,
+                                        const double* Rl, double rho, unsigned conmask, int lane) {
   typedef Dim<4> D;
   const int N = P.N;
   const double* cst = sm + L.cst;
   const double* cr = cst + D::C_CR;
-  double y[12];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) y[i] = sm[L.XT + kXT * N + 9 + i];
+  const int c = lane & 15, tp = c / 3, j = c - 3 * tp;
+  const int zero = L.cst + kZeroSlots;
+  // per-lane operand addresses at knot 0 and their stride per knot
+  const bool rot = (tp == 1 || tp == 3) && c < 12;
+  const int ia = rot ? L.AB + (tp == 1 ? 0 : 9) + j : zero, sa = rot ? kAB : 0;          // A1(:, j) / A3(:, j): + 3 r
+  const bool tq = tp == 1;
+  const int iw = tq ? L.AB + 18 + j : zero, sw = tq ? kAB : 0;                              // W(:, j): + 3 r
+  const int da = rot ? 3 : 0, dw = tq ? 3 : 0;
+  const int il = (c < 12) ? L.XT + 9 + c : zero, sl_ = (c < 12) ? kXT : 0;
+  const double self = (c < 12 && tp != 1) ? 1.0 : 0.0, hsh = (tp == 2 && c < 12) ? P.h : 0.0;
   const double cpf = P.h * (P.hh * P.inv_mass), cvf = P.h * P.inv_mass;
+  const double mself = (tp == 0) ? cpf : 0.0, mshl = (tp == 0) ? cvf : (tq ? P.h : 0.0), mw = tq ? P.h * (0.5 * P.hh) : 0.0;
+  double y = sm[il + sl_ * N];
   for (int k = N - 1; k >= 0; --k) {
-    const double* AB = sm + L.AB + kAB * k;
-    const double* lx = sm + L.XT + kXT * k + 9;
-    double m6[6];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      m6[a] = cpf * y[a] + cvf * y[6 + a];
-      m6[3 + a] = P.h * ((0.5 * P.hh) * (AB[18 + a] * y[3] + AB[21 + a] * y[4] + AB[24 + a] * y[5]) + y[9 + a]);
-    }
-    if (lane < 6) {
-      double v = m6[0];
-#pragma unroll
-      for (int i = 1; i < 6; ++i) v = (lane == i) ? m6[i] : v;
-      my[6 * k + lane] = v;
-    }
-    double yn[12];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      yn[a] = lx[a] + y[a];
-      yn[3 + a] = lx[3 + a] + (AB[a] * y[3] + AB[3 + a] * y[4] + AB[6 + a] * y[5]);
-      yn[6 + a] = lx[6 + a] + (P.h * y[a] + y[6 + a]);
-      yn[9 + a] = lx[9 + a] + ((AB[9 + a] * y[3] + AB[12 + a] * y[4] + AB[15 + a] * y[5]) + y[9 + a]);
-    }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) y[i] = yn[i];
+    const double a0 = sm[ia + sa * k], a1 = sm[ia + sa * k + da], a2 = sm[ia + sa * k + 2 * da];
+    const double w0 = sm[iw + sw * k], w1 = sm[iw + sw * k + dw], w2 = sm[iw + sw * k + 2 * dw];
+    const double lx = sm[il + sl_ * k];
+    const double b3 = dpp_mov<0x153>(y), b4 = dpp_mov<0x154>(y), b5 = dpp_mov<0x155>(y);      // row_newbcast:3..5
+    const double up = dpp_mov<0x106>(y);                                                       // row_shl:6: lane c reads c + 6
+    const double dn = dpp_mov<0x116>(y);                                                       // row_shr:6: lane c reads c - 6
+    const double m = fma(mself, y, mshl * up) + mw * (w0 * b3 + w1 * b4 + w2 * b5);
+    if (lane < 6) my[6 * k + lane] = m;
+    y = lx + (self * y + hsh * dn + (a0 * b3 + a1 * b4 + a2 * b5));
   }
   QSYNC();
   double g = 0.0;
-  for (int q = lane; q < N * D::NU; q += kWave) {
-    const int k = q / D::NU, j = q - D::NU * k, l = j / 3, a = j - 3 * l;
+  for (int q = lane; q < 4 * N; q += kWave) {
+    const int k = q >> 2, l = q & 3;
     if (!(conmask & (1u << l))) continue;
     const double* m = my + 6 * k;
-    const double* bw = sm + L.bw0 + j;
-    double gu = P.R[j] * (sm[L.U + q] - sm[L.uref + j]) + cst[D::C_CON + l] * m[a] +
-                (bw[0] * m[3] + bw[D::NU] * m[4] + bw[2 * D::NU] * m[5]);
+    const double* bw = sm + L.bw0 + 3 * l;
+    const double con = cst[D::C_CON + l];
+    double zp[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int idx = D::NC * k + 6 * l + i;
-      const double z = sl[L.LAM + idx] + rho * sl[L.RC + idx];
-      gu += (z > 0.0) ? z * cr[3 * i + a] : 0.0;
+      zp[i] = fmax(sl[L.LAM + idx] + rho * sl[L.RC + idx], 0.0);
     }
-    g = fmax(g, fabs(gu));
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int jj = 3 * l + a;
+      double gu = Rl[jj] * (sm[L.U + D::NU * k + jj] - sm[L.uref + jj]) + con * m[a] +
+                  (bw[a] * m[3] + bw[D::NU + a] * m[4] + bw[2 * D::NU + a] * m[5]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) gu += zp[i] * cr[3 * i + a];
+      g = fmax(g, fabs(gu));
+    }
   }
   return wave_max(g);
 }
-
 
 }  // namespace qmpc
