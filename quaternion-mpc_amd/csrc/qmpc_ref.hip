@@ -17,6 +17,7 @@
 #pragma once
 
 #include "qmpc_device.h"      // included after qmpc_kernels.hip by qmpc_hip.hip
+#include "qmpc_wform.h"       // stationarity_w: the row-parallel costate sweep (four-point QuatMpc)
 
 namespace qmpc {
 
