@@ -17,6 +17,9 @@ timeout 900 python bench.py > "$out/bench_default.json" 2> "$out/bench_default.e
 timeout 300 python tools/wform_check.py --reps 30 > "$out/wform_vs_round1_b1024.txt" 2>&1
 for b in 2048 4096 8192 16384; do timeout 300 python tools/wform_check.py --batch $b --oracle 64 --reps 8 2>&1 | grep -E "WFORM|wform vs" >> "$out/wform_vs_round1_midsize.txt"; done
 timeout 600 python tools/handoff_bench.py --cases 10:32768,10:65536,20:65536,10:262144 --caps 0,default > "$out/handoff.txt" 2>&1
+timeout 900 python tools/refmode_bench.py > "$out/refmode_bench.txt" 2>&1
+timeout 900 python tools/refmode_lane_bench.py --cases 10:16384,10:32768,10:40960,10:65536,10:262144,20:16384,20:32768,20:65536 > "$out/refmode_lane.txt" 2>&1
+for b in 1024 4096 16384 65536; do for f in 0 1; do QMPC_LOOP_FUSED=$f timeout 300 python tools/loop_bench.py --robots $b --mode 1 --ticks 60 2>&1 | tail -1 >> "$out/loop_refmode.txt"; done; done
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d "$out/prof" -- python "$root/bench.py" > "$out/prof_bench.json" 2> "$out/prof_bench.err"
 cd "$root"

@@ -8,7 +8,7 @@ REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO))
 import __graft_entry__ as g  # noqa: E402
 ap = argparse.ArgumentParser()
-ap.add_argument("--cases", default="10:1024,10:8192,10:65536,20:1024,20:65536")
+ap.add_argument("--cases", default="10:1024,10:2048,10:8192,10:32768,12:1024,3:1024,20:1024,20:16384")
 a = ap.parse_args()
 pkg = g._load_pkg(); lib = pkg.load_library()
 import torch  # noqa: E402
@@ -18,6 +18,7 @@ for case in a.cases.split(","):
     rec = pkg.random_go1_trot_states(B, config_id=3 if N == 20 else 2)
     d_in = torch.from_numpy(rec.view(np.float64).reshape(B, -1).copy()).cuda()
     res = {}
+    os.environ["QMPC_LANE_REF_MIN"] = str(1 << 30)      # the wave kernels at every size
     for wf in (0, 1):
         os.environ["QMPC_WFORM"] = str(wf)
         s = pkg.Solver(p, B, 0, lib)
