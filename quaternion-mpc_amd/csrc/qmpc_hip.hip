@@ -119,7 +119,7 @@ constexpr int kLaneMinBatchOther = 18432;
 // reference mode (AL-iLQR, <= 10 iterations; qmpc_lane_ref_kernel): measured against the wave-per-instance reference kernels
 // (tools/refmode_lane_bench.py, N=10): 16384: 1.49 vs 1.74 M solves/s, 32768: 2.70 vs 1.78 M, 65536: 4.59 vs 1.83 M (N=20: 2.53 vs 0.79 M)
 constexpr int kLaneRefMinBatch = 36864;      // N <= 12: the wave kernels try four step lengths per rollout (32768: 3.17 vs 2.81 M, 40960: 3.19 vs 3.46 M)
-constexpr int kLaneRefMinBatchLong = 20480;   // horizons beyond 12 (N=20: 16384: 0.83 vs 0.93 M on the wave kernels, 32768: 1.47 vs 0.93 M)
+constexpr int kLaneRefMinBatchLong = 24576;   // horizons beyond 12 (N=20: 16384: 0.83 vs 1.14 M on the wave kernels, 32768: 1.47 vs 1.15 M)
 
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \

@@ -113,6 +113,123 @@ __device__ inline double ref_stationarity(const DevParams& P, const Layout& L, d
   return wave_max(g);
 }
 
+// ---- line search of the four-point QuatMpc problem on the dense kernels, THREE trial step lengths per rollout --------------
+// The closed-loop rollout (rollout_closed, qmpc_kernels.hip) keeps the 16 lanes 4 l + a busy and lets every lane advance
+// the same state; the trials of one line search are independent of each other.  Each 16-lane row of the wavefront therefore
+// rolls its own step length alpha 2^-g out (rows 0..2; row 3 repeats row 2): the inputs are broadcast inside the row
+// (row_newbcast), the state cost of the row's trajectory is summed on the way, increments and states are left in
+//   group 0: dU, Xc      group 1: DLAM (12 N), S (13 N)      group 2: XT (12 N), DS (13 N)
+// -- the reference mode uses none of S / DS / DLAM during the search (the input weights of stationarity_w sit in the last 12
+// entries of DLAM), and the cost expansions in XT are dead between the backward pass and the expansions at the accepted point.
+// The same idea as rollout_trials_w (qmpc_wform.h), which has four groups because its wrench-space records are smaller.
+__device__ __forceinline__ int trial_du_slot(const Layout& L, int g) { return g == 0 ? L.dU : (g == 1 ? L.DLAM : L.XT); }
+__device__ __forceinline__ int trial_x_slot(const Layout& L, int g) { return g == 0 ? L.Xc + 13 : (g == 1 ? L.S : L.DS); }
+
+template <class MD, bool LEAN>
+__device__ inline double rollout_trials_dense(const DevParams& P, const Layout& L, double* sm, const double* KD,
+                                              const double* ROT, double alpha_g, int lane) {
+  typedef typename MD::D D;
+  static_assert(D::NU == 12, "one 16-lane row per trial: four contact points");
+  const int N = P.N;
+  const double* cst = sm + L.cst;
+  typename MD::template RegsT<LEAN> M;
+  M.load(cst, sm + L.bw0);
+  const int r = lane & 15, g = (lane >> 4) < 2 ? (lane >> 4) : 2;
+  const bool ulane = (r & 3) < 3;
+  const int ql = ulane ? (r >> 2) : 0, qa = ulane ? (r & 3) : 0;
+  const int uj = 3 * ql + qa;
+  double* dug = sm + trial_du_slot(L, g);
+  double* xg = sm + trial_x_slot(L, g);
+  double xc[13], xn[13];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) xc[i] = cst[D::C_X0 + i];
+  if (lane == 15)
+#pragma unroll
+    for (int i = 0; i < 13; ++i) sm[L.Xc + i] = xc[i];
+  double Jx = MD::knot_cost(P, sm + L.refp, sm + L.uref, 0, xc, nullptr);
+  for (int k = 0; k < N; ++k) {
+    RollLoads cur;
+    roll_load<D, true>(L, sm, KD, ROT, k, uj, ql, qa, cur);
+    double dx[12];
+    MD::state_diff(cur.xo, xc, dx);
+    const double* kd = cur.kd;
+    const double p0 = alpha_g * kd[12] + kd[0] * dx[0] + kd[1] * dx[1] + kd[2] * dx[2];
+    const double p1 = kd[3] * dx[3] + kd[4] * dx[4] + kd[5] * dx[5];
+    const double p2 = kd[6] * dx[6] + kd[7] * dx[7] + kd[8] * dx[8];
+    const double p3 = kd[9] * dx[9] + kd[10] * dx[10] + kd[11] * dx[11];
+    const double s = (p0 + p1) + (p2 + p3);
+    const double s0 = dpp_mov<0x00>(s), s1 = dpp_mov<0x55>(s), s2 = dpp_mov<0xAA>(s);   // quad_perm broadcasts
+    const double inc = cur.T[0] * s0 + cur.T[1] * s1 + cur.T[2] * s2;
+    if (ulane) dug[D::NU * k + uj] = inc;
+    const double unew = cur.uo + inc;
+    double un[12];      // input 3 l + a from lane 4 l + a of the row (row_newbcast)
+    un[0] = dpp_mov<0x150>(unew); un[1] = dpp_mov<0x151>(unew); un[2] = dpp_mov<0x152>(unew);
+    un[3] = dpp_mov<0x154>(unew); un[4] = dpp_mov<0x155>(unew); un[5] = dpp_mov<0x156>(unew);
+    un[6] = dpp_mov<0x158>(unew); un[7] = dpp_mov<0x159>(unew); un[8] = dpp_mov<0x15A>(unew);
+    un[9] = dpp_mov<0x15C>(unew); un[10] = dpp_mov<0x15D>(unew); un[11] = dpp_mov<0x15E>(unew);
+    MD::template step<LEAN>(P, M, xc, un, xn);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) xc[i] = xn[i];
+    if (r == 15)
+#pragma unroll
+      for (int i = 0; i < 13; ++i) xg[13 * k + i] = xn[i];
+    Jx += MD::knot_cost(P, sm + L.refp, sm + L.uref, k + 1, xc, nullptr);
+  }
+  QSYNC();
+  return Jx;
+}
+
+// the inputs' share of the three trials' merit, one lane per (knot, contact point): u = U + dU_g, input cost,
+// augmented-Lagrangian terms and violation of the point's cone rows (the arithmetic of ref_merit).  Per-lane partial sums:
+// Ju = input cost, mer = Ju + (AL terms) / (2 rho), vi = violation.
+template <class D>
+__device__ inline void trial_inputs_dense(const DevParams& P, const Layout& L, const double* sm, const double* sl,
+                                          const double* Rl, double rho, int lane, double Ju[3], double mer[3], double vi[3]) {
+  const int N = P.N;
+  const double* cst = sm + L.cst;
+  const double* cr = cst + D::C_CR;
+  double al[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) { Ju[g] = 0.0; al[g] = 0.0; vi[g] = 0.0; }
+  for (int q = lane; q < 4 * N; q += kWave) {
+    const int k = q >> 2, l = q & 3;
+    const bool stance = cst[D::C_CON + l] != 0.0;
+    double u0[3], ur[3], Rw[3], lam[6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      u0[a] = sm[L.U + D::NU * k + 3 * l + a];
+      ur[a] = sm[L.uref + 3 * l + a];
+      Rw[a] = Rl[3 * l + a];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lam[i] = sl[L.LAM + D::NC * k + 6 * l + i];
+    const double fzc = -P.fz_max * cst[D::C_CON + l];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const double* du = sm + trial_du_slot(L, g) + D::NU * k + 3 * l;
+      double u[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) u[a] = u0[a] + du[a];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { const double e = u[a] - ur[a]; Ju[g] += 0.5 * Rw[a] * e * e; }
+      if (stance) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          double c = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
+          if (i == 4) c += fzc;
+          double zz = lam[i] + rho * c;
+          if (zz < 0.0) zz = 0.0;
+          al[g] += zz * zz - lam[i] * lam[i];
+          vi[g] = fmax(vi[g], fmax(c, 0.0));
+        }
+      }
+    }
+  }
+  const double i2r = 1.0 / (2.0 * rho);
+#pragma unroll
+  for (int g = 0; g < 3; ++g) mer[g] = Ju[g] + al[g] * i2r;
+}
+
 template <class MD, int VAR>
 __global__ __launch_bounds__(64, 1) void qmpc_ref_kernel(   // one wave per SIMD: the line-search loop keeps ~400 registers live
     DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
