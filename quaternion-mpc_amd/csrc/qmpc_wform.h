@@ -304,6 +304,9 @@ struct ColOps {
 // loads.  The three column multipliers wt[t] / at[t] of a lane sit 3 doubles apart in the knot's record (immediate
 // offsets of one index register); the Wt block of the M fragment and the A1 / A3 blocks of the N = Abar - I fragment
 // ARE those multipliers on the lanes whose fragment row is 3 + t.
+#ifndef QMPC_W_FUSED_ROWS
+#define QMPC_W_FUSED_ROWS 1      // input recovery + directions, and the apply step, one lane per (knot, contact point)
+#endif
 constexpr int kZeroSlots = 54;      // cst[54..63] hold 0.0 (cst[] is used up to slot 52)
 struct BwPat {
   ColOps co;
@@ -888,6 +891,123 @@ __device__ inline int recover_inputs_w(const DevParams& P, const Layout& L, doub
   }
   QSYNC();
   return __any(bad ? 1 : 0);
+}
+
+// ---- converged mode, one lane per (knot, contact point): the input increments of the trial step (recover_inputs_w), then
+// the slack / multiplier directions of the point's six rows and its share of the step lengths (ipm_directions of
+// qmpc_kernels.hip: ds = -(a_i . dU_l + rc), dlam = (target - (1 + kappa) s lam - lam ds) / s, fraction to the boundary).
+// The rows' loads are issued together, nothing branches, and the ratio tests keep the smallest s / (-ds) as a fraction
+// (compared by cross-multiplication): one division per lane instead of two per row.  `kapbits` returns the weakly-active
+// flags of the lane's rows (bit 6 j + i: row i of the lane's j-th (knot, point)), read from the DS slot before the
+// directions overwrite it; apply_w consumes them.  Returns nonzero (wave-uniform) when an increment is not finite.
+__device__ inline int recover_directions_w(const DevParams& P, const Layout& L, double* sm, double* sl, const double* ROT,
+                                           double target, int lane, double* alpha_p, double* alpha_d, double* full_step,
+                                           unsigned& kapbits) {
+  typedef Dim<4> D;
+  const int N = P.N;
+  const double* cst = sm + L.cst;
+  const double* cr = cst + D::C_CR;
+  bool bad = false;
+  double pn = 1.0, pd = 0.0, dn = 1.0, dd = 0.0;      // smallest s / (-ds), lam / (-dlam) so far, as fractions (den 0: none)
+  double stp = 0.0;
+  unsigned bits = 0;
+  int j = 0;
+  for (int q = lane; q < 4 * N; q += kWave, ++j) {
+    const int k = q >> 2, l = q & 3;
+    const bool stance = cst[D::C_CON + l] != 0.0;
+    const double* rec = ROT + D::ROT * k + 21 * l;
+    const int i0 = D::NC * k + 6 * l;
+    double T[9], z[6], sv[6], lv[6], kap[6], rc[6];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) T[i] = rec[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) z[i] = ROT[zeta_slot(k, i)];
+    const double l10 = rec[9], l20 = rec[10], l21 = rec[11], id0 = rec[12], id1 = rec[13], id2 = rec[14];
+    const double g0 = rec[15], g1 = rec[16], g2 = rec[17];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { sv[i] = sl[L.S + i0 + i]; lv[i] = sl[L.LAM + i0 + i]; kap[i] = sl[L.DS + i0 + i]; rc[i] = sl[L.RC + i0 + i]; }
+    const double* bw = sm + L.bw0 + 3 * l;
+    double du[3] = {0.0, 0.0, 0.0};
+    if (stance) {
+      double f[3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) f[b] = z[b] + (bw[b] * z[3] + bw[D::NU + b] * z[4] + bw[2 * D::NU + b] * z[5]);
+      const double t0 = g0 + (T[0] * f[0] + T[3] * f[1] + T[6] * f[2]);
+      const double t1 = g1 + (T[1] * f[0] + T[4] * f[1] + T[7] * f[2]);
+      const double t2 = g2 + (T[2] * f[0] + T[5] * f[1] + T[8] * f[2]);
+      const double y0 = t0, y1 = t1 - l10 * y0, y2 = t2 - l20 * y0 - l21 * y1;
+      const double x2 = id2 * y2;
+      const double x1 = id1 * y1 - l21 * x2;
+      const double x0 = id0 * y0 - l10 * x1 - l20 * x2;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) du[a] = -(T[3 * a] * x0 + T[3 * a + 1] * x1 + T[3 * a + 2] * x2);
+    }
+    double* o = sm + L.dU + D::NU * k + 3 * l;
+    o[0] = du[0]; o[1] = du[1]; o[2] = du[2];
+    bad = bad || !(isfinite(du[0]) && isfinite(du[1]) && isfinite(du[2]));
+    stp = fmax(stp, fmax(fabs(du[0]), fmax(fabs(du[1]), fabs(du[2]))));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
+      double dsv = -(jd + rc[i]);
+      double dlv = (target - (1.0 + kap[i]) * sv[i] * lv[i] - lv[i] * dsv) * fast_rcp(sv[i]);
+      dsv = stance ? dsv : 0.0;
+      dlv = stance ? dlv : 0.0;
+      // sv / (-dsv) < pn / pd  <=>  sv pd < pn (-dsv)   (pd = 0: nothing yet, any candidate wins)
+      const bool up = (dsv < 0.0) && (pd == 0.0 || sv[i] * pd < pn * (-dsv));
+      pn = up ? sv[i] : pn; pd = up ? -dsv : pd;
+      const bool ud = (dlv < 0.0) && (dd == 0.0 || lv[i] * dd < dn * (-dlv));
+      dn = ud ? lv[i] : dn; dd = ud ? -dlv : dd;
+      sl[L.DS + i0 + i] = dsv;
+      sl[L.DLAM + i0 + i] = dlv;
+      bits |= (stance && kap[i] != 0.0) ? (1u << (6 * j + i)) : 0u;
+    }
+  }
+  const double ap = (pd > 0.0) ? fmin(1.0, P.tau * pn * fast_rcp(pd)) : 1.0;
+  const double ad = (dd > 0.0) ? fmin(1.0, P.tau * dn * fast_rcp(dd)) : 1.0;
+  *alpha_p = wave_min(ap);
+  *alpha_d = wave_min(ad);
+  *full_step = wave_max(stp);
+  kapbits = bits;
+  QSYNC();
+  return __any(bad ? 1 : 0);
+}
+
+// apply the step to (s, rc, lambda) and leave the weakly-active (Tapia) flags in the DS slot -- ipm_apply of qmpc_kernels.hip
+// with the rows of a contact point in one lane
+__device__ inline void apply_w(const DevParams& P, const Layout& L, double* sl, double ap, double ad, unsigned conmask,
+                               int lane, unsigned kapbits, double& sl_part, double& rc_part) {
+  typedef Dim<4> D;
+  const int N = P.N;
+  sl_part = 0.0;
+  rc_part = 0.0;
+  const bool full = (ap >= 0.99) && (ad >= 0.99);
+  const double rcs = (ap >= 1.0) ? 0.0 : (1.0 - ap);
+  int j = 0;
+  for (int q = lane; q < 4 * N; q += kWave, ++j) {
+    const int k = q >> 2, l = q & 3;
+    if (!(conmask & (1u << l))) continue;
+    const int i0 = D::NC * k + 6 * l;
+    double s0[6], l0[6], ds[6], dl[6], rc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      s0[i] = sl[L.S + i0 + i]; l0[i] = sl[L.LAM + i0 + i]; ds[i] = sl[L.DS + i0 + i]; dl[i] = sl[L.DLAM + i0 + i]; rc[i] = sl[L.RC + i0 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const bool kap0 = (kapbits >> (6 * j + i)) & 1u;
+      const double s1 = s0[i] + ap * ds[i];
+      const double l1 = l0[i] + ad * dl[i];
+      const double rc1 = (ap >= 1.0) ? 0.0 : rcs * rc[i];
+      sl[L.S + i0 + i] = s1;
+      sl[L.RC + i0 + i] = rc1;
+      sl[L.LAM + i0 + i] = l1;
+      sl_part += s1 * l1;
+      rc_part = fmax(rc_part, fabs(rc1));
+      const bool sig = full && (s1 < 0.6 * s0[i]) && (l1 < 0.6 * l0[i]) && (kap0 || ((s1 > 0.4 * s0[i]) && (l1 > 0.4 * l0[i])));
+      sl[L.DS + i0 + i] = sig ? 1.0 : 0.0;
+    }
+  }
 }
 
 // ---- reference mode: FOUR trial step lengths of the backtracking line search per rollout ------------------------------
