@@ -103,6 +103,7 @@ struct qmpc_handle {
   int hstate_cap;
   int lane_ref_min;            // reference-mode batches from this size on take the lane kernel (env QMPC_LANE_REF_MIN)
   int lane_cap;                // straggler hand-off: iteration cap of the lane kernel in cold plain solves (0: off; env QMPC_LANE_CAP)
+  int lane_cap_loop;           // ... and in the solves of a cold-started closed loop (in-gait states need fewer iterations; env QMPC_LANE_CAP_LOOP)
 };
 
 constexpr unsigned kLaneMaxSlots = 1024 * 64;   // one wavefront per SIMD of the chip
@@ -118,6 +119,7 @@ constexpr int kLaneMinBatchLong = 16384;      // QuatMpc, longer horizons
 constexpr int kLaneMinBatchOther = 18432;
 // reference mode (AL-iLQR, <= 10 iterations; qmpc_lane_ref_kernel): measured against the wave-per-instance reference kernels
 // (tools/refmode_lane_bench.py, N=10): 16384: 1.49 vs 1.74 M solves/s, 32768: 2.70 vs 1.78 M, 65536: 4.59 vs 1.83 M (N=20: 2.53 vs 0.79 M)
+constexpr int kLaneCapLoop = 0;               // iteration cap of the lane kernel in the cold-started closed loop (0: no hand-off there)
 constexpr int kLaneRefMinBatch = 36864;      // N <= 12: the wave kernels try four step lengths per rollout (32768: 3.17 vs 2.81 M, 40960: 3.19 vs 3.46 M)
 constexpr int kLaneRefMinBatchLong = 24576;   // horizons beyond 12 (N=20: 16384: 0.83 vs 1.14 M on the wave kernels, 32768: 1.47 vs 1.15 M)
 
@@ -357,6 +359,8 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     h->lane_ref_min = lrm ? std::atoi(lrm) : (N <= 12 ? kLaneRefMinBatch : kLaneRefMinBatchLong);
     const char* lc = std::getenv("QMPC_LANE_CAP");
     h->lane_cap = lc ? std::atoi(lc) : 15 + N / 10;
+    const char* lcl = std::getenv("QMPC_LANE_CAP_LOOP");
+    h->lane_cap_loop = lcl ? std::atoi(lcl) : kLaneCapLoop;
     const char* ls = std::getenv("QMPC_LANE_SORT");
     h->lane_sort = ls ? std::atoi(ls) : 1;
     // the lane kernel reads its parameters from a constant-memory table with one slot per LIVE handle (a slot is rewritten
@@ -448,6 +452,25 @@ static qmpc_status ensure_lane_buffers(qmpc_handle* h) {
   }
   return QMPC_OK;
 }
+// Hand-off buffers, on first use.  One state record (8 + 60 N doubles) per instance of the handle's capacity: 8-10 % of a batch
+// is handed over in the measured workloads, but WHICH record an instance gets is decided by an atomic counter, so only room
+// for all of them keeps the results independent of timing (320 MB at 65536 x N=10, 1.3 GB at 262144 x N=10; held until
+// qmpc_destroy, like the lane kernel's workspace).  If the memory is not there the hand-off is switched off for this handle.
+static bool ensure_handoff_buffers(qmpc_handle* h) {
+  if (h->d_handoff) return true;
+  h->hstate_cap = h->max_batch;
+  const size_t rec_bytes = sizeof(double) * qmpc_lane_handoff_record_doubles(h->params.horizon);
+  if (hipMalloc(&h->d_handoff, qmpc_lane_handoff_list_bytes(h->max_batch)) != hipSuccess ||
+      hipMalloc(&h->d_hstate, rec_bytes * (size_t)h->hstate_cap) != hipSuccess) {
+    (void)hipGetLastError();
+    if (h->d_handoff) (void)hipFree(h->d_handoff);
+    h->d_handoff = nullptr; h->d_hstate = nullptr;
+    h->lane_cap = 0;
+    h->lane_cap_loop = 0;
+    return false;
+  }
+  return true;
+}
 // d_u_init / d_traj_u: previous solutions [batch][N][3 NL] to start from (null: cold) / where to leave this one (null:
 // not wanted); they may be the same buffer.  check_prev: d_info still holds the records of the previous solves
 static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces, qmpc_info* d_info,
@@ -456,22 +479,7 @@ static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* 
   const int nl = h->params.model == QMPC_MODEL_CONVEX ? -4 : model_nl(h->params.model);     // -4: ConvexMpc's model (qmpc_lane.hip)
   const qmpc_status es = ensure_lane_buffers(h);
   if (es != QMPC_OK) return es;
-  if (iter_cap > 0 && !h->d_handoff) {      // hand-off buffers, on first use (never inside a stream capture: plain solves only)
-    // One state record (8 + 60 N doubles) per instance of the handle's capacity: 8-10 % of a batch is handed over in the
-    // measured workloads, but WHICH record an instance gets is decided by an atomic counter, so only room for all of them
-    // keeps the results independent of timing (320 MB at 65536 x N=10, 1.3 GB at 262144 x N=10; held until qmpc_destroy,
-    // like the lane kernel's workspace).  If the memory is not there the hand-off is switched off for this handle.
-    h->hstate_cap = h->max_batch;
-    const size_t rec_bytes = sizeof(double) * qmpc_lane_handoff_record_doubles(h->params.horizon);
-    if (hipMalloc(&h->d_handoff, qmpc_lane_handoff_list_bytes(h->max_batch)) != hipSuccess ||
-        hipMalloc(&h->d_hstate, rec_bytes * (size_t)h->hstate_cap) != hipSuccess) {
-      (void)hipGetLastError();
-      if (h->d_handoff) (void)hipFree(h->d_handoff);
-      h->d_handoff = nullptr; h->d_hstate = nullptr;
-      h->lane_cap = 0;
-      iter_cap = 0;
-    }
-  }
+  if (iter_cap > 0 && !ensure_handoff_buffers(h)) iter_cap = 0;      // (never inside a stream capture: qmpc_loop_run calls it first)
   HIP_TRY(qmpc_lane_launch(nl, h->lane_pslot, (int)batch, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, h->d_lane_ws, h->lane_slots,
                            h->lane_sort ? h->d_lane_scratch : nullptr, h->lane_params_resident ? 0 : 1, d_u_init, d_traj_u,
                            check_prev, h->lane_order_prev ? 1 : 0, d_traj_x, iter_cap, iter_cap > 0 ? h->d_handoff : nullptr,
@@ -522,15 +530,15 @@ static int ref_wform_variant(const qmpc_handle* h, int32_t batch) {
 
 static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces,
                                 qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s, bool timed = true,
-                                bool handoff = true) {
+                                int handoff = 1) {      // 0: no straggler hand-off, 1: plain solve (lane_cap), 2: closed loop (lane_cap_loop)
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;   // the gains workspace is sized by max_batch
   if (timed) HIP_TRY(hipEventRecord(h->ev0, s));
   if (h->params.mode == QMPC_MODE_REFERENCE) {     // the reference's own AL-iLQR mode (qmpc_ref.hip)
     const bool ws = batch > 1024 || h->lds_bytes > 40 * 1024 || h->variant >= 2 || h->params.model == QMPC_MODEL_QUAT8;
     // Monte-Carlo scale (plain solves of QuatMpc's problem): one lane per instance, the AL variant of the lane passes
     // (qmpc_lane_core.h: lane_solve_ref; qmpc_lane.hip: qmpc_lane_ref_kernel)
-    if (handoff && h->params.model == QMPC_MODEL_QUAT && h->lane_pslot >= 0 && !d_tx &&
-        (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min))) {
+    if (handoff == 1 && h->params.model == QMPC_MODEL_QUAT && h->lane_pslot >= 0 && !d_tx &&      // plain solves only: the closed loop
+        (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min))) {                      // keeps the wave kernels in this mode
       const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s, nullptr, d_tu, 0, nullptr, 0);
       if (ls != QMPC_OK) return ls;
       if (timed) {
@@ -574,10 +582,11 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
     // straggler hand-off (see qmpc_create): only where the library chose the lane kernel by itself (QMPC_VARIANT=4 forces
     // the pure lane kernel) and there at every batch size (a shard of a batch gives the bits of the whole batch), with status
     // records to select from
+    const int cap = handoff == 2 ? h->lane_cap_loop : h->lane_cap;
     const int wv = (handoff && h->variant == 0 && h->wform && h->params.model == QMPC_MODEL_QUAT && d_info &&
-                    h->lane_cap > 0 && h->lane_cap < h->params.iterations_max)
+                    cap > 0 && cap < h->params.iterations_max)
                        ? (h->lds_bytes_w <= 40 * 1024 ? 3 : (h->lds_bytes_wg <= 40 * 1024 ? 5 : 0)) : 0;
-    const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s, nullptr, d_tu, 0, d_tx, wv ? h->lane_cap : 0);
+    const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s, nullptr, d_tu, 0, d_tx, wv ? cap : 0);
     if (ls != QMPC_OK) return ls;
     if (wv && h->d_handoff) {     // one workgroup per SIMD walks the list the lane kernel left (8-10 % of the batch in the measured workloads)
       // QMPC_HANDOFF_RESTART=1 (experiments, tests): the wave kernel ignores the state records and solves the list from scratch
@@ -1143,7 +1152,7 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
       HIP_TRY(qmpc_warm_launch(var, convex ? 1 : 0, (int)batch, variant_lds(h, var), s, &h->dev, sizeof h->dev, h->d_in, first ? nullptr : h->d_traj_u,
                                h->d_forces, h->d_info, h->d_traj_u, variant_gws(h, var), /*check_prev=*/1));
     } else {
-      const qmpc_status st = launch_solve(h, batch, h->d_in, h->d_forces, h->d_info, nullptr, nullptr, s, /*timed=*/false, /*handoff=*/false);
+      const qmpc_status st = launch_solve(h, batch, h->d_in, h->d_forces, h->d_info, nullptr, nullptr, s, /*timed=*/false, /*handoff=*/2);
       if (st != QMPC_OK) return st;
     }
     if (convex)
@@ -1204,6 +1213,7 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
     h->lane_params_resident = true;
     static const bool order_env = [] { const char* e = std::getenv("QMPC_LANE_ORDER_PREV"); return !e || e[0] != '0'; }();
     h->lane_order_prev = order_env;
+    if (!warm && h->lane_cap_loop > 0 && h->params.mode == QMPC_MODE_CONVERGED) (void)ensure_handoff_buffers(h);      // not capturable either
   }
   if (warm) {                            // the cold first tick is not the tick the graph repeats
     const qmpc_status st = one_tick(true);
