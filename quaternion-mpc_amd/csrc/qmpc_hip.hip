@@ -119,7 +119,10 @@ constexpr int kLaneMinBatchLong = 16384;      // QuatMpc, longer horizons
 constexpr int kLaneMinBatchOther = 18432;
 // reference mode (AL-iLQR, <= 10 iterations; qmpc_lane_ref_kernel): measured against the wave-per-instance reference kernels
 // (tools/refmode_lane_bench.py, N=10): 16384: 1.49 vs 1.74 M solves/s, 32768: 2.70 vs 1.78 M, 65536: 4.59 vs 1.83 M (N=20: 2.53 vs 0.79 M)
-constexpr int kLaneCapLoop = 0;               // iteration cap of the lane kernel in the cold-started closed loop (0: no hand-off there)
+// iteration cap of the lane kernel in the solves of a cold-started closed loop, 11 + N/10 (in-gait states: 10.3 iterations on
+// average, 17 at most, against 13.6 / 23 of the random states of the plain-solve benchmark): 32768 robots 7.47 -> 7.96 M
+// robot-ticks/s, 65536: 11.98 -> 12.76 M (caps 10 .. 13 scanned, tools/loop_bench.py; QMPC_LANE_CAP_LOOP=0 switches it off)
+constexpr int kLaneCapLoopBase = 11;
 constexpr int kLaneRefMinBatch = 36864;      // N <= 12: the wave kernels try four step lengths per rollout (32768: 3.17 vs 2.81 M, 40960: 3.19 vs 3.46 M)
 constexpr int kLaneRefMinBatchLong = 24576;   // horizons beyond 12 (N=20: 16384: 0.83 vs 1.14 M on the wave kernels, 32768: 1.47 vs 1.15 M)
 
@@ -360,7 +363,7 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     const char* lc = std::getenv("QMPC_LANE_CAP");
     h->lane_cap = lc ? std::atoi(lc) : 15 + N / 10;
     const char* lcl = std::getenv("QMPC_LANE_CAP_LOOP");
-    h->lane_cap_loop = lcl ? std::atoi(lcl) : kLaneCapLoop;
+    h->lane_cap_loop = lcl ? std::atoi(lcl) : kLaneCapLoopBase + N / 10;
     const char* ls = std::getenv("QMPC_LANE_SORT");
     h->lane_sort = ls ? std::atoi(ls) : 1;
     // the lane kernel reads its parameters from a constant-memory table with one slot per LIVE handle (a slot is rewritten
