@@ -650,7 +650,7 @@ def main():
                                                               "mean_iterations": float(finlw["iterations"].mean()),
                                                               "position_difference_to_cold_start_m":
                                                                   float(np.abs(finlw["pos_world"] - finl["pos_world"]).max())},
-                                               "launch_form": "three kernels per tick (graph replay), solve = qmpc_lane_kernel"}
+                                               "launch_form": "three kernels per tick (graph replay), solve = qmpc_lane_kernel (cold start: stragglers beyond 12 iterations continued by qmpc_solve_w_list_kernel inside the tick)"}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(pkg, N, config_id, model=args.model)
             f_cpu = cb.pop("_forces")
