@@ -525,7 +525,7 @@ static double* variant_gws(const qmpc_handle* h, int var) { return (var == 1 || 
 static int ref_wform_variant(const qmpc_handle* h, int32_t batch) {
   if (!h->wform || h->params.model != QMPC_MODEL_QUAT || h->params.mode != QMPC_MODE_REFERENCE) return 0;
   static const int maxn = std::getenv("QMPC_REF_WFORM_MAXN") ? std::atoi(std::getenv("QMPC_REF_WFORM_MAXN")) : 12;
-  if (h->params.horizon > maxn) return 0;
+  if (h->params.horizon > maxn || h->params.horizon < 2) return 0;      // (one knot: the input weights would not fit behind the trial states)
   const bool ws = batch > 1024 || h->lds_bytes_w > 40 * 1024 || h->variant >= 2;
   if (!ws) return 3;
   return h->lds_bytes_wg <= 80 * 1024 ? 5 : 0;

@@ -1657,7 +1657,7 @@ def test_loop_joint_velocities_are_the_time_derivative_of_the_joint_angles(pkg, 
         st, jp, fb0 = st1, jp1, fb1
     s.close()
     assert seen > 150 and worst < 0.05, worst       # measured 0.01 (O(dt) of the midpoint average); 0.5 without the term@pytest.mark.gpu
-@pytest.mark.parametrize("N,lsmax", [(10, 0), (10, 2), (10, 5), (20, 1), (20, 4), (12, 7)])
+@pytest.mark.parametrize("N,lsmax", [(10, 0), (10, 2), (10, 5), (20, 1), (20, 4), (12, 7), (2, 10), (1, 10)])
 def test_reference_mode_line_search_limits(pkg, lib, oracle, N, lsmax):
     """The wave kernels try the step lengths of the backtracking line search several at a time (four per rollout on the
     wrench-form kernels of horizons <= 12, three on the dense ones): with `linesearch_max` not a multiple of the group size
