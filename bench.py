@@ -487,7 +487,7 @@ def main():
                                          "outputs_identical": same2},
                        "roofline": roofline_object(kernel_name(Bl, Nl), ach, tr, tr_src, lg["kernel_ms"], Bl, Bl * (8 * 48 + 8 * 12 + 40))}
                 # the reference's own solver mode on the same batch (AL-iLQR, <= 10 iterations): the lane kernel's AL passes
-                # from 36864 instances on (24576 beyond N=12), the wave-per-instance reference kernels below
+                # from 32768 instances on (22528 beyond N=12), the wave-per-instance reference kernels below
                 if not args.no_reference_mode:
                     prl = pkg.default_params(Nl, pkg.MODE_REFERENCE, lib)
                     srl = pkg.Solver(prl, Bl, device=local, lib=lib)
@@ -505,7 +505,7 @@ def main():
                     ent["reference_mode"] = {
                         "value": Bl / (float(np.median(kms)) * 1e-3), "unit": "solves/s", "kernel_ms": float(np.median(kms)),
                         "kernel": ("qmpc_lane_ref_kernel (lane per instance, AL variant of the lane passes)"
-                                   if Bl >= int(os.environ.get("QMPC_LANE_REF_MIN", "36864" if Nl <= 12 else "24576")) else
+                                   if Bl >= int(os.environ.get("QMPC_LANE_REF_MIN", "32768" if Nl <= 12 else "22528")) else
                                    ("qmpc_ref_w_kernel<5> (wave per instance, wrench form, gains in the workspace)" if Nl <= 12
                                     else "qmpc_ref_kernel (wave per instance, dense 12x12 stage algebra)")),
                         "mean_iterations": float(inf_l["iterations"].mean()),

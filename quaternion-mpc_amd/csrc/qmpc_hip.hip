@@ -123,8 +123,8 @@ constexpr int kLaneMinBatchOther = 18432;
 // average, 17 at most, against 13.6 / 23 of the random states of the plain-solve benchmark): 32768 robots 7.47 -> 7.96 M
 // robot-ticks/s, 65536: 11.98 -> 12.76 M (caps 10 .. 13 scanned, tools/loop_bench.py; QMPC_LANE_CAP_LOOP=0 switches it off)
 constexpr int kLaneCapLoopBase = 11;
-constexpr int kLaneRefMinBatch = 36864;      // N <= 12: the wave kernels try four step lengths per rollout (32768: 3.17 vs 2.81 M, 40960: 3.19 vs 3.46 M)
-constexpr int kLaneRefMinBatchLong = 24576;   // horizons beyond 12 (N=20: 16384: 0.83 vs 1.14 M on the wave kernels, 32768: 1.47 vs 1.15 M)
+constexpr int kLaneRefMinBatch = 32768;      // N <= 12: wave kernels (four step lengths per rollout) 3.29 M at 32768, lane kernel (two per sweep) 3.35 M
+constexpr int kLaneRefMinBatchLong = 22528;   // horizons beyond 12 (N=20: wave kernels 1.14-1.18 M; lane kernel 18.3 ms up to 32768 instances: 1.79 M there)
 
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \

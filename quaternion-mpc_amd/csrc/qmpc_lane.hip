@@ -199,7 +199,7 @@ __device__ __noinline__ void call_C_AL(PassArgs a, QL_PRIV_AS const LaneK<NL>* K
   priv_store(alp, al);
 }
 template <int NL>
-__device__ __noinline__ void call_A_AL(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp) {
+__device__ __noinline__ void call_A_AL(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp, int sel) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
   const WsOff O = make_wsoff<NL>(P.N);
@@ -207,7 +207,7 @@ __device__ __noinline__ void call_A_AL(PassArgs a, QL_PRIV_AS const LaneK<NL>* K
   priv_load(K, Kp);
   LaneState st;
   priv_load(st, sp);
-  pass_A_AL<NL>(P, c, O, K, st);
+  pass_A_AL<NL>(P, c, O, K, st, sel);
 }
 template <int NL>
 __device__ __noinline__ void call_S(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp, QL_PRIV_AS LaneAL* alp) {
@@ -272,19 +272,17 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_ref_kernel(int pslot, con
       int ls = 0;
       while (__any(searching)) {
         if (searching) {
-          call_C_AL<NL>(a, Kp, sp, alp);
-          const double expected = al.alpha * al.dV1;
-          const double slack = 1e-12 * fmax(1.0, fabs(al.J));
-          if (isfinite(al.Jn) && al.Jn - al.J <= 1e-4 * expected + slack) { accepted = true; searching = false; }
+          call_C_AL<NL>(a, Kp, sp, alp);                  // trials ls and ls + 1 (step lengths alpha, alpha / 2) in one sweep
+          if (al_accept_pair(P, al, ls)) { accepted = true; searching = false; }
           else {
-            al.alpha *= 0.5;
-            if (++ls > P.linesearch_max) searching = false;
+            ls += 2;
+            if (ls > P.linesearch_max) searching = false;
           }
         }
       }
       if (active && !accepted) { st.status = QMPC_LINESEARCH_FAIL; --iter; active = false; }
       if (active) {
-        call_A_AL<NL>(a, Kp, sp);
+        call_A_AL<NL>(a, Kp, sp, al.sel);
         st.last_step = al.stp;
         const double dJ = al.J - al.Jn;
         al.J = al.Jn; al.Jp = al.Jnp; al.viol = al.vn;

@@ -966,8 +966,10 @@ struct LaneAL {
   double dV1;               // expected decrease of a full step (pass B)
   double alpha;             // step length of the line-search trial
   double Jn, Jnp, vn, stp;  // the trial's merit, plain objective, violation, largest input increment
+  double Jn2, Jnp2, vn2, stp2;  // ... and those of the second trial of the same pass (step length alpha / 2)
   double stat;              // stationarity |grad_U L_A|_inf (pass S)
   int searching;            // this lane's line search is still running (its trial increments may be overwritten)
+  int sel;                  // which of the pass's two trials was accepted: its increments are in the dU slot (0) or the RC slot (1)
 };
 template <int NL, bool WARM = false, int MD = MD_QUAT, bool AL = false>
 QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const LaneK<NL>& K, LaneState& st, FootPtr fp,
@@ -1885,8 +1887,9 @@ QL_FN void pass_M(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
 
 // ---- pass A_AL: apply the accepted increment of the line search and roll the states out open loop ----------------------
 template <int NL>
-QL_FN void pass_A_AL(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, const LaneState& st) {
+QL_FN void pass_A_AL(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, const LaneState& st, int sel = 0) {
   const int N = P.N;
+  const int dsl = sel ? O.RC : O.dU;      // the accepted trial's increments (per lane: see pass_C_AL)
   const double gb[3] = {K.rot[6] * (-9.81), K.rot[7] * (-9.81), K.rot[8] * (-9.81)};
   const unsigned order = any_stance<NL>(st.con);
   double x[13], xn[13];
@@ -1897,7 +1900,7 @@ QL_FN void pass_A_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       uk[3 * l + a] = c.W(O.U + 3 * NL * k + 3 * l + a);
-      dk[3 * l + a] = c.W(O.dU + 3 * NL * k + 3 * l + a);
+      dk[3 * l + a] = c.W(dsl + 3 * NL * k + 3 * l + a);
     }
   };
 #pragma unroll
@@ -1930,17 +1933,25 @@ QL_FN void pass_A_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
 
 // ---- pass C_AL: one trial of the line search -- closed-loop rollout at step length al.alpha, the trial's increments
 // (stored while `live`), its merit, violation and largest increment ---------------------------------------------------------
-template <int NL>
+// NA = 2: TWO trials of the backtracking line search in one sweep, step lengths alpha and alpha / 2.  They share the loads (old
+// state, gains, inputs, multipliers) and the per-point blocks (weights, frame, L D L': functions of the current inputs only);
+// the rollout, the input recovery and the merit terms run once per step length.  The increments of the second trial go to the
+// RC slot (unused in this mode), 3 NL per knot like the dU slot.
+template <int NL, int NA = 2>
 QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, const LaneState& st, LaneAL& al, bool live) {
   typedef LDim<NL> D;
   const int N = P.N;
   const double gb[3] = {K.rot[6] * (-9.81), K.rot[7] * (-9.81), K.rot[8] * (-9.81)};
   double cr[18];
   cone_rows(P, K.rot, cr);
-  const double alpha = al.alpha;
-  double xc[13], xn[13];
+  double alpha[NA];
+  alpha[0] = al.alpha;
+  if (NA > 1) alpha[NA - 1] = 0.5 * al.alpha;
+  double xc[NA][13], xn[13];
 #pragma unroll
-  for (int i = 0; i < 13; ++i) xc[i] = c.W(O.X + i);
+  for (int q = 0; q < NA; ++q)
+#pragma unroll
+    for (int i = 0; i < 13; ++i) xc[q][i] = c.W(O.X + i);
   const unsigned order = any_stance<NL>(st.con);
   // old state, gains, inputs and multipliers of a knot are fetched one knot ahead, into the registers just consumed
   double xo[13], gn[D::GAIN], uk[3 * NL], lk[6 * NL];
@@ -1959,39 +1970,49 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
   load_head(0);
 #pragma unroll
   for (int l = 0; l < NL; ++l) if ((order >> l) & 1u) load_leg(0, l);
-  double Jp = 0.0, alsum = 0.0, viol = 0.0, stp = 0.0;
-  bool bad = false;
+  double Jp[NA], alsum[NA], viol[NA], stp[NA];
+  bool bad[NA];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) { Jp[q] = 0.0; alsum[q] = 0.0; viol[q] = 0.0; stp[q] = 0.0; bad[q] = false; }
   for (int k = 0; k < N; ++k) {
     const int kn = (k + 1 < N) ? k + 1 : k;
-    Jp += al_state_cost(P, K.refp, k, xc);
-    double dx[12];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      dx[a] = xc[a] - xo[a];
-      dx[6 + a] = xc[7 + a] - xo[7 + a];
-      dx[9 + a] = xc[10 + a] - xo[10 + a];
-    }
+    double zeta[NA][6];
     {
       double G[12];
       quatG(&xo[3], G);
-      const double isc = ql_rcp(xo[3] * xc[3] + xo[4] * xc[4] + xo[5] * xc[5] + xo[6] * xc[6]);
 #pragma unroll
-      for (int a = 0; a < 3; ++a) dx[3 + a] = (G[a] * xc[3] + G[3 + a] * xc[4] + G[6 + a] * xc[5] + G[9 + a] * xc[6]) * isc;
-    }
-    double zeta[6];
+      for (int q = 0; q < NA; ++q) {
+        Jp[q] += al_state_cost(P, K.refp, k, xc[q]);
+        double dx[12];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) zeta[i] = alpha * gn[36 + i];
+        for (int a = 0; a < 3; ++a) {
+          dx[a] = xc[q][a] - xo[a];
+          dx[6 + a] = xc[q][7 + a] - xo[7 + a];
+          dx[9 + a] = xc[q][10 + a] - xo[10 + a];
+        }
+        const double isc = ql_rcp(xo[3] * xc[q][3] + xo[4] * xc[q][4] + xo[5] * xc[q][5] + xo[6] * xc[q][6]);
 #pragma unroll
-    for (int j = 0; j < 12; ++j)
+        for (int a = 0; a < 3; ++a)
+          dx[3 + a] = (G[a] * xc[q][3] + G[3 + a] * xc[q][4] + G[6 + a] * xc[q][5] + G[9 + a] * xc[q][6]) * isc;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        float g0, g1;
-        unpack2f(gn[3 * j + i], g0, g1);
-        zeta[2 * i] += (double)g0 * dx[j];
-        zeta[2 * i + 1] += (double)g1 * dx[j];
+        for (int i = 0; i < 6; ++i) zeta[q][i] = alpha[q] * gn[36 + i];
+#pragma unroll
+        for (int j = 0; j < 12; ++j)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            float g0, g1;
+            unpack2f(gn[3 * j + i], g0, g1);
+            zeta[q][2 * i] += (double)g0 * dx[j];
+            zeta[q][2 * i + 1] += (double)g1 * dx[j];
+          }
       }
+    }
     load_head(kn);
-    double F[3] = {0, 0, 0}, wd[3] = {K.wd0[0], K.wd0[1], K.wd0[2]};
+    double F[NA][3], wd[NA][3];
+#pragma unroll
+    for (int q = 0; q < NA; ++q)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { F[q][a] = 0.0; wd[q][a] = K.wd0[a]; }
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       if (!((order >> l) & 1u)) continue;       // wave-uniform
@@ -2015,41 +2036,54 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
       leg_bw0(P, &K.foot[3 * l], B);
       LegBlk lb;
       leg_block(P, cr, rcl, l, sv, lv, 0u, 1.0, 0.0, u, st.uz, lb);
-      // rhs = T'(zeta_f + Bw0' zeta_t) + alpha gq;  du = -T Db^-1 rhs
-      double t[3], rh[3];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) t[a] = zeta[a] + B[a] * zeta[3] + B[3 + a] * zeta[4] + B[6 + a] * zeta[5];
+      for (int q = 0; q < NA; ++q) {
+        // rhs = T'(zeta_f + Bw0' zeta_t) + alpha gq;  du = -T Db^-1 rhs
+        double t[3], rh[3];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) rh[a] = lb.T[a] * t[0] + lb.T[3 + a] * t[1] + lb.T[6 + a] * t[2] + alpha * lb.gq[a];
-      const double y0 = rh[0], y1 = rh[1] - lb.l10 * y0, y2 = rh[2] - lb.l20 * y0 - lb.l21 * y1;
-      const double z2 = y2 * lb.id2;
-      const double z1 = y1 * lb.id1 - lb.l21 * z2;
-      const double z0 = y0 * lb.id0 - lb.l10 * z1 - lb.l20 * z2;
-      double un[3];
+        for (int a = 0; a < 3; ++a) t[a] = zeta[q][a] + B[a] * zeta[q][3] + B[3 + a] * zeta[q][4] + B[6 + a] * zeta[q][5];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const double du = -(lb.T[3 * a] * z0 + lb.T[3 * a + 1] * z1 + lb.T[3 * a + 2] * z2);
-        stp = fmax(stp, fabs(du));
-        bad = bad || !(fabs(du) <= 1e300);
-        un[a] = u[a] + du;
-        if (live) c.W(O.dU + 3 * NL * k + 3 * l + a) = du;
-      }
-      Jp += al_point_terms(P, cr, l, un, st.uz, lam, al.rho, alsum, viol);
+        for (int a = 0; a < 3; ++a) rh[a] = lb.T[a] * t[0] + lb.T[3 + a] * t[1] + lb.T[6 + a] * t[2] + alpha[q] * lb.gq[a];
+        const double y0 = rh[0], y1 = rh[1] - lb.l10 * y0, y2 = rh[2] - lb.l20 * y0 - lb.l21 * y1;
+        const double z2 = y2 * lb.id2;
+        const double z1 = y1 * lb.id1 - lb.l21 * z2;
+        const double z0 = y0 * lb.id0 - lb.l10 * z1 - lb.l20 * z2;
+        double un[3];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        F[a] += un[a];
-        wd[a] += B[3 * a] * un[0] + B[3 * a + 1] * un[1] + B[3 * a + 2] * un[2];
+        for (int a = 0; a < 3; ++a) {
+          const double du = -(lb.T[3 * a] * z0 + lb.T[3 * a + 1] * z1 + lb.T[3 * a + 2] * z2);
+          stp[q] = fmax(stp[q], fabs(du));
+          bad[q] = bad[q] || !(fabs(du) <= 1e300);
+          un[a] = u[a] + du;
+          if (live) c.W((q == 0 ? O.dU : O.RC) + 3 * NL * k + 3 * l + a) = du;
+        }
+        Jp[q] += al_point_terms(P, cr, l, un, st.uz, lam, al.rho, alsum[q], viol[q]);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          F[q][a] += un[a];
+          wd[q][a] += B[3 * a] * un[0] + B[3 * a + 1] * un[1] + B[3 * a + 2] * un[2];
+        }
       }
     }
-    srbd_step_fw(P, gb, xc, F, wd, xn);
 #pragma unroll
-    for (int i = 0; i < 13; ++i) xc[i] = xn[i];
+    for (int q = 0; q < NA; ++q) {
+      srbd_step_fw(P, gb, xc[q], F[q], wd[q], xn);
+#pragma unroll
+      for (int i = 0; i < 13; ++i) xc[q][i] = xn[i];
+    }
   }
-  Jp += al_state_cost(P, K.refp, N, xc);
-  al.Jnp = Jp;
-  al.vn = viol;
-  al.stp = stp;
-  al.Jn = bad ? (double)NAN : Jp + alsum / (2.0 * al.rho);
+#pragma unroll
+  for (int q = 0; q < NA; ++q) Jp[q] += al_state_cost(P, K.refp, N, xc[q]);
+  al.Jnp = Jp[0];
+  al.vn = viol[0];
+  al.stp = stp[0];
+  al.Jn = bad[0] ? (double)NAN : Jp[0] + alsum[0] / (2.0 * al.rho);
+  if (NA > 1) {
+    al.Jnp2 = Jp[NA - 1];
+    al.vn2 = viol[NA - 1];
+    al.stp2 = stp[NA - 1];
+    al.Jn2 = bad[NA - 1] ? (double)NAN : Jp[NA - 1] + alsum[NA - 1] / (2.0 * al.rho);
+  }
 }
 
 // ---- pass S: |grad_U L_A|_inf at (X, U) through the costate recursion  y_k = lx_k + Abar_k' y_{k+1},
@@ -2223,11 +2257,25 @@ QL_FN void lane_setup_ref(const DevParams& P, const Ctx& c, const WsOff& O, cons
   al.rho = P.penalty_initial;
   al.irho = 1.0 / al.rho;
   al.J = 0.0; al.Jp = 0.0; al.viol = 0.0; al.dV1 = 0.0; al.alpha = 1.0; al.Jn = 0.0; al.Jnp = 0.0; al.vn = 0.0; al.stp = 0.0;
-  al.stat = 0.0; al.searching = 0;
+  al.Jn2 = 0.0; al.Jnp2 = 0.0; al.vn2 = 0.0; al.stp2 = 0.0;
+  al.stat = 0.0; al.searching = 0; al.sel = 0;
 }
 
 // ---- the whole reference-mode solve of one lane (host build: tests; the kernel runs the same steps in lock step,
 // qmpc_lane.hip) -------------------------------------------------------------------------------------------------------------
+// Armijo test of the two trials of one pass_C_AL sweep, in the order of the backtracking sequence (trial ls at al.alpha, trial
+// ls + 1 at half of it, the second only while ls + 1 <= linesearch_max).  Accepted: al.alpha / Jn / Jnp / vn / stp are those of
+// the accepted trial and al.sel names its increments; rejected: al.alpha is the step length of trial ls + 2.
+QL_FN bool al_accept_pair(const DevParams& P, LaneAL& al, int ls) {
+  const double slack = 1e-12 * fmax(1.0, fabs(al.J));
+  if (isfinite(al.Jn) && al.Jn - al.J <= 1e-4 * (al.alpha * al.dV1) + slack) { al.sel = 0; return true; }
+  if (ls + 1 <= P.linesearch_max && isfinite(al.Jn2) && al.Jn2 - al.J <= 1e-4 * (0.5 * al.alpha * al.dV1) + slack) {
+    al.alpha *= 0.5; al.Jn = al.Jn2; al.Jnp = al.Jnp2; al.vn = al.vn2; al.stp = al.stp2; al.sel = 1;
+    return true;
+  }
+  al.alpha *= 0.25;
+  return false;
+}
 template <int NL>
 QL_FN void lane_solve_ref(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st) {
   LaneAL al;
@@ -2242,15 +2290,12 @@ QL_FN void lane_solve_ref(const DevParams& P, const Ctx& c, const WsOff& O, cons
     if (!pass_B<NL, false, MD_QUAT, true>(P, c, O, K, st, (FootPtr)K.foot, &al)) { st.status = QMPC_NOT_PD; --iter; break; }
     al.alpha = 1.0;
     bool accepted = false;
-    for (int ls = 0; ls <= P.linesearch_max; ++ls) {
-      pass_C_AL<NL>(P, c, O, K, st, al, true);
-      const double expected = al.alpha * al.dV1;
-      const double slack = 1e-12 * fmax(1.0, fabs(al.J));
-      if (isfinite(al.Jn) && al.Jn - al.J <= 1e-4 * expected + slack) { accepted = true; break; }
-      al.alpha *= 0.5;
+    for (int ls = 0; ls <= P.linesearch_max && !accepted; ls += 2) {
+      pass_C_AL<NL>(P, c, O, K, st, al, true);          // trials ls and ls + 1
+      accepted = al_accept_pair(P, al, ls);
     }
     if (!accepted) { st.status = QMPC_LINESEARCH_FAIL; --iter; break; }
-    pass_A_AL<NL>(P, c, O, K, st);
+    pass_A_AL<NL>(P, c, O, K, st, al.sel);
     st.last_step = al.stp;
     const double dJ = al.J - al.Jn;
     al.J = al.Jn; al.Jp = al.Jnp; al.viol = al.vn;
