@@ -245,8 +245,8 @@ qmpc_status qmpc_solve_warm_device(qmpc_handle* h, int32_t batch, const qmpc_inp
  * problem to the same KKT point but round differently: forces agree to ~1e-10 N across a threshold (tested to 1e-7 N),
  * bit for bit within a family and for a shard of a batch against the whole batch.  Their device buffers are allocated on
  * the first call that needs them, sized by max_batch, and held until qmpc_destroy: the lane kernel's workspace (<= 1024
- * wavefronts x 0.84 MB at N=10: 0.86 GB) and the state records of the straggler hand-off (8 + 60 N doubles per instance
- * of max_batch: 320 MB at 65536 x N=10) -- create the handle with the max_batch you mean to use. */
+ * wavefronts x 0.84 MB at N=10: 0.86 GB) and the state records of the straggler hand-off (8 + 84 N doubles per instance
+ * of max_batch: 445 MB at 65536 x N=10) -- create the handle with the max_batch you mean to use. */
 qmpc_status qmpc_solve_device(qmpc_handle* h, int32_t batch, const qmpc_input* d_in,
                               double* d_forces_body, qmpc_info* d_info, void* stream);
 qmpc_status qmpc_wait(qmpc_handle* h);

@@ -103,6 +103,7 @@ struct qmpc_handle {
   int hstate_cap;
   int lane_ref_min;            // reference-mode batches from this size on take the lane kernel (env QMPC_LANE_REF_MIN)
   int lane_cap;                // straggler hand-off: iteration cap of the lane kernel in cold plain solves (0: off; env QMPC_LANE_CAP)
+  int lane_cap_warm;           // ... and in warm-started solves of the closed loop (env QMPC_LANE_CAP_WARM; 0: off)
   int lane_cap_loop;           // ... and in the solves of a cold-started closed loop (in-gait states need fewer iterations; env QMPC_LANE_CAP_LOOP)
 };
 
@@ -123,6 +124,10 @@ constexpr int kLaneMinBatchOther = 18432;
 // average, 17 at most, against 13.6 / 23 of the random states of the plain-solve benchmark): 32768 robots 7.47 -> 7.96 M
 // robot-ticks/s, 65536: 11.98 -> 12.76 M (caps 10 .. 13 scanned, tools/loop_bench.py; QMPC_LANE_CAP_LOOP=0 switches it off)
 constexpr int kLaneCapLoopBase = 11;
+// ... and in its warm-started ticks (5.7 iterations on average, 13-17 at most; the records then carry the rows' initial slack
+// residuals): 32768 robots 8.45 -> 9.97 M robot-ticks/s, 65536: 14.5 -> 15.9 M; N=20: 3.44 -> 4.45 M, 5.87 -> 6.86 M (caps 5 .. 10
+// scanned; QMPC_LANE_CAP_WARM=0 switches it off)
+constexpr int kLaneCapWarm = 8;
 constexpr int kLaneRefMinBatch = 32768;      // N <= 12: wave kernels (four step lengths per rollout) 3.29 M at 32768, lane kernel (two per sweep) 3.35 M
 constexpr int kLaneRefMinBatchLong = 22528;   // horizons beyond 12 (N=20: wave kernels 1.14-1.18 M; lane kernel 18.3 ms up to 32768 instances: 1.79 M there)
 
@@ -364,6 +369,8 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     h->lane_cap = lc ? std::atoi(lc) : 15 + N / 10;
     const char* lcl = std::getenv("QMPC_LANE_CAP_LOOP");
     h->lane_cap_loop = lcl ? std::atoi(lcl) : kLaneCapLoopBase + N / 10;
+    const char* lcw = std::getenv("QMPC_LANE_CAP_WARM");
+    h->lane_cap_warm = lcw ? std::atoi(lcw) : kLaneCapWarm;
     const char* ls = std::getenv("QMPC_LANE_SORT");
     h->lane_sort = ls ? std::atoi(ls) : 1;
     // the lane kernel reads its parameters from a constant-memory table with one slot per LIVE handle (a slot is rewritten
@@ -455,9 +462,9 @@ static qmpc_status ensure_lane_buffers(qmpc_handle* h) {
   }
   return QMPC_OK;
 }
-// Hand-off buffers, on first use.  One state record (8 + 60 N doubles) per instance of the handle's capacity: 8-10 % of a batch
+// Hand-off buffers, on first use.  One state record (8 + 84 N doubles) per instance of the handle's capacity: 8-10 % of a batch
 // is handed over in the measured workloads, but WHICH record an instance gets is decided by an atomic counter, so only room
-// for all of them keeps the results independent of timing (320 MB at 65536 x N=10, 1.3 GB at 262144 x N=10; held until
+// for all of them keeps the results independent of timing (445 MB at 65536 x N=10, 1.8 GB at 262144 x N=10; held until
 // qmpc_destroy, like the lane kernel's workspace).  If the memory is not there the hand-off is switched off for this handle.
 static bool ensure_handoff_buffers(qmpc_handle* h) {
   if (h->d_handoff) return true;
@@ -470,6 +477,7 @@ static bool ensure_handoff_buffers(qmpc_handle* h) {
     h->d_handoff = nullptr; h->d_hstate = nullptr;
     h->lane_cap = 0;
     h->lane_cap_loop = 0;
+    h->lane_cap_warm = 0;
     return false;
   }
   return true;
@@ -1147,9 +1155,16 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
       hipLaunchKernelGGL(qmpc_loop_front_kernel, dim3(blocks), dim3(64), 0, s, LP, d_states, h->d_in, h->d_loop_row, (int)batch);
     HIP_TRY(hipGetLastError());
     if (warm && use_lane(h, batch, nullptr, nullptr)) {
+      // straggler hand-off of the warm-started ticks (not the cold first one): the records carry the rows' initial residuals
+      const int wcap = (!first && h->variant == 0 && h->wform && h->params.model == QMPC_MODEL_QUAT && h->d_handoff &&
+                        h->lane_cap_warm > 0 && h->lane_cap_warm < h->params.iterations_max) ? h->lane_cap_warm : 0;
+      const int wv = wcap ? (h->lds_bytes_w <= 40 * 1024 ? 3 : (h->lds_bytes_wg <= 40 * 1024 ? 5 : 0)) : 0;
       const qmpc_status st = launch_lane(h, batch, h->d_in, h->d_forces, h->d_info, s, first ? nullptr : h->d_traj_u, h->d_traj_u,
-                                         /*check_prev=*/1);
+                                         /*check_prev=*/1, nullptr, wv ? wcap : 0);
       if (st != QMPC_OK) return st;
+      if (wv)
+        HIP_TRY(qmpc_wform_launch_list(wv, 1024, variant_lds(h, wv), s, &h->dev, sizeof h->dev, h->d_in, h->d_forces, h->d_info, h->d_traj_u,
+                                       nullptr, h->d_handoff + 64, h->d_handoff, variant_gws(h, wv), h->d_hstate, h->hstate_cap));
     } else if (warm) {
       const int var = body_variant(h, batch);
       HIP_TRY(qmpc_warm_launch(var, convex ? 1 : 0, (int)batch, variant_lds(h, var), s, &h->dev, sizeof h->dev, h->d_in, first ? nullptr : h->d_traj_u,
@@ -1216,7 +1231,7 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
     h->lane_params_resident = true;
     static const bool order_env = [] { const char* e = std::getenv("QMPC_LANE_ORDER_PREV"); return !e || e[0] != '0'; }();
     h->lane_order_prev = order_env;
-    if (!warm && h->lane_cap_loop > 0 && h->params.mode == QMPC_MODE_CONVERGED) (void)ensure_handoff_buffers(h);      // not capturable either
+    if ((warm ? h->lane_cap_warm : h->lane_cap_loop) > 0 && h->params.mode == QMPC_MODE_CONVERGED) (void)ensure_handoff_buffers(h);      // not capturable either
   }
   if (warm) {                            // the cold first tick is not the tick the graph repeats
     const qmpc_status st = one_tick(true);

@@ -306,12 +306,12 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_ref_kernel(int pslot, con
 }
 
 // Straggler hand-off (four-point QuatMpc, cold launches): the state of an instance that reached the iteration cap, for
-// the wave-per-instance kernel to CONTINUE from (qmpc_wform_body.inc) -- one record of 8 + 60 N doubles:
+// the wave-per-instance kernel to CONTINUE from (qmpc_wform_body.inc) -- one record of 8 + 84 N doubles:
 // rho, last alpha_p, last alpha_d, last full step, iterations done, 3 spare; U [N][12]; slacks [N][24] (the Tapia flag in
-// the sign); multipliers [N][24].  The state is that of the top of the next iteration (the step applied, the barrier
+// the sign); multipliers [N][24]; initial slack residuals [N][24] (warm-started launches; flag in slot 5).  The state is that of the top of the next iteration (the step applied, the barrier
 // parameter not yet evaluated), which is where the wave kernel's loop begins.
 template <int NL>
-__device__ __noinline__ void call_dump(PassArgs a, QL_PRIV_AS const LaneState* sp, unsigned long long out) {
+__device__ __noinline__ void call_dump(PassArgs a, QL_PRIV_AS const LaneState* sp, unsigned long long out, int warm) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
   const WsOff O = make_wsoff<NL>(P.N);
@@ -319,13 +319,16 @@ __device__ __noinline__ void call_dump(PassArgs a, QL_PRIV_AS const LaneState* s
   priv_load(st, sp);
   double* o = reinterpret_cast<double*>(out);
   const int N = P.N;
-  o[0] = st.rho; o[1] = st.last_ap; o[2] = st.last_ad; o[3] = st.last_step; o[4] = (double)st.iters; o[5] = 0.0; o[6] = 0.0; o[7] = 0.0;
+  o[0] = st.rho; o[1] = st.last_ap; o[2] = st.last_ad; o[3] = st.last_step; o[4] = (double)st.iters; o[5] = warm ? 1.0 : 0.0; o[6] = 0.0; o[7] = 0.0;
   for (int i = 0; i < 3 * NL * N; ++i) o[8 + i] = c.W(O.U + i);
   for (int i = 0; i < 6 * NL * N; ++i) {
     const bool on = (st.con >> ((i % (6 * NL)) / 6)) & 1u;
     o[8 + 3 * NL * N + i] = on ? c.W(O.S + i) : 1.0;
     o[8 + 9 * NL * N + i] = on ? c.W(O.LAM + i) : 0.0;
   }
+  // a warm-started launch carries the rows' initial slack residuals per knot (rc_i = rho rc0_i): they travel too
+  if (warm)
+    for (int i = 0; i < 6 * NL * N; ++i) o[8 + 15 * NL * N + i] = c.W(O.RC + i);
 }
 
 template <int NL, int MD = MD_QUAT>
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
     if (NL == 4 && hcount && valid && itmax < P.iterations_max && st.status == QMPC_MAX_ITER) {
       const int ord = atomicAdd(hcount, 1);
       hsel[ord] = b;
-      if (ord < hcap) call_dump<NL>(a, sp, reinterpret_cast<unsigned long long>(hstate + (size_t)ord * (8 + 60 * (size_t)P.N)));
+      if (ord < hcap) call_dump<NL>(a, sp, reinterpret_cast<unsigned long long>(hstate + (size_t)ord * (8 + 84 * (size_t)P.N)), warm ? 1 : 0);
     }
 #if defined(QL_PROFILE)
     if (prof && base < (long long)slots) {      // first round of every wave; lane 0's clock, every lane's own iteration count
@@ -496,7 +499,7 @@ __attribute__((visibility("hidden"))) size_t qmpc_lane_ws_bytes(int N, int nl, u
 __attribute__((visibility("hidden"))) size_t qmpc_lane_scratch_bytes(int batch) { return sizeof(int) * (512 + (size_t)batch); }
 // hand-off list of a capped launch: count | instance indices [batch]; the state records live in their own buffer
 __attribute__((visibility("hidden"))) size_t qmpc_lane_handoff_list_bytes(int batch) { return sizeof(int) * (64 + (size_t)batch); }
-__attribute__((visibility("hidden"))) size_t qmpc_lane_handoff_record_doubles(int N) { return 8 + 60 * (size_t)N; }
+__attribute__((visibility("hidden"))) size_t qmpc_lane_handoff_record_doubles(int N) { return 8 + 84 * (size_t)N; }
 
 // slots: resident lanes (multiple of 64); scratch: qmpc_lane_scratch_bytes(batch) bytes, or null for no sort
 // pslot: the handle's slot in the constant-memory parameter table (qmpc_lane_param_slots() of them); the block is copied

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64, WVAR == 5 ? 2 : 1) void qmpc_solve_w_list_kerne
   for (int i = blockIdx.x; i < count; i += gridDim.x) {
     const int b = sel[i];
     // the instance's state at the lane kernel's iteration cap (null: none was kept, start from scratch)
-    const double* resume = (hstate && i < hcap) ? hstate + (size_t)i * (8 + 60 * (size_t)P.N) : nullptr;
+    const double* resume = (hstate && i < hcap) ? hstate + (size_t)i * (8 + 84 * (size_t)P.N) : nullptr;
     [&]() {                            // `return` in the body (rejected input) ends this instance only
 #include "qmpc_wform_body.inc"
     }();

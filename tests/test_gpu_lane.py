@@ -398,40 +398,47 @@ def test_closed_loop_at_the_automatic_switch_over(pkg, lib):
     assert np.abs(st["pos_world"] - st["pos_world"][0]).max() < 1e-9      # identical robots, identical states
 
 
-@pytest.mark.parametrize("N", [10, 20])
-def test_closed_loop_hand_off_of_the_lane_kernels_stragglers(pkg, lib, monkeypatch, N):
+@pytest.mark.parametrize("N,warm", [(10, 0), (20, 0), (10, 1), (20, 1)])
+def test_closed_loop_hand_off_of_the_lane_kernels_stragglers(pkg, lib, monkeypatch, N, warm):
     """Cold-started closed loop beyond the switch-over: the lane kernel stops at `11 + N/10` iterations per tick and the wave
     kernel continues the robots that are left, inside the captured tick.  20480 robots with different commands, the default cap
     and a cap of 8 (below the 10 iterations an in-gait solve needs: nearly every robot is handed over at every tick) against
     the pure lane kernel (QMPC_LANE_CAP_LOOP=0): same statuses, iteration counts, forces within 1e-9 N and positions within
     1e-9 m after 30 ticks; two runs bit-identical, and the run in two halves equal to the run in one piece."""
+    # warm = 1: the warm-started loop (cap 8; the records carry the rows' initial slack residuals), low cap 4
     lp = pkg.default_loop_params(lib)
-    B = 20480
+    lp.warm_start = float(warm)
+    B = 28672 if (warm and N == 10) else 20480          # the warm-started loop takes the lane kernel from 26624 robots on at N <= 12
+    env, low = ("QMPC_LANE_CAP_WARM", "4") if warm else ("QMPC_LANE_CAP_LOOP", "8")
     rng = np.random.default_rng(5)
     cmds = np.zeros((B, 7))
     cmds[:, 0] = rng.uniform(-0.5, 0.5, B); cmds[:, 1] = rng.uniform(-0.2, 0.2, B); cmds[:, 2] = rng.uniform(0.26, 0.32, B)
     cmds[:, 5] = rng.uniform(-0.5, 0.5, B)
     st0 = pkg.loop_states(cmds, lp, height=0.3, yaw=rng.uniform(-3, 3, B), lib=lib)
     out = {}
-    for cap in ("0", "8", None):
+    for cap in ("0", low, None):
         if cap is None:
-            monkeypatch.delenv("QMPC_LANE_CAP_LOOP", raising=False)
+            monkeypatch.delenv(env, raising=False)
         else:
-            monkeypatch.setenv("QMPC_LANE_CAP_LOOP", cap)
-        s = pkg.Solver(pkg.default_params(N, pkg.MODE_CONVERGED, lib), B, device=0, lib=lib)
+            monkeypatch.setenv(env, cap)
+        prm = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
+        if warm:
+            prm.ipm_mu0 = 1e-6
+        s = pkg.Solver(prm, B, device=0, lib=lib)
         st = s.loop_run(st0, 3, lp)
         st["movement_mode"] = 1.0
         a = s.loop_run(st, 30, lp)
         if cap != "0":
             b = s.loop_run(st, 30, lp)
             assert a.tobytes() == b.tobytes()
-            h = s.loop_run(s.loop_run(st, 13, lp), 17, lp)
-            assert h.tobytes() == a.tobytes()
+            if not warm:          # (the first tick of a warm-started call is a cold one: split runs differ by design)
+                h = s.loop_run(s.loop_run(st, 13, lp), 17, lp)
+                assert h.tobytes() == a.tobytes()
         s.close()
         out[cap] = a
     p = out["0"]
-    assert (p["status"] == 0).all() and (p["iterations"] > 8).mean() > 0.9
-    for cap in ("8", None):
+    assert (p["status"] == 0).all() and (p["iterations"] > (4 if warm else 8)).mean() > 0.9
+    for cap in (low, None):
         q = out[cap]
         assert np.array_equal(p["status"], q["status"]) and (p["iterations"] == q["iterations"]).mean() > 0.999
         assert np.abs(p["forces_body"] - q["forces_body"]).max() < 1e-9 and np.abs(p["pos_world"] - q["pos_world"]).max() < 1e-9
