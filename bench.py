@@ -332,33 +332,34 @@ def main():
         return {"elapsed": elapsed, "kernel_ms": kernel_ms, "info": info, "forces": forces, "rec": rec,
                 "solver": solver, "d_in": d_in}
 
-    def kernel_name(batch, horizon=None):
-        """dominant kernel of a launch of `batch` instances (qmpc_hip.hip: launch_solve / wform_variant / use_lane)"""
+    def kernel_name(batch, horizon=None, slv=None):
+        """dominant kernel of a launch of `batch` instances: the LIBRARY's own answer (qmpc_query: launch_solve's choice for
+        this handle, incl. whether the straggler hand-off is available), not a re-derivation of its thresholds"""
         hz = N if horizon is None else horizon
-        default_min = ("26624" if hz <= 12 else "16384") if args.model == "quat" else "18432"
-        lane_min = int(os.environ.get("QMPC_LANE_MIN", default_min))
-        var = os.environ.get("QMPC_VARIANT", "0")
-        wf = int(os.environ.get("QMPC_WFORM", "1"))
-        if var == "4" or (var == "0" and batch >= lane_min):
-            cap = int(os.environ.get("QMPC_LANE_CAP", str(15 + hz // 10)))
-            handoff = var == "0" and args.model == "quat" and wf and cap > 0
-            return "qmpc_lane_kernel (lane per instance, wrench form)" + (
-                f"; stragglers beyond {cap} iterations continued by qmpc_solve_w_list_kernel (one call)" if handoff else "")
-        if args.model == "quat" and wf and var in ("0", "1"):
-            all_lds = batch <= 1024 and hz <= 10
-            if all_lds:
-                return "qmpc_solve_w_kernel<3> (wave per instance, wrench form, everything in LDS)"
-            if wf != 3:
-                return "qmpc_solve_w_kernel<5> (wave per instance, wrench form, gains in the workspace)"
-        return "qmpc_solve_kernel (wave per instance, dense 12x12 stage algebra)"
+        own = slv is None
+        if own:
+            prm_ = (pkg.default_biped8_params if biped else (pkg.default_convex_params if convex else pkg.default_params))(hz, pkg.MODE_CONVERGED, lib)
+            slv = pkg.Solver(prm_, batch, device=local, lib=lib)
+        fam = slv.kernel_for_batch(batch)
+        cap = slv.query(pkg.QUERY_LANE_CAP, 1)
+        if own:
+            slv.close()
+        return {"lane_handoff": f"qmpc_lane_kernel (lane per instance, wrench form); stragglers beyond {cap} iterations continued by "
+                                "qmpc_solve_w_list_kernel (one call)",
+                "lane": "qmpc_lane_kernel (lane per instance, wrench form)",
+                "wform_lds": "qmpc_solve_w_kernel<3> (wave per instance, wrench form, everything in LDS)",
+                "wform_ws": "qmpc_solve_w_kernel<5> (wave per instance, wrench form, gains in the workspace)",
+                "dense_lds": "qmpc_solve_kernel<0> (wave per instance, dense 12x12 stage algebra, everything in LDS)",
+                "dense_ws": "qmpc_solve_kernel<1|2> (wave per instance, dense 12x12 stage algebra, gains in the workspace)"}[fam]
 
     def roofline_object(kname, ach, tr, tr_src, kms, batch, compulsory):
         """`frac` prices SURVEY 8d's algorithmic flops against the 78.6 TFLOP/s FP64 peak (the matrix and the vector FP64
-        rates of gfx950 are the same units).  `bound` says which instructions issue them in the dominant kernel: "mfma"
-        where FP64 MFMAs carry the stage products (the wave-per-instance kernels), "fp64_valu" for the lane-per-instance
-        kernel, whose ISA holds no matrix instruction (mfma_busy 0)."""
+        rates of gfx950 are the same units).  `bound` says which instructions issue them in the dominant kernel:
+        "fp64 (valu+mfma)" for the wave-per-instance kernels (FP64 MFMAs carry the row-mixing stage products, ~40 % of the
+        flops; the matrix pipe is 12-13 % busy), "fp64_valu" for the lane-per-instance kernel, whose ISA holds no matrix
+        instruction (mfma_busy 0)."""
         lane = kname.startswith("qmpc_lane_kernel")
-        o = {"bound": "fp64_valu" if lane else "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+        o = {"bound": "fp64_valu" if lane else "fp64 (valu+mfma)", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
              "frac": ach / FP64_PEAK_TFLOPS, "traffic": tr, "traffic_source": tr_src, "kernel": kname, "kernel_ms": kms,
              "algorithmic_bytes_per_launch": compulsory,
              "hbm_GBps": (tr / (kms * 1e-3) / 1e9) if tr else None,
@@ -413,7 +414,7 @@ def main():
                        "batch_per_gpu": B, "horizon": N, "parallelism": f"instance-sharded x{world}",
                        "instances": world * B, "converged": n_ok, "mean_iterations": mean_iters},
             "rates": {"device_resident": {"value": value, "unit": "solves/s", "ms_per_step": 1e3 * elapsed / args.steps}},
-            "roofline": roofline_object(kernel_name(B), achieved, traffic, traffic_src, kernel_ms, B,
+            "roofline": roofline_object(kernel_name(B, slv=solver), achieved, traffic, traffic_src, kernel_ms, B,
                                         B * (8 * (64 if biped else 48) + 8 * NU + 40)),
         }
         out["roofline"]["algorithmic_flops_per_launch"] = w_alg * B
@@ -433,19 +434,38 @@ def main():
             out["config"]["force_linf_vs_cpu"] = float(np.abs(d_f[idx] - fo).max())
         if world == 1:
             # the drop-in entry point as the controller calls it: HOST buffers, H2D + kernel + D2H, blocking
-            # (SURVEY 8d's definition of the metric; reported beside the resident figure, never `value`)
-            hsolve = solver.solve8 if biped else (solver.convex_solve if convex else solver.solve)
-            hsolve(rec)
-            reps = max(3, min(20, args.steps))
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                hsolve(rec)
-            dt = time.perf_counter() - t0
-            out["rates"]["host_buffer_call"] = {
-                "value": B * reps / dt, "unit": "solves/s", "ms_per_call": 1e3 * dt / reps,
-                "note": "qmpc_solve with pageable host buffers: H2D of the records + kernel + D2H of forces and status, blocking"}
+            # (SURVEY 8d's definition of the metric; reported beside the resident figure, never `value`).  Timed through
+            # the C ABI on caller-owned buffers, as a C++ host calls it: once with pinned buffers (qmpc_host_alloc: the
+            # library reads records / writes results in place, zero-copy) and once with pageable ones (staged by the handle)
+            hname = "qmpc_solve8" if biped else ("qmpc_convex_solve" if convex else "qmpc_solve")
+            hfn = getattr(lib, hname)
+            reps = max(20, min(200, args.steps * 4))
+            hb = {}
+            for kind in ("pinned", "pageable"):
+                if kind == "pinned":
+                    hin = solver.pinned((B, rec.dtype.itemsize), np.uint8)
+                    hf = solver.pinned((B, NU)); hi = solver.pinned((B,), pkg.INFO_DTYPE)
+                else:
+                    hin = np.empty((B, rec.dtype.itemsize), np.uint8)
+                    hf = np.zeros((B, NU)); hi = np.zeros(B, dtype=pkg.INFO_DTYPE)
+                hin[...] = rec.view(np.uint8).reshape(B, -1)
+                args_ = (solver._h, B, hin.ctypes.data, hf.ctypes.data, hi.ctypes.data)
+                for _ in range(3):
+                    assert hfn(*args_) == 0
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    hfn(*args_)
+                dt = time.perf_counter() - t0
+                assert np.array_equal(hf, d_f) and (hi["status"] == 0).sum() == n_ok, "host-buffer call differs from the resident one"
+                hb[kind] = {"value": B * reps / dt, "unit": "solves/s", "ms_per_call": 1e3 * dt / reps, "calls": reps}
+            out["rates"]["host_buffer_call"] = dict(hb["pinned"], note=(
+                f"{hname} on pinned host buffers (qmpc_host_alloc), blocking: records read from / forces and status written to host "
+                "memory by the kernel itself (zero-copy), one launch + one synchronisation; results bit-identical to the resident call"))
+            out["rates"]["host_buffer_call_pageable"] = dict(hb["pageable"], note=(
+                f"{hname} on pageable host buffers: one memcpy into / out of the handle's pinned staging around the same launch"))
             out["host_buffer_call"] = out["rates"]["host_buffer_call"]
             out["value_host_inclusive"] = out["rates"]["host_buffer_call"]["value"]     # SURVEY 8d's own definition of the metric
+            out["host_inclusive_over_resident"] = out["value_host_inclusive"] / value
         if world == 1 and args.model == "quat" and not args.no_large_batch and B == 1024 and N == 10:
             # secondary: the large-batch configurations of BASELINE.json on this GPU (the lane-per-instance kernel):
             # the per-GPU share of config 4 (32768 instances, N=10) and config 3 (65536 instances, N=20); never `value`
@@ -475,17 +495,18 @@ def main():
                 same2 = bool(torch.equal(o2[0], o2[1]))
                 s2.close()
                 del o2, i2
+                kn_l = kernel_name(Bl, Nl, slv=lg["solver"])
                 lg["solver"].close()
                 w_l = W_ALG_KFLOP_PER_KNOT * 1e3 * Nl
                 ach = w_l * Bl / (lg["kernel_ms"] * 1e-3) / 1e12
                 tr, tr_src = traffic_from_profiles(Bl, Nl, "quat")
                 ent = {"workload": f"Batch={Bl} random Go1 states, N={Nl}, seed 0x5EED0000+{cfg}: {what}",
                        "value": Bl * kl / lg["elapsed"], "unit": "solves/s", "steps": kl, "ms_per_step": 1e3 * lg["elapsed"] / kl,
-                       "kernel": kernel_name(Bl, Nl), "kernel_ms": lg["kernel_ms"],
+                       "kernel": kn_l, "kernel_ms": lg["kernel_ms"],
                        "converged": int((lg["info"]["status"] == 0).sum()), "mean_iterations": float(lg["info"]["iterations"].mean()),
                        "two_in_flight": {"value": Bl * 2 * kl / dt2, "unit": "solves/s", "ms_per_batch": 1e3 * dt2 / (2 * kl),
                                          "outputs_identical": same2},
-                       "roofline": roofline_object(kernel_name(Bl, Nl), ach, tr, tr_src, lg["kernel_ms"], Bl, Bl * (8 * 48 + 8 * 12 + 40))}
+                       "roofline": roofline_object(kn_l, ach, tr, tr_src, lg["kernel_ms"], Bl, Bl * (8 * 48 + 8 * 12 + 40))}
                 # the reference's own solver mode on the same batch (AL-iLQR, <= 10 iterations): the lane kernel's AL passes
                 # from 32768 instances on (22528 beyond N=12), the wave-per-instance reference kernels below
                 if not args.no_reference_mode:

@@ -28,6 +28,7 @@
 #ifndef QMPC_H_
 #define QMPC_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -252,11 +253,54 @@ qmpc_status qmpc_solve_device(qmpc_handle* h, int32_t batch, const qmpc_input* d
 qmpc_status qmpc_wait(qmpc_handle* h);
 
 /* Host buffers, NOT blocking: H2D copy, kernel and D2H copies are queued on the handle's stream and the call
- * returns; qmpc_wait(h) completes them.  `in`, `forces_body` and `info` must stay valid until then (pinned
- * host memory makes the copies truly asynchronous).  Lets the caller of the controller thread (Main.cpp:103-118)
- * do other work during the solve. */
+ * returns; qmpc_wait(h) completes them.  `in`, `forces_body` and `info` must stay valid until then, and `in` must not
+ * be modified before qmpc_wait when it is pinned (see below).  Lets the caller of the controller thread
+ * (Main.cpp:103-118) do other work during the solve. */
 qmpc_status qmpc_solve_async(qmpc_handle* h, int32_t batch, const qmpc_input* in,
                              double* forces_body, qmpc_info* info);
+
+/* How the host-buffer calls (qmpc_solve, qmpc_solve_traj, qmpc_solve_async, qmpc_convex_solve*, qmpc_solve8*) move their
+ * data -- SURVEY.md 8d's metric is exactly this call: records in host memory -> forces in host memory.
+ *   - Batches that take a wave-per-instance kernel (QuatMpc: up to 26623 instances) run ZERO-COPY: every wavefront reads
+ *     its 384-byte record from, and writes its forces / status record to, host memory the device can address.  Buffers
+ *     from qmpc_host_alloc (or hipHostMalloc / hipHostRegister) are used in place; pageable buffers go through pinned
+ *     staging the handle owns (one memcpy in, one out).  One launch, one synchronisation; results are bit-identical to
+ *     qmpc_solve_device.  QMPC_ZERO_COPY=0 restores explicit copies.
+ *   - Lane-kernel batches (which sort and re-read their records) use hipMemcpyAsync on the handle's stream; with pinned
+ *     buffers those copies are true DMA. */
+void*       qmpc_host_alloc(size_t bytes);      /* pinned, device-addressable host memory (NULL on failure) */
+void        qmpc_host_free(void* p);
+
+/* Allocate NOW whatever a solve (or closed loop) of up to `batch` instances on this handle needs later: the lane kernel's
+ * workspace (<= 0.86 GB at N=10), the state records of the straggler hand-off (8 + 84 N doubles per instance of max_batch),
+ * the pinned staging of the host-buffer calls.  After it returns no solve of up to `batch` instances allocates -- e.g.
+ * inside the caller's own stream capture -- and qmpc_query tells whether the hand-off is available.  Optional: without it
+ * the same buffers are allocated by the first call that needs them. */
+qmpc_status qmpc_prepare(qmpc_handle* h, int32_t batch);
+
+/* Handle state the results can depend on, and which kernel family a batch size selects. */
+enum qmpc_query_what {
+  QMPC_QUERY_HANDOFF_ACTIVE       = 1,  /* 1: lane-kernel batches hand their stragglers to the wave kernel (results: the
+                                           hand-off's rounding family); 0: pure lane kernel (switched off, another model / mode,
+                                           or the records could not be allocated -- ~1e-10 N apart, not bit-identical) */
+  QMPC_QUERY_HANDOFF_ALLOC_FAILED = 2,  /* 1: the records' allocation failed on this handle (also reported on stderr) */
+  QMPC_QUERY_KERNEL_FOR_BATCH     = 3,  /* arg = batch: the qmpc_kernel_family a plain solve of that size launches */
+  QMPC_QUERY_LAST_KERNEL          = 4,  /* family of the most recent solve launch */
+  QMPC_QUERY_LANE_CAP             = 5,  /* arg = 1 plain solve / 2 cold closed loop / 3 warm closed loop: iteration cap of the
+                                           capped lane launch (0: no hand-off) */
+  QMPC_QUERY_DEVICE_BYTES         = 6,  /* device memory the handle holds right now */
+  QMPC_QUERY_ZERO_COPY            = 7   /* 1: host-buffer calls of wave-kernel batches run zero-copy */
+};
+enum qmpc_kernel_family {
+  QMPC_KERNEL_NONE         = 0,
+  QMPC_KERNEL_WFORM_LDS    = 1,   /* wave per instance, wrench form, everything in LDS */
+  QMPC_KERNEL_WFORM_WS     = 2,   /* ... gains in the workspace */
+  QMPC_KERNEL_DENSE_LDS    = 3,   /* wave per instance, dense 12x12 stage algebra (round-1 family), everything in LDS */
+  QMPC_KERNEL_DENSE_WS     = 4,   /* ... gains (and slack arrays) in the workspace */
+  QMPC_KERNEL_LANE         = 5,   /* lane per instance */
+  QMPC_KERNEL_LANE_HANDOFF = 6    /* lane per instance to an iteration cap, stragglers continued by the wave kernel */
+};
+qmpc_status qmpc_query(qmpc_handle* h, int32_t what, int64_t arg, int64_t* value);
 
 /* Multi-GPU: the single collective of the path.  All-gathers `count` doubles per rank (e.g. the
  * [B/G][12] force block, or forces + qmpc_info records laid out in one buffer) from every rank's `d_local` into

@@ -232,6 +232,14 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.qmpc_wait.restype = i32
     lib.qmpc_solve_async.argtypes = [vp, i32, vp, vp, vp]
     lib.qmpc_solve_async.restype = i32
+    lib.qmpc_host_alloc.argtypes = [C.c_size_t]
+    lib.qmpc_host_alloc.restype = vp
+    lib.qmpc_host_free.argtypes = [vp]
+    lib.qmpc_host_free.restype = None
+    lib.qmpc_prepare.argtypes = [vp, i32]
+    lib.qmpc_prepare.restype = i32
+    lib.qmpc_query.argtypes = [vp, i32, C.c_int64, C.POINTER(C.c_int64)]
+    lib.qmpc_query.restype = i32
     lib.qmpc_gather.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
     lib.qmpc_gather.restype = i32
     lib.qmpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -369,7 +377,16 @@ EXPORTED_SYMBOLS = (
     "qmpc_loop_joint_commands",
     "qmpc_solve_warm",
     "qmpc_solve_warm_device",
+    "qmpc_host_alloc",
+    "qmpc_host_free",
+    "qmpc_prepare",
+    "qmpc_query",
 )
+
+# enum qmpc_query_what / qmpc_kernel_family (include/qmpc.h)
+QUERY_HANDOFF_ACTIVE, QUERY_HANDOFF_ALLOC_FAILED, QUERY_KERNEL_FOR_BATCH, QUERY_LAST_KERNEL, QUERY_LANE_CAP, \
+    QUERY_DEVICE_BYTES, QUERY_ZERO_COPY = 1, 2, 3, 4, 5, 6, 7
+KERNEL_FAMILY = {0: "none", 1: "wform_lds", 2: "wform_ws", 3: "dense_lds", 4: "dense_ws", 5: "lane", 6: "lane_handoff"}
 
 
 def default_params(horizon: int = 10, mode: int = MODE_CONVERGED, lib: C.CDLL | None = None) -> Params:
@@ -448,6 +465,7 @@ class Solver:
         self.params = params.copy()
         self.max_batch = int(max_batch)
         self._h = C.c_void_p()
+        self._pinned = []
         st = self.lib.qmpc_create(C.byref(self.params), self.max_batch, device, C.byref(self._h))
         if st != OK:
             self._h = C.c_void_p()
@@ -458,6 +476,9 @@ class Solver:
         if h is not None and h.value:
             self._h = None
             self.lib.qmpc_destroy(h)
+        for p in getattr(self, "_pinned", []):
+            self.lib.qmpc_host_free(p)
+        self._pinned = []
 
     def __del__(self):
         try:                      # module globals may already be gone at interpreter shutdown
@@ -488,6 +509,39 @@ class Solver:
         if st != OK:
             raise QmpcError(st, "qmpc_solve")
         return forces, info
+
+    def prepare(self, batch: int | None = None):
+        """Allocate now what solves of up to `batch` instances need later (qmpc_prepare)."""
+        st = self.lib.qmpc_prepare(self._h, int(self.max_batch if batch is None else batch))
+        if st != OK:
+            raise QmpcError(st, "qmpc_prepare")
+
+    def query(self, what: int, arg: int = 0) -> int:
+        v = C.c_int64()
+        st = self.lib.qmpc_query(self._h, int(what), int(arg), C.byref(v))
+        if st != OK:
+            raise QmpcError(st, "qmpc_query")
+        return int(v.value)
+
+    def kernel_for_batch(self, batch: int) -> str:
+        return KERNEL_FAMILY[self.query(QUERY_KERNEL_FOR_BATCH, batch)]
+
+    def pinned(self, shape, dtype=np.float64) -> np.ndarray:
+        """Array in pinned, device-addressable host memory (qmpc_host_alloc); freed with the solver."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        p = self.lib.qmpc_host_alloc(max(n, 1))
+        if not p:
+            raise MemoryError("qmpc_host_alloc")
+        self._pinned.append(p)
+        buf = (C.c_char * max(n, 1)).from_address(p)
+        return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+    def solve_into(self, inputs: np.ndarray, forces: np.ndarray, info: np.ndarray | None = None):
+        """qmpc_solve on caller-owned buffers (no allocation, no conversion): the call a C host makes."""
+        st = self.lib.qmpc_solve(self._h, inputs.shape[0], _ptr(inputs), _ptr(forces), _ptr(info) if info is not None else None)
+        if st != OK:
+            raise QmpcError(st, "qmpc_solve")
 
     def solve_warm(self, inputs: np.ndarray, u_init: np.ndarray | None = None):
         """Warm-started solve: (forces [B,12], info, traj_u [B,N,12]); u_init = a previous traj_u (None: cold)."""

@@ -105,6 +105,16 @@ struct qmpc_handle {
   int lane_cap;                // straggler hand-off: iteration cap of the lane kernel in cold plain solves (0: off; env QMPC_LANE_CAP)
   int lane_cap_warm;           // ... and in warm-started solves of the closed loop (env QMPC_LANE_CAP_WARM; 0: off)
   int lane_cap_loop;           // ... and in the solves of a cold-started closed loop (in-gait states need fewer iterations; env QMPC_LANE_CAP_LOOP)
+  int handoff_failed;          // 1: the hand-off records could not be allocated -- this handle runs the pure lane kernel (qmpc_query)
+  int last_kernel;             // QMPC_KERNEL_* of the most recent solve launch (qmpc_query)
+  // host-buffer calls (qmpc_solve*, qmpc_solve_async): pinned staging owned by the handle.  Batches below the lane kernel's
+  // threshold are solved ZERO-COPY: the wavefront of an instance reads its 384-byte record from pinned host memory with its
+  // one coalesced load and writes forces / status straight back, so H2D, kernel and D2H are one launch and one
+  // synchronisation (records cross the link while other wavefronts compute)
+  unsigned char* h_stage_in;   // [max_batch] records
+  unsigned char* h_stage_out;  // [max_batch] (forces | info)
+  int zero_copy;               // env QMPC_ZERO_COPY (default 1)
+  struct { double* forces; qmpc_info* info; size_t fbytes, ibytes; } pending;   // copy-out owed to a pageable caller (qmpc_wait)
 };
 
 constexpr unsigned kLaneMaxSlots = 1024 * 64;   // one wavefront per SIMD of the chip
@@ -373,6 +383,8 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     h->lane_cap_warm = lcw ? std::atoi(lcw) : kLaneCapWarm;
     const char* ls = std::getenv("QMPC_LANE_SORT");
     h->lane_sort = ls ? std::atoi(ls) : 1;
+    const char* zc = std::getenv("QMPC_ZERO_COPY");
+    h->zero_copy = zc ? std::atoi(zc) : 1;
     // the lane kernel reads its parameters from a constant-memory table with one slot per LIVE handle (a slot is rewritten
     // before every launch of its handle, on that launch's stream): slots come from a free list and go back in
     // qmpc_destroy; a handle created while all of them are taken keeps the wave-per-instance kernels
@@ -394,6 +406,8 @@ void qmpc_destroy(qmpc_handle* h) {
   if (h->d_lane_scratch) (void)hipFree(h->d_lane_scratch);
   if (h->d_handoff) (void)hipFree(h->d_handoff);
   if (h->d_hstate) (void)hipFree(h->d_hstate);
+  if (h->h_stage_in) (void)hipHostFree(h->h_stage_in);
+  if (h->h_stage_out) (void)hipHostFree(h->h_stage_out);
   if (h->d_leg) (void)hipFree(h->d_leg);
   if (h->d_loop_row) (void)hipFree(h->d_loop_row);
   if (h->d_loop) (void)hipFree(h->d_loop);
@@ -468,13 +482,19 @@ static qmpc_status ensure_lane_buffers(qmpc_handle* h) {
 // qmpc_destroy, like the lane kernel's workspace).  If the memory is not there the hand-off is switched off for this handle.
 static bool ensure_handoff_buffers(qmpc_handle* h) {
   if (h->d_handoff) return true;
+  if (h->handoff_failed) return false;
   h->hstate_cap = h->max_batch;
   const size_t rec_bytes = sizeof(double) * qmpc_lane_handoff_record_doubles(h->params.horizon);
   if (hipMalloc(&h->d_handoff, qmpc_lane_handoff_list_bytes(h->max_batch)) != hipSuccess ||
       hipMalloc(&h->d_hstate, rec_bytes * (size_t)h->hstate_cap) != hipSuccess) {
-    (void)hipGetLastError();
+    // NOT silent: a handle without records runs the pure lane kernel, whose results agree with the hand-off's to ~1e-10 N but
+    // not bit for bit -- the caller can see it (stderr, qmpc_query(QMPC_QUERY_HANDOFF_ACTIVE)) and avoid it (qmpc_prepare
+    // right after qmpc_create, before other allocations take the memory)
+    std::fprintf(stderr, "qmpc: straggler hand-off records (%zu MB) could not be allocated: %s -- this handle keeps the pure lane kernel\n",
+                 (rec_bytes * (size_t)h->hstate_cap) >> 20, hipGetErrorString(hipGetLastError()));
     if (h->d_handoff) (void)hipFree(h->d_handoff);
     h->d_handoff = nullptr; h->d_hstate = nullptr;
+    h->handoff_failed = 1;
     h->lane_cap = 0;
     h->lane_cap_loop = 0;
     h->lane_cap_warm = 0;
@@ -506,6 +526,11 @@ static int wform_variant(const qmpc_handle* h, int32_t batch) {
   if (!h->wform || h->params.model != QMPC_MODEL_QUAT || h->params.mode != QMPC_MODE_CONVERGED) return 0;
   const int pv = pick_variant(h, batch);
   if (pv == 0) return h->lds_bytes_w <= 40 * 1024 ? 3 : 0;
+  // Longer horizons (N=20, the reference's own configuration: 75 KB per instance): everything in LDS as long as every
+  // instance of the batch finds a CU with room -- two per CU up to N=21 (512 instances), one per CU beyond (256) -- i.e. for
+  // the single robot and small fleets; the workspace form (two waves per SIMD) from there on.  Round 5, tools/latency_b1.py.
+  static const int small_lds = std::getenv("QMPC_WFORM_SMALL_LDS") ? std::atoi(std::getenv("QMPC_WFORM_SMALL_LDS")) : 1;
+  if (small_lds && h->variant == 0 && h->lds_bytes_w <= 160 * 1024 && batch <= 256 * (int)((160 * 1024) / h->lds_bytes_w)) return 3;
   return (h->wform != 3 && h->lds_bytes_wg <= 80 * 1024) ? 5 : 0;
 }
 static bool use_wform(const qmpc_handle* h, int32_t batch) { return wform_variant(h, batch) == 3; }
@@ -518,6 +543,21 @@ static size_t variant_lds(const qmpc_handle* h, int var) {
   return var == 5 ? h->lds_bytes_wg : (var == 3 ? h->lds_bytes_w : (var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes)));
 }
 static double* variant_gws(const qmpc_handle* h, int var) { return (var == 1 || var == 2 || var == 5) ? h->d_gws : nullptr; }
+
+// Straggler hand-off: the wave kernel that CONTINUES what a capped lane launch leaves -- 3 (everything in LDS), 5 (gains in
+// the workspace; up to 80 KB of LDS, i.e. every horizon the handle accepts: two workgroups per CU instead of four), 0: no
+// hand-off for this handle.  ONE predicate for launch_solve, the closed loop's ticks and the pre-allocation before a capture.
+static int handoff_variant(const qmpc_handle* h) {
+  if (h->variant != 0 || !h->wform || h->params.model != QMPC_MODEL_QUAT || h->params.mode != QMPC_MODE_CONVERGED ||
+      h->handoff_failed)
+    return 0;
+  return h->lds_bytes_w <= 40 * 1024 ? 3 : (h->lds_bytes_wg <= 80 * 1024 ? 5 : 0);
+}
+static int handoff_grid(const qmpc_handle* h, int wv) { return variant_lds(h, wv) <= 40 * 1024 ? 1024 : 512; }   // one resident round
+static int handoff_cap(const qmpc_handle* h, int kind) {      // kind 1: plain cold solve, 2: cold closed loop, 3: warm closed loop
+  const int cap = kind == 3 ? h->lane_cap_warm : (kind == 2 ? h->lane_cap_loop : h->lane_cap);
+  return (cap > 0 && cap < h->params.iterations_max && handoff_variant(h)) ? cap : 0;
+}
 
 // reference mode of QuatMpc's problem: the wrench-form kernels (3: everything in LDS, one instance per SIMD; 5: gains in the
 // workspace), with the rule of the round-1 reference kernels for which of the two; 0: keep the round-1 kernels.
@@ -552,6 +592,7 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
         (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min))) {                      // keeps the wave kernels in this mode
       const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s, nullptr, d_tu, 0, nullptr, 0);
       if (ls != QMPC_OK) return ls;
+      h->last_kernel = QMPC_KERNEL_LANE;
       if (timed) {
         HIP_TRY(hipEventRecord(h->ev1, s));
         h->timed = true;
@@ -559,6 +600,7 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
       return QMPC_OK;
     }
     if (const int wv = ref_wform_variant(h, batch)) {      // QuatMpc's problem: on the wrench-form algebra (qmpc_wform_ref_body.inc)
+      h->last_kernel = wv == 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
       HIP_TRY(qmpc_wform_ref_launch(wv, (int)batch, variant_lds(h, wv), s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, d_tu, d_tx,
                                     variant_gws(h, wv)));
       if (timed) {
@@ -569,6 +611,7 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
     }
     const size_t lds_r = ws ? h->lds_bytes_g : h->lds_bytes;
     double* gws_r = ws ? h->d_gws : nullptr;
+    h->last_kernel = ws ? QMPC_KERNEL_DENSE_WS : QMPC_KERNEL_DENSE_LDS;
 #define QMPC_LAUNCH_REF(kern) \
   hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kWave), lds_r, s, h->dev, d_in, d_forces, d_info, d_tu, d_tx, \
                      (int)batch, gws_r)
@@ -593,17 +636,16 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
     // straggler hand-off (see qmpc_create): only where the library chose the lane kernel by itself (QMPC_VARIANT=4 forces
     // the pure lane kernel) and there at every batch size (a shard of a batch gives the bits of the whole batch), with status
     // records to select from
-    const int cap = handoff == 2 ? h->lane_cap_loop : h->lane_cap;
-    const int wv = (handoff && h->variant == 0 && h->wform && h->params.model == QMPC_MODEL_QUAT && d_info &&
-                    cap > 0 && cap < h->params.iterations_max)
-                       ? (h->lds_bytes_w <= 40 * 1024 ? 3 : (h->lds_bytes_wg <= 40 * 1024 ? 5 : 0)) : 0;
+    const int cap = (handoff && d_info) ? handoff_cap(h, handoff) : 0;
+    const int wv = cap ? handoff_variant(h) : 0;
     const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s, nullptr, d_tu, 0, d_tx, wv ? cap : 0);
     if (ls != QMPC_OK) return ls;
+    h->last_kernel = (wv && h->d_handoff) ? QMPC_KERNEL_LANE_HANDOFF : QMPC_KERNEL_LANE;
     if (wv && h->d_handoff) {     // one workgroup per SIMD walks the list the lane kernel left (8-10 % of the batch in the measured workloads)
       // QMPC_HANDOFF_RESTART=1 (experiments, tests): the wave kernel ignores the state records and solves the list from scratch
       const char* hr = std::getenv("QMPC_HANDOFF_RESTART");
       const bool restart = hr && std::atoi(hr) != 0;
-      HIP_TRY(qmpc_wform_launch_list(wv, 1024, variant_lds(h, wv), s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, d_tu, d_tx,
+      HIP_TRY(qmpc_wform_launch_list(wv, handoff_grid(h, wv), variant_lds(h, wv), s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, d_tu, d_tx,
                                      h->d_handoff + 64, h->d_handoff, variant_gws(h, wv), restart ? nullptr : h->d_hstate, h->hstate_cap));
     }
     if (timed) {
@@ -613,6 +655,7 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
     return QMPC_OK;
   }
   if (const int wv = wform_variant(h, batch)) {
+    h->last_kernel = wv == 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
     HIP_TRY(qmpc_wform_launch(wv, 0, (int)batch, wv == 5 ? h->lds_bytes_wg : h->lds_bytes_w, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info,
                               d_tu, d_tx, nullptr, wv == 5 ? h->d_gws : nullptr));
     if (timed) {
@@ -624,6 +667,7 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
   const int var = pick_variant(h, batch);
   const size_t lds = var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes);
   double* gws = var >= 1 ? h->d_gws : nullptr;
+  h->last_kernel = var >= 1 ? QMPC_KERNEL_DENSE_WS : QMPC_KERNEL_DENSE_LDS;
 #define QMPC_LAUNCH(kern) \
   hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(kWave), lds, s, h->dev, d_in, d_forces, d_info, d_tu, d_tx, \
                      (int)batch, (long long*)nullptr, gws)
@@ -678,11 +722,13 @@ qmpc_status qmpc_convex_solve_device(qmpc_handle* h, int32_t batch, const qmpc_c
   return launch_solve(h, batch, reinterpret_cast<const qmpc_input*>(d_in), d_forces_world, d_info, nullptr, nullptr, s);
 }
 
+static void finish_pending(qmpc_handle* h);
 qmpc_status qmpc_wait(qmpc_handle* h) {
   if (!h) return QMPC_BAD_ARGUMENT;
   HIP_TRY(hipSetDevice(h->device));
   if (h->timed) HIP_TRY(hipEventSynchronize(h->ev1));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  finish_pending(h);          // zero-copy host call into pageable buffers: the copy-out it still owes
   return QMPC_OK;
 }
 
@@ -694,7 +740,44 @@ qmpc_status qmpc_last_kernel_ms(qmpc_handle* h, float* ms) {
   return QMPC_OK;
 }
 
-// host-buffer solve shared by both models (nx = doubles per state in traj_x)
+// Is p host memory the device can address (hipHostMalloc / hipHostRegister / qmpc_host_alloc)?  *dev = its device-side alias.
+static bool pinned_alias(const void* p, size_t bytes, void** dev) {
+  hipPointerAttribute_t a;
+  std::memset(&a, 0, sizeof a);
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
+  (void)bytes;
+  *dev = a.devicePointer;
+  return true;
+}
+static qmpc_status ensure_stage(qmpc_handle* h, int nl) {
+  if (h->h_stage_in) return QMPC_OK;
+  const size_t rec = sizeof(double) * (32 + 4 * nl), out = sizeof(double) * 3 * nl + sizeof(qmpc_info);
+  void *a = nullptr, *b = nullptr;
+  if (hipHostMalloc(&a, rec * (size_t)h->max_batch, hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc(&b, out * (size_t)h->max_batch, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    if (a) (void)hipHostFree(a);
+    h->zero_copy = 0;            // no pinned memory to be had: the copies below take the runtime's own staging
+    return QMPC_OK;
+  }
+  h->h_stage_in = static_cast<unsigned char*>(a);
+  h->h_stage_out = static_cast<unsigned char*>(b);
+  return QMPC_OK;
+}
+// copy-out owed to a pageable caller of the zero-copy path (after the stream has drained)
+static void finish_pending(qmpc_handle* h) {
+  if (h->pending.forces) std::memcpy(h->pending.forces, h->h_stage_out, h->pending.fbytes);
+  if (h->pending.info) std::memcpy(h->pending.info, h->h_stage_out + h->pending.fbytes, h->pending.ibytes);
+  h->pending.forces = nullptr;
+  h->pending.info = nullptr;
+}
+
+// host-buffer solve shared by the models (nx = doubles per state in traj_x).
+// Batches that take a wave-per-instance kernel run ZERO-COPY (see qmpc_handle): records are read from, forces and status
+// written to, host memory the device can address -- the caller's own buffers when they are pinned (qmpc_host_alloc,
+// hipHostMalloc, hipHostRegister), the handle's pinned staging otherwise (one memcpy in, one out).  Lane-kernel batches
+// (which sort and re-read their records) and calls that want trajectories keep explicit copies on the handle's stream.
 static qmpc_status solve_host(qmpc_handle* h, int32_t batch, const qmpc_input* in, double* forces_body,
                               qmpc_info* info, double* traj_u, double* traj_x, int model, int nx,
                               bool blocking = true) {
@@ -703,17 +786,53 @@ static qmpc_status solve_host(qmpc_handle* h, int32_t batch, const qmpc_input* i
   if (batch == 0) return QMPC_OK;
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
   HIP_TRY(hipSetDevice(h->device));
+  if (h->pending.forces || h->pending.info) {      // an earlier qmpc_solve_async was never waited for: complete it first
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    finish_pending(h);
+  }
   const int N = h->params.horizon;
   const int nl = model_nl(model), nu = 3 * nl;
   const size_t rec = sizeof(double) * (32 + 4 * nl);
+  const size_t fbytes = sizeof(double) * nu * (size_t)batch, ibytes = sizeof(qmpc_info) * (size_t)batch;
   if (traj_u && !h->d_traj_u) HIP_TRY(hipMalloc(&h->d_traj_u, sizeof(double) * nu * N * (size_t)h->max_batch));
   if (traj_x && !h->d_traj_x) HIP_TRY(hipMalloc(&h->d_traj_x, sizeof(double) * 13 * (N + 1) * (size_t)h->max_batch));
+  const bool lane = use_lane(h, batch, nullptr, nullptr) ||
+                    (h->params.mode == QMPC_MODE_REFERENCE && model == QMPC_MODEL_QUAT && h->lane_pslot >= 0 &&
+                     (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min)));
+  if (h->zero_copy && !lane) {
+    void *din = nullptr, *df = nullptr, *di = nullptr;
+    const bool in_pinned = pinned_alias(in, rec * (size_t)batch, &din);
+    const bool out_pinned = pinned_alias(forces_body, fbytes, &df) && (!info || pinned_alias(info, ibytes, &di));
+    if (!in_pinned || !out_pinned) {
+      const qmpc_status es = ensure_stage(h, nl);
+      if (es != QMPC_OK) return es;
+    }
+    if (h->zero_copy) {
+      if (!in_pinned) { std::memcpy(h->h_stage_in, in, rec * (size_t)batch); din = h->h_stage_in; }
+      if (!out_pinned) { df = h->h_stage_out; di = h->h_stage_out + fbytes; }
+      const qmpc_status st = launch_solve(h, batch, static_cast<const qmpc_input*>(din), static_cast<double*>(df),
+                                          info ? static_cast<qmpc_info*>(di) : h->d_info, traj_u ? h->d_traj_u : nullptr,
+                                          traj_x ? h->d_traj_x : nullptr, h->stream);
+      if (st != QMPC_OK) return st;
+      if (traj_u) HIP_TRY(hipMemcpyAsync(traj_u, h->d_traj_u, sizeof(double) * nu * N * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+      if (traj_x) HIP_TRY(hipMemcpyAsync(traj_x, h->d_traj_x, sizeof(double) * nx * (N + 1) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+      if (!out_pinned) {
+        h->pending.forces = forces_body; h->pending.fbytes = fbytes;
+        h->pending.info = info; h->pending.ibytes = ibytes;
+      }
+      if (blocking) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        finish_pending(h);
+      }
+      return QMPC_OK;
+    }
+  }
   HIP_TRY(hipMemcpyAsync(h->d_in, in, rec * (size_t)batch, hipMemcpyHostToDevice, h->stream));
   const qmpc_status st = launch_solve(h, batch, h->d_in, h->d_forces, h->d_info, traj_u ? h->d_traj_u : nullptr,
                                       traj_x ? h->d_traj_x : nullptr, h->stream);
   if (st != QMPC_OK) return st;
-  HIP_TRY(hipMemcpyAsync(forces_body, h->d_forces, sizeof(double) * nu * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
-  if (info) HIP_TRY(hipMemcpyAsync(info, h->d_info, sizeof(qmpc_info) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(forces_body, h->d_forces, fbytes, hipMemcpyDeviceToHost, h->stream));
+  if (info) HIP_TRY(hipMemcpyAsync(info, h->d_info, ibytes, hipMemcpyDeviceToHost, h->stream));
   if (traj_u) HIP_TRY(hipMemcpyAsync(traj_u, h->d_traj_u, sizeof(double) * nu * N * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   if (traj_x) HIP_TRY(hipMemcpyAsync(traj_x, h->d_traj_x, sizeof(double) * nx * (N + 1) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   if (blocking) HIP_TRY(hipStreamSynchronize(h->stream));
@@ -829,6 +948,85 @@ qmpc_status qmpc_linearize(qmpc_handle* h, int32_t batch, const qmpc_input* in, 
 qmpc_status qmpc_convex_linearize(qmpc_handle* h, int32_t batch, const qmpc_convex_input* in, double* A, double* B,
                                   double* X) {
   return linearize_host(h, batch, reinterpret_cast<const qmpc_input*>(in), A, B, X, QMPC_MODEL_CONVEX, 12);
+}
+
+// ---- pinned host buffers, eager allocation, handle queries ------------------------------------------------------------------
+void* qmpc_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+void qmpc_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
+// Everything a solve of `batch` instances will need, allocated NOW: the lane kernel's workspace and sort scratch, the
+// hand-off records, the pinned staging of the host-buffer calls.  Afterwards no solve of up to `batch` instances allocates
+// (safe inside the caller's own stream capture) and qmpc_query(QMPC_QUERY_HANDOFF_ACTIVE) says which family of roundings
+// the handle's large-batch results belong to.
+qmpc_status qmpc_prepare(qmpc_handle* h, int32_t batch) {
+  if (!h || batch < 1) return QMPC_BAD_ARGUMENT;
+  if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
+  HIP_TRY(hipSetDevice(h->device));
+  const bool ref_lane = h->params.mode == QMPC_MODE_REFERENCE && h->params.model == QMPC_MODEL_QUAT && h->lane_pslot >= 0 &&
+                        (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min));
+  bool lane_loop = false;
+  if (h->params.mode == QMPC_MODE_CONVERGED && h->lane_pslot >= 0 && h->variant == 0)
+    lane_loop = batch >= (h->lane_min_loop_cold < h->lane_min_batch ? h->lane_min_loop_cold : h->lane_min_batch);
+  if (use_lane(h, batch, nullptr, nullptr) || ref_lane || lane_loop) {
+    const qmpc_status es = ensure_lane_buffers(h);
+    if (es != QMPC_OK) return es;
+    if (!ref_lane && (handoff_cap(h, 1) || handoff_cap(h, 2) || handoff_cap(h, 3))) (void)ensure_handoff_buffers(h);
+  } else if (h->zero_copy) {
+    const qmpc_status es = ensure_stage(h, model_nl(h->params.model));
+    if (es != QMPC_OK) return es;
+  }
+  return QMPC_OK;
+}
+
+// kernel family launch_solve gives a plain solve of `batch` instances on this handle (QMPC_KERNEL_*)
+static int kernel_for_batch(const qmpc_handle* h, int32_t batch) {
+  if (h->params.mode == QMPC_MODE_REFERENCE) {
+    if (h->params.model == QMPC_MODEL_QUAT && h->lane_pslot >= 0 && (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min)))
+      return QMPC_KERNEL_LANE;
+    if (const int wv = ref_wform_variant(h, batch)) return wv == 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
+    const bool ws = batch > 1024 || h->lds_bytes > 40 * 1024 || h->variant >= 2 || h->params.model == QMPC_MODEL_QUAT8;
+    return ws ? QMPC_KERNEL_DENSE_WS : QMPC_KERNEL_DENSE_LDS;
+  }
+  if (use_lane(h, batch, nullptr, nullptr)) return handoff_cap(h, 1) ? QMPC_KERNEL_LANE_HANDOFF : QMPC_KERNEL_LANE;
+  if (const int wv = wform_variant(h, batch)) return wv == 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
+  return pick_variant(h, batch) >= 1 ? QMPC_KERNEL_DENSE_WS : QMPC_KERNEL_DENSE_LDS;
+}
+
+qmpc_status qmpc_query(qmpc_handle* h, int32_t what, int64_t arg, int64_t* value) {
+  if (!h || !value) return QMPC_BAD_ARGUMENT;
+  switch (what) {
+    case QMPC_QUERY_HANDOFF_ACTIVE:      // 1: capped lane launches hand their stragglers over; 0: pure lane kernel (off, or allocation failed)
+      *value = (handoff_cap(h, 1) || handoff_cap(h, 2) || handoff_cap(h, 3)) ? 1 : 0;
+      return QMPC_OK;
+    case QMPC_QUERY_HANDOFF_ALLOC_FAILED: *value = h->handoff_failed; return QMPC_OK;
+    case QMPC_QUERY_KERNEL_FOR_BATCH:
+      if (arg < 1 || arg > h->max_batch) return QMPC_BAD_ARGUMENT;
+      *value = kernel_for_batch(h, (int32_t)arg);
+      return QMPC_OK;
+    case QMPC_QUERY_LAST_KERNEL: *value = h->last_kernel; return QMPC_OK;
+    case QMPC_QUERY_LANE_CAP: *value = handoff_cap(h, arg == 3 ? 3 : (arg == 2 ? 2 : 1)); return QMPC_OK;
+    case QMPC_QUERY_DEVICE_BYTES: {      // device memory the handle holds right now
+      const int N = h->params.horizon, nl = model_nl(h->params.model), nu = 3 * nl;
+      size_t b = (sizeof(double) * (32 + 4 * nl) + sizeof(double) * nu + sizeof(qmpc_info)) * (size_t)h->max_batch;
+      b += sizeof(double) * (size_t)N * (13 * nu + 21 * nl + 30 * nl) * (size_t)h->max_batch;
+      if (h->d_lane_ws) b += qmpc_lane_ws_bytes(N, nl, h->lane_slots) + qmpc_lane_scratch_bytes(h->max_batch);
+      if (h->d_handoff) b += qmpc_lane_handoff_list_bytes(h->max_batch) + sizeof(double) * qmpc_lane_handoff_record_doubles(N) * (size_t)h->hstate_cap;
+      if (h->d_traj_u) b += sizeof(double) * nu * N * (size_t)h->max_batch;
+      if (h->d_traj_x) b += sizeof(double) * 13 * (N + 1) * (size_t)h->max_batch;
+      if (h->d_A) b += 2 * sizeof(double) * 144 * N * (size_t)h->max_batch;
+      b += sizeof(double) * (h->leg_cap + h->loop_cap);
+      *value = (int64_t)b;
+      return QMPC_OK;
+    }
+    case QMPC_QUERY_ZERO_COPY: *value = h->zero_copy; return QMPC_OK;
+    default: return QMPC_BAD_ARGUMENT;
+  }
 }
 
 // ---- multi-GPU: the one collective of the path --------------------------------
@@ -1156,14 +1354,13 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
     HIP_TRY(hipGetLastError());
     if (warm && use_lane(h, batch, nullptr, nullptr)) {
       // straggler hand-off of the warm-started ticks (not the cold first one): the records carry the rows' initial residuals
-      const int wcap = (!first && h->variant == 0 && h->wform && h->params.model == QMPC_MODEL_QUAT && h->d_handoff &&
-                        h->lane_cap_warm > 0 && h->lane_cap_warm < h->params.iterations_max) ? h->lane_cap_warm : 0;
-      const int wv = wcap ? (h->lds_bytes_w <= 40 * 1024 ? 3 : (h->lds_bytes_wg <= 40 * 1024 ? 5 : 0)) : 0;
+      const int wcap = (!first && h->d_handoff) ? handoff_cap(h, 3) : 0;
+      const int wv = wcap ? handoff_variant(h) : 0;
       const qmpc_status st = launch_lane(h, batch, h->d_in, h->d_forces, h->d_info, s, first ? nullptr : h->d_traj_u, h->d_traj_u,
                                          /*check_prev=*/1, nullptr, wv ? wcap : 0);
       if (st != QMPC_OK) return st;
       if (wv)
-        HIP_TRY(qmpc_wform_launch_list(wv, 1024, variant_lds(h, wv), s, &h->dev, sizeof h->dev, h->d_in, h->d_forces, h->d_info, h->d_traj_u,
+        HIP_TRY(qmpc_wform_launch_list(wv, handoff_grid(h, wv), variant_lds(h, wv), s, &h->dev, sizeof h->dev, h->d_in, h->d_forces, h->d_info, h->d_traj_u,
                                        nullptr, h->d_handoff + 64, h->d_handoff, variant_gws(h, wv), h->d_hstate, h->hstate_cap));
     } else if (warm) {
       const int var = body_variant(h, batch);
@@ -1231,7 +1428,7 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
     h->lane_params_resident = true;
     static const bool order_env = [] { const char* e = std::getenv("QMPC_LANE_ORDER_PREV"); return !e || e[0] != '0'; }();
     h->lane_order_prev = order_env;
-    if ((warm ? h->lane_cap_warm : h->lane_cap_loop) > 0 && h->params.mode == QMPC_MODE_CONVERGED) (void)ensure_handoff_buffers(h);      // not capturable either
+    if (handoff_cap(h, warm ? 3 : 2)) (void)ensure_handoff_buffers(h);      // not capturable either; only where the ticks will hand over
   }
   if (warm) {                            // the cold first tick is not the tick the graph repeats
     const qmpc_status st = one_tick(true);

@@ -62,8 +62,10 @@ __global__ __launch_bounds__(64, WVAR == 5 ? 2 : 1) void qmpc_solve_w_kernel(
 // the grid as stride.  The straggler hand-off of large batches (qmpc_hip.hip: launch_solve): the lane-per-instance kernel
 // stops after a fixed number of iterations and the few instances it leaves unconverged are solved here, where one
 // interior-point iteration takes a tenth of the time.
+// One workgroup per SIMD walks the list (grid <= 1024), so the workspace form too is compiled for ONE wave per SIMD here: with
+// the 256-register budget of the plain <5> kernel this instantiation spilled 87 VGPRs (352 B of scratch) for nothing.
 template <int WVAR>
-__global__ __launch_bounds__(64, WVAR == 5 ? 2 : 1) void qmpc_solve_w_list_kernel(
+__global__ __launch_bounds__(64, 1) void qmpc_solve_w_list_kernel(
     DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
     double* __restrict__ traj_u, double* __restrict__ traj_x, const int* __restrict__ sel, const int* __restrict__ sel_count,
     double* __restrict__ gws, const double* __restrict__ hstate, int hcap) {

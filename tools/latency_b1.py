@@ -12,23 +12,42 @@ from bench import load_pkg  # noqa: E402
 
 pkg = load_pkg()
 lib = pkg.load_library()
-for name, N, mk, gen, call in (
-        ("QuatMpc   N=10", 10, pkg.default_params, pkg.random_go1_trot_states, "solve"),
-        ("QuatMpc   N=20", 20, pkg.default_params, pkg.random_go1_trot_states, "solve"),
-        ("ConvexMpc N=20", 20, pkg.default_convex_params, pkg.random_go1_convex_states, "convex_solve")):
-    p = mk(N, 0, lib)
+SAMPLES = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+for name, N, mode, mk, gen, call in (
+        ("QuatMpc   N=10 converged", 10, 0, pkg.default_params, pkg.random_go1_trot_states, "qmpc_solve"),
+        ("QuatMpc   N=20 converged", 20, 0, pkg.default_params, pkg.random_go1_trot_states, "qmpc_solve"),
+        ("QuatMpc   N=10 reference mode (AL-iLQR <= 10 iterations, QuatMpc.cpp:21-26)", 10, 1, pkg.default_params, pkg.random_go1_trot_states, "qmpc_solve"),
+        ("QuatMpc   N=20 reference mode (the reference's own operating point, gazebo_go1_quat_mpc.yaml:36-37)", 20, 1, pkg.default_params,
+         pkg.random_go1_trot_states, "qmpc_solve"),
+        ("ConvexMpc N=20 converged", 20, 0, pkg.default_convex_params, pkg.random_go1_convex_states, "qmpc_convex_solve")):
+    p = mk(N, mode, lib)
     s = pkg.Solver(p, 1, 0, lib)
-    recs = gen(200, config_id=2 if call == "solve" else 12)
-    getattr(s, call)(recs[:1])
-    lat, its = [], []
-    for i in range(200):
-        t0 = time.perf_counter()
-        f, info = getattr(s, call)(recs[i:i + 1])
-        lat.append(time.perf_counter() - t0)
-        its.append(int(info["iterations"][0]))
-    lat = np.array(lat) * 1e3
-    print(f"{name}: batch-1 blocking latency mean {lat.mean():.3f} ms, p50 {np.median(lat):.3f}, p99 {np.percentile(lat, 99):.3f}, "
-          f"max {lat.max():.3f} ms; mean iterations {np.mean(its):.1f}")
+    recs = gen(SAMPLES, config_id=2 if call == "qmpc_solve" else 12)
+    fn = getattr(lib, call)
+    for kind in ("pinned", "pageable"):
+        # caller-owned buffers, as the C++ host class holds them: pinned (qmpc_host_alloc) or plain members
+        if kind == "pinned":
+            hin = s.pinned((1,), recs.dtype); hf = s.pinned((1, 12)); hi = s.pinned((1,), pkg.INFO_DTYPE)
+        else:
+            hin = np.zeros(1, dtype=recs.dtype); hf = np.zeros((1, 12)); hi = np.zeros(1, dtype=pkg.INFO_DTYPE)
+        a = (s._h, 1, hin.ctypes.data, hf.ctypes.data, hi.ctypes.data)
+        lat, its = np.zeros(SAMPLES), np.zeros(SAMPLES, dtype=int)
+        first = None
+        for i in range(-20, SAMPLES):          # 20 untimed warm-up calls (the first one allocates and loads code objects)
+            hin[0] = recs[max(i, 0)]
+            t0 = time.perf_counter()
+            rc = fn(*a)
+            dt = time.perf_counter() - t0
+            assert rc == 0
+            if first is None:
+                first = dt
+            if i >= 0:
+                lat[i] = dt * 1e3
+                its[i] = hi["iterations"][0]
+        worst = int(lat.argmax())
+        print(f"{name}, {kind} buffers: batch-1 blocking latency mean {lat.mean():.3f} ms, p50 {np.median(lat):.3f}, p99 {np.percentile(lat, 99):.3f}, "
+              f"max {lat.max():.3f} ms (call {worst}, {its[worst]} iterations); mean iterations {its.mean():.1f}, max {its.max()}; "
+              f"very first call {first * 1e3:.1f} ms; kernel family {s.kernel_for_batch(1)}", flush=True)
     s.close()
 
 # ---- one trotting robot, the whole tick on the device (front end + solve + plant, qmpc_loop_run_device with batch 1): cold
