@@ -532,7 +532,7 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
   }
   const double* rec = static_cast<const double*>(in);
   if (hcount) {
-    const hipError_t e = hipMemsetAsync(hcount, 0, sizeof(int), s);
+    const hipError_t e = hipMemsetAsync(hcount, 0, 2 * sizeof(int), s);      // the list's length and the list kernel's cursor
     if (e != hipSuccess) return e;
   }
   const int* perm = nullptr;

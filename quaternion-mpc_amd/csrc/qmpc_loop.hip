@@ -24,6 +24,14 @@
 
 #include <type_traits>
 
+// The controller-side functions of a tick (front end, back end): branchy scalar code on one lane.  They are CALLED, not
+// inlined -- in the persistent kernel their temporaries and the 820-double state record competed with the solve body for
+// the 256 registers of the two-waves-per-SIMD instantiations (140-244 spilled VGPRs, rounds 2-4); as functions they get
+// their own allocation (one copy per occupancy: template parameter OCC, so that the calling kernel's register limit
+// carries over) and the save / restore happens once per tick.  The per-tick kernels call the same functions: the two launch
+// forms are bit-identical only when both compile the SAME function bodies (inlined into one and called from the other
+// they differed in the last bit, round 5).
+#define QMPC_LOOP_FN __device__ __attribute__((noinline))
 namespace qmpc {
 
 __device__ inline double loop_filter(qmpc_loop_filter& f, double v) {   // MovingWindowFilter.hpp:28-62
@@ -221,7 +229,8 @@ __device__ inline void loop_foot_update(const qmpc_loop_params& LP, qmpc_loop_st
     for (int a = 0; a < 3; ++a) s.foot_target_world[3 * l + a] = s.leg[l].fsm_pos[a];
 }
 
-__device__ inline void loop_front_one(const qmpc_loop_params& LP, qmpc_loop_state& s, qmpc_input& in) {
+template <int OCC = 1>
+QMPC_LOOP_FN void loop_front_one(const qmpc_loop_params& LP, qmpc_loop_state& s, qmpc_input& in) {
 #pragma clang fp contract(off)
   double R[9], Rz[9], foot_body[12], flag[4], tgt_world[12];
   loop_feedback(LP, s, R, Rz, foot_body, flag);
@@ -286,7 +295,8 @@ __device__ inline void loop_front_one(const qmpc_loop_params& LP, qmpc_loop_stat
 // (BaseInterface.cpp:197-199,217-223); goal_update: the desired position is the joystick's (body_x, body_y, height) --
 // kept in pos_d_world[0:2], which this controller never integrates -- and velx ramps at 1 m/s^2; the gait FSM, the
 // Raibert targets and the published foot targets are those of QuatMpc.
-__device__ inline void loop_front_convex_one(const qmpc_loop_params& LP, qmpc_loop_state& s, qmpc_convex_input& in) {
+template <int OCC = 1>
+QMPC_LOOP_FN void loop_front_convex_one(const qmpc_loop_params& LP, qmpc_loop_state& s, qmpc_convex_input& in) {
 #pragma clang fp contract(off)
   double R[9], Rz[9], foot_body[12], flag[4], tgt_world[12];
   loop_feedback(LP, s, R, Rz, foot_body, flag);
@@ -341,8 +351,8 @@ __global__ __launch_bounds__(64) void qmpc_loop_front_kernel(qmpc_loop_params LP
 // ---- back end of one tick: outputs (QuatMpc.cpp:263-273), plant step, swing feet -----------------
 // forces: the 12 forces of this robot's solve; trace_f / trace_c: this robot's slots in the trace row of this tick (or null)
 // WORLD: the solve returns WORLD-frame forces (ConvexMpc); optimized_input = R' u (ConvexMpc.cpp:188-190)
-template <bool WORLD = false>
-__device__ inline void loop_post_one(const DevParams& P, const qmpc_loop_params& LP, qmpc_loop_state& s,
+template <bool WORLD = false, int OCC = 1>
+QMPC_LOOP_FN void loop_post_one(const DevParams& P, const qmpc_loop_params& LP, qmpc_loop_state& s,
                                      const double* __restrict__ forces, const qmpc_info& inf, double* __restrict__ trace_f,
                                      double* __restrict__ trace_c) {
 #pragma clang fp contract(off)
@@ -432,14 +442,16 @@ __global__ __launch_bounds__(64, (REF && VAR != 5) ? 1 : QMPC_SOLVE_WAVES(QuatMo
   const int lane = threadIdx.x;
   typedef typename std::conditional<CONVEX, ConvexModel, QuatModel>::type MD;
   constexpr bool PROF = false;
+  // the called front / back end: one copy per occupancy, so that the register limit of the calling kernel carries over
+  constexpr int OCC = (REF && VAR != 5) ? 1 : QMPC_SOLVE_WAVES(QuatModel, VAR);
   const qmpc_input* in_ = rec;
   double *traj_u = nullptr, *traj_x = nullptr;
   long long* prof_out = nullptr;
   bool prev_ok = false;
   for (int t = 0; t < ticks; ++t) {
     if (lane == 0) {
-      if (CONVEX) loop_front_convex_one(LP, st[b], reinterpret_cast<qmpc_convex_input*>(rec)[b]);
-      else loop_front_one(LP, st[b], rec[b]);
+      if (CONVEX) loop_front_convex_one<OCC>(LP, st[b], reinterpret_cast<qmpc_convex_input*>(rec)[b]);
+      else loop_front_one<OCC>(LP, st[b], rec[b]);
     }
     __syncthreads();                      // the record (global memory) is visible to the wave
     if constexpr (REF && (VAR == 3 || VAR == 5)) {
@@ -470,8 +482,8 @@ __global__ __launch_bounds__(64, (REF && VAR != 5) ? 1 : QMPC_SOLVE_WAVES(QuatMo
     prev_ok = info[b].status == QMPC_OK || info[b].status == QMPC_MAX_ITER;   // uniform: every lane reads the same word
     if (lane == 0) {
       const size_t slot = (size_t)t * batch + b;
-      loop_post_one<CONVEX>(P, LP, st[b], forces + 12 * (size_t)b, info[b], trace_f ? trace_f + 12 * slot : nullptr,
-                            trace_c ? trace_c + 4 * slot : nullptr);
+      loop_post_one<CONVEX, OCC>(P, LP, st[b], forces + 12 * (size_t)b, info[b], trace_f ? trace_f + 12 * slot : nullptr,
+                                 trace_c ? trace_c + 4 * slot : nullptr);
     }
     __syncthreads();
     if (JOINT) {                          // the joint level of the tick (qmpc_joint.hip): one lane per leg

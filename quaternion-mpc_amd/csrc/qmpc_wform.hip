@@ -75,8 +75,17 @@ __global__ __launch_bounds__(64, 1) void qmpc_solve_w_list_kernel(
   constexpr int warm_t = 0;
   long long* prof_out = nullptr;
   const int wslot = blockIdx.x;
-  const int count = *sel_count;
-  for (int i = blockIdx.x; i < count; i += gridDim.x) {
+  const int count = sel_count[0];
+  // the workgroups DRAW their instances from a cursor (sel_count[1], zeroed with the count before the lane launch) instead of
+  // striding the list: what is left of a handed-over solve varies from one iteration to ten, and with a fixed assignment
+  // the launch lasted as long as the unluckiest workgroup's share.  Which workgroup continues an instance does not touch its
+  // result (wslot only names a scratch slice).
+  int* cursor = const_cast<int*>(sel_count) + 1;
+  for (;;) {
+    int i = 0;
+    if (lane == 0) i = atomicAdd(cursor, 1);
+    i = __builtin_amdgcn_readfirstlane(i);
+    if (i >= count) break;
     const int b = sel[i];
     // the instance's state at the lane kernel's iteration cap (null: none was kept, start from scratch)
     const double* resume = (hstate && i < hcap) ? hstate + (size_t)i * (8 + 84 * (size_t)P.N) : nullptr;
