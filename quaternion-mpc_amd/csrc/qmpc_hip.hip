@@ -572,10 +572,13 @@ static int handoff_cap(const qmpc_handle* h, int kind) {      // kind 1: plain c
 // worst 8.7e-7).  QMPC_REF_WFORM_MAXN overrides the limit (experiments).
 static int ref_wform_variant(const qmpc_handle* h, int32_t batch) {
   if (!h->wform || h->params.model != QMPC_MODEL_QUAT || h->params.mode != QMPC_MODE_REFERENCE) return 0;
-  static const int maxn = std::getenv("QMPC_REF_WFORM_MAXN") ? std::atoi(std::getenv("QMPC_REF_WFORM_MAXN")) : 12;
+  static const int maxn = std::getenv("QMPC_REF_WFORM_MAXN") ? std::atoi(std::getenv("QMPC_REF_WFORM_MAXN")) : QMPC_MAX_HORIZON;
   if (h->params.horizon > maxn || h->params.horizon < 2) return 0;      // (one knot: the input weights would not fit behind the trial states)
-  const bool ws = batch > 1024 || h->lds_bytes_w > 40 * 1024 || h->variant >= 2;
-  if (!ws) return 3;
+  if (h->variant < 2) {
+    if (batch <= 1024 && h->lds_bytes_w <= 40 * 1024) return 3;
+    // longer horizons: everything in LDS while every instance finds a CU with room (wform_variant's rule)
+    if (h->variant == 0 && h->lds_bytes_w <= 160 * 1024 && batch <= 256 * (int)((160 * 1024) / h->lds_bytes_w)) return 3;
+  }
   return h->lds_bytes_wg <= 80 * 1024 ? 5 : 0;
 }
 

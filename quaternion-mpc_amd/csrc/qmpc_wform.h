@@ -407,17 +407,19 @@ __device__ __forceinline__ double times_Abar(double x, const ColOps& co, const d
 #ifndef QMPC_GJ_FUSED
 #define QMPC_GJ_FUSED 0     // measured: 1.76 M against 1.82 M solves/s -- the 64-bit DPP form issues slower than mov + fma
 #endif
-template <int J>
-__device__ __forceinline__ double gj6_step(double M[2], double Rr[2], int c, int g, bool& pd) {
+template <int J, bool INV = false>
+__device__ __forceinline__ double gj6_step(double M[2], double Rr[2], int c, int g, bool& pd, double* Iv = nullptr) {
   constexpr int ej = J >> 2, gj = J & 3;
-  double mrow, rrow;
+  double mrow, rrow, irow = 0.0;
   if (QMPC_GJ_PERM) {
     mrow = rowgroup_bcast<gj>(M[ej]);
     rrow = rowgroup_bcast<gj>(Rr[ej]);
+    if (INV) irow = rowgroup_bcast<gj>(Iv[ej]);
   } else {
     const int src = (gj << 4) | c;
     mrow = __shfl(M[ej], src);      // row J, same column, all row groups
     rrow = __shfl(Rr[ej], src);
+    if (INV) irow = __shfl(Iv[ej], src);
   }
   const double piv = read_lane(M[ej], (gj << 4) | J);
   pd = pd && (piv > 0.0);          // false for a NaN pivot too (fmin / fmax would drop it silently)
@@ -434,6 +436,7 @@ __device__ __forceinline__ double gj6_step(double M[2], double Rr[2], int c, int
       "v_fmac_f64_dpp %1, %1, %4 row_newbcast:%6 row_mask:%8 bank_mask:0xf"
       : "+v"(M[0]), "+v"(M[1]), "+v"(Rr[0]), "+v"(Rr[1])
       : "v"(nm), "v"(nr), "n"(J), "n"(m0), "n"(m1));
+  static_assert(!INV, "the fused form does not track the inverse");
 #else
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
@@ -441,6 +444,7 @@ __device__ __forceinline__ double gj6_step(double M[2], double Rr[2], int c, int
     const double f = ((e == ej) && (g == gj)) ? 0.0 : col * ninv;
     M[e] = fma(f, mrow, M[e]);
     Rr[e] = fma(f, rrow, Rr[e]);
+    if (INV) Iv[e] = fma(f, irow, Iv[e]);
   }
 #endif
   return ninv;
@@ -448,7 +452,13 @@ __device__ __forceinline__ double gj6_step(double M[2], double Rr[2], int c, int
 
 // Riccati backward pass in the wrench form; writes per knot [Xw | xw] and [Xz | xz] (KD).  Returns nonzero when a pivot
 // of W' is not positive (P lost positive definiteness: QMPC_NOT_PD).
-template <bool PROF>
+// REFINE (reference mode, round 5): one step of iterative refinement on the 6 x 6 stage solve.  W' = S6 (I + G S6) carries
+// cond(S6) twice; the residual is taken on the system that carries it ONCE, (I + G S6) X = -C (not symmetric, so never
+// eliminated itself), and the correction goes back through the SPD elimination: W' dX = S6 r, with W'^-1 tracked by the same
+// Gauss-Jordan steps (a third fragment pair that starts as the identity).  The converged mode does not need it -- its fixed
+// point does not depend on the accuracy of a Newton direction -- but a TRUNCATED iterate keeps the rounding of its
+// directions: without the refinement 65 % of the N=20 reference-mode forces were within 1e-6 N of the oracle's.
+template <bool PROF, bool REFINE = false>
 // y0out (optional, 6 per knot): y0_k = M' p_{k+1}, the wrench-space costate BEFORE the stage solve -- the rotated input
 // gradient of contact point l is V_l' y0 + gq_l (the expected decrease of the reference mode's line search needs it)
 __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const BwPat& bp, double* sm, double* KD,
@@ -533,15 +543,46 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
     Wm[1] = S6[1] + times_M(Qf[1], co, wt);
     tick_dep(prof, PH_MFMA, Wm[0], Wm[1]);
     // ---- 5. W' X = -Q ----
-    const double n0 = gj6_step<0>(Wm, Qf, c, g, pd);
-    const double n1 = gj6_step<1>(Wm, Qf, c, g, pd);
-    const double n2 = gj6_step<2>(Wm, Qf, c, g, pd);
-    const double n3 = gj6_step<3>(Wm, Qf, c, g, pd);
-    const double n4 = gj6_step<4>(Wm, Qf, c, g, pd);
-    const double n5 = gj6_step<5>(Wm, Qf, c, g, pd);
+    double Iv[2];
+    if (REFINE) {      // the identity, rows 0..5: it leaves the elimination as diag * W'^-1
+      Iv[0] = (c == g) ? 1.0 : 0.0;
+      Iv[1] = (g < 2 && c == 4 + g) ? 1.0 : 0.0;
+    }
+    const double n0 = gj6_step<0, REFINE>(Wm, Qf, c, g, pd, Iv);
+    const double n1 = gj6_step<1, REFINE>(Wm, Qf, c, g, pd, Iv);
+    const double n2 = gj6_step<2, REFINE>(Wm, Qf, c, g, pd, Iv);
+    const double n3 = gj6_step<3, REFINE>(Wm, Qf, c, g, pd, Iv);
+    const double n4 = gj6_step<4, REFINE>(Wm, Qf, c, g, pd, Iv);
+    const double n5 = gj6_step<5, REFINE>(Wm, Qf, c, g, pd, Iv);
+    const double nd0 = (g == 0) ? n0 : (g == 1 ? n1 : (g == 2 ? n2 : n3)), nd1 = (g == 0) ? n4 : n5;
     double Xf[2];
-    Xf[0] = Qf[0] * ((g == 0) ? n0 : (g == 1 ? n1 : (g == 2 ? n2 : n3)));      // X = -diag^-1 Q
-    Xf[1] = rowok1 ? Qf[1] * ((g == 0) ? n4 : n5) : 0.0;
+    Xf[0] = Qf[0] * nd0;      // X = -diag^-1 Q
+    Xf[1] = rowok1 ? Qf[1] * nd1 : 0.0;
+    if (REFINE) {
+      // -r = C + X + G (S6 X);  v = S6 (-r);  X <- X - W'^-1 v   (nWi = -W'^-1 = n_r Iv, rows 6, 7 zero like every operand here)
+      double nWi[2], T1[2], nr[2], vv[2];
+      nWi[0] = Iv[0] * nd0;
+      nWi[1] = (g < 2) ? Iv[1] * nd1 : 0.0;
+      {
+        const d4 a = mtm2(S6, Xf, z4);
+        T1[0] = a[0]; T1[1] = a[1];
+      }
+      {
+        const d4 ini = {Cf[0] + Xf[0], Cf[1] + Xf[1], 0.0, 0.0};
+        const d4 a = mtm2(Gf, T1, ini);
+        nr[0] = a[0]; nr[1] = rowok1 ? a[1] : 0.0;
+      }
+      {
+        const d4 a = mtm2(S6, nr, z4);
+        vv[0] = a[0]; vv[1] = a[1];
+      }
+      {
+        const d4 ini = {Xf[0], Xf[1], 0.0, 0.0};
+        const d4 a = mtm2(nWi, vv, ini);
+        Xf[0] = a[0];
+        Xf[1] = rowok1 ? a[1] : 0.0;
+      }
+    }
     tick_dep(prof, PH_SOLVE, Xf[0], Xf[1]);
     // ---- 6. Pi = [P | p] + Yp_fb' X ;  7. gains [Xz | xz] = Yp + S6 X ----
     double Pi[3];

@@ -97,8 +97,11 @@ __global__ __launch_bounds__(64, 1) void qmpc_solve_w_list_kernel(
 }
 
 // The reference's own solver mode (AL-iLQR, <= 10 iterations) on the wrench-form algebra (qmpc_wform_ref_body.inc)
-template <int WVAR>
-__global__ __launch_bounds__(64, WVAR == 5 ? 2 : 1) void qmpc_ref_w_kernel(
+// OCC: waves per SIMD the workspace form is compiled for -- 2 for batches beyond one instance per SIMD, 1 (the whole register
+// file: no spill) for the batches up to 1024 that only take the workspace form because a long horizon does not fit four
+// instances' LDS into a CU (N=20, the reference's own configuration)
+template <int WVAR, int OCC = (WVAR == 5 ? 2 : 1)>
+__global__ __launch_bounds__(64, OCC) void qmpc_ref_w_kernel(
     DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
     double* __restrict__ traj_u, double* __restrict__ traj_x, int batch, double* __restrict__ gws) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -123,11 +126,12 @@ __attribute__((visibility("hidden"))) size_t qmpc_wform_lds_bytes(int N, int kd_
 }
 __attribute__((visibility("hidden"))) size_t qmpc_wform_slice_doubles(int N) { return wform_slice(N); }
 __attribute__((visibility("hidden"))) hipError_t qmpc_wform_set_lds(int bytes) {
-  const void* k[8] = {reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 3>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 3>),
+  const void* k[9] = {reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 3>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 3>),
                       reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 5>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 5>),
                       reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<3>), reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<5>),
-                      reinterpret_cast<const void*>(qmpc_ref_w_kernel<3>), reinterpret_cast<const void*>(qmpc_ref_w_kernel<5>)};
-  for (int i = 0; i < 8; ++i) {
+                      reinterpret_cast<const void*>(qmpc_ref_w_kernel<3>), reinterpret_cast<const void*>(qmpc_ref_w_kernel<5>),
+                      reinterpret_cast<const void*>(qmpc_ref_w_kernel<5, 1>)};
+  for (int i = 0; i < 9; ++i) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
   }
@@ -176,7 +180,9 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_wform_ref_launch(int var, 
   if (dev_params_size != sizeof(DevParams)) return hipErrorInvalidValue;
   DevParams P;
   std::memcpy(&P, dev_params, sizeof P);
-  if (var == 5)
+  if (var == 5 && batch <= 1024)      // one instance per SIMD at most: the whole register file (no spill)
+    hipLaunchKernelGGL((qmpc_ref_w_kernel<5, 1>), dim3((unsigned)batch), dim3(kWave), lds, s, P, in, forces, info, traj_u, traj_x, batch, gws);
+  else if (var == 5)
     hipLaunchKernelGGL(qmpc_ref_w_kernel<5>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in, forces, info, traj_u, traj_x, batch, gws);
   else
     hipLaunchKernelGGL(qmpc_ref_w_kernel<3>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in, forces, info, traj_u, traj_x, batch, gws);

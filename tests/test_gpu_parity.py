@@ -796,8 +796,10 @@ def test_reference_mode_on_device_matches_oracle_reference_mode(pkg, lib, oracle
     penalty_scaling = 20, backtracking line search, status ignored (QuatMpc.cpp:21-26,256) -- against the oracle's
     restatement of that scheme (oracle/qo_altro.c).  The result is a TRUNCATED iterate, so rounding differences are
     not damped by convergence and a line-search or active-row decision taken on a threshold may differ between the two
-    implementations: >= 95 % of the instances must agree to 1e-6 N with identical status and iteration count, the
-    rest are reported.  On the reference's own golden problems (nothing active) both agree with the JSON to 2e-4 N."""
+    implementations: >= 99 % of the instances must agree to 1e-6 N with identical status and iteration count, the
+    rest are reported (round 5: measured 512/512 at every horizon, worst 3e-10 N -- beyond N=12 the wrench-form kernels solve
+    their 6 x 6 stage systems with one step of iterative refinement; the round-4 kernels reached 97.7 % at N=20 and 14 % at
+    N=32).  On the reference's own golden problems (nothing active) both agree with the JSON to 2e-4 N."""
     # goldens: stand problem of TestAltroQuatMpc.cpp at the reference's tolerances
     p, rec, cols = golden_problem(pkg, pkg.default_params(20, pkg.MODE_REFERENCE, lib), "stand")
     s = pkg.Solver(p, 4, device=0, lib=lib)
@@ -809,19 +811,21 @@ def test_reference_mode_on_device_matches_oracle_reference_mode(pkg, lib, oracle
     Ug = np.array(json.loads((GOLDEN / "quat_mpc_test.json").read_text())["input_trajectory"])
     assert np.abs(f[0][cols] - Ug[0]).max() < 2e-4       # both are 1e-4-stationarity iterates of the same scheme
     # the benchmark workload in the reference's mode
-    for N, cfg in ((10, 2), (20, 3)):
+    for N, cfg, cap in ((10, 2, 512), (20, 3, 512), (20, 3, 2048), (32, 3, 512)):      # cap 2048 at N=20: the workspace form
         p = pkg.default_params(N, pkg.MODE_REFERENCE, lib)
-        rec = pkg.random_go1_trot_states(512, config_id=cfg)
-        s = pkg.Solver(p, 512, device=0, lib=lib)
+        rec = pkg.random_go1_trot_states(cap, config_id=cfg)[:512] if cap == 512 else pkg.random_go1_trot_states(cap, config_id=cfg)
+        s = pkg.Solver(p, cap, device=0, lib=lib)
+        assert s.kernel_for_batch(cap) == ("wform_ws" if (cap > 512 or N > 21) else "wform_lds")
         f, info = s.solve(rec)
         s.close()
+        f, info, rec = f[:512], info[:512], rec[:512]
         fo, io = oracle.solve(p, rec, threads=8)
         d = np.abs(f - fo).max(axis=1)
         same = (d < 1e-6) & (info["status"] == io["status"]) & (info["iterations"] == io["iterations"])
-        print(f"reference mode N={N}: {int(same.sum())}/512 instances identical (1e-6 N, status, iterations); status counts GPU "
+        print(f"reference mode N={N} (batch {cap}): {int(same.sum())}/512 instances identical (1e-6 N, status, iterations); status counts GPU "
               f"{np.bincount(info['status'], minlength=6).tolist()} oracle {np.bincount(io['status'], minlength=6).tolist()}; "
               f"median |f - f_oracle| {np.median(d):.2e}, worst {d.max():.2e}; iterations mean {info['iterations'].mean():.2f}")
-        assert same.mean() >= 0.95
+        assert same.mean() >= 0.99
         assert (info["iterations"] <= 10).all()
         assert (f.reshape(-1, 4, 3)[rec["contacts"] == 0] == 0).all()          # swing legs exactly 0
 
