@@ -81,7 +81,7 @@ void case_unconstrained() {
               bad, (int)s.IsInitialized(), (int)st, s.GetIterations(), c0, s.CalcCost(), norm(xN), norm(x0));
 }
 
-void case_goal() {
+void case_goal(bool cubic = false) {
   DiSetup d;
   ALTROSolver s(d.horizon);
   const std::vector<double> x0 = {1.0, 2.0, 0.0, 0.0};
@@ -97,16 +97,17 @@ void case_goal() {
   s.SetState(x0.data(), kN, 0, LastIndex);
   s.SetInput(u0.data(), kM, 0, LastIndex);
   AltroOptions o;
+  o.use_backtracking_linesearch = !cubic;
   o.penalty_scaling = 100;
   s.SetOptions(o);
   const SolveStatus st = s.Solve();
   std::vector<double> xN(kN);
   s.GetState(xN.data(), d.horizon);
-  std::printf("di_goal bad=%d status=%d iterations=%d dist=%.17g feas=%.17g\n", bad, (int)st, s.GetIterations(),
+  std::printf("di_goal%s bad=%d status=%d iterations=%d dist=%.17g feas=%.17g\n", cubic ? "_cubic" : "", bad, (int)st, s.GetIterations(),
               norm(xN), s.GetPrimalFeasibility());
 }
 
-void case_bounds() {
+void case_bounds(bool cubic = false) {
   DiSetup d;
   ALTROSolver s(d.horizon);
   const std::vector<double> x0 = {2.0, 2.0, 0.0, 0.0};
@@ -132,6 +133,7 @@ void case_bounds() {
   s.SetState(x0.data(), kN, 0, LastIndex);
   s.SetInput(u0.data(), kM, 0, LastIndex);
   AltroOptions o;
+  o.use_backtracking_linesearch = !cubic;
   o.penalty_scaling = 100;
   o.penalty_initial = 100;
   s.SetOptions(o);
@@ -139,11 +141,11 @@ void case_bounds() {
   std::vector<double> xN(kN), u(kM);
   s.GetState(xN.data(), d.horizon);
   s.GetInput(u.data(), 0);
-  std::printf("di_bounds bad=%d status=%d iterations=%d dist=%.17g u0=%.17g u1=%.17g ncon_idx=%d\n", bad, (int)st,
+  std::printf("di_bounds%s bad=%d status=%d iterations=%d dist=%.17g u0=%.17g u1=%.17g ncon_idx=%d\n", cubic ? "_cubic" : "", bad, (int)st,
               s.GetIterations(), norm(xN), u[0], u[1], (int)idx.size());
 }
 
-void case_pendulum_goal() {
+void case_pendulum_goal(bool cubic = false) {
   // simple pendulum, explicit midpoint; terminal equality x_N = (pi, 0), N = 20, tf = 2
   const double l = 0.5, g = 9.81, bf = 0.1, ml2 = 1.0 * l * l;
   auto f = [=](double* xd, const double* x, const double* u) {
@@ -194,12 +196,13 @@ void case_pendulum_goal() {
   const double u0[1] = {0.1};
   s.SetInput(u0, 1, 0, LastIndex);
   AltroOptions o;
+  o.use_backtracking_linesearch = !cubic;
   o.iterations_max = 100;
   s.SetOptions(o);
   const SolveStatus st = s.Solve();
   double xN[2];
   s.GetState(xN, N);
-  std::printf("pendulum_goal bad=%d status=%d iterations=%d dist=%.17g\n", bad, (int)st, s.GetIterations(),
+  std::printf("pendulum_goal%s bad=%d status=%d iterations=%d dist=%.17g\n", cubic ? "_cubic" : "", bad, (int)st, s.GetIterations(),
               std::hypot(xN[0] - M_PI, xN[1]));
 }
 
@@ -254,6 +257,7 @@ void case_quatmpc_stand(bool tight) {
   o.penalty_scaling = 20.0;
   o.use_quaternion = true;
   o.quat_start_index = 3;
+  o.use_backtracking_linesearch = true;  // QuatMpc.cpp:23
   if (tight) { o.tol_stationarity = 1e-9; o.tol_cost_intermediate = 1e-12; o.iterations_max = 50; }
   ALTROSolver s(N);
   int bad = 0;
@@ -276,7 +280,7 @@ void case_quatmpc_stand(bool tight) {
 }
 
 // TestDoubleIntegrator.cpp:377-492: goal constraint + |u| <= u_bnd as a second-order cone c = (u, u_bnd)
-void case_soc() {
+void case_soc(bool cubic = false) {
   DiSetup d;
   ALTROSolver s(d.horizon);
   const std::vector<double> x0 = {2.0, 2.0, 0.0, 0.0};
@@ -299,6 +303,7 @@ void case_soc() {
   s.SetState(x0.data(), kN, 0, LastIndex);
   s.SetInput(u0.data(), kM, 0, LastIndex);
   AltroOptions o;
+  o.use_backtracking_linesearch = !cubic;
   o.penalty_initial = 1.0;
   o.penalty_scaling = 100;
   s.SetOptions(o);
@@ -306,7 +311,7 @@ void case_soc() {
   std::vector<double> xN(kN), u(kM);
   s.GetState(xN.data(), d.horizon);
   s.GetInput(u.data(), 0);
-  std::printf("di_soc bad=%d status=%d iterations=%d dist=%.17g unorm=%.17g feas=%.17g\n", bad, (int)st, s.GetIterations(),
+  std::printf("di_soc%s bad=%d status=%d iterations=%d dist=%.17g unorm=%.17g feas=%.17g\n", cubic ? "_cubic" : "", bad, (int)st, s.GetIterations(),
               norm(xN), norm(u), s.GetPrimalFeasibility());
 }
 
@@ -431,6 +436,7 @@ void case_bicycle_mpc(const std::string& dir, int warm = 0, bool shift = false, 
   for (int k = 0; k <= N; ++k) solver.SetState(&xr[4 * k], n, k);
   AltroOptions opts;
   opts.iterations_max = 80;
+  opts.use_backtracking_linesearch = true;      // TestBicycle.cpp:154
   solver.SetOptions(opts);
   solver.SetWarmStart(warm, shift);
   std::vector<double> xs(4 * (Nsim + 1), 0.0), us(2 * Nsim, 0.0);
@@ -483,5 +489,10 @@ int main(int argc, char** argv) {
   case_soc();
   case_quatmpc_stand(false);
   case_quatmpc_stand(true);
+  // the generic KATs once more with upstream's default (interpolating) line search as recalled (qo_altro.c: linesearch_cubic)
+  case_goal(true);
+  case_bounds(true);
+  case_pendulum_goal(true);
+  case_soc(true);
   return 0;
 }

@@ -650,6 +650,134 @@ static double dual_update(solver_ws* ws) {
 }
 
 
+/* ---- the interpolating line search (upstream default, use_backtracking_linesearch = false) ------------------------------
+ * RECALLED from upstream ALTRO-C (the reference pins the fork zixinz990/altro@b47202ff, CMakeLists.txt:34-40, which is not in
+ * the tree): the merit phi(alpha) is the AL cost of the closed-loop rollout at step length alpha, its slope dphi(alpha) the
+ * gradient of that cost at the CANDIDATE trajectory contracted with d(x,u)/d(alpha) of the rollout,
+ *     dx_0/da = 0,   du_k/da = d_k + K_k dx_k/da,   dx_{k+1}/da = A_k dx_k/da + B_k du_k/da   (A, B at the candidate),
+ *     dphi = sum_k (lx_k + Jx_k' z_k)' dx_k/da + (lu_k + Ju_k' z_k)' du_k/da   (+ the terminal knot),  z = Proj(lam + rho c).
+ * Search: start at alpha = 1; accept when sufficient decrease (c1 = 1e-4) AND |dphi| <= c2 |dphi(0)| (c2 = 0.9) hold; grow
+ * the step (x 1.5, up to 2) while the merit still falls steeply; once a minimum is bracketed, zoom with the minimiser of the
+ * cubic through both end points' values and slopes (bisection when it leaves the bracket).  Only the generic known-answer
+ * tests reach it: every caller on the path selects the backtracking search. */
+static double merit_and_slope(solver_ws* ws, double alpha, double* plain, double* viol, double* dphi) {
+  const qo_problem* p = ws->prob;
+  const int ne = ws->ne, m = ws->m, N = ws->N;
+  rollout_closed_loop(ws, alpha);
+  const double phi = total_cost(ws, ws->Xc, ws->Uc, plain, viol);
+  if (!dphi) return phi;
+  if (!isfinite(phi)) { *dphi = 0.0; return phi; }
+  /* expansions at the candidate: install it as the nominal trajectory for the call, then put the nominal back (the gains
+   * K, d are not touched; the stale expansions are recomputed at the accepted point by the caller) */
+  double* Xn = ws->X; double* Un = ws->U;
+  ws->X = ws->Xc; ws->U = ws->Uc;
+  expansions(ws);
+  soc_refresh(ws);
+  double dx[NE_MAX], dxn[NE_MAX], du[M_MAX], zp[QO_MAXP], act[QO_MAXP];
+  memset(dx, 0, sizeof dx);
+  double slope = 0.0;
+  for (int k = 0; k <= N; ++k) {
+    const knot_ws* kw = &ws->kn[k];
+    if (k < N)
+      for (int j = 0; j < m; ++j) {
+        double sv = kw->d[j];
+        for (int b = 0; b < ne; ++b) sv += kw->K[j * ne + b] * dx[b];
+        du[j] = sv;
+      }
+    for (int a = 0; a < ne; ++a) slope += kw->lx[a] * dx[a];
+    if (k < N) for (int j = 0; j < m; ++j) slope += kw->lu[j] * du[j];
+    for (int ci = 0; ci < p->ncon; ++ci) {
+      if (!con_active_at(&p->con[ci], k)) continue;
+      al_multiplier(ws, k, ci, zp, act);
+      for (int r = 0; r < p->con[ci].p; ++r) {
+        double jd = 0.0;
+        for (int a = 0; a < ne; ++a) jd += kw->Jx[ci][r * ne + a] * dx[a];
+        if (k < N) for (int j = 0; j < m; ++j) jd += kw->Ju[ci][r * m + j] * du[j];
+        slope += zp[r] * jd;
+      }
+    }
+    if (k < N) {
+      for (int a = 0; a < ne; ++a) {
+        double sv = 0.0;
+        for (int b = 0; b < ne; ++b) sv += kw->A[a * ne + b] * dx[b];
+        for (int j = 0; j < m; ++j) sv += kw->B[a * m + j] * du[j];
+        dxn[a] = sv;
+      }
+      memcpy(dx, dxn, sizeof(double) * ne);
+    }
+  }
+  ws->X = Xn; ws->U = Un;
+  *dphi = slope;
+  return phi;
+}
+
+/* minimiser of the cubic through (a, fa, ga) and (b, fb, gb) (Nocedal & Wright, eq. 3.59); NaN when it does not exist */
+static double cubic_min(double a, double fa, double ga, double b, double fb, double gb) {
+  const double d1 = ga + gb - 3.0 * (fa - fb) / (a - b);
+  const double rad = d1 * d1 - ga * gb;
+  if (!(rad >= 0.0)) return NAN;
+  const double d2 = ((b > a) ? 1.0 : -1.0) * sqrt(rad);
+  return b - (b - a) * (gb + d2 - d1) / (gb - ga + 2.0 * d2);
+}
+
+/* returns 1 and the accepted step (candidate in Xc, Uc, dU) or 0; *evals counts merit evaluations */
+static int linesearch_cubic(solver_ws* ws, const qo_options* o, double phi0, double dphi0, double* alpha_out, double* Jn,
+                            double* Jn_plain, double* vn, int* evals) {
+  const double c1 = 1e-4, c2 = 0.9, alpha_max = 2.0, beta_increase = 1.5, min_interval = 1e-6;
+  const int max_iters = 25;
+  if (!(dphi0 < 0.0)) return 0;       /* not a descent direction */
+  double a_lo = 0.0, f_lo = phi0, g_lo = dphi0, a_hi = 0.0, f_hi = 0.0, g_hi = 0.0;
+  double alpha = 1.0, a_prev = 0.0, f_prev = phi0, g_prev = dphi0;
+  int bracketed = 0, hit_max = 0;
+  double f = 0.0, g = 0.0, pl = 0.0, vi = 0.0;
+  for (int it = 0; it < max_iters; ++it) {
+    f = merit_and_slope(ws, alpha, &pl, &vi, &g);
+    ++*evals;
+    if (o->verbose > 1) fprintf(stderr, "   ls(cubic) bracket alpha=%.6f phi=%.15e dphi=%.3e (phi0=%.15e dphi0=%.3e)\n", alpha, f, g, phi0, dphi0);
+    const int decrease = isfinite(f) && f <= phi0 + c1 * alpha * dphi0;
+    if (!decrease || (it > 0 && f >= f_prev)) {
+      a_lo = a_prev; f_lo = f_prev; g_lo = g_prev; a_hi = alpha; f_hi = f; g_hi = g; bracketed = 1;
+      break;
+    }
+    if (fabs(g) <= c2 * fabs(dphi0)) { *alpha_out = alpha; *Jn = f; *Jn_plain = pl; *vn = vi; return 1; }
+    if (g >= 0.0) {
+      a_lo = alpha; f_lo = f; g_lo = g; a_hi = a_prev; f_hi = f_prev; g_hi = g_prev; bracketed = 1;
+      break;
+    }
+    if (hit_max) { *alpha_out = alpha; *Jn = f; *Jn_plain = pl; *vn = vi; return 1; }
+    a_prev = alpha; f_prev = f; g_prev = g;
+    alpha = fmin(alpha * beta_increase, alpha_max);
+    hit_max = alpha >= alpha_max;
+  }
+  if (!bracketed) return 0;
+  for (int it = 0; it < max_iters; ++it) {
+    double a = isfinite(f_hi) ? cubic_min(a_lo, f_lo, g_lo, a_hi, f_hi, g_hi) : NAN;
+    const double lo = fmin(a_lo, a_hi), hi = fmax(a_lo, a_hi);
+    if (!isfinite(a) || a <= lo || a >= hi) a = 0.5 * (a_lo + a_hi);
+    f = merit_and_slope(ws, a, &pl, &vi, &g);
+    ++*evals;
+    if (o->verbose > 1) fprintf(stderr, "   ls(cubic) zoom [%.6f, %.6f] alpha=%.6f phi=%.15e dphi=%.3e\n", a_lo, a_hi, a, f, g);
+    const int decrease = isfinite(f) && f <= phi0 + c1 * a * dphi0;
+    if (!decrease || f >= f_lo) {
+      a_hi = a; f_hi = f; g_hi = g;
+    } else {
+      if (fabs(g) <= c2 * fabs(dphi0)) { *alpha_out = a; *Jn = f; *Jn_plain = pl; *vn = vi; return 1; }
+      if (g * (a_hi - a_lo) >= 0.0) { a_hi = a_lo; f_hi = f_lo; g_hi = g_lo; }
+      a_lo = a; f_lo = f; g_lo = g;
+    }
+    if (fabs(a_hi - a_lo) < min_interval) {
+      /* window too small: upstream returns the best point with sufficient decrease; the candidate buffers must hold it */
+      if (a_lo > 0.0) {
+        f = merit_and_slope(ws, a_lo, &pl, &vi, NULL);
+        *alpha_out = a_lo; *Jn = f; *Jn_plain = pl; *vn = vi;
+        return 1;
+      }
+      return 0;
+    }
+  }
+  return 0;
+}
+
 /* ---- converged mode: primal-dual interior point on the Riccati core ----------
  * (The reference has no such mode: its AL-iLQR scheme, restated above, stalls on
  * states whose optimum sits on many cone faces.)  Newton steps on the perturbed
@@ -927,6 +1055,11 @@ int qo_altro_solve(const qo_problem* prob, const qo_options* opts, double* X, do
     /* forward pass: backtracking line search on the AL merit */
     double alpha = 1.0, Jn = J, Jn_plain = Jplain, vn = viol;
     int accepted = 0;
+    if (opts->linesearch_cubic) {
+      int evals = 0;
+      accepted = linesearch_cubic(&ws, opts, J, ws.dV1, &alpha, &Jn, &Jn_plain, &vn, &evals);
+      r.linesearch_halvings += evals - 1;
+    } else
     for (int ls = 0; ls <= opts->linesearch_max; ++ls) {
       rollout_closed_loop(&ws, alpha);
       Jn = total_cost(&ws, ws.Xc, ws.Uc, &Jn_plain, &vn);

@@ -67,6 +67,11 @@ typedef struct qo_options {
   double tol_stationarity, tol_feasibility, tol_cost_intermediate;
   double tol_step;
   int linesearch_max;
+  /* 0: backtracking on the sufficient-decrease test (use_backtracking_linesearch = true: what every caller on the path
+   * selects, QuatMpc.cpp:23, ConvexMpc.cpp:38, TestBicycle.cpp:154); 1: the interpolating strong-Wolfe search that is the
+   * upstream default (bracketing + cubic-interpolation zoom on merit and merit slope), RECALLED -- the fork is not in the
+   * reference tree -- and used by the generic known-answer tests only                                                    */
+  int linesearch_cubic;
   int verbose;
   /* converged mode: primal-dual interior point on the same Riccati core,
    * run until barrier <= ipm_mu_final, |c+s| <= tol_feasibility and the last
