@@ -36,8 +36,10 @@ hipError_t qmpc_warm_launch(int var, int convex, int batch, size_t lds, hipStrea
                             double* gws, int check_prev);
 
 // qmpc_wform.hip (fourth translation unit): the wave-per-instance kernel with the wrench-form elimination (small batches)
-size_t qmpc_wform_lds_bytes(int N, int kd_global);
-size_t qmpc_wform_slice_doubles(int N);
+size_t qmpc_wform_lds_bytes(int N, int kd_global, int nl);
+size_t qmpc_wform_slice_doubles(int N, int nl);
+hipError_t qmpc_wform_launch8(int var, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size, const void* in,
+                              double* forces, qmpc_info* info, double* traj_u, double* traj_x, double* gws);
 hipError_t qmpc_wform_set_lds(int bytes);
 hipError_t qmpc_wform_launch(int var, int prof, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
                              const qmpc_input* in, double* forces, qmpc_info* info, double* traj_u, double* traj_x,
@@ -127,7 +129,10 @@ constexpr int kLaneMinLoopCold = 18432;       // ... of the cold-started closed 
 // 16384: 0.78 vs 0.82 M, 20480: 0.97 vs 0.84 M)
 constexpr int kLaneMinBatch = 26624;          // QuatMpc, horizons up to 12
 constexpr int kLaneMinBatchLong = 16384;      // QuatMpc, longer horizons
-constexpr int kLaneMinBatchOther = 18432;
+constexpr int kLaneMinBatchOther = 18432;      // ConvexMpc (round-1 wave kernels below it)
+// 8-point model, round 5 (the wave side is the wrench-form kernel, four instances per CU at N=16): 28672 instances wave 1.35 M
+// vs lane 1.17 M solves/s, 32768: 1.35 vs 1.32 M, 40960: 1.36 vs 1.71 M
+constexpr int kLaneMinBatch8 = 34816;
 // reference mode (AL-iLQR, <= 10 iterations; qmpc_lane_ref_kernel): measured against the wave-per-instance reference kernels
 // (tools/refmode_lane_bench.py, N=10): 16384: 1.49 vs 1.74 M solves/s, 32768: 2.70 vs 1.78 M, 65536: 4.59 vs 1.83 M (N=20: 2.53 vs 0.79 M)
 // iteration cap of the lane kernel in the solves of a cold-started closed loop, 11 + N/10 (in-gait states: 10.3 iterations on
@@ -310,7 +315,7 @@ static qmpc_status create_resources(qmpc_handle* h, int N, int nl, int nu) {
   if (params->model != QMPC_MODEL_QUAT8)
     for (int v = 0; v < 6; ++v) if (v != 4) HIP_TRY(qmpc_fused_set_lds(v, 160 * 1024));     // the closed loop's persistent kernels
   if (params->model != QMPC_MODEL_QUAT8) HIP_TRY(qmpc_warm_set_lds(160 * 1024));
-  if (params->model == QMPC_MODEL_QUAT) HIP_TRY(qmpc_wform_set_lds(160 * 1024));
+  if (params->model == QMPC_MODEL_QUAT || params->model == QMPC_MODEL_QUAT8) HIP_TRY(qmpc_wform_set_lds(160 * 1024));
   if (params->mode == QMPC_MODE_REFERENCE) {
     if (params->model == QMPC_MODEL_QUAT8) {
       QMPC_SET_LDS((qmpc_ref_kernel<Quat8Model, 1>), h->lds_bytes_g);     // never everything in LDS
@@ -361,10 +366,11 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     h->variant = v ? std::atoi(v) : 0;
     const char* wf = std::getenv("QMPC_WFORM");
     h->wform = wf ? std::atoi(wf) : 1;
-    h->lds_bytes_w = qmpc_wform_lds_bytes(N, 0);
-    h->lds_bytes_wg = qmpc_wform_lds_bytes(N, 1);
+    h->lds_bytes_w = qmpc_wform_lds_bytes(N, 0, nl);
+    h->lds_bytes_wg = qmpc_wform_lds_bytes(N, 1, nl);
     const char* lm = std::getenv("QMPC_LANE_MIN");
-    h->lane_min_batch = lm ? std::atoi(lm) : (params->model == QMPC_MODEL_QUAT ? (N <= 12 ? kLaneMinBatch : kLaneMinBatchLong) : kLaneMinBatchOther);
+    h->lane_min_batch = lm ? std::atoi(lm) : (params->model == QMPC_MODEL_QUAT ? (N <= 12 ? kLaneMinBatch : kLaneMinBatchLong)
+                                                          : (params->model == QMPC_MODEL_QUAT8 ? kLaneMinBatch8 : kLaneMinBatchOther));
     h->lane_min_loop_cold = lm ? h->lane_min_batch : (kLaneMinLoopCold < h->lane_min_batch ? kLaneMinLoopCold : h->lane_min_batch);
     // Straggler hand-off (cold plain solves of QuatMpc's problem on the lane kernel): a launch of the lane kernel lasts as
     // long as its slowest instance -- 23 interior-point iterations at N=10 (mean 13.6), 31 at N=20 (mean 14.6) -- while
@@ -523,7 +529,15 @@ static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* 
 // layout, with the gains in the workspace (5) for the mid-size batches below the lane kernel's threshold.
 // QMPC_WFORM=0 keeps the round-1 kernels (A/B runs); QMPC_WFORM=3 restricts it to the all-LDS form.
 static int wform_variant(const qmpc_handle* h, int32_t batch) {
-  if (!h->wform || h->params.model != QMPC_MODEL_QUAT || h->params.mode != QMPC_MODE_CONVERGED) return 0;
+  if (!h->wform || h->params.mode != QMPC_MODE_CONVERGED) return 0;
+  if (h->params.model == QMPC_MODEL_QUAT8) {
+    // eight contact points (round 5): 94 KB (everything in LDS) / 49 KB (workspace form) per instance at N=16, one wave per
+    // SIMD either way -- everything in LDS while every instance finds a CU with room, the workspace form (three per CU) beyond
+    if (h->variant >= 2 && h->variant != 3) return h->lds_bytes_wg <= 160 * 1024 ? 5 : 0;
+    if (h->lds_bytes_w <= 160 * 1024 && batch <= 256 * (int)((160 * 1024) / h->lds_bytes_w)) return 3;
+    return h->lds_bytes_wg <= 160 * 1024 ? 5 : (h->lds_bytes_w <= 160 * 1024 ? 3 : 0);
+  }
+  if (h->params.model != QMPC_MODEL_QUAT) return 0;
   const int pv = pick_variant(h, batch);
   if (pv == 0) return h->lds_bytes_w <= 40 * 1024 ? 3 : 0;
   // Longer horizons (N=20, the reference's own configuration: 75 KB per instance): everything in LDS as long as every
@@ -659,6 +673,10 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
   }
   if (const int wv = wform_variant(h, batch)) {
     h->last_kernel = wv == 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
+    if (h->params.model == QMPC_MODEL_QUAT8) {
+      HIP_TRY(qmpc_wform_launch8(wv, (int)batch, wv == 5 ? h->lds_bytes_wg : h->lds_bytes_w, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info,
+                                 d_tu, d_tx, wv == 5 ? h->d_gws : nullptr));
+    } else
     HIP_TRY(qmpc_wform_launch(wv, 0, (int)batch, wv == 5 ? h->lds_bytes_wg : h->lds_bytes_w, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info,
                               d_tu, d_tx, nullptr, wv == 5 ? h->d_gws : nullptr));
     if (timed) {

@@ -45,13 +45,17 @@ struct LayoutW {
 constexpr int kGK = 27;
 // workspace variant (kd_global): the gains KD, the per-point records ROT and the per-knot blocks GK live in a global
 // workspace slice of the instance, [KD | ROT | GK], instead of LDS (19 KB of LDS at N=10: two waves per SIMD)
-__host__ __device__ inline size_t wform_slice(int N) { return ((size_t)N * (13 * 12 + 21 * 4 + kGK) + 1 + 1) & ~(size_t)1; }
+// NL contact points (4: Go1; 8: the synthetic biped of BASELINE config 5): the per-point arrays scale with NL, the gains
+// [Xw | xw], [Xz | xz] (156 per knot) and the per-knot blocks G, r6 live in the 6-dimensional wrench space and do not
+template <int NL = 4>
+__host__ __device__ inline size_t wform_slice(int N) { return ((size_t)N * (13 * 12 + 21 * NL + kGK) + 1 + 1) & ~(size_t)1; }
+template <int NL = 4>
 __host__ __device__ inline Layout make_layout_w(int N, LayoutW* W, bool kd_global = false) {
   Layout L;
   int o = 0;
   auto take = [&](int n) { int r = o; o += n; return r; };
-  constexpr int nu = 12, nc = 24, nl = 4;
-  L.cst = take(64);
+  constexpr int nu = 3 * NL, nc = 6 * NL, nl = NL;
+  L.cst = take(NL == 4 ? 64 : 80);
   L.bw0 = take(3 * nu);
   L.refp = take(13);
   L.uref = take(nu);
@@ -61,15 +65,17 @@ __host__ __device__ inline Layout make_layout_w(int N, LayoutW* W, bool kd_globa
   L.dU = take(N * nu);
   L.S = take(N * nc);
   L.LAM = take(N * nc);
-  L.DS = take(N * nc);
-  L.DLAM = take(N * nc);
+  // eight points: the directions are not kept (apply_w recomputes them from dU, the lane kernel's rule) and the weakly-active
+  // flags live in a register bit field -- 12 KB less at N=16, which is what lets four instances share a CU
+  L.DS = (NL == 8) ? -1 : take(N * nc);
+  L.DLAM = (NL == 8) ? -1 : take(N * nc);
   L.RC = take(N * nc);
   L.AB = take(N * kAB);
   L.XT = take((N + 1) * kXT);
   if (kd_global) {
-    L.KD = 0; L.ROT = N * 13 * nu; W->GK = N * (13 * nu + 21 * nl);      // offsets inside the workspace slice
+    L.KD = 0; L.ROT = N * 13 * 12; W->GK = N * (13 * 12 + 21 * nl);      // offsets inside the workspace slice
   } else {
-    L.KD = take(N * 13 * nu);       // per knot [Xw | xw] (rows 0..5) and [Xz | xz] (rows 6..11), 13 entries per row
+    L.KD = take(N * 13 * 12);       // per knot [Xw | xw] (rows 0..5) and [Xz | xz] (rows 6..11), 13 entries per row
     L.ROT = take(N * 21 * nl);      // per (knot, point): T (9), l10 l20 l21, id0 id1 id2, gq (3), 3 spare (zeta, below)
     W->GK = take(N * kGK + 1);      // per knot G (21) r6 (6); one 0.0 behind the array (masked operand reads point at it)
   }
@@ -79,7 +85,8 @@ __host__ __device__ inline Layout make_layout_w(int N, LayoutW* W, bool kd_globa
   return L;
 }
 // the costate zeta_k (6) of the trial rollout is parked in the spare slots of the knot's first two ROT records
-__device__ __forceinline__ int zeta_slot(int k, int i) { return 84 * k + 21 * (i / 3) + 18 + (i % 3); }
+template <int NL = 4>
+__device__ __forceinline__ int zeta_slot(int k, int i) { return 21 * NL * k + 21 * (i / 3) + 18 + (i % 3); }
 
 constexpr int S6I_(int i, int j) { return i * 6 - i * (i - 1) / 2 + (j - i); }
 __host__ __device__ constexpr int S6I(int i, int j) { return i <= j ? S6I_(i, j) : S6I_(j, i); }      // also at run time
@@ -90,19 +97,21 @@ __host__ __device__ constexpr int S6I(int i, int j) { return i <= j ? S6I_(i, j)
 // lane quad: their shares are summed with quad_perm moves and lane 0 of the quad stores the knot's 27 numbers. ----
 // AL = true (reference mode, qmpc_wform_ref_body.inc): augmented-Lagrangian weights instead of barrier weights,
 //   w_i = rho [lam_i + rho c_i > 0],  g_i = max(lam_i + rho c_i, 0)   (SURVEY.md Appendix B), c_i in the RC slot, `target` = rho
-template <bool AL = false>
+template <bool AL = false, int NL = 4>
 __device__ inline void prepass_w(const DevParams& P, const Layout& L, double* sm, const double* sl,
-                                 double* ROT, double* GK, double target, int lane) {
-  typedef Dim<4> D;
+                                 double* ROT, double* GK, double target, int lane, unsigned kapbits = 0) {
+  typedef Dim<NL> D;
+  constexpr int LSH = (NL == 8) ? 3 : 2;
+  static_assert(NL == 4 || NL == 8, "contact points per knot: one lane quad or two");
   const int N = P.N;
   const double* cst = sm + L.cst;
   double cr[18];
 #pragma unroll
   for (int i = 0; i < 18; ++i) cr[i] = cst[D::C_CR + i];
-  for (int q0 = 0; q0 < 4 * N; q0 += kWave) {
+  for (int q0 = 0; q0 < NL * N; q0 += kWave) {
     const int q = q0 + lane;
-    const bool live = q < 4 * N;
-    const int k = live ? (q >> 2) : 0, l = q & 3;
+    const bool live = q < NL * N;
+    const int k = live ? (q >> LSH) : 0, l = q & (NL - 1);
     double* out = ROT + D::ROT * k + 21 * l;
     double acc[kGK];
 #pragma unroll
@@ -113,7 +122,8 @@ __device__ inline void prepass_w(const DevParams& P, const Layout& L, double* sm
       out[9] = 0; out[10] = 0; out[11] = 0; out[12] = 1; out[13] = 1; out[14] = 1; out[15] = 0; out[16] = 0; out[17] = 0;
     }
     if (stance) {
-      const double R0 = P.R[3 * l], R1 = P.R[3 * l + 1], R2 = P.R[3 * l + 2];
+      const int lr = (NL == 4) ? l : (l & 3);      // r_weights[j % 12] weights input j
+      const double R0 = P.R[3 * lr], R1 = P.R[3 * lr + 1], R2 = P.R[3 * lr + 2];
       double w[6], gi[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -125,7 +135,8 @@ __device__ inline void prepass_w(const DevParams& P, const Layout& L, double* sm
           gi[i] = (z > 0.0) ? z : 0.0;
         } else {
           const double s = sl[L.S + D::NC * k + 6 * l + i];
-          const double kap = sl[L.DS + D::NC * k + 6 * l + i];     // weakly-active flag (see ipm_apply)
+          // weakly-active flag (see ipm_apply); eight points: bit 6 j + i of the lane's j-th (knot, point)
+          const double kap = (NL == 8) ? (((kapbits >> (6 * (q0 >> 6) + i)) & 1u) ? 1.0 : 0.0) : sl[L.DS + D::NC * k + 6 * l + i];
           const double is = fast_rcp(s);
           w[i] = lam * is;
           gi[i] = (target + lam * rc) * is - kap * lam;
@@ -243,12 +254,13 @@ __device__ inline void prepass_w(const DevParams& P, const Layout& L, double* sm
         for (int j = i; j < 6; ++j) acc[S6I(i, j)] = b0 * v0[j] + b1 * v1[j] + b2 * v2[j];
       }
     }
-    // sum over the quad (the four contact points of the knot)
+    // sum over the quad (the four contact points of the knot; eight: the neighbouring quad too)
 #pragma unroll
     for (int i = 0; i < kGK; ++i) {
       double v = acc[i];
       v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
       v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+      if (NL == 8) v += dpp_mov<0x141>(v);      // row_half_mirror: lane i of a group of eight reads lane 7 - i (the other quad)
       acc[i] = v;
     }
     if (live && l == 0) {
@@ -308,16 +320,18 @@ struct ColOps {
 #define QMPC_W_FUSED_ROWS 1      // input recovery + directions, and the apply step, one lane per (knot, contact point)
 #endif
 constexpr int kZeroSlots = 54;      // cst[54..63] hold 0.0 (cst[] is used up to slot 52)
+template <int NL> __host__ __device__ constexpr int kZeroSlotsT() { return NL == 4 ? kZeroSlots : 70; }      // 8 points: cst[] is used up to slot 68 of 80
 struct BwPat {
   ColOps co;
   double Mc[3], Nc[2], qadd[3], sel[3];     // sel[t]: 1.0 where the lane's fragment row is 3 + t
   int ix_w, st_w, ix_a, st_a, ix_x[3], st_x[3], ix_g[2], st_g[2], kwo[2], xoffN[3];
   bool c12;
+  template <int NL = 4>
   __device__ __forceinline__ void init(const DevParams& P, const Layout& L, int lane) {
     const int N = P.N;
     const int c = lane & 15, g = lane >> 4;
     co.init(P, c);
-    const int zs = L.cst + kZeroSlots;
+    const int zs = L.cst + kZeroSlotsT<NL>();
     const bool c35 = (c >= 3 && c < 6), c911 = (c >= 9 && c < 12);
     c12 = c == 12;
     const int abN = L.AB + kAB * (N - 1);
@@ -646,36 +660,49 @@ __device__ __forceinline__ void srbd_step_w(const DevParams& P, const double gb[
 }
 
 // wrench of every knot from the inputs U (WITH_DU: U + dU), lane (k, i), i < 6
-template <bool WITH_DU>
+template <bool WITH_DU, int NL = 4>
 __device__ inline void wrench_from_inputs(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm, int lane) {
   const int N = P.N;
+  constexpr int NU = 3 * NL;
   for (int q = lane; q < 6 * N; q += kWave) {
     const int k = q / 6, i = q - 6 * k;
-    double u[12];
+    double u[NU];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) u[j] = sm[L.U + 12 * k + j] + (WITH_DU ? sm[L.dU + 12 * k + j] : 0.0);
-    const double* b = sm + L.bw0 + ((i >= 3) ? 12 * (i - 3) : 0);
-    double s0 = 0.0, s1 = 0.0, f0 = 0.0, f1 = 0.0;
+    for (int j = 0; j < NU; ++j) u[j] = sm[L.U + NU * k + j] + (WITH_DU ? sm[L.dU + NU * k + j] : 0.0);
+    const double* b = sm + L.bw0 + ((i >= 3) ? NU * (i - 3) : 0);
+    if (NL == 4) {
+      double s0 = 0.0, s1 = 0.0, f0 = 0.0, f1 = 0.0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) { s0 += b[j] * u[j]; s1 += b[6 + j] * u[6 + j]; }
+      for (int j = 0; j < 6; ++j) { s0 += b[j] * u[j]; s1 += b[6 + j] * u[6 + j]; }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      f0 += (i == a) ? u[a] + u[6 + a] : 0.0;
-      f1 += (i == a) ? u[3 + a] + u[9 + a] : 0.0;
+      for (int a = 0; a < 3; ++a) {
+        f0 += (i == a) ? u[a] + u[6 + a] : 0.0;
+        f1 += (i == a) ? u[3 + a] + u[9 + a] : 0.0;
+      }
+      sm[LW.WR + q] = (i < 3) ? f0 + f1 : s0 + s1;
+    } else {
+      double sv[4] = {0.0, 0.0, 0.0, 0.0}, fv[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int j = 0; j < NU; ++j) sv[j / 6] += b[j] * u[j];
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) fv[l >> 1] += (i == a) ? u[3 * l + a] : 0.0;
+      sm[LW.WR + q] = (i < 3) ? (fv[0] + fv[1]) + (fv[2] + fv[3]) : (sv[0] + sv[1]) + (sv[2] + sv[3]);
     }
-    sm[LW.WR + q] = (i < 3) ? f0 + f1 : s0 + s1;
   }
   QSYNC();
 }
 
 // shortened primal step: scale the trial increment and re-roll the states open loop from the knots' wrenches
+template <int NL = 4>
 __device__ inline void rollout_scaled_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm, double ap, int lane) {
-  typedef Dim<4> D;
+  typedef Dim<NL> D;
   const int N = P.N;
   const double* cst = sm + L.cst;
   for (int i = lane; i < N * D::NU; i += kWave) sm[L.dU + i] *= ap;
   QSYNC();
-  wrench_from_inputs<true>(P, L, LW, sm, lane);
+  wrench_from_inputs<true, NL>(P, L, LW, sm, lane);
   double gb[3], wd0[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) { gb[a] = cst[D::C_GB + a]; wd0[a] = cst[D::C_WD0 + a]; }
@@ -703,8 +730,9 @@ __device__ inline void rollout_scaled_w(const DevParams& P, const Layout& L, con
 // ---- expansions at (X, U): four lanes per knot (three columns of the Jacobian blocks + the cost expansion) as in
 // expand_knot_part (qmpc_device.h; AltroUtils.cpp:78-110,153-168), with the angular acceleration taken from the knot's
 // wrench (WR) instead of being re-summed over the twelve inputs by every lane ------------------------------------------
+template <int NL = 4>
 __device__ inline void expansions_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm, int lane) {
-  typedef Dim<4> D;
+  typedef Dim<NL> D;
   const int N = P.N;
   const double* cst = sm + L.cst;
   for (int q = lane; q < 4 * (N + 1); q += kWave) {
@@ -758,7 +786,7 @@ __device__ inline void expansions_w(const DevParams& P, const Layout& L, const L
     } else {
       // the cost expansion of knot k = 0..N (part 3 of expand_knot_part)
       double u0[1] = {0.0};
-      expand_knot_part<4>(P, cst, sm + L.bw0, sm + L.refp, k, 3, x, u0, x, ABk, XTk);
+      expand_knot_part<NL>(P, cst, sm + L.bw0, sm + L.refp, k, 3, x, u0, x, ABk, XTk);
     }
   }
   QSYNC();
@@ -782,10 +810,10 @@ __device__ __forceinline__ void roll_load_w(const Layout& L, const LayoutW& LW, 
 }
 // PF: the next knot's gains / old state / Jacobian blocks are loaded one knot ahead into a second register set (90 more
 // registers: the one-wave-per-SIMD form); without it the loads sit at the top of the knot (two waves per SIMD hide them)
-template <bool PROF, bool PF>
+template <bool PROF, bool PF, int NL = 4>
 __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm,
                                         const double* KD, double* ROT, int lane, Prof<PROF>& prof, double alpha = 1.0) {
-  typedef Dim<4> D;
+  typedef Dim<NL> D;
   const int N = P.N;
   const double* cst = sm + L.cst;
   double gb[3], wd0[3];
@@ -820,7 +848,7 @@ __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, con
     const double p2 = kd[6] * e[6] + kd[7] * e[7] + kd[8] * e[8];
     const double p3 = kd[9] * e[9] + kd[10] * e[10] + kd[11] * e[11];
     const double s = (p0 + p1) + (p2 + p3);
-    if (zlane) ROT[zeta_slot(k, lane - 6)] = s;      // the costate of the contact points, for the input recovery
+    if (zlane) ROT[zeta_slot<NL>(k, lane - 6)] = s;      // the costate of the contact points, for the input recovery
     double wn = cur.wk + s;
     tick_dep1(prof, PH_R_GAIN, wn);
     if (PF && k + 1 < N) roll_load_w(L, LW, sm, KD, k + 1, row, wi, nxt);      // one knot ahead
@@ -895,14 +923,16 @@ __device__ inline double expected_decrease_w(const DevParams& P, const Layout& L
 //      du_l = -T_l D~_l^-1 (V_l' zeta + gq_l),   V_l' zeta = T_l' (zeta_f + Bw0_l' zeta_t) ----
 // Returns nonzero (wave-uniform) when an increment is not finite: the trial step is then NOT applied (QMPC_NOT_PD, the
 // rule of the lane kernel) -- the step-length reductions that follow drop NaNs silently.
+template <int NL = 4>
 __device__ inline int recover_inputs_w(const DevParams& P, const Layout& L, double* sm, const double* ROT, int lane,
                                        double alpha = 1.0, const double* zsrc = nullptr) {
-  typedef Dim<4> D;
+  typedef Dim<NL> D;
+  constexpr int LSH = (NL == 8) ? 3 : 2;
   const int N = P.N;
   const double* cst = sm + L.cst;
   bool bad = false;
-  for (int q = lane; q < 4 * N; q += kWave) {
-    const int k = q >> 2, l = q & 3;
+  for (int q = lane; q < NL * N; q += kWave) {
+    const int k = q >> LSH, l = q & (NL - 1);
     double du[3] = {0.0, 0.0, 0.0};
     if (cst[D::C_CON + l] != 0.0) {
       const double* rec = ROT + D::ROT * k + 21 * l;
@@ -910,7 +940,7 @@ __device__ inline int recover_inputs_w(const DevParams& P, const Layout& L, doub
 #pragma unroll
       for (int i = 0; i < 9; ++i) T[i] = rec[i];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) z[i] = zsrc ? zsrc[6 * k + i] : ROT[zeta_slot(k, i)];
+      for (int i = 0; i < 6; ++i) z[i] = zsrc ? zsrc[6 * k + i] : ROT[zeta_slot<NL>(k, i)];
       const double l10 = rec[9], l20 = rec[10], l21 = rec[11], id0 = rec[12], id1 = rec[13], id2 = rec[14];
       const double* bw = sm + L.bw0 + 3 * l;
       double f[3];
@@ -941,10 +971,12 @@ __device__ inline int recover_inputs_w(const DevParams& P, const Layout& L, doub
 // (compared by cross-multiplication): one division per lane instead of two per row.  `kapbits` returns the weakly-active
 // flags of the lane's rows (bit 6 j + i: row i of the lane's j-th (knot, point)), read from the DS slot before the
 // directions overwrite it; apply_w consumes them.  Returns nonzero (wave-uniform) when an increment is not finite.
+template <int NL = 4>
 __device__ inline int recover_directions_w(const DevParams& P, const Layout& L, double* sm, double* sl, const double* ROT,
                                            double target, int lane, double* alpha_p, double* alpha_d, double* full_step,
                                            unsigned& kapbits) {
-  typedef Dim<4> D;
+  typedef Dim<NL> D;
+  constexpr int LSH = (NL == 8) ? 3 : 2;
   const int N = P.N;
   const double* cst = sm + L.cst;
   const double* cr = cst + D::C_CR;
@@ -953,8 +985,8 @@ __device__ inline int recover_directions_w(const DevParams& P, const Layout& L, 
   double stp = 0.0;
   unsigned bits = 0;
   int j = 0;
-  for (int q = lane; q < 4 * N; q += kWave, ++j) {
-    const int k = q >> 2, l = q & 3;
+  for (int q = lane; q < NL * N; q += kWave, ++j) {
+    const int k = q >> LSH, l = q & (NL - 1);
     const bool stance = cst[D::C_CON + l] != 0.0;
     const double* rec = ROT + D::ROT * k + 21 * l;
     const int i0 = D::NC * k + 6 * l;
@@ -962,11 +994,14 @@ __device__ inline int recover_directions_w(const DevParams& P, const Layout& L, 
 #pragma unroll
     for (int i = 0; i < 9; ++i) T[i] = rec[i];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) z[i] = ROT[zeta_slot(k, i)];
+    for (int i = 0; i < 6; ++i) z[i] = ROT[zeta_slot<NL>(k, i)];
     const double l10 = rec[9], l20 = rec[10], l21 = rec[11], id0 = rec[12], id1 = rec[13], id2 = rec[14];
     const double g0 = rec[15], g1 = rec[16], g2 = rec[17];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { sv[i] = sl[L.S + i0 + i]; lv[i] = sl[L.LAM + i0 + i]; kap[i] = sl[L.DS + i0 + i]; rc[i] = sl[L.RC + i0 + i]; }
+    for (int i = 0; i < 6; ++i) {
+      sv[i] = sl[L.S + i0 + i]; lv[i] = sl[L.LAM + i0 + i]; rc[i] = sl[L.RC + i0 + i];
+      kap[i] = (NL == 8) ? (((kapbits >> (6 * j + i)) & 1u) ? 1.0 : 0.0) : sl[L.DS + i0 + i];
+    }
     const double* bw = sm + L.bw0 + 3 * l;
     double du[3] = {0.0, 0.0, 0.0};
     if (stance) {
@@ -999,8 +1034,10 @@ __device__ inline int recover_directions_w(const DevParams& P, const Layout& L, 
       pn = up ? sv[i] : pn; pd = up ? -dsv : pd;
       const bool ud = (dlv < 0.0) && (dd == 0.0 || lv[i] * dd < dn * (-dlv));
       dn = ud ? lv[i] : dn; dd = ud ? -dlv : dd;
-      sl[L.DS + i0 + i] = dsv;
-      sl[L.DLAM + i0 + i] = dlv;
+      if (NL != 8) {
+        sl[L.DS + i0 + i] = dsv;
+        sl[L.DLAM + i0 + i] = dlv;
+      }
       bits |= (stance && kap[i] != 0.0) ? (1u << (6 * j + i)) : 0u;
     }
   }
@@ -1016,24 +1053,43 @@ __device__ inline int recover_directions_w(const DevParams& P, const Layout& L, 
 
 // apply the step to (s, rc, lambda) and leave the weakly-active (Tapia) flags in the DS slot -- ipm_apply of qmpc_kernels.hip
 // with the rows of a contact point in one lane
+// Eight points: the directions are recomputed here from the trial increment dU (still unscaled: the caller applies before it
+// re-rolls a shortened step) and the new flags go back into `kapbits`; sm / target are only read in that form.
+template <int NL = 4>
 __device__ inline void apply_w(const DevParams& P, const Layout& L, double* sl, double ap, double ad, unsigned conmask,
-                               int lane, unsigned kapbits, double& sl_part, double& rc_part) {
-  typedef Dim<4> D;
+                               int lane, unsigned& kapbits, double& sl_part, double& rc_part, const double* sm = nullptr,
+                               double target = 0.0) {
+  typedef Dim<NL> D;
+  constexpr int LSH = (NL == 8) ? 3 : 2;
   const int N = P.N;
   sl_part = 0.0;
   rc_part = 0.0;
   const bool full = (ap >= 0.99) && (ad >= 0.99);
   const double rcs = (ap >= 1.0) ? 0.0 : (1.0 - ap);
   int j = 0;
-  for (int q = lane; q < 4 * N; q += kWave, ++j) {
-    const int k = q >> 2, l = q & 3;
+  for (int q = lane; q < NL * N; q += kWave, ++j) {
+    const int k = q >> LSH, l = q & (NL - 1);
     if (!(conmask & (1u << l))) continue;
     const int i0 = D::NC * k + 6 * l;
     double s0[6], l0[6], ds[6], dl[6], rc[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      s0[i] = sl[L.S + i0 + i]; l0[i] = sl[L.LAM + i0 + i]; ds[i] = sl[L.DS + i0 + i]; dl[i] = sl[L.DLAM + i0 + i]; rc[i] = sl[L.RC + i0 + i];
+      s0[i] = sl[L.S + i0 + i]; l0[i] = sl[L.LAM + i0 + i]; rc[i] = sl[L.RC + i0 + i];
+      if (NL != 8) { ds[i] = sl[L.DS + i0 + i]; dl[i] = sl[L.DLAM + i0 + i]; }
     }
+    if (NL == 8) {
+      const double* cr = sm + L.cst + D::C_CR;
+      const double* du = sm + L.dU + D::NU * k + 3 * l;
+      const double du0 = du[0], du1 = du[1], du2 = du[2];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const double kp = ((kapbits >> (6 * j + i)) & 1u) ? 1.0 : 0.0;
+        const double jd = cr[3 * i] * du0 + cr[3 * i + 1] * du1 + cr[3 * i + 2] * du2;
+        ds[i] = -(jd + rc[i]);
+        dl[i] = (target - (1.0 + kp) * s0[i] * l0[i] - l0[i] * ds[i]) * fast_rcp(s0[i]);
+      }
+    }
+    unsigned newbits = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const bool kap0 = (kapbits >> (6 * j + i)) & 1u;
@@ -1046,8 +1102,10 @@ __device__ inline void apply_w(const DevParams& P, const Layout& L, double* sl, 
       sl_part += s1 * l1;
       rc_part = fmax(rc_part, fabs(rc1));
       const bool sig = full && (s1 < 0.6 * s0[i]) && (l1 < 0.6 * l0[i]) && (kap0 || ((s1 > 0.4 * s0[i]) && (l1 > 0.4 * l0[i])));
-      sl[L.DS + i0 + i] = sig ? 1.0 : 0.0;
+      if (NL == 8) newbits |= sig ? (1u << (6 * j + i)) : 0u;
+      else sl[L.DS + i0 + i] = sig ? 1.0 : 0.0;
     }
+    if (NL == 8) kapbits = (kapbits & ~(63u << (6 * j))) | newbits;
   }
 }
 

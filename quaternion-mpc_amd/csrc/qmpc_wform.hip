@@ -58,6 +58,29 @@ __global__ __launch_bounds__(64, WVAR == 5 ? 2 : 1) void qmpc_solve_w_kernel(
 #include "qmpc_wform_body.inc"
 }
 
+// ---- the same solve for EIGHT contact points (QuatModelT<8>: the synthetic biped of BASELINE config 5; round 5) ----------
+// The wrench space is 6-dimensional whatever the number of contact points: the backward pass, the closed-loop rollout and
+// the gains are those of the four-point kernel; the per-point phases (pre-pass, input recovery + directions, apply) walk
+// 8 N (knot, point) pairs, a knot's eight shares of G / r6 are summed over two lane quads.  One wave per SIMD in either
+// variant: an instance holds 94 KB (3) / 49 KB (5) of LDS at N=16, so the workspace form too leaves a SIMD at most one wave.
+template <int WVAR>
+__global__ __launch_bounds__(64, 1) void qmpc_solve8_w_kernel(
+    DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
+    double* __restrict__ traj_u, double* __restrict__ traj_x, int batch, double* __restrict__ gws) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int b = blockIdx.x;
+  if (b >= batch) return;
+  const int wslot = b;
+  const int lane = threadIdx.x;
+  constexpr bool PROF = false;
+  long long* prof_out = nullptr;
+  constexpr int warm_t = 0;
+  constexpr const double* resume = nullptr;
+#define QMPC_WNL 8
+#include "qmpc_wform_body.inc"
+#undef QMPC_WNL
+}
+
 // The same solve over a LIST of instances (sel[0 .. *sel_count), built on the device): the workgroups walk the list with
 // the grid as stride.  The straggler hand-off of large batches (qmpc_hip.hip: launch_solve): the lane-per-instance kernel
 // stops after a fixed number of iterations and the few instances it leaves unconverged are solved here, where one
@@ -120,18 +143,19 @@ __global__ __launch_bounds__(64, OCC) void qmpc_ref_w_kernel(
 using namespace qmpc_wform_tu;
 
 // called from qmpc_hip.hip (declared there); hidden: not part of the C ABI
-__attribute__((visibility("hidden"))) size_t qmpc_wform_lds_bytes(int N, int kd_global) {
+__attribute__((visibility("hidden"))) size_t qmpc_wform_lds_bytes(int N, int kd_global, int nl) {
   LayoutW LW;
-  return (size_t)make_layout_w(N, &LW, kd_global != 0).total * sizeof(double);
+  return (size_t)(nl == 8 ? make_layout_w<8>(N, &LW, kd_global != 0) : make_layout_w<4>(N, &LW, kd_global != 0)).total * sizeof(double);
 }
-__attribute__((visibility("hidden"))) size_t qmpc_wform_slice_doubles(int N) { return wform_slice(N); }
+__attribute__((visibility("hidden"))) size_t qmpc_wform_slice_doubles(int N, int nl) { return nl == 8 ? wform_slice<8>(N) : wform_slice<4>(N); }
 __attribute__((visibility("hidden"))) hipError_t qmpc_wform_set_lds(int bytes) {
-  const void* k[9] = {reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 3>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 3>),
+  const void* k[11] = {reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 3>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 3>),
                       reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 5>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 5>),
                       reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<3>), reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<5>),
                       reinterpret_cast<const void*>(qmpc_ref_w_kernel<3>), reinterpret_cast<const void*>(qmpc_ref_w_kernel<5>),
-                      reinterpret_cast<const void*>(qmpc_ref_w_kernel<5, 1>)};
-  for (int i = 0; i < 9; ++i) {
+                      reinterpret_cast<const void*>(qmpc_ref_w_kernel<5, 1>),
+                      reinterpret_cast<const void*>(qmpc_solve8_w_kernel<3>), reinterpret_cast<const void*>(qmpc_solve8_w_kernel<5>)};
+  for (int i = 0; i < 11; ++i) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
   }
@@ -154,6 +178,20 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_wform_launch(int var, int 
     if (prof) QMPC_LAUNCH_W(true, 3); else QMPC_LAUNCH_W(false, 3);
   }
 #undef QMPC_LAUNCH_W
+  return hipGetLastError();
+}
+// eight contact points (records of 64 doubles, 24 forces per instance); var as above
+__attribute__((visibility("hidden"))) hipError_t qmpc_wform_launch8(int var, int batch, size_t lds, hipStream_t s, const void* dev_params,
+                                                                    size_t dev_params_size, const void* in, double* forces, qmpc_info* info,
+                                                                    double* traj_u, double* traj_x, double* gws) {
+  if (dev_params_size != sizeof(DevParams)) return hipErrorInvalidValue;
+  DevParams P;
+  std::memcpy(&P, dev_params, sizeof P);
+  const qmpc_input* in_ = static_cast<const qmpc_input*>(in);
+  if (var == 5)
+    hipLaunchKernelGGL(qmpc_solve8_w_kernel<5>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in_, forces, info, traj_u, traj_x, batch, gws);
+  else
+    hipLaunchKernelGGL(qmpc_solve8_w_kernel<3>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in_, forces, info, traj_u, traj_x, batch, gws);
   return hipGetLastError();
 }
 // the instances sel[0 .. *sel_count) (device memory), `grid` workgroups walking the list

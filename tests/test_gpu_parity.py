@@ -473,6 +473,40 @@ def test_biped8_forces_match_oracle(pkg, lib, oracle, N):
     s.close()
 
 
+def test_biped8_wrench_form_kernels(pkg, lib, oracle, monkeypatch):
+    """Round 5: the 8-contact-point model on the wrench-form wave kernels (qmpc_solve8_w_kernel) -- everything in LDS up to
+    512 instances at N=16, gains / per-point records in the workspace beyond (no direction arrays, flags in a register: four
+    instances per CU) -- on the per-GPU share of BASELINE config 5 (65536 instances over 8 GPUs = 8192, N=16): every
+    instance converges, a sample equals the oracle to 1e-5 N (individual corner forces, see above) with identical iteration
+    counts on >= 97 %, the two variants agree to 1e-7 N, the dense round-1 kernels (QMPC_WFORM=0) give the same forces."""
+    N, B = 16, 8192
+    p = pkg.default_biped8_params(N, pkg.MODE_CONVERGED, lib)
+    rec = pkg.random_biped8_states(B, config_id=5)
+    s = pkg.Solver(p, B, device=0, lib=lib)
+    assert [s.kernel_for_batch(b) for b in (1, 512, 513, 8192)] == ["wform_lds", "wform_lds", "wform_ws", "wform_ws"]
+    f, info = s.solve8(rec)
+    f2, info2 = s.solve8(rec)
+    assert np.array_equal(f, f2) and np.array_equal(info, info2)
+    assert (info["status"] == 0).all() and info["max_violation"].max() < 1e-8
+    swing = np.repeat(rec["contacts"] == 0, 3, axis=1)
+    assert np.abs(f[swing]).max() == 0.0
+    fl, il = s.solve8(rec[:512])                                   # the all-LDS variant on the first 512
+    assert np.abs(fl - f[:512]).max() < 1e-7 and np.array_equal(il["iterations"], info["iterations"][:512])
+    idx = np.arange(0, B, B // 192)[:192]
+    fo, io = oracle.solve8(p, rec[idx], threads=8)
+    err = np.abs(f[idx] - fo).max()
+    same = float((info["iterations"][idx] == io["iterations"]).mean())
+    print(f"8-point wrench-form kernel, B={B} N={N}: sample of {len(idx)} vs oracle: max |df| {err:.2e} N, iteration counts equal on {100 * same:.1f} %")
+    assert (io["status"] == 0).all() and err < 1e-5 and same >= 0.97
+    s.close()
+    monkeypatch.setenv("QMPC_WFORM", "0")
+    s0 = pkg.Solver(p, B, device=0, lib=lib)
+    assert s0.kernel_for_batch(B) == "dense_ws"
+    f0, i0 = s0.solve8(rec[:2048])
+    s0.close()
+    assert np.abs(f0 - f[:2048]).max() < 1e-5 and float((i0["iterations"] == info["iterations"][:2048]).mean()) >= 0.97
+
+
 def test_eight_point_kernel_reduces_to_the_four_leg_one(pkg, lib):
     """Go1 parameters, Go1 footholds in points 0-3, points 4-7 in swing: the TU=2 kernel must return the
     forces of the (golden-pinned) 4-leg kernel."""
