@@ -38,6 +38,8 @@ hipError_t qmpc_warm_launch(int var, int convex, int batch, size_t lds, hipStrea
 // qmpc_wform.hip (fourth translation unit): the wave-per-instance kernel with the wrench-form elimination (small batches)
 size_t qmpc_wform_lds_bytes(int N, int kd_global, int nl);
 size_t qmpc_wform_slice_doubles(int N, int nl);
+hipError_t qmpc_wform_launch_convex(int var, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
+                                    const void* in, double* forces, qmpc_info* info, double* traj_u, double* traj_x, double* gws);
 hipError_t qmpc_wform_launch8(int var, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size, const void* in,
                               double* forces, qmpc_info* info, double* traj_u, double* traj_x, double* gws);
 hipError_t qmpc_wform_set_lds(int bytes);
@@ -315,7 +317,7 @@ static qmpc_status create_resources(qmpc_handle* h, int N, int nl, int nu) {
   if (params->model != QMPC_MODEL_QUAT8)
     for (int v = 0; v < 6; ++v) if (v != 4) HIP_TRY(qmpc_fused_set_lds(v, 160 * 1024));     // the closed loop's persistent kernels
   if (params->model != QMPC_MODEL_QUAT8) HIP_TRY(qmpc_warm_set_lds(160 * 1024));
-  if (params->model == QMPC_MODEL_QUAT || params->model == QMPC_MODEL_QUAT8) HIP_TRY(qmpc_wform_set_lds(160 * 1024));
+  HIP_TRY(qmpc_wform_set_lds(160 * 1024));
   if (params->mode == QMPC_MODE_REFERENCE) {
     if (params->model == QMPC_MODEL_QUAT8) {
       QMPC_SET_LDS((qmpc_ref_kernel<Quat8Model, 1>), h->lds_bytes_g);     // never everything in LDS
@@ -528,8 +530,21 @@ static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* 
 // the round-1 family would keep everything in LDS (one instance per SIMD at most) and four instances fit a CU with its
 // layout, with the gains in the workspace (5) for the mid-size batches below the lane kernel's threshold.
 // QMPC_WFORM=0 keeps the round-1 kernels (A/B runs); QMPC_WFORM=3 restricts it to the all-LDS form.
-static int wform_variant(const qmpc_handle* h, int32_t batch) {
+// `plain`: the caller is a plain solve (launch_solve) -- ConvexMpc's problem has the wrench form there only; its warm start
+// and its closed loop keep the round-1 bodies (qmpc_solve_body.inc), and body_variant must keep naming those
+static int wform_variant(const qmpc_handle* h, int32_t batch, bool plain = false) {
   if (!h->wform || h->params.mode != QMPC_MODE_CONVERGED) return 0;
+  if (h->params.model == QMPC_MODEL_CONVEX) {
+    if (!plain || h->variant >= 2) return 0;
+    // the same rule as QuatMpc's problem at its horizon (N=20: 75 KB per instance): everything in LDS while every instance
+    // finds a CU with room, the workspace form (two waves per SIMD) beyond
+    if (h->lds_bytes_w <= 160 * 1024 && batch <= 256 * (int)((160 * 1024) / h->lds_bytes_w)) return 3;
+    // ... as long as the batch is ONE round of resident instances (N=20: 37 KB, four per CU = 1024): beyond that the round-1
+    // kernel with its slack arrays in the workspace too (17 KB: two waves per SIMD) wins -- measured at N=20, 8192 instances:
+    // 0.87 M (round-1) against 0.68 M solves/s
+    if (h->lds_bytes_wg <= 80 * 1024 && batch <= 256 * (int)((160 * 1024) / h->lds_bytes_wg)) return 5;
+    return 0;
+  }
   if (h->params.model == QMPC_MODEL_QUAT8) {
     // eight contact points (round 5): 94 KB (everything in LDS) / 49 KB (workspace form) per instance at N=16, one wave per
     // SIMD either way -- everything in LDS while every instance finds a CU with room, the workspace form (three per CU) beyond
@@ -671,9 +686,12 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
     }
     return QMPC_OK;
   }
-  if (const int wv = wform_variant(h, batch)) {
+  if (const int wv = wform_variant(h, batch, handoff != 2)) {      // (handoff 2: a tick of the closed loop -- its two launch forms share a body)
     h->last_kernel = wv == 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
-    if (h->params.model == QMPC_MODEL_QUAT8) {
+    if (h->params.model == QMPC_MODEL_CONVEX) {
+      HIP_TRY(qmpc_wform_launch_convex(wv, (int)batch, wv == 5 ? h->lds_bytes_wg : h->lds_bytes_w, s, &h->dev, sizeof h->dev, d_in, d_forces,
+                                       d_info, d_tu, d_tx, wv == 5 ? h->d_gws : nullptr));
+    } else if (h->params.model == QMPC_MODEL_QUAT8) {
       HIP_TRY(qmpc_wform_launch8(wv, (int)batch, wv == 5 ? h->lds_bytes_wg : h->lds_bytes_w, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info,
                                  d_tu, d_tx, wv == 5 ? h->d_gws : nullptr));
     } else
@@ -1015,7 +1033,7 @@ static int kernel_for_batch(const qmpc_handle* h, int32_t batch) {
     return ws ? QMPC_KERNEL_DENSE_WS : QMPC_KERNEL_DENSE_LDS;
   }
   if (use_lane(h, batch, nullptr, nullptr)) return handoff_cap(h, 1) ? QMPC_KERNEL_LANE_HANDOFF : QMPC_KERNEL_LANE;
-  if (const int wv = wform_variant(h, batch)) return wv == 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
+  if (const int wv = wform_variant(h, batch, true)) return wv == 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
   return pick_variant(h, batch) >= 1 ? QMPC_KERNEL_DENSE_WS : QMPC_KERNEL_DENSE_LDS;
 }
 

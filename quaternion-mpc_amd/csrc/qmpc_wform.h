@@ -91,13 +91,58 @@ __device__ __forceinline__ int zeta_slot(int k, int i) { return 21 * NL * k + 21
 constexpr int S6I_(int i, int j) { return i * 6 - i * (i - 1) / 2 + (j - i); }
 __host__ __device__ constexpr int S6I(int i, int j) { return i <= j ? S6I_(i, j) : S6I_(j, i); }      // also at run time
 
+// ---- the sibling controller's problem on the same kernels (round 5; ConvexMpc.cpp:81-198, AltroUtils.cpp:224-359) ----------
+// MD = WM_CONVEX: the Euler-angle model.  Its state stays in the reference's order [rpy, pos, w, v] in LDS (X, 13 doubles
+// apart like the quaternion state); inside the recursion the blocks are ordered like the error state of the quaternion
+// model, [p, phi, v, w] (cvperm), and the midpoint transition has the shape the backward pass is written for,
+//   Abar = [[I,0,hI,0],[0,A1,0,A3],[0,0,I,0],[0,0,0,I]],  A1 = I + h [0 0 j0; 0 0 j1; 0 0 0],  A3 = h [c s hh j0; -s c hh j1; 0 0 1]
+// (c, s, j at the midpoint yaw; the reference's Jacobian omits d Iw^-1 / d yaw, AltroUtils.cpp:295-359), and
+// Bbar = M Wr_k with the wrench (F, t') where t' = Iw(yaw_m)^-1 sum r x u: the inertia at the MIDPOINT yaw goes into the
+// per-point map knot by knot (Winv_k [r_l]x, formed where it is used from the knot's four numbers), M's attitude block is
+// Wt = h hh Rz_m' Iw(yaw)^-1 Iw(yaw_m).  The cone rows act on the world-frame forces directly.  The rollout carries the RAW
+// wrench (F, sum r x u): an increment dt' of the linearised torque is dt = Iw(yaw_m) dt' exactly.  This is the formulation
+// of the lane kernel's MD_CONVEX passes (qmpc_lane_core.h), in the fragment layout.
+// Per-knot numbers beyond A1 / A3 / W (AB record, same slots as the quaternion model): Winv_k = Iw(yaw_m)^-1 (w00 w01 w11 wzz)
+// and Iw(yaw_m) (i00 i01 i11 izz) in slots 0..7 of the knot's XT record (the model's cost Hessian is constant: no block there).
+enum { WM_QUAT = 0, WM_CONVEX = 1 };
+__host__ __device__ constexpr int cvperm(int r) { return r < 3 ? r + 3 : (r < 6 ? r - 3 : (r < 9 ? r + 3 : r - 3)); }   // internal row -> state index
+__device__ __forceinline__ void cv_step_w(const DevParams& P, const double* x, const double w[6], double* xn) {
+  double s0, c0, w00, w01, w11;
+  sincos(x[2], &s0, &c0);
+  ConvexModel::winv(P, c0, s0, w00, w01, w11);
+  const double vd[3] = {w[0] * P.inv_mass, w[1] * P.inv_mass, w[2] * P.inv_mass - 9.81};
+  const double wd0[3] = {w00 * w[3] + w01 * w[4], w01 * w[3] + w11 * w[4], P.Iinv[8] * w[5]};
+  const double yawm = x[2] + P.hh * x[8];
+  const double wm[3] = {x[6] + P.hh * wd0[0], x[7] + P.hh * wd0[1], x[8] + P.hh * wd0[2]};
+  double sm_, cm_;
+  sincos(yawm, &sm_, &cm_);
+  ConvexModel::winv(P, cm_, sm_, w00, w01, w11);
+  const double wdm[3] = {w00 * w[3] + w01 * w[4], w01 * w[3] + w11 * w[4], P.Iinv[8] * w[5]};
+  xn[0] = x[0] + P.h * (cm_ * wm[0] + sm_ * wm[1]);
+  xn[1] = x[1] + P.h * (-sm_ * wm[0] + cm_ * wm[1]);
+  xn[2] = x[2] + P.h * wm[2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    xn[3 + a] = x[3 + a] + P.h * (x[9 + a] + P.hh * vd[a]);
+    xn[6 + a] = x[6 + a] + P.h * wdm[a];
+    xn[9 + a] = x[9 + a] + P.h * vd[a];
+  }
+  xn[12] = 0.0;
+}
+// y = Winv_k t  (t a 3-vector of the wrench's torque part)
+__device__ __forceinline__ void cv_winv_mul(const double* W, const double t[3], double y[3]) {
+  y[0] = W[0] * t[0] + W[1] * t[1];
+  y[1] = W[1] * t[0] + W[2] * t[1];
+  y[2] = W[3] * t[2];
+}
+
 // ---- pre-pass over (knot, contact point), one lane each: barrier weights, rotated frame, L D L' of the 3 x 3 block,
 // and the point's share of G = sum V D^-1 V', r6 = sum V D^-1 g (the arithmetic of rotation_prepass in
 // qmpc_kernels.hip followed by leg_block / pass B step 1 of qmpc_lane_core.h).  The four points of a knot sit in one
 // lane quad: their shares are summed with quad_perm moves and lane 0 of the quad stores the knot's 27 numbers. ----
 // AL = true (reference mode, qmpc_wform_ref_body.inc): augmented-Lagrangian weights instead of barrier weights,
 //   w_i = rho [lam_i + rho c_i > 0],  g_i = max(lam_i + rho c_i, 0)   (SURVEY.md Appendix B), c_i in the RC slot, `target` = rho
-template <bool AL = false, int NL = 4>
+template <bool AL = false, int NL = 4, int MD = WM_QUAT>
 __device__ inline void prepass_w(const DevParams& P, const Layout& L, double* sm, const double* sl,
                                  double* ROT, double* GK, double target, int lane, unsigned kapbits = 0) {
   typedef Dim<NL> D;
@@ -236,6 +281,16 @@ __device__ inline void prepass_w(const DevParams& P, const Layout& L, double* sm
 #pragma unroll
           for (int b = 0; b < 3; ++b)
             V[9 + 3 * a + b] = bw[D::NU * a] * T[b] + bw[D::NU * a + 1] * T[3 + b] + bw[D::NU * a + 2] * T[6 + b];
+        if (MD == WM_CONVEX) {      // bw is [r_l]x: the point map of knot k is Winv_k [r_l]x
+          const double* Wk = sm + L.XT + kXT * k;
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            const double t3[3] = {V[9 + b], V[12 + b], V[15 + b]};
+            double y[3];
+            cv_winv_mul(Wk, t3, y);
+            V[9 + b] = y[0]; V[12 + b] = y[1]; V[15 + b] = y[2];
+          }
+        }
       }
       const double y0 = gq[0], y1 = gq[1] - l10 * y0, y2 = gq[2] - l20 * y0 - l21 * y1;
       const double z0 = id0 * y0, z1 = id1 * y1, z2 = id2 * y2;
@@ -326,7 +381,7 @@ struct BwPat {
   double Mc[3], Nc[2], qadd[3], sel[3];     // sel[t]: 1.0 where the lane's fragment row is 3 + t
   int ix_w, st_w, ix_a, st_a, ix_x[3], st_x[3], ix_g[2], st_g[2], kwo[2], xoffN[3];
   bool c12;
-  template <int NL = 4>
+  template <int NL = 4, int MD = WM_QUAT>
   __device__ __forceinline__ void init(const DevParams& P, const Layout& L, int lane) {
     const int N = P.N;
     const int c = lane & 15, g = lane >> 4;
@@ -352,8 +407,9 @@ struct BwPat {
         else if (r >= 9) v = (r - 9 == c - 3) ? P.h : 0.0;
       }
       Mc[e] = v;
-      qadd[e] = (c < 12 && r == c && !phi) ? P.Q[(r < 3) ? r : r + 1] : 0.0;
-      const bool xv = (phi && c35) || c12;
+      if (MD == WM_CONVEX) qadd[e] = (c < 12 && r == c) ? P.Q[cvperm(r < 12 ? r : 0)] : 0.0;      // LQR cost: constant diagonal Hessian
+      else qadd[e] = (c < 12 && r == c && !phi) ? P.Q[(r < 3) ? r : r + 1] : 0.0;
+      const bool xv = (MD == WM_CONVEX) ? c12 : ((phi && c35) || c12);
       const int xo = c12 ? 9 + r : 3 * (r - 3) + (c - 3);
       xoffN[e] = xv ? xo : -1;
       ix_x[e] = xv ? L.XT + kXT * (N - 1) + xo : zs;
@@ -472,14 +528,14 @@ __device__ __forceinline__ double gj6_step(double M[2], double Rr[2], int c, int
 // Gauss-Jordan steps (a third fragment pair that starts as the identity).  The converged mode does not need it -- its fixed
 // point does not depend on the accuracy of a Newton direction -- but a TRUNCATED iterate keeps the rounding of its
 // directions: without the refinement 65 % of the N=20 reference-mode forces were within 1e-6 N of the oracle's.
-template <bool PROF, bool REFINE = false>
+template <bool PROF, bool REFINE = false, int MD = WM_QUAT>
 // y0out (optional, 6 per knot): y0_k = M' p_{k+1}, the wrench-space costate BEFORE the stage solve -- the rotated input
 // gradient of contact point l is V_l' y0 + gq_l (the expected decrease of the reference mode's line search needs it)
 __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const BwPat& bp, double* sm, double* KD,
                                       const double* GK, int lane, Prof<PROF>& prof, double* y0out = nullptr) {
   const int N = P.N;
   const int c = lane & 15, g = lane >> 4;
-  const double wscale = (0.5 * P.hh) * P.h;        // Wt = (h^2 / 4) Gn'Gm
+  const double wscale = (MD == WM_CONVEX) ? P.h * P.hh : (0.5 * P.hh) * P.h;        // Wt = (h^2 / 4) Gn'Gm;  ConvexMpc: h hh (Rz_m' Iw^-1 Iw_m)
   const ColOps& co = bp.co;
   const double* Mc = bp.Mc;
   const double* Nc = bp.Nc;
@@ -695,7 +751,7 @@ __device__ inline void wrench_from_inputs(const DevParams& P, const Layout& L, c
 }
 
 // shortened primal step: scale the trial increment and re-roll the states open loop from the knots' wrenches
-template <int NL = 4>
+template <int NL = 4, int MD = WM_QUAT>
 __device__ inline void rollout_scaled_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm, double ap, int lane) {
   typedef Dim<NL> D;
   const int N = P.N;
@@ -715,7 +771,8 @@ __device__ inline void rollout_scaled_w(const DevParams& P, const Layout& L, con
     const int kn = (k + 1 < N) ? k + 1 : k;
 #pragma unroll
     for (int i = 0; i < 6; ++i) wn[i] = sm[LW.WR + 6 * kn + i];
-    srbd_step_w(P, gb, wd0, x, w, xn);
+    if (MD == WM_CONVEX) cv_step_w(P, x, w, xn);
+    else srbd_step_w(P, gb, wd0, x, w, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) x[i] = xn[i];
 #pragma unroll
@@ -730,11 +787,59 @@ __device__ inline void rollout_scaled_w(const DevParams& P, const Layout& L, con
 // ---- expansions at (X, U): four lanes per knot (three columns of the Jacobian blocks + the cost expansion) as in
 // expand_knot_part (qmpc_device.h; AltroUtils.cpp:78-110,153-168), with the angular acceleration taken from the knot's
 // wrench (WR) instead of being re-summed over the twelve inputs by every lane ------------------------------------------
-template <int NL = 4>
+template <int NL = 4, int MD = WM_QUAT>
 __device__ inline void expansions_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm, int lane) {
   typedef Dim<NL> D;
   const int N = P.N;
   const double* cst = sm + L.cst;
+  if (MD == WM_CONVEX) {
+    // one lane per knot (two sincos dominate): A1, A3, W = Rz_m' Iw(yaw)^-1 Iw(yaw_m) into the AB record, Winv_k / Iw_k and
+    // the cost gradient (internal block order) into XT -- the arithmetic of ConvexModel::expand / cv_expansion
+    for (int k = lane; k <= N; k += kWave) {
+      double x[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) x[i] = sm[L.X + 13 * k + i];
+      double* ABk = sm + L.AB + kAB * k;
+      double* XTk = sm + L.XT + kXT * k;
+      if (k < N) {
+        const double t0 = sm[LW.WR + 6 * k + 3], t1 = sm[LW.WR + 6 * k + 4];
+        double s0, c0, w00, w01, w11;
+        sincos(x[2], &s0, &c0);
+        ConvexModel::winv(P, c0, s0, w00, w01, w11);
+        const double wm0 = x[6] + P.hh * (w00 * t0 + w01 * t1);
+        const double wm1 = x[7] + P.hh * (w01 * t0 + w11 * t1);
+        double sm_, cm_;
+        sincos(x[2] + P.hh * x[8], &sm_, &cm_);
+        const double j0 = wm1 * cm_ - wm0 * sm_, j1 = -wm0 * cm_ - wm1 * sm_;
+        const double m00 = cm_ * w00 + sm_ * w01, m01 = cm_ * w01 + sm_ * w11;
+        const double m10 = -sm_ * w00 + cm_ * w01, m11 = -sm_ * w01 + cm_ * w11;
+        ConvexModel::winv(P, cm_, sm_, w00, w01, w11);
+        const double ixx = 1.0 / P.Iinv[0], iyy = 1.0 / P.Iinv[4], izz = 1.0 / P.Iinv[8];
+        const double i00 = cm_ * cm_ * ixx + sm_ * sm_ * iyy, i01 = cm_ * sm_ * (ixx - iyy), i11 = sm_ * sm_ * ixx + cm_ * cm_ * iyy;
+        ABk[0] = 1.0; ABk[1] = 0.0; ABk[2] = P.h * j0;
+        ABk[3] = 0.0; ABk[4] = 1.0; ABk[5] = P.h * j1;
+        ABk[6] = 0.0; ABk[7] = 0.0; ABk[8] = 1.0;
+        ABk[9] = P.h * cm_;   ABk[10] = P.h * sm_; ABk[11] = P.h * P.hh * j0;
+        ABk[12] = -P.h * sm_; ABk[13] = P.h * cm_; ABk[14] = P.h * P.hh * j1;
+        ABk[15] = 0.0; ABk[16] = 0.0; ABk[17] = P.h;
+        ABk[18] = m00 * i00 + m01 * i01; ABk[19] = m00 * i01 + m01 * i11; ABk[20] = 0.0;
+        ABk[21] = m10 * i00 + m11 * i01; ABk[22] = m10 * i01 + m11 * i11; ABk[23] = 0.0;
+        ABk[24] = 0.0; ABk[25] = 0.0; ABk[26] = 1.0;
+        XTk[0] = w00; XTk[1] = w01; XTk[2] = w11; XTk[3] = P.Iinv[8];
+        XTk[4] = i00; XTk[5] = i01; XTk[6] = i11; XTk[7] = izz;
+        XTk[8] = 0.0;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) XTk[i] = 0.0;
+      }
+      double xr[12];
+      ConvexModel::xref(P, sm + L.refp, k, xr);
+#pragma unroll
+      for (int r = 0; r < 12; ++r) XTk[9 + r] = P.Q[cvperm(r)] * (x[cvperm(r)] - xr[cvperm(r)]);
+    }
+    QSYNC();
+    return;
+  }
   for (int q = lane; q < 4 * (N + 1); q += kWave) {
     const int k = q >> 2, part = q & 3;
     double x[13];
@@ -797,6 +902,16 @@ __device__ inline void expansions_w(const DevParams& P, const Layout& L, const L
 struct RollLoadsW {
   double xo[13], ab[18], kd[13], wk;
 };
+// ConvexMpc: the knot's raw wrench (all six, every lane advances the state) and Iw(yaw_m) of the linearisation
+struct RollLoadsC {
+  double wr[6], iw[4];
+};
+__device__ __forceinline__ void roll_load_c(const Layout& L, const LayoutW& LW, const double* sm, int k, RollLoadsC& r) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r.wr[i] = sm[LW.WR + 6 * k + i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.iw[i] = sm[L.XT + kXT * k + 4 + i];
+}
 __device__ __forceinline__ void roll_load_w(const Layout& L, const LayoutW& LW, const double* sm, const double* KD, int k,
                                             int row, int wi, RollLoadsW& r) {
 #pragma unroll
@@ -810,7 +925,7 @@ __device__ __forceinline__ void roll_load_w(const Layout& L, const LayoutW& LW, 
 }
 // PF: the next knot's gains / old state / Jacobian blocks are loaded one knot ahead into a second register set (90 more
 // registers: the one-wave-per-SIMD form); without it the loads sit at the top of the knot (two waves per SIMD hide them)
-template <bool PROF, bool PF, int NL = 4>
+template <bool PROF, bool PF, int NL = 4, int MD = WM_QUAT>
 __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm,
                                         const double* KD, double* ROT, int lane, Prof<PROF>& prof, double alpha = 1.0) {
   typedef Dim<NL> D;
@@ -832,7 +947,12 @@ __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, con
   auto knot = [&](int k, RollLoadsW& cur, RollLoadsW& nxt) {
     if (!PF) roll_load_w(L, LW, sm, KD, k, row, wi, cur);
     double dx[12], e[12];
-    QuatModel::state_diff(cur.xo, xc, dx);
+    if (MD == WM_CONVEX) {
+#pragma unroll
+      for (int r = 0; r < 12; ++r) dx[r] = xc[cvperm(r)] - cur.xo[cvperm(r)];      // internal block order [p, phi, v, w]
+    } else {
+      QuatModel::state_diff(cur.xo, xc, dx);
+    }
     // e = Abar dx
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -849,13 +969,21 @@ __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, con
     const double p3 = kd[9] * e[9] + kd[10] * e[10] + kd[11] * e[11];
     const double s = (p0 + p1) + (p2 + p3);
     if (zlane) ROT[zeta_slot<NL>(k, lane - 6)] = s;      // the costate of the contact points, for the input recovery
-    double wn = cur.wk + s;
+    double wn = (MD == WM_CONVEX) ? s : cur.wk + s;      // (ConvexMpc: the increment alone; the torque part changes frame below)
     tick_dep1(prof, PH_R_GAIN, wn);
     if (PF && k + 1 < N) roll_load_w(L, LW, sm, KD, k + 1, row, wi, nxt);      // one knot ahead
     double w[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) w[i] = read_lane(wn, i);
     tick_dep(prof, PH_R_BCAST, w[0], w[5]);
+    if (MD == WM_CONVEX) {
+      RollLoadsC rc;
+      roll_load_c(L, LW, sm, k, rc);
+      const double d3 = rc.iw[0] * w[3] + rc.iw[1] * w[4], d4 = rc.iw[1] * w[3] + rc.iw[2] * w[4], d5 = rc.iw[3] * w[5];
+      w[0] += rc.wr[0]; w[1] += rc.wr[1]; w[2] += rc.wr[2];
+      w[3] = rc.wr[3] + d3; w[4] = rc.wr[4] + d4; w[5] = rc.wr[5] + d5;
+      cv_step_w(P, xc, w, xn);
+    } else
     srbd_step_w(P, gb, wd0, xc, w, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) xc[i] = xn[i];
@@ -923,7 +1051,7 @@ __device__ inline double expected_decrease_w(const DevParams& P, const Layout& L
 //      du_l = -T_l D~_l^-1 (V_l' zeta + gq_l),   V_l' zeta = T_l' (zeta_f + Bw0_l' zeta_t) ----
 // Returns nonzero (wave-uniform) when an increment is not finite: the trial step is then NOT applied (QMPC_NOT_PD, the
 // rule of the lane kernel) -- the step-length reductions that follow drop NaNs silently.
-template <int NL = 4>
+template <int NL = 4, int MD = WM_QUAT>
 __device__ inline int recover_inputs_w(const DevParams& P, const Layout& L, double* sm, const double* ROT, int lane,
                                        double alpha = 1.0, const double* zsrc = nullptr) {
   typedef Dim<NL> D;
@@ -941,6 +1069,11 @@ __device__ inline int recover_inputs_w(const DevParams& P, const Layout& L, doub
       for (int i = 0; i < 9; ++i) T[i] = rec[i];
 #pragma unroll
       for (int i = 0; i < 6; ++i) z[i] = zsrc ? zsrc[6 * k + i] : ROT[zeta_slot<NL>(k, i)];
+      if (MD == WM_CONVEX) {      // Bw0_l' z_t = [r_l]x' (Winv_k z_t)
+        double y[3];
+        cv_winv_mul(sm + L.XT + kXT * k, z + 3, y);
+        z[3] = y[0]; z[4] = y[1]; z[5] = y[2];
+      }
       const double l10 = rec[9], l20 = rec[10], l21 = rec[11], id0 = rec[12], id1 = rec[13], id2 = rec[14];
       const double* bw = sm + L.bw0 + 3 * l;
       double f[3];
@@ -971,7 +1104,7 @@ __device__ inline int recover_inputs_w(const DevParams& P, const Layout& L, doub
 // (compared by cross-multiplication): one division per lane instead of two per row.  `kapbits` returns the weakly-active
 // flags of the lane's rows (bit 6 j + i: row i of the lane's j-th (knot, point)), read from the DS slot before the
 // directions overwrite it; apply_w consumes them.  Returns nonzero (wave-uniform) when an increment is not finite.
-template <int NL = 4>
+template <int NL = 4, int MD = WM_QUAT>
 __device__ inline int recover_directions_w(const DevParams& P, const Layout& L, double* sm, double* sl, const double* ROT,
                                            double target, int lane, double* alpha_p, double* alpha_d, double* full_step,
                                            unsigned& kapbits) {
@@ -995,6 +1128,11 @@ __device__ inline int recover_directions_w(const DevParams& P, const Layout& L, 
     for (int i = 0; i < 9; ++i) T[i] = rec[i];
 #pragma unroll
     for (int i = 0; i < 6; ++i) z[i] = ROT[zeta_slot<NL>(k, i)];
+    if (MD == WM_CONVEX) {
+      double y[3];
+      cv_winv_mul(sm + L.XT + kXT * k, z + 3, y);
+      z[3] = y[0]; z[4] = y[1]; z[5] = y[2];
+    }
     const double l10 = rec[9], l20 = rec[10], l21 = rec[11], id0 = rec[12], id1 = rec[13], id2 = rec[14];
     const double g0 = rec[15], g1 = rec[16], g2 = rec[17];
 #pragma unroll

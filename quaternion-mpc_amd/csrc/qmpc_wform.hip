@@ -81,6 +81,26 @@ __global__ __launch_bounds__(64, 1) void qmpc_solve8_w_kernel(
 #undef QMPC_WNL
 }
 
+// ---- ConvexMpc's problem (the sibling controller: Euler-angle model, world-frame forces; ConvexMpc.cpp:81-198) on the same
+// body (round 5): WVAR 3 everything in LDS, 5 gains / per-point records / per-knot blocks in the workspace (two waves per SIMD)
+template <int WVAR>
+__global__ __launch_bounds__(64, WVAR == 5 ? 2 : 1) void qmpc_solve_cw_kernel(
+    DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
+    double* __restrict__ traj_u, double* __restrict__ traj_x, int batch, double* __restrict__ gws) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int b = blockIdx.x;
+  if (b >= batch) return;
+  const int wslot = b;
+  const int lane = threadIdx.x;
+  constexpr bool PROF = false;
+  long long* prof_out = nullptr;
+  constexpr int warm_t = 0;
+  constexpr const double* resume = nullptr;
+#define QMPC_WMODEL WM_CONVEX
+#include "qmpc_wform_body.inc"
+#undef QMPC_WMODEL
+}
+
 // The same solve over a LIST of instances (sel[0 .. *sel_count), built on the device): the workgroups walk the list with
 // the grid as stride.  The straggler hand-off of large batches (qmpc_hip.hip: launch_solve): the lane-per-instance kernel
 // stops after a fixed number of iterations and the few instances it leaves unconverged are solved here, where one
@@ -149,13 +169,14 @@ __attribute__((visibility("hidden"))) size_t qmpc_wform_lds_bytes(int N, int kd_
 }
 __attribute__((visibility("hidden"))) size_t qmpc_wform_slice_doubles(int N, int nl) { return nl == 8 ? wform_slice<8>(N) : wform_slice<4>(N); }
 __attribute__((visibility("hidden"))) hipError_t qmpc_wform_set_lds(int bytes) {
-  const void* k[11] = {reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 3>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 3>),
+  const void* k[13] = {reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 3>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 3>),
                       reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 5>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 5>),
                       reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<3>), reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<5>),
                       reinterpret_cast<const void*>(qmpc_ref_w_kernel<3>), reinterpret_cast<const void*>(qmpc_ref_w_kernel<5>),
                       reinterpret_cast<const void*>(qmpc_ref_w_kernel<5, 1>),
-                      reinterpret_cast<const void*>(qmpc_solve8_w_kernel<3>), reinterpret_cast<const void*>(qmpc_solve8_w_kernel<5>)};
-  for (int i = 0; i < 11; ++i) {
+                      reinterpret_cast<const void*>(qmpc_solve8_w_kernel<3>), reinterpret_cast<const void*>(qmpc_solve8_w_kernel<5>),
+                      reinterpret_cast<const void*>(qmpc_solve_cw_kernel<3>), reinterpret_cast<const void*>(qmpc_solve_cw_kernel<5>)};
+  for (int i = 0; i < 13; ++i) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
   }
@@ -192,6 +213,20 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_wform_launch8(int var, int
     hipLaunchKernelGGL(qmpc_solve8_w_kernel<5>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in_, forces, info, traj_u, traj_x, batch, gws);
   else
     hipLaunchKernelGGL(qmpc_solve8_w_kernel<3>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in_, forces, info, traj_u, traj_x, batch, gws);
+  return hipGetLastError();
+}
+// ConvexMpc's problem (records of 48 doubles, 12 world-frame forces per instance); var as above
+__attribute__((visibility("hidden"))) hipError_t qmpc_wform_launch_convex(int var, int batch, size_t lds, hipStream_t s, const void* dev_params,
+                                                                          size_t dev_params_size, const void* in, double* forces,
+                                                                          qmpc_info* info, double* traj_u, double* traj_x, double* gws) {
+  if (dev_params_size != sizeof(DevParams)) return hipErrorInvalidValue;
+  DevParams P;
+  std::memcpy(&P, dev_params, sizeof P);
+  const qmpc_input* in_ = static_cast<const qmpc_input*>(in);
+  if (var == 5)
+    hipLaunchKernelGGL(qmpc_solve_cw_kernel<5>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in_, forces, info, traj_u, traj_x, batch, gws);
+  else
+    hipLaunchKernelGGL(qmpc_solve_cw_kernel<3>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in_, forces, info, traj_u, traj_x, batch, gws);
   return hipGetLastError();
 }
 // the instances sel[0 .. *sel_count) (device memory), `grid` workgroups walking the list

@@ -329,6 +329,40 @@ def test_convex_forces_match_oracle(pkg, lib, oracle, N, cfg):
     s.close(); s2.close()
 
 
+@pytest.mark.parametrize("N", [20, 10])
+def test_convex_wrench_form_kernels(pkg, lib, oracle, monkeypatch, N):
+    """Round 5: ConvexMpc's problem on the wrench-form wave kernels (qmpc_solve_cw_kernel: Euler-angle model in the block
+    order [p, phi, v, w], the midpoint inertia in a per-knot point map, raw wrench in the rollout) for batches of one
+    resident round -- everything in LDS / workspace form -- against the oracle (1e-6 N, iteration counts), against each
+    other (1e-7 N) and against the dense round-1 kernels (QMPC_WFORM=0); input / state trajectories included."""
+    p = pkg.default_convex_params(N, pkg.MODE_CONVERGED, lib)
+    cfg = 12 if N == 10 else 13
+    big = 1024 if N == 20 else 2048
+    rec = pkg.random_go1_convex_states(big, config_id=cfg)
+    s = pkg.Solver(p, big, device=0, lib=lib)
+    assert s.kernel_for_batch(64) == "wform_lds" and s.kernel_for_batch(big) == "wform_ws" and s.kernel_for_batch(big + 1) == "dense_ws"
+    fb, ib, tub, txb = s.convex_solve(rec, want_traj=True)                 # workspace form
+    fs, is_, tus, txs = s.convex_solve(rec[:256], want_traj=True)          # everything in LDS
+    assert (ib["status"] == 0).all() and (is_["status"] == 0).all()
+    assert np.abs(fb[:256] - fs).max() < 1e-7 and np.array_equal(ib["iterations"][:256], is_["iterations"])
+    x0 = np.concatenate([rec[k][:256] for k in ("euler", "pos_world", "ang_vel_world", "lin_vel_world")], axis=1)
+    assert np.array_equal(tus[:, 0, :], fs) and np.array_equal(txs[:, 0, :], x0)      # x_init in the reference's state order
+    fo, io, tuo, txo = oracle.convex_solve(p, rec[:256], threads=8, want_traj=True)
+    assert (io["status"] == 0).all()
+    assert np.abs(fs - fo).max() < 1e-6 and np.abs(fb[:256] - fo).max() < 1e-6
+    assert np.abs(tus - tuo).max() < 1e-5 and np.abs(txs - txo).max() < 1e-8 and np.abs(txb[:256] - txo).max() < 1e-8
+    assert (is_["iterations"] == io["iterations"]).mean() >= 0.95
+    swing = np.repeat(rec["contacts"] == 0, 3, axis=1)
+    assert np.abs(fb[swing]).max() == 0.0
+    s.close()
+    monkeypatch.setenv("QMPC_WFORM", "0")
+    s0 = pkg.Solver(p, big, device=0, lib=lib)
+    assert s0.kernel_for_batch(64) in ("dense_lds", "dense_ws")
+    f0, i0 = s0.convex_solve(rec)
+    s0.close()
+    assert np.abs(f0 - fb).max() < 1e-6 and float((i0["iterations"] == ib["iterations"]).mean()) >= 0.95
+
+
 def test_convex_handle_rejects_quaternion_calls(pkg, lib):
     p, s = _convex_solver(pkg, lib, 10)
     with pytest.raises(pkg.QmpcError) as e:
@@ -1824,5 +1858,5 @@ def test_prepare_and_query(pkg, lib):
         os.environ.pop("QMPC_LANE_CAP", None)
     pc = pkg.default_convex_params(20, pkg.MODE_CONVERGED, lib)
     scv = pkg.Solver(pc, 20000, device=0, lib=lib)
-    assert scv.kernel_for_batch(20000) == "lane" and scv.query(pkg.QUERY_HANDOFF_ACTIVE) == 0 and scv.kernel_for_batch(64) == "dense_ws"
+    assert scv.kernel_for_batch(20000) == "lane" and scv.query(pkg.QUERY_HANDOFF_ACTIVE) == 0 and scv.kernel_for_batch(64) == "wform_lds" and scv.kernel_for_batch(1024) == "wform_ws" and scv.kernel_for_batch(1025) == "dense_ws"
     scv.close()
