@@ -83,6 +83,7 @@ struct qmpc_handle {
   size_t lds_bytes_g;     // gains in the global workspace
   size_t lds_bytes_s;     // gains and slack arrays in the global workspace
   size_t lds_bytes_w;     // the wrench-form kernel (qmpc_wform.hip), everything in LDS
+  size_t lds_bytes_ws;    // ... and with its slack arrays there too (WVAR 6; plain solves at long horizons)
   size_t lds_bytes_wg;    // ... with its gains / per-point records / per-knot blocks in the global workspace
   int wform;              // 1: batches that keep everything in LDS take the wrench-form kernel (env QMPC_WFORM, default 1)
   int* d_loop_row;        // trace row counter of the closed loop (qmpc_loop_run*)
@@ -370,6 +371,7 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     h->wform = wf ? std::atoi(wf) : 1;
     h->lds_bytes_w = qmpc_wform_lds_bytes(N, 0, nl);
     h->lds_bytes_wg = qmpc_wform_lds_bytes(N, 1, nl);
+    h->lds_bytes_ws = qmpc_wform_lds_bytes(N, 2, nl);
     const char* lm = std::getenv("QMPC_LANE_MIN");
     h->lane_min_batch = lm ? std::atoi(lm) : (params->model == QMPC_MODEL_QUAT ? (N <= 12 ? kLaneMinBatch : kLaneMinBatchLong)
                                                           : (params->model == QMPC_MODEL_QUAT8 ? kLaneMinBatch8 : kLaneMinBatchOther));
@@ -530,6 +532,10 @@ static qmpc_status launch_lane(qmpc_handle* h, int32_t batch, const qmpc_input* 
 // the round-1 family would keep everything in LDS (one instance per SIMD at most) and four instances fit a CU with its
 // layout, with the gains in the workspace (5) for the mid-size batches below the lane kernel's threshold.
 // QMPC_WFORM=0 keeps the round-1 kernels (A/B runs); QMPC_WFORM=3 restricts it to the all-LDS form.
+static bool wform6_ok(const qmpc_handle* h) {      // env QMPC_WFORM6=0 switches the variant off (A/B runs)
+  static const int on = std::getenv("QMPC_WFORM6") ? std::atoi(std::getenv("QMPC_WFORM6")) : 1;
+  return on && h->params.horizon >= 4 && h->lds_bytes_ws <= 80 * 1024;
+}
 // `plain`: the caller is a plain solve (launch_solve) -- ConvexMpc's problem has the wrench form there only; its warm start
 // and its closed loop keep the round-1 bodies (qmpc_solve_body.inc), and body_variant must keep naming those
 static int wform_variant(const qmpc_handle* h, int32_t batch, bool plain = false) {
@@ -543,7 +549,7 @@ static int wform_variant(const qmpc_handle* h, int32_t batch, bool plain = false
     // kernel with its slack arrays in the workspace too (17 KB: two waves per SIMD) wins -- measured at N=20, 8192 instances:
     // 0.87 M (round-1) against 0.68 M solves/s
     if (h->lds_bytes_wg <= 80 * 1024 && batch <= 256 * (int)((160 * 1024) / h->lds_bytes_wg)) return 5;
-    return 0;
+    return (wform6_ok(h) && h->lds_bytes_wg > 20 * 1024) ? 6 : 0;      // (short horizons: the round-1 kernel, 1.60 against 1.61 M at N=10)
   }
   if (h->params.model == QMPC_MODEL_QUAT8) {
     // eight contact points (round 5): 94 KB (everything in LDS) / 49 KB (workspace form) per instance at N=16, one wave per
@@ -560,6 +566,11 @@ static int wform_variant(const qmpc_handle* h, int32_t batch, bool plain = false
   // the single robot and small fleets; the workspace form (two waves per SIMD) from there on.  Round 5, tools/latency_b1.py.
   static const int small_lds = std::getenv("QMPC_WFORM_SMALL_LDS") ? std::atoi(std::getenv("QMPC_WFORM_SMALL_LDS")) : 1;
   if (small_lds && h->variant == 0 && h->lds_bytes_w <= 160 * 1024 && batch <= 256 * (int)((160 * 1024) / h->lds_bytes_w)) return 3;
+  // Long horizons, mid-size batches (round 5): with 37 KB of LDS (N=20) the workspace form leaves a SIMD ONE wave, and the
+  // round-1 kernel with its slack arrays in the workspace (two waves per SIMD) was faster -- N=20: 8192 instances 1.12 M against
+  // 0.97 M solves/s.  WVAR 6 moves the wrench form's slack arrays out as well (18 KB); plain solves only (the warm-started
+  // solve and the closed loop keep 5: their launch forms share one body).
+  if (plain && h->wform != 3 && wform6_ok(h) && h->lds_bytes_wg > 20 * 1024 && batch > 256 * (int)((160 * 1024) / h->lds_bytes_wg)) return 6;
   return (h->wform != 3 && h->lds_bytes_wg <= 80 * 1024) ? 5 : 0;
 }
 static bool use_wform(const qmpc_handle* h, int32_t batch) { return wform_variant(h, batch) == 3; }
@@ -569,9 +580,9 @@ static bool use_wform(const qmpc_handle* h, int32_t batch) { return wform_varian
 // bit-identical only on the same body
 static int body_variant(const qmpc_handle* h, int32_t batch) { const int wv = wform_variant(h, batch); return wv ? wv : pick_variant(h, batch); }
 static size_t variant_lds(const qmpc_handle* h, int var) {
-  return var == 5 ? h->lds_bytes_wg : (var == 3 ? h->lds_bytes_w : (var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes)));
+  return var == 6 ? h->lds_bytes_ws : var == 5 ? h->lds_bytes_wg : (var == 3 ? h->lds_bytes_w : (var == 2 ? h->lds_bytes_s : (var == 1 ? h->lds_bytes_g : h->lds_bytes)));
 }
-static double* variant_gws(const qmpc_handle* h, int var) { return (var == 1 || var == 2 || var == 5) ? h->d_gws : nullptr; }
+static double* variant_gws(const qmpc_handle* h, int var) { return (var == 1 || var == 2 || var == 5 || var == 6) ? h->d_gws : nullptr; }
 
 // Straggler hand-off: the wave kernel that CONTINUES what a capped lane launch leaves -- 3 (everything in LDS), 5 (gains in
 // the workspace; up to 80 KB of LDS, i.e. every horizon the handle accepts: two workgroups per CU instead of four), 0: no
@@ -632,7 +643,7 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
       return QMPC_OK;
     }
     if (const int wv = ref_wform_variant(h, batch)) {      // QuatMpc's problem: on the wrench-form algebra (qmpc_wform_ref_body.inc)
-      h->last_kernel = wv == 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
+      h->last_kernel = wv >= 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
       HIP_TRY(qmpc_wform_ref_launch(wv, (int)batch, variant_lds(h, wv), s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, d_tu, d_tx,
                                     variant_gws(h, wv)));
       if (timed) {
@@ -687,16 +698,16 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
     return QMPC_OK;
   }
   if (const int wv = wform_variant(h, batch, handoff != 2)) {      // (handoff 2: a tick of the closed loop -- its two launch forms share a body)
-    h->last_kernel = wv == 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
+    h->last_kernel = wv >= 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
     if (h->params.model == QMPC_MODEL_CONVEX) {
-      HIP_TRY(qmpc_wform_launch_convex(wv, (int)batch, wv == 5 ? h->lds_bytes_wg : h->lds_bytes_w, s, &h->dev, sizeof h->dev, d_in, d_forces,
-                                       d_info, d_tu, d_tx, wv == 5 ? h->d_gws : nullptr));
+      HIP_TRY(qmpc_wform_launch_convex(wv, (int)batch, variant_lds(h, wv), s, &h->dev, sizeof h->dev, d_in, d_forces,
+                                       d_info, d_tu, d_tx, variant_gws(h, wv)));
     } else if (h->params.model == QMPC_MODEL_QUAT8) {
       HIP_TRY(qmpc_wform_launch8(wv, (int)batch, wv == 5 ? h->lds_bytes_wg : h->lds_bytes_w, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info,
                                  d_tu, d_tx, wv == 5 ? h->d_gws : nullptr));
     } else
-    HIP_TRY(qmpc_wform_launch(wv, 0, (int)batch, wv == 5 ? h->lds_bytes_wg : h->lds_bytes_w, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info,
-                              d_tu, d_tx, nullptr, wv == 5 ? h->d_gws : nullptr));
+    HIP_TRY(qmpc_wform_launch(wv, 0, (int)batch, variant_lds(h, wv), s, &h->dev, sizeof h->dev, d_in, d_forces, d_info,
+                              d_tu, d_tx, nullptr, variant_gws(h, wv)));
     if (timed) {
       HIP_TRY(hipEventRecord(h->ev1, s));
       h->timed = true;
@@ -1028,12 +1039,12 @@ static int kernel_for_batch(const qmpc_handle* h, int32_t batch) {
   if (h->params.mode == QMPC_MODE_REFERENCE) {
     if (h->params.model == QMPC_MODEL_QUAT && h->lane_pslot >= 0 && (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min)))
       return QMPC_KERNEL_LANE;
-    if (const int wv = ref_wform_variant(h, batch)) return wv == 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
+    if (const int wv = ref_wform_variant(h, batch)) return wv >= 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
     const bool ws = batch > 1024 || h->lds_bytes > 40 * 1024 || h->variant >= 2 || h->params.model == QMPC_MODEL_QUAT8;
     return ws ? QMPC_KERNEL_DENSE_WS : QMPC_KERNEL_DENSE_LDS;
   }
   if (use_lane(h, batch, nullptr, nullptr)) return handoff_cap(h, 1) ? QMPC_KERNEL_LANE_HANDOFF : QMPC_KERNEL_LANE;
-  if (const int wv = wform_variant(h, batch, true)) return wv == 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
+  if (const int wv = wform_variant(h, batch, true)) return wv >= 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
   return pick_variant(h, batch) >= 1 ? QMPC_KERNEL_DENSE_WS : QMPC_KERNEL_DENSE_LDS;
 }
 

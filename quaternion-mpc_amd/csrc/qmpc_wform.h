@@ -40,17 +40,22 @@ namespace qmpc {
 // ---- LDS layout: that of the all-LDS variant, the set-up scratch aliased onto the slack array, plus per knot the
 // wrench-space blocks G (21, symmetric) and r6 (6) of the contact points and the wrench Wr u_k (6) ------------------
 struct LayoutW {
-  int GK, WR;
+  int GK, WR, SLW;      // SLW: where the slack block [S | LAM | RC] starts inside the workspace slice (sl_global layouts)
 };
 constexpr int kGK = 27;
 // workspace variant (kd_global): the gains KD, the per-point records ROT and the per-knot blocks GK live in a global
 // workspace slice of the instance, [KD | ROT | GK], instead of LDS (19 KB of LDS at N=10: two waves per SIMD)
 // NL contact points (4: Go1; 8: the synthetic biped of BASELINE config 5): the per-point arrays scale with NL, the gains
 // [Xw | xw], [Xz | xz] (156 per knot) and the per-knot blocks G, r6 live in the 6-dimensional wrench space and do not
+// sl_global (WVAR 6, round 5): the slack / multiplier / residual arrays S, LAM, RC live in the workspace slice too, behind
+// [KD | ROT | GK]; such a layout is LEAN (no direction arrays, weakly-active flags in a register) like the eight-point one.
+// N=20: 37 KB -> 18 KB of LDS, i.e. two waves per SIMD at the reference's own horizon.
 template <int NL = 4>
-__host__ __device__ inline size_t wform_slice(int N) { return ((size_t)N * (13 * 12 + 21 * NL + kGK) + 1 + 1) & ~(size_t)1; }
+__host__ __device__ inline size_t wform_slice(int N, bool sl_global = false) {
+  return ((size_t)N * (13 * 12 + 21 * NL + kGK + (sl_global ? 18 * NL : 0)) + 1 + 1) & ~(size_t)1;
+}
 template <int NL = 4>
-__host__ __device__ inline Layout make_layout_w(int N, LayoutW* W, bool kd_global = false) {
+__host__ __device__ inline Layout make_layout_w(int N, LayoutW* W, bool kd_global = false, bool sl_global = false) {
   Layout L;
   int o = 0;
   auto take = [&](int n) { int r = o; o += n; return r; };
@@ -63,24 +68,32 @@ __host__ __device__ inline Layout make_layout_w(int N, LayoutW* W, bool kd_globa
   L.U = take(N * nu);
   L.Xc = take((N + 1) * 13);
   L.dU = take(N * nu);
-  L.S = take(N * nc);
-  L.LAM = take(N * nc);
-  // eight points: the directions are not kept (apply_w recomputes them from dU, the lane kernel's rule) and the weakly-active
-  // flags live in a register bit field -- 12 KB less at N=16, which is what lets four instances share a CU
-  L.DS = (NL == 8) ? -1 : take(N * nc);
-  L.DLAM = (NL == 8) ? -1 : take(N * nc);
-  L.RC = take(N * nc);
+  const bool lean = (NL == 8) || sl_global;
+  if (sl_global) {      // offsets relative to the slack block of the workspace slice
+    L.S = 0; L.LAM = N * nc; L.RC = 2 * N * nc;
+  } else {
+    L.S = take(N * nc);
+    L.LAM = take(N * nc);
+  }
+  // lean layouts: the directions are not kept (apply_w recomputes them from dU, the lane kernel's rule) and the weakly-active
+  // flags live in a register bit field -- 12 KB less for eight points at N=16, which is what lets four instances share a CU
+  L.DS = lean ? -1 : take(N * nc);
+  L.DLAM = lean ? -1 : take(N * nc);
+  if (!sl_global) L.RC = take(N * nc);
   L.AB = take(N * kAB);
   L.XT = take((N + 1) * kXT);
   if (kd_global) {
     L.KD = 0; L.ROT = N * 13 * 12; W->GK = N * (13 * 12 + 21 * nl);      // offsets inside the workspace slice
+    W->SLW = (N * (13 * 12 + 21 * nl + kGK) + 1 + 1) & ~1;
   } else {
     L.KD = take(N * 13 * 12);       // per knot [Xw | xw] (rows 0..5) and [Xz | xz] (rows 6..11), 13 entries per row
     L.ROT = take(N * 21 * nl);      // per (knot, point): T (9), l10 l20 l21, id0 id1 id2, gq (3), 3 spare (zeta, below)
     W->GK = take(N * kGK + 1);      // per knot G (21) r6 (6); one 0.0 behind the array (masked operand reads point at it)
   }
   W->WR = take(N * 6);
-  L.tile = L.S;                   // set-up scratch (one record): the slack arrays are initialised after it
+  // set-up scratch (one record): the slack arrays are initialised after it; with the slacks in the workspace X (13 (N + 1)
+  // doubles, written by the rollout that follows the set-up) takes the record
+  L.tile = sl_global ? L.X : L.S;
   L.total = (o + 1) & ~1;
   return L;
 }
@@ -142,7 +155,7 @@ __device__ __forceinline__ void cv_winv_mul(const double* W, const double t[3], 
 // lane quad: their shares are summed with quad_perm moves and lane 0 of the quad stores the knot's 27 numbers. ----
 // AL = true (reference mode, qmpc_wform_ref_body.inc): augmented-Lagrangian weights instead of barrier weights,
 //   w_i = rho [lam_i + rho c_i > 0],  g_i = max(lam_i + rho c_i, 0)   (SURVEY.md Appendix B), c_i in the RC slot, `target` = rho
-template <bool AL = false, int NL = 4, int MD = WM_QUAT>
+template <bool AL = false, int NL = 4, int MD = WM_QUAT, bool LEAN = (NL == 8)>
 __device__ inline void prepass_w(const DevParams& P, const Layout& L, double* sm, const double* sl,
                                  double* ROT, double* GK, double target, int lane, unsigned kapbits = 0) {
   typedef Dim<NL> D;
@@ -181,7 +194,7 @@ __device__ inline void prepass_w(const DevParams& P, const Layout& L, double* sm
         } else {
           const double s = sl[L.S + D::NC * k + 6 * l + i];
           // weakly-active flag (see ipm_apply); eight points: bit 6 j + i of the lane's j-th (knot, point)
-          const double kap = (NL == 8) ? (((kapbits >> (6 * (q0 >> 6) + i)) & 1u) ? 1.0 : 0.0) : sl[L.DS + D::NC * k + 6 * l + i];
+          const double kap = LEAN ? (((kapbits >> (6 * (q0 >> 6) + i)) & 1u) ? 1.0 : 0.0) : sl[L.DS + D::NC * k + 6 * l + i];
           const double is = fast_rcp(s);
           w[i] = lam * is;
           gi[i] = (target + lam * rc) * is - kap * lam;
@@ -1104,7 +1117,7 @@ __device__ inline int recover_inputs_w(const DevParams& P, const Layout& L, doub
 // (compared by cross-multiplication): one division per lane instead of two per row.  `kapbits` returns the weakly-active
 // flags of the lane's rows (bit 6 j + i: row i of the lane's j-th (knot, point)), read from the DS slot before the
 // directions overwrite it; apply_w consumes them.  Returns nonzero (wave-uniform) when an increment is not finite.
-template <int NL = 4, int MD = WM_QUAT>
+template <int NL = 4, int MD = WM_QUAT, bool LEAN = (NL == 8)>
 __device__ inline int recover_directions_w(const DevParams& P, const Layout& L, double* sm, double* sl, const double* ROT,
                                            double target, int lane, double* alpha_p, double* alpha_d, double* full_step,
                                            unsigned& kapbits) {
@@ -1138,7 +1151,7 @@ __device__ inline int recover_directions_w(const DevParams& P, const Layout& L, 
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       sv[i] = sl[L.S + i0 + i]; lv[i] = sl[L.LAM + i0 + i]; rc[i] = sl[L.RC + i0 + i];
-      kap[i] = (NL == 8) ? (((kapbits >> (6 * j + i)) & 1u) ? 1.0 : 0.0) : sl[L.DS + i0 + i];
+      kap[i] = LEAN ? (((kapbits >> (6 * j + i)) & 1u) ? 1.0 : 0.0) : sl[L.DS + i0 + i];
     }
     const double* bw = sm + L.bw0 + 3 * l;
     double du[3] = {0.0, 0.0, 0.0};
@@ -1172,7 +1185,7 @@ __device__ inline int recover_directions_w(const DevParams& P, const Layout& L, 
       pn = up ? sv[i] : pn; pd = up ? -dsv : pd;
       const bool ud = (dlv < 0.0) && (dd == 0.0 || lv[i] * dd < dn * (-dlv));
       dn = ud ? lv[i] : dn; dd = ud ? -dlv : dd;
-      if (NL != 8) {
+      if (!LEAN) {
         sl[L.DS + i0 + i] = dsv;
         sl[L.DLAM + i0 + i] = dlv;
       }
@@ -1193,7 +1206,7 @@ __device__ inline int recover_directions_w(const DevParams& P, const Layout& L, 
 // with the rows of a contact point in one lane
 // Eight points: the directions are recomputed here from the trial increment dU (still unscaled: the caller applies before it
 // re-rolls a shortened step) and the new flags go back into `kapbits`; sm / target are only read in that form.
-template <int NL = 4>
+template <int NL = 4, bool LEAN = (NL == 8)>
 __device__ inline void apply_w(const DevParams& P, const Layout& L, double* sl, double ap, double ad, unsigned conmask,
                                int lane, unsigned& kapbits, double& sl_part, double& rc_part, const double* sm = nullptr,
                                double target = 0.0) {
@@ -1213,9 +1226,9 @@ __device__ inline void apply_w(const DevParams& P, const Layout& L, double* sl, 
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       s0[i] = sl[L.S + i0 + i]; l0[i] = sl[L.LAM + i0 + i]; rc[i] = sl[L.RC + i0 + i];
-      if (NL != 8) { ds[i] = sl[L.DS + i0 + i]; dl[i] = sl[L.DLAM + i0 + i]; }
+      if (!LEAN) { ds[i] = sl[L.DS + i0 + i]; dl[i] = sl[L.DLAM + i0 + i]; }
     }
-    if (NL == 8) {
+    if (LEAN) {
       const double* cr = sm + L.cst + D::C_CR;
       const double* du = sm + L.dU + D::NU * k + 3 * l;
       const double du0 = du[0], du1 = du[1], du2 = du[2];
@@ -1240,10 +1253,10 @@ __device__ inline void apply_w(const DevParams& P, const Layout& L, double* sl, 
       sl_part += s1 * l1;
       rc_part = fmax(rc_part, fabs(rc1));
       const bool sig = full && (s1 < 0.6 * s0[i]) && (l1 < 0.6 * l0[i]) && (kap0 || ((s1 > 0.4 * s0[i]) && (l1 > 0.4 * l0[i])));
-      if (NL == 8) newbits |= sig ? (1u << (6 * j + i)) : 0u;
+      if (LEAN) newbits |= sig ? (1u << (6 * j + i)) : 0u;
       else sl[L.DS + i0 + i] = sig ? 1.0 : 0.0;
     }
-    if (NL == 8) kapbits = (kapbits & ~(63u << (6 * j))) | newbits;
+    if (LEAN) kapbits = (kapbits & ~(63u << (6 * j))) | newbits;
   }
 }
 

@@ -43,8 +43,10 @@ namespace qmpc {
 // ---- the solve kernel (QuatMpc's problem, four contact points, everything in LDS, one wave per SIMD) -----------------
 // WVAR 3: everything in LDS, one wave per SIMD (small batches); 5: gains, per-point records and per-knot blocks in the
 // global workspace (one slice per instance), two waves per SIMD (mid-size batches)
+// 6 (round 5): the slack / multiplier / residual arrays in the workspace slice too -- long horizons (N=20: 18 KB of LDS, two
+// waves per SIMD where 5 keeps 37 KB and one)
 template <bool PROF, int WVAR>
-__global__ __launch_bounds__(64, WVAR == 5 ? 2 : 1) void qmpc_solve_w_kernel(
+__global__ __launch_bounds__(64, (WVAR == 5 || WVAR == 6) ? 2 : 1) void qmpc_solve_w_kernel(
     DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
     double* __restrict__ traj_u, double* __restrict__ traj_x, int batch, long long* __restrict__ prof_out,
     double* __restrict__ gws) {
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(64, 1) void qmpc_solve8_w_kernel(
 // ---- ConvexMpc's problem (the sibling controller: Euler-angle model, world-frame forces; ConvexMpc.cpp:81-198) on the same
 // body (round 5): WVAR 3 everything in LDS, 5 gains / per-point records / per-knot blocks in the workspace (two waves per SIMD)
 template <int WVAR>
-__global__ __launch_bounds__(64, WVAR == 5 ? 2 : 1) void qmpc_solve_cw_kernel(
+__global__ __launch_bounds__(64, (WVAR == 5 || WVAR == 6) ? 2 : 1) void qmpc_solve_cw_kernel(
     DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
     double* __restrict__ traj_u, double* __restrict__ traj_x, int batch, double* __restrict__ gws) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -163,20 +165,23 @@ __global__ __launch_bounds__(64, OCC) void qmpc_ref_w_kernel(
 using namespace qmpc_wform_tu;
 
 // called from qmpc_hip.hip (declared there); hidden: not part of the C ABI
+// kd_global: 0 everything in LDS (WVAR 3), 1 gains / records / blocks in the workspace (5), 2 the slack arrays as well (6)
 __attribute__((visibility("hidden"))) size_t qmpc_wform_lds_bytes(int N, int kd_global, int nl) {
   LayoutW LW;
-  return (size_t)(nl == 8 ? make_layout_w<8>(N, &LW, kd_global != 0) : make_layout_w<4>(N, &LW, kd_global != 0)).total * sizeof(double);
+  return (size_t)(nl == 8 ? make_layout_w<8>(N, &LW, kd_global != 0, kd_global == 2)
+                          : make_layout_w<4>(N, &LW, kd_global != 0, kd_global == 2)).total * sizeof(double);
 }
-__attribute__((visibility("hidden"))) size_t qmpc_wform_slice_doubles(int N, int nl) { return nl == 8 ? wform_slice<8>(N) : wform_slice<4>(N); }
+__attribute__((visibility("hidden"))) size_t qmpc_wform_slice_doubles(int N, int nl) { return nl == 8 ? wform_slice<8>(N, true) : wform_slice<4>(N, true); }
 __attribute__((visibility("hidden"))) hipError_t qmpc_wform_set_lds(int bytes) {
-  const void* k[13] = {reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 3>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 3>),
+  const void* k[15] = {reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 3>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 3>),
                       reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 5>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 5>),
                       reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<3>), reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<5>),
                       reinterpret_cast<const void*>(qmpc_ref_w_kernel<3>), reinterpret_cast<const void*>(qmpc_ref_w_kernel<5>),
                       reinterpret_cast<const void*>(qmpc_ref_w_kernel<5, 1>),
                       reinterpret_cast<const void*>(qmpc_solve8_w_kernel<3>), reinterpret_cast<const void*>(qmpc_solve8_w_kernel<5>),
-                      reinterpret_cast<const void*>(qmpc_solve_cw_kernel<3>), reinterpret_cast<const void*>(qmpc_solve_cw_kernel<5>)};
-  for (int i = 0; i < 13; ++i) {
+                      reinterpret_cast<const void*>(qmpc_solve_cw_kernel<3>), reinterpret_cast<const void*>(qmpc_solve_cw_kernel<5>),
+                      reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 6>), reinterpret_cast<const void*>(qmpc_solve_cw_kernel<6>)};
+  for (int i = 0; i < 15; ++i) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
   }
@@ -193,7 +198,9 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_wform_launch(int var, int 
 #define QMPC_LAUNCH_W(PR, V) \
   hipLaunchKernelGGL((qmpc_solve_w_kernel<PR, V>), dim3((unsigned)batch), dim3(kWave), lds, s, P, in, forces, info, traj_u, traj_x, \
                      batch, prof_out, gws)
-  if (var == 5) {
+  if (var == 6) {
+    QMPC_LAUNCH_W(false, 6);
+  } else if (var == 5) {
     if (prof) QMPC_LAUNCH_W(true, 5); else QMPC_LAUNCH_W(false, 5);
   } else {
     if (prof) QMPC_LAUNCH_W(true, 3); else QMPC_LAUNCH_W(false, 3);
@@ -223,7 +230,9 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_wform_launch_convex(int va
   DevParams P;
   std::memcpy(&P, dev_params, sizeof P);
   const qmpc_input* in_ = static_cast<const qmpc_input*>(in);
-  if (var == 5)
+  if (var == 6)
+    hipLaunchKernelGGL(qmpc_solve_cw_kernel<6>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in_, forces, info, traj_u, traj_x, batch, gws);
+  else if (var == 5)
     hipLaunchKernelGGL(qmpc_solve_cw_kernel<5>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in_, forces, info, traj_u, traj_x, batch, gws);
   else
     hipLaunchKernelGGL(qmpc_solve_cw_kernel<3>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in_, forces, info, traj_u, traj_x, batch, gws);
