@@ -96,7 +96,9 @@ struct qmpc_handle {
   double* d_lane_ws;      // structure-of-arrays workspace of the lane-per-instance kernel: [elements][lane_slots], on first use
   unsigned lane_slots;    // resident lanes it is sized for
   int* d_lane_scratch;    // counting sort of the batch on the stance mask: hist | cursor | perm[max_batch]
-  int lane_min_batch;     // batches from this size on take the lane-per-instance kernel (env QMPC_LANE_MIN)
+  int lane_min_batch;     // cold plain solves from this size on take the lane-per-instance kernel (env QMPC_LANE_MIN)
+  int lane_min_body;      // ... warm-started solves and the closed loop's ticks (their wave side is the shared body: WVAR 5, not 6)
+  bool lane_body;         // set while such a call runs
   int lane_sort;          // 1: order the batch by stance mask first (env QMPC_LANE_SORT)
   int lane_pslot;         // this handle's slot in the lane kernel's constant-memory parameter table
   bool lane_params_resident;   // set while a stream capture repeats launches with unchanged parameters (closed loop)
@@ -131,8 +133,14 @@ constexpr int kLaneMinLoopCold = 18432;       // ... of the cold-started closed 
 // 8-point model keep the round-1 wave kernels and cross earlier (ConvexMpc N=10 / 20: equal at 16384 / 20480; 8-point
 // 16384: 0.78 vs 0.82 M, 20480: 0.97 vs 0.84 M)
 constexpr int kLaneMinBatch = 26624;          // QuatMpc, horizons up to 12
-constexpr int kLaneMinBatchLong = 16384;      // QuatMpc, longer horizons
-constexpr int kLaneMinBatchOther = 18432;      // ConvexMpc (round-1 wave kernels below it)
+// QuatMpc, longer horizons; round 5 (the wave side is the wrench-form kernel with its slack arrays in the workspace, WVAR 6):
+// N=16 20480: wave 2.20 vs lane 2.15 M solves/s, 24576: 2.23 vs 2.52; N=20 20480: 1.64 vs 1.60, 24576: 1.67 vs 1.90;
+// N=24 16384: 1.20 vs 1.03, 20480: 1.20 vs 1.25
+constexpr int kLaneMinBatchLong = 21504;
+constexpr int kLaneMinBatchVeryLong = 18432;  // horizons beyond 22
+constexpr int kLaneMinBatchOther = 18432;      // ConvexMpc, short horizons (round-1 wave kernels below it)
+// ConvexMpc at its own horizon (N=20; WVAR 6 below the threshold): 20480 instances wave 1.21 vs lane 1.11 M, 24576: 1.22 vs 1.29
+constexpr int kLaneMinBatchConvexLong = 22528;
 // 8-point model, round 5 (the wave side is the wrench-form kernel, four instances per CU at N=16): 28672 instances wave 1.35 M
 // vs lane 1.17 M solves/s, 32768: 1.35 vs 1.32 M, 40960: 1.36 vs 1.71 M
 constexpr int kLaneMinBatch8 = 34816;
@@ -373,9 +381,14 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     h->lds_bytes_wg = qmpc_wform_lds_bytes(N, 1, nl);
     h->lds_bytes_ws = qmpc_wform_lds_bytes(N, 2, nl);
     const char* lm = std::getenv("QMPC_LANE_MIN");
-    h->lane_min_batch = lm ? std::atoi(lm) : (params->model == QMPC_MODEL_QUAT ? (N <= 12 ? kLaneMinBatch : kLaneMinBatchLong)
-                                                          : (params->model == QMPC_MODEL_QUAT8 ? kLaneMinBatch8 : kLaneMinBatchOther));
-    h->lane_min_loop_cold = lm ? h->lane_min_batch : (kLaneMinLoopCold < h->lane_min_batch ? kLaneMinLoopCold : h->lane_min_batch);
+    h->lane_min_batch = lm ? std::atoi(lm) : (params->model == QMPC_MODEL_QUAT ? (N <= 12 ? kLaneMinBatch : (N <= 22 ? kLaneMinBatchLong : kLaneMinBatchVeryLong))
+                                                          : (params->model == QMPC_MODEL_QUAT8 ? kLaneMinBatch8
+                                                                                               : (N > 12 ? kLaneMinBatchConvexLong : kLaneMinBatchOther)));
+    // warm-started solves / loop ticks: the switch-over measured against the WVAR 5 body (round 4; unchanged)
+    h->lane_min_body = lm ? h->lane_min_batch
+                          : (params->model == QMPC_MODEL_QUAT ? (N <= 12 ? kLaneMinBatch : 16384)
+                                                              : (params->model == QMPC_MODEL_QUAT8 ? kLaneMinBatch8 : kLaneMinBatchOther));
+    h->lane_min_loop_cold = lm ? h->lane_min_batch : (kLaneMinLoopCold < h->lane_min_body ? kLaneMinLoopCold : h->lane_min_body);
     // Straggler hand-off (cold plain solves of QuatMpc's problem on the lane kernel): a launch of the lane kernel lasts as
     // long as its slowest instance -- 23 interior-point iterations at N=10 (mean 13.6), 31 at N=20 (mean 14.6) -- while
     // only 8 % / 10 % of the instances are still running after 16 / 17.  The lane kernel stops there, leaves the state of
@@ -463,7 +476,7 @@ static bool use_lane(const qmpc_handle* h, int32_t batch, const double* d_tu, co
   (void)d_tu; (void)d_tx;
   if (h->params.mode != QMPC_MODE_CONVERGED || h->lane_pslot < 0) return false;
   if (h->variant == 4) return true;
-  return h->variant == 0 && batch >= (h->lane_loop_cold ? h->lane_min_loop_cold : h->lane_min_batch);
+  return h->variant == 0 && batch >= (h->lane_loop_cold ? h->lane_min_loop_cold : (h->lane_body ? h->lane_min_body : h->lane_min_batch));
 }
 // workspace of the lane kernel, allocated at first use (never inside a stream capture: qmpc_loop_run calls this first)
 static qmpc_status ensure_lane_buffers(qmpc_handle* h) {
@@ -897,6 +910,8 @@ qmpc_status qmpc_solve_warm_device(qmpc_handle* h, int32_t batch, const qmpc_inp
   if (batch == 0) return QMPC_OK;
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
   HIP_TRY(hipSetDevice(h->device));
+  struct BodyGuard { qmpc_handle* h; bool prev; ~BodyGuard() { h->lane_body = prev; } } body_guard{h, h->lane_body};
+  h->lane_body = true;
   if (use_lane(h, batch, nullptr, nullptr))      // large batches: the lane-per-instance kernel, same start rule
     return launch_lane(h, batch, d_in, d_forces_body, d_info, stream ? (hipStream_t)stream : h->stream, d_u_init, d_traj_u, 0);
   const int var = body_variant(h, batch);
@@ -1022,7 +1037,7 @@ qmpc_status qmpc_prepare(qmpc_handle* h, int32_t batch) {
                         (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min));
   bool lane_loop = false;
   if (h->params.mode == QMPC_MODE_CONVERGED && h->lane_pslot >= 0 && h->variant == 0)
-    lane_loop = batch >= (h->lane_min_loop_cold < h->lane_min_batch ? h->lane_min_loop_cold : h->lane_min_batch);
+    lane_loop = batch >= (h->lane_min_loop_cold < h->lane_min_body ? h->lane_min_loop_cold : h->lane_min_body);
   if (use_lane(h, batch, nullptr, nullptr) || ref_lane || lane_loop) {
     const qmpc_status es = ensure_lane_buffers(h);
     if (es != QMPC_OK) return es;
@@ -1468,9 +1483,10 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   // and the parameters do not change between the ticks of a call).
   struct ResidentGuard {
     qmpc_handle* h;
-    ~ResidentGuard() { h->lane_params_resident = false; h->lane_order_prev = false; h->lane_loop_cold = false; }
+    ~ResidentGuard() { h->lane_params_resident = false; h->lane_order_prev = false; h->lane_loop_cold = false; h->lane_body = false; }
   } resident_guard{h};
   h->lane_loop_cold = !warm;
+  h->lane_body = true;
   if (use_lane(h, batch, nullptr, nullptr)) {
     const qmpc_status es = ensure_lane_buffers(h);
     if (es != QMPC_OK) return es;

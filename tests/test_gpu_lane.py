@@ -220,7 +220,7 @@ def test_more_live_handles_than_parameter_slots(pkg, lib, oracle, monkeypatch):
         s.close()
 
 
-@pytest.mark.parametrize("N,B", [(10, 32768), (20, 16384), (24, 16384)])      # N=24: 44 KB of LDS per list-kernel workgroup (512 of them)
+@pytest.mark.parametrize("N,B", [(10, 32768), (20, 22528), (24, 20480)])      # (beyond the switch-over of each horizon); N=24: 44 KB of LDS per list-kernel workgroup (512 of them)
 def test_straggler_hand_off_of_large_batches(pkg, lib, oracle, monkeypatch, N, B):
     """Cold plain solves the library sends to the lane kernel by itself (qmpc_hip.hip: launch_solve): the lane kernel stops at
     a fixed iteration cap and the wrench-form wave kernel CONTINUES the instances left from their state records.  Against

@@ -1844,12 +1844,12 @@ def test_prepare_and_query(pkg, lib):
     # N=20 (the reference's horizon): everything in LDS for the single robot and small fleets, the workspace form beyond;
     # N=24: the hand-off now exists for every horizon (80 KB gate), and says so
     p20 = pkg.default_params(20, pkg.MODE_CONVERGED, lib)
-    s20 = pkg.Solver(p20, 20000, device=0, lib=lib)
-    assert [s20.kernel_for_batch(b) for b in (1, 512, 513, 16383, 16384)] == ["wform_lds", "wform_lds", "wform_ws", "wform_ws", "lane_handoff"]
+    s20 = pkg.Solver(p20, 22000, device=0, lib=lib)
+    assert [s20.kernel_for_batch(b) for b in (1, 512, 513, 21503, 21504)] == ["wform_lds", "wform_lds", "wform_ws", "wform_ws", "lane_handoff"]
     s20.close()
     p24 = pkg.default_params(24, pkg.MODE_CONVERGED, lib)
-    s24 = pkg.Solver(p24, 16384, device=0, lib=lib)
-    assert s24.kernel_for_batch(16384) == "lane_handoff" and s24.query(pkg.QUERY_LANE_CAP, 1) == 17
+    s24 = pkg.Solver(p24, 18432, device=0, lib=lib)
+    assert s24.kernel_for_batch(18431) == "wform_ws" and s24.kernel_for_batch(18432) == "lane_handoff" and s24.query(pkg.QUERY_LANE_CAP, 1) == 17
     s24.close()
     os.environ["QMPC_LANE_CAP"] = "0"
     try:
@@ -1859,6 +1859,6 @@ def test_prepare_and_query(pkg, lib):
     finally:
         os.environ.pop("QMPC_LANE_CAP", None)
     pc = pkg.default_convex_params(20, pkg.MODE_CONVERGED, lib)
-    scv = pkg.Solver(pc, 20000, device=0, lib=lib)
-    assert scv.kernel_for_batch(20000) == "lane" and scv.query(pkg.QUERY_HANDOFF_ACTIVE) == 0 and scv.kernel_for_batch(64) == "wform_lds" and scv.kernel_for_batch(1024) == "wform_ws" and scv.kernel_for_batch(1025) == "wform_ws"
+    scv = pkg.Solver(pc, 24000, device=0, lib=lib)
+    assert scv.kernel_for_batch(20000) == "wform_ws" and scv.query(pkg.QUERY_HANDOFF_ACTIVE) == 0 and scv.kernel_for_batch(64) == "wform_lds" and scv.kernel_for_batch(1024) == "wform_ws" and scv.kernel_for_batch(1025) == "wform_ws" and scv.kernel_for_batch(22528) == "lane"
     scv.close()
