@@ -324,7 +324,7 @@ static qmpc_status create_resources(qmpc_handle* h, int N, int nl, int nu) {
     QMPC_SET_LDS(qmpc_linearize_kernel<QuatModel>, h->lds_bytes_g);
   }
   if (params->model != QMPC_MODEL_QUAT8)
-    for (int v = 0; v < 6; ++v) if (v != 4) HIP_TRY(qmpc_fused_set_lds(v, 160 * 1024));     // the closed loop's persistent kernels
+    for (int v = 0; v < 7; ++v) if (v != 4) HIP_TRY(qmpc_fused_set_lds(v, 160 * 1024));     // the closed loop's persistent kernels
   if (params->model != QMPC_MODEL_QUAT8) HIP_TRY(qmpc_warm_set_lds(160 * 1024));
   HIP_TRY(qmpc_wform_set_lds(160 * 1024));
   if (params->mode == QMPC_MODE_REFERENCE) {
@@ -384,9 +384,10 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     h->lane_min_batch = lm ? std::atoi(lm) : (params->model == QMPC_MODEL_QUAT ? (N <= 12 ? kLaneMinBatch : (N <= 22 ? kLaneMinBatchLong : kLaneMinBatchVeryLong))
                                                           : (params->model == QMPC_MODEL_QUAT8 ? kLaneMinBatch8
                                                                                                : (N > 12 ? kLaneMinBatchConvexLong : kLaneMinBatchOther)));
-    // warm-started solves / loop ticks: the switch-over measured against the WVAR 5 body (round 4; unchanged)
+    // warm-started solves / loop ticks: QuatMpc's launch forms share the plain solve's variants (and switch-over); ConvexMpc's
+    // keep the round-1 bodies and the round-4 switch-over
     h->lane_min_body = lm ? h->lane_min_batch
-                          : (params->model == QMPC_MODEL_QUAT ? (N <= 12 ? kLaneMinBatch : 16384)
+                          : (params->model == QMPC_MODEL_QUAT ? (N <= 12 ? kLaneMinBatch : (N <= 22 ? kLaneMinBatchLong : kLaneMinBatchVeryLong))
                                                               : (params->model == QMPC_MODEL_QUAT8 ? kLaneMinBatch8 : kLaneMinBatchOther));
     h->lane_min_loop_cold = lm ? h->lane_min_batch : (kLaneMinLoopCold < h->lane_min_body ? kLaneMinLoopCold : h->lane_min_body);
     // Straggler hand-off (cold plain solves of QuatMpc's problem on the lane kernel): a launch of the lane kernel lasts as
@@ -581,9 +582,9 @@ static int wform_variant(const qmpc_handle* h, int32_t batch, bool plain = false
   if (small_lds && h->variant == 0 && h->lds_bytes_w <= 160 * 1024 && batch <= 256 * (int)((160 * 1024) / h->lds_bytes_w)) return 3;
   // Long horizons, mid-size batches (round 5): with 37 KB of LDS (N=20) the workspace form leaves a SIMD ONE wave, and the
   // round-1 kernel with its slack arrays in the workspace (two waves per SIMD) was faster -- N=20: 8192 instances 1.12 M against
-  // 0.97 M solves/s.  WVAR 6 moves the wrench form's slack arrays out as well (18 KB); plain solves only (the warm-started
-  // solve and the closed loop keep 5: their launch forms share one body).
-  if (plain && h->wform != 3 && wform6_ok(h) && h->lds_bytes_wg > 20 * 1024 && batch > 256 * (int)((160 * 1024) / h->lds_bytes_wg)) return 6;
+  // 0.97 M solves/s.  WVAR 6 moves the wrench form's slack arrays out as well (18 KB); every launch form of QuatMpc's problem
+  // (plain, warm-started, the closed loop's two forms) is instantiated on it, so they stay bit-identical.
+  if (h->wform != 3 && wform6_ok(h) && h->lds_bytes_wg > 20 * 1024 && batch > 256 * (int)((160 * 1024) / h->lds_bytes_wg)) return 6;
   return (h->wform != 3 && h->lds_bytes_wg <= 80 * 1024) ? 5 : 0;
 }
 static bool use_wform(const qmpc_handle* h, int32_t batch) { return wform_variant(h, batch) == 3; }

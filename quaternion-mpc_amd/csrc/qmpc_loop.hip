@@ -464,7 +464,7 @@ __global__ __launch_bounds__(64, (REF && VAR != 5) ? 1 : QMPC_SOLVE_WAVES(QuatMo
       [&]() {                             // `return` in the body (rejected input) ends this tick's solve only
 #include "qmpc_ref_body.inc"
       }();
-    } else if constexpr (VAR == 3 || VAR == 5) {
+    } else if constexpr (VAR == 3 || VAR == 5 || VAR == 6) {
       [&]() {
         const int warm_t = (LP.warm_start != 0.0 && prev_ok) ? t : 0;   // t > 0 and the last solve left a usable U in LDS
         constexpr int WVAR = VAR;
@@ -517,11 +517,12 @@ __global__ __launch_bounds__(64, QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_sol
   const int warm_t = usable ? 1 : 0;
   if (usable) {
     LayoutW LWw;
-    const Layout Lw = (VAR == 3 || VAR == 5) ? make_layout_w(P.N, &LWw, VAR == 5) : make_layout(P.N, VAR == 1 || VAR == 2, MD::NL, VAR == 2);
+    const Layout Lw = (VAR == 3 || VAR == 5 || VAR == 6) ? make_layout_w(P.N, &LWw, VAR == 5 || VAR == 6, VAR == 6)
+                                                         : make_layout(P.N, VAR == 1 || VAR == 2, MD::NL, VAR == 2);
     for (int i = lane; i < P.N * 12; i += kWave) sm[Lw.U + i] = u_init[(size_t)b * P.N * 12 + i];
     __syncthreads();
   }
-  if constexpr (VAR == 3 || VAR == 5) {
+  if constexpr (VAR == 3 || VAR == 5 || VAR == 6) {
     constexpr int WVAR = VAR;
     const int wslot = b;
     constexpr const double* resume = nullptr;

@@ -24,6 +24,7 @@ static const void* fused_kernel(int var) {
                            : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0, JOINT, true, false>);
   if (var == 3 && !CONVEX) return reinterpret_cast<const void*>(qmpc_loop_fused_kernel<3, JOINT, false, false>);
   if (var == 5 && !CONVEX) return reinterpret_cast<const void*>(qmpc_loop_fused_kernel<5, JOINT, false, false>);
+  if (var == 6 && !CONVEX) return reinterpret_cast<const void*>(qmpc_loop_fused_kernel<6, JOINT, false, false>);
   return var == 2 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<2, JOINT, false, CONVEX>)
                   : (var == 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1, JOINT, false, CONVEX>)
                               : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0, JOINT, false, CONVEX>));
@@ -85,6 +86,7 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int 
   } else {
     if (var == 3) QMPC_LAUNCH_FUSED_J(3, false);
     else if (var == 5) QMPC_LAUNCH_FUSED_J(5, false);
+    else if (var == 6) QMPC_LAUNCH_FUSED_J(6, false);
     else if (var == 2) QMPC_LAUNCH_FUSED_J(2, false);
     else if (var == 1) QMPC_LAUNCH_FUSED_J(1, false);
     else QMPC_LAUNCH_FUSED_J(0, false);
@@ -97,11 +99,11 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int 
 }
 
 __attribute__((visibility("hidden"))) hipError_t qmpc_warm_set_lds(int bytes) {
-  const void* k[8] = {reinterpret_cast<const void*>(qmpc_solve_warm_kernel<0, false>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<1, false>),
+  const void* k[9] = {reinterpret_cast<const void*>(qmpc_solve_warm_kernel<6, false>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<0, false>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<1, false>),
                       reinterpret_cast<const void*>(qmpc_solve_warm_kernel<2, false>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<0, true>),
                       reinterpret_cast<const void*>(qmpc_solve_warm_kernel<1, true>),  reinterpret_cast<const void*>(qmpc_solve_warm_kernel<2, true>),
                       reinterpret_cast<const void*>(qmpc_solve_warm_kernel<3, false>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<5, false>)};
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 9; ++i) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
   }
@@ -125,6 +127,7 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_warm_launch(int var, int c
   } else {
     if (var == 3) QMPC_LAUNCH_WARM(3, false);
     else if (var == 5) QMPC_LAUNCH_WARM(5, false);
+    else if (var == 6) QMPC_LAUNCH_WARM(6, false);
     else if (var == 2) QMPC_LAUNCH_WARM(2, false);
     else if (var == 1) QMPC_LAUNCH_WARM(1, false);
     else QMPC_LAUNCH_WARM(0, false);
