@@ -262,7 +262,9 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_wform_ref_launch(int var, 
   if (dev_params_size != sizeof(DevParams)) return hipErrorInvalidValue;
   DevParams P;
   std::memcpy(&P, dev_params, sizeof P);
-  if (var == 5 && batch <= 1024)      // one instance per SIMD at most: the whole register file (no spill)
+  // one instance per SIMD at most -- a small batch, or a horizon whose LDS (> 20 KB: N >= 11) leaves a CU four instances
+  // anyway: the whole register file (the 256-register instantiation spills 157 VGPRs and would gain no occupancy for it)
+  if (var == 5 && (batch <= 1024 || lds > 20 * 1024))
     hipLaunchKernelGGL((qmpc_ref_w_kernel<5, 1>), dim3((unsigned)batch), dim3(kWave), lds, s, P, in, forces, info, traj_u, traj_x, batch, gws);
   else if (var == 5)
     hipLaunchKernelGGL(qmpc_ref_w_kernel<5>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in, forces, info, traj_u, traj_x, batch, gws);
