@@ -386,9 +386,7 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
                                                                                                : (N > 12 ? kLaneMinBatchConvexLong : kLaneMinBatchOther)));
     // warm-started solves / loop ticks: QuatMpc's launch forms share the plain solve's variants (and switch-over); ConvexMpc's
     // keep the round-1 bodies and the round-4 switch-over
-    h->lane_min_body = lm ? h->lane_min_batch
-                          : (params->model == QMPC_MODEL_QUAT ? (N <= 12 ? kLaneMinBatch : (N <= 22 ? kLaneMinBatchLong : kLaneMinBatchVeryLong))
-                                                              : (params->model == QMPC_MODEL_QUAT8 ? kLaneMinBatch8 : kLaneMinBatchOther));
+    h->lane_min_body = h->lane_min_batch;
     h->lane_min_loop_cold = lm ? h->lane_min_batch : (kLaneMinLoopCold < h->lane_min_body ? kLaneMinLoopCold : h->lane_min_body);
     // Straggler hand-off (cold plain solves of QuatMpc's problem on the lane kernel): a launch of the lane kernel lasts as
     // long as its slowest instance -- 23 interior-point iterations at N=10 (mean 13.6), 31 at N=20 (mean 14.6) -- while
@@ -550,12 +548,13 @@ static bool wform6_ok(const qmpc_handle* h) {      // env QMPC_WFORM6=0 switches
   static const int on = std::getenv("QMPC_WFORM6") ? std::atoi(std::getenv("QMPC_WFORM6")) : 1;
   return on && h->params.horizon >= 4 && h->lds_bytes_ws <= 80 * 1024;
 }
-// `plain`: the caller is a plain solve (launch_solve) -- ConvexMpc's problem has the wrench form there only; its warm start
-// and its closed loop keep the round-1 bodies (qmpc_solve_body.inc), and body_variant must keep naming those
+// (`plain`: the caller is a plain solve; since the closed loop's kernels include the wrench-form body for ConvexMpc's problem
+// too, every launch form of a model takes the same variant and the flag decides nothing any more)
 static int wform_variant(const qmpc_handle* h, int32_t batch, bool plain = false) {
+  (void)plain;
   if (!h->wform || h->params.mode != QMPC_MODE_CONVERGED) return 0;
   if (h->params.model == QMPC_MODEL_CONVEX) {
-    if (!plain || h->variant >= 2) return 0;
+    if (h->variant >= 2) return 0;
     // the same rule as QuatMpc's problem at its horizon (N=20: 75 KB per instance): everything in LDS while every instance
     // finds a CU with room, the workspace form (two waves per SIMD) beyond
     if (h->lds_bytes_w <= 160 * 1024 && batch <= 256 * (int)((160 * 1024) / h->lds_bytes_w)) return 3;

@@ -464,6 +464,16 @@ __global__ __launch_bounds__(64, (REF && VAR != 5) ? 1 : QMPC_SOLVE_WAVES(QuatMo
       [&]() {                             // `return` in the body (rejected input) ends this tick's solve only
 #include "qmpc_ref_body.inc"
       }();
+    } else if constexpr ((VAR == 3 || VAR == 5 || VAR == 6) && CONVEX) {
+      [&]() {                             // ConvexMpc's problem on the wrench-form body (round 5)
+        const int warm_t = (LP.warm_start != 0.0 && prev_ok) ? t : 0;
+        constexpr int WVAR = VAR;
+        const int wslot = b;
+        constexpr const double* resume = nullptr;
+#define QMPC_WMODEL WM_CONVEX
+#include "qmpc_wform_body.inc"
+#undef QMPC_WMODEL
+      }();
     } else if constexpr (VAR == 3 || VAR == 5 || VAR == 6) {
       [&]() {
         const int warm_t = (LP.warm_start != 0.0 && prev_ok) ? t : 0;   // t > 0 and the last solve left a usable U in LDS
@@ -522,7 +532,14 @@ __global__ __launch_bounds__(64, QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_sol
     for (int i = lane; i < P.N * 12; i += kWave) sm[Lw.U + i] = u_init[(size_t)b * P.N * 12 + i];
     __syncthreads();
   }
-  if constexpr (VAR == 3 || VAR == 5 || VAR == 6) {
+  if constexpr ((VAR == 3 || VAR == 5 || VAR == 6) && CONVEX) {
+    constexpr int WVAR = VAR;
+    const int wslot = b;
+    constexpr const double* resume = nullptr;
+#define QMPC_WMODEL WM_CONVEX
+#include "qmpc_wform_body.inc"
+#undef QMPC_WMODEL
+  } else if constexpr (VAR == 3 || VAR == 5 || VAR == 6) {
     constexpr int WVAR = VAR;
     const int wslot = b;
     constexpr const double* resume = nullptr;

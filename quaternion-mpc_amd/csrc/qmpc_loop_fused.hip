@@ -22,9 +22,9 @@ static const void* fused_kernel(int var) {
   if (REF && var == 5) return reinterpret_cast<const void*>(qmpc_loop_fused_kernel<5, JOINT, true, false>);
   if (REF) return var >= 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1, JOINT, true, false>)
                            : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0, JOINT, true, false>);
-  if (var == 3 && !CONVEX) return reinterpret_cast<const void*>(qmpc_loop_fused_kernel<3, JOINT, false, false>);
-  if (var == 5 && !CONVEX) return reinterpret_cast<const void*>(qmpc_loop_fused_kernel<5, JOINT, false, false>);
-  if (var == 6 && !CONVEX) return reinterpret_cast<const void*>(qmpc_loop_fused_kernel<6, JOINT, false, false>);
+  if (var == 3) return reinterpret_cast<const void*>(qmpc_loop_fused_kernel<3, JOINT, false, CONVEX>);
+  if (var == 5) return reinterpret_cast<const void*>(qmpc_loop_fused_kernel<5, JOINT, false, CONVEX>);
+  if (var == 6) return reinterpret_cast<const void*>(qmpc_loop_fused_kernel<6, JOINT, false, CONVEX>);
   return var == 2 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<2, JOINT, false, CONVEX>)
                   : (var == 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1, JOINT, false, CONVEX>)
                               : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<0, JOINT, false, CONVEX>));
@@ -75,7 +75,10 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int 
                      forces, info, trace_f, trace_c, ticks, batch, gws, JL)
   if (convex) {
     if (reference_mode) return hipErrorInvalidValue;
-    if (var == 2) QMPC_LAUNCH_FUSED_CJ(2);
+    if (var == 3) QMPC_LAUNCH_FUSED_CJ(3);
+    else if (var == 5) QMPC_LAUNCH_FUSED_CJ(5);
+    else if (var == 6) QMPC_LAUNCH_FUSED_CJ(6);
+    else if (var == 2) QMPC_LAUNCH_FUSED_CJ(2);
     else if (var == 1) QMPC_LAUNCH_FUSED_CJ(1);
     else QMPC_LAUNCH_FUSED_CJ(0);
   } else if (reference_mode) {
@@ -99,11 +102,13 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int 
 }
 
 __attribute__((visibility("hidden"))) hipError_t qmpc_warm_set_lds(int bytes) {
-  const void* k[9] = {reinterpret_cast<const void*>(qmpc_solve_warm_kernel<6, false>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<0, false>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<1, false>),
+  const void* k[12] = {reinterpret_cast<const void*>(qmpc_solve_warm_kernel<3, true>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<5, true>),
+                      reinterpret_cast<const void*>(qmpc_solve_warm_kernel<6, true>),
+                      reinterpret_cast<const void*>(qmpc_solve_warm_kernel<6, false>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<0, false>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<1, false>),
                       reinterpret_cast<const void*>(qmpc_solve_warm_kernel<2, false>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<0, true>),
                       reinterpret_cast<const void*>(qmpc_solve_warm_kernel<1, true>),  reinterpret_cast<const void*>(qmpc_solve_warm_kernel<2, true>),
                       reinterpret_cast<const void*>(qmpc_solve_warm_kernel<3, false>), reinterpret_cast<const void*>(qmpc_solve_warm_kernel<5, false>)};
-  for (int i = 0; i < 9; ++i) {
+  for (int i = 0; i < 12; ++i) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
   }
@@ -121,7 +126,10 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_warm_launch(int var, int c
   hipLaunchKernelGGL((qmpc_solve_warm_kernel<V, C>), dim3((unsigned)batch), dim3(kWave), lds, s, P, in, u_init, forces, info, \
                      traj_u, batch, gws, check_prev)
   if (convex) {
-    if (var == 2) QMPC_LAUNCH_WARM(2, true);
+    if (var == 3) QMPC_LAUNCH_WARM(3, true);
+    else if (var == 5) QMPC_LAUNCH_WARM(5, true);
+    else if (var == 6) QMPC_LAUNCH_WARM(6, true);
+    else if (var == 2) QMPC_LAUNCH_WARM(2, true);
     else if (var == 1) QMPC_LAUNCH_WARM(1, true);
     else QMPC_LAUNCH_WARM(0, true);
   } else {
