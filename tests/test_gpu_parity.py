@@ -1420,9 +1420,11 @@ def test_reference_mode_closed_loop_matches_host_classes(pkg, lib):
 @pytest.mark.parametrize("robots,ticks,horizon,mode,model",
                          [(96, 90, 10, 0, "quat"), (3000, 12, 10, 0, "quat"), (40, 60, 20, 0, "quat"), (64, 90, 10, 1, "quat"),
                           (64, 90, 10, 0, "convex"), (96, 90, 10, 0, "quat warm"), (2500, 12, 10, 0, "quat warm"),
-                          (64, 90, 10, 0, "convex warm")],
+                          (64, 90, 10, 0, "convex warm"), (1500, 8, 20, 0, "quat"), (1500, 8, 20, 0, "quat warm"),
+                          (1200, 8, 20, 0, "convex")],
                          ids=["96 robots N=10", "3000 robots (several rounds per SIMD)", "N=20", "reference mode", "ConvexMpc",
-                              "warm start", "warm start, 2500 robots", "ConvexMpc, warm start"])
+                              "warm start", "warm start, 2500 robots", "ConvexMpc, warm start", "N=20, 1500 robots (WVAR 6)",
+                              "N=20, 1500 robots, warm start (WVAR 6)", "ConvexMpc N=20, 1200 robots (WVAR 6)"])
 def test_persistent_loop_kernel_equals_the_per_tick_sequence(robots, ticks, horizon, mode, model):
     """qmpc_loop_run* has two launch forms: three kernels per tick (graph replay) and ONE persistent kernel in which a
     wave owns a robot for all ticks (the default up to 2048 robots: the per-tick tails of different robots average out,
