@@ -242,7 +242,8 @@ qmpc_status qmpc_solve_warm_device(qmpc_handle* h, int32_t batch, const qmpc_inp
  *
  * Which kernel runs is chosen from the batch size (converged mode; QuatMpc N <= 12: everything in LDS up to 1024
  * instances, gains in a workspace up to 26623, from 26624 on one LANE per instance with the stragglers handed back to the
- * wave kernel; the thresholds of the other models and horizons are in qmpc_hip.hip).  The kernel families solve the same
+ * wave kernel; N = 13 .. 22: the lane kernel from 21504; the thresholds of the other models are in qmpc_hip.hip, and
+ * qmpc_query(QMPC_QUERY_KERNEL_FOR_BATCH) answers for a given handle).  The kernel families solve the same
  * problem to the same KKT point but round differently: forces agree to ~1e-10 N across a threshold (tested to 1e-7 N),
  * bit for bit within a family and for a shard of a batch against the whole batch.  Their device buffers are allocated on
  * the first call that needs them, sized by max_batch, and held until qmpc_destroy: the lane kernel's workspace (<= 1024
@@ -261,7 +262,7 @@ qmpc_status qmpc_solve_async(qmpc_handle* h, int32_t batch, const qmpc_input* in
 
 /* How the host-buffer calls (qmpc_solve, qmpc_solve_traj, qmpc_solve_async, qmpc_convex_solve*, qmpc_solve8*) move their
  * data -- SURVEY.md 8d's metric is exactly this call: records in host memory -> forces in host memory.
- *   - Batches that take a wave-per-instance kernel (QuatMpc: up to 26623 instances) run ZERO-COPY: every wavefront reads
+ *   - Batches that take a wave-per-instance kernel (QuatMpc, N <= 12: up to 26623 instances) run ZERO-COPY: every wavefront reads
  *     its 384-byte record from, and writes its forces / status record to, host memory the device can address.  Buffers
  *     from qmpc_host_alloc (or hipHostMalloc / hipHostRegister) are used in place; pageable buffers go through pinned
  *     staging the handle owns (one memcpy in, one out).  One launch, one synchronisation; results are bit-identical to
