@@ -141,9 +141,9 @@ constexpr int kLaneMinBatchVeryLong = 18432;  // horizons beyond 22
 constexpr int kLaneMinBatchOther = 18432;      // ConvexMpc, short horizons (round-1 wave kernels below it)
 // ConvexMpc at its own horizon (N=20; WVAR 6 below the threshold): 20480 instances wave 1.21 vs lane 1.11 M, 24576: 1.22 vs 1.29
 constexpr int kLaneMinBatchConvexLong = 22528;
-// 8-point model, round 5 (the wave side is the wrench-form kernel, four instances per CU at N=16): 28672 instances wave 1.35 M
-// vs lane 1.17 M solves/s, 32768: 1.35 vs 1.32 M, 40960: 1.36 vs 1.71 M
-constexpr int kLaneMinBatch8 = 34816;
+// 8-point model, round 5 (the wave side is the wrench-form kernel, with its slack arrays in the workspace beyond one resident
+// round: two waves per SIMD at N=16): 32768 instances wave 1.95 vs lane 1.35 M solves/s, 49152: 1.99 vs 1.85 M; 65536: lane 2.3 M
+constexpr int kLaneMinBatch8 = 57344;
 // reference mode (AL-iLQR, <= 10 iterations; qmpc_lane_ref_kernel): measured against the wave-per-instance reference kernels
 // (tools/refmode_lane_bench.py, N=10): 16384: 1.49 vs 1.74 M solves/s, 32768: 2.70 vs 1.78 M, 65536: 4.59 vs 1.83 M (N=20: 2.53 vs 0.79 M)
 // iteration cap of the lane kernel in the solves of a cold-started closed loop, 11 + N/10 (in-gait states: 10.3 iterations on
@@ -569,6 +569,8 @@ static int wform_variant(const qmpc_handle* h, int32_t batch, bool plain = false
     // SIMD either way -- everything in LDS while every instance finds a CU with room, the workspace form (three per CU) beyond
     if (h->variant >= 2 && h->variant != 3) return h->lds_bytes_wg <= 160 * 1024 ? 5 : 0;
     if (h->lds_bytes_w <= 160 * 1024 && batch <= 256 * (int)((160 * 1024) / h->lds_bytes_w)) return 3;
+    // beyond one resident round of the workspace form: the slack arrays out as well (WVAR 6: 18 KB at N=16, two waves per SIMD)
+    if (wform6_ok(h) && h->lds_bytes_wg <= 160 * 1024 && batch > 256 * (int)((160 * 1024) / h->lds_bytes_wg)) return 6;
     return h->lds_bytes_wg <= 160 * 1024 ? 5 : (h->lds_bytes_w <= 160 * 1024 ? 3 : 0);
   }
   if (h->params.model != QMPC_MODEL_QUAT) return 0;
@@ -716,8 +718,8 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
       HIP_TRY(qmpc_wform_launch_convex(wv, (int)batch, variant_lds(h, wv), s, &h->dev, sizeof h->dev, d_in, d_forces,
                                        d_info, d_tu, d_tx, variant_gws(h, wv)));
     } else if (h->params.model == QMPC_MODEL_QUAT8) {
-      HIP_TRY(qmpc_wform_launch8(wv, (int)batch, wv == 5 ? h->lds_bytes_wg : h->lds_bytes_w, s, &h->dev, sizeof h->dev, d_in, d_forces, d_info,
-                                 d_tu, d_tx, wv == 5 ? h->d_gws : nullptr));
+      HIP_TRY(qmpc_wform_launch8(wv, (int)batch, variant_lds(h, wv), s, &h->dev, sizeof h->dev, d_in, d_forces, d_info,
+                                 d_tu, d_tx, variant_gws(h, wv)));
     } else
     HIP_TRY(qmpc_wform_launch(wv, 0, (int)batch, variant_lds(h, wv), s, &h->dev, sizeof h->dev, d_in, d_forces, d_info,
                               d_tu, d_tx, nullptr, variant_gws(h, wv)));

@@ -65,8 +65,9 @@ __global__ __launch_bounds__(64, (WVAR == 5 || WVAR == 6) ? 2 : 1) void qmpc_sol
 // the gains are those of the four-point kernel; the per-point phases (pre-pass, input recovery + directions, apply) walk
 // 8 N (knot, point) pairs, a knot's eight shares of G / r6 are summed over two lane quads.  One wave per SIMD in either
 // variant: an instance holds 94 KB (3) / 49 KB (5) of LDS at N=16, so the workspace form too leaves a SIMD at most one wave.
+// WVAR 6 (slack arrays in the workspace too: 18 KB of LDS at N=16) is compiled for two waves per SIMD
 template <int WVAR>
-__global__ __launch_bounds__(64, 1) void qmpc_solve8_w_kernel(
+__global__ __launch_bounds__(64, WVAR == 6 ? 2 : 1) void qmpc_solve8_w_kernel(
     DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
     double* __restrict__ traj_u, double* __restrict__ traj_x, int batch, double* __restrict__ gws) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -173,15 +174,16 @@ __attribute__((visibility("hidden"))) size_t qmpc_wform_lds_bytes(int N, int kd_
 }
 __attribute__((visibility("hidden"))) size_t qmpc_wform_slice_doubles(int N, int nl) { return nl == 8 ? wform_slice<8>(N, true) : wform_slice<4>(N, true); }
 __attribute__((visibility("hidden"))) hipError_t qmpc_wform_set_lds(int bytes) {
-  const void* k[15] = {reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 3>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 3>),
+  const void* k[16] = {reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 3>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 3>),
                       reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 5>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 5>),
                       reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<3>), reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<5>),
                       reinterpret_cast<const void*>(qmpc_ref_w_kernel<3>), reinterpret_cast<const void*>(qmpc_ref_w_kernel<5>),
                       reinterpret_cast<const void*>(qmpc_ref_w_kernel<5, 1>),
                       reinterpret_cast<const void*>(qmpc_solve8_w_kernel<3>), reinterpret_cast<const void*>(qmpc_solve8_w_kernel<5>),
                       reinterpret_cast<const void*>(qmpc_solve_cw_kernel<3>), reinterpret_cast<const void*>(qmpc_solve_cw_kernel<5>),
-                      reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 6>), reinterpret_cast<const void*>(qmpc_solve_cw_kernel<6>)};
-  for (int i = 0; i < 15; ++i) {
+                      reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 6>), reinterpret_cast<const void*>(qmpc_solve_cw_kernel<6>),
+                      reinterpret_cast<const void*>(qmpc_solve8_w_kernel<6>)};
+  for (int i = 0; i < 16; ++i) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
   }
@@ -216,7 +218,9 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_wform_launch8(int var, int
   DevParams P;
   std::memcpy(&P, dev_params, sizeof P);
   const qmpc_input* in_ = static_cast<const qmpc_input*>(in);
-  if (var == 5)
+  if (var == 6)
+    hipLaunchKernelGGL(qmpc_solve8_w_kernel<6>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in_, forces, info, traj_u, traj_x, batch, gws);
+  else if (var == 5)
     hipLaunchKernelGGL(qmpc_solve8_w_kernel<5>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in_, forces, info, traj_u, traj_x, batch, gws);
   else
     hipLaunchKernelGGL(qmpc_solve8_w_kernel<3>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in_, forces, info, traj_u, traj_x, batch, gws);

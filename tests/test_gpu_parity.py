@@ -520,6 +520,7 @@ def test_biped8_wrench_form_kernels(pkg, lib, oracle, monkeypatch):
     rec = pkg.random_biped8_states(B, config_id=5)
     s = pkg.Solver(p, B, device=0, lib=lib)
     assert [s.kernel_for_batch(b) for b in (1, 512, 513, 8192)] == ["wform_lds", "wform_lds", "wform_ws", "wform_ws"]
+    # (513 .. 1024: the workspace form with the slack arrays in LDS, four per CU; beyond: those in the workspace too, two waves per SIMD)
     f, info = s.solve8(rec)
     f2, info2 = s.solve8(rec)
     assert np.array_equal(f, f2) and np.array_equal(info, info2)
@@ -528,6 +529,8 @@ def test_biped8_wrench_form_kernels(pkg, lib, oracle, monkeypatch):
     assert np.abs(f[swing]).max() == 0.0
     fl, il = s.solve8(rec[:512])                                   # the all-LDS variant on the first 512
     assert np.abs(fl - f[:512]).max() < 1e-7 and np.array_equal(il["iterations"], info["iterations"][:512])
+    fm, im = s.solve8(rec[:1024])                                  # WVAR 5 (one resident round)
+    assert np.abs(fm - f[:1024]).max() < 1e-7 and np.array_equal(im["iterations"], info["iterations"][:1024])
     idx = np.arange(0, B, B // 192)[:192]
     fo, io = oracle.solve8(p, rec[idx], threads=8)
     err = np.abs(f[idx] - fo).max()
