@@ -8,7 +8,7 @@ cp $src/bench_default.json profiles/r05_bench_default.json
 cp $src/pytest_gpu.log profiles/r05_pytest_gpu.log
 stats=$(find $src/prof -name "*kernel_stats.csv" | head -1)
 cp "$stats" profiles/r05_rocprofv3_kernel_stats_default_cmd.csv
-for f in phase_cycles latency_b1 refmode_check handoff wform_vs_round1_midsize loop_bench; do
+for f in phase_cycles latency_b1 refmode_check handoff wform_vs_round1_midsize loop_bench soak; do
   [ -f $src/$f.txt ] && cp $src/$f.txt profiles/r05_$f.txt
 done
 if [ -d $src/pmc_b1024_n10 ]; then

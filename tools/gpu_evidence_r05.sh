@@ -26,6 +26,7 @@ if [ -z "$quick" ]; then
     if [ $w = 1 ]; then extra="--warm 1 --mu0 1e-6"; else extra=""; fi
     for f in 1 0; do echo "robots $r warm $w fused $f: $(QMPC_LOOP_FUSED=$f timeout 300 python tools/loop_bench.py --robots $r --ticks 100 $extra 2>&1 | tail -1)"; done
   done; done > "$out/loop_bench.txt" 2>&1
+  timeout 1500 bash tools/soak_r05.sh > "$out/soak.txt" 2>&1
   bash tools/pmc_r05.sh $tag/pmc_b1024_n10 1024 10 > /dev/null 2>&1
   bash tools/pmc_r05.sh $tag/pmc_b8192_n10 8192 10 > /dev/null 2>&1
   bash tools/pmc_r05.sh $tag/pmc_b32768_n10 32768 10 > /dev/null 2>&1
