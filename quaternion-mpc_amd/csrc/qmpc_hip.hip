@@ -805,15 +805,16 @@ qmpc_status qmpc_last_kernel_ms(qmpc_handle* h, float* ms) {
   return QMPC_OK;
 }
 
-// Is p host memory the device can address (hipHostMalloc / hipHostRegister / qmpc_host_alloc)?  *dev = its device-side alias.
-static bool pinned_alias(const void* p, size_t bytes, void** dev) {
+// What kind of memory is p?  1: host memory the device can address (hipHostMalloc / hipHostRegister / qmpc_host_alloc; *dev =
+// its device-side alias), 2: device (or managed) memory -- a caller that hands a host-buffer entry point such a pointer gets
+// the explicit-copy path, which takes any kind --, 0: pageable host memory (or unknown to the runtime)
+static int pointer_kind(const void* p, void** dev) {
   hipPointerAttribute_t a;
   std::memset(&a, 0, sizeof a);
-  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-  if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
-  (void)bytes;
-  *dev = a.devicePointer;
-  return true;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (a.type == hipMemoryTypeHost && a.devicePointer) { *dev = a.devicePointer; return 1; }
+  if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeArray) return 2;
+  return 0;
 }
 static qmpc_status ensure_stage(qmpc_handle* h, int nl) {
   if (h->h_stage_in) return QMPC_OK;
@@ -866,13 +867,14 @@ static qmpc_status solve_host(qmpc_handle* h, int32_t batch, const qmpc_input* i
                      (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min)));
   if (h->zero_copy && !lane) {
     void *din = nullptr, *df = nullptr, *di = nullptr;
-    const bool in_pinned = pinned_alias(in, rec * (size_t)batch, &din);
-    const bool out_pinned = pinned_alias(forces_body, fbytes, &df) && (!info || pinned_alias(info, ibytes, &di));
-    if (!in_pinned || !out_pinned) {
+    const int k_in = pointer_kind(in, &din), k_f = pointer_kind(forces_body, &df), k_i = info ? pointer_kind(info, &di) : 1;
+    const bool in_pinned = k_in == 1, out_pinned = k_f == 1 && k_i == 1;
+    const bool any_device = k_in == 2 || k_f == 2 || k_i == 2;      // not host buffers at all: the copy path below takes them
+    if (!any_device && (!in_pinned || !out_pinned)) {
       const qmpc_status es = ensure_stage(h, nl);
       if (es != QMPC_OK) return es;
     }
-    if (h->zero_copy) {
+    if (h->zero_copy && !any_device) {
       if (!in_pinned) { std::memcpy(h->h_stage_in, in, rec * (size_t)batch); din = h->h_stage_in; }
       if (!out_pinned) { df = h->h_stage_out; di = h->h_stage_out + fbytes; }
       const qmpc_status st = launch_solve(h, batch, static_cast<const qmpc_input*>(din), static_cast<double*>(df),
@@ -892,12 +894,12 @@ static qmpc_status solve_host(qmpc_handle* h, int32_t batch, const qmpc_input* i
       return QMPC_OK;
     }
   }
-  HIP_TRY(hipMemcpyAsync(h->d_in, in, rec * (size_t)batch, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_in, in, rec * (size_t)batch, hipMemcpyDefault, h->stream));
   const qmpc_status st = launch_solve(h, batch, h->d_in, h->d_forces, h->d_info, traj_u ? h->d_traj_u : nullptr,
                                       traj_x ? h->d_traj_x : nullptr, h->stream);
   if (st != QMPC_OK) return st;
-  HIP_TRY(hipMemcpyAsync(forces_body, h->d_forces, fbytes, hipMemcpyDeviceToHost, h->stream));
-  if (info) HIP_TRY(hipMemcpyAsync(info, h->d_info, ibytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(forces_body, h->d_forces, fbytes, hipMemcpyDefault, h->stream));
+  if (info) HIP_TRY(hipMemcpyAsync(info, h->d_info, ibytes, hipMemcpyDefault, h->stream));
   if (traj_u) HIP_TRY(hipMemcpyAsync(traj_u, h->d_traj_u, sizeof(double) * nu * N * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   if (traj_x) HIP_TRY(hipMemcpyAsync(traj_x, h->d_traj_x, sizeof(double) * nx * (N + 1) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
   if (blocking) HIP_TRY(hipStreamSynchronize(h->stream));

@@ -1812,6 +1812,12 @@ def test_host_buffer_calls_zero_copy_pinned_and_pageable(pkg, lib):
     s.solve_async(rec[::-1].copy(), f7, None)
     s.wait()
     assert np.array_equal(f6, f_res) and np.array_equal(f7, f_res[::-1])
+    # a caller that hands the host-buffer entry point DEVICE pointers gets the explicit-copy path (no host dereference)
+    d_f2 = torch.full((B, 12), -1.0, dtype=torch.float64, device="cuda")
+    d_i2 = torch.zeros(B, pkg.INFO_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    assert lib.qmpc_solve(s._h, B, C.c_void_p(d_in.data_ptr()), C.c_void_p(d_f2.data_ptr()), C.c_void_p(d_i2.data_ptr())) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d_f2.cpu().numpy(), f_res)
     # trajectories still arrive (explicit copies next to the zero-copy records)
     ft, it_, tu, tx = s.solve(rec, want_traj=True)
     assert np.array_equal(ft, f_res) and np.array_equal(tu[:, 0, :], f_res)
