@@ -64,6 +64,16 @@ def test_bad_arguments_are_rejected(lib, pkg):
     assert lib.qmpc_create(C.byref(p), 4, 0, C.byref(h)) == pkg.BAD_ARGUMENT
 
 
+def test_round5_entry_points_reject_null_handles(lib, pkg):
+    """qmpc_prepare / qmpc_query without a handle (no device needed): BAD_ARGUMENT, nothing dereferenced; qmpc_host_free(NULL)
+    is a no-op; qmpc_host_alloc(0) returns NULL."""
+    v = C.c_int64(7)
+    assert lib.qmpc_prepare(None, 16) == pkg.BAD_ARGUMENT
+    assert lib.qmpc_query(None, pkg.QUERY_KERNEL_FOR_BATCH, 16, C.byref(v)) == pkg.BAD_ARGUMENT and v.value == 7
+    lib.qmpc_host_free(None)
+    assert not lib.qmpc_host_alloc(0)
+
+
 def test_fails_loudly_without_gpu(lib, pkg):
     """No silent CPU path: without a HIP device creation must return NO_DEVICE."""
     import torch
