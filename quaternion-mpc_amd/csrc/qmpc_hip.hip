@@ -83,7 +83,7 @@ struct qmpc_handle {
   size_t lds_bytes_g;     // gains in the global workspace
   size_t lds_bytes_s;     // gains and slack arrays in the global workspace
   size_t lds_bytes_w;     // the wrench-form kernel (qmpc_wform.hip), everything in LDS
-  size_t lds_bytes_ws;    // ... and with its slack arrays there too (WVAR 6; plain solves at long horizons)
+  size_t lds_bytes_ws;    // ... and with its slack arrays there too (WVAR 6; long horizons)
   size_t lds_bytes_wg;    // ... with its gains / per-point records / per-knot blocks in the global workspace
   int wform;              // 1: batches that keep everything in LDS take the wrench-form kernel (env QMPC_WFORM, default 1)
   int* d_loop_row;        // trace row counter of the closed loop (qmpc_loop_run*)
@@ -96,9 +96,7 @@ struct qmpc_handle {
   double* d_lane_ws;      // structure-of-arrays workspace of the lane-per-instance kernel: [elements][lane_slots], on first use
   unsigned lane_slots;    // resident lanes it is sized for
   int* d_lane_scratch;    // counting sort of the batch on the stance mask: hist | cursor | perm[max_batch]
-  int lane_min_batch;     // cold plain solves from this size on take the lane-per-instance kernel (env QMPC_LANE_MIN)
-  int lane_min_body;      // ... warm-started solves and the closed loop's ticks (their wave side is the shared body: WVAR 5, not 6)
-  bool lane_body;         // set while such a call runs
+  int lane_min_batch;     // batches from this size on take the lane-per-instance kernel (env QMPC_LANE_MIN)
   int lane_sort;          // 1: order the batch by stance mask first (env QMPC_LANE_SORT)
   int lane_pslot;         // this handle's slot in the lane kernel's constant-memory parameter table
   bool lane_params_resident;   // set while a stream capture repeats launches with unchanged parameters (closed loop)
@@ -384,10 +382,8 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     h->lane_min_batch = lm ? std::atoi(lm) : (params->model == QMPC_MODEL_QUAT ? (N <= 12 ? kLaneMinBatch : (N <= 22 ? kLaneMinBatchLong : kLaneMinBatchVeryLong))
                                                           : (params->model == QMPC_MODEL_QUAT8 ? kLaneMinBatch8
                                                                                                : (N > 12 ? kLaneMinBatchConvexLong : kLaneMinBatchOther)));
-    // warm-started solves / loop ticks: QuatMpc's launch forms share the plain solve's variants (and switch-over); ConvexMpc's
-    // keep the round-1 bodies and the round-4 switch-over
-    h->lane_min_body = h->lane_min_batch;
-    h->lane_min_loop_cold = lm ? h->lane_min_batch : (kLaneMinLoopCold < h->lane_min_body ? kLaneMinLoopCold : h->lane_min_body);
+    // (warm-started solves share the plain solve's variants and switch-over; the cold-started loop's in-gait states switch earlier)
+    h->lane_min_loop_cold = lm ? h->lane_min_batch : (kLaneMinLoopCold < h->lane_min_batch ? kLaneMinLoopCold : h->lane_min_batch);
     // Straggler hand-off (cold plain solves of QuatMpc's problem on the lane kernel): a launch of the lane kernel lasts as
     // long as its slowest instance -- 23 interior-point iterations at N=10 (mean 13.6), 31 at N=20 (mean 14.6) -- while
     // only 8 % / 10 % of the instances are still running after 16 / 17.  The lane kernel stops there, leaves the state of
@@ -475,7 +471,7 @@ static bool use_lane(const qmpc_handle* h, int32_t batch, const double* d_tu, co
   (void)d_tu; (void)d_tx;
   if (h->params.mode != QMPC_MODE_CONVERGED || h->lane_pslot < 0) return false;
   if (h->variant == 4) return true;
-  return h->variant == 0 && batch >= (h->lane_loop_cold ? h->lane_min_loop_cold : (h->lane_body ? h->lane_min_body : h->lane_min_batch));
+  return h->variant == 0 && batch >= (h->lane_loop_cold ? h->lane_min_loop_cold : h->lane_min_batch);
 }
 // workspace of the lane kernel, allocated at first use (never inside a stream capture: qmpc_loop_run calls this first)
 static qmpc_status ensure_lane_buffers(qmpc_handle* h) {
@@ -548,10 +544,9 @@ static bool wform6_ok(const qmpc_handle* h) {      // env QMPC_WFORM6=0 switches
   static const int on = std::getenv("QMPC_WFORM6") ? std::atoi(std::getenv("QMPC_WFORM6")) : 1;
   return on && h->params.horizon >= 4 && h->lds_bytes_ws <= 80 * 1024;
 }
-// (`plain`: the caller is a plain solve; since the closed loop's kernels include the wrench-form body for ConvexMpc's problem
-// too, every launch form of a model takes the same variant and the flag decides nothing any more)
-static int wform_variant(const qmpc_handle* h, int32_t batch, bool plain = false) {
-  (void)plain;
+// Every launch form of a model (plain solve, warm-started solve, per-tick and persistent closed loop) includes the same body, so
+// ONE rule names the variant for all of them -- they are bit-identical only then.
+static int wform_variant(const qmpc_handle* h, int32_t batch) {
   if (!h->wform || h->params.mode != QMPC_MODE_CONVERGED) return 0;
   if (h->params.model == QMPC_MODEL_CONVEX) {
     if (h->variant >= 2) return 0;
@@ -712,7 +707,7 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
     }
     return QMPC_OK;
   }
-  if (const int wv = wform_variant(h, batch, handoff != 2)) {      // (handoff 2: a tick of the closed loop -- its two launch forms share a body)
+  if (const int wv = wform_variant(h, batch)) {
     h->last_kernel = wv >= 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
     if (h->params.model == QMPC_MODEL_CONVEX) {
       HIP_TRY(qmpc_wform_launch_convex(wv, (int)batch, variant_lds(h, wv), s, &h->dev, sizeof h->dev, d_in, d_forces,
@@ -914,8 +909,6 @@ qmpc_status qmpc_solve_warm_device(qmpc_handle* h, int32_t batch, const qmpc_inp
   if (batch == 0) return QMPC_OK;
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
   HIP_TRY(hipSetDevice(h->device));
-  struct BodyGuard { qmpc_handle* h; bool prev; ~BodyGuard() { h->lane_body = prev; } } body_guard{h, h->lane_body};
-  h->lane_body = true;
   if (use_lane(h, batch, nullptr, nullptr))      // large batches: the lane-per-instance kernel, same start rule
     return launch_lane(h, batch, d_in, d_forces_body, d_info, stream ? (hipStream_t)stream : h->stream, d_u_init, d_traj_u, 0);
   const int var = body_variant(h, batch);
@@ -1041,7 +1034,7 @@ qmpc_status qmpc_prepare(qmpc_handle* h, int32_t batch) {
                         (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min));
   bool lane_loop = false;
   if (h->params.mode == QMPC_MODE_CONVERGED && h->lane_pslot >= 0 && h->variant == 0)
-    lane_loop = batch >= (h->lane_min_loop_cold < h->lane_min_body ? h->lane_min_loop_cold : h->lane_min_body);
+    lane_loop = batch >= (h->lane_min_loop_cold < h->lane_min_batch ? h->lane_min_loop_cold : h->lane_min_batch);
   if (use_lane(h, batch, nullptr, nullptr) || ref_lane || lane_loop) {
     const qmpc_status es = ensure_lane_buffers(h);
     if (es != QMPC_OK) return es;
@@ -1063,7 +1056,7 @@ static int kernel_for_batch(const qmpc_handle* h, int32_t batch) {
     return ws ? QMPC_KERNEL_DENSE_WS : QMPC_KERNEL_DENSE_LDS;
   }
   if (use_lane(h, batch, nullptr, nullptr)) return handoff_cap(h, 1) ? QMPC_KERNEL_LANE_HANDOFF : QMPC_KERNEL_LANE;
-  if (const int wv = wform_variant(h, batch, true)) return wv >= 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
+  if (const int wv = wform_variant(h, batch)) return wv >= 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
   return pick_variant(h, batch) >= 1 ? QMPC_KERNEL_DENSE_WS : QMPC_KERNEL_DENSE_LDS;
 }
 
@@ -1487,10 +1480,9 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   // and the parameters do not change between the ticks of a call).
   struct ResidentGuard {
     qmpc_handle* h;
-    ~ResidentGuard() { h->lane_params_resident = false; h->lane_order_prev = false; h->lane_loop_cold = false; h->lane_body = false; }
+    ~ResidentGuard() { h->lane_params_resident = false; h->lane_order_prev = false; h->lane_loop_cold = false; }
   } resident_guard{h};
   h->lane_loop_cold = !warm;
-  h->lane_body = true;
   if (use_lane(h, batch, nullptr, nullptr)) {
     const qmpc_status es = ensure_lane_buffers(h);
     if (es != QMPC_OK) return es;
