@@ -792,6 +792,63 @@ def test_randomised_parameter_sets_convex_and_biped(pkg, lib, oracle):
         assert np.abs(wr(f) - wr(fo)).max() < 1e-6 and np.abs(f - fo).max() < 1e-4, (t, N)
 
 
+def test_randomised_parameter_sets_through_every_wrench_form_variant(pkg, lib, oracle):
+    """Round 5: random parameter sets (friction, force limit, weights, mass, knot spacing, horizon) for the three models at batch
+    sizes that select the workspace forms -- WVAR 5 (one resident round) and WVAR 6 (slack arrays in the workspace too; beyond it)
+    -- where the fixed-parameter tests only use the YAML values.  A sample of each batch against the oracle (1e-6 N; 8-point
+    model: foot wrench 1e-6, corner forces 1e-4) and the whole batch against the all-LDS form of the same kernels (1e-7 N,
+    identical iteration counts: the variants differ only in where their arrays live)."""
+    rng = np.random.default_rng(79)
+    cases = []
+    for t in range(3):                     # QuatMpc: long horizons (WVAR 6 from N=11 on)
+        N = int(rng.choice([12, 16, 20, 24]))
+        p = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
+        p.mu = float(rng.uniform(0.3, 1.0)); p.fz_max = float(rng.uniform(60, 300)); p.w = float(rng.uniform(1, 100))
+        p.mass = float(rng.uniform(9, 16))
+        for i in range(13):
+            p.q_weights[i] = float(p.q_weights[i] * rng.uniform(0.3, 3.0))
+        for i in range(12):
+            p.r_weights[i] = float(10 ** rng.uniform(-6.5, -4))
+        hs = float(rng.choice([0.005, 0.01]))
+        p.h, p.h_ref = hs, hs
+        cases.append(("quat", p, pkg.random_go1_trot_states, "solve", oracle.solve, 70 + t))
+    for t in range(2):                     # ConvexMpc: its own horizon and a shorter one
+        N = int(rng.choice([14, 20]))
+        p = pkg.default_convex_params(N, pkg.MODE_CONVERGED, lib)
+        p.mu = float(rng.uniform(0.3, 1.0)); p.fz_max = float(rng.uniform(80, 300)); p.mass = float(rng.uniform(10, 15))
+        for i in range(12):
+            p.q_weights[i] = float(p.q_weights[i] * rng.uniform(0.5, 2.0)); p.r_weights[i] = float(p.r_weights[i] * rng.uniform(0.5, 2.0))
+        cases.append(("convex", p, pkg.random_go1_convex_states, "convex_solve", oracle.convex_solve, 80 + t))
+    for t in range(2):                     # 8-point model
+        N = int(rng.choice([10, 16]))
+        p = pkg.default_biped8_params(N, pkg.MODE_CONVERGED, lib)
+        p.mu = float(rng.uniform(0.4, 1.0)); p.fz_max = float(p.fz_max * rng.uniform(0.7, 1.5)); p.w = float(rng.uniform(5, 80))
+        cases.append(("biped8", p, pkg.random_biped8_states, "solve8", oracle.solve8, 90 + t))
+    for model, p, gen, call, ocall, cfg in cases:
+        B = 3072
+        s = pkg.Solver(p, B, device=0, lib=lib)
+        fams = [s.kernel_for_batch(b) for b in (64, 1024, B)]
+        assert fams[0] == "wform_lds" and fams[2] == "wform_ws", (model, p.horizon, fams)
+        rec = gen(B, config_id=cfg)
+        f, info = getattr(s, call)(rec)                       # the form of large batches (WVAR 6 at long horizons, else 5)
+        fm, im = getattr(s, call)(rec[:1024])                 # one resident round (WVAR 5, or still everything in LDS)
+        fs, is_ = getattr(s, call)(rec[:64])                  # everything in LDS
+        s.close()
+        assert (info["status"] == 0).all(), (model, p.horizon, np.unique(info["status"], return_counts=True))
+        tol = 1e-7 if model != "biped8" else 1e-5
+        assert np.abs(fm - f[:1024]).max() < tol and np.abs(fs - f[:64]).max() < tol, (model, p.horizon)
+        assert np.array_equal(im["iterations"], info["iterations"][:1024]) and np.array_equal(is_["iterations"], info["iterations"][:64])
+        idx = np.arange(0, B, B // 48)[:48]
+        fo, io = ocall(p, rec[idx], threads=8)
+        assert (io["status"] == 0).all()
+        if model == "biped8":
+            feet = rec["foot_pos_body"][idx].reshape(-1, 8, 3)
+            wr = lambda F: np.concatenate([F.reshape(-1, 8, 3).sum(1), np.cross(feet, F.reshape(-1, 8, 3)).sum(1)], axis=1)
+            assert np.abs(wr(f[idx]) - wr(fo)).max() < 1e-6 and np.abs(f[idx] - fo).max() < 1e-4, (model, p.horizon)
+        else:
+            assert np.abs(f[idx] - fo).max() < 1e-6, (model, p.horizon, float(np.abs(f[idx] - fo).max()))
+
+
 def test_async_host_call_and_rccl_gather(pkg, lib):
     """qmpc_solve_async + qmpc_wait equal the blocking call; qmpc_gather (ncclAllGather through the C ABI) on a
     one-rank RCCL communicator returns the local block (the multi-rank path runs in the driver's 8-GPU bench)."""
