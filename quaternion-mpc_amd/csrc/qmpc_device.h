@@ -30,6 +30,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // ---- per-instance LDS layout (offsets in doubles) ---------------------------
 struct Layout {
   int cst, bw0, refp, uref, X, U, Xc, dU, S, LAM, DS, DLAM, RC, AB, XT, KD, ROT, tile, total;
+  int CV;      // wrench-form layouts of ConvexMpc's problem (make_layout_w): 8 doubles per knot, Iw(yaw_m)^-1 and Iw(yaw_m)
 };
 
 // Per-knot record sizes

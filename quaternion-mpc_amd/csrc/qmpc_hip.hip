@@ -36,8 +36,10 @@ hipError_t qmpc_warm_launch(int var, int convex, int batch, size_t lds, hipStrea
                             double* gws, int check_prev);
 
 // qmpc_wform.hip (fourth translation unit): the wave-per-instance kernel with the wrench-form elimination (small batches)
-size_t qmpc_wform_lds_bytes(int N, int kd_global, int nl);
+size_t qmpc_wform_lds_bytes(int N, int kd_global, int nl, int convex);
 size_t qmpc_wform_slice_doubles(int N, int nl);
+hipError_t qmpc_wform_ref_launch_convex(int var, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
+                                        const void* in, double* forces, qmpc_info* info, double* traj_u, double* traj_x, double* gws);
 hipError_t qmpc_wform_launch_convex(int var, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
                                     const void* in, double* forces, qmpc_info* info, double* traj_u, double* traj_x, double* gws);
 hipError_t qmpc_wform_launch8(int var, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size, const void* in,
@@ -375,9 +377,9 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     h->variant = v ? std::atoi(v) : 0;
     const char* wf = std::getenv("QMPC_WFORM");
     h->wform = wf ? std::atoi(wf) : 1;
-    h->lds_bytes_w = qmpc_wform_lds_bytes(N, 0, nl);
-    h->lds_bytes_wg = qmpc_wform_lds_bytes(N, 1, nl);
-    h->lds_bytes_ws = qmpc_wform_lds_bytes(N, 2, nl);
+    h->lds_bytes_w = qmpc_wform_lds_bytes(N, 0, nl, params->model == QMPC_MODEL_CONVEX);
+    h->lds_bytes_wg = qmpc_wform_lds_bytes(N, 1, nl, params->model == QMPC_MODEL_CONVEX);
+    h->lds_bytes_ws = qmpc_wform_lds_bytes(N, 2, nl, params->model == QMPC_MODEL_CONVEX);
     const char* lm = std::getenv("QMPC_LANE_MIN");
     h->lane_min_batch = lm ? std::atoi(lm) : (params->model == QMPC_MODEL_QUAT ? (N <= 12 ? kLaneMinBatch : (N <= 22 ? kLaneMinBatchLong : kLaneMinBatchVeryLong))
                                                           : (params->model == QMPC_MODEL_QUAT8 ? kLaneMinBatch8
@@ -621,7 +623,8 @@ static int handoff_cap(const qmpc_handle* h, int kind) {      // kind 1: plain c
 // 1.1e-8 N): W' = S6 (I + G S6) carries cond(S6) twice.  N=16: all within 1e-6 N of the round-1 kernels (median 2.5e-8,
 // worst 8.7e-7).  QMPC_REF_WFORM_MAXN overrides the limit (experiments).
 static int ref_wform_variant(const qmpc_handle* h, int32_t batch) {
-  if (!h->wform || h->params.model != QMPC_MODEL_QUAT || h->params.mode != QMPC_MODE_REFERENCE) return 0;
+  if (!h->wform || h->params.mode != QMPC_MODE_REFERENCE) return 0;
+  if (h->params.model != QMPC_MODEL_QUAT && h->params.model != QMPC_MODEL_CONVEX) return 0;      // (the 8-point model: round-1 kernels)
   static const int maxn = std::getenv("QMPC_REF_WFORM_MAXN") ? std::atoi(std::getenv("QMPC_REF_WFORM_MAXN")) : QMPC_MAX_HORIZON;
   if (h->params.horizon > maxn || h->params.horizon < 2) return 0;      // (one knot: the input weights would not fit behind the trial states)
   if (h->variant < 2) {
@@ -654,6 +657,10 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
     }
     if (const int wv = ref_wform_variant(h, batch)) {      // QuatMpc's problem: on the wrench-form algebra (qmpc_wform_ref_body.inc)
       h->last_kernel = wv >= 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
+      if (h->params.model == QMPC_MODEL_CONVEX)
+        HIP_TRY(qmpc_wform_ref_launch_convex(wv, (int)batch, variant_lds(h, wv), s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, d_tu,
+                                             d_tx, variant_gws(h, wv)));
+      else
       HIP_TRY(qmpc_wform_ref_launch(wv, (int)batch, variant_lds(h, wv), s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, d_tu, d_tx,
                                     variant_gws(h, wv)));
       if (timed) {

@@ -55,7 +55,7 @@ __host__ __device__ inline size_t wform_slice(int N, bool sl_global = false) {
   return ((size_t)N * (13 * 12 + 21 * NL + kGK + (sl_global ? 18 * NL : 0)) + 1 + 1) & ~(size_t)1;
 }
 template <int NL = 4>
-__host__ __device__ inline Layout make_layout_w(int N, LayoutW* W, bool kd_global = false, bool sl_global = false) {
+__host__ __device__ inline Layout make_layout_w(int N, LayoutW* W, bool kd_global = false, bool sl_global = false, bool cv = false) {
   Layout L;
   int o = 0;
   auto take = [&](int n) { int r = o; o += n; return r; };
@@ -91,6 +91,7 @@ __host__ __device__ inline Layout make_layout_w(int N, LayoutW* W, bool kd_globa
     W->GK = take(N * kGK + 1);      // per knot G (21) r6 (6); one 0.0 behind the array (masked operand reads point at it)
   }
   W->WR = take(N * 6);
+  L.CV = cv ? take(N * 8) : -1;      // ConvexMpc: per knot Winv_k (w00 w01 w11 wzz) and Iw_k (i00 i01 i11 izz)
   // set-up scratch (one record): the slack arrays are initialised after it; with the slacks in the workspace X (13 (N + 1)
   // doubles, written by the rollout that follows the set-up) takes the record
   L.tile = sl_global ? L.X : L.S;
@@ -116,7 +117,7 @@ __host__ __device__ constexpr int S6I(int i, int j) { return i <= j ? S6I_(i, j)
 // wrench (F, sum r x u): an increment dt' of the linearised torque is dt = Iw(yaw_m) dt' exactly.  This is the formulation
 // of the lane kernel's MD_CONVEX passes (qmpc_lane_core.h), in the fragment layout.
 // Per-knot numbers beyond A1 / A3 / W (AB record, same slots as the quaternion model): Winv_k = Iw(yaw_m)^-1 (w00 w01 w11 wzz)
-// and Iw(yaw_m) (i00 i01 i11 izz) in slots 0..7 of the knot's XT record (the model's cost Hessian is constant: no block there).
+// and Iw(yaw_m) (i00 i01 i11 izz) in an array of their own (Layout::CV, 8 per knot; in LDS in every variant).
 enum { WM_QUAT = 0, WM_CONVEX = 1 };
 __host__ __device__ constexpr int cvperm(int r) { return r < 3 ? r + 3 : (r < 6 ? r - 3 : (r < 9 ? r + 3 : r - 3)); }   // internal row -> state index
 __device__ __forceinline__ void cv_step_w(const DevParams& P, const double* x, const double w[6], double* xn) {
@@ -295,7 +296,7 @@ __device__ inline void prepass_w(const DevParams& P, const Layout& L, double* sm
           for (int b = 0; b < 3; ++b)
             V[9 + 3 * a + b] = bw[D::NU * a] * T[b] + bw[D::NU * a + 1] * T[3 + b] + bw[D::NU * a + 2] * T[6 + b];
         if (MD == WM_CONVEX) {      // bw is [r_l]x: the point map of knot k is Winv_k [r_l]x
-          const double* Wk = sm + L.XT + kXT * k;
+          const double* Wk = sm + L.CV + 8 * k;
 #pragma unroll
           for (int b = 0; b < 3; ++b) {
             const double t3[3] = {V[9 + b], V[12 + b], V[15 + b]};
@@ -838,13 +839,12 @@ __device__ inline void expansions_w(const DevParams& P, const Layout& L, const L
         ABk[18] = m00 * i00 + m01 * i01; ABk[19] = m00 * i01 + m01 * i11; ABk[20] = 0.0;
         ABk[21] = m10 * i00 + m11 * i01; ABk[22] = m10 * i01 + m11 * i11; ABk[23] = 0.0;
         ABk[24] = 0.0; ABk[25] = 0.0; ABk[26] = 1.0;
-        XTk[0] = w00; XTk[1] = w01; XTk[2] = w11; XTk[3] = P.Iinv[8];
-        XTk[4] = i00; XTk[5] = i01; XTk[6] = i11; XTk[7] = izz;
-        XTk[8] = 0.0;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) XTk[i] = 0.0;
+        double* CVk = sm + L.CV + 8 * k;
+        CVk[0] = w00; CVk[1] = w01; CVk[2] = w11; CVk[3] = P.Iinv[8];
+        CVk[4] = i00; CVk[5] = i01; CVk[6] = i11; CVk[7] = izz;
       }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) XTk[i] = 0.0;      // (no attitude block in this cost's Hessian)
       double xr[12];
       ConvexModel::xref(P, sm + L.refp, k, xr);
 #pragma unroll
@@ -923,7 +923,7 @@ __device__ __forceinline__ void roll_load_c(const Layout& L, const LayoutW& LW, 
 #pragma unroll
   for (int i = 0; i < 6; ++i) r.wr[i] = sm[LW.WR + 6 * k + i];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) r.iw[i] = sm[L.XT + kXT * k + 4 + i];
+  for (int i = 0; i < 4; ++i) r.iw[i] = sm[L.CV + 8 * k + 4 + i];
 }
 __device__ __forceinline__ void roll_load_w(const Layout& L, const LayoutW& LW, const double* sm, const double* KD, int k,
                                             int row, int wi, RollLoadsW& r) {
@@ -1022,6 +1022,7 @@ __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, con
 // ---- expected decrease of a full step, sum_k d_k' Qu_k (the Armijo test of the reference mode's line search): one lane
 // per (knot, contact point); d_l = -D~_l^-1 (V_l' xz + gq_l) is the feed-forward part of the point's step, Qu_l = V_l' y0 + gq_l
 // its gradient (y0 from the backward pass, xz = column 12 of [Xz | xz]) ---------------------------------------------------
+template <int MD = WM_QUAT>
 __device__ inline double expected_decrease_w(const DevParams& P, const Layout& L, double* sm, const double* KD,
                                              const double* ROT, const double* y0, int lane) {
   typedef Dim<4> D;
@@ -1037,6 +1038,13 @@ __device__ inline double expected_decrease_w(const DevParams& P, const Layout& L
     for (int i = 0; i < 9; ++i) T[i] = rec[i];
 #pragma unroll
     for (int i = 0; i < 6; ++i) { xz[i] = KD[156 * k + 13 * (6 + i) + 12]; yk[i] = y0[6 * k + i]; }
+    if (MD == WM_CONVEX) {      // Bw0_l' t = [r_l]x' (Winv_k t)
+      double a[3], b[3];
+      cv_winv_mul(sm + L.CV + 8 * k, xz + 3, a);
+      cv_winv_mul(sm + L.CV + 8 * k, yk + 3, b);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { xz[3 + i] = a[i]; yk[3 + i] = b[i]; }
+    }
     const double l10 = rec[9], l20 = rec[10], l21 = rec[11], id0 = rec[12], id1 = rec[13], id2 = rec[14];
     const double* bw = sm + L.bw0 + 3 * l;
     double fz[3], fy[3];
@@ -1084,7 +1092,7 @@ __device__ inline int recover_inputs_w(const DevParams& P, const Layout& L, doub
       for (int i = 0; i < 6; ++i) z[i] = zsrc ? zsrc[6 * k + i] : ROT[zeta_slot<NL>(k, i)];
       if (MD == WM_CONVEX) {      // Bw0_l' z_t = [r_l]x' (Winv_k z_t)
         double y[3];
-        cv_winv_mul(sm + L.XT + kXT * k, z + 3, y);
+        cv_winv_mul(sm + L.CV + 8 * k, z + 3, y);
         z[3] = y[0]; z[4] = y[1]; z[5] = y[2];
       }
       const double l10 = rec[9], l20 = rec[10], l21 = rec[11], id0 = rec[12], id1 = rec[13], id2 = rec[14];
@@ -1143,7 +1151,7 @@ __device__ inline int recover_directions_w(const DevParams& P, const Layout& L, 
     for (int i = 0; i < 6; ++i) z[i] = ROT[zeta_slot<NL>(k, i)];
     if (MD == WM_CONVEX) {
       double y[3];
-      cv_winv_mul(sm + L.XT + kXT * k, z + 3, y);
+      cv_winv_mul(sm + L.CV + 8 * k, z + 3, y);
       z[3] = y[0]; z[4] = y[1]; z[5] = y[2];
     }
     const double l10 = rec[9], l20 = rec[10], l21 = rec[11], id0 = rec[12], id1 = rec[13], id2 = rec[14];
@@ -1272,9 +1280,10 @@ __device__ inline void apply_w(const DevParams& P, const Layout& L, double* sl, 
 __device__ __forceinline__ int trial_states_slot(const Layout& L, int g) {      // knots 1..N of group g's trajectory
   return g == 0 ? L.Xc + 13 : (g == 1 ? L.S : (g == 2 ? L.DLAM : L.XT));
 }
-template <bool PF>
+template <bool PF, int MD = WM_QUAT>
 __device__ inline double rollout_trials_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm,
                                           const double* KD, double* ZG, double alpha_g, int lane) {
+  typedef typename std::conditional<MD == WM_CONVEX, ConvexModel, QuatModel>::type TM;
   typedef Dim<4> D;
   const int N = P.N;
   const double* cst = sm + L.cst;
@@ -1291,12 +1300,17 @@ __device__ inline double rollout_trials_w(const DevParams& P, const Layout& L, c
   if (lane == 15)
 #pragma unroll
     for (int i = 0; i < 13; ++i) sm[L.Xc + i] = xc[i];
-  double Jx = QuatModel::knot_cost(P, sm + L.refp, sm + L.uref, 0, xc, nullptr);
+  double Jx = TM::knot_cost(P, sm + L.refp, sm + L.uref, 0, xc, nullptr);
   // one knot; PF: the next knot's gains / old state / Jacobian blocks are loaded meanwhile into the other register set
   auto knot = [&](int k, RollLoadsW& cur, RollLoadsW& nxt) {
     if (!PF) roll_load_w(L, LW, sm, KD, k, row, wi, cur);
     double dx[12], e[12];
-    QuatModel::state_diff(cur.xo, xc, dx);
+    if (MD == WM_CONVEX) {
+#pragma unroll
+      for (int rr = 0; rr < 12; ++rr) dx[rr] = xc[cvperm(rr)] - cur.xo[cvperm(rr)];
+    } else {
+      QuatModel::state_diff(cur.xo, xc, dx);
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       e[a] = dx[a] + P.h * dx[6 + a];
@@ -1311,19 +1325,27 @@ __device__ inline double rollout_trials_w(const DevParams& P, const Layout& L, c
     const double p2 = kd[6] * e[6] + kd[7] * e[7] + kd[8] * e[8];
     const double p3 = kd[9] * e[9] + kd[10] * e[10] + kd[11] * e[11];
     const double s = (p0 + p1) + (p2 + p3);
-    const double wn = cur.wk + s;
+    const double wn = (MD == WM_CONVEX) ? s : cur.wk + s;
     if (r >= 6 && r < 12) zg[6 * k + r - 6] = s;
     if (PF && k + 1 < N) roll_load_w(L, LW, sm, KD, k + 1, row, wi, nxt);
     double w[6];
     w[0] = dpp_mov<0x150>(wn); w[1] = dpp_mov<0x151>(wn); w[2] = dpp_mov<0x152>(wn);      // row_newbcast:0..5
     w[3] = dpp_mov<0x153>(wn); w[4] = dpp_mov<0x154>(wn); w[5] = dpp_mov<0x155>(wn);
+    if (MD == WM_CONVEX) {
+      RollLoadsC rc;
+      roll_load_c(L, LW, sm, k, rc);
+      const double d3 = rc.iw[0] * w[3] + rc.iw[1] * w[4], d4 = rc.iw[1] * w[3] + rc.iw[2] * w[4], d5 = rc.iw[3] * w[5];
+      w[0] += rc.wr[0]; w[1] += rc.wr[1]; w[2] += rc.wr[2];
+      w[3] = rc.wr[3] + d3; w[4] = rc.wr[4] + d4; w[5] = rc.wr[5] + d5;
+      cv_step_w(P, xc, w, xn);
+    } else
     srbd_step_w(P, gb, wd0, xc, w, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) xc[i] = xn[i];
     if (r == 15)
 #pragma unroll
       for (int i = 0; i < 13; ++i) xg[13 * k + i] = xn[i];
-    Jx += QuatModel::knot_cost(P, sm + L.refp, sm + L.uref, k + 1, xc, nullptr);
+    Jx += TM::knot_cost(P, sm + L.refp, sm + L.uref, k + 1, xc, nullptr);
   };
   if (PF) {
     RollLoadsW ra, rb;
@@ -1344,6 +1366,7 @@ __device__ inline double rollout_trials_w(const DevParams& P, const Layout& L, c
 // the group's costates, u = U + du, then the input cost, the augmented-Lagrangian terms max(lambda + rho c, 0)^2 - lambda^2
 // and the violation max(c, 0) of the point's cone rows (the arithmetic of ref_merit in qmpc_ref.hip).  Per-lane partial sums:
 // Ju = input cost, mer = Ju + (augmented-Lagrangian terms) / (2 rho), vi = violation.
+template <int MD = WM_QUAT>
 __device__ inline void trial_inputs_w(const DevParams& P, const Layout& L, const double* sm, const double* sl,
                                       const double* ROT, const double* ZG, const double* Rl, double alpha, double rho,
                                       int lane, double Ju[4], double mer[4], double vi[4]) {
@@ -1378,7 +1401,15 @@ __device__ inline void trial_inputs_w(const DevParams& P, const Layout& L, const
       const double ag = alpha * (g == 0 ? 1.0 : (g == 1 ? 0.5 : (g == 2 ? 0.25 : 0.125)));
       double u[3] = {u0[0], u0[1], u0[2]};
       if (stance) {
-        const double* z = ZG + 6 * N * g + 6 * k;
+        const double* zs = ZG + 6 * N * g + 6 * k;
+        double z[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) z[i] = zs[i];
+        if (MD == WM_CONVEX) {
+          double y[3];
+          cv_winv_mul(sm + L.CV + 8 * k, z + 3, y);
+          z[3] = y[0]; z[4] = y[1]; z[5] = y[2];
+        }
         double f[3];
 #pragma unroll
         for (int b = 0; b < 3; ++b) f[b] = z[b] + (bw[b] * z[3] + bw[D::NU + b] * z[4] + bw[2 * D::NU + b] * z[5]);
@@ -1422,6 +1453,7 @@ __device__ inline void trial_inputs_w(const DevParams& P, const Layout& L, const
 #ifndef QMPC_STAT_ATTR
 #define QMPC_STAT_ATTR inline
 #endif
+template <int MD = WM_QUAT>
 __device__ QMPC_STAT_ATTR double stationarity_w(const DevParams& P, const Layout& L, double* sm, const double* sl, double* my,
                                         const double* Rl, double rho, unsigned conmask, int lane) {
   typedef Dim<4> D;
@@ -1439,7 +1471,8 @@ __device__ QMPC_STAT_ATTR double stationarity_w(const DevParams& P, const Layout
   const int il = (c < 12) ? L.XT + 9 + c : zero, sl_ = (c < 12) ? kXT : 0;
   const double self = (c < 12 && tp != 1) ? 1.0 : 0.0, hsh = (tp == 2 && c < 12) ? P.h : 0.0;
   const double cpf = P.h * (P.hh * P.inv_mass), cvf = P.h * P.inv_mass;
-  const double mself = (tp == 0) ? cpf : 0.0, mshl = (tp == 0) ? cvf : (tq ? P.h : 0.0), mw = tq ? P.h * (0.5 * P.hh) : 0.0;
+  const double mself = (tp == 0) ? cpf : 0.0, mshl = (tp == 0) ? cvf : (tq ? P.h : 0.0),
+               mw = tq ? ((MD == WM_CONVEX) ? P.h * P.hh : P.h * (0.5 * P.hh)) : 0.0;
   double y = sm[il + sl_ * N];
   for (int k = N - 1; k >= 0; --k) {
     const double a0 = sm[ia + sa * k], a1 = sm[ia + sa * k + da], a2 = sm[ia + sa * k + 2 * da];
@@ -1457,7 +1490,14 @@ __device__ QMPC_STAT_ATTR double stationarity_w(const DevParams& P, const Layout
   for (int q = lane; q < 4 * N; q += kWave) {
     const int k = q >> 2, l = q & 3;
     if (!(conmask & (1u << l))) continue;
-    const double* m = my + 6 * k;
+    double m[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) m[i] = my[6 * k + i];
+    if (MD == WM_CONVEX) {
+      double y[3];
+      cv_winv_mul(sm + L.CV + 8 * k, m + 3, y);
+      m[3] = y[0]; m[4] = y[1]; m[5] = y[2];
+    }
     const double* bw = sm + L.bw0 + 3 * l;
     const double con = cst[D::C_CON + l];
     double zp[6];

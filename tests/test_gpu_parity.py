@@ -1022,9 +1022,11 @@ def test_reference_mode_edge_cases_and_convex_model(pkg, lib, oracle):
     print(f"ConvexMpc reference mode: {int(same.sum())}/256 identical status and iterations; forces median {np.median(d):.2e}, "
           f"worst {d.max():.2e} N; cost worst {np.abs(info['cost'] - io['cost']).max():.2e}")
     # 5 ms knots make the first Newton systems of this problem ~1e11-conditioned (only R = 1e-6 sees the force
-    # directions): five truncated iterations leave the two implementations' rounding 1e-7 ... 4e-4 N apart, while
-    # status, iteration count and objective agree (in converged mode the same pair meets to 1e-12 N)
-    assert same.mean() >= 0.95 and d.max() < 2e-3 and np.median(d) < 1e-4
+    # directions).  Round 4 (dense kernels): five truncated iterations left the two implementations' rounding 1e-7 ... 1e-3 N
+    # apart (median 1e-5, 55 of 512 within 1e-6).  Round 5: the wrench-form reference kernels with refined stage solves --
+    # median 1e-12 N, >= 99 % within 1e-6 N (an instance whose active-row decision sits on its threshold may still be 4e-4 off);
+    # status, iteration count and objective agree
+    assert same.mean() >= 0.95 and d.max() < 2e-3 and np.median(d) < 1e-9 and float((d < 1e-6).mean()) >= 0.99
     assert np.abs(info["cost"] - io["cost"]).max() < 1e-6
 
 
