@@ -8,7 +8,7 @@ REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO))
 import __graft_entry__ as g  # noqa: E402
 pkg = g._load_pkg(); lib = pkg.load_library()
-N, B = 10, 1024
+N, B = int(os.environ.get("RP_N", "10")), int(os.environ.get("RP_B", "1024"))
 p = pkg.default_params(N, pkg.MODE_REFERENCE, lib)
 rec = pkg.random_go1_trot_states(B, config_id=2)
 s = pkg.Solver(p, B, 0, lib)
