@@ -156,6 +156,10 @@ constexpr int kLaneCapLoopBase = 11;
 constexpr int kLaneCapWarm = 8;
 constexpr int kLaneRefMinBatch = 32768;      // N <= 12: wave kernels (four step lengths per rollout) 3.29 M at 32768, lane kernel (two per sweep) 3.35 M
 constexpr int kLaneRefMinBatchLong = 22528;   // horizons beyond 12 (N=20: wave kernels 1.14-1.18 M; lane kernel 18.3 ms up to 32768 instances: 1.79 M there)
+// ConvexMpc's own mode (five iterations; tools/refmode_lane_bench.py --model convex): N=20 16384 instances wave 1.70 vs lane 1.68 M solves/s,
+// 24576: 1.72 vs 2.38 M, 65536: 1.74 vs 5.61 M; N=10 16384: 3.85 vs 3.37 M, 32768: 4.00 vs 6.00 M, 65536: 4.05 vs 10.5 M
+constexpr int kLaneRefMinBatchConvex = 20480;
+constexpr int kLaneRefMinBatchConvexLong = 17408;
 
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
@@ -394,7 +398,9 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     // result of an instance depends neither on timing nor on the batch it is part of.  Measured (caps 14 .. 20 scanned):
     // B=32768 N=10 4.14 -> 5.2 M solves/s, B=65536 N=10 6.8 -> 8.3 M, B=65536 N=20 3.25 -> 3.83 M, B=262144 N=10 9.1 -> 9.8 M.
     const char* lrm = std::getenv("QMPC_LANE_REF_MIN");
-    h->lane_ref_min = lrm ? std::atoi(lrm) : (N <= 12 ? kLaneRefMinBatch : kLaneRefMinBatchLong);
+    h->lane_ref_min = lrm ? std::atoi(lrm)
+                          : (params->model == QMPC_MODEL_CONVEX ? (N <= 12 ? kLaneRefMinBatchConvex : kLaneRefMinBatchConvexLong)
+                                                                : (N <= 12 ? kLaneRefMinBatch : kLaneRefMinBatchLong));
     const char* lc = std::getenv("QMPC_LANE_CAP");
     h->lane_cap = lc ? std::atoi(lc) : 15 + N / 10;
     const char* lcl = std::getenv("QMPC_LANE_CAP_LOOP");
@@ -635,6 +641,13 @@ static int ref_wform_variant(const qmpc_handle* h, int32_t batch) {
   return h->lds_bytes_wg <= 80 * 1024 ? 5 : 0;
 }
 
+// Reference-mode batches of Monte-Carlo scale take the AL variant of the lane passes (qmpc_lane_core.h: lane_solve_ref;
+// qmpc_lane.hip: qmpc_lane_ref_kernel): QuatMpc's problem and ConvexMpc's (its own mode: five iterations)
+static bool ref_lane_batch(const qmpc_handle* h, int32_t batch) {
+  return h->params.mode == QMPC_MODE_REFERENCE && (h->params.model == QMPC_MODEL_QUAT || h->params.model == QMPC_MODEL_CONVEX) &&
+         h->lane_pslot >= 0 && (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min));
+}
+
 static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces,
                                 qmpc_info* d_info, double* d_tu, double* d_tx, hipStream_t s, bool timed = true,
                                 int handoff = 1) {      // 0: no straggler hand-off, 1: plain solve (lane_cap), 2: closed loop (lane_cap_loop)
@@ -644,9 +657,8 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
     const bool ws = batch > 1024 || h->lds_bytes > 40 * 1024 || h->variant >= 2 || h->params.model == QMPC_MODEL_QUAT8;
     // Monte-Carlo scale (plain solves of QuatMpc's problem): one lane per instance, the AL variant of the lane passes
     // (qmpc_lane_core.h: lane_solve_ref; qmpc_lane.hip: qmpc_lane_ref_kernel)
-    if (handoff == 1 && h->params.model == QMPC_MODEL_QUAT && h->lane_pslot >= 0 && !d_tx &&      // plain solves only: the closed loop
-        (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min))) {                      // keeps the wave kernels in this mode
-      const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s, nullptr, d_tu, 0, nullptr, 0);
+    if (handoff == 1 && ref_lane_batch(h, batch)) {      // plain solves only: the closed loop keeps the wave kernels in this mode
+      const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s, nullptr, d_tu, 0, d_tx, 0);
       if (ls != QMPC_OK) return ls;
       h->last_kernel = QMPC_KERNEL_LANE;
       if (timed) {
@@ -864,9 +876,7 @@ static qmpc_status solve_host(qmpc_handle* h, int32_t batch, const qmpc_input* i
   const size_t fbytes = sizeof(double) * nu * (size_t)batch, ibytes = sizeof(qmpc_info) * (size_t)batch;
   if (traj_u && !h->d_traj_u) HIP_TRY(hipMalloc(&h->d_traj_u, sizeof(double) * nu * N * (size_t)h->max_batch));
   if (traj_x && !h->d_traj_x) HIP_TRY(hipMalloc(&h->d_traj_x, sizeof(double) * 13 * (N + 1) * (size_t)h->max_batch));
-  const bool lane = use_lane(h, batch, nullptr, nullptr) ||
-                    (h->params.mode == QMPC_MODE_REFERENCE && model == QMPC_MODEL_QUAT && h->lane_pslot >= 0 &&
-                     (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min)));
+  const bool lane = use_lane(h, batch, nullptr, nullptr) || ref_lane_batch(h, batch);
   if (h->zero_copy && !lane) {
     void *din = nullptr, *df = nullptr, *di = nullptr;
     const int k_in = pointer_kind(in, &din), k_f = pointer_kind(forces_body, &df), k_i = info ? pointer_kind(info, &di) : 1;
@@ -1037,8 +1047,7 @@ qmpc_status qmpc_prepare(qmpc_handle* h, int32_t batch) {
   if (!h || batch < 1) return QMPC_BAD_ARGUMENT;
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
   HIP_TRY(hipSetDevice(h->device));
-  const bool ref_lane = h->params.mode == QMPC_MODE_REFERENCE && h->params.model == QMPC_MODEL_QUAT && h->lane_pslot >= 0 &&
-                        (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min));
+  const bool ref_lane = ref_lane_batch(h, batch);
   bool lane_loop = false;
   if (h->params.mode == QMPC_MODE_CONVERGED && h->lane_pslot >= 0 && h->variant == 0)
     lane_loop = batch >= (h->lane_min_loop_cold < h->lane_min_batch ? h->lane_min_loop_cold : h->lane_min_batch);
@@ -1056,8 +1065,7 @@ qmpc_status qmpc_prepare(qmpc_handle* h, int32_t batch) {
 // kernel family launch_solve gives a plain solve of `batch` instances on this handle (QMPC_KERNEL_*)
 static int kernel_for_batch(const qmpc_handle* h, int32_t batch) {
   if (h->params.mode == QMPC_MODE_REFERENCE) {
-    if (h->params.model == QMPC_MODEL_QUAT && h->lane_pslot >= 0 && (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min)))
-      return QMPC_KERNEL_LANE;
+    if (ref_lane_batch(h, batch)) return QMPC_KERNEL_LANE;
     if (const int wv = ref_wform_variant(h, batch)) return wv >= 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
     const bool ws = batch > 1024 || h->lds_bytes > 40 * 1024 || h->variant >= 2 || h->params.model == QMPC_MODEL_QUAT8;
     return ws ? QMPC_KERNEL_DENSE_WS : QMPC_KERNEL_DENSE_LDS;

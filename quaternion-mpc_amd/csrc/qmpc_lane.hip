@@ -155,7 +155,7 @@ __device__ __noinline__ void call_setup_ref(PassArgs a, QL_PRIV_AS const LaneSta
   lane_setup_ref<NL>(P, c, O, st, al);
   priv_store(alp, al);
 }
-template <int NL, bool UPDATE>
+template <int NL, bool UPDATE, int MD>
 __device__ __noinline__ void call_M(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp, QL_PRIV_AS LaneAL* alp) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
@@ -166,10 +166,10 @@ __device__ __noinline__ void call_M(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
   priv_load(st, sp);
   LaneAL al;
   priv_load(al, (QL_PRIV_AS const LaneAL*)alp);
-  pass_M<NL, UPDATE>(P, c, O, K, st, al);
+  pass_M<NL, UPDATE, MD>(P, c, O, K, st, al);
   priv_store(alp, al);
 }
-template <int NL>
+template <int NL, int MD>
 __device__ __noinline__ bool call_B_AL(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp, QL_PRIV_AS LaneAL* alp) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
@@ -180,11 +180,11 @@ __device__ __noinline__ bool call_B_AL(PassArgs a, QL_PRIV_AS const LaneK<NL>* K
   priv_load(st, sp);
   LaneAL al;
   priv_load(al, (QL_PRIV_AS const LaneAL*)alp);
-  const bool ok = pass_B<NL, false, MD_QUAT, true>(P, c, O, K, st, (FootPtr)Kp->foot, &al);
+  const bool ok = pass_B<NL, false, MD, true>(P, c, O, K, st, (FootPtr)Kp->foot, &al);
   priv_store(alp, al);
   return ok;
 }
-template <int NL>
+template <int NL, int MD>
 __device__ __noinline__ void call_C_AL(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp, QL_PRIV_AS LaneAL* alp) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
@@ -195,10 +195,10 @@ __device__ __noinline__ void call_C_AL(PassArgs a, QL_PRIV_AS const LaneK<NL>* K
   priv_load(st, sp);
   LaneAL al;
   priv_load(al, (QL_PRIV_AS const LaneAL*)alp);
-  pass_C_AL<NL>(P, c, O, K, st, al, true);
+  pass_C_AL<NL, 2, MD>(P, c, O, K, st, al, true);
   priv_store(alp, al);
 }
-template <int NL>
+template <int NL, int MD>
 __device__ __noinline__ void call_A_AL(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp, int sel) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
@@ -207,9 +207,9 @@ __device__ __noinline__ void call_A_AL(PassArgs a, QL_PRIV_AS const LaneK<NL>* K
   priv_load(K, Kp);
   LaneState st;
   priv_load(st, sp);
-  pass_A_AL<NL>(P, c, O, K, st, sel);
+  pass_A_AL<NL, MD>(P, c, O, K, st, sel);
 }
-template <int NL>
+template <int NL, int MD>
 __device__ __noinline__ void call_S(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp, QL_PRIV_AS LaneAL* alp) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
@@ -220,13 +220,13 @@ __device__ __noinline__ void call_S(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
   priv_load(st, sp);
   LaneAL al;
   priv_load(al, (QL_PRIV_AS const LaneAL*)alp);
-  pass_S<NL>(P, c, O, K, st, al);
+  pass_S<NL, MD>(P, c, O, K, st, al);
   priv_store(alp, al);
 }
 
 // The reference's own solver mode, one lane per instance: the steps of lane_solve_ref (qmpc_lane_core.h) in lock step.  A
 // lane whose line search has ended waits (masked off) while others of its wavefront try shorter steps.
-template <int NL>
+template <int NL, int MD = MD_QUAT>
 __global__ __launch_bounds__(kLaneWave) void qmpc_lane_ref_kernel(int pslot, const double* __restrict__ in, double* __restrict__ forces,
                                                                   qmpc_info* __restrict__ info, int batch, double* __restrict__ ws,
                                                                   unsigned slots, int lanes, const int* __restrict__ perm,
@@ -250,14 +250,14 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_ref_kernel(int pslot, con
     const int b = valid ? (perm ? perm[pos] : (int)pos) : 0;
     bool active = false;
     if (valid) {
-      call_setup<NL, MD_QUAT>(a, reinterpret_cast<unsigned long long>(in + (size_t)b * D::REC), 0ull, Kp, sp);
+      call_setup<NL, MD>(a, reinterpret_cast<unsigned long long>(in + (size_t)b * D::REC), 0ull, Kp, sp);
       active = st.active;
     }
     int iter = 0;
     if (active) {
       call_setup_ref<NL>(a, sp, alp);
-      call_A<NL, false, MD_QUAT>(a, Kp, sp);        // X <- rollout of U = u_ref (first iteration of the apply pass)
-      call_M<NL, false>(a, Kp, sp, alp);
+      call_A<NL, false, MD>(a, Kp, sp);        // X <- rollout of U = u_ref (first iteration of the apply pass)
+      call_M<NL, false, MD>(a, Kp, sp, alp);
       st.status = QMPC_MAX_ITER;
       st.last_step = 0.0;
     }
@@ -265,14 +265,14 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_ref_kernel(int pslot, con
       bool searching = false;
       if (active) {
         ++iter;
-        if (!call_B_AL<NL>(a, Kp, sp, alp)) { st.status = QMPC_NOT_PD; --iter; active = false; }
+        if (!call_B_AL<NL, MD>(a, Kp, sp, alp)) { st.status = QMPC_NOT_PD; --iter; active = false; }
         else { al.alpha = 1.0; searching = true; }
       }
       bool accepted = false;
       int ls = 0;
       while (__any(searching)) {
         if (searching) {
-          call_C_AL<NL>(a, Kp, sp, alp);                  // trials ls and ls + 1 (step lengths alpha, alpha / 2) in one sweep
+          call_C_AL<NL, MD>(a, Kp, sp, alp);                  // trials ls and ls + 1 (step lengths alpha, alpha / 2) in one sweep
           if (al_accept_pair(P, al, ls)) { accepted = true; searching = false; }
           else {
             ls += 2;
@@ -282,14 +282,14 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_ref_kernel(int pslot, con
       }
       if (active && !accepted) { st.status = QMPC_LINESEARCH_FAIL; --iter; active = false; }
       if (active) {
-        call_A_AL<NL>(a, Kp, sp, al.sel);
+        call_A_AL<NL, MD>(a, Kp, sp, al.sel);
         st.last_step = al.stp;
         const double dJ = al.J - al.Jn;
         al.J = al.Jn; al.Jp = al.Jnp; al.viol = al.vn;
-        call_S<NL>(a, Kp, sp, alp);
+        call_S<NL, MD>(a, Kp, sp, alp);
         if (al.stat < P.tol_stat && al.viol < P.tol_feas) { st.status = QMPC_OK; active = false; }
         else {
-          if (al.stat < P.tol_stat || fabs(dJ) < P.tol_cost_int) call_M<NL, true>(a, Kp, sp, alp);
+          if (al.stat < P.tol_stat || fabs(dJ) < P.tol_cost_int) call_M<NL, true, MD>(a, Kp, sp, alp);
           if (iter >= P.iterations_max) active = false;
         }
       }
@@ -297,10 +297,10 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_ref_kernel(int pslot, con
     if (valid) {
       st.iters = iter;
       if (st.active) st.mu = al.rho;       // the info record's last field is the penalty in this mode
-      call_finish<NL, MD_QUAT>(a, Kp, sp, reinterpret_cast<unsigned long long>(forces + (size_t)b * D::NU),
+      call_finish<NL, MD>(a, Kp, sp, reinterpret_cast<unsigned long long>(forces + (size_t)b * D::NU),
                                info ? reinterpret_cast<unsigned long long>(info + b) : 0ull,
                                traj_u ? reinterpret_cast<unsigned long long>(traj_u + (size_t)b * tstride) : 0ull,
-                               traj_x ? reinterpret_cast<unsigned long long>(traj_x + (size_t)b * (size_t)(P.N + 1) * 13) : 0ull);
+                               traj_x ? reinterpret_cast<unsigned long long>(traj_x + (size_t)b * (size_t)(P.N + 1) * (MD == MD_CONVEX ? 12 : 13)) : 0ull);
     }
   }
 }
@@ -566,10 +566,14 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
   prof = d_prof;
   (void)hipMemsetAsync(d_prof, 0, sizeof(long long) * 16 * 1024, s);
 #endif
-  if (P.mode == QMPC_MODE_REFERENCE) {      // the reference's own solver mode (four-point QuatMpc): qmpc_lane_ref_kernel
-    if (nl != 4 || convex || u_init) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(qmpc_lane_ref_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm,
-                       traj_u, traj_x);
+  if (P.mode == QMPC_MODE_REFERENCE) {      // the reference's own solver mode (four-point QuatMpc, ConvexMpc): qmpc_lane_ref_kernel
+    if (nl != 4 || u_init) return hipErrorInvalidValue;
+    if (convex)
+      hipLaunchKernelGGL((qmpc_lane_ref_kernel<4, MD_CONVEX>), dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used,
+                         lanes, perm, traj_u, traj_x);
+    else
+      hipLaunchKernelGGL(qmpc_lane_ref_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm,
+                         traj_u, traj_x);
     return hipGetLastError();
   }
   if (nl == 8)

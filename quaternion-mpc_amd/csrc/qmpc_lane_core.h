@@ -1790,8 +1790,19 @@ QL_FN bool lane_iteration(const DevParams& P, const Ctx& c, const WsOff& O, cons
 // =====================================================================================================================
 
 // stage cost of knot k at state x (full coordinates) -- the terms of lane_finish / knot_cost
+template <int MD = MD_QUAT>
 QL_FN double al_state_cost(const DevParams& P, const double refp[13], int k, const double* x) {
   double xr[13];
+  if constexpr (MD == MD_CONVEX) {      // quadratic in the 12 states (ConvexMpc.cpp:107-109)
+    cv_xref_at(P, refp, k, xr);
+    double Jc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const double e = x[i] - xr[i];
+      Jc += 0.5 * P.Q[i] * e * e;
+    }
+    return Jc;
+  }
   xref_at(P, refp, k, xr);
   double J = 0.0, dq = 0.0;
 #pragma unroll
@@ -1822,7 +1833,7 @@ QL_FN double al_point_terms(const DevParams& P, const double cr[18], int l, cons
 
 // ---- pass M: AL merit, plain objective and violation of the CURRENT trajectory; UPDATE: the dual update first
 // (lambda <- max(lambda + rho c, 0), then rho <- min(rho * scaling, max)) -------------------------------------------------
-template <int NL, bool UPDATE>
+template <int NL, bool UPDATE, int MD = MD_QUAT>
 QL_FN void pass_M(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, const LaneState& st, LaneAL& al) {
   const int N = P.N;
   double cr[18];
@@ -1854,7 +1865,7 @@ QL_FN void pass_M(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
 #pragma unroll
     for (int i = 0; i < 13; ++i) x[i] = xk[i];
     if (k < N) load_x(k + 1);
-    Jp += al_state_cost(P, K.refp, k, x);
+    Jp += al_state_cost<MD>(P, K.refp, k, x);
     if (k == N) break;
     const int kn = (k + 1 < N) ? k + 1 : k;
 #pragma unroll
@@ -1886,7 +1897,7 @@ QL_FN void pass_M(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
 }
 
 // ---- pass A_AL: apply the accepted increment of the line search and roll the states out open loop ----------------------
-template <int NL>
+template <int NL, int MD = MD_QUAT>
 QL_FN void pass_A_AL(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, const LaneState& st, int sel = 0) {
   const int N = P.N;
   const int dsl = sel ? O.RC : O.dU;      // the accepted trial's increments (per lane: see pass_C_AL)
@@ -1918,14 +1929,21 @@ QL_FN void pass_A_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
       if (!((st.con >> l) & 1u)) continue;
 #pragma unroll
       for (int a = 0; a < 3; ++a) c.W(O.U + 3 * NL * k + 3 * l + a) = u[a];
+      if constexpr (MD == MD_CONVEX) {      // wd collects the raw torque sum
+#pragma unroll
+        for (int a = 0; a < 3; ++a) F[a] += u[a];
+        cv_cross_acc(&K.foot[3 * l], u, wd);
+      } else {
       leg_bw0(P, &K.foot[3 * l], B);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         F[a] += u[a];
         wd[a] += B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
       }
+      }
     }
-    srbd_step_fw(P, gb, x, F, wd, xn);
+    if constexpr (MD == MD_CONVEX) cv_step_fw(P, x, F, wd, xn);
+    else srbd_step_fw(P, gb, x, F, wd, xn);
 #pragma unroll
     for (int i = 0; i < 13; ++i) { x[i] = xn[i]; c.W(O.X + 13 * (k + 1) + i) = xn[i]; }
   }
@@ -1937,7 +1955,7 @@ QL_FN void pass_A_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
 // state, gains, inputs, multipliers) and the per-point blocks (weights, frame, L D L': functions of the current inputs only);
 // the rollout, the input recovery and the merit terms run once per step length.  The increments of the second trial go to the
 // RC slot (unused in this mode), 3 NL per knot like the dU slot.
-template <int NL, int NA = 2>
+template <int NL, int NA = 2, int MD = MD_QUAT>
 QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, const LaneState& st, LaneAL& al, bool live) {
   typedef LDim<NL> D;
   const int N = P.N;
@@ -1977,13 +1995,24 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
   for (int k = 0; k < N; ++k) {
     const int kn = (k + 1 < N) ? k + 1 : k;
     double zeta[NA][6];
+    double Wk[4] = {0, 0, 0, 0};       // ConvexMpc's model: Iw^-1 at the OLD knot state's midpoint yaw (the linearisation point)
+    if constexpr (MD == MD_CONVEX) cv_winv_mid(P, xo[2], xo[8], Wk);
     {
       double G[12];
-      quatG(&xo[3], G);
+      if constexpr (MD != MD_CONVEX) quatG(&xo[3], G);
 #pragma unroll
       for (int q = 0; q < NA; ++q) {
-        Jp[q] += al_state_cost(P, K.refp, k, xc[q]);
+        Jp[q] += al_state_cost<MD>(P, K.refp, k, xc[q]);
         double dx[12];
+        if constexpr (MD == MD_CONVEX) {      // blocks in the recursion's order [p, phi, v, w]
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            dx[a] = xc[q][3 + a] - xo[3 + a];
+            dx[3 + a] = xc[q][a] - xo[a];
+            dx[6 + a] = xc[q][9 + a] - xo[9 + a];
+            dx[9 + a] = xc[q][6 + a] - xo[6 + a];
+          }
+        } else {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           dx[a] = xc[q][a] - xo[a];
@@ -1994,6 +2023,7 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
 #pragma unroll
         for (int a = 0; a < 3; ++a)
           dx[3 + a] = (G[a] * xc[q][3] + G[3 + a] * xc[q][4] + G[6 + a] * xc[q][5] + G[9 + a] * xc[q][6]) * isc;
+        }
 #pragma unroll
         for (int i = 0; i < 6; ++i) zeta[q][i] = alpha[q] * gn[36 + i];
 #pragma unroll
@@ -2033,7 +2063,8 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
         rcl[i] = act ? z * al.irho : 0.0;
         lv[i] = act ? al.rho : 0.0;
       }
-      leg_bw0(P, &K.foot[3 * l], B);
+      if constexpr (MD == MD_CONVEX) cv_leg_bw0(Wk, &K.foot[3 * l], B);
+      else leg_bw0(P, &K.foot[3 * l], B);
       LegBlk lb;
       leg_block(P, cr, rcl, l, sv, lv, 0u, 1.0, 0.0, u, st.uz, lb);
 #pragma unroll
@@ -2058,22 +2089,29 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
           if (live) c.W((q == 0 ? O.dU : O.RC) + 3 * NL * k + 3 * l + a) = du;
         }
         Jp[q] += al_point_terms(P, cr, l, un, st.uz, lam, al.rho, alsum[q], viol[q]);
+        if constexpr (MD == MD_CONVEX) {      // the rollout wants the raw torque r x u
+#pragma unroll
+          for (int a = 0; a < 3; ++a) F[q][a] += un[a];
+          cv_cross_acc(&K.foot[3 * l], un, wd[q]);
+        } else {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           F[q][a] += un[a];
           wd[q][a] += B[3 * a] * un[0] + B[3 * a + 1] * un[1] + B[3 * a + 2] * un[2];
         }
+        }
       }
     }
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
-      srbd_step_fw(P, gb, xc[q], F[q], wd[q], xn);
+      if constexpr (MD == MD_CONVEX) cv_step_fw(P, xc[q], F[q], wd[q], xn);
+      else srbd_step_fw(P, gb, xc[q], F[q], wd[q], xn);
 #pragma unroll
       for (int i = 0; i < 13; ++i) xc[q][i] = xn[i];
     }
   }
 #pragma unroll
-  for (int q = 0; q < NA; ++q) Jp[q] += al_state_cost(P, K.refp, N, xc[q]);
+  for (int q = 0; q < NA; ++q) Jp[q] += al_state_cost<MD>(P, K.refp, N, xc[q]);
   al.Jnp = Jp[0];
   al.vn = viol[0];
   al.stp = stp[0];
@@ -2088,7 +2126,7 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
 
 // ---- pass S: |grad_U L_A|_inf at (X, U) through the costate recursion  y_k = lx_k + Abar_k' y_{k+1},
 //      gu_l = R (u_l - uref_l) + Wr_l' (M_k' y_{k+1}) + sum_i max(lam_i + rho c_i, 0) a_i   (ref_stationarity of qmpc_ref.hip)
-template <int NL>
+template <int NL, int MD = MD_QUAT>
 QL_FN void pass_S(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, const LaneState& st, LaneAL& al) {
   const int N = P.N;
   const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
@@ -2098,7 +2136,7 @@ QL_FN void pass_S(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   double y[12];
   {
     double lxx[6];
-    cost_expansion<NL, MD_QUAT>(P, c, O, K, N, y, lxx);
+    cost_expansion<NL, MD>(P, c, O, K, N, y, lxx);
   }
   // state of the knot, quaternion of the next one, inputs and multipliers: one knot ahead, into the registers just consumed
   double xk[13], qn[4], uk[3 * NL], lk[6 * NL];
@@ -2132,19 +2170,25 @@ QL_FN void pass_S(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     load_head(kn);
 #pragma unroll
     for (int l = 0; l < NL; ++l) if ((order >> l) & 1u) load_leg(kn, l);
-    // the knot's angular acceleration (for the expansion)
+    // the knot's angular acceleration (for the expansion; ConvexMpc's model: the raw torque sum)
     double wd[3] = {K.wd0[0], K.wd0[1], K.wd0[2]};
+    double Wk[4] = {0, 0, 0, 0};
+    if constexpr (MD == MD_CONVEX) cv_winv_mid(P, x[2], x[8], Wk);
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       if (!((st.con >> l) & 1u)) continue;
+      if constexpr (MD == MD_CONVEX) cv_cross_acc(&K.foot[3 * l], &u[3 * l], wd);
+      else {
       double B[9];
       leg_bw0(P, &K.foot[3 * l], B);
 #pragma unroll
       for (int a = 0; a < 3; ++a) wd[a] += B[3 * a] * u[3 * l] + B[3 * a + 1] * u[3 * l + 1] + B[3 * a + 2] * u[3 * l + 2];
+      }
     }
     // dynamics expansion (pass B step 2)
     double A1[9], A3[9], Wt[9];
-    {
+    if constexpr (MD == MD_CONVEX) cv_expansion(P, x, wd, A1, A3, Wt);
+    else {
       double G0[12], Gm[12], Gn[12];
       quatG(&x[3], G0);
       double qm[4], wm[3];
@@ -2189,7 +2233,8 @@ QL_FN void pass_S(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     for (int l = 0; l < NL; ++l) {
       if (!((st.con >> l) & 1u)) continue;
       double B[9];
-      leg_bw0(P, &K.foot[3 * l], B);
+      if constexpr (MD == MD_CONVEX) cv_leg_bw0(Wk, &K.foot[3 * l], B);
+      else leg_bw0(P, &K.foot[3 * l], B);
       const double* ul = &u[3 * l];
       double gu[3];
 #pragma unroll
@@ -2210,6 +2255,16 @@ QL_FN void pass_S(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     // y_k = lx_k + Abar' y_{k+1}; the cost expansion of knot k from the state already in registers
     {
       double xr[13], lxf[13], lx[12];
+      if constexpr (MD == MD_CONVEX) {      // cost_expansion's convex branch on the state in registers
+        cv_xref_at(P, K.refp, k, xr);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          lx[a] = P.Q[3 + a] * (x[3 + a] - xr[3 + a]);
+          lx[3 + a] = P.Q[a] * (x[a] - xr[a]);
+          lx[6 + a] = P.Q[9 + a] * (x[9 + a] - xr[9 + a]);
+          lx[9 + a] = P.Q[6 + a] * (x[6 + a] - xr[6 + a]);
+        }
+      } else {
       xref_at(P, K.refp, k, xr);
 #pragma unroll
       for (int i = 0; i < 13; ++i) lxf[i] = P.Q[i] * (x[i] - xr[i]);
@@ -2225,6 +2280,7 @@ QL_FN void pass_S(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
         lx[6 + a] = lxf[7 + a];
         lx[9 + a] = lxf[10 + a];
         lx[3 + a] = G[a] * lxf[3] + G[3 + a] * lxf[4] + G[6 + a] * lxf[5] + G[9 + a] * lxf[6];
+      }
       }
       const double f0 = y[3], f1 = y[4], f2 = y[5];
 #pragma unroll
@@ -2276,32 +2332,32 @@ QL_FN bool al_accept_pair(const DevParams& P, LaneAL& al, int ls) {
   al.alpha *= 0.25;
   return false;
 }
-template <int NL>
+template <int NL, int MD = MD_QUAT>
 QL_FN void lane_solve_ref(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st) {
   LaneAL al;
   lane_setup_ref<NL>(P, c, O, st, al);
   st.it = 1;
-  pass_A<NL, false, MD_QUAT>(P, c, O, K, st, true, (FootPtr)K.foot);      // X <- rollout of U = u_ref
-  pass_M<NL, false>(P, c, O, K, st, al);
+  pass_A<NL, false, MD>(P, c, O, K, st, true, (FootPtr)K.foot);      // X <- rollout of U = u_ref
+  pass_M<NL, false, MD>(P, c, O, K, st, al);
   int iter = 0;
   st.status = QMPC_MAX_ITER;
   st.last_step = 0.0;
   for (iter = 1; iter <= P.iterations_max; ++iter) {
-    if (!pass_B<NL, false, MD_QUAT, true>(P, c, O, K, st, (FootPtr)K.foot, &al)) { st.status = QMPC_NOT_PD; --iter; break; }
+    if (!pass_B<NL, false, MD, true>(P, c, O, K, st, (FootPtr)K.foot, &al)) { st.status = QMPC_NOT_PD; --iter; break; }
     al.alpha = 1.0;
     bool accepted = false;
     for (int ls = 0; ls <= P.linesearch_max && !accepted; ls += 2) {
-      pass_C_AL<NL>(P, c, O, K, st, al, true);          // trials ls and ls + 1
+      pass_C_AL<NL, 2, MD>(P, c, O, K, st, al, true);          // trials ls and ls + 1
       accepted = al_accept_pair(P, al, ls);
     }
     if (!accepted) { st.status = QMPC_LINESEARCH_FAIL; --iter; break; }
-    pass_A_AL<NL>(P, c, O, K, st, al.sel);
+    pass_A_AL<NL, MD>(P, c, O, K, st, al.sel);
     st.last_step = al.stp;
     const double dJ = al.J - al.Jn;
     al.J = al.Jn; al.Jp = al.Jnp; al.viol = al.vn;
-    pass_S<NL>(P, c, O, K, st, al);
+    pass_S<NL, MD>(P, c, O, K, st, al);
     if (al.stat < P.tol_stat && al.viol < P.tol_feas) { st.status = QMPC_OK; break; }
-    if (al.stat < P.tol_stat || fabs(dJ) < P.tol_cost_int) pass_M<NL, true>(P, c, O, K, st, al);
+    if (al.stat < P.tol_stat || fabs(dJ) < P.tol_cost_int) pass_M<NL, true, MD>(P, c, O, K, st, al);
   }
   if (iter > P.iterations_max) iter = P.iterations_max;
   st.iters = iter;

@@ -22,7 +22,7 @@ static int solve_all(const DevParams& P, int batch, const double* rec, double* f
     const size_t ts = (size_t)P.N * 3 * NL;
     lane_setup<NL, MD>(P, c, O, rec + (size_t)b * LDim<NL>::REC, K, st, warm, u_init ? u_init + b * ts : nullptr);
     if (st.active && P.mode == QMPC_MODE_REFERENCE) {
-      if constexpr (MD == MD_QUAT) lane_solve_ref<NL>(P, c, O, K, st);
+      lane_solve_ref<NL, MD>(P, c, O, K, st);
     } else if (st.active)
       while (lane_iteration<NL, MD>(P, c, O, K, st, warm)) {}
     lane_finish<NL, MD>(P, c, O, K, st, forces + (size_t)b * 3 * NL, info ? info + b : nullptr, traj_u ? traj_u + b * ts : nullptr);

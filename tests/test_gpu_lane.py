@@ -166,12 +166,17 @@ def test_lane_kernel_reference_mode(pkg, lib, oracle, monkeypatch, N, B):
         s = pkg.Solver(p, B, device=0, lib=lib)
         f, info, tu, tx = s.solve(rec, want_traj=True) if v == 0 else (*s.solve(rec), None, None)
         if v == 4:
-            f2, info2 = s.solve(rec)
+            f2, info2, tu, tx = s.solve(rec, want_traj=True)        # trajectories come from the lane kernel as well
             assert np.array_equal(f, f2) and np.array_equal(info["iterations"], info2["iterations"])
+            assert pkg.KERNEL_FAMILY[s.query(pkg.QUERY_LAST_KERNEL)] == "lane" and np.array_equal(tu[:, 0, :], f2)
         s.close()
         out[v] = (f, info)
+        out[("traj", v)] = (tu, tx)
     fl, il = out[4]
     fw, iw = out[0]
+    dt = np.abs(out[("traj", 4)][1] - out[("traj", 0)][1]).reshape(B, -1).max(axis=1)
+    # (state trajectories of two truncated iterates: every knot of the horizon counts, N = 20 measured 83 % within 1e-6)
+    assert np.isfinite(dt).all() and (dt < (1e-6 if N <= 10 else 1e-5)).mean() >= 0.9
     fo, io = oracle.solve(p, rec, threads=8)
     assert np.array_equal(il["status"], io["status"]) and np.array_equal(il["iterations"], io["iterations"])
     assert np.array_equal(il["status"], iw["status"]) and np.array_equal(il["iterations"], iw["iterations"])
@@ -545,6 +550,63 @@ def test_lane_kernel_convex_model_matches_oracle(pkg, lib, oracle, monkeypatch, 
     assert np.abs(f[np.repeat(rec["contacts"] == 0, 3, axis=1)]).max() == 0.0
     print(f"convex N={N}: lane vs oracle {np.abs(f - fo).max():.2e} N, vs wave kernel {np.abs(f - res[0][0]).max():.2e} N, "
           f"iterations equal on {(di == 0).mean():.3f}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,B", [(20, 1024), (10, 2048)])
+def test_lane_kernel_convex_reference_mode(pkg, lib, oracle, monkeypatch, N, B):
+    """ConvexMpc's OWN solver mode (five AL-iLQR iterations, ConvexMpc.cpp:36-38) on the lane kernel
+    (qmpc_lane_ref_kernel<4, MD_CONVEX>): against the oracle on every instance -- identical status words and iteration
+    counts, forces of the truncated iterates within 1e-6 N on >= 95 % -- and against the wrench-form reference kernels; a
+    record without contacts and a rejected record keep their status words; trajectories come back; the library reports the
+    lane family for this mode at Monte-Carlo sizes."""
+    p = pkg.default_convex_params(N, pkg.MODE_REFERENCE, lib)
+    rec = pkg.random_go1_convex_states(B, config_id=12)
+    rec["contacts"][5] = 0.0
+    rec["euler"][9, 1] = np.nan
+    out = {}
+    for v in (4, 0):
+        _forced(monkeypatch, v)
+        monkeypatch.setenv("QMPC_LANE_REF_MIN", str(1 << 30))       # variant 0: the wave kernels at this size
+        s = pkg.Solver(p, B, device=0, lib=lib)
+        out[v] = s.convex_solve(rec)
+        if v == 4:
+            f2, info2 = s.convex_solve(rec)
+            assert np.array_equal(out[4][0], f2) and np.array_equal(out[4][1]["iterations"], info2["iterations"])
+            assert pkg.KERNEL_FAMILY[s.query(pkg.QUERY_LAST_KERNEL)] == "lane"
+            ft, it, tu, tx = s.convex_solve(rec, want_traj=True)        # trajectories from the lane kernel too
+            assert pkg.KERNEL_FAMILY[s.query(pkg.QUERY_LAST_KERNEL)] == "lane"
+            assert np.array_equal(ft, f2) and np.array_equal(tu[:, 0, :], f2) and np.isfinite(tx).all()
+            out["traj"] = (tu, tx)
+        else:
+            out["traj0"] = s.convex_solve(rec, want_traj=True)[2:]
+        s.close()
+    monkeypatch.delenv("QMPC_LANE_REF_MIN")
+    _forced(monkeypatch, 0)
+    s = pkg.Solver(p, 65536, device=0, lib=lib)
+    assert s.kernel_for_batch(65536) == "lane" and s.kernel_for_batch(1024) != "lane"
+    s.close()
+    fl, il = out[4]
+    fw, iw = out[0]
+    fo, io = oracle.convex_solve(oracle.default_convex_params(N, 1), rec, threads=8)
+    # state trajectories of the two kernel families: the lane kernel stores its feedback gains in single precision and a
+    # truncated iterate does not damp that -- later knots of the lane kernel's trajectory are 1e-5 N / 2e-6 (state units) from
+    # the oracle's (median, N = 20; the wrench-form wave kernels: 1e-12), the first-knot forces the controller applies 2e-7 N
+    dt = np.abs(out["traj"][1] - out["traj0"][1]).reshape(B, -1).max(axis=1)
+    assert (dt < 1e-4).mean() >= 0.95 and np.median(dt) < 1e-5
+    assert np.array_equal(il["status"], io["status"]) and np.array_equal(il["iterations"], io["iterations"])
+    assert np.array_equal(il["status"], iw["status"]) and np.array_equal(il["iterations"], iw["iterations"])
+    assert il["status"][5] == pkg.NO_CONTACT and il["status"][9] == pkg.NAN_INPUT
+    d = np.abs(fl - fo).max(axis=1)
+    dw = np.abs(fl - fw).max(axis=1)
+    print(f"lane kernel, ConvexMpc reference mode N={N} B={B}: vs oracle within 1e-6 N on {100 * (d < 1e-6).mean():.1f} % (median "
+          f"{np.median(d):.1e}, worst {d.max():.1e}); vs wave kernels {100 * (dw < 1e-6).mean():.1f} %; status counts "
+          f"{np.bincount(il['status'], minlength=6).tolist()}")
+    assert (d < 1e-6).mean() >= 0.95 and (dw < 1e-6).mean() >= 0.95
+    assert (il["iterations"] <= 5).all() and np.isfinite(fl).all()
+    assert (fl.reshape(-1, 4, 3)[rec["contacts"] == 0] == 0).all()
+    solved = io["status"] <= 1
+    assert np.abs(il["cost"][solved] - io["cost"][solved]).max() < 1e-6 * max(1.0, np.abs(io["cost"][solved]).max())
 
 
 def test_convex_closed_loop_with_the_lane_kernel(pkg, lib, monkeypatch):

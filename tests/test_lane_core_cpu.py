@@ -182,3 +182,23 @@ def test_lane_core_reference_mode_matches_oracle(pkg, oracle, lane, N, B, cfg):
     assert np.abs(f[np.repeat(rec["contacts"] == 0, 3, axis=1)]).max() == 0.0
     solved = io["status"] <= 1
     assert np.abs(info["cost"][solved] - io["cost"][solved]).max() < 1e-6 * max(1.0, np.abs(io["cost"][solved]).max())
+
+
+@pytest.mark.parametrize("N", [10, 20])
+def test_lane_core_convex_reference_mode_matches_oracle(pkg, oracle, lane, N):
+    """ConvexMpc's OWN solver mode (five AL-iLQR iterations, ConvexMpc.cpp:36-38) on the lane passes (lane_solve_ref<4, MD_CONVEX>):
+    status words and iteration counts identical to the oracle's; forces of the truncated iterates within 1e-6 N on >= 95 % of
+    the instances (single-precision feedback gains; measured below)."""
+    p = oracle.default_convex_params(N, 1)
+    rec = pkg.random_go1_convex_states(96, config_id=12)
+    rec["contacts"][4] = 0.0
+    f, info = lane(p, rec)
+    fo, io = oracle.convex_solve(p, rec, threads=8)
+    assert np.array_equal(info["status"], io["status"]) and info["status"][4] == pkg.NO_CONTACT
+    assert np.array_equal(info["iterations"], io["iterations"]) and (info["iterations"] <= p.iterations_max).all()
+    d = np.abs(f - fo).max(axis=1)
+    print(f"lane core, ConvexMpc reference mode N={N}: forces within 1e-6 N on {100 * (d < 1e-6).mean():.1f} %, median {np.median(d):.1e}, "
+          f"worst {d.max():.1e}; status counts {np.bincount(info['status'], minlength=6).tolist()}")
+    assert (d < 1e-6).mean() >= 0.95
+    solved = io["status"] <= 1
+    assert np.abs(info["cost"][solved] - io["cost"][solved]).max() < 1e-6 * max(1.0, np.abs(io["cost"][solved]).max())
