@@ -158,6 +158,9 @@ constexpr int kLaneRefMinBatch = 32768;      // N <= 12: wave kernels (four step
 constexpr int kLaneRefMinBatchLong = 22528;   // horizons beyond 12 (N=20: wave kernels 1.14-1.18 M; lane kernel 18.3 ms up to 32768 instances: 1.79 M there)
 // ConvexMpc's own mode (five iterations; tools/refmode_lane_bench.py --model convex): N=20 16384 instances wave 1.70 vs lane 1.68 M solves/s,
 // 24576: 1.72 vs 2.38 M, 65536: 1.74 vs 5.61 M; N=10 16384: 3.85 vs 3.37 M, 32768: 4.00 vs 6.00 M, 65536: 4.05 vs 10.5 M
+// 8-point model (N=16; its wave-per-instance reference kernels are the round-1 ones; tools/refmode_lane_bench.py --model biped8):
+// 8192 instances wave 0.43 vs lane 0.27 M solves/s, 16384: 0.44 vs 0.51 M, 32768: 0.45 vs 0.84 M, 65536: 0.46 vs 1.42 M
+constexpr int kLaneRefMinBatch8 = 14336;
 constexpr int kLaneRefMinBatchConvex = 20480;
 constexpr int kLaneRefMinBatchConvexLong = 17408;
 
@@ -400,7 +403,8 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     const char* lrm = std::getenv("QMPC_LANE_REF_MIN");
     h->lane_ref_min = lrm ? std::atoi(lrm)
                           : (params->model == QMPC_MODEL_CONVEX ? (N <= 12 ? kLaneRefMinBatchConvex : kLaneRefMinBatchConvexLong)
-                                                                : (N <= 12 ? kLaneRefMinBatch : kLaneRefMinBatchLong));
+                             : params->model == QMPC_MODEL_QUAT8 ? kLaneRefMinBatch8
+                                                                 : (N <= 12 ? kLaneRefMinBatch : kLaneRefMinBatchLong));
     const char* lc = std::getenv("QMPC_LANE_CAP");
     h->lane_cap = lc ? std::atoi(lc) : 15 + N / 10;
     const char* lcl = std::getenv("QMPC_LANE_CAP_LOOP");
@@ -642,10 +646,9 @@ static int ref_wform_variant(const qmpc_handle* h, int32_t batch) {
 }
 
 // Reference-mode batches of Monte-Carlo scale take the AL variant of the lane passes (qmpc_lane_core.h: lane_solve_ref;
-// qmpc_lane.hip: qmpc_lane_ref_kernel): QuatMpc's problem and ConvexMpc's (its own mode: five iterations)
+// qmpc_lane.hip: qmpc_lane_ref_kernel): QuatMpc's problem (four or eight contact points) and ConvexMpc's (its own mode: five iterations)
 static bool ref_lane_batch(const qmpc_handle* h, int32_t batch) {
-  return h->params.mode == QMPC_MODE_REFERENCE && (h->params.model == QMPC_MODEL_QUAT || h->params.model == QMPC_MODEL_CONVEX) &&
-         h->lane_pslot >= 0 && (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min));
+  return h->params.mode == QMPC_MODE_REFERENCE && h->lane_pslot >= 0 && (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min));
 }
 
 static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces,

@@ -566,9 +566,12 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
   prof = d_prof;
   (void)hipMemsetAsync(d_prof, 0, sizeof(long long) * 16 * 1024, s);
 #endif
-  if (P.mode == QMPC_MODE_REFERENCE) {      // the reference's own solver mode (four-point QuatMpc, ConvexMpc): qmpc_lane_ref_kernel
-    if (nl != 4 || u_init) return hipErrorInvalidValue;
-    if (convex)
+  if (P.mode == QMPC_MODE_REFERENCE) {      // the reference's own solver mode (QuatMpc with four or eight contact points, ConvexMpc): qmpc_lane_ref_kernel
+    if (u_init) return hipErrorInvalidValue;
+    if (nl == 8)
+      hipLaunchKernelGGL(qmpc_lane_ref_kernel<8>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm,
+                         traj_u, traj_x);
+    else if (convex)
       hipLaunchKernelGGL((qmpc_lane_ref_kernel<4, MD_CONVEX>), dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used,
                          lanes, perm, traj_u, traj_x);
     else

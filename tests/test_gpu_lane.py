@@ -552,6 +552,39 @@ def test_lane_kernel_convex_model_matches_oracle(pkg, lib, oracle, monkeypatch, 
           f"iterations equal on {(di == 0).mean():.3f}")
 
 
+def test_lane_kernel_8_point_reference_mode(pkg, lib, oracle, monkeypatch):
+    """The 8-contact-point model in the reference's solver mode on the lane kernel (qmpc_lane_ref_kernel<8>): status words and
+    iteration counts identical to the oracle's and to the wave-per-instance reference kernels', forces of the truncated
+    iterates within 1e-6 N on >= 95 % of the instances."""
+    N, B = 16, 768
+    p = pkg.default_biped8_params(N, pkg.MODE_REFERENCE, lib)
+    rec = pkg.random_biped8_states(B, config_id=5)
+    rec["contacts"][5] = 0.0
+    out = {}
+    for v in (4, 0):
+        _forced(monkeypatch, v)
+        monkeypatch.setenv("QMPC_LANE_REF_MIN", str(1 << 30))
+        s = pkg.Solver(p, B, device=0, lib=lib)
+        out[v] = s.solve8(rec)
+        if v == 4:
+            assert pkg.KERNEL_FAMILY[s.query(pkg.QUERY_LAST_KERNEL)] == "lane"
+        s.close()
+    fl, il = out[4]
+    fw, iw = out[0]
+    fo, io = oracle.solve8(oracle.default_biped8_params(N, 1), rec, threads=8)
+    assert np.array_equal(il["status"], io["status"]) and np.array_equal(il["iterations"], io["iterations"])
+    assert np.array_equal(il["status"], iw["status"]) and np.array_equal(il["iterations"], iw["iterations"])
+    assert il["status"][5] == pkg.NO_CONTACT
+    d = np.abs(fl - fo).max(axis=1)
+    dw = np.abs(fl - fw).max(axis=1)
+    print(f"lane kernel, 8-point model, reference mode N={N} B={B}: vs oracle within 1e-6 N on {100 * (d < 1e-6).mean():.1f} % (median "
+          f"{np.median(d):.1e}, worst {d.max():.1e}); vs wave kernels {100 * (dw < 1e-6).mean():.1f} %; status counts "
+          f"{np.bincount(il['status'], minlength=6).tolist()}")
+    assert (d < 1e-6).mean() >= 0.95 and (dw < 1e-6).mean() >= 0.9
+    assert (il["iterations"] <= 10).all() and np.isfinite(fl).all()
+    assert (fl.reshape(-1, 8, 3)[rec["contacts"] == 0] == 0).all()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,B", [(20, 1024), (10, 2048)])
 def test_lane_kernel_convex_reference_mode(pkg, lib, oracle, monkeypatch, N, B):
