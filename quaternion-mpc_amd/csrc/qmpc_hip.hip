@@ -1405,7 +1405,6 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   if (g && batch > 0 && (!d_joint_pos || (!d_cmd && !d_trace_cmd))) return QMPC_BAD_ARGUMENT;
   if (h->params.model != QMPC_MODEL_QUAT && h->params.model != QMPC_MODEL_CONVEX) return QMPC_BAD_ARGUMENT;
   const bool convex = h->params.model == QMPC_MODEL_CONVEX;
-  if (convex && h->params.mode != QMPC_MODE_CONVERGED) return QMPC_UNSUPPORTED;
   // the device tick of ConvexMpc carries the controller period as the literal 5 ms (velocity ramp, gait clock): a handle
   // with another knot spacing would silently part from the host class and the reference (ConvexMpc.cpp:9,62,208)
   if (convex && h->params.h != (float)(5.0 / 1000.0)) return QMPC_UNSUPPORTED;
@@ -1476,7 +1475,9 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   static const int fused_env = [] { const char* e = std::getenv("QMPC_LOOP_FUSED"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
   // measured, persistent vs per-tick: +25 % (256), +28 % (1024), +8 % (2048), -3 % (4096); with the warm start, whose
   // iteration counts spread more: +61 % (1024), +33 % (2048), +8 % (4096), -14 % (16384)
-  const bool fused = fused_env >= 0 ? fused_env == 1 : batch <= (warm ? 4096 : 2048);
+  // (ConvexMpc's own solver mode exists in the per-tick form only)
+  const bool fused = (convex && h->params.mode == QMPC_MODE_REFERENCE) ? false
+                                                                       : (fused_env >= 0 ? fused_env == 1 : batch <= (warm ? 4096 : 2048));
   if (fused) {
     const bool ref = h->params.mode == QMPC_MODE_REFERENCE;
     // the reference-mode kernels exist with everything in LDS (0) and with the gains in the workspace (1): launch_solve's rule

@@ -220,8 +220,8 @@ class ClosedLoopHostT : public ClosedLoopHostBase<State> {
 
  private:
   template <class M = Mpc>
-  typename std::enable_if<std::is_same<M, ConvexMpcHipT<State>>::value>::type make_mpc(const QmpcApi& api, int device, int, int) {
-    mpc = new Mpc(state, api, device);
+  typename std::enable_if<std::is_same<M, ConvexMpcHipT<State>>::value>::type make_mpc(const QmpcApi& api, int device, int mode, int) {
+    mpc = new Mpc(state, api, device, mode);
   }
   template <class M = Mpc>
   typename std::enable_if<!std::is_same<M, ConvexMpcHipT<State>>::value>::type make_mpc(const QmpcApi& api, int device, int mode,

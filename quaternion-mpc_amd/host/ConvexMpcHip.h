@@ -21,11 +21,13 @@ namespace legged {
 template <class State>
 class ConvexMpcHipT : public LeggedMpcHipT<State> {
  public:
-  ConvexMpcHipT(State& state, const QmpcApi& api, int device = 0) : api_(api) {   // ConvexMpc.cpp:5-39
+  // mode: QMPC_MODE_CONVERGED, or QMPC_MODE_REFERENCE = the reference's own solver settings (five AL-iLQR iterations,
+  // ConvexMpc.cpp:36-38)
+  ConvexMpcHipT(State& state, const QmpcApi& api, int device = 0, int mode = QMPC_MODE_CONVERGED) : api_(api) {   // ConvexMpc.cpp:5-39
     h = state.param.mpc_update_period;   // [ms]
     horizon = state.param.mpc_horizon;
     for (int i = 0; i < NUM_LEG; ++i) leg_FSM[i].reset_params(state.param.gait_freq, i);
-    api_.default_convex_params(&params_, horizon, QMPC_MODE_CONVERGED);
+    api_.default_convex_params(&params_, horizon, mode);
     params_.h = static_cast<float>(h / 1000.0);    // SetTimeStep(h / 1000.0), float in the callbacks
     params_.h_ref = h / 1000.0;
     // the model's mass and inertia are literals upstream (AltroUtils.cpp:239,270-272): the defaults
@@ -127,7 +129,10 @@ class ConvexMpcHipT : public LeggedMpcHipT<State> {
       std::fprintf(stderr, "ConvexMpcHip::grf_update: qmpc_convex_solve failed with status %d\n", (int)last_status_);
       return false;
     }
-    if (info.status != QMPC_OK && info.status != QMPC_MAX_ITER) {   // zero forces / broken iterate: keep the previous ones
+    // (in its own solver mode a failed line search leaves the last accepted iterate, which upstream applies: ConvexMpc.cpp:186-190
+    // reads the inputs whatever Solve() returned)
+    if (info.status != QMPC_OK && info.status != QMPC_MAX_ITER &&
+        !(params_.mode == QMPC_MODE_REFERENCE && info.status == QMPC_LINESEARCH_FAIL)) {   // zero forces / broken iterate: keep the previous ones
       std::fprintf(stderr, "ConvexMpcHip::grf_update: instance status %d, previous forces kept\n", (int)info.status);
       return false;
     }

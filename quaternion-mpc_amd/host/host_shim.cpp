@@ -185,12 +185,15 @@ void* qh_loop_create_opts(const char* lib_path, int horizon, int mode, int drop_
   return h;
 }
 // the sibling controller in the same loop: ConvexMpcHipT (gazebo_go1_convex_mpc.yaml values)
-void* qh_loop_create_convex(const char* lib_path, int horizon, const qmpc_loop_params* lp, const qmpc_loop_state* init) {
+void* qh_loop_create_convex_mode(const char* lib_path, int horizon, int mode, const qmpc_loop_params* lp, const qmpc_loop_state* init) {
   LoopHarness* h = new LoopHarness();
   legged::QmpcApi api;
   if (!(lib_path && lib_path[0]) || !bind_api(&h->base, lib_path, api)) { delete h; return nullptr; }
-  h->loop = new legged::ClosedLoopHostT<LeggedStateLite, legged::ConvexMpcHipT<LeggedStateLite>>(api, *lp, *init, horizon, 0);
+  h->loop = new legged::ClosedLoopHostT<LeggedStateLite, legged::ConvexMpcHipT<LeggedStateLite>>(api, *lp, *init, horizon, 0, mode);
   return h;
+}
+void* qh_loop_create_convex(const char* lib_path, int horizon, const qmpc_loop_params* lp, const qmpc_loop_state* init) {
+  return qh_loop_create_convex_mode(lib_path, horizon, QMPC_MODE_CONVERGED, lp, init);
 }
 void* qh_loop_create_mode(const char* lib_path, int horizon, int mode, const qmpc_loop_params* lp, const qmpc_loop_state* init) {
   return qh_loop_create_opts(lib_path, horizon, mode, 1, lp, init);
