@@ -647,8 +647,16 @@ static int ref_wform_variant(const qmpc_handle* h, int32_t batch) {
 
 // Reference-mode batches of Monte-Carlo scale take the AL variant of the lane passes (qmpc_lane_core.h: lane_solve_ref;
 // qmpc_lane.hip: qmpc_lane_ref_kernel): QuatMpc's problem (four or eight contact points) and ConvexMpc's (its own mode: five iterations)
-static bool ref_lane_batch(const qmpc_handle* h, int32_t batch) {
-  return h->params.mode == QMPC_MODE_REFERENCE && h->lane_pslot >= 0 && (h->variant == 4 || (h->variant == 0 && batch >= h->lane_ref_min));
+// In a closed loop the in-gait states need 1.8 iterations on average (plain solves of the benchmark states: 8.6) and the
+// lane kernel's fixed costs weigh more: N=10 32768 robots wave kernels 12.7 vs lane 9.2 M robot-ticks/s, 65536: 13.2 vs 16.4 M
+// (49152: 12.7 vs 10.1 M; ConvexMpc: 12.9 vs 8.9 M at 32768, 13.6 vs 16.6 M at 65536; N=20 65536 robots: 4.28 vs 4.99 M,
+// ConvexMpc 4.73 vs 8.37 M; tools/loop_bench.py --mode 1)
+constexpr int kLaneRefMinLoop = 61440;
+static bool ref_lane_batch(const qmpc_handle* h, int32_t batch, bool loop = false) {
+  if (h->params.mode != QMPC_MODE_REFERENCE || h->lane_pslot < 0) return false;
+  if (h->variant == 4) return true;
+  const int min_batch = (loop && h->lane_ref_min < kLaneRefMinLoop && !std::getenv("QMPC_LANE_REF_MIN")) ? kLaneRefMinLoop : h->lane_ref_min;
+  return h->variant == 0 && batch >= min_batch;
 }
 
 static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input* d_in, double* d_forces,
@@ -660,7 +668,7 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
     const bool ws = batch > 1024 || h->lds_bytes > 40 * 1024 || h->variant >= 2 || h->params.model == QMPC_MODEL_QUAT8;
     // Monte-Carlo scale (plain solves of QuatMpc's problem): one lane per instance, the AL variant of the lane passes
     // (qmpc_lane_core.h: lane_solve_ref; qmpc_lane.hip: qmpc_lane_ref_kernel)
-    if (handoff == 1 && ref_lane_batch(h, batch)) {      // plain solves only: the closed loop keeps the wave kernels in this mode
+    if (handoff != 0 && ref_lane_batch(h, batch, handoff == 2)) {      // plain solves and the ticks of a closed loop (its workspace and parameters are set up before the capture)
       const qmpc_status ls = launch_lane(h, batch, d_in, d_forces, d_info, s, nullptr, d_tu, 0, d_tx, 0);
       if (ls != QMPC_OK) return ls;
       h->last_kernel = QMPC_KERNEL_LANE;
@@ -1510,6 +1518,11 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
     static const bool order_env = [] { const char* e = std::getenv("QMPC_LANE_ORDER_PREV"); return !e || e[0] != '0'; }();
     h->lane_order_prev = order_env;
     if (handoff_cap(h, warm ? 3 : 2)) (void)ensure_handoff_buffers(h);      // not capturable either; only where the ticks will hand over
+  } else if (ref_lane_batch(h, batch, true)) {      // the reference's solver mode at Monte-Carlo scale: qmpc_lane_ref_kernel in every tick
+    const qmpc_status es = ensure_lane_buffers(h);
+    if (es != QMPC_OK) return es;
+    HIP_TRY(qmpc_lane_upload_params(h->lane_pslot, s, &h->dev, sizeof h->dev));
+    h->lane_params_resident = true;
   }
   if (warm) {                            // the cold first tick is not the tick the graph repeats
     const qmpc_status st = one_tick(true);

@@ -388,6 +388,45 @@ def test_closed_loop_with_the_lane_kernel(pkg, lib, monkeypatch):
     assert dp < 1e-7
 
 
+@pytest.mark.parametrize("model", ["quat", "convex"])
+def test_reference_mode_closed_loop_with_the_lane_kernel(pkg, lib, monkeypatch, model):
+    """The closed loop in the reference's OWN solver mode at Monte-Carlo scale: every tick's solve on qmpc_lane_ref_kernel
+    (workspace and parameters set up before the tick sequence is captured), against the same robots on the wave-per-instance
+    reference kernels.  Truncated iterates of two kernel families differ by up to 1e-5 N on a few instances (the lane kernel's
+    single-precision gains), which a closed loop carries along: gait state exact, positions to 1e-5 m over 46 ticks."""
+    lp = pkg.default_loop_params(lib)
+    rng = np.random.default_rng(23)
+    B = 3072
+    cmds = np.zeros((B, 7))
+    cmds[:, 0] = rng.uniform(-0.5, 0.5, B); cmds[:, 1] = rng.uniform(-0.2, 0.2, B); cmds[:, 2] = rng.uniform(0.26, 0.32, B)
+    cmds[:, 5] = rng.uniform(-0.5, 0.5, B); cmds[:, 6] = (rng.random(B) < 0.9).astype(float)
+    cmds[cmds[:, 6] == 0, :2] = 0.0
+    cmds[cmds[:, 6] == 0, 5] = 0.0
+    stand = cmds.copy(); stand[:, 6] = 0.0
+    st0 = pkg.loop_states(stand, lp, height=0.3, yaw=rng.uniform(-3, 3, B), lib=lib)
+    p = (pkg.default_convex_params if model == "convex" else pkg.default_params)(10, pkg.MODE_REFERENCE, lib)
+    out = {}
+    for v in (4, 0):
+        _forced(monkeypatch, v)
+        monkeypatch.setenv("QMPC_LANE_REF_MIN", str(1 << 30))       # variant 0: the wave kernels at this size
+        s = pkg.Solver(p, B, device=0, lib=lib)
+        st = s.loop_run(st0, 6, lp)
+        st["movement_mode"] = cmds[:, 6]
+        st = s.loop_run(st, 40, lp)
+        if v == 4:
+            assert pkg.KERNEL_FAMILY[s.query(pkg.QUERY_KERNEL_FOR_BATCH, B)] == "lane"
+        s.close()
+        out[v] = st
+        assert np.isfinite(st["pos_world"]).all() and (st["tick"] == 46).all()
+    assert np.array_equal(out[4]["contacts"], out[0]["contacts"])
+    same = (out[4]["status"] == out[0]["status"]) & (out[4]["iterations"] == out[0]["iterations"])
+    dp = np.abs(out[4]["pos_world"] - out[0]["pos_world"]).max(axis=1)
+    print(f"reference-mode closed loop ({model}), lane vs wave kernels, {B} robots, 46 ticks: position difference median {np.median(dp):.1e} m, "
+          f"worst {dp.max():.1e} m; last tick's status / iteration words equal on {100 * same.mean():.2f} %")
+    assert dp.max() < 1e-5 and same.mean() >= 0.99
+    assert (np.abs(out[4]["pos_world"][:, 2] - cmds[:, 2]) < 0.08).all()
+
+
 def test_closed_loop_at_the_automatic_switch_over(pkg, lib):
     """24576 robots: beyond the batch size from which qmpc_solve* picks the lane kernel by itself; the loop must do the same."""
     lp = pkg.default_loop_params(lib)
