@@ -478,8 +478,7 @@ void qmpc_loop_state_init(qmpc_loop_state* s, const qmpc_loop_params* lp, const 
                           double height, double yaw);
 /* `ticks` ticks for `batch` instances.  Host buffers in/out; trace_forces [ticks][batch][12] (body frame) and
  * trace_contacts [ticks][batch][4] may be NULL.  The handle is a QuatMpc handle (QMPC_MODEL_QUAT, either solver mode) or a
- * ConvexMpc handle (QMPC_MODEL_CONVEX, either solver mode; its own five-iteration mode in the per-tick kernel sequence at
- * every size): the latter runs ConvexMpc's tick -- its goal_update
+ * ConvexMpc handle (QMPC_MODEL_CONVEX, either solver mode): the latter runs ConvexMpc's tick -- its goal_update
  * (ConvexMpc.cpp:51-79; pos_d_world[0:2] hold joy.body_x / body_y, roll / pitch rate commands are ignored), its feedback
  * and record, R' u into the plant -- with host/ClosedLoopHost.h over ConvexMpcHipT as the parity reference.  The device
  * tick of ConvexMpc carries the controller period as the literal 5 ms (as the QuatMpc tick does upstream): a ConvexMpc

@@ -1483,9 +1483,10 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   static const int fused_env = [] { const char* e = std::getenv("QMPC_LOOP_FUSED"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
   // measured, persistent vs per-tick: +25 % (256), +28 % (1024), +8 % (2048), -3 % (4096); with the warm start, whose
   // iteration counts spread more: +61 % (1024), +33 % (2048), +8 % (4096), -14 % (16384)
-  // (ConvexMpc's own solver mode exists in the per-tick form only)
-  const bool fused = (convex && h->params.mode == QMPC_MODE_REFERENCE) ? false
-                                                                       : (fused_env >= 0 ? fused_env == 1 : batch <= (warm ? 4096 : 2048));
+  // (ConvexMpc's own solver mode: the persistent kernel exists on the wrench-form reference bodies only)
+  const bool fused = (convex && h->params.mode == QMPC_MODE_REFERENCE && !ref_wform_variant(h, batch))
+                         ? false
+                         : (fused_env >= 0 ? fused_env == 1 : batch <= (warm ? 4096 : 2048));
   if (fused) {
     const bool ref = h->params.mode == QMPC_MODE_REFERENCE;
     // the reference-mode kernels exist with everything in LDS (0) and with the gains in the workspace (1): launch_solve's rule

@@ -430,7 +430,7 @@ struct FusedJoint {          // the joint level closing every tick (JOINT instan
 // VAR: 0 / 1 / 2 as in qmpc_solve_kernel; 3 / 5: the wrench-form body (qmpc_wform_body.inc; QuatMpc's problem, converged
 // mode) with everything in LDS / with its gains in the workspace
 // REF: the reference's own solver mode (AL-iLQR, <= 10 iterations; one wave per SIMD like qmpc_ref_kernel, VAR 0 / 1)
-// CONVEX: the sibling controller's problem (ConvexModel; converged mode only)
+// CONVEX: the sibling controller's problem (ConvexModel; its own solver mode on the wrench-form bodies 3 / 5 only)
 template <int VAR, bool JOINT, bool REF, bool CONVEX = false>
 __global__ __launch_bounds__(64, (REF && VAR != 5) ? 1 : QMPC_SOLVE_WAVES(QuatModel, VAR)) void qmpc_loop_fused_kernel(
     DevParams P, qmpc_loop_params LP, qmpc_loop_state* __restrict__ st, qmpc_input* __restrict__ rec,
@@ -454,7 +454,15 @@ __global__ __launch_bounds__(64, (REF && VAR != 5) ? 1 : QMPC_SOLVE_WAVES(QuatMo
       else loop_front_one<OCC>(LP, st[b], rec[b]);
     }
     __syncthreads();                      // the record (global memory) is visible to the wave
-    if constexpr (REF && (VAR == 3 || VAR == 5)) {
+    if constexpr (REF && (VAR == 3 || VAR == 5) && CONVEX) {
+      [&]() {                             // ConvexMpc's own solver mode (five AL-iLQR iterations) on the wrench-form algebra
+        constexpr int WVAR = VAR;
+        const int wslot = b;
+#define QMPC_WMODEL WM_CONVEX
+#include "qmpc_wform_ref_body.inc"
+#undef QMPC_WMODEL
+      }();
+    } else if constexpr (REF && (VAR == 3 || VAR == 5)) {
       [&]() {                             // the reference's solver mode on the wrench-form algebra
         constexpr int WVAR = VAR;
         const int wslot = b;

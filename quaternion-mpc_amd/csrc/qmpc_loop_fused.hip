@@ -18,6 +18,8 @@ using namespace qmpc_fused_tu;
 // called from qmpc_hip.hip (declared there); hidden: not part of the C ABI
 template <bool JOINT, bool REF, bool CONVEX = false>
 static const void* fused_kernel(int var) {
+  if (REF && CONVEX) return var == 5 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<5, JOINT, true, true>)
+                                     : reinterpret_cast<const void*>(qmpc_loop_fused_kernel<3, JOINT, true, true>);
   if (REF && var == 3) return reinterpret_cast<const void*>(qmpc_loop_fused_kernel<3, JOINT, true, false>);
   if (REF && var == 5) return reinterpret_cast<const void*>(qmpc_loop_fused_kernel<5, JOINT, true, false>);
   if (REF) return var >= 1 ? reinterpret_cast<const void*>(qmpc_loop_fused_kernel<1, JOINT, true, false>)
@@ -31,9 +33,10 @@ static const void* fused_kernel(int var) {
 }
 
 __attribute__((visibility("hidden"))) hipError_t qmpc_fused_set_lds(int var, int bytes) {
-  const void* k[6] = {fused_kernel<false, false>(var), fused_kernel<true, false>(var), fused_kernel<false, true>(var),
-                      fused_kernel<true, true>(var),   fused_kernel<false, false, true>(var), fused_kernel<true, false, true>(var)};
-  for (int i = 0; i < 6; ++i) {
+  const void* k[8] = {fused_kernel<false, false>(var), fused_kernel<true, false>(var), fused_kernel<false, true>(var),
+                      fused_kernel<true, true>(var),   fused_kernel<false, false, true>(var), fused_kernel<true, false, true>(var),
+                      fused_kernel<false, true, true>(var), fused_kernel<true, true, true>(var)};
+  for (int i = 0; i < 8; ++i) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
   }
@@ -73,8 +76,15 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_fused_launch(int var, int 
 #define QMPC_LAUNCH_FUSED4(V, J) \
   hipLaunchKernelGGL((qmpc_loop_fused_kernel<V, J, false, true>), dim3((unsigned)batch), dim3(kWave), lds, s, P, LP, st, rec, \
                      forces, info, trace_f, trace_c, ticks, batch, gws, JL)
-  if (convex) {
-    if (reference_mode) return hipErrorInvalidValue;
+  if (convex && reference_mode) {       // ConvexMpc's own solver mode: the wrench-form reference bodies only
+    if (var != 3 && var != 5) return hipErrorInvalidValue;
+#define QMPC_LAUNCH_FUSED5(V, J) \
+  hipLaunchKernelGGL((qmpc_loop_fused_kernel<V, J, true, true>), dim3((unsigned)batch), dim3(kWave), lds, s, P, LP, st, rec, \
+                     forces, info, trace_f, trace_c, ticks, batch, gws, JL)
+    if (var == 3) { if (geom) QMPC_LAUNCH_FUSED5(3, true); else QMPC_LAUNCH_FUSED5(3, false); }
+    else { if (geom) QMPC_LAUNCH_FUSED5(5, true); else QMPC_LAUNCH_FUSED5(5, false); }
+#undef QMPC_LAUNCH_FUSED5
+  } else if (convex) {
     if (var == 3) QMPC_LAUNCH_FUSED_CJ(3);
     else if (var == 5) QMPC_LAUNCH_FUSED_CJ(5);
     else if (var == 6) QMPC_LAUNCH_FUSED_CJ(6);

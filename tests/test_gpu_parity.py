@@ -1239,7 +1239,7 @@ def test_convex_mpc_closed_loop_matches_host_classes(pkg, lib, mode):
     feedback it reads (torso_euler, torso_ang_vel_world, foot_pos_abs_com), the shared gait FSM / Raibert targets, the
     solve on a ConvexMpc handle and R' u into the plant -- against ConvexMpcHipT in host/ClosedLoopHost.h, tick for tick.
     Mode 1: the reference's own solver settings (ConvexMpc.cpp:36-38; the last iterate is applied whatever its status) --
-    what a robot running the reference's ConvexMpc does; the per-tick kernel sequence only."""
+    what a robot running the reference's ConvexMpc does."""
     import __graft_entry__ as g
 
     host = C.CDLL(str(g.build_host()))
@@ -1491,10 +1491,11 @@ def test_reference_mode_closed_loop_matches_host_classes(pkg, lib):
                          [(96, 90, 10, 0, "quat"), (3000, 12, 10, 0, "quat"), (40, 60, 20, 0, "quat"), (64, 90, 10, 1, "quat"),
                           (64, 90, 10, 0, "convex"), (96, 90, 10, 0, "quat warm"), (2500, 12, 10, 0, "quat warm"),
                           (64, 90, 10, 0, "convex warm"), (1500, 8, 20, 0, "quat"), (1500, 8, 20, 0, "quat warm"),
-                          (1200, 8, 20, 0, "convex")],
+                          (1200, 8, 20, 0, "convex"), (64, 60, 10, 1, "convex"), (600, 8, 20, 1, "convex")],
                          ids=["96 robots N=10", "3000 robots (several rounds per SIMD)", "N=20", "reference mode", "ConvexMpc",
                               "warm start", "warm start, 2500 robots", "ConvexMpc, warm start", "N=20, 1500 robots (WVAR 6)",
-                              "N=20, 1500 robots, warm start (WVAR 6)", "ConvexMpc N=20, 1200 robots (WVAR 6)"])
+                              "N=20, 1500 robots, warm start (WVAR 6)", "ConvexMpc N=20, 1200 robots (WVAR 6)",
+                              "ConvexMpc, its own solver mode", "ConvexMpc, its own solver mode, N=20, 600 robots (workspace form)"])
 def test_persistent_loop_kernel_equals_the_per_tick_sequence(robots, ticks, horizon, mode, model):
     """qmpc_loop_run* has two launch forms: three kernels per tick (graph replay) and ONE persistent kernel in which a
     wave owns a robot for all ticks (the default up to 2048 robots: the per-tick tails of different robots average out,
