@@ -544,12 +544,15 @@ def main():
             # config 5 (8-point model, N=16, 65536 instances over 8 GPUs), ConvexMpc at its own configuration, and QuatMpc at
             # the reference's horizon (N=20) at a mid-size batch and for the single robot; never `value`
             out["other_workloads"] = []
-            for (mdl, Nl, Bl, cfg, what) in (
+            for (mdl, Nl, Bl, cfg, what, *md) in (
                     ("biped8", 16, 8192, 5, "per-GPU share of BASELINE config 5 (8 contact points, 65536 instances over 8 GPUs)"),
                     ("convex", 20, 1024, 13, "ConvexMpc at its YAML horizon (gazebo_go1_convex_mpc.yaml), 1024 instances"),
                     ("quat", 20, 8192, 3, "QuatMpc at the reference's own horizon (gazebo_go1_quat_mpc.yaml:36-37), mid-size batch"),
-                    ("quat", 20, 1, 3, "QuatMpc, N=20, ONE robot (device-resident launch)")):
-                pm_ = {"biped8": pkg.default_biped8_params, "convex": pkg.default_convex_params, "quat": pkg.default_params}[mdl](Nl, pkg.MODE_CONVERGED, lib)
+                    ("quat", 20, 1, 3, "QuatMpc, N=20, ONE robot (device-resident launch)"),
+                    ("convex", 20, 65536, 13, "ConvexMpc in its OWN solver mode (five AL-iLQR iterations, ConvexMpc.cpp:36-38), Monte-Carlo size", 1),
+                    ("biped8", 16, 65536, 5, "8-contact-point model in the reference's solver mode (<= 10 AL-iLQR iterations), Monte-Carlo size", 1)):
+                mode_ = pkg.MODE_REFERENCE if md and md[0] else pkg.MODE_CONVERGED
+                pm_ = {"biped8": pkg.default_biped8_params, "convex": pkg.default_convex_params, "quat": pkg.default_params}[mdl](Nl, mode_, lib)
                 kl = max(3, min(10, args.steps))
                 lg = timed_leg(Bl, cfg, kl, 2, prm=pm_, model=mdl)
                 fam = lg["solver"].kernel_for_batch(Bl)
@@ -557,6 +560,7 @@ def main():
                 out["other_workloads"].append({
                     "workload": f"{mdl}, Batch={Bl}, N={Nl}, seed 0x5EED0000+{cfg}: {what}", "value": Bl * kl / lg["elapsed"], "unit": "solves/s",
                     "ms_per_step": 1e3 * lg["elapsed"] / kl, "kernel_ms": lg["kernel_ms"], "kernel_family": fam,
+                    "solver_mode": "reference" if mode_ == pkg.MODE_REFERENCE else "converged",
                     "converged": int((lg["info"]["status"] == 0).sum()), "mean_iterations": float(lg["info"]["iterations"].mean())})
                 del lg
         if world == 1 and not args.no_in_flight:

@@ -154,8 +154,10 @@ constexpr int kLaneCapLoopBase = 11;
 // residuals): 32768 robots 8.45 -> 9.97 M robot-ticks/s, 65536: 14.5 -> 15.9 M; N=20: 3.44 -> 4.45 M, 5.87 -> 6.86 M (caps 5 .. 10
 // scanned; QMPC_LANE_CAP_WARM=0 switches it off)
 constexpr int kLaneCapWarm = 8;
-constexpr int kLaneRefMinBatch = 32768;      // N <= 12: wave kernels (four step lengths per rollout) 3.29 M at 32768, lane kernel (two per sweep) 3.35 M
-constexpr int kLaneRefMinBatchLong = 22528;   // horizons beyond 12 (N=20: wave kernels 1.14-1.18 M; lane kernel 18.3 ms up to 32768 instances: 1.79 M there)
+// (round 5, against the wrench-form reference kernels: N=10 24576 instances wave 2.98 vs lane 2.77 M solves/s, 32768: 3.04 vs 3.39 M,
+// 40960: 3.07 vs 4.11 M; N=16 20480: 1.68 vs 1.52 M, 28672: 1.69 vs 1.99 M; N=20 20480: 1.28 vs 1.24 M, 24576: 1.29 vs 1.45 M)
+constexpr int kLaneRefMinBatch = 28672;       // N <= 12
+constexpr int kLaneRefMinBatchLong = 22528;   // horizons beyond 12
 // ConvexMpc's own mode (five iterations; tools/refmode_lane_bench.py --model convex): N=20 16384 instances wave 1.70 vs lane 1.68 M solves/s,
 // 24576: 1.72 vs 2.38 M, 65536: 1.74 vs 5.61 M; N=10 16384: 3.85 vs 3.37 M, 32768: 4.00 vs 6.00 M, 65536: 4.05 vs 10.5 M
 // 8-point model (N=16; its wave-per-instance reference kernels are the round-1 ones; tools/refmode_lane_bench.py --model biped8):
