@@ -45,6 +45,9 @@ hipError_t qmpc_wform_launch_convex(int var, int batch, size_t lds, hipStream_t 
 hipError_t qmpc_wform_launch8(int var, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size, const void* in,
                               double* forces, qmpc_info* info, double* traj_u, double* traj_x, double* gws);
 hipError_t qmpc_wform_set_lds(int bytes);
+size_t qmpc_wform_ref_lds_bytes(int N, int kd_global, int nl, int convex);
+hipError_t qmpc_wform_ref_launch8(int var, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size, const void* in,
+                                  double* forces, qmpc_info* info, double* traj_u, double* traj_x, double* gws);
 hipError_t qmpc_wform_launch(int var, int prof, int batch, size_t lds, hipStream_t s, const void* dev_params, size_t dev_params_size,
                              const qmpc_input* in, double* forces, qmpc_info* info, double* traj_u, double* traj_x,
                              long long* prof_out, double* gws);
@@ -87,6 +90,7 @@ struct qmpc_handle {
   size_t lds_bytes_w;     // the wrench-form kernel (qmpc_wform.hip), everything in LDS
   size_t lds_bytes_ws;    // ... and with its slack arrays there too (WVAR 6; long horizons)
   size_t lds_bytes_wg;    // ... with its gains / per-point records / per-knot blocks in the global workspace
+  size_t lds_bytes_wr, lds_bytes_wgr;   // the reference-mode body's layouts (they differ from the two above for eight contact points only)
   int wform;              // 1: batches that keep everything in LDS take the wrench-form kernel (env QMPC_WFORM, default 1)
   int* d_loop_row;        // trace row counter of the closed loop (qmpc_loop_run*)
   double* d_leg;          // staging of the host-buffer leg calls (grown on demand, freed with the handle)
@@ -160,9 +164,10 @@ constexpr int kLaneRefMinBatch = 28672;       // N <= 12
 constexpr int kLaneRefMinBatchLong = 22528;   // horizons beyond 12
 // ConvexMpc's own mode (five iterations; tools/refmode_lane_bench.py --model convex): N=20 16384 instances wave 1.70 vs lane 1.68 M solves/s,
 // 24576: 1.72 vs 2.38 M, 65536: 1.74 vs 5.61 M; N=10 16384: 3.85 vs 3.37 M, 32768: 4.00 vs 6.00 M, 65536: 4.05 vs 10.5 M
-// 8-point model (N=16; its wave-per-instance reference kernels are the round-1 ones; tools/refmode_lane_bench.py --model biped8):
-// 8192 instances wave 0.43 vs lane 0.27 M solves/s, 16384: 0.44 vs 0.51 M, 32768: 0.45 vs 0.84 M, 65536: 0.46 vs 1.42 M
-constexpr int kLaneRefMinBatch8 = 14336;
+// 8-point model (N=16; tools/refmode_lane_bench.py --model biped8), against its wrench-form reference kernels (qmpc_ref8_w_kernel):
+// 16384 instances wave 1.12 vs lane 0.50 M solves/s, 32768: 1.14 vs 0.85 M, 49152: 1.16 vs 1.18 M, 65536: 1.16 vs 1.45 M
+// (the round-1 dense reference kernels it ran on before: 0.43 M at 8192, 0.46 M at 65536)
+constexpr int kLaneRefMinBatch8 = 49152;
 constexpr int kLaneRefMinBatchConvex = 20480;
 constexpr int kLaneRefMinBatchConvexLong = 17408;
 
@@ -388,6 +393,8 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
     h->wform = wf ? std::atoi(wf) : 1;
     h->lds_bytes_w = qmpc_wform_lds_bytes(N, 0, nl, params->model == QMPC_MODEL_CONVEX);
     h->lds_bytes_wg = qmpc_wform_lds_bytes(N, 1, nl, params->model == QMPC_MODEL_CONVEX);
+    h->lds_bytes_wr = qmpc_wform_ref_lds_bytes(N, 0, nl, params->model == QMPC_MODEL_CONVEX);
+    h->lds_bytes_wgr = qmpc_wform_ref_lds_bytes(N, 1, nl, params->model == QMPC_MODEL_CONVEX);
     h->lds_bytes_ws = qmpc_wform_lds_bytes(N, 2, nl, params->model == QMPC_MODEL_CONVEX);
     const char* lm = std::getenv("QMPC_LANE_MIN");
     h->lane_min_batch = lm ? std::atoi(lm) : (params->model == QMPC_MODEL_QUAT ? (N <= 12 ? kLaneMinBatch : (N <= 22 ? kLaneMinBatchLong : kLaneMinBatchVeryLong))
@@ -636,9 +643,12 @@ static int handoff_cap(const qmpc_handle* h, int kind) {      // kind 1: plain c
 // worst 8.7e-7).  QMPC_REF_WFORM_MAXN overrides the limit (experiments).
 static int ref_wform_variant(const qmpc_handle* h, int32_t batch) {
   if (!h->wform || h->params.mode != QMPC_MODE_REFERENCE) return 0;
-  if (h->params.model != QMPC_MODEL_QUAT && h->params.model != QMPC_MODEL_CONVEX) return 0;      // (the 8-point model: round-1 kernels)
   static const int maxn = std::getenv("QMPC_REF_WFORM_MAXN") ? std::atoi(std::getenv("QMPC_REF_WFORM_MAXN")) : QMPC_MAX_HORIZON;
   if (h->params.horizon > maxn || h->params.horizon < 2) return 0;      // (one knot: the input weights would not fit behind the trial states)
+  if (h->params.model == QMPC_MODEL_QUAT8) {      // eight points (round 5): one wave per SIMD in either form; everything in LDS while
+    if (h->variant == 0 && h->lds_bytes_wr <= 160 * 1024 && batch <= 256 * (int)((160 * 1024) / h->lds_bytes_wr)) return 3;   // every instance finds a CU
+    return h->lds_bytes_wgr <= 160 * 1024 ? 5 : 0;
+  }
   if (h->variant < 2) {
     if (batch <= 1024 && h->lds_bytes_w <= 40 * 1024) return 3;
     // longer horizons: everything in LDS while every instance finds a CU with room (wform_variant's rule)
@@ -682,7 +692,10 @@ static qmpc_status launch_solve(qmpc_handle* h, int32_t batch, const qmpc_input*
     }
     if (const int wv = ref_wform_variant(h, batch)) {      // QuatMpc's problem: on the wrench-form algebra (qmpc_wform_ref_body.inc)
       h->last_kernel = wv >= 5 ? QMPC_KERNEL_WFORM_WS : QMPC_KERNEL_WFORM_LDS;
-      if (h->params.model == QMPC_MODEL_CONVEX)
+      if (h->params.model == QMPC_MODEL_QUAT8)
+        HIP_TRY(qmpc_wform_ref_launch8(wv, (int)batch, wv == 5 ? h->lds_bytes_wgr : h->lds_bytes_wr, s, &h->dev, sizeof h->dev, d_in, d_forces,
+                                       d_info, d_tu, d_tx, variant_gws(h, wv)));
+      else if (h->params.model == QMPC_MODEL_CONVEX)
         HIP_TRY(qmpc_wform_ref_launch_convex(wv, (int)batch, variant_lds(h, wv), s, &h->dev, sizeof h->dev, d_in, d_forces, d_info, d_tu,
                                              d_tx, variant_gws(h, wv)));
       else

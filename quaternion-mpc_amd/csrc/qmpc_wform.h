@@ -55,7 +55,8 @@ __host__ __device__ inline size_t wform_slice(int N, bool sl_global = false) {
   return ((size_t)N * (13 * 12 + 21 * NL + kGK + (sl_global ? 18 * NL : 0)) + 1 + 1) & ~(size_t)1;
 }
 template <int NL = 4>
-__host__ __device__ inline Layout make_layout_w(int N, LayoutW* W, bool kd_global = false, bool sl_global = false, bool cv = false) {
+__host__ __device__ inline Layout make_layout_w(int N, LayoutW* W, bool kd_global = false, bool sl_global = false, bool cv = false,
+                                                bool full = false) {      // full: the direction arrays even for eight points (reference mode)
   Layout L;
   int o = 0;
   auto take = [&](int n) { int r = o; o += n; return r; };
@@ -68,7 +69,7 @@ __host__ __device__ inline Layout make_layout_w(int N, LayoutW* W, bool kd_globa
   L.U = take(N * nu);
   L.Xc = take((N + 1) * 13);
   L.dU = take(N * nu);
-  const bool lean = (NL == 8) || sl_global;
+  const bool lean = ((NL == 8) && !full) || sl_global;
   if (sl_global) {      // offsets relative to the slack block of the workspace slice
     L.S = 0; L.LAM = N * nc; L.RC = 2 * N * nc;
   } else {
@@ -1022,15 +1023,16 @@ __device__ inline void rollout_closed_w(const DevParams& P, const Layout& L, con
 // ---- expected decrease of a full step, sum_k d_k' Qu_k (the Armijo test of the reference mode's line search): one lane
 // per (knot, contact point); d_l = -D~_l^-1 (V_l' xz + gq_l) is the feed-forward part of the point's step, Qu_l = V_l' y0 + gq_l
 // its gradient (y0 from the backward pass, xz = column 12 of [Xz | xz]) ---------------------------------------------------
-template <int MD = WM_QUAT>
+template <int MD = WM_QUAT, int NL = 4>
 __device__ inline double expected_decrease_w(const DevParams& P, const Layout& L, double* sm, const double* KD,
                                              const double* ROT, const double* y0, int lane) {
-  typedef Dim<4> D;
+  typedef Dim<NL> D;
+  constexpr int LSH = (NL == 8) ? 3 : 2;
   const int N = P.N;
   const double* cst = sm + L.cst;
   double part = 0.0;
-  for (int q = lane; q < 4 * N; q += kWave) {
-    const int k = q >> 2, l = q & 3;
+  for (int q = lane; q < NL * N; q += kWave) {
+    const int k = q >> LSH, l = q & (NL - 1);
     if (cst[D::C_CON + l] == 0.0) continue;
     const double* rec = ROT + D::ROT * k + 21 * l;
     double T[9], xz[6], yk[6];
@@ -1280,11 +1282,11 @@ __device__ inline void apply_w(const DevParams& P, const Layout& L, double* sl, 
 __device__ __forceinline__ int trial_states_slot(const Layout& L, int g) {      // knots 1..N of group g's trajectory
   return g == 0 ? L.Xc + 13 : (g == 1 ? L.S : (g == 2 ? L.DLAM : L.XT));
 }
-template <bool PF, int MD = WM_QUAT>
+template <bool PF, int MD = WM_QUAT, int NL = 4>
 __device__ inline double rollout_trials_w(const DevParams& P, const Layout& L, const LayoutW& LW, double* sm,
                                           const double* KD, double* ZG, double alpha_g, int lane) {
-  typedef typename std::conditional<MD == WM_CONVEX, ConvexModel, QuatModel>::type TM;
-  typedef Dim<4> D;
+  typedef typename std::conditional<MD == WM_CONVEX, ConvexModel, typename std::conditional<NL == 8, Quat8Model, QuatModel>::type>::type TM;
+  typedef Dim<NL> D;
   const int N = P.N;
   const double* cst = sm + L.cst;
   double gb[3], wd0[3];
@@ -1366,19 +1368,20 @@ __device__ inline double rollout_trials_w(const DevParams& P, const Layout& L, c
 // the group's costates, u = U + du, then the input cost, the augmented-Lagrangian terms max(lambda + rho c, 0)^2 - lambda^2
 // and the violation max(c, 0) of the point's cone rows (the arithmetic of ref_merit in qmpc_ref.hip).  Per-lane partial sums:
 // Ju = input cost, mer = Ju + (augmented-Lagrangian terms) / (2 rho), vi = violation.
-template <int MD = WM_QUAT>
+template <int MD = WM_QUAT, int NL = 4>
 __device__ inline void trial_inputs_w(const DevParams& P, const Layout& L, const double* sm, const double* sl,
                                       const double* ROT, const double* ZG, const double* Rl, double alpha, double rho,
                                       int lane, double Ju[4], double mer[4], double vi[4]) {
-  typedef Dim<4> D;
+  typedef Dim<NL> D;
+  constexpr int LSH = (NL == 8) ? 3 : 2;
   const int N = P.N;
   const double* cst = sm + L.cst;
   const double* cr = cst + D::C_CR;
   double al[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) { Ju[g] = 0.0; al[g] = 0.0; vi[g] = 0.0; }
-  for (int q = lane; q < 4 * N; q += kWave) {
-    const int k = q >> 2, l = q & 3;
+  for (int q = lane; q < NL * N; q += kWave) {
+    const int k = q >> LSH, l = q & (NL - 1);
     const bool stance = cst[D::C_CON + l] != 0.0;
     const double* rec = ROT + D::ROT * k + 21 * l;
     const double* bw = sm + L.bw0 + 3 * l;
@@ -1453,15 +1456,16 @@ __device__ inline void trial_inputs_w(const DevParams& P, const Layout& L, const
 #ifndef QMPC_STAT_ATTR
 #define QMPC_STAT_ATTR inline
 #endif
-template <int MD = WM_QUAT>
+template <int MD = WM_QUAT, int NL = 4>
 __device__ QMPC_STAT_ATTR double stationarity_w(const DevParams& P, const Layout& L, double* sm, const double* sl, double* my,
                                         const double* Rl, double rho, unsigned conmask, int lane) {
-  typedef Dim<4> D;
+  typedef Dim<NL> D;
+  constexpr int LSH = (NL == 8) ? 3 : 2;
   const int N = P.N;
   const double* cst = sm + L.cst;
   const double* cr = cst + D::C_CR;
   const int c = lane & 15, tp = c / 3, j = c - 3 * tp;
-  const int zero = L.cst + kZeroSlots;
+  const int zero = L.cst + kZeroSlotsT<NL>();
   // per-lane operand addresses at knot 0 and their stride per knot
   const bool rot = (tp == 1 || tp == 3) && c < 12;
   const int ia = rot ? L.AB + (tp == 1 ? 0 : 9) + j : zero, sa = rot ? kAB : 0;          // A1(:, j) / A3(:, j): + 3 r
@@ -1487,8 +1491,8 @@ __device__ QMPC_STAT_ATTR double stationarity_w(const DevParams& P, const Layout
   }
   QSYNC();
   double g = 0.0;
-  for (int q = lane; q < 4 * N; q += kWave) {
-    const int k = q >> 2, l = q & 3;
+  for (int q = lane; q < NL * N; q += kWave) {
+    const int k = q >> LSH, l = q & (NL - 1);
     if (!(conmask & (1u << l))) continue;
     double m[6];
 #pragma unroll

@@ -173,6 +173,22 @@ __global__ __launch_bounds__(64, OCC) void qmpc_ref_cw_kernel(
 #undef QMPC_WMODEL
 }
 
+// ... and of the eight-contact-point model (BASELINE config 5): the per-point phases walk 8 N (knot, point) pairs, the layout keeps
+// the direction slots (they hold y0, the trials' costates and trial states in this mode)
+template <int WVAR, int OCC = 1>
+__global__ __launch_bounds__(64, OCC) void qmpc_ref8_w_kernel(
+    DevParams P, const qmpc_input* __restrict__ in_, double* __restrict__ forces, qmpc_info* __restrict__ info,
+    double* __restrict__ traj_u, double* __restrict__ traj_x, int batch, double* __restrict__ gws) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int b = blockIdx.x;
+  if (b >= batch) return;
+  const int wslot = b;
+  const int lane = threadIdx.x;
+#define QMPC_WNL 8
+#include "qmpc_wform_ref_body.inc"
+#undef QMPC_WNL
+}
+
 }  // namespace qmpc
 #undef qmpc
 
@@ -187,9 +203,16 @@ __attribute__((visibility("hidden"))) size_t qmpc_wform_lds_bytes(int N, int kd_
   return (size_t)(nl == 8 ? make_layout_w<8>(N, &LW, kd_global != 0, kd_global == 2)
                           : make_layout_w<4>(N, &LW, kd_global != 0, kd_global == 2, convex != 0)).total * sizeof(double);
 }
+// the reference-mode body's layout (full: the direction slots exist for eight points too); kd_global: 0 / 1
+__attribute__((visibility("hidden"))) size_t qmpc_wform_ref_lds_bytes(int N, int kd_global, int nl, int convex) {
+  LayoutW LW;
+  return (size_t)(nl == 8 ? make_layout_w<8>(N, &LW, kd_global != 0, false, false, true)
+                          : make_layout_w<4>(N, &LW, kd_global != 0, false, convex != 0, true)).total * sizeof(double);
+}
 __attribute__((visibility("hidden"))) size_t qmpc_wform_slice_doubles(int N, int nl) { return nl == 8 ? wform_slice<8>(N, true) : wform_slice<4>(N, true); }
 __attribute__((visibility("hidden"))) hipError_t qmpc_wform_set_lds(int bytes) {
-  const void* k[19] = {reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 3>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 3>),
+  const void* k[21] = {reinterpret_cast<const void*>(qmpc_ref8_w_kernel<3, 1>), reinterpret_cast<const void*>(qmpc_ref8_w_kernel<5, 1>),
+                      reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 3>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 3>),
                       reinterpret_cast<const void*>(qmpc_solve_w_kernel<false, 5>), reinterpret_cast<const void*>(qmpc_solve_w_kernel<true, 5>),
                       reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<3>), reinterpret_cast<const void*>(qmpc_solve_w_list_kernel<5>),
                       reinterpret_cast<const void*>(qmpc_ref_w_kernel<3>), reinterpret_cast<const void*>(qmpc_ref_w_kernel<5>),
@@ -200,7 +223,7 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_wform_set_lds(int bytes) {
                       reinterpret_cast<const void*>(qmpc_solve8_w_kernel<6>),
                       reinterpret_cast<const void*>(qmpc_ref_cw_kernel<3, 1>), reinterpret_cast<const void*>(qmpc_ref_cw_kernel<5, 1>),
                       reinterpret_cast<const void*>(qmpc_ref_cw_kernel<5, 2>)};
-  for (int i = 0; i < 19; ++i) {
+  for (int i = 0; i < 21; ++i) {
     const hipError_t e = hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
   }
@@ -291,6 +314,20 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_wform_ref_launch(int var, 
     hipLaunchKernelGGL(qmpc_ref_w_kernel<5>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in, forces, info, traj_u, traj_x, batch, gws);
   else
     hipLaunchKernelGGL(qmpc_ref_w_kernel<3>, dim3((unsigned)batch), dim3(kWave), lds, s, P, in, forces, info, traj_u, traj_x, batch, gws);
+  return hipGetLastError();
+}
+// reference mode of the eight-point model: everything in LDS (3; one instance per CU) or gains / records / blocks in the workspace (5)
+__attribute__((visibility("hidden"))) hipError_t qmpc_wform_ref_launch8(int var, int batch, size_t lds, hipStream_t s, const void* dev_params,
+                                                                        size_t dev_params_size, const void* in, double* forces,
+                                                                        qmpc_info* info, double* traj_u, double* traj_x, double* gws) {
+  if (dev_params_size != sizeof(DevParams)) return hipErrorInvalidValue;
+  DevParams P;
+  std::memcpy(&P, dev_params, sizeof P);
+  const qmpc_input* in_ = static_cast<const qmpc_input*>(in);
+  if (var == 5)
+    hipLaunchKernelGGL((qmpc_ref8_w_kernel<5, 1>), dim3((unsigned)batch), dim3(kWave), lds, s, P, in_, forces, info, traj_u, traj_x, batch, gws);
+  else
+    hipLaunchKernelGGL((qmpc_ref8_w_kernel<3, 1>), dim3((unsigned)batch), dim3(kWave), lds, s, P, in_, forces, info, traj_u, traj_x, batch, gws);
   return hipGetLastError();
 }
 // reference mode of ConvexMpc's problem; same variants

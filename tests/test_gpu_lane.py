@@ -622,6 +622,10 @@ def test_lane_kernel_8_point_reference_mode(pkg, lib, oracle, monkeypatch):
     assert (d < 1e-6).mean() >= 0.95 and (dw < 1e-6).mean() >= 0.9
     assert (il["iterations"] <= 10).all() and np.isfinite(fl).all()
     assert (fl.reshape(-1, 8, 3)[rec["contacts"] == 0] == 0).all()
+    monkeypatch.delenv("QMPC_LANE_REF_MIN")
+    s = pkg.Solver(p, 65536, device=0, lib=lib)
+    assert s.kernel_for_batch(65536) == "lane" and s.kernel_for_batch(32768) == "wform_ws" and s.kernel_for_batch(64) == "wform_lds"
+    s.close()
 
 
 @pytest.mark.gpu

@@ -997,19 +997,27 @@ def test_reference_mode_edge_cases_and_convex_model(pkg, lib, oracle):
     assert (f[1] == 0).all() and (f[2] == 0).all() and (tu[1] == 0).all()
     assert np.array_equal(info["status"], io["status"]) and np.array_equal(info["iterations"], io["iterations"])
     assert np.abs(tu - tuo).max() < 1e-6 and np.abs(tx - txo).max() < 1e-9
+    # the 8-point model: since round 5 on the wrench-form reference kernels (qmpc_ref8_w_kernel: everything in LDS for batches
+    # that find a CU each, gains / records in the workspace beyond) -- both forms and the round-1 dense kernels (QMPC_WFORM=0,
+    # a separate process: the switch is read once) against the oracle
     p8 = pkg.default_biped8_params(16, pkg.MODE_REFERENCE, lib)
-    rec8 = pkg.random_biped8_states(128, config_id=5)
-    s = pkg.Solver(p8, 128, device=0, lib=lib)
-    f8, i8 = s.solve8(rec8)
-    s.close()
+    rec8 = pkg.random_biped8_states(640, config_id=5)
+    rec8["contacts"][3] = 0.0
     f8o, i8o = oracle.solve8(p8, rec8, threads=8)
-    same8 = (i8["status"] == i8o["status"]) & (i8["iterations"] == i8o["iterations"])
     feet = rec8["foot_pos_body"].reshape(-1, 8, 3)
-    wr = lambda F: np.concatenate([F.reshape(-1, 8, 3).sum(1), np.cross(feet, F.reshape(-1, 8, 3)).sum(1)], axis=1)
-    dw = np.abs(wr(f8) - wr(f8o)).max(axis=1)
-    print(f"8-point model reference mode: {int(same8.sum())}/128 identical status and iterations; foot wrench median "
-          f"{np.median(dw):.2e}, worst {dw.max():.2e}")
-    assert same8.mean() >= 0.95 and np.median(dw) < 1e-6 and dw.max() < 1e-3
+    wr = lambda F: np.concatenate([F.reshape(-1, 8, 3).sum(1), np.cross(feet[:len(F)], F.reshape(-1, 8, 3)).sum(1)], axis=1)
+    for B8, fam in ((640, "wform_ws"), (96, "wform_lds")):
+        s = pkg.Solver(p8, B8, device=0, lib=lib)
+        assert s.kernel_for_batch(B8) == fam
+        f8, i8, tu8, tx8 = s.solve8(rec8[:B8], want_traj=True)
+        s.close()
+        assert np.array_equal(i8["status"], i8o["status"][:B8]) and np.array_equal(i8["iterations"], i8o["iterations"][:B8])
+        assert i8["status"][3] == pkg.NO_CONTACT and (f8[3] == 0).all()
+        d8 = np.abs(f8 - f8o[:B8]).max(axis=1)
+        dw = np.abs(wr(f8) - wr(f8o[:B8])).max(axis=1)
+        print(f"8-point model reference mode [{fam}]: {B8}/{B8} identical status and iterations; forces median {np.median(d8):.2e}, worst "
+              f"{d8.max():.2e} N; foot wrench worst {dw.max():.2e}")
+        assert d8.max() < 1e-6 and np.array_equal(tu8[:, 0, :], f8) and np.isfinite(tx8).all()      # measured: 3.5e-10 N
     pc = pkg.default_convex_params(20, pkg.MODE_REFERENCE, lib)
     assert pc.iterations_max == 5
     recc = pkg.random_go1_convex_states(256, config_id=13)
