@@ -535,6 +535,50 @@ __device__ __forceinline__ double gj6_step(double M[2], double Rr[2], int c, int
   return ninv;
 }
 
+// Two Gauss-Jordan steps at once: the 2 x 2 pivot block B = [[a, b], [b, d]] on rows / columns (J0, J0 + 1), J0 = 0, 2, 4 (both
+// rows live in the same fragment register, in adjacent row groups).  Every other row r loses its columns J0, J0 + 1:
+//   row_r += f0 row_J0 + f1 row_J1,   (f0, f1) = -(M[r][J0], M[r][J0+1]) B^-1,   B^-1 = [[d, -b], [-b, a]] / det
+// and the pivot rows themselves leave as -B^-1 [row_J0; row_J1] (the same formula with (M[r][J0], M[r][J0+1]) = e_1, e_2 and
+// no old row): after the three steps the right-hand side holds X = -W'^-1 Q, the tracked inverse -W'^-1, nothing is
+// divided out at the end.  One reciprocal (of det = a d - b^2 > 0 together with a > 0: Sylvester) and one round of
+// cross-row-group broadcasts per PAIR of pivots: the serial chain of the stage solve has three links instead of six
+// (round 5: stage solve 950 -> see profiles/r05_phase_cycles.txt).  Block Cholesky: as stable as the scalar pivots
+// (the cancellation in det is the one the scalar Schur complement d - b^2 / a carries).
+#ifndef QMPC_GJ_BLOCK2
+#define QMPC_GJ_BLOCK2 1
+#endif
+template <int J0, bool INV = false>
+__device__ __forceinline__ void gj6_pair_step(double M[2], double Rr[2], int c, int g, bool& pd, double* Iv = nullptr) {
+  constexpr int ej = J0 >> 2, g0 = J0 & 3, g1 = g0 + 1;
+  static_assert((J0 & 1) == 0 && J0 < 6, "pivot pairs (0,1), (2,3), (4,5)");
+  const int s0 = (g0 << 4) | c, s1 = (g1 << 4) | c;
+  const double m0 = __shfl(M[ej], s0), m1 = __shfl(M[ej], s1);      // rows J0, J0 + 1, same column, all row groups
+  const double r0 = __shfl(Rr[ej], s0), r1 = __shfl(Rr[ej], s1);
+  double i0 = 0.0, i1 = 0.0;
+  if (INV) { i0 = __shfl(Iv[ej], s0); i1 = __shfl(Iv[ej], s1); }
+  const double a = read_lane(M[ej], (g0 << 4) | J0), b = read_lane(M[ej], (g0 << 4) | (J0 + 1)),
+               d = read_lane(M[ej], (g1 << 4) | (J0 + 1));
+  const double det = fma(a, d, -(b * b));
+  pd = pd && (a > 0.0) && (det > 0.0);      // false for NaNs too
+  const double rd = fast_rcp(det);
+  const double ia = a * rd, ib = b * rd, id = d * rd;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    double c0 = row_bcast<J0>(M[e]), c1 = row_bcast<J0 + 1>(M[e]);
+    double bm = M[e], br = Rr[e], bi = INV ? Iv[e] : 0.0;
+    if (e == ej) {
+      const bool p0 = g == g0, p1 = g == g1;
+      c0 = p0 ? 1.0 : (p1 ? 0.0 : c0);
+      c1 = p1 ? 1.0 : (p0 ? 0.0 : c1);
+      if (p0 || p1) { bm = 0.0; br = 0.0; bi = 0.0; }
+    }
+    const double f0 = fma(ib, c1, -(id * c0)), f1 = fma(ib, c0, -(ia * c1));
+    M[e] = fma(f1, m1, fma(f0, m0, bm));
+    Rr[e] = fma(f1, r1, fma(f0, r0, br));
+    if (INV) Iv[e] = fma(f1, i1, fma(f0, i0, bi));
+  }
+}
+
 // Riccati backward pass in the wrench form; writes per knot [Xw | xw] and [Xz | xz] (KD).  Returns nonzero when a pivot
 // of W' is not positive (P lost positive definiteness: QMPC_NOT_PD).
 // REFINE (reference mode, round 5): one step of iterative refinement on the 6 x 6 stage solve.  W' = S6 (I + G S6) carries
@@ -633,6 +677,15 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
       Iv[0] = (c == g) ? 1.0 : 0.0;
       Iv[1] = (g < 2 && c == 4 + g) ? 1.0 : 0.0;
     }
+    double Xf[2];
+#if QMPC_GJ_BLOCK2
+    gj6_pair_step<0, REFINE>(Wm, Qf, c, g, pd, Iv);
+    gj6_pair_step<2, REFINE>(Wm, Qf, c, g, pd, Iv);
+    gj6_pair_step<4, REFINE>(Wm, Qf, c, g, pd, Iv);
+    const double nd0 = 1.0, nd1 = 1.0;      // (the pivot rows leave the block steps as -B^-1 row)
+    Xf[0] = Qf[0];
+    Xf[1] = rowok1 ? Qf[1] : 0.0;
+#else
     const double n0 = gj6_step<0, REFINE>(Wm, Qf, c, g, pd, Iv);
     const double n1 = gj6_step<1, REFINE>(Wm, Qf, c, g, pd, Iv);
     const double n2 = gj6_step<2, REFINE>(Wm, Qf, c, g, pd, Iv);
@@ -640,9 +693,9 @@ __device__ inline int backward_pass_w(const DevParams& P, const Layout& L, const
     const double n4 = gj6_step<4, REFINE>(Wm, Qf, c, g, pd, Iv);
     const double n5 = gj6_step<5, REFINE>(Wm, Qf, c, g, pd, Iv);
     const double nd0 = (g == 0) ? n0 : (g == 1 ? n1 : (g == 2 ? n2 : n3)), nd1 = (g == 0) ? n4 : n5;
-    double Xf[2];
     Xf[0] = Qf[0] * nd0;      // X = -diag^-1 Q
     Xf[1] = rowok1 ? Qf[1] * nd1 : 0.0;
+#endif
     if (REFINE) {
       // -r = C + X + G (S6 X);  v = S6 (-r);  X <- X - W'^-1 v   (nWi = -W'^-1 = n_r Iv, rows 6, 7 zero like every operand here)
       double nWi[2], T1[2], nr[2], vv[2];
