@@ -508,7 +508,7 @@ def main():
                                          "outputs_identical": same2},
                        "roofline": roofline_object(kn_l, ach, tr, tr_src, lg["kernel_ms"], Bl, Bl * (8 * 48 + 8 * 12 + 40))}
                 # the reference's own solver mode on the same batch (AL-iLQR, <= 10 iterations): the lane kernel's AL passes
-                # from 32768 instances on (22528 beyond N=12), the wave-per-instance reference kernels below
+                # from 34816 instances on (28672 beyond N=12), the wave-per-instance reference kernels below -- the library says which
                 if not args.no_reference_mode:
                     prl = pkg.default_params(Nl, pkg.MODE_REFERENCE, lib)
                     srl = pkg.Solver(prl, Bl, device=local, lib=lib)
@@ -522,13 +522,13 @@ def main():
                         if r_:
                             kms.append(srl.last_kernel_ms())
                     inf_l = irl.cpu().numpy().view(pkg.INFO_DTYPE).reshape(Bl)
+                    fam_l = srl.kernel_for_batch(Bl)
                     srl.close()
                     ent["reference_mode"] = {
                         "value": Bl / (float(np.median(kms)) * 1e-3), "unit": "solves/s", "kernel_ms": float(np.median(kms)),
-                        "kernel": ("qmpc_lane_ref_kernel (lane per instance, AL variant of the lane passes)"
-                                   if Bl >= int(os.environ.get("QMPC_LANE_REF_MIN", "32768" if Nl <= 12 else "22528")) else
-                                   ("qmpc_ref_w_kernel<5> (wave per instance, wrench form, gains in the workspace)" if Nl <= 12
-                                    else "qmpc_ref_kernel (wave per instance, dense 12x12 stage algebra)")),
+                        "kernel": ("qmpc_lane_ref_kernel (lane per instance, AL variant of the lane passes, feedback gains in f64)"
+                                   if fam_l == "lane" else
+                                   "qmpc_ref_w_kernel<5> (wave per instance, wrench form with refined stage solves, gains in the workspace)"),
                         "mean_iterations": float(inf_l["iterations"].mean()),
                         "status_counts": {"converged": int((inf_l["status"] == 0).sum()), "iteration_cap": int((inf_l["status"] == 1).sum()),
                                           "linesearch_fail": int((inf_l["status"] == 4).sum()), "not_pd": int((inf_l["status"] == 5).sum())},

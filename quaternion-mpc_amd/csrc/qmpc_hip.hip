@@ -58,7 +58,7 @@ hipError_t qmpc_wform_launch_list(int var, int grid, size_t lds, hipStream_t s, 
                                   const int* sel, const int* sel_count, double* gws, const double* hstate, int hcap);
 
 // qmpc_lane.hip (third translation unit): the lane-per-instance kernel of large batches
-size_t qmpc_lane_ws_bytes(int N, int nl, unsigned slots);
+size_t qmpc_lane_ws_bytes(int N, int nl, unsigned slots, int wide);
 size_t qmpc_lane_scratch_bytes(int batch);
 int qmpc_lane_param_slots();
 hipError_t qmpc_lane_upload_params(int pslot, hipStream_t s, const void* dev_params, size_t dev_params_size);
@@ -160,16 +160,23 @@ constexpr int kLaneCapLoopBase = 11;
 constexpr int kLaneCapWarm = 8;
 // (round 5, against the wrench-form reference kernels: N=10 24576 instances wave 2.98 vs lane 2.77 M solves/s, 32768: 3.04 vs 3.39 M,
 // 40960: 3.07 vs 4.11 M; N=16 20480: 1.68 vs 1.52 M, 28672: 1.69 vs 1.99 M; N=20 20480: 1.28 vs 1.24 M, 24576: 1.29 vs 1.45 M)
-constexpr int kLaneRefMinBatch = 28672;       // N <= 12
-constexpr int kLaneRefMinBatchLong = 22528;   // horizons beyond 12
+// (end of round 5: the AL passes keep their feedback gains in double precision -- 78 instead of 42 elements per knot, every
+// truncated iterate within 7e-9 N of the oracle's on 0.6 M instances where the packed form left 0.07-1 % beyond 1e-6 N and a few
+// line searches per 100 000 decided the other way -- and pay for it in traffic: N=10 32768 instances wave 2.88 vs lane 2.74 M,
+// 36864: 2.89 vs 3.08 M, 65536: 2.97 vs 4.61 M; N=16 24576: 1.70 vs 1.45 M, 32768: 1.71 vs 1.83 M; N=20 24576: 1.30 vs 1.21 M,
+// 28672: 1.30 vs 1.36 M, 65536: 1.32 vs 2.53 M)
+constexpr int kLaneRefMinBatch = 34816;       // N <= 12
+constexpr int kLaneRefMinBatchLong = 28672;   // horizons beyond 12
 // ConvexMpc's own mode (five iterations; tools/refmode_lane_bench.py --model convex): N=20 16384 instances wave 1.70 vs lane 1.68 M solves/s,
 // 24576: 1.72 vs 2.38 M, 65536: 1.74 vs 5.61 M; N=10 16384: 3.85 vs 3.37 M, 32768: 4.00 vs 6.00 M, 65536: 4.05 vs 10.5 M
 // 8-point model (N=16; tools/refmode_lane_bench.py --model biped8), against its wrench-form reference kernels (qmpc_ref8_w_kernel):
 // 16384 instances wave 1.12 vs lane 0.50 M solves/s, 32768: 1.14 vs 0.85 M, 49152: 1.16 vs 1.18 M, 65536: 1.16 vs 1.45 M
 // (the round-1 dense reference kernels it ran on before: 0.43 M at 8192, 0.46 M at 65536)
 constexpr int kLaneRefMinBatch8 = 49152;
-constexpr int kLaneRefMinBatchConvex = 20480;
-constexpr int kLaneRefMinBatchConvexLong = 17408;
+// (ConvexMpc with double-precision gains: N=10 20480 instances wave 4.06 vs lane 3.70 M, 24576: 4.08 vs 4.26 M, 65536: 4.18 vs
+// 8.89 M; N=20 16384: 1.75 vs 1.54 M, 20480: 1.75 vs 1.81 M, 65536: 1.79 vs 4.63 M; the 8-point model's lane rate did not move)
+constexpr int kLaneRefMinBatchConvex = 22528;
+constexpr int kLaneRefMinBatchConvexLong = 19456;
 
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
@@ -504,7 +511,7 @@ static qmpc_status ensure_lane_buffers(qmpc_handle* h) {
     // both buffers or none: a handle with a workspace but no sort scratch would run unsorted for the rest of its life
     double* ws = nullptr;
     int* sc = nullptr;
-    if (hipMalloc(&ws, qmpc_lane_ws_bytes(h->params.horizon, nl, h->lane_slots)) != hipSuccess ||
+    if (hipMalloc(&ws, qmpc_lane_ws_bytes(h->params.horizon, nl, h->lane_slots, h->params.mode == QMPC_MODE_REFERENCE)) != hipSuccess ||
         hipMalloc(&sc, qmpc_lane_scratch_bytes(h->max_batch)) != hipSuccess) {
       std::fprintf(stderr, "qmpc: lane-kernel workspace allocation failed: %s\n", hipGetErrorString(hipGetLastError()));
       if (ws) (void)hipFree(ws);
@@ -1118,7 +1125,7 @@ qmpc_status qmpc_query(qmpc_handle* h, int32_t what, int64_t arg, int64_t* value
       const int N = h->params.horizon, nl = model_nl(h->params.model), nu = 3 * nl;
       size_t b = (sizeof(double) * (32 + 4 * nl) + sizeof(double) * nu + sizeof(qmpc_info)) * (size_t)h->max_batch;
       b += sizeof(double) * (size_t)N * (13 * nu + 21 * nl + 30 * nl) * (size_t)h->max_batch;
-      if (h->d_lane_ws) b += qmpc_lane_ws_bytes(N, nl, h->lane_slots) + qmpc_lane_scratch_bytes(h->max_batch);
+      if (h->d_lane_ws) b += qmpc_lane_ws_bytes(N, nl, h->lane_slots, h->params.mode == QMPC_MODE_REFERENCE) + qmpc_lane_scratch_bytes(h->max_batch);
       if (h->d_handoff) b += qmpc_lane_handoff_list_bytes(h->max_batch) + sizeof(double) * qmpc_lane_handoff_record_doubles(N) * (size_t)h->hstate_cap;
       if (h->d_traj_u) b += sizeof(double) * nu * N * (size_t)h->max_batch;
       if (h->d_traj_x) b += sizeof(double) * 13 * (N + 1) * (size_t)h->max_batch;

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_ref_kernel(int pslot, con
   typedef LDim<NL> D;
   const int lane = threadIdx.x;
   const DevParams& P = ql_params[pslot];
-  const size_t block_elems = (size_t)make_wsoff<NL>(P.N).total * kLaneWave;
+  const size_t block_elems = (size_t)make_wsoff<NL>(P.N, true).total * kLaneWave;      // wide layout: the second gain block
   const unsigned long long wsb = reinterpret_cast<unsigned long long>(ws + (size_t)blockIdx.x * block_elems);
   const PassArgs a = {pslot, (unsigned)wsb, (unsigned)(wsb >> 32), 8u * (unsigned)lane, 0u};
   const size_t tstride = (size_t)P.N * D::NU;
@@ -493,8 +493,8 @@ using namespace qmpc;
 using namespace qmpc::lane;
 
 // called from qmpc_hip.hip (declared there); hidden: not part of the C ABI
-__attribute__((visibility("hidden"))) size_t qmpc_lane_ws_bytes(int N, int nl, unsigned slots) {
-  return sizeof(double) * lane_ws_elements(N, nl) * (size_t)slots;
+__attribute__((visibility("hidden"))) size_t qmpc_lane_ws_bytes(int N, int nl, unsigned slots, int wide) {
+  return sizeof(double) * lane_ws_elements(N, nl, wide != 0) * (size_t)slots;      // wide: handles in the reference's solver mode
 }
 __attribute__((visibility("hidden"))) size_t qmpc_lane_scratch_bytes(int batch) { return sizeof(int) * (512 + (size_t)batch); }
 // hand-off list of a capped launch: count | instance indices [batch]; the state records live in their own buffer

@@ -90,6 +90,12 @@ struct LDim {
   // changes the Newton direction by 6e-8 of the step and not the fixed point -- followed by the feed-forward zeta0 (6) in
   // double precision
   static constexpr int GAIN = 36 + 6;
+  // The reference's solver mode (AL passes) keeps the feedback part in DOUBLE precision: a truncated iterate does not damp
+  // the rounding of its directions (5.9e-8 of the step in the packed form: 99.9 / 99.1 % of the N = 10 / 20 forces within
+  // 1e-6 N of the oracle's, and a handful of line searches per 100 000 instances decided the other way).  Columns 0..5
+  // (36 doubles) and zeta0 fill the SAME 42-element slot; columns 6..11 live in a second block of GAIN2 per knot at the end
+  // of the (wide) layout, so that no offset of the converged mode moves.
+  static constexpr int GAIN2 = 36;
 };
 
 // constants of one instance (registers)
@@ -101,12 +107,16 @@ struct LaneK {
   double refp[13];       // reference parameters: pos vel acc quat_d
 };
 
+#ifndef QL_AL_G2_AHEAD
+#define QL_AL_G2_AHEAD 0      // 1: the second gain block of the trial rollouts one knot ahead too (measured: it spills, 14.2 -> 17.0 ms at 65536 instances)
+#endif
 // workspace offsets in ELEMENTS of one lane's column (element e of lane s of a wave lives at wave_base[64 e + s])
 struct WsOff {
-  int X, U, dU, S, LAM, G, RC, total;
+  int X, U, dU, S, LAM, G, RC, total, G2;
 };
+// wide: the layout of the reference mode's passes (a second gain block G2 after everything else; every other offset equal)
 template <int NL>
-QL_HD WsOff make_wsoff(int N) {
+QL_HD WsOff make_wsoff(int N, bool wide = false) {
   WsOff o;
   int p = 0;
   o.X = p; p += 13 * (N + 1);
@@ -116,10 +126,14 @@ QL_HD WsOff make_wsoff(int N) {
   o.LAM = p; p += 6 * NL * N;
   o.G = p; p += LDim<NL>::GAIN * N;
   o.RC = p; p += 6 * NL * N;      // initial slack residuals per row: only a warm-started launch has them per knot
+  o.G2 = p;
+  if (wide) p += LDim<NL>::GAIN2 * N;
   o.total = p;
   return o;
 }
-inline size_t lane_ws_elements(int N, int nl) { return nl == 8 ? (size_t)make_wsoff<8>(N).total : (size_t)make_wsoff<4>(N).total; }
+inline size_t lane_ws_elements(int N, int nl, bool wide = false) {
+  return nl == 8 ? (size_t)make_wsoff<8>(N, wide).total : (size_t)make_wsoff<4>(N, wide).total;
+}
 
 // Addresses: a wave-uniform base (scalar registers, constant for the whole solve) plus one 32-bit per-lane byte offset
 // whose element part is a small multiple of the row size -- consecutive elements differ by an immediate.  On the device
@@ -1446,7 +1460,10 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
         for (int t = 0; t < 6; ++t) s -= S6[S6I(i, t)] * z[t];
         xg[i] = s;
       }
-      if (j < 12) {
+      if (AL && j < 12) {      // double precision: columns 0..5 in the slot, 6..11 in the second block
+#pragma unroll
+        for (int i = 0; i < 6; ++i) c.W((j < 6 ? O.G + D::GAIN * k + 6 * (j < 6 ? j : 0) : O.G2 + D::GAIN2 * k + 6 * (j >= 6 && j < 12 ? j - 6 : 0)) + i) = xg[i];
+      } else if (j < 12) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) c.W(O.G + D::GAIN * k + 3 * (j < 12 ? j : 0) + i) = pack2f((float)xg[2 * i], (float)xg[2 * i + 1]);
       } else {
@@ -1972,12 +1989,18 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
     for (int i = 0; i < 13; ++i) xc[q][i] = c.W(O.X + i);
   const unsigned order = any_stance<NL>(st.con);
   // old state, gains, inputs and multipliers of a knot are fetched one knot ahead, into the registers just consumed
-  double xo[13], gn[D::GAIN], uk[3 * NL], lk[6 * NL];
+  // (gains in double precision: columns 0..5 and zeta0 travel one knot ahead like before, columns 6..11 are fetched at the top
+  // of their knot and used after the first half)
+  double xo[13], gn[D::GAIN], g2[D::GAIN2], uk[3 * NL], lk[6 * NL];
   auto load_head = [&](int k) {
 #pragma unroll
     for (int i = 0; i < 13; ++i) xo[i] = c.W(O.X + 13 * k + i);
 #pragma unroll
     for (int i = 0; i < D::GAIN; ++i) gn[i] = c.W(O.G + D::GAIN * k + i);
+#if QL_AL_G2_AHEAD
+#pragma unroll
+    for (int i = 0; i < D::GAIN2; ++i) g2[i] = c.W(O.G2 + D::GAIN2 * k + i);
+#endif
   };
   auto load_leg = [&](int k, int l) {
 #pragma unroll
@@ -1995,6 +2018,10 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
   for (int k = 0; k < N; ++k) {
     const int kn = (k + 1 < N) ? k + 1 : k;
     double zeta[NA][6];
+#if !QL_AL_G2_AHEAD
+#pragma unroll
+    for (int i = 0; i < D::GAIN2; ++i) g2[i] = c.W(O.G2 + D::GAIN2 * k + i);
+#endif
     double Wk[4] = {0, 0, 0, 0};       // ConvexMpc's model: Iw^-1 at the OLD knot state's midpoint yaw (the linearisation point)
     if constexpr (MD == MD_CONVEX) cv_winv_mid(P, xo[2], xo[8], Wk);
     {
@@ -2027,14 +2054,13 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
 #pragma unroll
         for (int i = 0; i < 6; ++i) zeta[q][i] = alpha[q] * gn[36 + i];
 #pragma unroll
-        for (int j = 0; j < 12; ++j)
+        for (int j = 0; j < 6; ++j)
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            float g0, g1;
-            unpack2f(gn[3 * j + i], g0, g1);
-            zeta[q][2 * i] += (double)g0 * dx[j];
-            zeta[q][2 * i + 1] += (double)g1 * dx[j];
-          }
+          for (int i = 0; i < 6; ++i) zeta[q][i] += gn[6 * j + i] * dx[j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+          for (int i = 0; i < 6; ++i) zeta[q][i] += g2[6 * j + i] * dx[6 + j];
       }
     }
     load_head(kn);

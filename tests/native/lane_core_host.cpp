@@ -13,7 +13,7 @@ using namespace qmpc::lane;
 template <int NL, int MD = MD_QUAT>
 static int solve_all(const DevParams& P, int batch, const double* rec, double* forces, qmpc_info* info,
                      bool warm = false, const double* u_init = nullptr, double* traj_u = nullptr) {
-  const WsOff O = make_wsoff<NL>(P.N);
+  const WsOff O = make_wsoff<NL>(P.N, P.mode == QMPC_MODE_REFERENCE);
   std::vector<double> ws((size_t)O.total), pl((size_t)LDim<NL>::PLDS);
   for (int b = 0; b < batch; ++b) {
     Ctx c = {ws.data(), 8, 0, pl.data(), 8, 0};

@@ -175,8 +175,11 @@ def test_lane_kernel_reference_mode(pkg, lib, oracle, monkeypatch, N, B):
     fl, il = out[4]
     fw, iw = out[0]
     dt = np.abs(out[("traj", 4)][1] - out[("traj", 0)][1]).reshape(B, -1).max(axis=1)
-    # (state trajectories of two truncated iterates: every knot of the horizon counts, N = 20 measured 83 % within 1e-6)
-    assert np.isfinite(dt).all() and (dt < (1e-6 if N <= 10 else 1e-5)).mean() >= 0.9
+    # (state trajectories of two truncated iterates, every knot of the horizon: with the feedback gains of the AL passes in double
+    # precision -- end of round 5 -- the two kernel families agree like their first-knot forces do; the packed single-precision
+    # gains left 83 % of the N = 20 trajectories within 1e-6)
+    print(f"lane vs wave kernels, reference mode N={N}: state trajectories within 1e-6 on {100 * (dt < 1e-6).mean():.2f} %, worst {dt.max():.1e}")
+    assert np.isfinite(dt).all() and (dt < 1e-6).mean() >= 0.995
     fo, io = oracle.solve(p, rec, threads=8)
     assert np.array_equal(il["status"], io["status"]) and np.array_equal(il["iterations"], io["iterations"])
     assert np.array_equal(il["status"], iw["status"]) and np.array_equal(il["iterations"], iw["iterations"])
@@ -185,8 +188,9 @@ def test_lane_kernel_reference_mode(pkg, lib, oracle, monkeypatch, N, B):
     dw = np.abs(fl - fw).max(axis=1)
     print(f"lane kernel, reference mode N={N} B={B}: vs oracle within 1e-6 N on {100 * (d < 1e-6).mean():.1f} % (median {np.median(d):.1e}, worst "
           f"{d.max():.1e}); vs wave kernels {100 * (dw < 1e-6).mean():.1f} %; status counts {np.bincount(il['status'], minlength=6).tolist()}")
-    # (two truncated iterates against each other at N = 20: the wave kernels' own agreement with the oracle is 97 %)
-    assert (d < 1e-6).mean() >= 0.95 and (dw < 1e-6).mean() >= (0.95 if N <= 10 else 0.90)
+    # (double-precision gains in the AL passes: 0.6 M soak instances without one force beyond 7e-9 N of the oracle's; the packed
+    # form held 99.9 % / 99.1 % of the N = 10 / 20 forces to 1e-6 N)
+    assert (d < 1e-6).mean() >= 0.999 and (dw < 1e-6).mean() >= 0.999
     assert (il["iterations"] <= 10).all() and np.isfinite(fl).all()
     assert (fl.reshape(-1, 4, 3)[rec["contacts"] == 0] == 0).all()
     solved = io["status"] <= 1
@@ -619,7 +623,7 @@ def test_lane_kernel_8_point_reference_mode(pkg, lib, oracle, monkeypatch):
     print(f"lane kernel, 8-point model, reference mode N={N} B={B}: vs oracle within 1e-6 N on {100 * (d < 1e-6).mean():.1f} % (median "
           f"{np.median(d):.1e}, worst {d.max():.1e}); vs wave kernels {100 * (dw < 1e-6).mean():.1f} %; status counts "
           f"{np.bincount(il['status'], minlength=6).tolist()}")
-    assert (d < 1e-6).mean() >= 0.95 and (dw < 1e-6).mean() >= 0.9
+    assert (d < 1e-6).mean() >= 0.999 and (dw < 1e-6).mean() >= 0.999
     assert (il["iterations"] <= 10).all() and np.isfinite(fl).all()
     assert (fl.reshape(-1, 8, 3)[rec["contacts"] == 0] == 0).all()
     monkeypatch.delenv("QMPC_LANE_REF_MIN")
@@ -665,11 +669,12 @@ def test_lane_kernel_convex_reference_mode(pkg, lib, oracle, monkeypatch, N, B):
     fl, il = out[4]
     fw, iw = out[0]
     fo, io = oracle.convex_solve(oracle.default_convex_params(N, 1), rec, threads=8)
-    # state trajectories of the two kernel families: the lane kernel stores its feedback gains in single precision and a
-    # truncated iterate does not damp that -- later knots of the lane kernel's trajectory are 1e-5 N / 2e-6 (state units) from
-    # the oracle's (median, N = 20; the wrench-form wave kernels: 1e-12), the first-knot forces the controller applies 2e-7 N
+    # state trajectories of the two kernel families (the AL passes keep their feedback gains in double precision since the end of
+    # round 5: with the packed single-precision gains later knots of the lane kernel's trajectory were 1e-5 N / 2e-6 state
+    # units from the oracle's at N = 20)
     dt = np.abs(out["traj"][1] - out["traj0"][1]).reshape(B, -1).max(axis=1)
-    assert (dt < 1e-4).mean() >= 0.95 and np.median(dt) < 1e-5
+    print(f"lane vs wave kernels, ConvexMpc reference mode N={N}: state trajectories median {np.median(dt):.1e}, worst {dt.max():.1e}")
+    assert (dt < 1e-6).mean() >= 0.995 and np.median(dt) < 1e-9
     assert np.array_equal(il["status"], io["status"]) and np.array_equal(il["iterations"], io["iterations"])
     assert np.array_equal(il["status"], iw["status"]) and np.array_equal(il["iterations"], iw["iterations"])
     assert il["status"][5] == pkg.NO_CONTACT and il["status"][9] == pkg.NAN_INPUT
@@ -678,7 +683,7 @@ def test_lane_kernel_convex_reference_mode(pkg, lib, oracle, monkeypatch, N, B):
     print(f"lane kernel, ConvexMpc reference mode N={N} B={B}: vs oracle within 1e-6 N on {100 * (d < 1e-6).mean():.1f} % (median "
           f"{np.median(d):.1e}, worst {d.max():.1e}); vs wave kernels {100 * (dw < 1e-6).mean():.1f} %; status counts "
           f"{np.bincount(il['status'], minlength=6).tolist()}")
-    assert (d < 1e-6).mean() >= 0.95 and (dw < 1e-6).mean() >= 0.95
+    assert (d < 1e-6).mean() >= 0.99 and (dw < 1e-6).mean() >= 0.999
     assert (il["iterations"] <= 5).all() and np.isfinite(fl).all()
     assert (fl.reshape(-1, 4, 3)[rec["contacts"] == 0] == 0).all()
     solved = io["status"] <= 1
