@@ -108,7 +108,7 @@ struct LaneK {
 };
 
 #ifndef QL_AL_G2_AHEAD
-#define QL_AL_G2_AHEAD 0      // 1: the second gain block of the trial rollouts one knot ahead too (measured: it spills, 14.2 -> 17.0 ms at 65536 instances)
+#define QL_AL_G2_AHEAD 2      // second gain block of the trial rollouts: 0 at the top of its knot, 1 a whole knot ahead (it spills: 14.2 -> 17.0 ms at 65536 instances), 2 at the end of the previous knot
 #endif
 // workspace offsets in ELEMENTS of one lane's column (element e of lane s of a wave lives at wave_base[64 e + s])
 struct WsOff {
@@ -1997,7 +1997,7 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
     for (int i = 0; i < 13; ++i) xo[i] = c.W(O.X + 13 * k + i);
 #pragma unroll
     for (int i = 0; i < D::GAIN; ++i) gn[i] = c.W(O.G + D::GAIN * k + i);
-#if QL_AL_G2_AHEAD
+#if QL_AL_G2_AHEAD == 1
 #pragma unroll
     for (int i = 0; i < D::GAIN2; ++i) g2[i] = c.W(O.G2 + D::GAIN2 * k + i);
 #endif
@@ -2009,6 +2009,10 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
     for (int i = 0; i < 6; ++i) lk[6 * l + i] = c.W(O.LAM + 6 * NL * k + 6 * l + i);
   };
   load_head(0);
+#if QL_AL_G2_AHEAD == 2
+#pragma unroll
+  for (int i = 0; i < D::GAIN2; ++i) g2[i] = c.W(O.G2 + i);
+#endif
 #pragma unroll
   for (int l = 0; l < NL; ++l) if ((order >> l) & 1u) load_leg(0, l);
   double Jp[NA], alsum[NA], viol[NA], stp[NA];
@@ -2018,7 +2022,7 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
   for (int k = 0; k < N; ++k) {
     const int kn = (k + 1 < N) ? k + 1 : k;
     double zeta[NA][6];
-#if !QL_AL_G2_AHEAD
+#if QL_AL_G2_AHEAD == 0
 #pragma unroll
     for (int i = 0; i < D::GAIN2; ++i) g2[i] = c.W(O.G2 + D::GAIN2 * k + i);
 #endif
@@ -2128,6 +2132,11 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
         }
       }
     }
+#if QL_AL_G2_AHEAD == 2
+    // the next knot's second gain block: issued once the per-point phase has released its registers, covered by the state steps
+#pragma unroll
+    for (int i = 0; i < D::GAIN2; ++i) g2[i] = c.W(O.G2 + D::GAIN2 * kn + i);
+#endif
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
       if constexpr (MD == MD_CONVEX) cv_step_fw(P, xc[q], F[q], wd[q], xn);
