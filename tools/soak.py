@@ -63,7 +63,7 @@ if a.closed_loop:
     yaws = rng.uniform(-3.1, 3.1, B)
     stand = cmds.copy(); stand[:, 6] = 0.0
     st_init = pkg.loop_states(stand, lp, height=0.3, yaw=yaws, lib=lib)
-    prm = pkg.default_params(a.horizon, pkg.MODE_CONVERGED, lib)
+    prm = pkg.default_params(a.horizon, pkg.MODE_REFERENCE if a.mode else pkg.MODE_CONVERGED, lib)
     prm.drop_ang_vel = 0 if a.feed_ang_vel else 1
     s = pkg.Solver(prm, B, device=0, lib=lib)
     t0 = time.time()
@@ -80,7 +80,7 @@ if a.closed_loop:
     nonok = int((st["status"] != 0).sum())
     worst_f, cdiff = 0.0, 0
     for i in range(min(a.check, B)):
-        h = host.qh_loop_create_opts(str(pkg.LIB_PATH).encode(), a.horizon, pkg.MODE_CONVERGED, 0 if a.feed_ang_vel else 1,
+        h = host.qh_loop_create_opts(str(pkg.LIB_PATH).encode(), a.horizon, pkg.MODE_REFERENCE if a.mode else pkg.MODE_CONVERGED, 0 if a.feed_ang_vel else 1,
                                      C.addressof(lp), st_init[i:i + 1].ctypes.data)
         e = np.zeros(1, dtype=pkg.LOOP_STATE_DTYPE)
         host.qh_loop_set_warm_start(h, 1 if a.warm else 0)
@@ -95,7 +95,7 @@ if a.closed_loop:
             worst_f = max(worst_f, float(np.abs(e[0]["forces_body"] - tf[t, i]).max()))
         host.qh_loop_destroy(h)
     dist = np.linalg.norm(st["pos_world"][:, :2] - st0["pos_world"][:, :2], axis=1)[~down]
-    print(f"closed-loop soak{' (angular velocity fed to the MPC)' if a.feed_ang_vel else ''}{' (warm start)' if a.warm else ''}: {B} robots x {a.ticks} ticks ({a.ticks * 0.005:.1f} s of robot time) in {dt:.1f} s = "
+    print(f"closed-loop soak{' (reference mode)' if a.mode else ''}{' (angular velocity fed to the MPC)' if a.feed_ang_vel else ''}{' (warm start)' if a.warm else ''}: {B} robots x {a.ticks} ticks ({a.ticks * 0.005:.1f} s of robot time) in {dt:.1f} s = "
           f"{B * a.ticks / dt:.3g} robot-ticks/s incl. traces; robots down {fell}, last-tick solver status != OK {nonok}; "
           f"distance walked median {np.median(dist):.3f} m, max {dist.max():.3f} m; {min(a.check, B)} robots replayed on the host "
           f"classes: contact-flag differences {cdiff}, worst force difference {worst_f:.3e} N")
