@@ -62,15 +62,18 @@ __device__ __forceinline__ void priv_store(QL_PRIV_AS T* dst, const T& src) {
 struct PassArgs {
   int pslot;
   unsigned ws_lo, ws_hi;     // this wave's workspace block
-  unsigned lane8;            // 8 x lane
+  unsigned lane8;            // 8 x lane (pair mode: 8 x (lane & 31) -- the partner lanes share a column)
   unsigned warm;             // wave-uniform: the launch carries previous solutions (qmpc_solve_warm*, the warm-started loop)
+  unsigned half;             // pair mode: 1 on lanes 32..63 (Ctx::half); 0 otherwise
+  unsigned lmask;            // wave-uniform: Ctx::lmask (0x1F8, pair mode 0xF8)
 };
 template <int NL>
 __device__ __forceinline__ Ctx pass_ctx(const PassArgs& a) {
   extern __shared__ __attribute__((aligned(16))) double ql_lds[];
   const unsigned lo = __builtin_amdgcn_readfirstlane(a.ws_lo), hi = __builtin_amdgcn_readfirstlane(a.ws_hi);
   QL_GLOBAL_AS double* ws = reinterpret_cast<QL_GLOBAL_AS double*>(((unsigned long long)hi << 32) | lo);
-  Ctx c = {ws, 8u * kLaneWave, a.lane8, (QL_LDS_AS double*)ql_lds, 8u * kLaneWave, a.lane8};
+  Ctx c = {ws, 8u * kLaneWave, a.lane8, (QL_LDS_AS double*)ql_lds, 8u * kLaneWave, a.lane8, a.half,
+           (unsigned)__builtin_amdgcn_readfirstlane(a.lmask)};
   return c;
 }
 template <int NL, int MD>
@@ -114,7 +117,7 @@ __device__ __noinline__ bool call_B(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
 #endif
   return ok;
 }
-template <int NL, bool WARM, int MD>
+template <int NL, bool WARM, int MD, bool PAIR = false>
 __device__ __noinline__ void call_C(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS LaneState* sp) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
@@ -123,7 +126,7 @@ __device__ __noinline__ void call_C(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
   priv_load(K, Kp);
   LaneState st;
   priv_load(st, (QL_PRIV_AS const LaneState*)sp);
-  pass_C<NL, WARM, MD>(P, c, O, K, st, (FootPtr)Kp->foot);
+  pass_C<NL, WARM, MD, PAIR>(P, c, O, K, st, (FootPtr)Kp->foot);
   if (!st.bad_step) st.iters = st.it;
   priv_store(sp, st);
 }
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_ref_kernel(int pslot, con
   const DevParams& P = ql_params[pslot];
   const size_t block_elems = (size_t)make_wsoff<NL>(P.N, true).total * kLaneWave;      // wide layout: the second gain block
   const unsigned long long wsb = reinterpret_cast<unsigned long long>(ws + (size_t)blockIdx.x * block_elems);
-  const PassArgs a = {pslot, (unsigned)wsb, (unsigned)(wsb >> 32), 8u * (unsigned)lane, 0u};
+  const PassArgs a = {pslot, (unsigned)wsb, (unsigned)(wsb >> 32), 8u * (unsigned)lane, 0u, 0u, 0x1F8u};
   const size_t tstride = (size_t)P.N * D::NU;
   LaneK<NL> K;
   LaneState st;
@@ -348,7 +351,15 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
   const int itmax = (iter_cap > 0 && iter_cap < P.iterations_max) ? iter_cap : P.iterations_max;
   const size_t block_elems = (size_t)make_wsoff<NL>(P.N).total * kLaneWave;
   const unsigned long long wsb = reinterpret_cast<unsigned long long>(ws + (size_t)blockIdx.x * block_elems);
-  const PassArgs a = {pslot, (unsigned)wsb, (unsigned)(wsb >> 32), 8u * (unsigned)lane, u_init ? 1u : 0u};
+  // Lane pairs (four-point quaternion model, batches that fill half of every wavefront): lanes i and i + 32 take the SAME instance;
+  // every pass runs duplicated on the partner -- a wave64 FP64 instruction issues its four passes whatever the mask -- except the
+  // per-point blocks of the trial pass, which the pair splits (pass_C<..., PAIR>).  QMPC_LANE_PAIR=0 restores the masked half.
+  constexpr bool kPairable = NL == 4 && MD == MD_QUAT;
+  const bool pairm = kPairable && lanes == -32;      // (the launcher passes -32 for pair mode)
+  if (lanes < 0) lanes = -lanes;
+  const int lane_i = pairm ? (lane & 31) : lane;
+  const PassArgs a = {pslot, (unsigned)wsb, (unsigned)(wsb >> 32), 8u * (unsigned)lane_i, u_init ? 1u : 0u,
+                      pairm ? (unsigned)(lane >> 5) : 0u, pairm ? 0xF8u : 0x1F8u};
   const bool warm = u_init != nullptr;      // kernel argument: scalar
   const size_t tstride = (size_t)P.N * D::NU;      // doubles per instance in u_init / traj_u
   LaneK<NL> K;
@@ -357,8 +368,8 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
   QL_PRIV_AS LaneState* sp = (QL_PRIV_AS LaneState*)&st;
   // `lanes` (64, or 32 when the batch would otherwise leave SIMDs without a wavefront) lanes of a wave take instances
   for (long long base = (long long)blockIdx.x * lanes; base < batch; base += slots) {
-    const long long pos = base + lane;
-    const bool valid = lane < lanes && pos < batch;
+    const long long pos = base + lane_i;
+    const bool valid = (pairm || lane < lanes) && pos < batch;
     const int b = valid ? (perm ? perm[pos] : (int)pos) : 0;
     bool active = false;
     if (valid) {
@@ -394,7 +405,9 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
           const bool wrows = warm && __any(st.rho != 0.0);
           if (!(wrows ? call_B<NL, true, MD>(a, Kp, sp) : call_B<NL, false, MD>(a, Kp, sp))) { st.status = QMPC_NOT_PD; active = false; }
           else {
-            if (wrows) call_C<NL, true, MD>(a, Kp, sp); else call_C<NL, false, MD>(a, Kp, sp);
+            if (wrows) call_C<NL, true, MD>(a, Kp, sp);
+            else if (kPairable && pairm) call_C<NL, false, MD, kPairable>(a, Kp, sp);
+            else call_C<NL, false, MD>(a, Kp, sp);
             if (st.bad_step) { st.status = QMPC_NOT_PD; active = false; }     // a non-finite trial step is not applied
           }
         }
@@ -410,7 +423,7 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
                       traj_x ? reinterpret_cast<unsigned long long>(traj_x + (size_t)b * (size_t)(P.N + 1) * (MD == MD_CONVEX ? 12 : 13)) : 0ull);
     // hand-off: an instance stopped by the cap joins the list; its state travels with it while the buffer has room (the
     // wave kernel starts the others from scratch)
-    if (NL == 4 && hcount && valid && itmax < P.iterations_max && st.status == QMPC_MAX_ITER) {
+    if (NL == 4 && hcount && valid && (!pairm || lane < 32) && itmax < P.iterations_max && st.status == QMPC_MAX_ITER) {
       const int ord = atomicAdd(hcount, 1);
       hsel[ord] = b;
       if (ord < hcap) call_dump<NL>(a, sp, reinterpret_cast<unsigned long long>(hstate + (size_t)ord * (8 + 84 * (size_t)P.N)), warm ? 1 : 0);
@@ -585,9 +598,13 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
   else if (convex)
     hipLaunchKernelGGL((qmpc_lane_kernel<4, MD_CONVEX>), dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes,
                        perm, prof, u_init, traj_u, check_prev, traj_x, iter_cap, hcount, hsel, hstate, hcap);
-  else
-    hipLaunchKernelGGL(qmpc_lane_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm, prof,
+  else {
+    // half-filled wavefronts of the four-point quaternion model: lane pairs (the kernel reads -32 as "32 instances, pairs")
+    static const int pair_env = std::getenv("QMPC_LANE_PAIR") ? std::atoi(std::getenv("QMPC_LANE_PAIR")) : 1;
+    const int lanes_arg = (lanes == 32 && pair_env) ? -32 : lanes;
+    hipLaunchKernelGGL(qmpc_lane_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes_arg, perm, prof,
                        u_init, traj_u, check_prev, traj_x, iter_cap, hcount, hsel, hstate, hcap);
+  }
 #if defined(QL_PROFILE)
   {
     static long long hp[16 * 1024];

@@ -160,6 +160,12 @@ struct Ctx {
   unsigned woff;             // this lane's byte offset inside a row
   QL_LDS_AS double* pl;      // lane-private rows for the cost-to-go matrix (LDS): [entry][lane]
   unsigned prow, poff;
+  // Lane PAIRS (round 5; batches that fill only half of every wavefront): lanes i and i + 32 work on the SAME instance --
+  // same column of the workspace and of the LDS rows (woff = poff = 8 (lane & 31)), every pass duplicated except the
+  // per-point blocks of the passes that split them (pass_C<..., PAIR>: lane i takes the first point of a pair, lane i + 32
+  // the second).  A wave64 FP64 instruction issues its four 16-lane passes whatever the mask, so the partner lanes are free.
+  unsigned half = 0;         // 1 on the upper partner lane of a pair
+  unsigned lmask = 0x1F8;    // relane(): 8 (lane & 63), or 8 (lane & 31) in pair mode (0xF8)
   QL_FN QL_GLOBAL_AS double& W(int e) const {
     return *reinterpret_cast<QL_GLOBAL_AS double*>(reinterpret_cast<QL_GLOBAL_AS char*>(ws) + ((unsigned)e * wrow + woff));
   }
@@ -173,7 +179,7 @@ struct Ctx {
 #if QL_DEVICE
     unsigned x;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 3, %0" : "=v"(x));
-    woff = x;
+    woff = x & lmask;
 #endif
   }
 };
@@ -189,6 +195,20 @@ enum { LP_A = 0, LP_B_HEAD, LP_B_LEGS, LP_B_EXPAND, LP_B_MP, LP_B_CONGR, LP_B_FA
 #define QL_ANY(x) (__any((int)(x)) != 0)
 #else
 #define QL_ANY(x) (x)
+#endif
+// values of the two partner lanes of a pair, seen by BOTH of them in the same order (v_permlane32_swap: no LDS): lo = the lower
+// half-wave's lane, hi = the upper's -- whatever is formed from (lo, hi) is bit-identical in the two lanes
+#if QL_DEVICE
+QL_FN void ql_pair(double x, double& lo, double& hi) {
+  typedef unsigned u2v_ __attribute__((ext_vector_type(2)));
+  const unsigned xl = (unsigned)__double2loint(x), xh = (unsigned)__double2hiint(x);
+  const u2v_ l = __builtin_amdgcn_permlane32_swap(xl, xl, false, false);
+  const u2v_ h = __builtin_amdgcn_permlane32_swap(xh, xh, false, false);
+  lo = __hiloint2double((int)h[0], (int)l[0]);
+  hi = __hiloint2double((int)h[1], (int)l[1]);
+}
+#else
+QL_FN void ql_pair(double x, double& lo, double& hi) { lo = x; hi = x; }
 #endif
 #if QL_DEVICE && !defined(QL_NO_FENCE)
 #define QL_FENCE() asm volatile("" ::: "memory")
@@ -1610,8 +1630,14 @@ QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr
 }
 
 // ---- pass C: closed-loop trial rollout (alpha = 1) + slack / multiplier directions + step lengths ----------------------
-template <int NL, bool WARM = false, int MD = MD_QUAT>
+// PAIR (lane pairs, see Ctx): the two points of a pair are worked on by the two partner lanes -- one leg_compute_C per lane
+// instead of two -- and what the state step needs of both (force and torque sums) is exchanged per knot; the step-length
+// candidates are combined once, at the end of the pass.  Both partner lanes add the two shares in the plain form's order,
+// (F + a) + b, so a pair-mode launch returns the bits of a plain one (the multiplier ratio, tracked per lane and combined at
+// the end, could differ from the plain form's running maximum only between two rows whose ratios tie exactly).
+template <int NL, bool WARM = false, int MD = MD_QUAT, bool PAIR = false>
 QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st, FootPtr fp) {
+  static_assert(!PAIR || (MD != MD_CONVEX && !WARM), "pair split: cold passes of the quaternion model");
   typedef LDim<NL> D;
   const int N = P.N;
   const double gb[3] = {K.rot[6] * (-9.81), K.rot[7] * (-9.81), K.rot[8] * (-9.81)};
@@ -1645,10 +1671,14 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   }
   {
     const int p0 = first_bit(porder);
-    fetch_ahead<NL>(c, O, 0, NL == 4 ? p0 : 2 * p0, Ra, fp, rcrows);
-    fetch_ahead<NL>(c, O, 0, NL == 4 ? 3 - p0 : 2 * p0 + 1, Rb, fp, rcrows);
+    if (PAIR) {
+      fetch_ahead<NL>(c, O, 0, c.half ? pair_leg<NL>(p0, 1) : pair_leg<NL>(p0, 0), Ra, fp, rcrows);
+    } else {
+      fetch_ahead<NL>(c, O, 0, NL == 4 ? p0 : 2 * p0, Ra, fp, rcrows);
+      fetch_ahead<NL>(c, O, 0, NL == 4 ? 3 - p0 : 2 * p0 + 1, Rb, fp, rcrows);
+    }
   }
-  double rp = 0.0, dn = 0.0, dd = 1.0, stp = 0.0;
+  double rp = 0.0, dnA = 0.0, ddA = 1.0, dnB = 0.0, ddB = 1.0, stp = 0.0;      // (A: first points of the pairs, B: second points)
   bool bad = false;
   for (int k = 0; k < N; ++k) {
     const int kn = (k + 1 < N) ? k + 1 : k;      // the last knot re-reads itself
@@ -1708,6 +1738,39 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     for (int pr = 0; pr < NL / 2; ++pr) {
       const int la = pair_leg<NL>(pr, 0), lb = pair_leg<NL>(pr, 1);
       const bool on_a = (st.con >> la) & 1u, on_b = (st.con >> lb) & 1u;
+      if (PAIR) {
+        if ((porder >> pr) & 1u) {       // wave-uniform
+          const int lm = c.half ? lb : la;      // this lane's point of the pair
+          const bool on_m = c.half ? on_b : on_a;
+          LegOutC om;
+          leg_compute_C<NL, MD>(P, K, cr, rc0, Ra, lm, zeta, st, om, rcrows, Wk);
+          {     // the next pair's row into the registers just consumed
+            const int pn = next_bit(porder, pr);
+            const int kq = pn >= 0 ? k : kn, pq = pn >= 0 ? pn : first_bit(porder);
+            fetch_ahead<NL>(c, O, kq, c.half ? pair_leg<NL>(pq, 1) : pair_leg<NL>(pq, 0), Ra, fp, rcrows);
+          }
+          double fm[3], tm[3];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            if (on_m) c.W(O.dU + 3 * NL * k + 3 * lm + a) = om.du[a];
+            fm[a] = on_m ? om.u[a] : 0.0;
+            const double t = om.B[3 * a] * om.u[0] + om.B[3 * a + 1] * om.u[1] + om.B[3 * a + 2] * om.u[2];
+            tm[a] = on_m ? t : 0.0;
+          }
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            double lo, hi;
+            ql_pair(fm[a], lo, hi);      // lo: the first point's share, hi: the second's -- added in the plain form's order
+            F[a] = (F[a] + lo) + hi;
+            ql_pair(tm[a], lo, hi);
+            wd[a] = (wd[a] + lo) + hi;
+          }
+          if (on_m) {
+            rp = fmax(rp, om.rp); stp = fmax(stp, om.stp); bad = bad || om.bad;
+            const bool better = om.dn * ddA > dnA * om.dd; dnA = better ? om.dn : dnA; ddA = better ? om.dd : ddA;      // (this lane's own points)
+          }
+        }
+      } else
       if ((porder >> pr) & 1u) {       // wave-uniform
         LegOutC oa, ob;
         leg_compute_C<NL, MD>(P, K, cr, rc0, Ra, la, zeta, st, oa, rcrows, Wk);
@@ -1727,7 +1790,7 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
           }
           if constexpr (MD == MD_CONVEX) cv_cross_acc(oa.r, oa.u, wd);
           rp = fmax(rp, oa.rp); stp = fmax(stp, oa.stp); bad = bad || oa.bad;
-          { const bool better = oa.dn * dd > dn * oa.dd; dn = better ? oa.dn : dn; dd = better ? oa.dd : dd; }
+          { const bool better = oa.dn * ddA > dnA * oa.dd; dnA = better ? oa.dn : dnA; ddA = better ? oa.dd : ddA; }
         }
         if (on_b) {
 #pragma unroll
@@ -1738,7 +1801,7 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
           }
           if constexpr (MD == MD_CONVEX) cv_cross_acc(ob.r, ob.u, wd);
           rp = fmax(rp, ob.rp); stp = fmax(stp, ob.stp); bad = bad || ob.bad;
-          { const bool better = ob.dn * dd > dn * ob.dd; dn = better ? ob.dn : dn; dd = better ? ob.dd : dd; }
+          { const bool better = ob.dn * ddA > dnA * ob.dd; dnA = better ? ob.dn : dnA; ddA = better ? ob.dd : ddA; }      // (one running ratio in the plain form)
         }
       }
     }
@@ -1749,6 +1812,16 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     for (int i = 0; i < 13; ++i) xc[i] = xn[i];
     QL_TICK(st, LP_C_STEP);
   }
+  if (PAIR) {      // the partner's candidates: the lower lane tracked the first points (A), the upper lane the second (B)
+    double lo, hi;
+    ql_pair(rp, lo, hi); rp = fmax(lo, hi);
+    ql_pair(stp, lo, hi); stp = fmax(lo, hi);
+    ql_pair(bad ? 1.0 : 0.0, lo, hi); bad = (lo != 0.0) || (hi != 0.0);
+    ql_pair(dnA, lo, hi); dnA = lo; dnB = hi;
+    ql_pair(ddA, lo, hi); ddA = lo; ddB = hi;
+  }
+  double dn = dnA, dd = ddA;
+  { const bool better = dnB * dd > dn * ddB; dn = better ? dnB : dn; dd = better ? ddB : dd; }
   const double ap = (rp > P.tau) ? P.tau / rp : 1.0;
   const double ad = (dn * 1.0 > P.tau * dd) ? P.tau * dd / dn : 1.0;
   st.bad_step = (bad || !(ap > 0.0) || !(ad > 0.0)) ? 1 : 0;      // also a NaN step length (0 * inf in the ratios)
