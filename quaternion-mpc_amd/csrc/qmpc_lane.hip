@@ -102,7 +102,7 @@ __device__ __noinline__ void call_A(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
   pass_A<NL, WARM, MD>(P, c, O, K, st, st.it == 1, (FootPtr)Kp->foot);
   priv_store(sp, st);
 }
-template <int NL, bool WARM, int MD>
+template <int NL, bool WARM, int MD, bool PAIR = false>
 __device__ __noinline__ bool call_B(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS LaneState* sp) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
@@ -111,7 +111,7 @@ __device__ __noinline__ bool call_B(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
   priv_load(K, Kp);
   LaneState st;
   priv_load(st, (QL_PRIV_AS const LaneState*)sp);
-  const bool ok = pass_B<NL, WARM, MD>(P, c, O, K, st, (FootPtr)Kp->foot);
+  const bool ok = pass_B<NL, WARM, MD, false, PAIR>(P, c, O, K, st, (FootPtr)Kp->foot);
 #if defined(QL_PROFILE)
   priv_store(sp, st);
 #endif
@@ -355,8 +355,9 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
   // every pass runs duplicated on the partner -- a wave64 FP64 instruction issues its four passes whatever the mask -- except the
   // per-point blocks of the trial pass, which the pair splits (pass_C<..., PAIR>).  QMPC_LANE_PAIR=0 restores the masked half.
   constexpr bool kPairable = NL == 4 && MD == MD_QUAT;
-  const bool pairm = kPairable && lanes == -32;      // (the launcher passes -32 for pair mode)
-  if (lanes < 0) lanes = -lanes;
+  const bool pairm = kPairable && lanes <= -32;      // (the launcher passes -32 for pair mode; -33: the trial pass only)
+  const bool pair_b = lanes == -32;
+  if (lanes < 0) lanes = 32;
   const int lane_i = pairm ? (lane & 31) : lane;
   const PassArgs a = {pslot, (unsigned)wsb, (unsigned)(wsb >> 32), 8u * (unsigned)lane_i, u_init ? 1u : 0u,
                       pairm ? (unsigned)(lane >> 5) : 0u, pairm ? 0xF8u : 0x1F8u};
@@ -403,7 +404,9 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
           else if (st.it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
           st.target = sg * st.mu;
           const bool wrows = warm && __any(st.rho != 0.0);
-          if (!(wrows ? call_B<NL, true, MD>(a, Kp, sp) : call_B<NL, false, MD>(a, Kp, sp))) { st.status = QMPC_NOT_PD; active = false; }
+          const bool okB = wrows ? call_B<NL, true, MD>(a, Kp, sp)
+                                 : ((kPairable && pairm && pair_b) ? call_B<NL, false, MD, kPairable>(a, Kp, sp) : call_B<NL, false, MD>(a, Kp, sp));
+          if (!okB) { st.status = QMPC_NOT_PD; active = false; }
           else {
             if (wrows) call_C<NL, true, MD>(a, Kp, sp);
             else if (kPairable && pairm) call_C<NL, false, MD, kPairable>(a, Kp, sp);
@@ -601,7 +604,7 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
   else {
     // half-filled wavefronts of the four-point quaternion model: lane pairs (the kernel reads -32 as "32 instances, pairs")
     static const int pair_env = std::getenv("QMPC_LANE_PAIR") ? std::atoi(std::getenv("QMPC_LANE_PAIR")) : 1;
-    const int lanes_arg = (lanes == 32 && pair_env) ? -32 : lanes;
+    const int lanes_arg = (lanes == 32 && pair_env) ? (pair_env == 2 ? -33 : -32) : lanes;      // QMPC_LANE_PAIR=2: split the trial pass only
     hipLaunchKernelGGL(qmpc_lane_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes_arg, perm, prof,
                        u_init, traj_u, check_prev, traj_x, iter_cap, hcount, hsel, hstate, hcap);
   }

@@ -1005,9 +1005,13 @@ struct LaneAL {
   int searching;            // this lane's line search is still running (its trial increments may be overwritten)
   int sel;                  // which of the pass's two trials was accepted: its increments are in the dU slot (0) or the RC slot (1)
 };
-template <int NL, bool WARM = false, int MD = MD_QUAT, bool AL = false>
+// PAIR (lane pairs, see Ctx and pass_C): the stance points of the wavefront, in ascending order, are taken two at a time -- the
+// first of a round by the lower partner lane, the second by the upper -- and each lane's contribution to wd, r6 and G (30
+// doubles) reaches both partners through v_permlane32_swap, added in the plain form's order (first point, then second).
+template <int NL, bool WARM = false, int MD = MD_QUAT, bool AL = false, bool PAIR = false>
 QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const LaneK<NL>& K, LaneState& st, FootPtr fp,
                   LaneAL* al = nullptr) {
+  static_assert(!PAIR || (MD != MD_CONVEX && !WARM && !AL && NL == 4), "pair split: cold converged passes of the four-point quaternion model");
   Ctx c = c_in;
   typedef LDim<NL> D;
   const int N = P.N;
@@ -1023,7 +1027,23 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
   const unsigned order = any_stance<NL>(st.con);      // at least one bit: the lanes of this call have a stance point
   const bool rcrows = WARM && QL_ANY(st.rho != 0.0);
   LegAheadT<WARM> R;         // rows of the NEXT contact point in processing order
-  fetch_ahead<NL>(c, O, N - 1, first_bit(order), R, fp, rcrows);
+  // pair form: the stance points of the wavefront in ascending order, four bits each (0xF: none)
+  unsigned plist = 0xFFFFu;
+  int pcount = 0;
+  if (PAIR) {
+    plist = 0;
+    for (int l = NL - 1; l >= 0; --l)
+      if ((order >> l) & 1u) { plist = (plist << 4) | (unsigned)l; ++pcount; }
+    plist |= 0xFFFFu << (4 * pcount);
+  }
+  // this lane's point of round r (the upper partner's may not exist: it then idles on the lower one's rows)
+  auto pair_point = [&](int r, bool& exists) {
+    const unsigned pa = (plist >> (8 * r)) & 0xFu, pb = (plist >> (8 * r + 4)) & 0xFu;
+    exists = !(c.half && pb == 0xFu);
+    return (int)((c.half && pb != 0xFu) ? pb : pa);
+  };
+  if (PAIR) { bool ex; fetch_ahead<NL>(c, O, N - 1, pair_point(0, ex), R, fp, rcrows); }
+  else fetch_ahead<NL>(c, O, N - 1, first_bit(order), R, fp, rcrows);
   bool ok = true;
   double dV1 = 0.0;           // AL only
   const double m1 = P.h * (P.hh * (1.0 / P.mass)), m2 = P.h * (1.0 / P.mass);
@@ -1066,6 +1086,86 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
       cone_rows(P, K.rot, cr);
       initial_rows(P, cr, st.uz, s0, rc0);
     }
+    if (PAIR) {
+#pragma unroll
+      for (int rd = 0; rd < NL / 2; ++rd) {
+        if (2 * rd >= pcount) continue;       // wave-uniform
+        bool exists;
+        const int lm = pair_point(rd, exists);
+        const bool on_m = exists && ((st.con >> lm) & 1u);
+        double u[3], sv[6], lv[6], r[3];
+        unsigned kap = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { u[a] = R.u[a]; r[a] = R.foot[a]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          lv[i] = R.lam[i];
+          kap |= (R.s[i] < 0.0) ? (1u << i) : 0u;
+          sv[i] = fabs(R.s[i]);
+        }
+        if (2 * (rd + 1) < pcount) {     // the next round's rows into the registers just copied out
+          bool ex;
+          c.relane();
+          fetch_ahead<NL>(c, O, k, pair_point(rd + 1, ex), R, fp, rcrows);
+        }
+        double wp[3] = {0, 0, 0}, r6p[6] = {0, 0, 0, 0, 0, 0}, G6p[21];
+#pragma unroll
+        for (int i = 0; i < 21; ++i) G6p[i] = 0.0;
+        {
+          double B[9];
+          leg_bw0(P, r, B);
+#pragma unroll
+          for (int a = 0; a < 3; ++a) wp[a] = B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
+          LegBlk lb;
+          leg_block(P, cr, rc0, lm, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
+          double V[18];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) V[i] = lb.T[i];
+          mm(B, lb.T, &V[9]);
+          const double y0 = lb.gq[0], y1 = lb.gq[1] - lb.l10 * y0, y2 = lb.gq[2] - lb.l20 * y0 - lb.l21 * y1;
+          const double z0 = lb.id0 * y0, z1 = lb.id1 * y1, z2 = lb.id2 * y2;
+          double v0[6], v1[6], v2[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            v0[i] = V[3 * i];
+            v1[i] = V[3 * i + 1] - lb.l10 * v0[i];
+            v2[i] = V[3 * i + 2] - lb.l20 * v0[i] - lb.l21 * v1[i];
+            r6p[i] = v0[i] * z0 + v1[i] * z1 + v2[i] * z2;
+          }
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            const double a0 = lb.id0 * v0[i], a1 = lb.id1 * v1[i], a2 = lb.id2 * v2[i];
+#pragma unroll
+            for (int j = i; j < 6; ++j) G6p[S6I(i, j)] = a0 * v0[j] + a1 * v1[j] + a2 * v2[j];
+          }
+        }
+        // both partners add the two points' shares in the plain form's order; a point that is not in stance contributes nothing
+        const unsigned pb_ = (plist >> (8 * rd + 4)) & 0xFu;
+        const bool on_lo = (st.con >> ((plist >> (8 * rd)) & 0xFu)) & 1u, on_hi = pb_ != 0xFu && ((st.con >> (pb_ & 3u)) & 1u);
+        (void)on_m;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          double lo, hi;
+          ql_pair(wp[a], lo, hi);
+          if (on_lo) wd[a] += lo;
+          if (on_hi) wd[a] += hi;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          double lo, hi;
+          ql_pair(r6p[i], lo, hi);
+          if (on_lo) r6[i] += lo;
+          if (on_hi) r6[i] += hi;
+        }
+#pragma unroll
+        for (int i = 0; i < 21; ++i) {
+          double lo, hi;
+          ql_pair(G6p[i], lo, hi);
+          if (on_lo) G6[i] += lo;
+          if (on_hi) G6[i] += hi;
+        }
+      }
+    } else
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       if (!((order >> l) & 1u)) continue;       // wave-uniform
@@ -1524,7 +1624,8 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     QL_FENCE();
     c.relane();
     QL_TICK(st, LP_B_UPD);
-    fetch_ahead<NL>(c, O, kn, first_bit(order), R, fp, rcrows);
+    if (PAIR) { bool ex; fetch_ahead<NL>(c, O, kn, pair_point(0, ex), R, fp, rcrows); }
+    else fetch_ahead<NL>(c, O, kn, first_bit(order), R, fp, rcrows);
     // ---- 6. stage cost of knot k ----
     {
       double lx[12], lxx[6];
