@@ -108,6 +108,7 @@ struct qmpc_handle {
   bool lane_params_resident;   // set while a stream capture repeats launches with unchanged parameters (closed loop)
   bool lane_loop_cold;         // set during a cold-started qmpc_loop_run*: the loop's own switch-over applies
   int lane_min_loop_cold;
+  int lane_min_warm;           // warm-started solves and loop ticks (their lane passes are not pair-split)
   bool lane_order_prev;        // closed loop: d_info holds every robot's previous record -- order the batch by its iteration count too
   int* d_handoff;              // straggler hand-off: count | list of instances the capped lane launch left (on first use)
   double* d_hstate;            // ... and their state records (hstate_cap of them)
@@ -136,12 +137,19 @@ constexpr int kLaneMinLoopCold = 18432;       // ... of the cold-started closed 
 // N=20 16384: 1.03 vs 0.99, 24576: 1.49 vs 1.00 (long horizons run one wave per SIMD on either side).  ConvexMpc and the
 // 8-point model keep the round-1 wave kernels and cross earlier (ConvexMpc N=10 / 20: equal at 16384 / 20480; 8-point
 // 16384: 0.78 vs 0.82 M, 20480: 0.97 vs 0.84 M)
-constexpr int kLaneMinBatch = 26624;          // QuatMpc, horizons up to 12
+// End of round 5: half-filled wavefronts run as lane PAIRS (qmpc_lane.hip: the per-point blocks of the backward and the trial
+// pass split across the partner lanes) and a round of the lane kernel costs 15 % less at every size below 32768 -- cold plain
+// solves and cold loops cross over earlier (tools/lane_switch_scan.py): N=10 12288 instances wave 3.26 vs lane 2.66 M solves/s,
+// 16384: 3.37 vs 3.50, 20480: 3.49 vs 4.32, 24576: 3.54 vs 5.16; N=16 16384: 2.15 vs 2.13, 20480: 2.22 vs 2.59; N=20 16384: 1.62
+// vs 1.59, 20480: 1.66 vs 1.95; N=24 12288: 1.16 vs 0.98, 16384: 1.22 vs 1.25.  Warm-started launches (their passes carry the
+// per-row residuals and are not split) keep the switch-over measured before: kLaneMinWarm*.
+constexpr int kLaneMinWarm = 26624, kLaneMinWarmLong = 21504, kLaneMinWarmVeryLong = 18432;
+constexpr int kLaneMinBatch = 15872;          // QuatMpc, horizons up to 12
 // QuatMpc, longer horizons; round 5 (the wave side is the wrench-form kernel with its slack arrays in the workspace, WVAR 6):
 // N=16 20480: wave 2.20 vs lane 2.15 M solves/s, 24576: 2.23 vs 2.52; N=20 20480: 1.64 vs 1.60, 24576: 1.67 vs 1.90;
 // N=24 16384: 1.20 vs 1.03, 20480: 1.20 vs 1.25
-constexpr int kLaneMinBatchLong = 21504;
-constexpr int kLaneMinBatchVeryLong = 18432;  // horizons beyond 22
+constexpr int kLaneMinBatchLong = 17408;
+constexpr int kLaneMinBatchVeryLong = 16384;  // horizons beyond 22
 constexpr int kLaneMinBatchOther = 18432;      // ConvexMpc, short horizons (round-1 wave kernels below it)
 // ConvexMpc at its own horizon (N=20; WVAR 6 below the threshold): 20480 instances wave 1.21 vs lane 1.11 M, 24576: 1.22 vs 1.29
 constexpr int kLaneMinBatchConvexLong = 22528;
@@ -409,6 +417,8 @@ qmpc_status qmpc_create(const qmpc_params* params, int32_t max_batch, int32_t de
                                                                                                : (N > 12 ? kLaneMinBatchConvexLong : kLaneMinBatchOther)));
     // (warm-started solves share the plain solve's variants and switch-over; the cold-started loop's in-gait states switch earlier)
     h->lane_min_loop_cold = lm ? h->lane_min_batch : (kLaneMinLoopCold < h->lane_min_batch ? kLaneMinLoopCold : h->lane_min_batch);
+    h->lane_min_warm = (lm || params->model != QMPC_MODEL_QUAT) ? h->lane_min_batch
+                                                                : (N <= 12 ? kLaneMinWarm : (N <= 22 ? kLaneMinWarmLong : kLaneMinWarmVeryLong));
     // Straggler hand-off (cold plain solves of QuatMpc's problem on the lane kernel): a launch of the lane kernel lasts as
     // long as its slowest instance -- 23 interior-point iterations at N=10 (mean 13.6), 31 at N=20 (mean 14.6) -- while
     // only 8 % / 10 % of the instances are still running after 16 / 17.  The lane kernel stops there, leaves the state of
@@ -495,11 +505,11 @@ static bool use_global_gains(const qmpc_handle* h, int32_t batch) { return pick_
 // Large batches of the converged mode go to the lane-per-instance kernel (qmpc_lane.hip): one lane per instance, the
 // working set streamed through a structure-of-arrays HBM workspace sized by the RESIDENT lanes (<= 1024 wavefronts).
 // It returns forces, info and (on request) the input and state trajectories.
-static bool use_lane(const qmpc_handle* h, int32_t batch, const double* d_tu, const double* d_tx) {
+static bool use_lane(const qmpc_handle* h, int32_t batch, const double* d_tu, const double* d_tx, bool warm = false) {
   (void)d_tu; (void)d_tx;
   if (h->params.mode != QMPC_MODE_CONVERGED || h->lane_pslot < 0) return false;
   if (h->variant == 4) return true;
-  return h->variant == 0 && batch >= (h->lane_loop_cold ? h->lane_min_loop_cold : h->lane_min_batch);
+  return h->variant == 0 && batch >= (warm ? h->lane_min_warm : (h->lane_loop_cold ? h->lane_min_loop_cold : h->lane_min_batch));
 }
 // workspace of the lane kernel, allocated at first use (never inside a stream capture: qmpc_loop_run calls this first)
 static qmpc_status ensure_lane_buffers(qmpc_handle* h) {
@@ -959,7 +969,7 @@ qmpc_status qmpc_solve_warm_device(qmpc_handle* h, int32_t batch, const qmpc_inp
   if (batch == 0) return QMPC_OK;
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
   HIP_TRY(hipSetDevice(h->device));
-  if (use_lane(h, batch, nullptr, nullptr))      // large batches: the lane-per-instance kernel, same start rule
+  if (use_lane(h, batch, nullptr, nullptr, true))      // large batches: the lane-per-instance kernel, same start rule
     return launch_lane(h, batch, d_in, d_forces_body, d_info, stream ? (hipStream_t)stream : h->stream, d_u_init, d_traj_u, 0);
   const int var = body_variant(h, batch);
   HIP_TRY(qmpc_warm_launch(var, 0, (int)batch, variant_lds(h, var), stream ? (hipStream_t)stream : h->stream, &h->dev, sizeof h->dev, d_in, d_u_init,
@@ -1461,7 +1471,7 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
     else
       hipLaunchKernelGGL(qmpc_loop_front_kernel, dim3(blocks), dim3(64), 0, s, LP, d_states, h->d_in, h->d_loop_row, (int)batch);
     HIP_TRY(hipGetLastError());
-    if (warm && use_lane(h, batch, nullptr, nullptr)) {
+    if (warm && use_lane(h, batch, nullptr, nullptr, true)) {
       // straggler hand-off of the warm-started ticks (not the cold first one): the records carry the rows' initial residuals
       const int wcap = (!first && h->d_handoff) ? handoff_cap(h, 3) : 0;
       const int wv = wcap ? handoff_variant(h) : 0;
@@ -1533,7 +1543,7 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
     ~ResidentGuard() { h->lane_params_resident = false; h->lane_order_prev = false; h->lane_loop_cold = false; }
   } resident_guard{h};
   h->lane_loop_cold = !warm;
-  if (use_lane(h, batch, nullptr, nullptr)) {
+  if (use_lane(h, batch, nullptr, nullptr, warm)) {
     const qmpc_status es = ensure_lane_buffers(h);
     if (es != QMPC_OK) return es;
     HIP_TRY(qmpc_lane_upload_params(h->lane_pslot, s, &h->dev, sizeof h->dev));
