@@ -404,8 +404,11 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
           else if (st.it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
           st.target = sg * st.mu;
           const bool wrows = warm && __any(st.rho != 0.0);
+          // (the warm instantiations are not split: a pair-split warm trial pass did not reproduce the plain form's bits --
+          // test_lane_kernel_warm_and_convex_beyond_the_resident_lanes -- and was withdrawn; profiles/HISTORY_r05.md 13)
+          const bool pb = kPairable && pairm && pair_b;
           const bool okB = wrows ? call_B<NL, true, MD>(a, Kp, sp)
-                                 : ((kPairable && pairm && pair_b) ? call_B<NL, false, MD, kPairable>(a, Kp, sp) : call_B<NL, false, MD>(a, Kp, sp));
+                                 : (pb ? call_B<NL, false, MD, kPairable>(a, Kp, sp) : call_B<NL, false, MD>(a, Kp, sp));
           if (!okB) { st.status = QMPC_NOT_PD; active = false; }
           else {
             if (wrows) call_C<NL, true, MD>(a, Kp, sp);

@@ -1011,7 +1011,7 @@ struct LaneAL {
 template <int NL, bool WARM = false, int MD = MD_QUAT, bool AL = false, bool PAIR = false>
 QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const LaneK<NL>& K, LaneState& st, FootPtr fp,
                   LaneAL* al = nullptr) {
-  static_assert(!PAIR || (MD != MD_CONVEX && !WARM && !AL && NL == 4), "pair split: cold converged passes of the four-point quaternion model");
+  static_assert(!PAIR || (MD != MD_CONVEX && !AL && NL == 4), "pair split: converged passes of the four-point quaternion model");
   Ctx c = c_in;
   typedef LDim<NL> D;
   const int N = P.N;
@@ -1097,6 +1097,9 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
         unsigned kap = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) { u[a] = R.u[a]; r[a] = R.foot[a]; }
+        double rcl[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rcl[i] = rcrows ? R.rc[i] : rc0[i];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
           lv[i] = R.lam[i];
@@ -1117,7 +1120,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
 #pragma unroll
           for (int a = 0; a < 3; ++a) wp[a] = B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
           LegBlk lb;
-          leg_block(P, cr, rc0, lm, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
+          leg_block(P, cr, rcl, lm, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
           double V[18];
 #pragma unroll
           for (int i = 0; i < 9; ++i) V[i] = lb.T[i];
@@ -1734,11 +1737,11 @@ QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr
 // PAIR (lane pairs, see Ctx): the two points of a pair are worked on by the two partner lanes -- one leg_compute_C per lane
 // instead of two -- and what the state step needs of both (force and torque sums) is exchanged per knot; the step-length
 // candidates are combined once, at the end of the pass.  Both partner lanes add the two shares in the plain form's order,
-// (F + a) + b, so a pair-mode launch returns the bits of a plain one (the multiplier ratio, tracked per lane and combined at
-// the end, could differ from the plain form's running maximum only between two rows whose ratios tie exactly).
+// (F + a) + b, and scan the two points' multiplier-ratio candidates in its order too (a running maximum compared by
+// cross-multiplication picks among near-equal rows by position): a pair-mode launch returns the bits of a plain one.
 template <int NL, bool WARM = false, int MD = MD_QUAT, bool PAIR = false>
 QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st, FootPtr fp) {
-  static_assert(!PAIR || (MD != MD_CONVEX && !WARM), "pair split: cold passes of the quaternion model");
+  static_assert(!PAIR || MD != MD_CONVEX, "pair split: the quaternion model");
   typedef LDim<NL> D;
   const int N = P.N;
   const double gb[3] = {K.rot[6] * (-9.81), K.rot[7] * (-9.81), K.rot[8] * (-9.81)};
@@ -1866,9 +1869,14 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
             ql_pair(tm[a], lo, hi);
             wd[a] = (wd[a] + lo) + hi;
           }
-          if (on_m) {
-            rp = fmax(rp, om.rp); stp = fmax(stp, om.stp); bad = bad || om.bad;
-            const bool better = om.dn * ddA > dnA * om.dd; dnA = better ? om.dn : dnA; ddA = better ? om.dd : ddA;      // (this lane's own points)
+          if (on_m) { rp = fmax(rp, om.rp); stp = fmax(stp, om.stp); bad = bad || om.bad; }
+          {     // the multiplier ratio is a running maximum compared by cross-multiplication: its winner among near-equal rows
+                // depends on the order of the scan, so both partners scan the two points' candidates in the plain form's order
+            double alo, ahi, blo, bhi;
+            ql_pair(on_m ? om.dn : 0.0, alo, ahi);
+            ql_pair(on_m ? om.dd : 1.0, blo, bhi);
+            { const bool better = alo * ddA > dnA * blo; dnA = better ? alo : dnA; ddA = better ? blo : ddA; }
+            { const bool better = ahi * ddA > dnA * bhi; dnA = better ? ahi : dnA; ddA = better ? bhi : ddA; }
           }
         }
       } else
@@ -1918,8 +1926,6 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     ql_pair(rp, lo, hi); rp = fmax(lo, hi);
     ql_pair(stp, lo, hi); stp = fmax(lo, hi);
     ql_pair(bad ? 1.0 : 0.0, lo, hi); bad = (lo != 0.0) || (hi != 0.0);
-    ql_pair(dnA, lo, hi); dnA = lo; dnB = hi;
-    ql_pair(ddA, lo, hi); ddA = lo; ddB = hi;
   }
   double dn = dnA, dd = ddA;
   { const bool better = dnB * dd > dn * ddB; dn = better ? dnB : dn; dd = better ? ddB : dd; }
