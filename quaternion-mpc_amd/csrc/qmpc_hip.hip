@@ -141,9 +141,10 @@ constexpr int kLaneMinLoopCold = 18432;       // ... of the cold-started closed 
 // pass split across the partner lanes) and a round of the lane kernel costs 15 % less at every size below 32768 -- cold plain
 // solves and cold loops cross over earlier (tools/lane_switch_scan.py): N=10 12288 instances wave 3.26 vs lane 2.66 M solves/s,
 // 16384: 3.37 vs 3.50, 20480: 3.49 vs 4.32, 24576: 3.54 vs 5.16; N=16 16384: 2.15 vs 2.13, 20480: 2.22 vs 2.59; N=20 16384: 1.62
-// vs 1.59, 20480: 1.66 vs 1.95; N=24 12288: 1.16 vs 0.98, 16384: 1.22 vs 1.25.  Warm-started launches (their passes carry the
-// per-row residuals and are not split) keep the switch-over measured before: kLaneMinWarm*.
-constexpr int kLaneMinWarm = 26624, kLaneMinWarmLong = 21504, kLaneMinWarmVeryLong = 18432;
+// vs 1.59, 20480: 1.66 vs 1.95; N=24 12288: 1.16 vs 0.98, 16384: 1.22 vs 1.25.  Warm-started launches have their own switch-over: kLaneMinWarm*.
+// (with the warm instantiations of the split passes, warm-started loops, lane vs wave kernels: N=10 16384 robots 7.13 vs 7.70 M
+// robot-ticks/s, 20480: 8.59 vs 7.84, 24576: 9.95 vs 7.98, 32768: 12.1 vs 8.2; N=20 16384: 3.68 vs 4.19, 24576: 5.19 vs 4.31)
+constexpr int kLaneMinWarm = 18432, kLaneMinWarmLong = 20480, kLaneMinWarmVeryLong = 18432;
 constexpr int kLaneMinBatch = 15872;          // QuatMpc, horizons up to 12
 // QuatMpc, longer horizons; round 5 (the wave side is the wrench-form kernel with its slack arrays in the workspace, WVAR 6):
 // N=16 20480: wave 2.20 vs lane 2.15 M solves/s, 24576: 2.23 vs 2.52; N=20 20480: 1.64 vs 1.60, 24576: 1.67 vs 1.90;

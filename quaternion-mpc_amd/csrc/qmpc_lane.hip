@@ -355,8 +355,9 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
   // every pass runs duplicated on the partner -- a wave64 FP64 instruction issues its four passes whatever the mask -- except the
   // per-point blocks of the trial pass, which the pair splits (pass_C<..., PAIR>).  QMPC_LANE_PAIR=0 restores the masked half.
   constexpr bool kPairable = NL == 4 && MD == MD_QUAT;
-  const bool pairm = kPairable && lanes <= -32;      // (the launcher passes -32 for pair mode; -33: the trial pass only)
-  const bool pair_b = lanes == -32;
+  const bool pairm = kPairable && lanes <= -32;      // (the launcher passes -34 for pair mode; -33: the trial pass of cold rounds only; -32: cold rounds only)
+  const bool pair_b = lanes == -32 || lanes == -34;
+  const bool pair_w = lanes == -34;
   if (lanes < 0) lanes = 32;
   const int lane_i = pairm ? (lane & 31) : lane;
   const PassArgs a = {pslot, (unsigned)wsb, (unsigned)(wsb >> 32), 8u * (unsigned)lane_i, u_init ? 1u : 0u,
@@ -404,14 +405,13 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
           else if (st.it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
           st.target = sg * st.mu;
           const bool wrows = warm && __any(st.rho != 0.0);
-          // (the warm instantiations are not split: a pair-split warm trial pass did not reproduce the plain form's bits --
-          // test_lane_kernel_warm_and_convex_beyond_the_resident_lanes -- and was withdrawn; profiles/HISTORY_r05.md 13)
+          // (the warm instantiations are split too since rho * rc reaches its sums rounded in every instantiation: ql_rounded)
           const bool pb = kPairable && pairm && pair_b;
-          const bool okB = wrows ? call_B<NL, true, MD>(a, Kp, sp)
+          const bool okB = wrows ? ((pb && pair_w) ? call_B<NL, true, MD, kPairable>(a, Kp, sp) : call_B<NL, true, MD>(a, Kp, sp))
                                  : (pb ? call_B<NL, false, MD, kPairable>(a, Kp, sp) : call_B<NL, false, MD>(a, Kp, sp));
           if (!okB) { st.status = QMPC_NOT_PD; active = false; }
           else {
-            if (wrows) call_C<NL, true, MD>(a, Kp, sp);
+            if (wrows) { if (kPairable && pairm && pair_w) call_C<NL, true, MD, kPairable>(a, Kp, sp); else call_C<NL, true, MD>(a, Kp, sp); }
             else if (kPairable && pairm) call_C<NL, false, MD, kPairable>(a, Kp, sp);
             else call_C<NL, false, MD>(a, Kp, sp);
             if (st.bad_step) { st.status = QMPC_NOT_PD; active = false; }     // a non-finite trial step is not applied
@@ -607,7 +607,7 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
   else {
     // half-filled wavefronts of the four-point quaternion model: lane pairs (the kernel reads -32 as "32 instances, pairs")
     static const int pair_env = std::getenv("QMPC_LANE_PAIR") ? std::atoi(std::getenv("QMPC_LANE_PAIR")) : 1;
-    const int lanes_arg = (lanes == 32 && pair_env) ? (pair_env == 2 ? -33 : -32) : lanes;      // QMPC_LANE_PAIR=2: split the trial pass only
+    const int lanes_arg = (lanes == 32 && pair_env) ? (pair_env == 2 ? -33 : (pair_env == 4 ? -32 : -34)) : lanes;      // 4: cold rounds only      // QMPC_LANE_PAIR=2: split the trial pass only
     hipLaunchKernelGGL(qmpc_lane_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes_arg, perm, prof,
                        u_init, traj_u, check_prev, traj_x, iter_cap, hcount, hsel, hstate, hcap);
   }

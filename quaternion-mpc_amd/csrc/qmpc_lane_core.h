@@ -57,6 +57,15 @@
 namespace qmpc {
 namespace lane {
 
+// a product that must reach its consumer ROUNDED (never contracted into the add that follows): whether the compiler fuses
+// rho * rc into a neighbouring sum depends on how many uses the product has in the surrounding code, i.e. on the
+// instantiation -- the plain and the pair-split warm passes differed by one rounding there
+QL_FN double ql_rounded(double x) {
+#if QL_DEVICE
+  asm volatile("" : "+v"(x));
+#endif
+  return x;
+}
 QL_FN double ql_rcp(double x) {
 #if QL_DEVICE
   double r = __builtin_amdgcn_rcp(x);
@@ -502,7 +511,7 @@ QL_FN void leg_block(const DevParams& P, const double cr[18], const double rc0[6
   for (int i = 0; i < 6; ++i) {
     const double is = ql_rcp(sv[i]);
     o.is[i] = is;
-    const double rc = rho * rc0[i];
+    const double rc = ql_rounded(rho * rc0[i]);
     w[i] = lv[i] * is;
     gi[i] = (target + lv[i] * rc) * is - (((kap >> i) & 1u) ? lv[i] : 0.0);
   }
@@ -882,7 +891,7 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
         for (int i = 0; i < 6; ++i) {
           const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
           const double kp = ((kap >> i) & 1u) ? 1.0 : 0.0;
-          const double dsv = -(jd + st.rho * rcl[i]);
+          const double dsv = -(jd + ql_rounded(st.rho * rcl[i]));
           const double dlv = (st.target - (1.0 + kp) * sv[i] * lv[i] - lv[i] * dsv) * ql_rcp(sv[i]);
           const double s1 = sv[i] + ap * dsv;
           const double l1 = lv[i] + ad * dlv;
@@ -1723,7 +1732,7 @@ QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr
   for (int i = 0; i < 6; ++i) {
     const double jd = cr[3 * i] * o.du[0] + cr[3 * i + 1] * o.du[1] + cr[3 * i + 2] * o.du[2];
     const double kp = ((kap >> i) & 1u) ? 1.0 : 0.0;
-    const double dsv = -(jd + st.rho * rc0[i]);
+    const double dsv = -(jd + ql_rounded(st.rho * rc0[i]));
     const double dlv = (st.target - (1.0 + kp) * sv[i] * lv[i] - lv[i] * dsv) * lb.is[i];
     rp = fmax(rp, -dsv * lb.is[i]);
     const bool better = (-dlv) * dd > dn * lv[i];       // -dlam_i / lam_i > dn / dd   (lam_i, dd > 0)

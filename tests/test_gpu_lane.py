@@ -456,7 +456,7 @@ def test_closed_loop_hand_off_of_the_lane_kernels_stragglers(pkg, lib, monkeypat
     # warm = 1: the warm-started loop (cap 8; the records carry the rows' initial slack residuals), low cap 4
     lp = pkg.default_loop_params(lib)
     lp.warm_start = float(warm)
-    B = 28672 if (warm and N == 10) else 20480          # the warm-started loop takes the lane kernel from 26624 robots on at N <= 12
+    B = 28672 if (warm and N == 10) else 20480          # (the warm-started loop takes the lane kernel from 18432 robots on at N <= 12, 20480 beyond)
     env, low = ("QMPC_LANE_CAP_WARM", "4") if warm else ("QMPC_LANE_CAP_LOOP", "8")
     rng = np.random.default_rng(5)
     cmds = np.zeros((B, 7))
