@@ -243,7 +243,7 @@ qmpc_status qmpc_solve_warm_device(qmpc_handle* h, int32_t batch, const qmpc_inp
  * Which kernel runs is chosen from the batch size (converged mode; QuatMpc N <= 12: everything in LDS up to 1024
  * instances, gains in a workspace up to 15871, from 15872 on one LANE per instance -- a lane PAIR while the batch fills only
  * half of every wavefront -- with the stragglers handed back to the wave kernel; N = 13 .. 22: the lane kernel from 17408;
- * warm-started launches: 26624 / 21504; the thresholds of the other models are in qmpc_hip.hip, and
+ * warm-started launches: 18432 / 20480; the thresholds of the other models are in qmpc_hip.hip, and
  * qmpc_query(QMPC_QUERY_KERNEL_FOR_BATCH) answers for a given handle).  The kernel families solve the same
  * problem to the same KKT point but round differently: forces agree to ~1e-10 N across a threshold (tested to 1e-7 N),
  * bit for bit within a family and for a shard of a batch against the whole batch.  Their device buffers are allocated on
