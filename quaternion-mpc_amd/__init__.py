@@ -434,6 +434,26 @@ def loop_states(commands, lp: LoopParams | None = None, height: float = 0.3, yaw
     return out
 
 
+class _PinnedBlock:
+    """Owner of one qmpc_host_alloc allocation.  numpy arrays made from it (np.asarray and any view) keep it alive through
+    their base chain; the memory is returned (qmpc_host_free) when the last of them is gone -- independent of any Solver."""
+
+    def __init__(self, lib, nbytes: int):
+        self._lib = lib
+        self.ptr = lib.qmpc_host_alloc(nbytes)
+        if not self.ptr:
+            raise MemoryError("qmpc_host_alloc")
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(self.ptr), False), "version": 3}
+
+    def __del__(self):
+        try:                      # the library may already be gone at interpreter shutdown
+            if self.ptr:
+                self._lib.qmpc_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
 class Solver:
     """Thin RAII wrapper over a qmpc_handle (one per GPU, single caller)."""
 
@@ -465,7 +485,6 @@ class Solver:
         self.params = params.copy()
         self.max_batch = int(max_batch)
         self._h = C.c_void_p()
-        self._pinned = []
         st = self.lib.qmpc_create(C.byref(self.params), self.max_batch, device, C.byref(self._h))
         if st != OK:
             self._h = C.c_void_p()
@@ -476,9 +495,6 @@ class Solver:
         if h is not None and h.value:
             self._h = None
             self.lib.qmpc_destroy(h)
-        for p in getattr(self, "_pinned", []):
-            self.lib.qmpc_host_free(p)
-        self._pinned = []
 
     def __del__(self):
         try:                      # module globals may already be gone at interpreter shutdown
@@ -527,19 +543,34 @@ class Solver:
         return KERNEL_FAMILY[self.query(QUERY_KERNEL_FOR_BATCH, batch)]
 
     def pinned(self, shape, dtype=np.float64) -> np.ndarray:
-        """Array in pinned, device-addressable host memory (qmpc_host_alloc); freed with the solver."""
+        """Array in pinned, device-addressable host memory (qmpc_host_alloc).  The allocation lives as long as the array
+        (or any view of it) does -- not as long as the solver: it is freed when the last reference goes away."""
         dt = np.dtype(dtype)
-        n = int(np.prod(shape)) * dt.itemsize
-        p = self.lib.qmpc_host_alloc(max(n, 1))
-        if not p:
-            raise MemoryError("qmpc_host_alloc")
-        self._pinned.append(p)
-        buf = (C.c_char * max(n, 1)).from_address(p)
-        return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+        count = int(np.prod(shape))
+        block = _PinnedBlock(self.lib, max(count * dt.itemsize, 1))
+        return np.asarray(block)[:count * dt.itemsize].view(dt).reshape(shape)      # base chain -> block
+
+    def _check_out(self, name: str, a: np.ndarray, dtype, rows: int, cols: int | None):
+        if not isinstance(a, np.ndarray) or not a.flags.c_contiguous or not a.flags.writeable:
+            raise ValueError(f"{name}: a writable C-contiguous numpy array is required")
+        if a.dtype != np.dtype(dtype):
+            raise ValueError(f"{name}: dtype {a.dtype}, expected {np.dtype(dtype)}")
+        need = rows * (cols if cols else 1)
+        if a.size < need or (cols and a.ndim == 2 and a.shape[1] != cols):
+            raise ValueError(f"{name}: shape {a.shape} cannot hold [{rows}" + (f", {cols}]" if cols else "]"))
 
     def solve_into(self, inputs: np.ndarray, forces: np.ndarray, info: np.ndarray | None = None):
-        """qmpc_solve on caller-owned buffers (no allocation, no conversion): the call a C host makes."""
-        st = self.lib.qmpc_solve(self._h, inputs.shape[0], _ptr(inputs), _ptr(forces), _ptr(info) if info is not None else None)
+        """qmpc_solve on caller-owned buffers (no allocation, no conversion): the call a C host makes.  The buffers are
+        checked (layout, element type, room for the batch): the kernel writes through raw pointers."""
+        if not isinstance(inputs, np.ndarray) or not inputs.flags.c_contiguous:
+            raise ValueError("inputs: a C-contiguous numpy array is required")
+        B = inputs.shape[0]
+        if inputs.nbytes != B * INPUT_DTYPE.itemsize:
+            raise ValueError(f"inputs: {inputs.nbytes} bytes for {B} records of {INPUT_DTYPE.itemsize} bytes")
+        self._check_out("forces", forces, np.float64, B, NU)
+        if info is not None:
+            self._check_out("info", info, INFO_DTYPE, B, None)
+        st = self.lib.qmpc_solve(self._h, B, _ptr(inputs), _ptr(forces), _ptr(info) if info is not None else None)
         if st != OK:
             raise QmpcError(st, "qmpc_solve")
 

@@ -127,6 +127,8 @@ struct qmpc_handle {
   unsigned char* h_stage_out;  // [max_batch] (forces | info)
   int zero_copy;               // env QMPC_ZERO_COPY (default 1)
   struct { double* forces; qmpc_info* info; size_t fbytes, ibytes; } pending;   // copy-out owed to a pageable caller (qmpc_wait)
+  int stage_in_busy;           // a non-blocking zero-copy launch may still be READING its records from h_stage_in: the staging is
+                               // not refilled before the stream has drained (qmpc_solve_async with a pageable `in`, pinned outputs)
 };
 
 constexpr unsigned kLaneMaxSlots = 1024 * 64;   // one wavefront per SIMD of the chip
@@ -852,6 +854,7 @@ qmpc_status qmpc_wait(qmpc_handle* h) {
   if (h->timed) HIP_TRY(hipEventSynchronize(h->ev1));
   HIP_TRY(hipStreamSynchronize(h->stream));
   finish_pending(h);          // zero-copy host call into pageable buffers: the copy-out it still owes
+  h->stage_in_busy = 0;
   return QMPC_OK;
 }
 
@@ -910,9 +913,12 @@ static qmpc_status solve_host(qmpc_handle* h, int32_t batch, const qmpc_input* i
   if (batch == 0) return QMPC_OK;
   if (batch > h->max_batch) return QMPC_BATCH_TOO_LARGE;
   HIP_TRY(hipSetDevice(h->device));
-  if (h->pending.forces || h->pending.info) {      // an earlier qmpc_solve_async was never waited for: complete it first
+  // an earlier qmpc_solve_async was never waited for: complete it first -- it owes a pageable caller its copy-out, or its
+  // kernel may still be reading records out of the staging this call is about to refill
+  if (h->pending.forces || h->pending.info || h->stage_in_busy) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     finish_pending(h);
+    h->stage_in_busy = 0;
   }
   const int N = h->params.horizon;
   const int nl = model_nl(model), nu = 3 * nl;
@@ -946,6 +952,8 @@ static qmpc_status solve_host(qmpc_handle* h, int32_t batch, const qmpc_input* i
       if (blocking) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         finish_pending(h);
+      } else if (!in_pinned) {
+        h->stage_in_busy = 1;
       }
       return QMPC_OK;
     }

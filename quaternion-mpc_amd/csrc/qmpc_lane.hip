@@ -89,7 +89,7 @@ __device__ __noinline__ void call_setup(PassArgs a, unsigned long long rec, unsi
   priv_store(Kp, K);
   priv_store(sp, st);
 }
-template <int NL, bool WARM, int MD>
+template <int NL, bool WARM, int MD, bool PAIR = false>
 __device__ __noinline__ void call_A(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS LaneState* sp) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
@@ -99,7 +99,7 @@ __device__ __noinline__ void call_A(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
   LaneState st;
   priv_load(st, (QL_PRIV_AS const LaneState*)sp);
   st.it += 1;
-  pass_A<NL, WARM, MD>(P, c, O, K, st, st.it == 1, (FootPtr)Kp->foot);
+  pass_A<NL, WARM, MD, PAIR>(P, c, O, K, st, st.it == 1, (FootPtr)Kp->foot);
   priv_store(sp, st);
 }
 template <int NL, bool WARM, int MD, bool PAIR = false>
@@ -350,7 +350,14 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
   // the launcher hands them to the wave-per-instance kernel (straggler hand-off, qmpc_hip.hip)
   const int itmax = (iter_cap > 0 && iter_cap < P.iterations_max) ? iter_cap : P.iterations_max;
   const size_t block_elems = (size_t)make_wsoff<NL>(P.N).total * kLaneWave;
+#if defined(QL_DIAG_ALIAS)
+  // diagnostic builds only (tools/lane_variants.py, profiles/r06_lane_traffic_bound.txt): every wavefront of an XCD works in
+  // ONE workspace block, so every access hits that XCD's L2 -- the results are garbage, the instruction stream is not
+  // (QL_DIAG_ROUNDS fixes the control flow)
+  const unsigned long long wsb = reinterpret_cast<unsigned long long>(ws + (size_t)(blockIdx.x % QL_DIAG_ALIAS) * block_elems);
+#else
   const unsigned long long wsb = reinterpret_cast<unsigned long long>(ws + (size_t)blockIdx.x * block_elems);
+#endif
   // Lane pairs (four-point quaternion model, batches that fill half of every wavefront): lanes i and i + 32 take the SAME instance;
   // every pass runs duplicated on the partner -- a wave64 FP64 instruction issues its four passes whatever the mask -- except the
   // per-point blocks of the trial pass, which the pair splits (pass_C<..., PAIR>).  QMPC_LANE_PAIR=0 restores the masked half.
@@ -387,13 +394,44 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_kernel(int pslot, const d
     st.last = clock64();
     int rounds = 0;
 #endif
+#if defined(QL_DIAG_ROUNDS)
+    // diagnostic builds only: a FIXED number of rounds whatever the iterates do (no convergence test, no failure exit), so
+    // that variants whose data are garbage (aliased workspace, elided stores) run the instruction stream of a real launch
+    for (int round = 0; round < QL_DIAG_ROUNDS; ++round) {
+      if (active) {
+        if (warm && __any(st.rho != 0.0)) {
+          if (kPairable && pairm && pair_b && pair_w) call_A<NL, true, MD, kPairable>(a, Kp, sp); else call_A<NL, true, MD>(a, Kp, sp);
+        } else if (kPairable && pairm && pair_b) call_A<NL, false, MD, kPairable>(a, Kp, sp);
+        else call_A<NL, false, MD>(a, Kp, sp);
+        double sg = P.sigma;
+        const double amin = fmin(st.last_ap, st.last_ad);
+        if (st.it > 1 && amin >= 0.99) sg = P.sigma_fast;
+        else if (st.it > 1 && amin < 0.2) sg = fmax(sg, 0.8);
+        else if (st.it > 1 && amin < 0.5) sg = fmax(sg, 0.5);
+        st.target = sg * st.mu;
+        const bool wrows = warm && __any(st.rho != 0.0);
+        const bool pb = kPairable && pairm && pair_b;
+        if (wrows) { if (pb && pair_w) call_B<NL, true, MD, kPairable>(a, Kp, sp); else call_B<NL, true, MD>(a, Kp, sp); }
+        else if (pb) call_B<NL, false, MD, kPairable>(a, Kp, sp);
+        else call_B<NL, false, MD>(a, Kp, sp);
+        if (wrows) { if (kPairable && pairm && pair_w) call_C<NL, true, MD, kPairable>(a, Kp, sp); else call_C<NL, true, MD>(a, Kp, sp); }
+        else if (kPairable && pairm) call_C<NL, false, MD, kPairable>(a, Kp, sp);
+        else call_C<NL, false, MD>(a, Kp, sp);
+      }
+    }
+    if (active) { st.status = QMPC_OK; active = false; }
+#endif
     while (__any(active)) {
       if (active) {
         // one interior-point iteration (the control flow of lane_iteration in qmpc_lane_core.h)
         // The warm instantiations of the passes (per-row initial residuals travelling with the rows) are needed only while
         // some lane still carries a slack residual: rho is exactly 0 after a lane's first full step, and from then on the
         // cold passes compute the same thing with fewer registers (their rc0 is multiplied by rho = 0).
-        if (warm && __any(st.rho != 0.0)) call_A<NL, true, MD>(a, Kp, sp); else call_A<NL, false, MD>(a, Kp, sp);
+        // (the apply pass is split across the lane pair wherever the backward pass is: QMPC_LANE_PAIR)
+        if (warm && __any(st.rho != 0.0)) {
+          if (kPairable && pairm && pair_b && pair_w) call_A<NL, true, MD, kPairable>(a, Kp, sp); else call_A<NL, true, MD>(a, Kp, sp);
+        } else if (kPairable && pairm && pair_b) call_A<NL, false, MD, kPairable>(a, Kp, sp);
+        else call_A<NL, false, MD>(a, Kp, sp);
         const double resid = st.rho * st.rcmax;
         if (st.mu <= P.mu_final && resid <= P.tol_feas && st.last_step <= P.tol_step) { st.status = QMPC_OK; active = false; }
         else if (st.it > itmax) { st.status = QMPC_MAX_ITER; active = false; }

@@ -41,6 +41,7 @@
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "qmpc_params_dev.h"
 
@@ -65,6 +66,16 @@ QL_FN double ql_rounded(double x) {
   asm volatile("" : "+v"(x));
 #endif
   return x;
+}
+// a value the caller knows to be wave-uniform, pinned to scalar registers: a per-lane choice between two such values then
+// stays a choice between VALUES (the compiler otherwise turns `cond ? p[i] : p[j]` into one vector load through a chosen address)
+QL_FN double ql_uniform(double x) {
+#if QL_DEVICE
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+#else
+  return x;
+#endif
 }
 QL_FN double ql_rcp(double x) {
 #if QL_DEVICE
@@ -178,6 +189,26 @@ struct Ctx {
   QL_FN QL_GLOBAL_AS double& W(int e) const {
     return *reinterpret_cast<QL_GLOBAL_AS double*>(reinterpret_cast<QL_GLOBAL_AS char*>(ws) + ((unsigned)e * wrow + woff));
   }
+  // store of a pass (the hot sweeps A / B / C): the same instruction as `W(e) = v`.  Diagnostic builds
+  // (-DQL_DIAG_NOSTORE, tools/lane_variants.py: the traffic-bound experiment of profiles/r06_lane_traffic_bound.txt)
+  // keep the value alive and drop the store.
+  QL_FN void St(int e, double v) const {
+#if defined(QL_DIAG_NOSTORE) && QL_DEVICE
+    asm volatile("" ::"v"(v));
+#elif defined(QL_PAIR_ST_LOWER) && QL_DEVICE
+    if (!half) W(e) = v;      // pair mode: the partner lanes' copies of a duplicated pass carry the same values to the same addresses
+#else
+    W(e) = v;
+#endif
+  }
+  // a store that is this lane's OWN in pair mode (the split trial pass: each partner writes its point's increments)
+  QL_FN void StOwn(int e, double v) const {
+#if defined(QL_DIAG_NOSTORE) && QL_DEVICE
+    asm volatile("" ::"v"(v));
+#else
+    W(e) = v;
+#endif
+  }
   QL_FN QL_LDS_AS double& PL(int i) const {
     return *reinterpret_cast<QL_LDS_AS double*>(reinterpret_cast<QL_LDS_AS char*>(pl) + ((unsigned)i * prow + poff));
   }
@@ -218,6 +249,20 @@ QL_FN void ql_pair(double x, double& lo, double& hi) {
 }
 #else
 QL_FN void ql_pair(double x, double& lo, double& hi) { lo = x; hi = x; }
+#endif
+// scheduling barrier: the instruction scheduler moves nothing across it (two unrolled per-point blocks whose temporaries
+// would otherwise be live together)
+#if QL_DEVICE && !defined(QL_NO_SCHED_BARRIER)
+#define QL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define QL_SCHED_BARRIER() do { } while (0)
+#endif
+// wait until no vector-memory operation of the wavefront is in flight (s_waitcnt vmcnt(0); gfx9 encoding: vmcnt in bits
+// 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima = no wait)
+#if QL_DEVICE
+#define QL_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
+#else
+#define QL_WAIT_VMEM() do { } while (0)
 #endif
 #if QL_DEVICE && !defined(QL_NO_FENCE)
 #define QL_FENCE() asm volatile("" ::: "memory")
@@ -504,8 +549,12 @@ struct LegBlk {
   double gq[3];                 // T' g_l
   double is[6];                 // 1 / s_i (the directions of pass C divide by the slacks again)
 };
+// Rw: the point's three input weights when the CALLER has them (the pair forms, where the point index differs between the
+// partner lanes: indexing P.R per lane is a vector load -- in flight together with the prefetches, and waiting for it is waiting
+// for them); null: P.R[3 (l mod 4) ..] with a wave-uniform l (scalar loads)
 QL_FN void leg_block(const DevParams& P, const double cr[18], const double rc0[6], int l, const double sv[6],
-                     const double lv[6], unsigned kap, double rho, double target, const double u[3], double uz, LegBlk& o) {
+                     const double lv[6], unsigned kap, double rho, double target, const double u[3], double uz, LegBlk& o,
+                     const double* Rw = nullptr) {
   double w[6], gi[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
@@ -555,7 +604,7 @@ QL_FN void leg_block(const DevParams& P, const double cr[18], const double rc0[6
   for (int a = 0; a < 3; ++a) { o.T[3 * a] = q1[a]; o.T[3 * a + 1] = q2[a]; o.T[3 * a + 2] = q3[a]; }
   const double* T = o.T;
   const int l4 = l & 3;     // R holds 12 weights: input j uses R[j % 12]
-  const double Rl[3] = {P.R[3 * l4], P.R[3 * l4 + 1], P.R[3 * l4 + 2]};
+  const double Rl[3] = {Rw ? Rw[0] : P.R[3 * l4], Rw ? Rw[1] : P.R[3 * l4 + 1], Rw ? Rw[2] : P.R[3 * l4 + 2]};
   const double ru[3] = {Rl[0] * u[0], Rl[1] * u[1], Rl[2] * (u[2] - uz)};
   // Db (upper triangle: 00 01 02 11 12 22) and the rotated gradient
   double d00, d01, d02, d11, d12, d22;
@@ -675,6 +724,29 @@ QL_FN int next_bit(unsigned m, int l) {
 
 #ifndef QL_PF_CH      // old state and gains of pass C one knot ahead
 #define QL_PF_CH 1
+#endif
+#ifndef QL_C_SPLIT       // pass C, plain form: the two points of a pair jointly in one basic block (0), one after the other, each
+                         // re-fetching its rows after its own block (1), or both re-fetching after the second block (2: the first
+                         // point's next rows are not in flight under the second point's temporaries -- no spill inside the loop)
+#define QL_C_SPLIT 2
+#endif
+#ifndef QL_C_CR_PER_LEG  // ... rebuilding the cone rows per point instead of keeping 24 registers through the pass
+#define QL_C_CR_PER_LEG 0
+#endif
+#ifndef QL_C_SPEC        // pass C, pair form: the sweep exists twice (both diagonal pairs in stance / one) instead of once with the
+#define QL_C_SPEC 0      // second pair's block under a wave-uniform condition
+#endif
+#ifndef QL_B_RW          // pair forms: the point's input weights from wave-uniform reads and a per-lane choice (1) or indexed per lane (0)
+#define QL_B_RW 1
+#endif
+#ifndef QL_C_RW
+#define QL_C_RW 1
+#endif
+#ifndef QL_C_FIRST_RT    // pass C, pair form: the first pair in stance runs unconditionally with a run-time pair index
+#define QL_C_FIRST_RT 1
+#endif
+#ifndef QL_B_XAHEAD      // pass B: the state of the stage cost is requested before the column sweep
+#define QL_B_XAHEAD 1
 #endif
 #ifndef QL_CR_PER_KNOT    // pass B rebuilds the cone rows per knot instead of keeping 24 registers through the factorisations
 #define QL_CR_PER_KNOT 1
@@ -828,9 +900,23 @@ QL_FN void lane_setup(const DevParams& P, const Ctx& c, const WsOff& O, const do
 // the increment; rc <- (1 - alpha_p) rc, exactly 0 after a full step.
 // WARM: a warm-started launch -- the inputs of the first iteration are read (they are not u_ref), and the rows' initial
 // slack residuals come from the workspace while any lane still carries a residual (rho != 0)
-template <int NL, bool WARM = false, int MD = MD_QUAT>
-QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st, bool first, FootPtr fp) {
+// PAIR (lane pairs, see Ctx and pass_B): the stance points of the wavefront, in ascending order, are taken two at a time -- the
+// first of a round by the lower partner lane, the second by the upper -- so a lane applies the step to ONE point's rows per
+// round (and has its next rows in flight for a whole round of the pair).  What the plain form accumulates in order is
+// accumulated in the same order here: the sum of s * lambda is a chain of fused multiply-adds that runs over the lower lane's
+// six rows, crosses to the upper lane (v_permlane32_swap), runs over its six rows and crosses back; force and torque sums
+// take the two shares as (acc + first) + second.  A pair-mode launch returns the bits of a plain one.
+template <int NL, bool WARM = false, int MD = MD_QUAT, bool PAIR = false>
+QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, LaneState& st, bool first_in, FootPtr fp) {
+  static_assert(!PAIR || (MD != MD_CONVEX && NL == 4), "pair split: the four-point quaternion model");
   constexpr bool warm = WARM;
+#if QL_DEVICE
+  // the lanes of a wavefront that are in this call are all at the same iteration: make the flag a scalar, so that the two
+  // forms of the sweep are a wave-uniform branch and not two masked regions with memory operations in them
+  const bool first = __builtin_amdgcn_readfirstlane((int)first_in) != 0;
+#else
+  const bool first = first_in;
+#endif
   const int N = P.N;
   const double gb[3] = {K.rot[6] * (-9.81), K.rot[7] * (-9.81), K.rot[8] * (-9.81)};
   const double* wd0 = K.wd0;
@@ -851,16 +937,138 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   const bool rcrows = WARM && QL_ANY(st.rho != 0.0);
   LegAheadT<WARM> R;         // rows, inputs and trial increments of the NEXT contact point in processing order (not at the first
                       // iteration: nothing is pending then and every input is at its reference)
-  if (!first) fetch_ahead<NL, true>(c, O, 0, first_bit(order), R, fp, rcrows);
-  else fetch_foot(fp, first_bit(order), R);
+  // pair form: the stance points of the wavefront in ascending order, four bits each (0xF: none)
+  unsigned plist = 0xFFFFu;
+  int pcount = 0;
+  if (PAIR) {
+    plist = 0;
+    for (int l = NL - 1; l >= 0; --l)
+      if ((order >> l) & 1u) { plist = (plist << 4) | (unsigned)l; ++pcount; }
+    plist |= 0xFFFFu << (4 * pcount);
+  }
+  // this lane's point of round r (the upper partner's may not exist: it then shadows the lower one's point and adds nothing)
+  auto pair_point = [&](int r, bool& exists) {
+    const unsigned pa = (plist >> (8 * r)) & 0xFu, pb = (plist >> (8 * r + 4)) & 0xFu;
+    exists = !(c.half && pb == 0xFu);
+    return (int)((c.half && pb != 0xFu) ? pb : pa);
+  };
+  {
+    bool ex;
+    const int l0 = PAIR ? pair_point(0, ex) : first_bit(order);
+    if (!first) fetch_ahead<NL, true>(c, O, 0, l0, R, fp, rcrows);
+    else fetch_foot(fp, l0, R);
+  }
   for (int k = 0; k < N; ++k) {
     const int kn = (k + 1 < N) ? k + 1 : k;
     double F[3] = {0, 0, 0}, wd[3] = {wd0[0], wd0[1], wd0[2]};
+    if constexpr (PAIR) {
+#pragma unroll
+      for (int rd = 0; rd < NL / 2; ++rd) {
+        if (2 * rd >= pcount) continue;       // wave-uniform
+        bool exists;
+        const int lm = pair_point(rd, exists);
+        const bool on_m = exists && ((st.con >> lm) & 1u);
+        const unsigned pa_ = (plist >> (8 * rd)) & 0xFu, pb_ = (plist >> (8 * rd + 4)) & 0xFu;
+        const bool on_lo = (st.con >> pa_) & 1u, on_hi = pb_ != 0xFu && ((st.con >> (pb_ & 3u)) & 1u);
+        const bool more = 2 * (rd + 1) < pcount;      // another round of this knot follows
+        double u[3] = {0.0, 0.0, st.uz}, r[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) r[a] = R.foot[a];
+        double rcl[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rcl[i] = rcrows ? R.rc[i] : rc0[i];
+        if (first) {
+          bool ex;
+          fetch_foot(fp, pair_point(more ? rd + 1 : 0, ex), R);
+          if (warm)      // the warm guess (once per solve: read in place)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) u[a] = c.W(O.U + 3 * NL * k + 3 * lm + a);
+        } else {
+          double du[3], sv[6], lv[6], so[6], lo[6], s1v[6], l1v[6];
+          unsigned kap = 0;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) { u[a] = R.u[a]; du[a] = R.du[a]; }
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            lv[i] = R.lam[i];
+            kap |= (R.s[i] < 0.0) ? (1u << i) : 0u;
+            sv[i] = fabs(R.s[i]);
+            so[i] = R.s[i];
+            lo[i] = R.lam[i];
+            s1v[i] = 0.0;
+            l1v[i] = 0.0;
+          }
+          {     // this lane's next rows: its point of the next round of this knot, or of the first round of the next knot
+            bool ex;
+            fetch_ahead<NL, true>(c, O, more ? k : kn, pair_point(more ? rd + 1 : 0, ex), R, fp, rcrows);
+          }
+          if (on_m) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+              const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
+              const double kp = ((kap >> i) & 1u) ? 1.0 : 0.0;
+              const double dsv = -(jd + ql_rounded(st.rho * rcl[i]));
+              const double dlv = (st.target - (1.0 + kp) * sv[i] * lv[i] - lv[i] * dsv) * ql_rcp(sv[i]);
+              const double s1 = sv[i] + ap * dsv;
+              const double l1 = lv[i] + ad * dlv;
+              const bool sig = tapia && (s1 < 0.6 * sv[i]) && (l1 < 0.6 * lv[i]) &&
+                               (kp != 0.0 || ((s1 > 0.4 * sv[i]) && (l1 > 0.4 * lv[i])));
+              so[i] = sig ? -s1 : s1;
+              lo[i] = l1;
+              s1v[i] = s1;
+              l1v[i] = l1;
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) u[a] += full ? du[a] : ap * du[a];
+          }
+          // the plain form's chain of fused multiply-adds: over the first point's rows on the lower lane, then over the second
+          // point's rows on the upper lane
+          {
+            double t = slsum, a_, b_;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t = fma(s1v[i], l1v[i], t);
+            t = on_m ? t : slsum;
+            ql_pair(t, a_, b_);
+            slsum = a_;
+            t = slsum;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t = fma(s1v[i], l1v[i], t);
+            t = on_m ? t : slsum;
+            ql_pair(t, a_, b_);
+            slsum = b_;
+          }
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            c.StOwn(O.S + 6 * NL * k + 6 * lm + i, so[i]);
+            c.StOwn(O.LAM + 6 * NL * k + 6 * lm + i, lo[i]);
+          }
+#pragma unroll
+          for (int a = 0; a < 3; ++a) c.StOwn(O.U + 3 * NL * k + 3 * lm + a, u[a]);
+        }
+        {
+          double B[9];
+          leg_bw0(P, r, B);
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const double tq = B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
+            double flo, fhi, tlo, thi;
+            ql_pair(u[a], flo, fhi);
+            ql_pair(tq, tlo, thi);
+            if (on_lo) { F[a] += flo; wd[a] += tlo; }
+            if (on_hi) { F[a] += fhi; wd[a] += thi; }
+          }
+        }
+      }
+    } else
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       if (!((order >> l) & 1u)) continue;       // wave-uniform
-      double u[3] = {0.0, 0.0, st.uz}, du[3] = {0, 0, 0}, sv[6], lv[6], r[3];
-      unsigned kap = 0;
+      // No memory operation of this block sits under a per-lane condition: the wavefront's memory counter is in order, and a
+      // wait for the prefetched rows is priced at the path with the FEWEST younger operations -- stores under `if (stance)`
+      // (a branch the compiler lets a wavefront skip) made every such wait a wait for those stores as well.  A lane whose
+      // point is not in stance stores back what it read.
+      const bool on = (st.con >> l) & 1u;
+      double u[3] = {0.0, 0.0, st.uz}, r[3];
 #pragma unroll
       for (int a = 0; a < 3; ++a) r[a] = kFootAhead ? R.foot[a] : K.foot[3 * l + a];
       double rcl[6];
@@ -872,8 +1080,9 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
         if (warm)      // the warm guess (once per solve: read in place)
 #pragma unroll
           for (int a = 0; a < 3; ++a) u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
-      }
-      if (!first) {
+      } else {
+        double du[3], sv[6], lv[6], so[6], lo[6];      // so, lo: what goes back into the rows
+        unsigned kap = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) { u[a] = R.u[a]; du[a] = R.du[a]; }
 #pragma unroll
@@ -881,33 +1090,39 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
           lv[i] = R.lam[i];
           kap |= (R.s[i] < 0.0) ? (1u << i) : 0u;
           sv[i] = fabs(R.s[i]);
+          so[i] = R.s[i];
+          lo[i] = R.lam[i];
         }
         const int ln = next_bit(order, l);
         fetch_ahead<NL, true>(c, O, ln >= 0 ? k : kn, ln >= 0 ? ln : first_bit(order), R, fp, rcrows);
-      }
-      if ((st.con >> l) & 1u) {
-      if (!first) {
+        if (on) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
+            const double kp = ((kap >> i) & 1u) ? 1.0 : 0.0;
+            const double dsv = -(jd + ql_rounded(st.rho * rcl[i]));
+            const double dlv = (st.target - (1.0 + kp) * sv[i] * lv[i] - lv[i] * dsv) * ql_rcp(sv[i]);
+            const double s1 = sv[i] + ap * dsv;
+            const double l1 = lv[i] + ad * dlv;
+            // Tapia indicators (see ipm_apply in qmpc_kernels.hip): both ratios near 1/2 on a full Newton step
+            const bool sig = tapia && (s1 < 0.6 * sv[i]) && (l1 < 0.6 * lv[i]) &&
+                             (kp != 0.0 || ((s1 > 0.4 * sv[i]) && (l1 > 0.4 * lv[i])));
+            so[i] = sig ? -s1 : s1;
+            lo[i] = l1;
+            slsum = fma(s1, l1, slsum);      // (explicitly fused: the pair form runs the same chain across two lanes)
+          }
+#pragma unroll
+          for (int a = 0; a < 3; ++a) u[a] += full ? du[a] : ap * du[a];
+        }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          const double jd = cr[3 * i] * du[0] + cr[3 * i + 1] * du[1] + cr[3 * i + 2] * du[2];
-          const double kp = ((kap >> i) & 1u) ? 1.0 : 0.0;
-          const double dsv = -(jd + ql_rounded(st.rho * rcl[i]));
-          const double dlv = (st.target - (1.0 + kp) * sv[i] * lv[i] - lv[i] * dsv) * ql_rcp(sv[i]);
-          const double s1 = sv[i] + ap * dsv;
-          const double l1 = lv[i] + ad * dlv;
-          // Tapia indicators (see ipm_apply in qmpc_kernels.hip): both ratios near 1/2 on a full Newton step
-          const bool sig = tapia && (s1 < 0.6 * sv[i]) && (l1 < 0.6 * lv[i]) &&
-                           (kp != 0.0 || ((s1 > 0.4 * sv[i]) && (l1 > 0.4 * lv[i])));
-          c.W(O.S + 6 * NL * k + 6 * l + i) = sig ? -s1 : s1;
-          c.W(O.LAM + 6 * NL * k + 6 * l + i) = l1;
-          slsum += s1 * l1;
+          c.St(O.S + 6 * NL * k + 6 * l + i, so[i]);
+          c.St(O.LAM + 6 * NL * k + 6 * l + i, lo[i]);
         }
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          u[a] += full ? du[a] : ap * du[a];
-          c.W(O.U + 3 * NL * k + 3 * l + a) = u[a];
-        }
+        for (int a = 0; a < 3; ++a) c.St(O.U + 3 * NL * k + 3 * l + a, u[a]);
       }
+      if (on) {
       if constexpr (MD == MD_CONVEX) {      // wd collects the torque sum
 #pragma unroll
         for (int a = 0; a < 3; ++a) F[a] += u[a];
@@ -926,7 +1141,7 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     if constexpr (MD == MD_CONVEX) cv_step_fw(P, x, F, wd, xn);
     else srbd_step_fw(P, gb, x, F, wd, xn);
 #pragma unroll
-    for (int i = 0; i < 13; ++i) { x[i] = xn[i]; c.W(O.X + 13 * (k + 1) + i) = xn[i]; }
+    for (int i = 0; i < 13; ++i) { x[i] = xn[i]; c.St(O.X + 13 * (k + 1) + i, xn[i]); }
   }
   if (!first) {
     st.mu = slsum / (double)(6 * N * st.nc);
@@ -949,10 +1164,10 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
 // wave that owns its SIMD.  Returns false when S6 loses positive definiteness (QMPC_NOT_PD).
 template <int NL, int MD = MD_QUAT>
 QL_FN void cost_expansion(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, int k, double lx[12],
-                          double lxx[6]) {
+                          double lxx[6], const double* xpre = nullptr) {
   double x[13];
 #pragma unroll
-  for (int i = 0; i < 13; ++i) x[i] = c.W(O.X + 13 * k + i);
+  for (int i = 0; i < 13; ++i) x[i] = xpre ? xpre[i] : c.W(O.X + 13 * k + i);
   if constexpr (MD == MD_CONVEX) {       // quadratic in the state; blocks reordered [p, phi, v, w]
     double xr[13];
     cv_xref_at(P, K.refp, k, xr);
@@ -1129,7 +1344,15 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
 #pragma unroll
           for (int a = 0; a < 3; ++a) wp[a] = B[3 * a] * u[0] + B[3 * a + 1] * u[1] + B[3 * a + 2] * u[2];
           LegBlk lb;
-          leg_block(P, cr, rcl, lm, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
+          // the weights of this lane's point from two wave-uniform reads (scalar loads) and a per-lane choice
+          double Rw[3];
+          {
+            const unsigned qa = (plist >> (8 * rd)) & 3u, qb = (plist >> (8 * rd + 4)) & 3u;
+            const bool second = c.half && ((plist >> (8 * rd + 4)) & 0xFu) != 0xFu;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) Rw[a] = second ? ql_uniform(P.R[3 * qb + a]) : ql_uniform(P.R[3 * qa + a]);
+          }
+          leg_block(P, cr, rcl, lm, sv, lv, kap, st.rho, st.target, u, st.uz, lb, QL_B_RW ? Rw : nullptr);
           double V[18];
 #pragma unroll
           for (int i = 0; i < 9; ++i) V[i] = lb.T[i];
@@ -1568,6 +1791,15 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     QL_FENCE();
     c.relane();
     QL_TICK(st, LP_B_MP);
+    // the knot's state for the stage cost (step 6), requested before the column sweep: the registers of the point rows are
+    // free here (the next knot's first point is fetched after the sweep), and read right behind that fetch the state cost a
+    // full memory latency per knot.  Plain cold form only: the pair-split and the warm instantiations have no 26 registers
+    // to spare (they spill 30 .. 120 B with it)
+    constexpr bool kXAhead = QL_B_XAHEAD && !PAIR && !WARM && !AL;
+    double xk[13];
+    if (kXAhead)
+#pragma unroll
+      for (int i = 0; i < 13; ++i) xk[i] = c.W(O.X + 13 * k + i);
 #pragma unroll
     for (int j = 0; j < 13; ++j) {
 #if defined(QL_COL_FENCE)
@@ -1597,10 +1829,10 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
         for (int i = 0; i < 6; ++i) c.W((j < 6 ? O.G + D::GAIN * k + 6 * (j < 6 ? j : 0) : O.G2 + D::GAIN2 * k + 6 * (j >= 6 && j < 12 ? j - 6 : 0)) + i) = xg[i];
       } else if (j < 12) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) c.W(O.G + D::GAIN * k + 3 * (j < 12 ? j : 0) + i) = pack2f((float)xg[2 * i], (float)xg[2 * i + 1]);
+        for (int i = 0; i < 3; ++i) c.St(O.G + D::GAIN * k + 3 * (j < 12 ? j : 0) + i, pack2f((float)xg[2 * i], (float)xg[2 * i + 1]));
       } else {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) c.W(O.G + D::GAIN * k + 36 + i) = xg[i];
+        for (int i = 0; i < 6; ++i) c.St(O.G + D::GAIN * k + 36 + i, xg[i]);
       }
       if (j < 12) {
 #pragma unroll
@@ -1641,7 +1873,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     // ---- 6. stage cost of knot k ----
     {
       double lx[12], lxx[6];
-      cost_expansion<NL, MD>(P, c, O, K, k, lx, lxx);
+      cost_expansion<NL, MD>(P, c, O, K, k, lx, lxx, kXAhead ? xk : nullptr);
       int q = 0;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -1679,7 +1911,8 @@ struct LegOutC {
 };
 template <int NL, int MD = MD_QUAT, class RT>
 QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr[18], const double rc0_[6], const RT& R,
-                         int l, const double zeta[6], const LaneState& st, LegOutC& o, bool rcrows, const double* Wk = nullptr) {
+                         int l, const double zeta[6], const LaneState& st, LegOutC& o, bool rcrows, const double* Wk = nullptr,
+                         const double* Rw = nullptr) {
   double rc0[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) rc0[i] = rcrows ? R.rc[i] : rc0_[i];
@@ -1702,7 +1935,7 @@ QL_FN void leg_compute_C(const DevParams& P, const LaneK<NL>& K, const double cr
     sv[i] = fabs(R.s[i]);
   }
   LegBlk lb;
-  leg_block(P, cr, rc0, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb);
+  leg_block(P, cr, rc0, l, sv, lv, kap, st.rho, st.target, u, st.uz, lb, Rw);
   // rhs = T'(zeta_f + Bw0' zeta_t) + gq;  du = -T Db^-1 rhs
   double t[3], rh[3];
 #pragma unroll
@@ -1782,6 +2015,11 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
 #pragma unroll
     for (int i = 0; i < D::GAIN; ++i) gn[i] = c.W(O.G + i);
   }
+  // The loads above are COMPLETE before the loop is entered: the compiler prices the wait for the gains at the head of a knot
+  // on the entry path too, where three of them were the youngest loads in flight -- which made it a wait for everything in
+  // flight (vmcnt(0)) at the head of EVERY knot, the rows' prefetch and the increments' stores included.  One exposed latency
+  // per sweep instead of one per knot.
+  QL_WAIT_VMEM();
   {
     const int p0 = first_bit(porder);
     if (PAIR) {
@@ -1793,6 +2031,15 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   }
   double rp = 0.0, dnA = 0.0, ddA = 1.0, dnB = 0.0, ddB = 1.0, stp = 0.0;      // (A: first points of the pairs, B: second points)
   bool bad = false;
+  // The sweep over the knots exists TWICE in the pair form -- for wavefronts with both diagonal pairs in stance and for those with
+  // one (run-time pair index) -- so that a knot is straight-line code.  With the second pair's block under a wave-uniform `if`
+  // inside ONE loop (i) the rows prefetched for the next knot had to be in the same registers at the join whichever path was
+  // taken -- the compiler put copies on the skipping path, and a copy is a use: a trot wavefront waited for its prefetch right
+  // after issuing it -- and (ii) the wait for the gains at the head of the next knot was priced on the path that skips every
+  // block, where the gains' own loads are the youngest in flight: a wait for everything (vmcnt(0)) at every head.
+  const int pf = first_bit(porder);
+  auto sweep = [&](auto both_c) {
+  constexpr bool BOTH = decltype(both_c)::value;
   for (int k = 0; k < N; ++k) {
     const int kn = (k + 1 < N) ? k + 1 : k;      // the last knot re-reads itself
     // dx = xc (-) X_k in error coordinates (inverse Cayley map, QuaternionUtils.cpp:16-18)
@@ -1844,52 +2091,119 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
       for (int i = 0; i < 13; ++i) xo[i] = c.W(O.X + 13 * kn + i);
 #pragma unroll
       for (int i = 0; i < D::GAIN; ++i) gn[i] = c.W(O.G + D::GAIN * kn + i);
+      // ... all of them HERE: left to itself the scheduler sinks the six feed-forward entries below the per-point blocks (their
+      // registers double as zeta), where they are the youngest loads in flight at the next head -- a wait for them is a wait
+      // for everything (vmcnt(0)): the rows' prefetch and the increments' stores included
+      QL_SCHED_BARRIER();
     }
     QL_TICK(st, LP_C_HEAD);
     double F[3] = {0, 0, 0}, wd[3] = {wd0[0], wd0[1], wd0[2]};
+    auto pair_blk = [&](const int pr) {
+      const int la = pair_leg<NL>(pr, 0), lb = pair_leg<NL>(pr, 1);
+      const bool on_a = (st.con >> la) & 1u, on_b = (st.con >> lb) & 1u;
+      const int lm = c.half ? lb : la;      // this lane's point of the pair
+      const bool on_m = c.half ? on_b : on_a;
+      LegOutC om;
+      double Rw[3];      // this lane's point's weights: two wave-uniform reads and a per-lane choice (see leg_block)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) Rw[a] = c.half ? ql_uniform(P.R[3 * (lb & 3) + a]) : ql_uniform(P.R[3 * (la & 3) + a]);
+      leg_compute_C<NL, MD>(P, K, cr, rc0, Ra, lm, zeta, st, om, rcrows, Wk, QL_C_RW ? Rw : nullptr);
+      {     // the next pair's row into the registers just consumed
+        const int pn = next_bit(porder, pr);
+        const int kq = pn >= 0 ? k : kn, pq = pn >= 0 ? pn : first_bit(porder);
+        fetch_ahead<NL>(c, O, kq, c.half ? pair_leg<NL>(pq, 1) : pair_leg<NL>(pq, 0), Ra, fp, rcrows);
+      }
+      double fm[3], tm[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        c.StOwn(O.dU + 3 * NL * k + 3 * lm + a, om.du[a]);      // every lane: no store under a per-lane condition (see pass A)
+        fm[a] = on_m ? om.u[a] : 0.0;
+        const double t = om.B[3 * a] * om.u[0] + om.B[3 * a + 1] * om.u[1] + om.B[3 * a + 2] * om.u[2];
+        tm[a] = on_m ? t : 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        double lo, hi;
+        ql_pair(fm[a], lo, hi);      // lo: the first point's share, hi: the second's -- added in the plain form's order
+        F[a] = (F[a] + lo) + hi;
+        ql_pair(tm[a], lo, hi);
+        wd[a] = (wd[a] + lo) + hi;
+      }
+      if (on_m) { rp = fmax(rp, om.rp); stp = fmax(stp, om.stp); bad = bad || om.bad; }
+      {     // the multiplier ratio is a running maximum compared by cross-multiplication: its winner among near-equal rows
+            // depends on the order of the scan, so both partners scan the two points' candidates in the plain form's order
+        double alo, ahi, blo, bhi;
+        ql_pair(on_m ? om.dn : 0.0, alo, ahi);
+        ql_pair(on_m ? om.dd : 1.0, blo, bhi);
+        { const bool better = alo * ddA > dnA * blo; dnA = better ? alo : dnA; ddA = better ? blo : ddA; }
+        { const bool better = ahi * ddA > dnA * bhi; dnA = better ? ahi : dnA; ddA = better ? bhi : ddA; }
+      }
+    };
+    if constexpr (PAIR) {
+      if (BOTH) { pair_blk(0); pair_blk(1); }
+      else if (QL_C_FIRST_RT) {
+        pair_blk(pf);
+        if (!QL_C_SPEC)
+#pragma unroll
+          for (int pr = 1; pr < NL / 2; ++pr)
+            if (pr > pf && ((porder >> pr) & 1u)) pair_blk(pr);       // wave-uniform
+      } else {
+#pragma unroll
+        for (int pr = 0; pr < NL / 2; ++pr)
+          if ((porder >> pr) & 1u) pair_blk(pr);       // wave-uniform
+      }
+    } else
 #pragma unroll
     for (int pr = 0; pr < NL / 2; ++pr) {
       const int la = pair_leg<NL>(pr, 0), lb = pair_leg<NL>(pr, 1);
       const bool on_a = (st.con >> la) & 1u, on_b = (st.con >> lb) & 1u;
       if (PAIR) {
-        if ((porder >> pr) & 1u) {       // wave-uniform
-          const int lm = c.half ? lb : la;      // this lane's point of the pair
-          const bool on_m = c.half ? on_b : on_a;
-          LegOutC om;
-          leg_compute_C<NL, MD>(P, K, cr, rc0, Ra, lm, zeta, st, om, rcrows, Wk);
-          {     // the next pair's row into the registers just consumed
-            const int pn = next_bit(porder, pr);
-            const int kq = pn >= 0 ? k : kn, pq = pn >= 0 ? pn : first_bit(porder);
-            fetch_ahead<NL>(c, O, kq, c.half ? pair_leg<NL>(pq, 1) : pair_leg<NL>(pq, 0), Ra, fp, rcrows);
-          }
-          double fm[3], tm[3];
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            if (on_m) c.W(O.dU + 3 * NL * k + 3 * lm + a) = om.du[a];
-            fm[a] = on_m ? om.u[a] : 0.0;
-            const double t = om.B[3 * a] * om.u[0] + om.B[3 * a + 1] * om.u[1] + om.B[3 * a + 2] * om.u[2];
-            tm[a] = on_m ? t : 0.0;
-          }
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            double lo, hi;
-            ql_pair(fm[a], lo, hi);      // lo: the first point's share, hi: the second's -- added in the plain form's order
-            F[a] = (F[a] + lo) + hi;
-            ql_pair(tm[a], lo, hi);
-            wd[a] = (wd[a] + lo) + hi;
-          }
-          if (on_m) { rp = fmax(rp, om.rp); stp = fmax(stp, om.stp); bad = bad || om.bad; }
-          {     // the multiplier ratio is a running maximum compared by cross-multiplication: its winner among near-equal rows
-                // depends on the order of the scan, so both partners scan the two points' candidates in the plain form's order
-            double alo, ahi, blo, bhi;
-            ql_pair(on_m ? om.dn : 0.0, alo, ahi);
-            ql_pair(on_m ? om.dd : 1.0, blo, bhi);
-            { const bool better = alo * ddA > dnA * blo; dnA = better ? alo : dnA; ddA = better ? blo : ddA; }
-            { const bool better = ahi * ddA > dnA * bhi; dnA = better ? ahi : dnA; ddA = better ? bhi : ddA; }
-          }
-        }
       } else
       if ((porder >> pr) & 1u) {       // wave-uniform
+#if QL_C_SPLIT
+        // one point at a time: compute, fetch the point's NEXT rows into the registers just consumed, use the result -- so that
+        // neither the two points' temporaries nor their results are live together (the joint form needs 140 ... 360 B of scratch
+        // per lane, and a scratch re-load behind the prefetches waits for them: the memory counter is in order).  The sums are
+        // formed in the joint form's order: first point, then second.
+        const int pn = next_bit(porder, pr);
+        const int kq = pn >= 0 ? k : kn, pq = pn >= 0 ? pn : first_bit(porder);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          const int lh = hb ? lb : la;
+          const bool on_h = hb ? on_b : on_a;
+          LegOutC oh;
+          if (QL_C_CR_PER_LEG) {
+            double s0[6];
+            cone_rows(P, K.rot, cr);
+            initial_rows(P, cr, st.uz, s0, rc0);
+          }
+          if (hb) {
+            leg_compute_C<NL, MD>(P, K, cr, rc0, Rb, lh, zeta, st, oh, rcrows, Wk);
+#if QL_C_SPLIT == 2
+            fetch_ahead<NL>(c, O, kq, NL == 4 ? pq : 2 * pq, Ra, fp, rcrows);
+#endif
+            fetch_ahead<NL>(c, O, kq, NL == 4 ? 3 - pq : 2 * pq + 1, Rb, fp, rcrows);
+          } else {
+            leg_compute_C<NL, MD>(P, K, cr, rc0, Ra, lh, zeta, st, oh, rcrows, Wk);
+#if QL_C_SPLIT != 2
+            fetch_ahead<NL>(c, O, kq, NL == 4 ? pq : 2 * pq, Ra, fp, rcrows);
+#endif
+          }
+#pragma unroll
+          for (int a = 0; a < 3; ++a) c.St(O.dU + 3 * NL * k + 3 * lh + a, oh.du[a]);      // every lane: no store under a per-lane condition (see pass A)
+          if (on_h) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              F[a] += oh.u[a];
+              if constexpr (MD != MD_CONVEX) wd[a] += oh.B[3 * a] * oh.u[0] + oh.B[3 * a + 1] * oh.u[1] + oh.B[3 * a + 2] * oh.u[2];
+            }
+            if constexpr (MD == MD_CONVEX) cv_cross_acc(oh.r, oh.u, wd);
+            rp = fmax(rp, oh.rp); stp = fmax(stp, oh.stp); bad = bad || oh.bad;
+            { const bool better = oh.dn * ddA > dnA * oh.dd; dnA = better ? oh.dn : dnA; ddA = better ? oh.dd : ddA; }      // (one running ratio in the plain form)
+          }
+          QL_SCHED_BARRIER();
+        }
+#else
         LegOutC oa, ob;
         leg_compute_C<NL, MD>(P, K, cr, rc0, Ra, la, zeta, st, oa, rcrows, Wk);
         leg_compute_C<NL, MD>(P, K, cr, rc0, Rb, lb, zeta, st, ob, rcrows, Wk);
@@ -1899,10 +2213,14 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
           fetch_ahead<NL>(c, O, kq, NL == 4 ? pq : 2 * pq, Ra, fp, rcrows);
           fetch_ahead<NL>(c, O, kq, NL == 4 ? 3 - pq : 2 * pq + 1, Rb, fp, rcrows);
         }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {      // every lane: no store under a per-lane condition (see pass A)
+          c.St(O.dU + 3 * NL * k + 3 * la + a, oa.du[a]);
+          c.St(O.dU + 3 * NL * k + 3 * lb + a, ob.du[a]);
+        }
         if (on_a) {
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
-            c.W(O.dU + 3 * NL * k + 3 * la + a) = oa.du[a];
             F[a] += oa.u[a];
             if constexpr (MD != MD_CONVEX) wd[a] += oa.B[3 * a] * oa.u[0] + oa.B[3 * a + 1] * oa.u[1] + oa.B[3 * a + 2] * oa.u[2];
           }
@@ -1913,7 +2231,6 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
         if (on_b) {
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
-            c.W(O.dU + 3 * NL * k + 3 * lb + a) = ob.du[a];
             F[a] += ob.u[a];
             if constexpr (MD != MD_CONVEX) wd[a] += ob.B[3 * a] * ob.u[0] + ob.B[3 * a + 1] * ob.u[1] + ob.B[3 * a + 2] * ob.u[2];
           }
@@ -1921,6 +2238,7 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
           rp = fmax(rp, ob.rp); stp = fmax(stp, ob.stp); bad = bad || ob.bad;
           { const bool better = ob.dn * ddA > dnA * ob.dd; dnA = better ? ob.dn : dnA; ddA = better ? ob.dd : ddA; }      // (one running ratio in the plain form)
         }
+#endif
       }
     }
     QL_TICK(st, LP_C_LEGS);
@@ -1930,6 +2248,9 @@ QL_FN void pass_C(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     for (int i = 0; i < 13; ++i) xc[i] = xn[i];
     QL_TICK(st, LP_C_STEP);
   }
+  };
+  if (QL_C_SPEC && PAIR && porder == 3u) sweep(std::true_type{});
+  else sweep(std::false_type{});
   if (PAIR) {      // the partner's candidates: the lower lane tracked the first points (A), the upper lane the second (B)
     double lo, hi;
     ql_pair(rp, lo, hi); rp = fmax(lo, hi);

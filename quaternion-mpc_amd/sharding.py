@@ -89,7 +89,11 @@ class StepPipeline:
     words of its shard, one contiguous float64 buffer), then ONE asynchronous all_gather returns every rank's block to
     every rank.  `slots` blocks rotate, so the gather of step i drains under the solve of step i+1 and never sits on
     the solve's critical path.  With world == 1 and multi=False there is no collective at all.  bench.py drives it
-    with the HIP launch; tests/_pipeline_worker.py drives the same code over gloo with a stand-in launch."""
+    with the HIP launch; tests/_pipeline_worker.py drives the same code over gloo with a stand-in launch.
+
+    Diagnosis of a multi-GPU run (stats()): how long this rank's solve stream was held up by a gather that had not drained
+    when its slot came round again -- on a GPU the wait is a stream dependency, so it is measured with a pair of events
+    on the current stream around `work.wait()`; on CPU tensors (gloo) the wait blocks the host and is timed there."""
 
     def __init__(self, world: int, rank: int, block_elems: int, device, slots: int = 2, multi: bool | None = None):
         import torch
@@ -100,23 +104,59 @@ class StepPipeline:
         self.gathered = ([torch.zeros(world, block_elems, dtype=torch.float64, device=device) for _ in range(slots)]
                          if self.multi else None)
         self.pending = [None] * slots
+        self._cuda = self.blocks[0].is_cuda
+        self.reset_stats()
+
+    def reset_stats(self) -> None:
+        """forget the waits recorded so far (call at the start of a timed region)"""
+        self._wait_host_s = 0.0
+        self._wait_events = []
+        self._gathers = 0
+        self._waits = 0
+
+    def _wait(self, buf: int) -> None:
+        w = self.pending[buf]
+        if w is None:
+            return
+        self._waits += 1
+        if self._cuda:
+            import torch
+
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            w.wait()                     # nccl: the current stream waits for the collective; the host does not block
+            e1.record()
+            self._wait_events.append((e0, e1))
+        else:
+            import time
+
+            t0 = time.perf_counter()
+            w.wait()
+            self._wait_host_s += time.perf_counter() - t0
+        self.pending[buf] = None
 
     def step(self, i: int, launch) -> None:
         import torch.distributed as dist
 
         buf = i % self.slots
-        if self.pending[buf] is not None:          # the buffer's previous gather must have drained
-            self.pending[buf].wait()
-            self.pending[buf] = None
+        self._wait(buf)                  # the buffer's previous gather must have drained
         launch(self.blocks[buf])
         if self.multi:
             self.pending[buf] = dist.all_gather_into_tensor(self.gathered[buf].view(-1), self.blocks[buf], async_op=True)
+            self._gathers += 1
 
     def drain(self) -> None:
-        for j, w in enumerate(self.pending):
-            if w is not None:
-                w.wait()
-            self.pending[j] = None
+        for j in range(self.slots):
+            self._wait(j)
+
+    def stats(self) -> dict:
+        """{"gathers": collectives issued, "waits": waits performed, "gather_wait_ms": total time the solve stream (GPU) or
+        the host (CPU tensors) was held by them} since the last reset_stats().  Synchronises the recorded events."""
+        ms = 1e3 * self._wait_host_s
+        for e0, e1 in self._wait_events:
+            e1.synchronize()
+            ms += e0.elapsed_time(e1)
+        return {"gathers": self._gathers, "waits": self._waits, "gather_wait_ms": ms}
 
     def block(self, i: int):
         return self.blocks[i % self.slots]

@@ -39,12 +39,15 @@ def launch(blk):
     blk[B * nu:].copy_(i_ref)
 
 
+pipe.reset_stats()
 for i in range(steps):
     pipe.step(i, launch)
 pipe.drain()
+stt = pipe.stats()      # the diagnosis fields of a multi-rank bench line: one gather per step, every one of them waited for
+ok_stats = stt["gathers"] == steps and stt["waits"] == steps and stt["gather_wait_ms"] >= 0.0
 full, finfo = solve(p, gen(world * B, config_id=cfg), threads=2)
 g = pipe.all_blocks(steps - 1)
-ok = g.shape == (world, B * (nu + IW))
+ok = ok_stats and g.shape == (world, B * (nu + IW))
 ok = ok and np.array_equal(g[:, :B * nu].reshape(world * B, nu).numpy(), full * float(steps))
 st = np.ascontiguousarray(g[:, B * nu:].numpy()).view(pkg.INFO_DTYPE).reshape(world * B)
 ok = ok and np.array_equal(st["status"], finfo["status"]) and np.array_equal(st["iterations"], finfo["iterations"])

@@ -1888,6 +1888,24 @@ def test_host_buffer_calls_zero_copy_pinned_and_pageable(pkg, lib):
     s.solve_async(rec[::-1].copy(), f7, None)
     s.wait()
     assert np.array_equal(f6, f_res) and np.array_equal(f7, f_res[::-1])
+    # ... also when only the RECORDS are pageable (pinned results owe no copy-out): the first launch may still be reading its
+    # records out of the handle's staging when the second call comes -- it must not be refilled under it (round-5 advice)
+    hf8 = s.pinned((B, 12)); hf9 = s.pinned((B, 12))
+    for _ in range(5):
+        hf8[...] = -1.0; hf9[...] = -1.0
+        s.solve_async(rec, hf8, None)
+        s.solve_async(rec[::-1].copy(), hf9, None)
+        s.wait()
+        assert np.array_equal(hf8, f_res) and np.array_equal(hf9, f_res[::-1])
+    # the pinned arrays own their allocation: they outlive the solver that made them (checked after close() below)
+    keep = s.pinned((4, 12)); keep[...] = 7.0
+    # solve_into checks what it hands the kernel
+    with pytest.raises(ValueError):
+        s.solve_into(rec, np.zeros((B - 1, 12)), None)
+    with pytest.raises(ValueError):
+        s.solve_into(rec, np.zeros((B, 12), dtype=np.float32), None)
+    with pytest.raises(ValueError):
+        s.solve_into(rec, np.zeros((B, 24))[:, ::2], None)
     # a caller that hands the host-buffer entry point DEVICE pointers gets the explicit-copy path (no host dereference)
     d_f2 = torch.full((B, 12), -1.0, dtype=torch.float64, device="cuda")
     d_i2 = torch.zeros(B, pkg.INFO_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
@@ -1898,6 +1916,9 @@ def test_host_buffer_calls_zero_copy_pinned_and_pageable(pkg, lib):
     ft, it_, tu, tx = s.solve(rec, want_traj=True)
     assert np.array_equal(ft, f_res) and np.array_equal(tu[:, 0, :], f_res)
     s.close()
+    del s
+    assert (keep == 7.0).all()
+    keep[...] = 8.0
     os.environ["QMPC_ZERO_COPY"] = "0"
     try:
         s0 = pkg.Solver(p, 512, device=0, lib=lib)

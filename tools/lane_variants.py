@@ -1,5 +1,5 @@
 """Build variants of the lane kernel (extra -D flags / -mllvm options) into tools/.prof/var_<name>.so for side-by-side
-timing on the GPU box:  python tools/lane_variants.py name1="-DX=1 -DY=0" name2="..."   (objects of the other two
+timing on the GPU box:  python tools/lane_variants.py name1="-DX=1 -DY=0" name2="..."   (objects of the other three
 translation units are reused from csrc/build/).  Then on the GPU:  for v in tools/.prof/var_*.so; QMPC_LIB=$v ..."""
 import subprocess
 import sys
@@ -30,5 +30,6 @@ for arg in sys.argv[1:]:
 for name, obj, p in procs:
     assert p.wait() == 0, name
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", str(OUT / f"var_{name}.so"),
-                    str(CSRC / "build" / "qmpc_hip.o"), str(CSRC / "build" / "qmpc_loop_fused.o"), str(obj)], check=True)
+                    str(CSRC / "build" / "qmpc_hip.o"), str(CSRC / "build" / "qmpc_loop_fused.o"),
+                    str(CSRC / "build" / "qmpc_wform.o"), str(obj)], check=True)
     print("built", name)
