@@ -736,6 +736,9 @@ QL_FN int next_bit(unsigned m, int l) {
 #ifndef QL_C_SPEC        // pass C, pair form: the sweep exists twice (both diagonal pairs in stance / one) instead of once with the
 #define QL_C_SPEC 0      // second pair's block under a wave-uniform condition
 #endif
+#ifndef QL_A_KNOT_AHEAD  // pass A, plain form, four points: a buffer per point, fetched a knot ahead
+#define QL_A_KNOT_AHEAD 1
+#endif
 #ifndef QL_B_RW          // pair forms: the point's input weights from wave-uniform reads and a per-lane choice (1) or indexed per lane (0)
 #define QL_B_RW 1
 #endif
@@ -937,6 +940,12 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   const bool rcrows = WARM && QL_ANY(st.rho != 0.0);
   LegAheadT<WARM> R;         // rows, inputs and trial increments of the NEXT contact point in processing order (not at the first
                       // iteration: nothing is pending then and every input is at its reference)
+  // Plain form of the four-point models: one buffer PER POINT, fetched a whole knot ahead (point l of knot k + 1 is requested
+  // when point l of knot k has been copied out): the sweep has the registers (84 doubles) that the other two do not.  Worth
+  // 1 % only: with 1024 full wavefronts streaming this sweep sits at the HBM roof (40 KB per wavefront and knot in ~8 k cycles
+  // = 10 TB/s asked for), not on a latency (profiles/HISTORY_r06.md).
+  constexpr bool kKnotAhead = QL_A_KNOT_AHEAD && NL == 4 && !PAIR;
+  LegAheadT<WARM> Rk[kKnotAhead ? NL : 1];
   // pair form: the stance points of the wavefront in ascending order, four bits each (0xF: none)
   unsigned plist = 0xFFFFu;
   int pcount = 0;
@@ -952,7 +961,14 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     exists = !(c.half && pb == 0xFu);
     return (int)((c.half && pb != 0xFu) ? pb : pa);
   };
-  {
+  if constexpr (kKnotAhead) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (!((order >> l) & 1u)) continue;       // wave-uniform
+      if (!first) fetch_ahead<NL, true>(c, O, 0, l, Rk[l], fp, rcrows);
+      else fetch_foot(fp, l, Rk[l]);
+    }
+  } else {
     bool ex;
     const int l0 = PAIR ? pair_point(0, ex) : first_bit(order);
     if (!first) fetch_ahead<NL, true>(c, O, 0, l0, R, fp, rcrows);
@@ -1068,15 +1084,16 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
       // (a branch the compiler lets a wavefront skip) made every such wait a wait for those stores as well.  A lane whose
       // point is not in stance stores back what it read.
       const bool on = (st.con >> l) & 1u;
+      LegAheadT<WARM>& Rc = kKnotAhead ? Rk[kKnotAhead ? l : 0] : R;      // this point's rows
       double u[3] = {0.0, 0.0, st.uz}, r[3];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) r[a] = kFootAhead ? R.foot[a] : K.foot[3 * l + a];
+      for (int a = 0; a < 3; ++a) r[a] = kFootAhead ? Rc.foot[a] : K.foot[3 * l + a];
       double rcl[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) rcl[i] = rcrows ? R.rc[i] : rc0[i];
+      for (int i = 0; i < 6; ++i) rcl[i] = rcrows ? Rc.rc[i] : rc0[i];
       if (first) {
         const int ln = next_bit(order, l);
-        fetch_foot(fp, ln >= 0 ? ln : first_bit(order), R);
+        if (!kKnotAhead) fetch_foot(fp, ln >= 0 ? ln : first_bit(order), R);      // (a point's own buffer keeps its position)
         if (warm)      // the warm guess (once per solve: read in place)
 #pragma unroll
           for (int a = 0; a < 3; ++a) u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
@@ -1084,17 +1101,18 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
         double du[3], sv[6], lv[6], so[6], lo[6];      // so, lo: what goes back into the rows
         unsigned kap = 0;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { u[a] = R.u[a]; du[a] = R.du[a]; }
+        for (int a = 0; a < 3; ++a) { u[a] = Rc.u[a]; du[a] = Rc.du[a]; }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          lv[i] = R.lam[i];
-          kap |= (R.s[i] < 0.0) ? (1u << i) : 0u;
-          sv[i] = fabs(R.s[i]);
-          so[i] = R.s[i];
-          lo[i] = R.lam[i];
+          lv[i] = Rc.lam[i];
+          kap |= (Rc.s[i] < 0.0) ? (1u << i) : 0u;
+          sv[i] = fabs(Rc.s[i]);
+          so[i] = Rc.s[i];
+          lo[i] = Rc.lam[i];
         }
         const int ln = next_bit(order, l);
-        fetch_ahead<NL, true>(c, O, ln >= 0 ? k : kn, ln >= 0 ? ln : first_bit(order), R, fp, rcrows);
+        if (kKnotAhead) fetch_ahead<NL, true>(c, O, kn, l, Rc, fp, rcrows);      // the same point, one knot on (the last knot re-reads itself)
+        else fetch_ahead<NL, true>(c, O, ln >= 0 ? k : kn, ln >= 0 ? ln : first_bit(order), R, fp, rcrows);
         if (on) {
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
