@@ -174,6 +174,12 @@ inline size_t lane_ws_elements(int N, int nl, bool wide = false) {
 // prefetches just issued (the memory counter is in order: waiting for the re-load waited for the prefetch).
 constexpr bool kFootAhead = true;
 typedef QL_PRIV_AS const double* FootPtr;
+#ifndef QL_NT_ST         // the plain forms' sweep stores are non-temporal (nothing re-reads a row before the workspace has streamed
+#define QL_NT_ST 1         // through the caches once): config 3 -2 %, B=65536 N=10 -1 %; the pair forms (half the bytes per wavefront:
+#endif                    // their rows do come back from the L2) keep ordinary stores (StOwn): +1 % with the hint
+#ifndef QL_NT_LD
+#define QL_NT_LD 0
+#endif
 struct Ctx {
   QL_GLOBAL_AS double* ws;   // this wave's block of the workspace: [element][lane]
   unsigned wrow;             // bytes per workspace row (8 x lanes per wave)
@@ -197,14 +203,26 @@ struct Ctx {
     asm volatile("" ::"v"(v));
 #elif defined(QL_PAIR_ST_LOWER) && QL_DEVICE
     if (!half) W(e) = v;      // pair mode: the partner lanes' copies of a duplicated pass carry the same values to the same addresses
+#elif QL_NT_ST && QL_DEVICE
+    __builtin_nontemporal_store(v, &W(e));
 #else
     W(e) = v;
+#endif
+  }
+  // a row read that nothing re-reads before the workspace has streamed through the caches once (experiment: QL_NT_LD)
+  QL_FN double Ld(int e) const {
+#if QL_NT_LD && QL_DEVICE
+    return __builtin_nontemporal_load(&W(e));
+#else
+    return W(e);
 #endif
   }
   // a store that is this lane's OWN in pair mode (the split trial pass: each partner writes its point's increments)
   QL_FN void StOwn(int e, double v) const {
 #if defined(QL_DIAG_NOSTORE) && QL_DEVICE
     asm volatile("" ::"v"(v));
+#elif QL_NT_ST && QL_DEVICE
+    __builtin_nontemporal_store(v, &W(e));
 #else
     W(e) = v;
 #endif
@@ -689,17 +707,17 @@ QL_FN void fetch_ahead(const Ctx& c, const WsOff& O, int k, int l, RT& R, FootPt
   if constexpr (RT::kHasRc) {
     if (rcrows)
 #pragma unroll
-      for (int i = 0; i < 6; ++i) R.rc[i] = c.W(O.RC + 6 * NL * k + 6 * l + i);
+      for (int i = 0; i < 6; ++i) R.rc[i] = c.Ld(O.RC + 6 * NL * k + 6 * l + i);
   }
 #pragma unroll
-  for (int a = 0; a < 3; ++a) R.u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
+  for (int a = 0; a < 3; ++a) R.u[a] = c.Ld(O.U + 3 * NL * k + 3 * l + a);
   if (WITH_DU)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) R.du[a] = c.W(O.dU + 3 * NL * k + 3 * l + a);
+    for (int a = 0; a < 3; ++a) R.du[a] = c.Ld(O.dU + 3 * NL * k + 3 * l + a);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    R.s[i] = c.W(O.S + 6 * NL * k + 6 * l + i);
-    R.lam[i] = c.W(O.LAM + 6 * NL * k + 6 * l + i);
+    R.s[i] = c.Ld(O.S + 6 * NL * k + 6 * l + i);
+    R.lam[i] = c.Ld(O.LAM + 6 * NL * k + 6 * l + i);
   }
 }
 // wave-uniform stance mask: bit l set when any lane of the wavefront has contact point l in stance
@@ -1159,7 +1177,7 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     if constexpr (MD == MD_CONVEX) cv_step_fw(P, x, F, wd, xn);
     else srbd_step_fw(P, gb, x, F, wd, xn);
 #pragma unroll
-    for (int i = 0; i < 13; ++i) { x[i] = xn[i]; c.St(O.X + 13 * (k + 1) + i, xn[i]); }
+    for (int i = 0; i < 13; ++i) { x[i] = xn[i]; if (PAIR) c.StOwn(O.X + 13 * (k + 1) + i, xn[i]); else c.St(O.X + 13 * (k + 1) + i, xn[i]); }
   }
   if (!first) {
     st.mu = slsum / (double)(6 * N * st.nc);
@@ -1847,10 +1865,10 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
         for (int i = 0; i < 6; ++i) c.W((j < 6 ? O.G + D::GAIN * k + 6 * (j < 6 ? j : 0) : O.G2 + D::GAIN2 * k + 6 * (j >= 6 && j < 12 ? j - 6 : 0)) + i) = xg[i];
       } else if (j < 12) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) c.St(O.G + D::GAIN * k + 3 * (j < 12 ? j : 0) + i, pack2f((float)xg[2 * i], (float)xg[2 * i + 1]));
+        for (int i = 0; i < 3; ++i) { const double pk = pack2f((float)xg[2 * i], (float)xg[2 * i + 1]); if (PAIR) c.StOwn(O.G + D::GAIN * k + 3 * (j < 12 ? j : 0) + i, pk); else c.St(O.G + D::GAIN * k + 3 * (j < 12 ? j : 0) + i, pk); }
       } else {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) c.St(O.G + D::GAIN * k + 36 + i, xg[i]);
+        for (int i = 0; i < 6; ++i) { if (PAIR) c.StOwn(O.G + D::GAIN * k + 36 + i, xg[i]); else c.St(O.G + D::GAIN * k + 36 + i, xg[i]); }
       }
       if (j < 12) {
 #pragma unroll
@@ -2422,18 +2440,22 @@ QL_FN void pass_M(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
 #pragma unroll
       for (int i = 0; i < 6; ++i) lam[i] = lk[6 * l + i];
       load_leg(kn, l);
-      if (!((st.con >> l) & 1u)) continue;
+      const bool on = (st.con >> l) & 1u;
       if (UPDATE) {
+        if (on)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          double cv = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
-          if (i == 4) cv += -P.fz_max;
-          const double z = lam[i] + rho_old * cv;
-          lam[i] = (z > 0.0) ? z : 0.0;
-          c.W(O.LAM + 6 * NL * k + 6 * l + i) = lam[i];
-        }
+          for (int i = 0; i < 6; ++i) {
+            double cv = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
+            if (i == 4) cv += -P.fz_max;
+            const double z = lam[i] + rho_old * cv;
+            lam[i] = (z > 0.0) ? z : 0.0;
+          }
+        // every lane: no store under a per-lane condition (pass A: a wait behind a skippable block of stores waits for them);
+        // a lane whose point is not in stance stores back what it read
+#pragma unroll
+        for (int i = 0; i < 6; ++i) c.St(O.LAM + 6 * NL * k + 6 * l + i, lam[i]);
       }
-      Jp += al_point_terms(P, cr, l, u, st.uz, lam, al.rho, alsum, viol);
+      if (on) Jp += al_point_terms(P, cr, l, u, st.uz, lam, al.rho, alsum, viol);
     }
   }
   al.Jp = Jp;
@@ -2470,10 +2492,12 @@ QL_FN void pass_A_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
       double u[3], B[9];
 #pragma unroll
       for (int a = 0; a < 3; ++a) u[a] = uk[3 * l + a] + dk[3 * l + a];
+      const double uo[3] = {uk[3 * l], uk[3 * l + 1], uk[3 * l + 2]};
       load_leg(kn, l);
-      if (!((st.con >> l) & 1u)) continue;
+      const bool on = (st.con >> l) & 1u;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) c.W(O.U + 3 * NL * k + 3 * l + a) = u[a];
+      for (int a = 0; a < 3; ++a) c.St(O.U + 3 * NL * k + 3 * l + a, on ? u[a] : uo[a]);      // every lane (see pass_M)
+      if (!on) continue;
       if constexpr (MD == MD_CONVEX) {      // wd collects the raw torque sum
 #pragma unroll
         for (int a = 0; a < 3; ++a) F[a] += u[a];
@@ -2490,7 +2514,7 @@ QL_FN void pass_A_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
     if constexpr (MD == MD_CONVEX) cv_step_fw(P, x, F, wd, xn);
     else srbd_step_fw(P, gb, x, F, wd, xn);
 #pragma unroll
-    for (int i = 0; i < 13; ++i) { x[i] = xn[i]; c.W(O.X + 13 * (k + 1) + i) = xn[i]; }
+    for (int i = 0; i < 13; ++i) { x[i] = xn[i]; c.St(O.X + 13 * (k + 1) + i, xn[i]); }
   }
 }
 
@@ -2610,7 +2634,12 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
 #pragma unroll
       for (int i = 0; i < 6; ++i) lam[i] = lk[6 * l + i];
       load_leg(kn, l);
-      if (!((st.con >> l) & 1u)) continue;
+      double dq[NA][3];      // the trials' increments of this point (what goes to the dU / RC slots)
+#pragma unroll
+      for (int q = 0; q < NA; ++q)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dq[q][a] = 0.0;
+      if ((st.con >> l) & 1u) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         double cv = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
@@ -2644,7 +2673,7 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
           stp[q] = fmax(stp[q], fabs(du));
           bad[q] = bad[q] || !(fabs(du) <= 1e300);
           un[a] = u[a] + du;
-          if (live) c.W((q == 0 ? O.dU : O.RC) + 3 * NL * k + 3 * l + a) = du;
+          dq[q][a] = du;
         }
         Jp[q] += al_point_terms(P, cr, l, un, st.uz, lam, al.rho, alsum[q], viol[q]);
         if constexpr (MD == MD_CONVEX) {      // the rollout wants the raw torque r x u
@@ -2659,6 +2688,14 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
         }
         }
       }
+      }
+      // every lane: no store under a per-lane stance condition (a wait behind a skippable block of stores waits for them; the
+      // increments of a point that is not in stance are never read)
+      if (live)
+#pragma unroll
+        for (int q = 0; q < NA; ++q)
+#pragma unroll
+          for (int a = 0; a < 3; ++a) c.St((q == 0 ? O.dU : O.RC) + 3 * NL * k + 3 * l + a, dq[q][a]);
     }
 #if QL_AL_G2_AHEAD == 2
     // the next knot's second gain block: issued once the per-point phase has released its registers, covered by the state steps
