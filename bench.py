@@ -94,9 +94,8 @@ def cpu_baseline(pkg, horizon: int, config_id: int, seconds: float = 12.0, model
     return {
         "_forces": forces,       # popped by the caller: parity of the GPU batch against the same instances
         "value": n / dt, "unit": "solves/s", "cores": cores, "kind": "port",
-        "sample": f"first {n} instances of the same synthetic workload (N={horizon}), {cores} host threads "
-                  f"(= usable cores: affinity capped by the cgroup CPU quota; {os.cpu_count()} logical CPUs visible), "
-                  f"instance-parallel; oracle/ C restatement, {dt:.1f} s; mean {float(info['iterations'].mean()):.1f} iterations",
+        "sample": f"first {n} instances of the same workload, {cores} threads (cgroup quota; {os.cpu_count()} logical CPUs), "
+                  f"oracle/ C restatement, {dt:.1f} s",
     }
 
 
@@ -135,10 +134,7 @@ def two_in_flight(pkg, lib, params, args, d_in, NU):
     same = bool(torch.equal(outs[0], outs[1]))
     for sv in solvers:
         sv.close()
-    return {"value": B * args.steps / dt, "unit": "solves/s", "ms_per_step": 1e3 * dt / args.steps, "steps": args.steps,
-            "outputs_identical": same,
-            "note": "secondary: consecutive independent batches on two streams (two handles, gains in the workspace "
-                    "so that both batches are resident); not the contract value"}
+    return {"value": B * args.steps / dt, "ms_per_step": 1e3 * dt / args.steps, "outputs_identical": same}
 
 
 def traffic_from_profiles(B, N, model):
@@ -189,6 +185,21 @@ def sq_from_profiles(B, N, model):
         return d
     except (OSError, ValueError):
         return None
+
+
+def compact(o):
+    """floats to six significant digits: the line has to fit the driver's 8 KB tail"""
+    if isinstance(o, float):
+        return float(f"{o:.6g}")
+    if isinstance(o, dict):
+        return {k: compact(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [compact(v) for v in o]
+    return o
+
+
+def loop_form(persistent: bool) -> str:
+    return "persistent wave-per-robot kernel" if persistent else "three kernels per tick (graph replay)"
 
 
 def main():
@@ -305,6 +316,7 @@ def main():
         torch.cuda.synchronize()
         flush_c_stdio()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        pipe.reset_stats()
         t0 = time.perf_counter()
         ev0.record(stream)
         for i in range(steps):
@@ -312,16 +324,31 @@ def main():
         ev1.record(stream)
         pipe.drain()
         torch.cuda.synchronize()
+        own_elapsed = time.perf_counter() - t0          # this rank's own clock, before the closing barrier
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        # HIP events on the launch stream: average launch duration (back-to-back launches; in a multi-rank run the waits for
+        # gathers that had not drained sit between the launches and are inside this figure: gather_wait_ms says how much)
+        kernel_ms = ev0.elapsed_time(ev1) / steps
+        pst = pipe.stats()
+        ranks = None
         if multi:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        # HIP events on the launch stream: average launch duration (back-to-back launches)
-        kernel_ms = ev0.elapsed_time(ev1) / steps
+            # diagnosis of a scaling run: every rank's kernel time per step, the time its solve stream was held by gathers
+            # that had not drained, and its own wall clock -- min / max over the ranks, gathered with one small collective
+            mine = torch.tensor([kernel_ms, pst["gather_wait_ms"] / steps, 1e3 * own_elapsed / steps], dtype=torch.float64, device="cuda")
+            allr = torch.zeros(world, 3, dtype=torch.float64, device="cuda")
+            dist.all_gather_into_tensor(allr.view(-1), mine)
+            a_ = allr.cpu().numpy()
+            ranks = {"kernel_ms": {"min": float(a_[:, 0].min()), "max": float(a_[:, 0].max()), "argmax": int(a_[:, 0].argmax())},
+                     "gather_wait_ms": {"min": float(a_[:, 1].min()), "max": float(a_[:, 1].max())},
+                     "own_ms_per_step": {"min": float(a_[:, 2].min()), "max": float(a_[:, 2].max())},
+                     "gathers_per_step": pst["gathers"] / steps,
+                     "gather_bytes_per_step": int(world * Bl * (nu + IW) * 8)}
         last = pipe.block(steps - 1)
         allb = pipe.all_blocks(steps - 1)
         if multi:   # every rank holds every rank's forces and status: the gathered block must carry the local one
@@ -330,7 +357,7 @@ def main():
         info = np.ascontiguousarray(allb[:, Bl * nu:].cpu().numpy()).view(pkg.INFO_DTYPE).reshape(world, Bl)
         forces = last[:Bl * nu].view(Bl, nu).cpu().numpy().copy()
         return {"elapsed": elapsed, "kernel_ms": kernel_ms, "info": info, "forces": forces, "rec": rec,
-                "solver": solver, "d_in": d_in}
+                "solver": solver, "d_in": d_in, "ranks": ranks, "gather_wait_ms": pst["gather_wait_ms"] / steps}
 
     def kernel_name(batch, horizon=None, slv=None):
         """dominant kernel of a launch of `batch` instances: the LIBRARY's own answer (qmpc_query: launch_solve's choice for
@@ -344,13 +371,13 @@ def main():
         cap = slv.query(pkg.QUERY_LANE_CAP, 1)
         if own:
             slv.close()
-        return {"lane_handoff": f"qmpc_lane_kernel (lane per instance, wrench form); stragglers beyond {cap} iterations continued by "
-                                "qmpc_solve_w_list_kernel (one call)",
-                "lane": "qmpc_lane_kernel (lane per instance, wrench form)",
-                "wform_lds": "qmpc_solve_w_kernel<3> (wave per instance, wrench form, everything in LDS)",
-                "wform_ws": "qmpc_solve_w_kernel<5> (wave per instance, wrench form, gains in the workspace)",
-                "dense_lds": "qmpc_solve_kernel<0> (wave per instance, dense 12x12 stage algebra, everything in LDS)",
-                "dense_ws": "qmpc_solve_kernel<1|2> (wave per instance, dense 12x12 stage algebra, gains in the workspace)"}[fam]
+        # the family is the library's answer; which instantiation of it runs (WVAR 5 / 6, model) is in profiles/BENCH_NOTES.md
+        return {"lane_handoff": f"qmpc_lane_kernel + qmpc_solve_w_list_kernel beyond {cap} iterations",
+                "lane": "qmpc_lane_kernel",
+                "wform_lds": "wrench-form wave kernel, all LDS",
+                "wform_ws": "wrench-form wave kernel, workspace form",
+                "dense_lds": "dense wave kernel, all LDS",
+                "dense_ws": "dense wave kernel, workspace form"}[fam]
 
     def roofline_object(kname, ach, tr, tr_src, kms, batch, compulsory):
         """`frac` prices SURVEY 8d's algorithmic flops against the 78.6 TFLOP/s FP64 peak (the matrix and the vector FP64
@@ -359,15 +386,11 @@ def main():
         flops; the matrix pipe is 12-13 % busy), "fp64_valu" for the lane-per-instance kernel, whose ISA holds no matrix
         instruction (mfma_busy 0)."""
         lane = kname.startswith("qmpc_lane_kernel")
-        o = {"bound": "fp64_valu" if lane else "fp64 (valu+mfma)", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-             "frac": ach / FP64_PEAK_TFLOPS, "traffic": tr, "traffic_source": tr_src, "kernel": kname, "kernel_ms": kms,
-             "algorithmic_bytes_per_launch": compulsory,
-             "hbm_GBps": (tr / (kms * 1e-3) / 1e9) if tr else None,
-             "hbm_frac_of_8TBps": (tr / (kms * 1e-3) / 8e12) if tr else None,
-             "traffic_to_compulsory": (tr / compulsory) if tr else None}
-        if lane:
-            o["storage"] = "f64 arithmetic; the 6 x 12 feedback gains are stored as packed f32 pairs (forces within 1e-6 N of the oracle)"
-        return o
+        return {"bound": "fp64_valu" if lane else "fp64 (valu+mfma)", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / FP64_PEAK_TFLOPS, "traffic": tr, "kernel": kname, "kernel_ms": kms,
+                "algorithmic_bytes_per_launch": compulsory,
+                "hbm_GBps": (tr / (kms * 1e-3) / 1e9) if tr else None,
+                "traffic_to_compulsory": (tr / compulsory) if tr else None}
 
     leg = timed_leg(B, config_id, args.steps, args.warmup)
     elapsed, kernel_ms, info, rec = leg["elapsed"], leg["kernel_ms"], leg["info"], leg["rec"]
@@ -383,12 +406,16 @@ def main():
         p4 = pkg.default_params(10, pkg.MODE_CONVERGED, lib)
         k4 = max(2, min(5, args.steps))
         leg4 = timed_leg(B4, 4, k4, 1, prm=p4, model="quat")
-        config4 = {"workload": f"BASELINE config 4: Batch=262144 Go1 trot states, N=10, sharded x{world} "
-                               f"({B4} per GPU), seed 0x5EED0000+4; device-resident, one all_gather per step",
+        kn4 = kernel_name(B4, 10, slv=leg4["solver"]) if rank == 0 else ""
+        ach4 = W_ALG_KFLOP_PER_KNOT * 1e3 * 10 * B4 / (leg4["kernel_ms"] * 1e-3) / 1e12
+        tr4, _ = traffic_from_profiles(B4, 10, "quat")
+        config4 = {"workload": f"config 4: 262144 Go1 states, N=10, x{world} ({B4} per GPU), one all_gather per step",
                    "value": world * B4 * k4 / leg4["elapsed"], "unit": "solves/s", "steps": k4, "warmup": 1,
                    "ms_per_step": 1e3 * leg4["elapsed"] / k4, "kernel_ms": leg4["kernel_ms"],
                    "instances": world * B4, "converged": int((leg4["info"]["status"] == 0).sum()),
-                   "mean_iterations": float(leg4["info"]["iterations"].mean())}
+                   "mean_iterations": float(leg4["info"]["iterations"].mean()),
+                   "roofline": roofline_object(kn4, ach4, tr4, None, leg4["kernel_ms"], B4, B4 * (8 * 48 + 8 * 12 + 40)),
+                   "ranks": leg4["ranks"]}
         leg4["solver"].close()
         del leg4
 
@@ -405,26 +432,23 @@ def main():
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"Batch={B} random {'biped8 ' if biped else 'Go1 '}{'ConvexMpc ' if convex else ''}states per GPU, N={N}, converged mode "
-                                   f"(interior point to |dU|<=1e-8 N), generator seed 0x5EED0000+{config_id}; "
-                                   "`value` = DEVICE-RESIDENT rate (records already in HBM, forces and status left in HBM, one "
-                                   "launch in flight per GPU); the host-buffer rate (H2D + kernel + D2H, SURVEY 8d) is "
-                                   "rates.host_buffer_call",
+            "config": {"workload": f"Batch={B} random {'biped8 ' if biped else 'Go1 '}{'ConvexMpc ' if convex else ''}states per GPU, N={N}, "
+                                   f"converged mode, seed 0x5EED0000+{config_id}, device-resident",
                        "value_is": "rates.device_resident",
                        "batch_per_gpu": B, "horizon": N, "parallelism": f"instance-sharded x{world}",
                        "instances": world * B, "converged": n_ok, "mean_iterations": mean_iters},
-            "rates": {"device_resident": {"value": value, "unit": "solves/s", "ms_per_step": 1e3 * elapsed / args.steps}},
+            "rates": {"device_resident": value},
             "roofline": roofline_object(kernel_name(B, slv=solver), achieved, traffic, traffic_src, kernel_ms, B,
                                         B * (8 * (64 if biped else 48) + 8 * NU + 40)),
         }
         out["roofline"]["algorithmic_flops_per_launch"] = w_alg * B
-        out["roofline"]["note"] = ("FP64 MFMA/vector roof (78.6 TF); algorithmic work W_alg=159*N kFLOP/solve (SURVEY 8d); "
-                                   "compulsory HBM traffic is 460 B/solve, i.e. not the binding roof")
+        out["notes"] = "profiles/BENCH_NOTES.md"          # what every field means, counter sources, kernel instantiations
         sq = sq_from_profiles(B, N, args.model)
         if sq is not None:
             out["roofline"]["mfma_busy"] = sq.get("mfma_busy")
             out["roofline"]["issue_frac"] = sq.get("issue_frac")
-            out["roofline"]["sq_source"] = sq.get("source")
+        if multi:
+            out["ranks"] = leg["ranks"]
         if config4 is not None:
             out["config4"] = config4
         if args.check:
@@ -458,20 +482,16 @@ def main():
                 dt = time.perf_counter() - t0
                 assert np.array_equal(hf, d_f) and (hi["status"] == 0).sum() == n_ok, "host-buffer call differs from the resident one"
                 hb[kind] = {"value": B * reps / dt, "unit": "solves/s", "ms_per_call": 1e3 * dt / reps, "calls": reps}
-            out["rates"]["host_buffer_call"] = dict(hb["pinned"], note=(
-                f"{hname} on pinned host buffers (qmpc_host_alloc), blocking: records read from / forces and status written to host "
-                "memory by the kernel itself (zero-copy), one launch + one synchronisation; results bit-identical to the resident call"))
-            out["rates"]["host_buffer_call_pageable"] = dict(hb["pageable"], note=(
-                f"{hname} on pageable host buffers: one memcpy into / out of the handle's pinned staging around the same launch"))
-            out["host_buffer_call"] = out["rates"]["host_buffer_call"]
-            out["value_host_inclusive"] = out["rates"]["host_buffer_call"]["value"]     # SURVEY 8d's own definition of the metric
+            out["rates"]["host_buffer_call"] = hb["pinned"]["value"]
+            out["rates"]["host_buffer_call_pageable"] = hb["pageable"]["value"]
+            out["rates"]["host_buffer_ms_per_call"] = hb["pinned"]["ms_per_call"]
+            out["value_host_inclusive"] = hb["pinned"]["value"]     # SURVEY 8d's own definition of the metric
             out["host_inclusive_over_resident"] = out["value_host_inclusive"] / value
         if world == 1 and args.model == "quat" and not args.no_large_batch and B == 1024 and N == 10:
             # secondary: the large-batch configurations of BASELINE.json on this GPU (the lane-per-instance kernel):
             # the per-GPU share of config 4 (32768 instances, N=10) and config 3 (65536 instances, N=20); never `value`
             out["large_batch"] = []
-            for (Bl, Nl, cfg, what) in ((32768, 10, 4, "per-GPU share of BASELINE config 4 (262144 instances over 8 GPUs)"),
-                                        (65536, 20, 3, "BASELINE config 3")):
+            for (Bl, Nl, cfg, what) in ((32768, 10, 4, "per-GPU share of config 4"), (65536, 20, 3, "config 3")):
                 pl_ = pkg.default_params(Nl, pkg.MODE_CONVERGED, lib)
                 kl = max(3, min(10, args.steps))
                 lg = timed_leg(Bl, cfg, kl, 2, prm=pl_, model="quat")
@@ -500,12 +520,10 @@ def main():
                 w_l = W_ALG_KFLOP_PER_KNOT * 1e3 * Nl
                 ach = w_l * Bl / (lg["kernel_ms"] * 1e-3) / 1e12
                 tr, tr_src = traffic_from_profiles(Bl, Nl, "quat")
-                ent = {"workload": f"Batch={Bl} random Go1 states, N={Nl}, seed 0x5EED0000+{cfg}: {what}",
+                ent = {"workload": f"B={Bl} N={Nl}: {what}",
                        "value": Bl * kl / lg["elapsed"], "unit": "solves/s", "steps": kl, "ms_per_step": 1e3 * lg["elapsed"] / kl,
-                       "kernel": kn_l, "kernel_ms": lg["kernel_ms"],
                        "converged": int((lg["info"]["status"] == 0).sum()), "mean_iterations": float(lg["info"]["iterations"].mean()),
-                       "two_in_flight": {"value": Bl * 2 * kl / dt2, "unit": "solves/s", "ms_per_batch": 1e3 * dt2 / (2 * kl),
-                                         "outputs_identical": same2},
+                       "two_in_flight": {"value": Bl * 2 * kl / dt2, "outputs_identical": same2},
                        "roofline": roofline_object(kn_l, ach, tr, tr_src, lg["kernel_ms"], Bl, Bl * (8 * 48 + 8 * 12 + 40))}
                 # the reference's own solver mode on the same batch (AL-iLQR, <= 10 iterations): the lane kernel's AL passes
                 # from 34816 instances on (28672 beyond N=12), the wave-per-instance reference kernels below -- the library says which
@@ -525,19 +543,13 @@ def main():
                     fam_l = srl.kernel_for_batch(Bl)
                     srl.close()
                     ent["reference_mode"] = {
-                        "value": Bl / (float(np.median(kms)) * 1e-3), "unit": "solves/s", "kernel_ms": float(np.median(kms)),
-                        "kernel": ("qmpc_lane_ref_kernel (lane per instance, AL variant of the lane passes, feedback gains in f64)"
-                                   if fam_l == "lane" else
-                                   "qmpc_ref_w_kernel<5> (wave per instance, wrench form with refined stage solves, gains in the workspace)"),
-                        "mean_iterations": float(inf_l["iterations"].mean()),
-                        "status_counts": {"converged": int((inf_l["status"] == 0).sum()), "iteration_cap": int((inf_l["status"] == 1).sum()),
-                                          "linesearch_fail": int((inf_l["status"] == 4).sum()), "not_pd": int((inf_l["status"] == 5).sum())},
-                        "note": "secondary: the reference's own operating mode (truncated AL-iLQR iterate) at this batch size; never `value`"}
+                        "value": Bl / (float(np.median(kms)) * 1e-3), "kernel_ms": float(np.median(kms)),
+                        "kernel": "qmpc_lane_ref_kernel" if fam_l == "lane" else "qmpc_ref_w_kernel (workspace form)",
+                        "mean_iterations": float(inf_l["iterations"].mean())}
                     del frl, irl, d_inl
                 sql = sq_from_profiles(Bl, Nl, "quat")
                 if sql is not None:
                     ent["roofline"]["issue_frac"] = sql.get("issue_frac")
-                    ent["roofline"]["sq_source"] = sql.get("source")
                 out["large_batch"].append(ent)
                 del lg
             # secondary: the other workloads the wrench-form wave kernels serve since round 5 -- the per-GPU share of BASELINE
@@ -545,12 +557,12 @@ def main():
             # the reference's horizon (N=20) at a mid-size batch and for the single robot; never `value`
             out["other_workloads"] = []
             for (mdl, Nl, Bl, cfg, what, *md) in (
-                    ("biped8", 16, 8192, 5, "per-GPU share of BASELINE config 5 (8 contact points, 65536 instances over 8 GPUs)"),
-                    ("convex", 20, 1024, 13, "ConvexMpc at its YAML horizon (gazebo_go1_convex_mpc.yaml), 1024 instances"),
-                    ("quat", 20, 8192, 3, "QuatMpc at the reference's own horizon (gazebo_go1_quat_mpc.yaml:36-37), mid-size batch"),
-                    ("quat", 20, 1, 3, "QuatMpc, N=20, ONE robot (device-resident launch)"),
-                    ("convex", 20, 65536, 13, "ConvexMpc in its OWN solver mode (five AL-iLQR iterations, ConvexMpc.cpp:36-38), Monte-Carlo size", 1),
-                    ("biped8", 16, 65536, 5, "8-contact-point model in the reference's solver mode (<= 10 AL-iLQR iterations), Monte-Carlo size", 1)):
+                    ("biped8", 16, 8192, 5, "per-GPU share of config 5"),
+                    ("convex", 20, 1024, 13, "ConvexMpc, YAML horizon"),
+                    ("quat", 20, 8192, 3, "reference's horizon, mid-size"),
+                    ("quat", 20, 1, 3, "one robot"),
+                    ("convex", 20, 65536, 13, "ConvexMpc, own solver mode", 1),
+                    ("biped8", 16, 65536, 5, "8-point model, reference mode", 1)):
                 mode_ = pkg.MODE_REFERENCE if md and md[0] else pkg.MODE_CONVERGED
                 pm_ = {"biped8": pkg.default_biped8_params, "convex": pkg.default_convex_params, "quat": pkg.default_params}[mdl](Nl, mode_, lib)
                 kl = max(3, min(10, args.steps))
@@ -558,10 +570,9 @@ def main():
                 fam = lg["solver"].kernel_for_batch(Bl)
                 lg["solver"].close()
                 out["other_workloads"].append({
-                    "workload": f"{mdl}, Batch={Bl}, N={Nl}, seed 0x5EED0000+{cfg}: {what}", "value": Bl * kl / lg["elapsed"], "unit": "solves/s",
-                    "ms_per_step": 1e3 * lg["elapsed"] / kl, "kernel_ms": lg["kernel_ms"], "kernel_family": fam,
-                    "solver_mode": "reference" if mode_ == pkg.MODE_REFERENCE else "converged",
-                    "converged": int((lg["info"]["status"] == 0).sum()), "mean_iterations": float(lg["info"]["iterations"].mean())})
+                    "workload": f"{mdl} B={Bl} N={Nl}: {what}", "value": Bl * kl / lg["elapsed"],
+                    "ms_per_step": 1e3 * lg["elapsed"] / kl, "kernel_family": fam,
+                    "mean_iterations": float(lg["info"]["iterations"].mean())})
                 del lg
         if world == 1 and not args.no_in_flight:
             out["two_in_flight"] = two_in_flight(pkg, lib, params, args, d_in, NU)
@@ -586,13 +597,11 @@ def main():
             du = np.abs(fr.cpu().numpy() - d_f).max(axis=1)
             sr.close()
             out["reference_mode"] = {
-                "value": B * args.steps / dt, "unit": "solves/s", "ms_per_step": 1e3 * dt / args.steps,
+                "value": B * args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
                 "iterations_max": int(pr.iterations_max), "mean_iterations": float(ri["iterations"].mean()),
                 "status_counts": {"converged": int((ri["status"] == 0).sum()), "iteration_cap": int((ri["status"] == 1).sum()),
                                   "linesearch_fail": int((ri["status"] == 4).sum()), "not_pd": int((ri["status"] == 5).sum())},
-                "u0_distance_to_converged_N": {"median": float(np.median(du)), "p90": float(np.percentile(du, 90)), "max": float(du.max())},
-                "note": "secondary: what the reference's solver mode returns (a <=10-iteration AL-iLQR iterate) and what it "
-                        "costs on this GPU; the contract value is the converged mode"}
+                "u0_distance_to_converged_N": {"median": float(np.median(du)), "max": float(du.max())}}
         if world == 1 and args.model == "quat" and not args.no_closed_loop:
             # secondary: the device-resident closed loop (front end + solve + plant per tick, state in HBM) for B robots
             # with DIFFERENT commands (the Monte-Carlo use; 10 % stand): 8 stand ticks, 40 ticks into the gait, then 100
@@ -609,6 +618,7 @@ def main():
             pl = pkg.default_params(N, pkg.MODE_CONVERGED, lib)
             pl.drop_ang_vel = 0          # the MPC sees the body's angular velocity (with the reference's x_init quirk the
             sl = pkg.Solver(pl, B, device=local, lib=lib)   # ideal plant is undamped: DESIGN 3e); its own handle
+            sl_form = B <= 2048 and os.environ.get("QMPC_LOOP_FUSED") != "0"
             st = sl.loop_run(st, 8, lp)
             st["movement_mode"] = walk.astype(float)
             d_st = torch.from_numpy(st.view(np.uint8).reshape(B, -1).copy()).cuda()
@@ -639,18 +649,12 @@ def main():
             sl.close()
             fin = np.ascontiguousarray(d_st.cpu().numpy()).view(pkg.LOOP_STATE_DTYPE).reshape(B)
             out["closed_loop"] = {"value": B * ticks / dt, "unit": "robot-ticks/s", "ticks": ticks, "robots": B,
-                                  "ms_per_tick": 1e3 * dt / ticks, "solver_ok": int((fin["status"] == 0).sum()),
+                                  "solver_ok": int((fin["status"] == 0).sum()),
                                   "mean_iterations": float(fin["iterations"].mean()),
-                                  "warm_start": {"value": B * ticks / dtw, "unit": "robot-ticks/s", "ms_per_tick": 1e3 * dtw / ticks,
-                                                 "solver_ok": int((finw["status"] == 0).sum()),
+                                  "warm_start": {"value": B * ticks / dtw, "solver_ok": int((finw["status"] == 0).sum()),
                                                  "mean_iterations": float(finw["iterations"].mean()),
-                                                 "position_difference_to_cold_start_m": float(np.abs(finw["pos_world"] - fin["pos_world"]).max()),
-                                                 "note": "qmpc_loop_params.warm_start = 1, params.ipm_mu0 = 1e-6"},
-                                  "launch_form": ("persistent wave-per-robot kernel" if B <= 2048 and os.environ.get("QMPC_LOOP_FUSED") != "0"
-                                                  else "three kernels per tick (graph replay)"),
-                                  "note": "secondary: qmpc_loop_run_device (goal + gait FSM + swing quintic + Raibert + "
-                                          "record packing -> solve -> rigid-body plant), robots with random commands, params.drop_ang_vel = 0, state "
-                                          "resident in HBM; tools/loop_bench.py compares the two launch forms"}
+                                                 "position_difference_to_cold_start_m": float(np.abs(finw["pos_world"] - fin["pos_world"]).max())},
+                                  "launch_form": loop_form(sl_form)}
             if B == 1024 and N == 10 and not args.no_large_batch:
                 # ... and the Monte-Carlo scale: 65536 robots, per-tick launch form, the solves on the lane-per-instance
                 # kernel (cold start); 8 stand ticks, 30 ticks into the gait, 40 timed ticks
@@ -685,16 +689,13 @@ def main():
                 dtlw = time.perf_counter() - t0lw
                 finlw = np.ascontiguousarray(d_swl.cpu().numpy()).view(pkg.LOOP_STATE_DTYPE).reshape(BL)
                 swl.close()
-                out["closed_loop"]["large"] = {"value": BL * tl / dtl, "unit": "robot-ticks/s", "robots": BL, "ticks": tl,
-                                               "ms_per_tick": 1e3 * dtl / tl, "solver_ok": int((finl["status"] == 0).sum()),
+                out["closed_loop"]["large"] = {"value": BL * tl / dtl, "robots": BL, "ticks": tl,
+                                               "solver_ok": int((finl["status"] == 0).sum()),
                                                "mean_iterations": float(finl["iterations"].mean()),
-                                               "warm_start": {"value": BL * tl / dtlw, "unit": "robot-ticks/s",
-                                                              "ms_per_tick": 1e3 * dtlw / tl,
+                                               "warm_start": {"value": BL * tl / dtlw,
                                                               "solver_ok": int((finlw["status"] == 0).sum()),
-                                                              "mean_iterations": float(finlw["iterations"].mean()),
-                                                              "position_difference_to_cold_start_m":
-                                                                  float(np.abs(finlw["pos_world"] - finl["pos_world"]).max())},
-                                               "launch_form": "three kernels per tick (graph replay), solve = qmpc_lane_kernel (cold start: stragglers beyond 12 iterations continued by qmpc_solve_w_list_kernel inside the tick)"}
+                                                              "mean_iterations": float(finlw["iterations"].mean())},
+                                               "launch_form": "per-tick graph, lane kernel + hand-off"}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(pkg, N, config_id, model=args.model)
             f_cpu = cb.pop("_forces")
@@ -704,7 +705,7 @@ def main():
             out["cpu_baseline"] = cb
         flush_c_stdio()
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        print(json.dumps(compact(out), separators=(",", ":")), flush=True)
     solver.close()
     if multi:
         dist.destroy_process_group()

@@ -1779,6 +1779,26 @@ def test_c_example_runs_on_the_gpu(pkg, lib, tmp_path):
     assert r.stdout.count("status 0") == 16
 
 
+def test_cpp_sharded_example_runs_on_the_visible_devices(pkg, lib, tmp_path):
+    """examples/solve_sharded.cpp: one process, one host thread + one handle per visible device, contiguous shards,
+    qmpc_solve_device + ONE qmpc_gather (ncclAllGather) per device carrying forces and status words -- the C++ host's form
+    of the multi-GPU path (on a one-GPU box: one device, a one-rank communicator)."""
+    import shutil
+    import subprocess
+
+    repo = Path(__file__).resolve().parents[1]
+    so = repo / "quaternion-mpc_amd" / "csrc" / "libqmpc_hip.so"
+    if not (Path("/opt/rocm/include/rccl/rccl.h").exists() and shutil.which("g++")):
+        pytest.skip("RCCL headers / g++ not available")
+    exe = tmp_path / "solve_sharded"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", str(repo / "include"), "-I", "/opt/rocm/include",
+                    str(repo / "examples" / "solve_sharded.cpp"), "-o", str(exe), str(so), f"-Wl,-rpath,{so.parent}",
+                    "-L", "/opt/rocm/lib", "-lamdhip64", "-lrccl", "-lpthread"], check=True)
+    r = subprocess.run([str(exe), "3000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "not converged: 0" in r.stdout and "identical on all devices: yes" in r.stdout
+
+
 def test_loop_joint_velocities_are_the_time_derivative_of_the_joint_angles(pkg, lib):
     """The 'measured' joint velocities of the loop's joint level are J^-1 (R'(v_foot - v_torso) - w x foot_body): with the
     body turning (yaw-rate command, so w != 0) they must agree with the finite difference of the joint angles between two
