@@ -1525,9 +1525,14 @@ static qmpc_status loop_run_impl(qmpc_handle* h, const qmpc_loop_params* lp, int
   // measured, persistent vs per-tick: +25 % (256), +28 % (1024), +8 % (2048), -3 % (4096); with the warm start, whose
   // iteration counts spread more: +61 % (1024), +33 % (2048), +8 % (4096), -14 % (16384)
   // (ConvexMpc's own solver mode: the persistent kernel exists on the wrench-form reference bodies only)
+  // Round 6 (tools/r06_loop_decide.sh, profiles/r06_loop_decide.txt): the workspace-form instantiations (two waves per SIMD,
+  // 256 registers, 41 ... 165 spilled VGPRs outside their inner loops) were measured against the per-tick form on every
+  // configuration that selects them -- persistent +8 ... +45 % everywhere except ConvexMpc's own solver mode in the workspace
+  // form (N=20, 2048 robots: 0.849 vs 0.832 ms per tick), which therefore takes the per-tick form unless forced.
+  const bool conv_ref_ws = convex && h->params.mode == QMPC_MODE_REFERENCE && ref_wform_variant(h, batch) == 5;
   const bool fused = (convex && h->params.mode == QMPC_MODE_REFERENCE && !ref_wform_variant(h, batch))
                          ? false
-                         : (fused_env >= 0 ? fused_env == 1 : batch <= (warm ? 4096 : 2048));
+                         : (fused_env >= 0 ? fused_env == 1 : (batch <= (warm ? 4096 : 2048) && !conv_ref_ws));
   if (fused) {
     const bool ref = h->params.mode == QMPC_MODE_REFERENCE;
     // the reference-mode kernels exist with everything in LDS (0) and with the gains in the workspace (1): launch_solve's rule
