@@ -147,12 +147,15 @@ constexpr int kLaneMinLoopCold = 18432;       // ... of the cold-started closed 
 // (with the warm instantiations of the split passes, warm-started loops, lane vs wave kernels: N=10 16384 robots 7.13 vs 7.70 M
 // robot-ticks/s, 20480: 8.59 vs 7.84, 24576: 9.95 vs 7.98, 32768: 12.1 vs 8.2; N=20 16384: 3.68 vs 4.19, 24576: 5.19 vs 4.31)
 constexpr int kLaneMinWarm = 18432, kLaneMinWarmLong = 20480, kLaneMinWarmVeryLong = 18432;
-constexpr int kLaneMinBatch = 15872;          // QuatMpc, horizons up to 12
+// Round 6 (apply pass split across the lane pair, stores outside the per-lane conditions: a round of the lane kernel another
+// 7-10 % cheaper): N=10 13312 instances wave 4.14 vs lane 4.39 ms, 14336: 4.35 vs 4.42, 16384: 4.88 vs 4.45; N=16 14336: 6.93 vs 7.22,
+// 16384: 7.80 vs 7.37; N=20 14336: 9.15 vs 9.65, 16384: 10.16 vs 9.73; N=24 14336: 11.8 vs 12.2 (tools/lane_switch_scan.py)
+constexpr int kLaneMinBatch = 14848;          // QuatMpc, horizons up to 12
 // QuatMpc, longer horizons; round 5 (the wave side is the wrench-form kernel with its slack arrays in the workspace, WVAR 6):
 // N=16 20480: wave 2.20 vs lane 2.15 M solves/s, 24576: 2.23 vs 2.52; N=20 20480: 1.64 vs 1.60, 24576: 1.67 vs 1.90;
 // N=24 16384: 1.20 vs 1.03, 20480: 1.20 vs 1.25
-constexpr int kLaneMinBatchLong = 17408;
-constexpr int kLaneMinBatchVeryLong = 16384;  // horizons beyond 22
+constexpr int kLaneMinBatchLong = 15872;
+constexpr int kLaneMinBatchVeryLong = 15872;  // horizons beyond 22
 constexpr int kLaneMinBatchOther = 18432;      // ConvexMpc, short horizons (round-1 wave kernels below it)
 // ConvexMpc at its own horizon (N=20; WVAR 6 below the threshold): 20480 instances wave 1.21 vs lane 1.11 M, 24576: 1.22 vs 1.29
 constexpr int kLaneMinBatchConvexLong = 22528;
@@ -1107,10 +1110,18 @@ qmpc_status qmpc_prepare(qmpc_handle* h, int32_t batch) {
     const qmpc_status es = ensure_lane_buffers(h);
     if (es != QMPC_OK) return es;
     if (!ref_lane && (handoff_cap(h, 1) || handoff_cap(h, 2) || handoff_cap(h, 3))) (void)ensure_handoff_buffers(h);
-  } else if (h->zero_copy) {
+  }
+  // the pinned staging of the host-buffer calls: ALWAYS (a handle prepared for a lane-kernel batch may still be handed a smaller
+  // batch on host buffers, which runs zero-copy), and the buffers the closed loops and the trajectory / warm-started calls
+  // otherwise allocate on first use -- nothing of that may happen inside a caller's stream capture
+  if (h->zero_copy) {
     const qmpc_status es = ensure_stage(h, model_nl(h->params.model));
     if (es != QMPC_OK) return es;
   }
+  const int nu = 3 * model_nl(h->params.model), N = h->params.horizon;
+  if (!h->d_traj_u) HIP_TRY(hipMalloc(&h->d_traj_u, sizeof(double) * nu * N * (size_t)h->max_batch));
+  if (!h->d_traj_x) HIP_TRY(hipMalloc(&h->d_traj_x, sizeof(double) * 13 * (N + 1) * (size_t)h->max_batch));
+  if (!h->d_loop_row) HIP_TRY(hipMalloc(&h->d_loop_row, sizeof(int) * 4));
   return QMPC_OK;
 }
 
