@@ -172,7 +172,7 @@ __device__ __noinline__ void call_M(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, 
   pass_M<NL, UPDATE, MD>(P, c, O, K, st, al);
   priv_store(alp, al);
 }
-template <int NL, int MD>
+template <int NL, int MD, bool PAIR = false>
 __device__ __noinline__ bool call_B_AL(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp, QL_PRIV_AS LaneAL* alp) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
@@ -183,11 +183,11 @@ __device__ __noinline__ bool call_B_AL(PassArgs a, QL_PRIV_AS const LaneK<NL>* K
   priv_load(st, sp);
   LaneAL al;
   priv_load(al, (QL_PRIV_AS const LaneAL*)alp);
-  const bool ok = pass_B<NL, false, MD, true>(P, c, O, K, st, (FootPtr)Kp->foot, &al);
+  const bool ok = pass_B<NL, false, MD, true, PAIR>(P, c, O, K, st, (FootPtr)Kp->foot, &al);
   priv_store(alp, al);
   return ok;
 }
-template <int NL, int MD>
+template <int NL, int MD, bool PAIR = false>
 __device__ __noinline__ void call_C_AL(PassArgs a, QL_PRIV_AS const LaneK<NL>* Kp, QL_PRIV_AS const LaneState* sp, QL_PRIV_AS LaneAL* alp) {
   const DevParams& P = ql_params[__builtin_amdgcn_readfirstlane(a.pslot)];
   const Ctx c = pass_ctx<NL>(a);
@@ -198,7 +198,7 @@ __device__ __noinline__ void call_C_AL(PassArgs a, QL_PRIV_AS const LaneK<NL>* K
   priv_load(st, sp);
   LaneAL al;
   priv_load(al, (QL_PRIV_AS const LaneAL*)alp);
-  pass_C_AL<NL, 2, MD>(P, c, O, K, st, al, true);
+  pass_C_AL<NL, 2, MD, PAIR>(P, c, O, K, st, al, true);
   priv_store(alp, al);
 }
 template <int NL, int MD>
@@ -233,13 +233,27 @@ template <int NL, int MD = MD_QUAT>
 __global__ __launch_bounds__(kLaneWave) void qmpc_lane_ref_kernel(int pslot, const double* __restrict__ in, double* __restrict__ forces,
                                                                   qmpc_info* __restrict__ info, int batch, double* __restrict__ ws,
                                                                   unsigned slots, int lanes, const int* __restrict__ perm,
-                                                                  double* traj_u, double* traj_x) {
+                                                                  double* traj_u, double* traj_x, long long* __restrict__ prof) {
   typedef LDim<NL> D;
   const int lane = threadIdx.x;
   const DevParams& P = ql_params[pslot];
+#if defined(QL_PROFILE)
+  long long tp[6] = {0, 0, 0, 0, 0, 0}, tl = clock64();      // diagnostic build: cycles in B / C / A / S / M / rest (lane 0's clock)
+#define QL_RTICK(i) do { const long long n_ = clock64(); tp[i] += n_ - tl; tl = n_; } while (0)
+#else
+#define QL_RTICK(i) do { } while (0)
+#endif
   const size_t block_elems = (size_t)make_wsoff<NL>(P.N, true).total * kLaneWave;      // wide layout: the second gain block
   const unsigned long long wsb = reinterpret_cast<unsigned long long>(ws + (size_t)blockIdx.x * block_elems);
-  const PassArgs a = {pslot, (unsigned)wsb, (unsigned)(wsb >> 32), 8u * (unsigned)lane, 0u, 0u, 0x1F8u};
+  // Lane pairs (four-point quaternion model, batches that fill half of every wavefront; round 6): lanes i and i + 32 take the SAME
+  // instance, every pass duplicated on the partner except the per-point blocks of the trial sweeps, which the pair splits
+  // (pass_C_AL<..., PAIR>).  The launcher passes lanes = -34; QMPC_LANE_PAIR=0 restores the masked half.
+  constexpr bool kPairable = NL == 4 && MD == MD_QUAT;
+  const bool pairm = kPairable && lanes < 0;
+  if (lanes < 0) lanes = 32;
+  const int lane_i = pairm ? (lane & 31) : lane;
+  const PassArgs a = {pslot, (unsigned)wsb, (unsigned)(wsb >> 32), 8u * (unsigned)lane_i, 0u, pairm ? (unsigned)(lane >> 5) : 0u,
+                      pairm ? 0xF8u : 0x1F8u};
   const size_t tstride = (size_t)P.N * D::NU;
   LaneK<NL> K;
   LaneState st;
@@ -248,8 +262,8 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_ref_kernel(int pslot, con
   QL_PRIV_AS LaneState* sp = (QL_PRIV_AS LaneState*)&st;
   QL_PRIV_AS LaneAL* alp = (QL_PRIV_AS LaneAL*)&al;
   for (long long base = (long long)blockIdx.x * lanes; base < batch; base += slots) {
-    const long long pos = base + lane;
-    const bool valid = lane < lanes && pos < batch;
+    const long long pos = base + lane_i;
+    const bool valid = (pairm || lane < lanes) && pos < batch;
     const int b = valid ? (perm ? perm[pos] : (int)pos) : 0;
     bool active = false;
     if (valid) {
@@ -266,16 +280,19 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_ref_kernel(int pslot, con
     }
     while (__any(active)) {
       bool searching = false;
+      QL_RTICK(5);
       if (active) {
         ++iter;
-        if (!call_B_AL<NL, MD>(a, Kp, sp, alp)) { st.status = QMPC_NOT_PD; --iter; active = false; }
+        if (!((kPairable && pairm) ? call_B_AL<NL, MD, kPairable>(a, Kp, sp, alp) : call_B_AL<NL, MD>(a, Kp, sp, alp))) { st.status = QMPC_NOT_PD; --iter; active = false; }
         else { al.alpha = 1.0; searching = true; }
       }
+      QL_RTICK(0);
       bool accepted = false;
       int ls = 0;
       while (__any(searching)) {
         if (searching) {
-          call_C_AL<NL, MD>(a, Kp, sp, alp);                  // trials ls and ls + 1 (step lengths alpha, alpha / 2) in one sweep
+          // trials ls and ls + 1 (step lengths alpha, alpha / 2) in one sweep
+          if (kPairable && pairm) call_C_AL<NL, MD, kPairable>(a, Kp, sp, alp); else call_C_AL<NL, MD>(a, Kp, sp, alp);
           if (al_accept_pair(P, al, ls)) { accepted = true; searching = false; }
           else {
             ls += 2;
@@ -283,20 +300,28 @@ __global__ __launch_bounds__(kLaneWave) void qmpc_lane_ref_kernel(int pslot, con
           }
         }
       }
+      QL_RTICK(1);
       if (active && !accepted) { st.status = QMPC_LINESEARCH_FAIL; --iter; active = false; }
       if (active) {
         call_A_AL<NL, MD>(a, Kp, sp, al.sel);
+        QL_RTICK(2);
         st.last_step = al.stp;
         const double dJ = al.J - al.Jn;
         al.J = al.Jn; al.Jp = al.Jnp; al.viol = al.vn;
         call_S<NL, MD>(a, Kp, sp, alp);
+        QL_RTICK(3);
         if (al.stat < P.tol_stat && al.viol < P.tol_feas) { st.status = QMPC_OK; active = false; }
         else {
           if (al.stat < P.tol_stat || fabs(dJ) < P.tol_cost_int) call_M<NL, true, MD>(a, Kp, sp, alp);
           if (iter >= P.iterations_max) active = false;
         }
+        QL_RTICK(4);
       }
     }
+#if defined(QL_PROFILE)
+    if (prof && base < (long long)slots && lane == 0)
+      for (int i = 0; i < 6; ++i) prof[16 * blockIdx.x + i] = tp[i];
+#endif
     if (valid) {
       st.iters = iter;
       if (st.active) st.mu = al.rho;       // the info record's last field is the penalty in this mode
@@ -627,13 +652,29 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
     if (u_init) return hipErrorInvalidValue;
     if (nl == 8)
       hipLaunchKernelGGL(qmpc_lane_ref_kernel<8>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm,
-                         traj_u, traj_x);
+                         traj_u, traj_x, prof);
     else if (convex)
       hipLaunchKernelGGL((qmpc_lane_ref_kernel<4, MD_CONVEX>), dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used,
-                         lanes, perm, traj_u, traj_x);
-    else
-      hipLaunchKernelGGL(qmpc_lane_ref_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm,
-                         traj_u, traj_x);
+                         lanes, perm, traj_u, traj_x, prof);
+    else {
+      static const int pair_ref_env = std::getenv("QMPC_LANE_PAIR") ? std::atoi(std::getenv("QMPC_LANE_PAIR")) : 1;
+      hipLaunchKernelGGL(qmpc_lane_ref_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used,
+                         (lanes == 32 && pair_ref_env) ? -34 : lanes, perm, traj_u, traj_x, prof);
+    }
+#if defined(QL_PROFILE)
+    {
+      static long long hp[16 * 1024];
+      if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(hp, d_prof, sizeof hp, hipMemcpyDeviceToHost) == hipSuccess) {
+        static const char* names[6] = {"B_AL", "C_AL (line search)", "A_AL", "S", "M (+tests)", "rest"};
+        const unsigned nw = waves < 1024 ? waves : 1024;
+        double sum[6] = {0}, tot = 0.0;
+        for (unsigned w = 0; w < nw; ++w) for (int i = 0; i < 6; ++i) sum[i] += (double)hp[16 * w + i];
+        for (int i = 0; i < 6; ++i) tot += sum[i];
+        std::fprintf(stderr, "lane ref profile: batch %d N %d waves %u, %.0f cycles per wavefront\n", batch, P.N, waves, tot / nw);
+        for (int i = 0; i < 6; ++i) std::fprintf(stderr, "  %-20s %10.0f cycles  %5.1f %%\n", names[i], sum[i] / nw, 100.0 * sum[i] / tot);
+      }
+    }
+#endif
     return hipGetLastError();
   }
   if (nl == 8)

@@ -1271,7 +1271,7 @@ struct LaneAL {
 template <int NL, bool WARM = false, int MD = MD_QUAT, bool AL = false, bool PAIR = false>
 QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const LaneK<NL>& K, LaneState& st, FootPtr fp,
                   LaneAL* al = nullptr) {
-  static_assert(!PAIR || (MD != MD_CONVEX && !AL && NL == 4), "pair split: converged passes of the four-point quaternion model");
+  static_assert(!PAIR || (MD != MD_CONVEX && NL == 4), "pair split: the four-point quaternion model");
   Ctx c = c_in;
   typedef LDim<NL> D;
   const int N = P.N;
@@ -1371,7 +1371,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
           c.relane();
           fetch_ahead<NL>(c, O, k, pair_point(rd + 1, ex), R, fp, rcrows);
         }
-        double wp[3] = {0, 0, 0}, r6p[6] = {0, 0, 0, 0, 0, 0}, G6p[21];
+        double wp[3] = {0, 0, 0}, r6p[6] = {0, 0, 0, 0, 0, 0}, G6p[21], gamp = 0.0;
 #pragma unroll
         for (int i = 0; i < 21; ++i) G6p[i] = 0.0;
         {
@@ -1388,13 +1388,27 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
 #pragma unroll
             for (int a = 0; a < 3; ++a) Rw[a] = second ? ql_uniform(P.R[3 * qb + a]) : ql_uniform(P.R[3 * qa + a]);
           }
-          leg_block(P, cr, rcl, lm, sv, lv, kap, st.rho, st.target, u, st.uz, lb, QL_B_RW ? Rw : nullptr);
+          if constexpr (AL) {      // augmented-Lagrangian weights instead of barrier weights (see the plain form below)
+            kap = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+              double cv = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
+              if (i == 4) cv += -P.fz_max;
+              const double z = lv[i] + al->rho * cv;
+              const bool act = z > 0.0;
+              sv[i] = 1.0;
+              rcl[i] = act ? z * al->irho : 0.0;
+              lv[i] = act ? al->rho : 0.0;
+            }
+          }
+          leg_block(P, cr, rcl, lm, sv, lv, kap, AL ? 1.0 : st.rho, AL ? 0.0 : st.target, u, st.uz, lb, QL_B_RW ? Rw : nullptr);
           double V[18];
 #pragma unroll
           for (int i = 0; i < 9; ++i) V[i] = lb.T[i];
           mm(B, lb.T, &V[9]);
           const double y0 = lb.gq[0], y1 = lb.gq[1] - lb.l10 * y0, y2 = lb.gq[2] - lb.l20 * y0 - lb.l21 * y1;
           const double z0 = lb.id0 * y0, z1 = lb.id1 * y1, z2 = lb.id2 * y2;
+          if constexpr (AL) gamp = y0 * z0 + y1 * z1 + y2 * z2;
           double v0[6], v1[6], v2[6];
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
@@ -1420,6 +1434,12 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
           ql_pair(wp[a], lo, hi);
           if (on_lo) wd[a] += lo;
           if (on_hi) wd[a] += hi;
+        }
+        if constexpr (AL) {
+          double lo, hi;
+          ql_pair(gamp, lo, hi);
+          if (on_lo) gam += lo;
+          if (on_hi) gam += hi;
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -2524,8 +2544,13 @@ QL_FN void pass_A_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
 // state, gains, inputs, multipliers) and the per-point blocks (weights, frame, L D L': functions of the current inputs only);
 // the rollout, the input recovery and the merit terms run once per step length.  The increments of the second trial go to the
 // RC slot (unused in this mode), 3 NL per knot like the dU slot.
-template <int NL, int NA = 2, int MD = MD_QUAT>
+// PAIR (lane pairs, four-point quaternion model): the two points of a diagonal pair go to the two partner lanes -- one per-point
+// block per lane and pair instead of two; force / torque / objective shares cross the pair (v_permlane32_swap) and are added as
+// (acc + first) + second, the penalty sum runs as a chain over the lower lane's six rows, then over the upper lane's.  The plain
+// form of the four-point models visits the points in the same order (0, 3, 1, 2), so a pair-mode sweep returns its bits.
+template <int NL, int NA = 2, int MD = MD_QUAT, bool PAIR = false>
 QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<NL>& K, const LaneState& st, LaneAL& al, bool live) {
+  static_assert(!PAIR || (NL == 4 && MD == MD_QUAT), "pair split: the four-point quaternion model");
   typedef LDim<NL> D;
   const int N = P.N;
   const double gb[3] = {K.rot[6] * (-9.81), K.rot[7] * (-9.81), K.rot[8] * (-9.81)};
@@ -2560,13 +2585,31 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
 #pragma unroll
     for (int i = 0; i < 6; ++i) lk[6 * l + i] = c.W(O.LAM + 6 * NL * k + 6 * l + i);
   };
+  // pair form: one buffer per diagonal pair, holding THIS lane's point of it (per-lane row address)
+  auto load_pair = [&](int k, int pr) {
+    const int lm = c.half ? pair_leg<NL>(pr, 1) : pair_leg<NL>(pr, 0);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) uk[3 * pr + a] = c.W(O.U + 3 * NL * k + 3 * lm + a);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lk[6 * pr + i] = c.W(O.LAM + 6 * NL * k + 6 * lm + i);
+  };
+  // which pairs any lane of the wavefront has in stance
+  unsigned porder = 0;
+#pragma unroll
+  for (int pr = 0; pr < NL / 2; ++pr)
+    porder |= (((order >> pair_leg<NL>(pr, 0)) | (order >> pair_leg<NL>(pr, 1))) & 1u) << pr;
   load_head(0);
 #if QL_AL_G2_AHEAD == 2
 #pragma unroll
   for (int i = 0; i < D::GAIN2; ++i) g2[i] = c.W(O.G2 + i);
 #endif
+  if constexpr (PAIR) {
 #pragma unroll
-  for (int l = 0; l < NL; ++l) if ((order >> l) & 1u) load_leg(0, l);
+    for (int pr = 0; pr < NL / 2; ++pr) if ((porder >> pr) & 1u) load_pair(0, pr);
+  } else {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) if ((order >> l) & 1u) load_leg(0, l);
+  }
   double Jp[NA], alsum[NA], viol[NA], stp[NA];
   bool bad[NA];
 #pragma unroll
@@ -2625,21 +2668,10 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
     for (int q = 0; q < NA; ++q)
 #pragma unroll
       for (int a = 0; a < 3; ++a) { F[q][a] = 0.0; wd[q][a] = K.wd0[a]; }
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-      if (!((order >> l) & 1u)) continue;       // wave-uniform
-      double u[3], lam[6], sv[6], lv[6], rcl[6], B[9];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) u[a] = uk[3 * l + a];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) lam[i] = lk[6 * l + i];
-      load_leg(kn, l);
-      double dq[NA][3];      // the trials' increments of this point (what goes to the dU / RC slots)
-#pragma unroll
-      for (int q = 0; q < NA; ++q)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) dq[q][a] = 0.0;
-      if ((st.con >> l) & 1u) {
+    // one contact point: AL weights, factorised block, the trials' increments, new inputs, torque shares and merit terms
+    auto point = [&](const double u[3], const double lam[6], const double r[3], const double Rw[3], int l, double dq[NA][3],
+                     double fun[NA][3], double ftq[NA][3], double ju[NA], double at[NA][6]) {
+      double sv[6], lv[6], rcl[6], B[9];
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         double cv = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
@@ -2650,10 +2682,10 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
         rcl[i] = act ? z * al.irho : 0.0;
         lv[i] = act ? al.rho : 0.0;
       }
-      if constexpr (MD == MD_CONVEX) cv_leg_bw0(Wk, &K.foot[3 * l], B);
-      else leg_bw0(P, &K.foot[3 * l], B);
+      if constexpr (MD == MD_CONVEX) cv_leg_bw0(Wk, r, B);
+      else leg_bw0(P, r, B);
       LegBlk lb;
-      leg_block(P, cr, rcl, l, sv, lv, 0u, 1.0, 0.0, u, st.uz, lb);
+      leg_block(P, cr, rcl, l, sv, lv, 0u, 1.0, 0.0, u, st.uz, lb, Rw);
 #pragma unroll
       for (int q = 0; q < NA; ++q) {
         // rhs = T'(zeta_f + Bw0' zeta_t) + alpha gq;  du = -T Db^-1 rhs
@@ -2674,20 +2706,125 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
           bad[q] = bad[q] || !(fabs(du) <= 1e300);
           un[a] = u[a] + du;
           dq[q][a] = du;
+          fun[q][a] = un[a];
         }
-        Jp[q] += al_point_terms(P, cr, l, un, st.uz, lam, al.rho, alsum[q], viol[q]);
-        if constexpr (MD == MD_CONVEX) {      // the rollout wants the raw torque r x u
+        // the terms of al_point_terms: input cost, and per row the penalty term z^2 - lam^2 (added to the running sum by the caller)
+        const double e2 = un[2] - st.uz;
+        ju[q] = 0.5 * Rw[0] * un[0] * un[0] + 0.5 * Rw[1] * un[1] * un[1] + 0.5 * Rw[2] * e2 * e2;
 #pragma unroll
-          for (int a = 0; a < 3; ++a) F[q][a] += un[a];
-          cv_cross_acc(&K.foot[3 * l], un, wd[q]);
+        for (int i = 0; i < 6; ++i) {
+          double cv = cr[3 * i] * un[0] + cr[3 * i + 1] * un[1] + cr[3 * i + 2] * un[2];
+          if (i == 4) cv += -P.fz_max;
+          double z = lam[i] + al.rho * cv;
+          if (z < 0.0) z = 0.0;
+          at[q][i] = z * z - lam[i] * lam[i];
+          viol[q] = fmax(viol[q], fmax(cv, 0.0));
+        }
+        if constexpr (MD == MD_CONVEX) {      // the rollout wants the raw torque r x u: the caller forms it
+#pragma unroll
+          for (int a = 0; a < 3; ++a) ftq[q][a] = 0.0;
         } else {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          F[q][a] += un[a];
-          wd[q][a] += B[3 * a] * un[0] + B[3 * a + 1] * un[1] + B[3 * a + 2] * un[2];
-        }
+          for (int a = 0; a < 3; ++a) ftq[q][a] = B[3 * a] * un[0] + B[3 * a + 1] * un[1] + B[3 * a + 2] * un[2];
         }
       }
+    };
+    if constexpr (PAIR) {
+#pragma unroll
+      for (int pr = 0; pr < NL / 2; ++pr) {
+        if (!((porder >> pr) & 1u)) continue;       // wave-uniform
+        constexpr int dummy_ = 0; (void)dummy_;
+        const int la = pair_leg<NL>(pr, 0), lb_ = pair_leg<NL>(pr, 1);
+        const int lm = c.half ? lb_ : la;      // this lane's point of the pair
+        const bool on_m = (st.con >> lm) & 1u;
+        double u[3], lam[6], r[3], Rw[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          u[a] = uk[3 * pr + a];
+          r[a] = c.half ? K.foot[3 * lb_ + a] : K.foot[3 * la + a];
+          Rw[a] = c.half ? ql_uniform(P.R[3 * (lb_ & 3) + a]) : ql_uniform(P.R[3 * (la & 3) + a]);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) lam[i] = lk[6 * pr + i];
+        load_pair(kn, pr);
+        double dq[NA][3], fun[NA][3], ftq[NA][3], ju[NA], at[NA][6];
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+          ju[q] = 0.0;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) { dq[q][a] = 0.0; fun[q][a] = 0.0; ftq[q][a] = 0.0; }
+#pragma unroll
+          for (int i = 0; i < 6; ++i) at[q][i] = 0.0;
+        }
+        if (on_m) point(u, lam, r, Rw, lm, dq, fun, ftq, ju, at);
+        if (live)
+#pragma unroll
+          for (int q = 0; q < NA; ++q)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) c.StOwn((q == 0 ? O.dU : O.RC) + 3 * NL * k + 3 * lm + a, dq[q][a]);
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+          double lo, hi;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            ql_pair(fun[q][a], lo, hi);
+            F[q][a] = (F[q][a] + lo) + hi;
+            ql_pair(ftq[q][a], lo, hi);
+            wd[q][a] = (wd[q][a] + lo) + hi;
+          }
+          ql_pair(ju[q], lo, hi);
+          Jp[q] = (Jp[q] + lo) + hi;
+          // the penalty sum: a chain over the first point's rows (lower lane), then over the second's (upper lane)
+          double t = alsum[q];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) t += at[q][i];
+          ql_pair(t, lo, hi);
+          alsum[q] = lo;
+          t = alsum[q];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) t += at[q][i];
+          ql_pair(t, lo, hi);
+          alsum[q] = hi;
+        }
+      }
+    } else {
+#pragma unroll
+    for (int pr = 0; pr < NL / 2; ++pr)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int l = pair_leg<NL>(pr, jj);      // (the four-point models: 0, 3, 1, 2 -- the order of the pair form)
+      if (!((order >> l) & 1u)) continue;       // wave-uniform
+      double u[3], lam[6];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) u[a] = uk[3 * l + a];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) lam[i] = lk[6 * l + i];
+      load_leg(kn, l);
+      double dq[NA][3], fun[NA][3], ftq[NA][3], ju[NA], at[NA][6];
+#pragma unroll
+      for (int q = 0; q < NA; ++q)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dq[q][a] = 0.0;
+      if ((st.con >> l) & 1u) {
+        const double Rw[3] = {P.R[(3 * l) % 12], P.R[(3 * l + 1) % 12], P.R[(3 * l + 2) % 12]};
+        point(u, lam, &K.foot[3 * l], Rw, l, dq, fun, ftq, ju, at);
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+          Jp[q] += ju[q];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) alsum[q] += at[q][i];
+          if constexpr (MD == MD_CONVEX) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) F[q][a] += fun[q][a];
+            cv_cross_acc(&K.foot[3 * l], fun[q], wd[q]);
+          } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              F[q][a] += fun[q][a];
+              wd[q][a] += ftq[q][a];
+            }
+          }
+        }
       }
       // every lane: no store under a per-lane stance condition (a wait behind a skippable block of stores waits for them; the
       // increments of a point that is not in stance are never read)
@@ -2696,6 +2833,7 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
         for (int q = 0; q < NA; ++q)
 #pragma unroll
           for (int a = 0; a < 3; ++a) c.St((q == 0 ? O.dU : O.RC) + 3 * NL * k + 3 * l + a, dq[q][a]);
+    }
     }
 #if QL_AL_G2_AHEAD == 2
     // the next knot's second gain block: issued once the per-point phase has released its registers, covered by the state steps
@@ -2712,6 +2850,14 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
   }
 #pragma unroll
   for (int q = 0; q < NA; ++q) Jp[q] += al_state_cost<MD>(P, K.refp, N, xc[q]);
+  if (PAIR)      // each lane tracked its own points' largest increment / violation
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      double lo, hi;
+      ql_pair(stp[q], lo, hi); stp[q] = fmax(lo, hi);
+      ql_pair(viol[q], lo, hi); viol[q] = fmax(lo, hi);
+      ql_pair(bad[q] ? 1.0 : 0.0, lo, hi); bad[q] = (lo != 0.0) || (hi != 0.0);
+    }
   al.Jnp = Jp[0];
   al.vn = viol[0];
   al.stp = stp[0];

@@ -684,8 +684,10 @@ def test_bench_line_contract(pkg, lib):
     assert len(lines) == 1
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "two_in_flight", "host_buffer_call"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "two_in_flight", "rates", "notes"):
         assert key in d, key
+    assert len(lines[0]) < 8000                      # the driver keeps the last 8 KB of stdout: the whole line has to fit
+    assert d["rates"]["host_buffer_call"] > 0 and d["rates"]["device_resident"] == d["value"]
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 / (256 * 4) * 4 - 1.0) < 1e-6
     rf = d["roofline"]
@@ -1978,7 +1980,7 @@ def test_prepare_and_query(pkg, lib):
     s20.close()
     p24 = pkg.default_params(24, pkg.MODE_CONVERGED, lib)
     s24 = pkg.Solver(p24, 18432, device=0, lib=lib)
-    assert s24.kernel_for_batch(16383) == "wform_ws" and s24.kernel_for_batch(16384) == "lane_handoff" and s24.query(pkg.QUERY_LANE_CAP, 1) == 17
+    assert s24.kernel_for_batch(15871) == "wform_ws" and s24.kernel_for_batch(15872) == "lane_handoff" and s24.query(pkg.QUERY_LANE_CAP, 1) == 17
     s24.close()
     os.environ["QMPC_LANE_CAP"] = "0"
     try:
