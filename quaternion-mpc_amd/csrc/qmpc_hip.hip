@@ -179,8 +179,11 @@ constexpr int kLaneCapWarm = 8;
 // line searches per 100 000 decided the other way -- and pay for it in traffic: N=10 32768 instances wave 2.88 vs lane 2.74 M,
 // 36864: 2.89 vs 3.08 M, 65536: 2.97 vs 4.61 M; N=16 24576: 1.70 vs 1.45 M, 32768: 1.71 vs 1.83 M; N=20 24576: 1.30 vs 1.21 M,
 // 28672: 1.30 vs 1.36 M, 65536: 1.32 vs 2.53 M)
-constexpr int kLaneRefMinBatch = 34816;       // N <= 12
-constexpr int kLaneRefMinBatchLong = 28672;   // horizons beyond 12
+// Round 6: the trial sweeps and the AL backward pass run as lane PAIRS below 32769 instances (a trial of the sweep per partner lane,
+// a point of the pair per lane in the per-point blocks): N=10 18432 instances wave 6.42 vs lane 6.65 ms, 20480: 7.12 vs 6.85, 32768: 11.2 vs
+// 8.2 (4.0 M solves/s); N=16 14336: 8.63 vs 9.45, 18432: 10.9 vs 10.2; N=20 14336: 11.4 vs 11.8, 16384: 12.9 vs 12.0, 32768: 25.2 vs 15.1
+constexpr int kLaneRefMinBatch = 19456;       // N <= 12
+constexpr int kLaneRefMinBatchLong = 16384;   // horizons beyond 12
 // ConvexMpc's own mode (five iterations; tools/refmode_lane_bench.py --model convex): N=20 16384 instances wave 1.70 vs lane 1.68 M solves/s,
 // 24576: 1.72 vs 2.38 M, 65536: 1.74 vs 5.61 M; N=10 16384: 3.85 vs 3.37 M, 32768: 4.00 vs 6.00 M, 65536: 4.05 vs 10.5 M
 // 8-point model (N=16; tools/refmode_lane_bench.py --model biped8), against its wrench-form reference kernels (qmpc_ref8_w_kernel):

@@ -2556,12 +2556,20 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
   const double gb[3] = {K.rot[6] * (-9.81), K.rot[7] * (-9.81), K.rot[8] * (-9.81)};
   double cr[18];
   cone_rows(P, K.rot, cr);
+  static_assert(!PAIR || NA == 2, "pair form: the two trials of a sweep go to the two partner lanes");
   double alpha[NA];
   alpha[0] = al.alpha;
   if (NA > 1) alpha[NA - 1] = 0.5 * al.alpha;
-  double xc[NA][13], xn[13];
+  // Pair form: the rollout of a trial -- state, gains times state difference, objective, state step -- is ONE lane's work (lower
+  // lane: step length alpha, upper lane: alpha / 2; NH = 1 "head trial" per lane); the trial's costate zeta crosses to the partner
+  // before the per-point blocks (each lane: ITS point, both trials), the points' shares of a trial's sums cross back to its lane
+  constexpr int NH = PAIR ? 1 : NA;
+  double alh[NH];
 #pragma unroll
-  for (int q = 0; q < NA; ++q)
+  for (int q = 0; q < NH; ++q) alh[q] = PAIR ? (c.half ? alpha[NA - 1] : alpha[0]) : alpha[q];
+  double xc[NH][13], xn[13];
+#pragma unroll
+  for (int q = 0; q < NH; ++q)
 #pragma unroll
     for (int i = 0; i < 13; ++i) xc[q][i] = c.W(O.X + i);
   const unsigned order = any_stance<NL>(st.con);
@@ -2610,13 +2618,15 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
 #pragma unroll
     for (int l = 0; l < NL; ++l) if ((order >> l) & 1u) load_leg(0, l);
   }
-  double Jp[NA], alsum[NA], viol[NA], stp[NA];
+  double Jp[NH], alsum[NH], viol[NA], stp[NA];
   bool bad[NA];
 #pragma unroll
-  for (int q = 0; q < NA; ++q) { Jp[q] = 0.0; alsum[q] = 0.0; viol[q] = 0.0; stp[q] = 0.0; bad[q] = false; }
+  for (int q = 0; q < NA; ++q) { viol[q] = 0.0; stp[q] = 0.0; bad[q] = false; }
+#pragma unroll
+  for (int q = 0; q < NH; ++q) { Jp[q] = 0.0; alsum[q] = 0.0; }
   for (int k = 0; k < N; ++k) {
     const int kn = (k + 1 < N) ? k + 1 : k;
-    double zeta[NA][6];
+    double zeta[NA][6], zh[NH][6];
 #if QL_AL_G2_AHEAD == 0
 #pragma unroll
     for (int i = 0; i < D::GAIN2; ++i) g2[i] = c.W(O.G2 + D::GAIN2 * k + i);
@@ -2627,7 +2637,7 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
       double G[12];
       if constexpr (MD != MD_CONVEX) quatG(&xo[3], G);
 #pragma unroll
-      for (int q = 0; q < NA; ++q) {
+      for (int q = 0; q < NH; ++q) {
         Jp[q] += al_state_cost<MD>(P, K.refp, k, xc[q]);
         double dx[12];
         if constexpr (MD == MD_CONVEX) {      // blocks in the recursion's order [p, phi, v, w]
@@ -2645,27 +2655,36 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
           dx[6 + a] = xc[q][7 + a] - xo[7 + a];
           dx[9 + a] = xc[q][10 + a] - xo[10 + a];
         }
-        const double isc = ql_rcp(xo[3] * xc[q][3] + xo[4] * xc[q][4] + xo[5] * xc[q][5] + xo[6] * xc[q][6]);
+        // (explicitly fused, term by term: which of two products a sum fuses is otherwise the compiler's choice, and it chose
+        // differently in the instantiation that rolls ONE trial per lane -- the pair form must return the plain form's bits)
+        const double isc = ql_rcp(fma(xo[6], xc[q][6], fma(xo[5], xc[q][5], fma(xo[4], xc[q][4], xo[3] * xc[q][3]))));
 #pragma unroll
         for (int a = 0; a < 3; ++a)
-          dx[3 + a] = (G[a] * xc[q][3] + G[3 + a] * xc[q][4] + G[6 + a] * xc[q][5] + G[9 + a] * xc[q][6]) * isc;
+          dx[3 + a] = fma(G[9 + a], xc[q][6], fma(G[6 + a], xc[q][5], fma(G[3 + a], xc[q][4], G[a] * xc[q][3]))) * isc;
         }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) zeta[q][i] = alpha[q] * gn[36 + i];
+        for (int i = 0; i < 6; ++i) zh[q][i] = ql_rounded(alh[q] * gn[36 + i]);
 #pragma unroll
         for (int j = 0; j < 6; ++j)
 #pragma unroll
-          for (int i = 0; i < 6; ++i) zeta[q][i] += gn[6 * j + i] * dx[j];
+          for (int i = 0; i < 6; ++i) zh[q][i] = fma(gn[6 * j + i], dx[j], zh[q][i]);
 #pragma unroll
         for (int j = 0; j < 6; ++j)
 #pragma unroll
-          for (int i = 0; i < 6; ++i) zeta[q][i] += g2[6 * j + i] * dx[6 + j];
+          for (int i = 0; i < 6; ++i) zh[q][i] = fma(g2[6 * j + i], dx[6 + j], zh[q][i]);
       }
     }
-    load_head(kn);
-    double F[NA][3], wd[NA][3];
 #pragma unroll
-    for (int q = 0; q < NA; ++q)
+    for (int i = 0; i < 6; ++i) {
+      if constexpr (PAIR) ql_pair(zh[0][i], zeta[0][i], zeta[NA - 1][i]);      // lower lane's trial, upper lane's trial: both to both
+      else
+#pragma unroll
+        for (int q = 0; q < NA; ++q) zeta[q][i] = zh[q < NH ? q : 0][i];
+    }
+    load_head(kn);
+    double F[NH][3], wd[NH][3];
+#pragma unroll
+    for (int q = 0; q < NH; ++q)
 #pragma unroll
       for (int a = 0; a < 3; ++a) { F[q][a] = 0.0; wd[q][a] = K.wd0[a]; }
     // one contact point: AL weights, factorised block, the trials' increments, new inputs, torque shares and merit terms
@@ -2674,9 +2693,9 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
       double sv[6], lv[6], rcl[6], B[9];
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        double cv = cr[3 * i] * u[0] + cr[3 * i + 1] * u[1] + cr[3 * i + 2] * u[2];
+        double cv = fma(cr[3 * i + 2], u[2], fma(cr[3 * i + 1], u[1], cr[3 * i] * u[0]));
         if (i == 4) cv += -P.fz_max;
-        const double z = lam[i] + al.rho * cv;
+        const double z = fma(al.rho, cv, lam[i]);
         const bool act = z > 0.0;
         sv[i] = 1.0;
         rcl[i] = act ? z * al.irho : 0.0;
@@ -2691,17 +2710,19 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
         // rhs = T'(zeta_f + Bw0' zeta_t) + alpha gq;  du = -T Db^-1 rhs
         double t[3], rh[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) t[a] = zeta[q][a] + B[a] * zeta[q][3] + B[3 + a] * zeta[q][4] + B[6 + a] * zeta[q][5];
+        // (every sum of products explicitly fused, term by term: the compiler's choice of WHICH product a sum fuses differed between
+        // the plain and the pair instantiation of this block by an ulp of the increment)
+        for (int a = 0; a < 3; ++a) t[a] = fma(B[6 + a], zeta[q][5], fma(B[3 + a], zeta[q][4], fma(B[a], zeta[q][3], zeta[q][a])));
 #pragma unroll
-        for (int a = 0; a < 3; ++a) rh[a] = lb.T[a] * t[0] + lb.T[3 + a] * t[1] + lb.T[6 + a] * t[2] + alpha[q] * lb.gq[a];
-        const double y0 = rh[0], y1 = rh[1] - lb.l10 * y0, y2 = rh[2] - lb.l20 * y0 - lb.l21 * y1;
+        for (int a = 0; a < 3; ++a) rh[a] = fma(alpha[q], lb.gq[a], fma(lb.T[6 + a], t[2], fma(lb.T[3 + a], t[1], lb.T[a] * t[0])));
+        const double y0 = rh[0], y1 = fma(-lb.l10, y0, rh[1]), y2 = fma(-lb.l21, y1, fma(-lb.l20, y0, rh[2]));
         const double z2 = y2 * lb.id2;
-        const double z1 = y1 * lb.id1 - lb.l21 * z2;
-        const double z0 = y0 * lb.id0 - lb.l10 * z1 - lb.l20 * z2;
+        const double z1 = fma(-lb.l21, z2, y1 * lb.id1);
+        const double z0 = fma(-lb.l20, z2, fma(-lb.l10, z1, y0 * lb.id0));
         double un[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          const double du = -(lb.T[3 * a] * z0 + lb.T[3 * a + 1] * z1 + lb.T[3 * a + 2] * z2);
+          const double du = -fma(lb.T[3 * a + 2], z2, fma(lb.T[3 * a + 1], z1, lb.T[3 * a] * z0));
           stp[q] = fmax(stp[q], fabs(du));
           bad[q] = bad[q] || !(fabs(du) <= 1e300);
           un[a] = u[a] + du;
@@ -2710,14 +2731,14 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
         }
         // the terms of al_point_terms: input cost, and per row the penalty term z^2 - lam^2 (added to the running sum by the caller)
         const double e2 = un[2] - st.uz;
-        ju[q] = 0.5 * Rw[0] * un[0] * un[0] + 0.5 * Rw[1] * un[1] * un[1] + 0.5 * Rw[2] * e2 * e2;
+        ju[q] = fma(0.5 * Rw[2] * e2, e2, fma(0.5 * Rw[1] * un[1], un[1], 0.5 * Rw[0] * un[0] * un[0]));
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          double cv = cr[3 * i] * un[0] + cr[3 * i + 1] * un[1] + cr[3 * i + 2] * un[2];
+          double cv = fma(cr[3 * i + 2], un[2], fma(cr[3 * i + 1], un[1], cr[3 * i] * un[0]));
           if (i == 4) cv += -P.fz_max;
-          double z = lam[i] + al.rho * cv;
+          double z = fma(al.rho, cv, lam[i]);
           if (z < 0.0) z = 0.0;
-          at[q][i] = z * z - lam[i] * lam[i];
+          at[q][i] = fma(z, z, -(lam[i] * lam[i]));
           viol[q] = fmax(viol[q], fmax(cv, 0.0));
         }
         if constexpr (MD == MD_CONVEX) {      // the rollout wants the raw torque r x u: the caller forms it
@@ -2725,7 +2746,7 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
           for (int a = 0; a < 3; ++a) ftq[q][a] = 0.0;
         } else {
 #pragma unroll
-          for (int a = 0; a < 3; ++a) ftq[q][a] = B[3 * a] * un[0] + B[3 * a + 1] * un[1] + B[3 * a + 2] * un[2];
+          for (int a = 0; a < 3; ++a) ftq[q][a] = fma(B[3 * a + 2], un[2], fma(B[3 * a + 1], un[1], B[3 * a] * un[0]));
         }
       }
     };
@@ -2762,29 +2783,34 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
           for (int q = 0; q < NA; ++q)
 #pragma unroll
             for (int a = 0; a < 3; ++a) c.StOwn((q == 0 ? O.dU : O.RC) + 3 * NL * k + 3 * lm + a, dq[q][a]);
-#pragma unroll
-        for (int q = 0; q < NA; ++q) {
-          double lo, hi;
+        {
+          // this lane's TRIAL (lower lane: 0, upper lane: NA - 1) gets both points' shares: its own point's of that trial, and the
+          // partner's point's, which the partner sends (one exchange per quantity serves both lanes); added in the plain form's
+          // order -- the pair's first point (the lower lane's) before the second
+          constexpr int q1 = NA - 1;
+          auto other = [&](double mine_for_partner) { double lo, hi; ql_pair(mine_for_partner, lo, hi); return c.half ? lo : hi; };
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
-            ql_pair(fun[q][a], lo, hi);
-            F[q][a] = (F[q][a] + lo) + hi;
-            ql_pair(ftq[q][a], lo, hi);
-            wd[q][a] = (wd[q][a] + lo) + hi;
+            const double own = c.half ? fun[q1][a] : fun[0][a], oth = other(c.half ? fun[0][a] : fun[q1][a]);
+            F[0][a] = (F[0][a] + (c.half ? oth : own)) + (c.half ? own : oth);
+            const double ownt = c.half ? ftq[q1][a] : ftq[0][a], otht = other(c.half ? ftq[0][a] : ftq[q1][a]);
+            wd[0][a] = (wd[0][a] + (c.half ? otht : ownt)) + (c.half ? ownt : otht);
           }
-          ql_pair(ju[q], lo, hi);
-          Jp[q] = (Jp[q] + lo) + hi;
-          // the penalty sum: a chain over the first point's rows (lower lane), then over the second's (upper lane)
-          double t = alsum[q];
+          {
+            const double own = c.half ? ju[q1] : ju[0], oth = other(c.half ? ju[0] : ju[q1]);
+            Jp[0] = (Jp[0] + (c.half ? oth : own)) + (c.half ? own : oth);
+          }
+          double own6[6], oth6[6];
 #pragma unroll
-          for (int i = 0; i < 6; ++i) t += at[q][i];
-          ql_pair(t, lo, hi);
-          alsum[q] = lo;
-          t = alsum[q];
+          for (int i = 0; i < 6; ++i) {
+            own6[i] = c.half ? at[q1][i] : at[0][i];
+            oth6[i] = other(c.half ? at[0][i] : at[q1][i]);
+          }
+          // the penalty sum of the trial: a chain over the first point's rows, then over the second's
 #pragma unroll
-          for (int i = 0; i < 6; ++i) t += at[q][i];
-          ql_pair(t, lo, hi);
-          alsum[q] = hi;
+          for (int i = 0; i < 6; ++i) alsum[0] += c.half ? oth6[i] : own6[i];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) alsum[0] += c.half ? own6[i] : oth6[i];
         }
       }
     } else {
@@ -2841,7 +2867,7 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
     for (int i = 0; i < D::GAIN2; ++i) g2[i] = c.W(O.G2 + D::GAIN2 * kn + i);
 #endif
 #pragma unroll
-    for (int q = 0; q < NA; ++q) {
+    for (int q = 0; q < NH; ++q) {
       if constexpr (MD == MD_CONVEX) cv_step_fw(P, xc[q], F[q], wd[q], xn);
       else srbd_step_fw(P, gb, xc[q], F[q], wd[q], xn);
 #pragma unroll
@@ -2849,24 +2875,35 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
     }
   }
 #pragma unroll
-  for (int q = 0; q < NA; ++q) Jp[q] += al_state_cost<MD>(P, K.refp, N, xc[q]);
-  if (PAIR)      // each lane tracked its own points' largest increment / violation
+  for (int q = 0; q < NH; ++q) Jp[q] += al_state_cost<MD>(P, K.refp, N, xc[q]);
+  double JpF[NA], alF[NA];
+  if constexpr (PAIR) {
+    // the trial of a lane: largest increment / violation over BOTH points (the partner sends its point's figure of that trial), then
+    // every figure of both trials to both lanes
+    constexpr int q1 = NA - 1;
+    auto other = [&](double mine_for_partner) { double lo, hi; ql_pair(mine_for_partner, lo, hi); return c.half ? lo : hi; };
+    const double sm = fmax(c.half ? stp[q1] : stp[0], other(c.half ? stp[0] : stp[q1]));
+    const double vm = fmax(c.half ? viol[q1] : viol[0], other(c.half ? viol[0] : viol[q1]));
+    const double bm = ((c.half ? bad[q1] : bad[0]) ? 1.0 : 0.0) + other((c.half ? bad[0] : bad[q1]) ? 1.0 : 0.0);
+    double lo, hi;
+    ql_pair(Jp[0], lo, hi); JpF[0] = lo; JpF[q1] = hi;
+    ql_pair(alsum[0], lo, hi); alF[0] = lo; alF[q1] = hi;
+    ql_pair(sm, lo, hi); stp[0] = lo; stp[q1] = hi;
+    ql_pair(vm, lo, hi); viol[0] = lo; viol[q1] = hi;
+    ql_pair(bm, lo, hi); bad[0] = lo != 0.0; bad[q1] = hi != 0.0;
+  } else {
 #pragma unroll
-    for (int q = 0; q < NA; ++q) {
-      double lo, hi;
-      ql_pair(stp[q], lo, hi); stp[q] = fmax(lo, hi);
-      ql_pair(viol[q], lo, hi); viol[q] = fmax(lo, hi);
-      ql_pair(bad[q] ? 1.0 : 0.0, lo, hi); bad[q] = (lo != 0.0) || (hi != 0.0);
-    }
-  al.Jnp = Jp[0];
+    for (int q = 0; q < NA; ++q) { JpF[q] = Jp[q < NH ? q : 0]; alF[q] = alsum[q < NH ? q : 0]; }
+  }
+  al.Jnp = JpF[0];
   al.vn = viol[0];
   al.stp = stp[0];
-  al.Jn = bad[0] ? (double)NAN : Jp[0] + alsum[0] / (2.0 * al.rho);
+  al.Jn = bad[0] ? (double)NAN : JpF[0] + alF[0] / (2.0 * al.rho);
   if (NA > 1) {
-    al.Jnp2 = Jp[NA - 1];
+    al.Jnp2 = JpF[NA - 1];
     al.vn2 = viol[NA - 1];
     al.stp2 = stp[NA - 1];
-    al.Jn2 = bad[NA - 1] ? (double)NAN : Jp[NA - 1] + alsum[NA - 1] / (2.0 * al.rho);
+    al.Jn2 = bad[NA - 1] ? (double)NAN : JpF[NA - 1] + alF[NA - 1] / (2.0 * al.rho);
   }
 }
 

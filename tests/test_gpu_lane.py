@@ -826,3 +826,25 @@ def test_lane_kernel_convex_and_warm_randomised_parameter_sets(pkg, lib, oracle,
         assert ok.mean() > 0.9 and np.abs(f[ok] - fo[ok]).max() < 1e-6, (t, np.abs(f[ok] - fo[ok]).max())
         di = np.abs(info["iterations"][ok].astype(int) - io["iterations"][ok].astype(int))
         assert (di <= 1).mean() >= 0.95, (t, np.bincount(di))
+
+
+@pytest.mark.parametrize("N,B", [(10, 30000), (20, 17000)])
+def test_reference_mode_lane_pairs_return_the_plain_forms_bits(pkg, lib, oracle, monkeypatch, N, B):
+    """Round 6: reference-mode batches that fill half of every wavefront run the trial sweeps and the AL backward pass as lane
+    PAIRS (a trial of the sweep per partner lane, a point of the diagonal pair per lane).  A shard solved that way returns the
+    bits of its block of a full-wavefront launch (the plain form), status and iteration words included -- which took explicit
+    fma chains in the per-point block: the compiler's choice of which product a sum fuses differed between the instantiations by
+    an ulp of the increment.  And the words are the oracle's."""
+    _forced(monkeypatch, 4)
+    p = pkg.default_params(N, pkg.MODE_REFERENCE, lib)
+    rec = pkg.random_go1_trot_states(70000, config_id=3 if N == 20 else 2)
+    s = pkg.Solver(p, 70000, device=0, lib=lib)
+    f, info = s.solve(rec[:B])                     # 32 instances per wavefront: pairs
+    ff, fi = s.solve(rec)                          # full wavefronts: the plain form
+    s.close()
+    assert np.array_equal(f, ff[:B]) and np.array_equal(info["status"], fi["status"][:B]) and \
+        np.array_equal(info["iterations"], fi["iterations"][:B])
+    idx = np.arange(0, B, B // 96)
+    fo, io = oracle.solve(p, rec[idx], threads=8)
+    assert np.array_equal(io["status"], info["status"][idx]) and np.array_equal(io["iterations"], info["iterations"][idx])
+    assert np.abs(fo - f[idx]).max() < 1e-6

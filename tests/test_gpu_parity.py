@@ -689,9 +689,9 @@ def test_bench_line_contract(pkg, lib):
     assert len(lines[0]) < 8000                      # the driver keeps the last 8 KB of stdout: the whole line has to fit
     assert d["rates"]["host_buffer_call"] > 0 and d["rates"]["device_resident"] == d["value"]
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["dtype"] == "f64" and d["vs_baseline"] is None
-    assert abs(d["value"] * d["ms_per_step"] * 1e-3 / (256 * 4) * 4 - 1.0) < 1e-6
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 / (256 * 4) * 4 - 1.0) < 1e-4
     rf = d["roofline"]
-    assert rf["bound"] in ("hbm", "mfma", "fp64 (valu+mfma)", "fp64_valu") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["bound"] in ("hbm", "mfma", "fp64 (valu+mfma)", "fp64_valu") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5 * rf["frac"]      # (the line carries six significant digits)
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
     assert cb["force_linf_instances"] == 256 and cb["force_linf_gpu_vs_cpu"] < 1e-6      # the stated tolerance
