@@ -757,6 +757,9 @@ QL_FN int next_bit(unsigned m, int l) {
 #ifndef QL_A_KNOT_AHEAD  // pass A, plain form, four points: a buffer per point, fetched a knot ahead
 #define QL_A_KNOT_AHEAD 1
 #endif
+#ifndef QL_B_COLSPLIT    // pass B, pair form: the twelve gain columns split between the partner lanes
+#define QL_B_COLSPLIT 1
+#endif
 #ifndef QL_B_RW          // pair forms: the point's input weights from wave-uniform reads and a per-lane choice (1) or indexed per lane (0)
 #define QL_B_RW 1
 #endif
@@ -1827,15 +1830,17 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     for (int j = 0; j < 12; ++j) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        Y[j][a] = mf * c.PL(SI(a, j)) + m2 * c.PL(SI(6 + a, j));
-        Y[j][3 + a] = Wh[a] * c.PL(SI(3, j)) + Wh[3 + a] * c.PL(SI(4, j)) + Wh[6 + a] * c.PL(SI(5, j)) + P.h * c.PL(SI(9 + a, j));
+        // explicit chains: which product of such a sum is contracted depends on the instantiation (the uses of Y differ between
+        // the forms of this pass), and the forms have to return each other's bits
+        Y[j][a] = fma(m2, c.PL(SI(6 + a, j)), mf * c.PL(SI(a, j)));
+        Y[j][3 + a] = fma(P.h, c.PL(SI(9 + a, j)), fma(Wh[6 + a], c.PL(SI(5, j)), fma(Wh[3 + a], c.PL(SI(4, j)), Wh[a] * c.PL(SI(3, j)))));
       }
     }
     double yg[6];     // y' = Mt'p - S6 r6
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      yg[a] = mf * pv[a] + m2 * pv[6 + a];
-      yg[3 + a] = Wh[a] * pv[3] + Wh[3 + a] * pv[4] + Wh[6 + a] * pv[5] + P.h * pv[9 + a];
+      yg[a] = fma(m2, pv[6 + a], mf * pv[a]);
+      yg[3 + a] = fma(P.h, pv[9 + a], fma(Wh[6 + a], pv[5], fma(Wh[3 + a], pv[4], Wh[a] * pv[3])));
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -1856,8 +1861,65 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     if (kXAhead)
 #pragma unroll
       for (int i = 0; i < 13; ++i) xk[i] = c.W(O.X + 13 * k + i);
+    // Pair form: the twelve gain / cost-to-go columns are split between the partner lanes -- column p on the lower lane, column
+    // p + 6 on the upper, the same instruction stream with per-lane operands (a register select for the column of Y, per-lane
+    // workspace / LDS addresses); the rows p + 1 .. p + 6 of the upper lane's longer column run with the lower lanes masked.  Each
+    // column is computed by exactly the arithmetic of the plain form, so the cost-to-go entries and the gains are its bits; the
+    // gradient column (which updates p, a register of both lanes) stays on both.
+    constexpr bool kColSplit = PAIR && QL_B_COLSPLIT;
+    if constexpr (kColSplit) {
 #pragma unroll
-    for (int j = 0; j < 13; ++j) {
+      for (int p = 0; p < 6; ++p) {
+        double yj[6], z[6];
+        c.relane();
+        const int jm = c.half ? p + 6 : p;      // this lane's column
+#pragma unroll
+        for (int i = 0; i < 6; ++i) yj[i] = c.half ? Y[p + 6][i] : Y[p][i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < 6; ++t) s += Z[S6I(i, t)] * yj[t];
+          z[i] = s;
+        }
+        double xg[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          double s = yj[i];
+#pragma unroll
+          for (int t = 0; t < 6; ++t) s -= S6[S6I(i, t)] * z[t];
+          xg[i] = s;
+        }
+        if (AL) {      // double precision: columns 0..5 in the slot (lower lane), 6..11 in the second block (upper lane)
+          const int base = c.half ? O.G2 + D::GAIN2 * k + 6 * p : O.G + D::GAIN * k + 6 * p;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) c.StOwn(base + i, xg[i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) c.StOwn(O.G + D::GAIN * k + 3 * jm + i, pack2f((float)xg[2 * i], (float)xg[2 * i + 1]));
+        }
+        // rows 0 .. p of both lanes' columns: SI(i, p + 6) = SI(i, p) + 6 for i <= p
+#pragma unroll
+        for (int i = 0; i <= p; ++i) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < 6; ++t) s += Y[i][t] * z[t];
+          c.PL(SI(i, p) + (c.half ? 6 : 0)) -= s;
+        }
+        // rows p + 1 .. p + 6 of the upper lane's column
+        if (c.half) {
+#pragma unroll
+          for (int i = p + 1; i <= p + 6; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) s += Y[i][t] * z[t];
+            c.PL(SI(i, p + 6)) -= s;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = kColSplit ? 12 : 0; j < 13; ++j) {
 #if defined(QL_COL_FENCE)
       QL_FENCE();
 #endif
