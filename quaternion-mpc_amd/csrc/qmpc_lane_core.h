@@ -192,6 +192,7 @@ struct Ctx {
   // the second).  A wave64 FP64 instruction issues its four 16-lane passes whatever the mask, so the partner lanes are free.
   unsigned half = 0;         // 1 on the upper partner lane of a pair
   unsigned lmask = 0x1F8;    // relane(): 8 (lane & 63), or 8 (lane & 31) in pair mode (0xF8)
+  int foot_row = -1;         // pair forms: first of the LDS staging rows that hold the contact points' body-frame positions (-1: private memory)
   QL_FN QL_GLOBAL_AS double& W(int e) const {
     return *reinterpret_cast<QL_GLOBAL_AS double*>(reinterpret_cast<QL_GLOBAL_AS char*>(ws) + ((unsigned)e * wrow + woff));
   }
@@ -229,6 +230,58 @@ struct Ctx {
   }
   QL_FN QL_LDS_AS double& PL(int i) const {
     return *reinterpret_cast<QL_LDS_AS double*>(reinterpret_cast<QL_LDS_AS char*>(pl) + ((unsigned)i * prow + poff));
+  }
+  // Pair mode: the partner lanes share the lower 256 B of every 512-B row of the LDS block, the upper halves are unused -- 78
+  // staging rows that `global_load_lds_dwordx4` fills WITHOUT passing through registers (the pair forms have none to spare for
+  // prefetches: every register prefetch they were given came back as scratch traffic).  stage<n>(e0, h0): rows e0 .. e0 + n - 1
+  // of the workspace (256 B each in pair mode) into the staging rows h0 .. h0 + n - 1, n <= 8: sixteen lanes carry 16 B each
+  // (LDS address = M0 + instruction offset + 16 x lane id; the instruction offset also advances the global address, and
+  // both kinds of rows are 512 B apart).  The transfers count in vmcnt like loads: staged() waits for everything in flight.
+  template <int n>
+  QL_FN void stage(int e0, int h0) const {
+#if QL_DEVICE
+    static_assert(n >= 1 && n <= 8, "instruction offsets reach 4095");
+    // (the lanes 0..15 are forced on for the transfers whatever the exec mask is -- a lane carries 16 B = the values of TWO
+    // instances, neither of which need be its own -- so their addresses are formed inside, under the forced mask)
+    const unsigned long long sa = (unsigned long long)ws + (unsigned long long)(unsigned)e0 * wrow;
+    const unsigned sa_lo = __builtin_amdgcn_readfirstlane((unsigned)sa), sa_hi = __builtin_amdgcn_readfirstlane((unsigned)(sa >> 32));
+    const unsigned long long sbase = ((unsigned long long)sa_hi << 32) | sa_lo;
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)pl + (unsigned)h0 * prow + 256u);
+    unsigned long long sv;
+    unsigned vo;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, 0xffff\n\t"
+        "v_mbcnt_lo_u32_b32 %[vo], -1, 0\n\t"
+        "v_lshlrev_b32 %[vo], 4, %[vo]\n\t"
+        "s_mov_b32 m0, %[m0v]\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[vo], %[sb]\n\t"
+        ".if %[n] > 1\n\tglobal_load_lds_dwordx4 %[vo], %[sb] offset:512\n\t.endif\n\t"
+        ".if %[n] > 2\n\tglobal_load_lds_dwordx4 %[vo], %[sb] offset:1024\n\t.endif\n\t"
+        ".if %[n] > 3\n\tglobal_load_lds_dwordx4 %[vo], %[sb] offset:1536\n\t.endif\n\t"
+        ".if %[n] > 4\n\tglobal_load_lds_dwordx4 %[vo], %[sb] offset:2048\n\t.endif\n\t"
+        ".if %[n] > 5\n\tglobal_load_lds_dwordx4 %[vo], %[sb] offset:2560\n\t.endif\n\t"
+        ".if %[n] > 6\n\tglobal_load_lds_dwordx4 %[vo], %[sb] offset:3072\n\t.endif\n\t"
+        ".if %[n] > 7\n\tglobal_load_lds_dwordx4 %[vo], %[sb] offset:3584\n\t.endif\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [sv] "=&s"(sv), [vo] "=&v"(vo)
+        : [sb] "s"(sbase), [m0v] "s"(m0v), [n] "n"(n)
+        : "memory", "m0");
+#else
+    (void)e0; (void)h0;
+#endif
+  }
+  QL_FN void staged() const {
+#if QL_DEVICE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  }
+  QL_FN double SR(int h) const {      // this instance's value of staging row h
+    return *reinterpret_cast<QL_LDS_AS const double*>(reinterpret_cast<QL_LDS_AS const char*>(pl) + ((unsigned)h * prow + 256u + poff));
+  }
+  QL_FN void SRst(int h, double v) const {      // ... and a value parked there (both partner lanes write the same value)
+    *reinterpret_cast<QL_LDS_AS double*>(reinterpret_cast<QL_LDS_AS char*>(pl) + ((unsigned)h * prow + 256u + poff)) = v;
   }
   // Recompute the lane's row offset (three VALU instructions) instead of keeping it live: where the register file is full
   // the compiler parks this value in scratch and re-loads it before every group of workspace accesses -- a round trip to
@@ -315,6 +368,11 @@ struct LaneState {
 // symmetric 12 x 12 in 78 entries, upper triangle row-major
 constexpr int SI_(int i, int j) { return i * 12 - i * (i - 1) / 2 + (j - i); }
 constexpr int SI(int i, int j) { return i <= j ? SI_(i, j) : SI_(j, i); }
+// pass B, step 5: which lane of a pair / which column of the plain form computes the entry (i, 6 + j) of the cost-to-go's
+// off-diagonal block: kCross(i, j) -> as Y_i . z_(6+j) (column 6 + j), otherwise as z_i . Y_(6+j) (column i).  A tournament on
+// 0..5 plus the diagonal: for i != j exactly one of kCross(i, j), kCross(j, i) holds.
+constexpr bool kCross(int i, int j) { return i == j || (i - j + 6) % 6 == 1 || (i - j + 6) % 6 == 2 || ((i - j + 6) % 6 == 3 && i < j); }
+static_assert(kCross(1, 0) && !kCross(0, 1) && kCross(0, 3) && !kCross(3, 0) && kCross(5, 5), "tournament");
 // symmetric 6 x 6 in 21 entries
 constexpr int S6_(int i, int j) { return i * 6 - i * (i - 1) / 2 + (j - i); }
 constexpr int S6I(int i, int j) { return i <= j ? S6_(i, j) : S6_(j, i); }
@@ -696,14 +754,14 @@ struct LegAheadT<false> {
   static constexpr double rc[6] = {0, 0, 0, 0, 0, 0};
 };
 template <class RT>
-QL_FN void fetch_foot(FootPtr fp, int l, RT& R) {
+QL_FN void fetch_foot(const Ctx& c, FootPtr fp, int l, RT& R) {
   if (kFootAhead)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) R.foot[a] = fp[3 * l + a];
+    for (int a = 0; a < 3; ++a) R.foot[a] = (c.foot_row >= 0) ? c.SR(c.foot_row + 3 * l + a) : fp[3 * l + a];
 }
 template <int NL, bool WITH_DU = false, class RT>
 QL_FN void fetch_ahead(const Ctx& c, const WsOff& O, int k, int l, RT& R, FootPtr fp, bool rcrows = false) {     // k, l wave-uniform run-time values
-  fetch_foot(fp, l, R);
+  fetch_foot(c, fp, l, R);
   if constexpr (RT::kHasRc) {
     if (rcrows)
 #pragma unroll
@@ -756,6 +814,18 @@ QL_FN int next_bit(unsigned m, int l) {
 #endif
 #ifndef QL_A_KNOT_AHEAD  // pass A, plain form, four points: a buffer per point, fetched a knot ahead
 #define QL_A_KNOT_AHEAD 1
+#endif
+#ifndef QL_A_PAIR_AHEAD  // pass A, pair form: per-round row buffers fetched a knot ahead
+#define QL_A_PAIR_AHEAD 0
+#endif
+#ifndef QL_B_KLDS        // pass B, pair forms: the per-instance constants in LDS staging rows instead of private memory
+#define QL_B_KLDS 1
+#endif
+#ifndef QL_B_PARK        // pass B, pair forms: p waits in LDS staging rows across the contact points
+#define QL_B_PARK 0
+#endif
+#ifndef QL_B_XSTAGE      // pass B, pair forms: the knot's state through the LDS staging rows (global_load_lds)
+#define QL_B_XSTAGE 1
 #endif
 #ifndef QL_B_COLSPLIT    // pass B, pair form: the twelve gain columns split between the partner lanes
 #define QL_B_COLSPLIT 1
@@ -967,6 +1037,10 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
   // = 10 TB/s asked for), not on a latency (profiles/HISTORY_r06.md).
   constexpr bool kKnotAhead = QL_A_KNOT_AHEAD && NL == 4 && !PAIR;
   LegAheadT<WARM> Rk[kKnotAhead ? NL : 1];
+  // Pair form: one buffer per ROUND (this lane's point of the round), fetched a whole knot ahead as well -- the pair form of this
+  // sweep uses a fifth of the accumulation registers, and one round of it is shorter than a trip to HBM
+  constexpr bool kPairAhead = QL_A_PAIR_AHEAD && NL == 4 && PAIR;
+  LegAheadT<WARM> Rp[kPairAhead ? NL / 2 : 1];
   // pair form: the stance points of the wavefront in ascending order, four bits each (0xF: none)
   unsigned plist = 0xFFFFu;
   int pcount = 0;
@@ -987,13 +1061,21 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
     for (int l = 0; l < NL; ++l) {
       if (!((order >> l) & 1u)) continue;       // wave-uniform
       if (!first) fetch_ahead<NL, true>(c, O, 0, l, Rk[l], fp, rcrows);
-      else fetch_foot(fp, l, Rk[l]);
+      else fetch_foot(c, fp, l, Rk[l]);
+    }
+  } else if constexpr (kPairAhead) {
+#pragma unroll
+    for (int rd = 0; rd < NL / 2; ++rd) {
+      if (2 * rd >= pcount) continue;       // wave-uniform
+      bool ex;
+      if (!first) fetch_ahead<NL, true>(c, O, 0, pair_point(rd, ex), Rp[rd], fp, rcrows);
+      else fetch_foot(c, fp, pair_point(rd, ex), Rp[rd]);
     }
   } else {
     bool ex;
     const int l0 = PAIR ? pair_point(0, ex) : first_bit(order);
     if (!first) fetch_ahead<NL, true>(c, O, 0, l0, R, fp, rcrows);
-    else fetch_foot(fp, l0, R);
+    else fetch_foot(c, fp, l0, R);
   }
   for (int k = 0; k < N; ++k) {
     const int kn = (k + 1 < N) ? k + 1 : k;
@@ -1008,15 +1090,16 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
         const unsigned pa_ = (plist >> (8 * rd)) & 0xFu, pb_ = (plist >> (8 * rd + 4)) & 0xFu;
         const bool on_lo = (st.con >> pa_) & 1u, on_hi = pb_ != 0xFu && ((st.con >> (pb_ & 3u)) & 1u);
         const bool more = 2 * (rd + 1) < pcount;      // another round of this knot follows
+        LegAheadT<WARM>& Rr = kPairAhead ? Rp[kPairAhead ? rd : 0] : R;      // this lane's rows of the round
         double u[3] = {0.0, 0.0, st.uz}, r[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) r[a] = R.foot[a];
+        for (int a = 0; a < 3; ++a) r[a] = Rr.foot[a];
         double rcl[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) rcl[i] = rcrows ? R.rc[i] : rc0[i];
+        for (int i = 0; i < 6; ++i) rcl[i] = rcrows ? Rr.rc[i] : rc0[i];
         if (first) {
           bool ex;
-          fetch_foot(fp, pair_point(more ? rd + 1 : 0, ex), R);
+          if (!kPairAhead) fetch_foot(c, fp, pair_point(more ? rd + 1 : 0, ex), Rr);      // (a round's own buffer keeps its position)
           if (warm)      // the warm guess (once per solve: read in place)
 #pragma unroll
             for (int a = 0; a < 3; ++a) u[a] = c.W(O.U + 3 * NL * k + 3 * lm + a);
@@ -1024,20 +1107,21 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
           double du[3], sv[6], lv[6], so[6], lo[6], s1v[6], l1v[6];
           unsigned kap = 0;
 #pragma unroll
-          for (int a = 0; a < 3; ++a) { u[a] = R.u[a]; du[a] = R.du[a]; }
+          for (int a = 0; a < 3; ++a) { u[a] = Rr.u[a]; du[a] = Rr.du[a]; }
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
-            lv[i] = R.lam[i];
-            kap |= (R.s[i] < 0.0) ? (1u << i) : 0u;
-            sv[i] = fabs(R.s[i]);
-            so[i] = R.s[i];
-            lo[i] = R.lam[i];
+            lv[i] = Rr.lam[i];
+            kap |= (Rr.s[i] < 0.0) ? (1u << i) : 0u;
+            sv[i] = fabs(Rr.s[i]);
+            so[i] = Rr.s[i];
+            lo[i] = Rr.lam[i];
             s1v[i] = 0.0;
             l1v[i] = 0.0;
           }
           {     // this lane's next rows: its point of the next round of this knot, or of the first round of the next knot
             bool ex;
-            fetch_ahead<NL, true>(c, O, more ? k : kn, pair_point(more ? rd + 1 : 0, ex), R, fp, rcrows);
+            if (kPairAhead) fetch_ahead<NL, true>(c, O, kn, lm, Rr, fp, rcrows);      // the same round, one knot on (the last knot re-reads itself)
+            else fetch_ahead<NL, true>(c, O, more ? k : kn, pair_point(more ? rd + 1 : 0, ex), Rr, fp, rcrows);
           }
           if (on_m) {
 #pragma unroll
@@ -1114,7 +1198,7 @@ QL_FN void pass_A(const DevParams& P, const Ctx& c, const WsOff& O, const LaneK<
       for (int i = 0; i < 6; ++i) rcl[i] = rcrows ? Rc.rc[i] : rc0[i];
       if (first) {
         const int ln = next_bit(order, l);
-        if (!kKnotAhead) fetch_foot(fp, ln >= 0 ? ln : first_bit(order), R);      // (a point's own buffer keeps its position)
+        if (!kKnotAhead) fetch_foot(c, fp, ln >= 0 ? ln : first_bit(order), R);      // (a point's own buffer keeps its position)
         if (warm)      // the warm guess (once per solve: read in place)
 #pragma unroll
           for (int a = 0; a < 3; ++a) u[a] = c.W(O.U + 3 * NL * k + 3 * l + a);
@@ -1282,6 +1366,20 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
   constexpr int QPo = (MD == MD_CONVEX) ? 3 : 0, QVo = (MD == MD_CONVEX) ? 9 : 7, QWo = (MD == MD_CONVEX) ? 6 : 10;
   double pv[12];      // cost-to-go  1/2 dx'P dx + p'dx: P in the lane-private rows c.PL(), p in registers
   double cr[18], rc0[6];
+  // Pair forms: the per-instance constants of the pass (rotation, wd0, contact points: 24 values) wait in LDS staging rows
+  // 25.. instead of private memory -- the register allocator keeps none of them across a knot, and what it re-reads from
+  // scratch at the top of every knot comes back through the vector-memory counter, behind the sweep's stores and the prefetches
+  constexpr bool kKLds = PAIR && QL_B_KLDS && QL_DEVICE;
+  constexpr int kRotRow = 25, kWdRow = 34, kFootRow = 37;
+  if constexpr (kKLds) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.SRst(kRotRow + i, K.rot[i]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c.SRst(kWdRow + a, K.wd0[a]);
+#pragma unroll
+    for (int i = 0; i < 3 * NL; ++i) c.SRst(kFootRow + i, K.foot[i]);
+    c.foot_row = kFootRow;
+  }
   if (!QL_CR_PER_KNOT) {
     double s0[6];
     cone_rows(P, K.rot, cr);
@@ -1327,10 +1425,24 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
 #pragma unroll
     for (int i = 0; i < 12; ++i) pv[i] = lx[i];
   }
+  // Pair forms: the knot's state for the stage cost (step 6) goes through the LDS staging rows 0..12, requested a whole knot
+  // before its use (the plain cold form requests it into registers before the column sweep, kXAhead below)
+  constexpr bool kXStage = PAIR && QL_B_XSTAGE && QL_DEVICE;
+  // Pair forms: the gradient p of the cost-to-go (24 registers, idle from the end of a knot to step 4 of the next -- across the
+  // contact points, where the pressure peaks) waits in the staging rows 13..24: what the register allocator would otherwise
+  // park in scratch comes back through the vector-memory counter, i.e. behind every store and prefetch in flight
+  constexpr bool kPark = PAIR && QL_B_PARK && QL_DEVICE;
+  if constexpr (kPark)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) c.SRst(13 + i, pv[i]);
   for (int k = N - 1; k >= 0; --k) {
     QL_FENCE();
     c.relane();
     QL_TICK(st, LP_B_HEAD);
+    if constexpr (kXStage) {
+      c.template stage<8>(O.X + 13 * k, 0);
+      c.template stage<5>(O.X + 13 * k + 8, 8);
+    }
     // ---- 1. contact points; wd for the expansion ----
     double G6[21], r6[6];
 #pragma unroll
@@ -1339,14 +1451,21 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     for (int i = 0; i < 6; ++i) r6[i] = 0.0;
     double wd[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) wd[a] = K.wd0[a];
+    for (int a = 0; a < 3; ++a) wd[a] = kKLds ? c.SR(kWdRow + a) : K.wd0[a];
     double gam = 0.0;         // AL only: sum_l g_l' D_l^-1 g_l
     const int kn = (k > 0) ? k - 1 : 0;
     double Wk[4] = {0, 0, 0, 0};       // ConvexMpc's model: Iw^-1 at this knot's midpoint yaw
     if constexpr (MD == MD_CONVEX) cv_winv_mid(P, c.W(O.X + 13 * k + 2), c.W(O.X + 13 * k + 8), Wk);
     if (QL_CR_PER_KNOT) {      // rebuilt per knot: 24 registers that need not live through the factorisations
       double s0[6];
-      cone_rows(P, K.rot, cr);
+      if constexpr (kKLds) {
+        double rotk[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) rotk[i] = c.SR(kRotRow + i);
+        cone_rows(P, rotk, cr);
+      } else {
+        cone_rows(P, K.rot, cr);
+      }
       initial_rows(P, cr, st.uz, s0, rc0);
     }
     if (PAIR) {
@@ -1585,6 +1704,9 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     c.relane();
     QL_TICK(st, LP_B_EXPAND);
     double q6[6] = {0, 0, 0, 0, 0, 0}, ak = 0.0;      // AL only: q6 = G y0 + r6,  ak = y0'G y0 + 2 y0'r6 + gam
+    if constexpr (kPark && AL)
+#pragma unroll
+      for (int i = 0; i < 12; ++i) pv[i] = c.SR(13 + i);
     if constexpr (AL) {
       double y0v[6];
 #pragma unroll
@@ -1740,6 +1862,9 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     c.relane();
     QL_TICK(st, LP_B_FACT);
     // ---- 4. P <- Abar' P Abar, p <- Abar' p  in place on the symmetric storage; What = A1^-1 (Wt - h A3) ----
+    if constexpr (kPark && !AL)
+#pragma unroll
+      for (int i = 0; i < 12; ++i) pv[i] = c.SR(13 + i);
     {
       double F[9], W[9], t1[9], t2[9], t3[9], Rb[9];
       rdblk(c, 1, 1, F);
@@ -1824,17 +1949,34 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     c.relane();
     QL_TICK(st, LP_B_CONGR);
     // ---- 5. Y = Mt' P (rows f: mf P_p. + m2 P_v. ; rows t: What' P_f. + h P_w.), column by column ----
+    // Every sum of products of this step is written as an explicit chain: which product of `a b + c d` the compiler contracts
+    // depends on the instantiation, and the forms of this pass have to return each other's bits.
+    //
+    // Pair form (QL_B_COLSPLIT): the step is SPLIT between the partner lanes.  The lower lane owns the columns 0..5 of Y / of the
+    // gains / of the cost-to-go's upper-left block, the upper lane the columns 6..11 and the lower-right block: each forms only
+    // ITS six columns Y_h (36 registers instead of 72), solves them, stores their gains and updates its diagonal block.  The
+    // off-diagonal block P(i, 6 + j) -= Y_i' Z Y_(6+j) needs one column of each lane: after every round the lanes swap the z
+    // they just formed (v_permlane32_swap), and the entry is computed where the swap brought its operands together -- by the lower
+    // lane as Y_i . z_(6+j) when i is in S(j), by the upper lane as z_i . Y_(6+j) otherwise (S: a tournament on 0..5, kCross
+    // below, so that both lanes run the same row indices in the same instruction).  The plain form computes every entry by the
+    // same expression -- the (i, 6 + j) with i outside S(j) while it holds z_i, i.e. in column i.
     const double mf = m1 - P.h * m2;
-    double Y[12][6];
-#pragma unroll
-    for (int j = 0; j < 12; ++j) {
+    constexpr bool kColSplit = PAIR && QL_B_COLSPLIT;
+    constexpr int NY = kColSplit ? 6 : 12;
+    double Y[NY][6];
+    auto y_col = [&](const double (&pc)[12], double (&y)[6]) {      // column of Y from a column of P
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        // explicit chains: which product of such a sum is contracted depends on the instantiation (the uses of Y differ between
-        // the forms of this pass), and the forms have to return each other's bits
-        Y[j][a] = fma(m2, c.PL(SI(6 + a, j)), mf * c.PL(SI(a, j)));
-        Y[j][3 + a] = fma(P.h, c.PL(SI(9 + a, j)), fma(Wh[6 + a], c.PL(SI(5, j)), fma(Wh[3 + a], c.PL(SI(4, j)), Wh[a] * c.PL(SI(3, j)))));
+        y[a] = fma(m2, pc[6 + a], mf * pc[a]);
+        y[3 + a] = fma(P.h, pc[9 + a], fma(Wh[6 + a], pc[5], fma(Wh[3 + a], pc[4], Wh[a] * pc[3])));
       }
+    };
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {
+      double pc[12];
+#pragma unroll
+      for (int r = 0; r < 12; ++r) pc[r] = kColSplit ? c.PL(c.half ? SI(r, (j + 6) % 12) : SI(r, j)) : c.PL(SI(r, j));
+      y_col(pc, Y[j]);
     }
     double yg[6];     // y' = Mt'p - S6 r6
 #pragma unroll
@@ -1846,7 +1988,7 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     for (int i = 0; i < 6; ++i) {
       double s = yg[i];
 #pragma unroll
-      for (int t = 0; t < 6; ++t) s -= S6[S6I(i, t)] * r6[t];
+      for (int t = 0; t < 6; ++t) s = fma(-S6[S6I(i, t)], r6[t], s);
       yg[i] = s;
     }
     QL_FENCE();
@@ -1861,87 +2003,81 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     if (kXAhead)
 #pragma unroll
       for (int i = 0; i < 13; ++i) xk[i] = c.W(O.X + 13 * k + i);
-    // Pair form: the twelve gain / cost-to-go columns are split between the partner lanes -- column p on the lower lane, column
-    // p + 6 on the upper, the same instruction stream with per-lane operands (a register select for the column of Y, per-lane
-    // workspace / LDS addresses); the rows p + 1 .. p + 6 of the upper lane's longer column run with the lower lanes masked.  Each
-    // column is computed by exactly the arithmetic of the plain form, so the cost-to-go entries and the gains are its bits; the
-    // gradient column (which updates p, a register of both lanes) stays on both.
-    constexpr bool kColSplit = PAIR && QL_B_COLSPLIT;
+    if constexpr (kXStage) c.staged();      // (issued a knot's work ago: nothing to wait for; before the sweep's stores, which would be)
+    auto dot6 = [](const double (&u)[6], const double (&v)[6]) {
+      double s = u[0] * v[0];
+#pragma unroll
+      for (int t = 1; t < 6; ++t) s = fma(u[t], v[t], s);
+      return s;
+    };
+    auto col_solve = [&](const double (&yj)[6], double (&z)[6], double (&xg)[6]) {      // z = Z y, xg = y - S6 z
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        double s = Z[S6I(i, 0)] * yj[0];
+#pragma unroll
+        for (int t = 1; t < 6; ++t) s = fma(Z[S6I(i, t)], yj[t], s);
+        z[i] = s;
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        double s = yj[i];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) s = fma(-S6[S6I(i, t)], z[t], s);
+        xg[i] = s;
+      }
+    };
     if constexpr (kColSplit) {
 #pragma unroll
       for (int p = 0; p < 6; ++p) {
-        double yj[6], z[6];
+        double z[6], xg[6];
         c.relane();
-        const int jm = c.half ? p + 6 : p;      // this lane's column
-#pragma unroll
-        for (int i = 0; i < 6; ++i) yj[i] = c.half ? Y[p + 6][i] : Y[p][i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          double s = 0.0;
-#pragma unroll
-          for (int t = 0; t < 6; ++t) s += Z[S6I(i, t)] * yj[t];
-          z[i] = s;
-        }
-        double xg[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          double s = yj[i];
-#pragma unroll
-          for (int t = 0; t < 6; ++t) s -= S6[S6I(i, t)] * z[t];
-          xg[i] = s;
-        }
+        col_solve(Y[p], z, xg);
         if (AL) {      // double precision: columns 0..5 in the slot (lower lane), 6..11 in the second block (upper lane)
           const int base = c.half ? O.G2 + D::GAIN2 * k + 6 * p : O.G + D::GAIN * k + 6 * p;
 #pragma unroll
           for (int i = 0; i < 6; ++i) c.StOwn(base + i, xg[i]);
         } else {
+          const int base = O.G + D::GAIN * k + 3 * (c.half ? p + 6 : p);
 #pragma unroll
-          for (int i = 0; i < 3; ++i) c.StOwn(O.G + D::GAIN * k + 3 * jm + i, pack2f((float)xg[2 * i], (float)xg[2 * i + 1]));
+          for (int i = 0; i < 3; ++i) c.StOwn(base + i, pack2f((float)xg[2 * i], (float)xg[2 * i + 1]));
         }
-        // rows 0 .. p of both lanes' columns: SI(i, p + 6) = SI(i, p) + 6 for i <= p
+        // this lane's diagonal block: P(i, p) on the lower lane, P(6 + i, 6 + p) on the upper
 #pragma unroll
         for (int i = 0; i <= p; ++i) {
-          double s = 0.0;
-#pragma unroll
-          for (int t = 0; t < 6; ++t) s += Y[i][t] * z[t];
-          c.PL(SI(i, p) + (c.half ? 6 : 0)) -= s;
+          const int e = c.half ? SI(6 + i, 6 + p) : SI(i, p);
+          c.PL(e) -= dot6(Y[i], z);
         }
-        // rows p + 1 .. p + 6 of the upper lane's column
-        if (c.half) {
+        // the partner's z: z_(6+p) on the lower lane, z_p on the upper
+        double zp[6];
 #pragma unroll
-          for (int i = p + 1; i <= p + 6; ++i) {
-            double s = 0.0;
+        for (int t = 0; t < 6; ++t) {
+          double lo, hi;
+          ql_pair(z[t], lo, hi);
+          zp[t] = c.half ? lo : hi;
+        }
+        // off-diagonal block: P(q, 6 + p) -= Y_q . z_(6+p) on the lower lane, P(p, 6 + q) -= Y_(6+q) . z_p on the upper, q in S(p);
+        // the entry (p, 6 + p) is the lower lane's
 #pragma unroll
-            for (int t = 0; t < 6; ++t) s += Y[i][t] * z[t];
-            c.PL(SI(i, p + 6)) -= s;
+        for (int q = 0; q < 6; ++q) {
+          if (!kCross(q, p)) continue;
+          const double dq = dot6(Y[q], zp);
+          if (q == p) {
+            if (!c.half) c.PL(SI(p, 6 + p)) -= dq;
+          } else {
+            const int e = c.half ? SI(p, 6 + q) : SI(q, 6 + p);
+            c.PL(e) -= dq;
           }
         }
       }
     }
 #pragma unroll
     for (int j = kColSplit ? 12 : 0; j < 13; ++j) {
-#if defined(QL_COL_FENCE)
-      QL_FENCE();
-#endif
-      double yj[6], z[6];
+      double yj[6], z[6], xg[6];
       c.relane();
+      constexpr int kY0 = kColSplit ? 0 : 1;      // (the plain form's column index, 0 where the split form never reads Y[j])
 #pragma unroll
-      for (int i = 0; i < 6; ++i) yj[i] = (j < 12) ? Y[j < 12 ? j : 0][i] : yg[i];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        double s = 0.0;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) s += Z[S6I(i, t)] * yj[t];
-        z[i] = s;
-      }
-      double xg[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        double s = yj[i];
-#pragma unroll
-        for (int t = 0; t < 6; ++t) s -= S6[S6I(i, t)] * z[t];
-        xg[i] = s;
-      }
+      for (int i = 0; i < 6; ++i) yj[i] = (j < 12) ? Y[j < 12 ? j * kY0 : 0][i] : yg[i];
+      col_solve(yj, z, xg);
       if (AL && j < 12) {      // double precision: columns 0..5 in the slot, 6..11 in the second block
 #pragma unroll
         for (int i = 0; i < 6; ++i) c.W((j < 6 ? O.G + D::GAIN * k + 6 * (j < 6 ? j : 0) : O.G2 + D::GAIN2 * k + 6 * (j >= 6 && j < 12 ? j - 6 : 0)) + i) = xg[i];
@@ -1953,12 +2089,21 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
         for (int i = 0; i < 6; ++i) { if (PAIR) c.StOwn(O.G + D::GAIN * k + 36 + i, xg[i]); else c.St(O.G + D::GAIN * k + 36 + i, xg[i]); }
       }
       if (j < 12) {
+        if constexpr (!kColSplit) {
+          // rows of the column: all of its own block; of the off-diagonal block (j >= 6) those with i in S(j - 6) ...
 #pragma unroll
-        for (int i = 0; i <= j; ++i) {
-          double s = 0.0;
+          for (int i = 0; i <= j; ++i) {
+            if (j >= 6 && i < 6 && !kCross(i, j - 6)) continue;
+            c.PL(SI(i, j < 12 ? j : 0)) -= dot6(Y[i], z);
+          }
+          // ... and, while z_j of a column j < 6 is at hand, the entries (j, 6 + q) of the others: z_j . Y_(6+q), q in S(j), q != j
+          if (j < 6) {
 #pragma unroll
-          for (int t = 0; t < 6; ++t) s += Y[i][t] * z[t];
-          c.PL(SI(i, j < 12 ? j : 0)) -= s;
+            for (int q = 0; q < 6; ++q) {
+              if (!kCross(q, j < 6 ? j : 0) || q == j) continue;
+              c.PL(SI(j < 6 ? j : 0, 6 + q)) -= dot6(Y[(6 + q) * kY0], z);
+            }
+          }
         }
       } else {
 #pragma unroll
@@ -1967,19 +2112,23 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
           double t2 = 0.0;
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
-            double sw = 0.0;
+            double sw = S6[S6I(i, 0)] * z[0];
 #pragma unroll
-            for (int t = 0; t < 6; ++t) sw += S6[S6I(i, t)] * z[t];
-            t2 += q6[i] * sw;
+            for (int t = 1; t < 6; ++t) sw = fma(S6[S6I(i, t)], z[t], sw);
+            t2 = fma(q6[i], sw, t2);
           }
           dV1 -= ak - t2;
         }
+        if constexpr (kColSplit) {      // each lane its six rows of p, then both hold all twelve again
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-          double s = 0.0;
+          for (int i = 0; i < 6; ++i) {
+            double own = c.half ? pv[6 + i] : pv[i];
+            own -= dot6(Y[i], z);
+            ql_pair(own, pv[i], pv[6 + i]);
+          }
+        } else {
 #pragma unroll
-          for (int t = 0; t < 6; ++t) s += Y[i][t] * z[t];
-          pv[i] -= s;
+          for (int i = 0; i < 12; ++i) pv[i] -= dot6(Y[i * kY0], z);
         }
       }
     }
@@ -1991,7 +2140,10 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
     // ---- 6. stage cost of knot k ----
     {
       double lx[12], lxx[6];
-      cost_expansion<NL, MD>(P, c, O, K, k, lx, lxx, kXAhead ? xk : nullptr);
+      if constexpr (kXStage)
+#pragma unroll
+        for (int i = 0; i < 13; ++i) xk[i] = c.SR(i);
+      cost_expansion<NL, MD>(P, c, O, K, k, lx, lxx, (kXAhead || kXStage) ? xk : nullptr);
       int q = 0;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -2004,6 +2156,9 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
 #pragma unroll
       for (int i = 0; i < 12; ++i) pv[i] += lx[i];
     }
+    if constexpr (kPark)
+#pragma unroll
+      for (int i = 0; i < 12; ++i) c.SRst(13 + i, pv[i]);
     QL_FENCE();
     c.relane();
     QL_TICK(st, LP_B_GAIN);
