@@ -526,7 +526,7 @@ def main():
                        "two_in_flight": {"value": Bl * 2 * kl / dt2, "outputs_identical": same2},
                        "roofline": roofline_object(kn_l, ach, tr, tr_src, lg["kernel_ms"], Bl, Bl * (8 * 48 + 8 * 12 + 40))}
                 # the reference's own solver mode on the same batch (AL-iLQR, <= 10 iterations): the lane kernel's AL passes
-                # from 19456 instances on (16384 beyond N=12; lane pairs below 32769), the wave-per-instance reference kernels below -- the library says which
+                # from 19456 instances on (14848 beyond N=12; lane pairs below 32769), the wave-per-instance reference kernels below -- the library says which
                 if not args.no_reference_mode:
                     prl = pkg.default_params(Nl, pkg.MODE_REFERENCE, lib)
                     srl = pkg.Solver(prl, Bl, device=local, lib=lib)

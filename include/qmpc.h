@@ -241,8 +241,8 @@ qmpc_status qmpc_solve_warm_device(qmpc_handle* h, int32_t batch, const qmpc_inp
  * take one handle each (bench.py: two_in_flight).
  *
  * Which kernel runs is chosen from the batch size (converged mode; QuatMpc N <= 12: everything in LDS up to 1024
- * instances, gains in a workspace up to 14847, from 14848 on one LANE per instance -- a lane PAIR while the batch fills only
- * half of every wavefront -- with the stragglers handed back to the wave kernel; N = 13 .. 22: the lane kernel from 15872;
+ * instances, gains in a workspace up to 14335, from 14336 on one LANE per instance -- a lane PAIR while the batch fills only
+ * half of every wavefront -- with the stragglers handed back to the wave kernel; N = 13 .. 22: the lane kernel from 14848;
  * warm-started launches: 18432 / 20480; the thresholds of the other models are in qmpc_hip.hip, and
  * qmpc_query(QMPC_QUERY_KERNEL_FOR_BATCH) answers for a given handle).  The kernel families solve the same
  * problem to the same KKT point but round differently: forces agree to ~1e-10 N across a threshold (tested to 1e-7 N),
@@ -263,7 +263,7 @@ qmpc_status qmpc_solve_async(qmpc_handle* h, int32_t batch, const qmpc_input* in
 
 /* How the host-buffer calls (qmpc_solve, qmpc_solve_traj, qmpc_solve_async, qmpc_convex_solve*, qmpc_solve8*) move their
  * data -- SURVEY.md 8d's metric is exactly this call: records in host memory -> forces in host memory.
- *   - Batches that take a wave-per-instance kernel (every batch below the lane kernel's threshold: 14847 instances for QuatMpc at N <= 12; qmpc_query(QMPC_QUERY_KERNEL_FOR_BATCH) answers for a handle) run ZERO-COPY: every wavefront reads
+ *   - Batches that take a wave-per-instance kernel (every batch below the lane kernel's threshold: 14335 instances for QuatMpc at N <= 12; qmpc_query(QMPC_QUERY_KERNEL_FOR_BATCH) answers for a handle) run ZERO-COPY: every wavefront reads
  *     its 384-byte record from, and writes its forces / status record to, host memory the device can address.  Buffers
  *     from qmpc_host_alloc (or hipHostMalloc / hipHostRegister) are used in place; pageable buffers go through pinned
  *     staging the handle owns (one memcpy in, one out).  One launch, one synchronisation; results are bit-identical to

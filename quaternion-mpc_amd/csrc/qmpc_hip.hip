@@ -150,12 +150,15 @@ constexpr int kLaneMinWarm = 18432, kLaneMinWarmLong = 20480, kLaneMinWarmVeryLo
 // Round 6 (apply pass split across the lane pair, stores outside the per-lane conditions: a round of the lane kernel another
 // 7-10 % cheaper): N=10 13312 instances wave 4.14 vs lane 4.39 ms, 14336: 4.35 vs 4.42, 16384: 4.88 vs 4.45; N=16 14336: 6.93 vs 7.22,
 // 16384: 7.80 vs 7.37; N=20 14336: 9.15 vs 9.65, 16384: 10.16 vs 9.73; N=24 14336: 11.8 vs 12.2 (tools/lane_switch_scan.py)
-constexpr int kLaneMinBatch = 14848;          // QuatMpc, horizons up to 12
+// ... and once more after the backward pass of the pair form was split by blocks and took its constants / the knot's state through LDS
+// (profiles/r06_lane_pair_lds.txt): N=10 13824: 4.18 vs 4.22 ms, 14336: 4.36 vs 4.22; N=16 14848: 6.94 vs 6.93; N=20 14848: 9.31 vs 9.23;
+// N=24 14336: 11.9 vs 11.7
+constexpr int kLaneMinBatch = 14336;          // QuatMpc, horizons up to 12
 // QuatMpc, longer horizons; round 5 (the wave side is the wrench-form kernel with its slack arrays in the workspace, WVAR 6):
 // N=16 20480: wave 2.20 vs lane 2.15 M solves/s, 24576: 2.23 vs 2.52; N=20 20480: 1.64 vs 1.60, 24576: 1.67 vs 1.90;
 // N=24 16384: 1.20 vs 1.03, 20480: 1.20 vs 1.25
-constexpr int kLaneMinBatchLong = 15872;
-constexpr int kLaneMinBatchVeryLong = 15872;  // horizons beyond 22
+constexpr int kLaneMinBatchLong = 14848;
+constexpr int kLaneMinBatchVeryLong = 14848;  // horizons beyond 22
 constexpr int kLaneMinBatchOther = 18432;      // ConvexMpc, short horizons (round-1 wave kernels below it)
 // ConvexMpc at its own horizon (N=20; WVAR 6 below the threshold): 20480 instances wave 1.21 vs lane 1.11 M, 24576: 1.22 vs 1.29
 constexpr int kLaneMinBatchConvexLong = 22528;
@@ -183,7 +186,7 @@ constexpr int kLaneCapWarm = 8;
 // a point of the pair per lane in the per-point blocks): N=10 18432 instances wave 6.42 vs lane 6.65 ms, 20480: 7.12 vs 6.85, 32768: 11.2 vs
 // 8.2 (4.0 M solves/s); N=16 14336: 8.63 vs 9.45, 18432: 10.9 vs 10.2; N=20 14336: 11.4 vs 11.8, 16384: 12.9 vs 12.0, 32768: 25.2 vs 15.1
 constexpr int kLaneRefMinBatch = 19456;       // N <= 12
-constexpr int kLaneRefMinBatchLong = 16384;   // horizons beyond 12
+constexpr int kLaneRefMinBatchLong = 14848;   // horizons beyond 12 (N=20 14336: 11.4 vs 11.4 ms, 16384: 12.9 vs 11.9 after the pair forms' LDS staging)
 // ConvexMpc's own mode (five iterations; tools/refmode_lane_bench.py --model convex): N=20 16384 instances wave 1.70 vs lane 1.68 M solves/s,
 // 24576: 1.72 vs 2.38 M, 65536: 1.74 vs 5.61 M; N=10 16384: 3.85 vs 3.37 M, 32768: 4.00 vs 6.00 M, 65536: 4.05 vs 10.5 M
 // 8-point model (N=16; tools/refmode_lane_bench.py --model biped8), against its wrench-form reference kernels (qmpc_ref8_w_kernel):

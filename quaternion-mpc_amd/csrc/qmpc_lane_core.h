@@ -321,6 +321,23 @@ QL_FN void ql_pair(double x, double& lo, double& hi) {
 #else
 QL_FN void ql_pair(double x, double& lo, double& hi) { lo = x; hi = x; }
 #endif
+// the PARTNER lane's value of x (lane ^ 32), through the LDS crossbar (ds_bpermute_b32: no memory, one instruction per half) --
+// where only the partner's value is wanted this replaces two copies, two swaps and two selects per value
+#if QL_DEVICE
+QL_FN double ql_partner(double x, unsigned addr) {      // addr = 4 (lane ^ 32)
+  const int lo = __builtin_amdgcn_ds_bpermute((int)addr, __double2loint(x));
+  const int hi = __builtin_amdgcn_ds_bpermute((int)addr, __double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+QL_FN unsigned ql_partner_addr() {
+  unsigned l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return (l ^ 32u) << 2;
+}
+#else
+QL_FN double ql_partner(double x, unsigned) { return x; }
+QL_FN unsigned ql_partner_addr() { return 0; }
+#endif
 // scheduling barrier: the instruction scheduler moves nothing across it (two unrolled per-point blocks whose temporaries
 // would otherwise be live together)
 #if QL_DEVICE && !defined(QL_NO_SCHED_BARRIER)
@@ -817,6 +834,9 @@ QL_FN int next_bit(unsigned m, int l) {
 #endif
 #ifndef QL_A_PAIR_AHEAD  // pass A, pair form: per-round row buffers fetched a knot ahead
 #define QL_A_PAIR_AHEAD 0
+#endif
+#ifndef QL_B_BPERM       // pass B, pair forms, step 5: the partner's z through ds_bpermute instead of swap + select
+#define QL_B_BPERM 1
 #endif
 #ifndef QL_B_KLDS        // pass B, pair forms: the per-instance constants in LDS staging rows instead of private memory
 #define QL_B_KLDS 1
@@ -2049,11 +2069,17 @@ QL_FN bool pass_B(const DevParams& P, const Ctx& c_in, const WsOff& O, const Lan
         }
         // the partner's z: z_(6+p) on the lower lane, z_p on the upper
         double zp[6];
+        if (QL_B_BPERM) {
+          const unsigned pa = ql_partner_addr();
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
-          double lo, hi;
-          ql_pair(z[t], lo, hi);
-          zp[t] = c.half ? lo : hi;
+          for (int t = 0; t < 6; ++t) zp[t] = ql_partner(z[t], pa);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 6; ++t) {
+            double lo, hi;
+            ql_pair(z[t], lo, hi);
+            zp[t] = c.half ? lo : hi;
+          }
         }
         // off-diagonal block: P(q, 6 + p) -= Y_q . z_(6+p) on the lower lane, P(p, 6 + q) -= Y_(6+q) . z_p on the upper, q in S(p);
         // the entry (p, 6 + p) is the lower lane's

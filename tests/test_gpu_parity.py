@@ -1958,8 +1958,8 @@ def test_prepare_and_query(pkg, lib):
     import os
     p = pkg.default_params(10, pkg.MODE_CONVERGED, lib)
     s = pkg.Solver(p, 32768, device=0, lib=lib)
-    # (the lane kernel takes over at 14848 instances: lane pairs since the end of round 5, the apply pass split too since round 6)
-    assert [s.kernel_for_batch(b) for b in (1, 1024, 1025, 14847, 14848, 32768)] == \
+    # (the lane kernel takes over at 14336 instances: lane pairs since the end of round 5, apply and backward pass split since round 6)
+    assert [s.kernel_for_batch(b) for b in (1, 1024, 1025, 14335, 14336, 32768)] == \
         ["wform_lds", "wform_lds", "wform_ws", "wform_ws", "lane_handoff", "lane_handoff"]
     assert s.query(pkg.QUERY_HANDOFF_ACTIVE) == 1 and s.query(pkg.QUERY_HANDOFF_ALLOC_FAILED) == 0
     assert s.query(pkg.QUERY_LANE_CAP, 1) == 16 and s.query(pkg.QUERY_LANE_CAP, 2) == 12 and s.query(pkg.QUERY_LANE_CAP, 3) == 8
@@ -1976,11 +1976,11 @@ def test_prepare_and_query(pkg, lib):
     # N=24: the hand-off now exists for every horizon (80 KB gate), and says so
     p20 = pkg.default_params(20, pkg.MODE_CONVERGED, lib)
     s20 = pkg.Solver(p20, 22000, device=0, lib=lib)
-    assert [s20.kernel_for_batch(b) for b in (1, 512, 513, 15871, 15872)] == ["wform_lds", "wform_lds", "wform_ws", "wform_ws", "lane_handoff"]
+    assert [s20.kernel_for_batch(b) for b in (1, 512, 513, 14847, 14848)] == ["wform_lds", "wform_lds", "wform_ws", "wform_ws", "lane_handoff"]
     s20.close()
     p24 = pkg.default_params(24, pkg.MODE_CONVERGED, lib)
     s24 = pkg.Solver(p24, 18432, device=0, lib=lib)
-    assert s24.kernel_for_batch(15871) == "wform_ws" and s24.kernel_for_batch(15872) == "lane_handoff" and s24.query(pkg.QUERY_LANE_CAP, 1) == 17
+    assert s24.kernel_for_batch(14847) == "wform_ws" and s24.kernel_for_batch(14848) == "lane_handoff" and s24.query(pkg.QUERY_LANE_CAP, 1) == 17
     s24.close()
     os.environ["QMPC_LANE_CAP"] = "0"
     try:
