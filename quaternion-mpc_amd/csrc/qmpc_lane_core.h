@@ -838,6 +838,12 @@ QL_FN int next_bit(unsigned m, int l) {
 #ifndef QL_B_BPERM       // pass B, pair forms, step 5: the partner's z through ds_bpermute instead of swap + select
 #define QL_B_BPERM 1
 #endif
+#ifndef QL_CAL_KLDS_PLAIN   // ... in the plain forms as well (the lanes' own slots of the LDS block)
+#define QL_CAL_KLDS_PLAIN 1
+#endif
+#ifndef QL_CAL_KLDS      // reference mode's trial sweep, pair form: per-instance constants in LDS staging rows
+#define QL_CAL_KLDS 30      // bits: 1 cone rows (off: with them read per knot the per-point block contracts its sums differently from the plain form), 2 gravity, 4 wd0, 8 contact points, 16 reference parameters
+#endif
 #ifndef QL_B_KLDS        // pass B, pair forms: the per-instance constants in LDS staging rows instead of private memory
 #define QL_B_KLDS 1
 #endif
@@ -2796,9 +2802,29 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
   static_assert(!PAIR || (NL == 4 && MD == MD_QUAT), "pair split: the four-point quaternion model");
   typedef LDim<NL> D;
   const int N = P.N;
-  const double gb[3] = {K.rot[6] * (-9.81), K.rot[7] * (-9.81), K.rot[8] * (-9.81)};
-  double cr[18];
-  cone_rows(P, K.rot, cr);
+  const double gb_[3] = {K.rot[6] * (-9.81), K.rot[7] * (-9.81), K.rot[8] * (-9.81)};
+  double cr_[18];
+  cone_rows(P, K.rot, cr_);
+  // The sweep's per-instance constants (gravity in the body frame, wd0, contact points, reference parameters: 31 values) wait in
+  // LDS and are read where they are used -- in registers across the knots they end up in scratch, and a scratch re-load comes
+  // back through the vector-memory counter, behind the rows in flight.  The LDS block is free in this pass (the cost-to-go matrix
+  // of the backward pass lives there, and that pass rebuilds it from the terminal cost at every call): the pair form uses the
+  // staging rows (upper halves), the plain form the lanes' own slots of the same rows.
+  constexpr bool kKLds = QL_CAL_KLDS && QL_DEVICE && (PAIR || QL_CAL_KLDS_PLAIN);
+  auto kld = [&](int h) -> double { return PAIR ? c.SR(h) : (double)c.PL(h); };
+  auto kst = [&](int h, double v) { if (PAIR) c.SRst(h, v); else c.PL(h) = v; };
+  constexpr bool kLCr = kKLds && (QL_CAL_KLDS & 1), kLGb = kKLds && (QL_CAL_KLDS & 2), kLWd = kKLds && (QL_CAL_KLDS & 4), kLFoot = kKLds && (QL_CAL_KLDS & 8), kLRef = kKLds && (QL_CAL_KLDS & 16);
+  constexpr int kCrRow = 0, kGbRow = 18, kWdRow = 21, kFootRow = 24, kRefRow = 24 + 3 * NL;
+  if constexpr (kKLds) {
+#pragma unroll
+    for (int i = 0; i < 18; ++i) kst(kCrRow + i, cr_[i]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { kst(kGbRow + a, gb_[a]); kst(kWdRow + a, K.wd0[a]); }
+#pragma unroll
+    for (int i = 0; i < 3 * NL; ++i) kst(kFootRow + i, K.foot[i]);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) kst(kRefRow + i, K.refp[i]);
+  }
   static_assert(!PAIR || NA == 2, "pair form: the two trials of a sweep go to the two partner lanes");
   double alpha[NA];
   alpha[0] = al.alpha;
@@ -2870,6 +2896,15 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
   for (int k = 0; k < N; ++k) {
     const int kn = (k + 1 < N) ? k + 1 : k;
     double zeta[NA][6], zh[NH][6];
+    double cr[18], gb[3], refk[13];
+    if constexpr (kKLds) QL_FENCE();      // (the reads below stay inside their knot)
+#pragma unroll
+    for (int i = 0; i < 13; ++i) refk[i] = kLRef ? kld(kRefRow + i) : K.refp[i];
+    if constexpr (!kLCr)
+#pragma unroll
+      for (int i = 0; i < 18; ++i) cr[i] = cr_[i];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) gb[a] = gb_[a];
 #if QL_AL_G2_AHEAD == 0
 #pragma unroll
     for (int i = 0; i < D::GAIN2; ++i) g2[i] = c.W(O.G2 + D::GAIN2 * k + i);
@@ -2881,7 +2916,7 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
       if constexpr (MD != MD_CONVEX) quatG(&xo[3], G);
 #pragma unroll
       for (int q = 0; q < NH; ++q) {
-        Jp[q] += al_state_cost<MD>(P, K.refp, k, xc[q]);
+        Jp[q] += al_state_cost<MD>(P, refk, k, xc[q]);
         double dx[12];
         if constexpr (MD == MD_CONVEX) {      // blocks in the recursion's order [p, phi, v, w]
 #pragma unroll
@@ -2929,7 +2964,11 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
 #pragma unroll
     for (int q = 0; q < NH; ++q)
 #pragma unroll
-      for (int a = 0; a < 3; ++a) { F[q][a] = 0.0; wd[q][a] = K.wd0[a]; }
+      for (int a = 0; a < 3; ++a) { F[q][a] = 0.0; wd[q][a] = kLWd ? kld(kWdRow + a) : K.wd0[a]; }
+    if constexpr (kLCr) {
+#pragma unroll
+      for (int i = 0; i < 18; ++i) cr[i] = kld(kCrRow + i);
+    }
     // one contact point: AL weights, factorised block, the trials' increments, new inputs, torque shares and merit terms
     auto point = [&](const double u[3], const double lam[6], const double r[3], const double Rw[3], int l, double dq[NA][3],
                      double fun[NA][3], double ftq[NA][3], double ju[NA], double at[NA][6]) {
@@ -3005,7 +3044,7 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           u[a] = uk[3 * pr + a];
-          r[a] = c.half ? K.foot[3 * lb_ + a] : K.foot[3 * la + a];
+          r[a] = kLFoot ? kld(kFootRow + 3 * lm + a) : (c.half ? K.foot[3 * lb_ + a] : K.foot[3 * la + a]);
           Rw[a] = c.half ? ql_uniform(P.R[3 * (lb_ & 3) + a]) : ql_uniform(P.R[3 * (la & 3) + a]);
         }
 #pragma unroll
@@ -3076,7 +3115,10 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
         for (int a = 0; a < 3; ++a) dq[q][a] = 0.0;
       if ((st.con >> l) & 1u) {
         const double Rw[3] = {P.R[(3 * l) % 12], P.R[(3 * l + 1) % 12], P.R[(3 * l + 2) % 12]};
-        point(u, lam, &K.foot[3 * l], Rw, l, dq, fun, ftq, ju, at);
+        double rl[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) rl[a] = kLFoot ? kld(kFootRow + 3 * l + a) : K.foot[3 * l + a];
+        point(u, lam, rl, Rw, l, dq, fun, ftq, ju, at);
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
           Jp[q] += ju[q];
@@ -3085,7 +3127,7 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
           if constexpr (MD == MD_CONVEX) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) F[q][a] += fun[q][a];
-            cv_cross_acc(&K.foot[3 * l], fun[q], wd[q]);
+            cv_cross_acc(rl, fun[q], wd[q]);
           } else {
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
@@ -3112,13 +3154,23 @@ QL_FN void pass_C_AL(const DevParams& P, const Ctx& c, const WsOff& O, const Lan
 #pragma unroll
     for (int q = 0; q < NH; ++q) {
       if constexpr (MD == MD_CONVEX) cv_step_fw(P, xc[q], F[q], wd[q], xn);
-      else srbd_step_fw(P, gb, xc[q], F[q], wd[q], xn);
+      else {
+        if constexpr (kLGb)
+#pragma unroll
+          for (int a = 0; a < 3; ++a) gb[a] = kld(kGbRow + a);
+        srbd_step_fw(P, gb, xc[q], F[q], wd[q], xn);
+      }
 #pragma unroll
       for (int i = 0; i < 13; ++i) xc[q][i] = xn[i];
     }
   }
 #pragma unroll
-  for (int q = 0; q < NH; ++q) Jp[q] += al_state_cost<MD>(P, K.refp, N, xc[q]);
+  for (int q = 0; q < NH; ++q) {
+    double refN[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) refN[i] = kLRef ? kld(kRefRow + i) : K.refp[i];
+    Jp[q] += al_state_cost<MD>(P, refN, N, xc[q]);
+  }
   double JpF[NA], alF[NA];
   if constexpr (PAIR) {
     // the trial of a lane: largest increment / violation over BOTH points (the partner sends its point's figure of that trial), then
