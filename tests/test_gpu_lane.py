@@ -848,3 +848,25 @@ def test_reference_mode_lane_pairs_return_the_plain_forms_bits(pkg, lib, oracle,
     fo, io = oracle.solve(p, rec[idx], threads=8)
     assert np.array_equal(io["status"], info["status"][idx]) and np.array_equal(io["iterations"], info["iterations"][idx])
     assert np.abs(fo - f[idx]).max() < 1e-6
+
+
+@pytest.mark.parametrize("N,B", [(10, 17001), (20, 15003)])
+def test_lane_pairs_return_the_plain_forms_bits(pkg, lib, oracle, monkeypatch, N, B):
+    """Round 6: in pair mode the apply pass, the per-point blocks and step 5 of the backward pass are split between the partner
+    lanes (the last by blocks of the cost-to-go matrix, with the partner's z swapped in), the per-instance constants and the knot's
+    state travel through the LDS halves the pair mode leaves unused (global_load_lds).  A shard solved that way -- its last
+    wavefront partly filled -- returns the bits of its block of a full-wavefront launch, iteration words included; the forces are
+    the oracle's."""
+    _forced(monkeypatch, 4)      # the pure lane kernel: no hand-off between the two forms
+    p = pkg.default_params(N, 0, lib)
+    rec = pkg.random_go1_trot_states(70000, config_id=3 if N == 20 else 4)
+    s = pkg.Solver(p, 70000, device=0, lib=lib)
+    f, info = s.solve(rec[:B])                     # 32 instances per wavefront: pairs
+    ff, fi = s.solve(rec)                          # full wavefronts: the plain form
+    s.close()
+    assert (info["status"] == 0).all()
+    assert np.array_equal(f, ff[:B]) and np.array_equal(info["iterations"], fi["iterations"][:B])
+    idx = np.arange(0, B, B // 64)
+    fo, io = oracle.solve(p, rec[idx], threads=8)
+    assert np.abs(fo - f[idx]).max() < 1e-8
+    assert (io["iterations"] == info["iterations"][idx]).mean() >= 0.98
