@@ -26,6 +26,13 @@
 
 #include "qmpc_lane_core.h"
 
+// The file is compiled as TWO units of the library (__graft_entry__.py): QL_UNIT 1 -- the converged mode's kernel, the sort
+// kernels and the launcher (qmpc_lane.hip itself, scheduling strategy max-ilp: +3 % for the pair forms, nothing for the plain
+// ones) -- and QL_UNIT 2 -- the reference mode's kernel with its own launcher (qmpc_lane_ref.hip includes this file; the default
+// strategy: max-ilp costs that kernel 5-8 %).  QL_UNIT 0 (tools/lane_variants.py): everything in one unit.
+#ifndef QL_UNIT
+#define QL_UNIT 0
+#endif
 namespace qmpc {
 namespace lane {
 
@@ -33,8 +40,8 @@ constexpr int kLaneWave = 64;
 constexpr int kParamSlots = 64;
 
 // Parameter blocks live in constant memory, one slot per handle: every pass reads what it needs with scalar loads and
-// nothing of it occupies registers across the passes.
-__constant__ DevParams ql_params[kParamSlots];
+// nothing of it occupies registers across the passes.  (static: the file is compiled as two units, each with its own table)
+static __constant__ DevParams ql_params[kParamSlots];
 
 
 // The three passes (and set-up / outputs) are compiled as SEPARATE functions: each gets the register file to itself --
@@ -540,6 +547,7 @@ __global__ __launch_bounds__(256) void qmpc_lane_sort_count(const double* __rest
   __syncthreads();
   if (hist[threadIdx.x]) atomicAdd(&scratch[threadIdx.x], hist[threadIdx.x]);
 }
+#if QL_UNIT != 2      // (not a template: defined once)
 __global__ __launch_bounds__(64) void qmpc_lane_sort_scan(int* __restrict__ scratch) {
   if (threadIdx.x != 0) return;
   int run = 0;
@@ -549,6 +557,7 @@ __global__ __launch_bounds__(64) void qmpc_lane_sort_scan(int* __restrict__ scra
     run += n;
   }
 }
+#endif
 template <int NL>
 __global__ __launch_bounds__(256) void qmpc_lane_sort_scatter(const double* __restrict__ in, int batch, int* __restrict__ scratch, int con_off,
                                                                   const qmpc_info* __restrict__ prev) {
@@ -574,6 +583,70 @@ __global__ __launch_bounds__(256) void qmpc_lane_sort_scatter(const double* __re
 using namespace qmpc;
 using namespace qmpc::lane;
 
+// the reference mode's launch (its own unit of the library when QL_UNIT is 1 / 2: the kernel is scheduled differently, see the top
+// of the file); dev_params: the block to upload into THIS unit's table first, or null (uploaded already)
+#if QL_UNIT != 1
+__attribute__((visibility("hidden"))) hipError_t qmpc_lane_ref_upload_params(int pslot, hipStream_t s, const void* dev_params) {
+#if QL_UNIT == 2
+  return hipMemcpyToSymbolAsync(HIP_SYMBOL(ql_params), dev_params, sizeof(DevParams), sizeof(DevParams) * (size_t)pslot, hipMemcpyHostToDevice, s);
+#else
+  (void)pslot; (void)s; (void)dev_params;
+  return hipSuccess;      // one unit: one table
+#endif
+}
+__attribute__((visibility("hidden"))) hipError_t qmpc_lane_ref_launch(int nl, int pslot, int batch, hipStream_t s, const void* dev_params,
+                                                                       const double* rec, double* forces, qmpc_info* info, double* ws,
+                                                                       unsigned waves, unsigned used, int lanes, const int* perm, double* traj_u,
+                                                                       double* traj_x, size_t lds, long long* prof) {
+  const bool convex = nl == -4;
+  if (convex) nl = 4;
+#if QL_UNIT == 2
+  if (dev_params) {
+    const hipError_t e = qmpc_lane_ref_upload_params(pslot, s, dev_params);
+    if (e != hipSuccess) return e;
+  }
+#endif
+#if defined(QL_PROFILE)
+  long long* d_prof = prof;
+  DevParams P;
+  if (dev_params) memcpy(&P, dev_params, sizeof P); else memset(&P, 0, sizeof P);
+#endif
+  {
+    if (nl == 8)
+      hipLaunchKernelGGL(qmpc_lane_ref_kernel<8>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm,
+                         traj_u, traj_x, prof);
+    else if (convex)
+      hipLaunchKernelGGL((qmpc_lane_ref_kernel<4, MD_CONVEX>), dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used,
+                         lanes, perm, traj_u, traj_x, prof);
+    else {
+      static const int pair_ref_env = std::getenv("QMPC_LANE_PAIR") ? std::atoi(std::getenv("QMPC_LANE_PAIR")) : 1;
+      hipLaunchKernelGGL(qmpc_lane_ref_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used,
+                         (lanes == 32 && pair_ref_env) ? -34 : lanes, perm, traj_u, traj_x, prof);
+    }
+#if defined(QL_PROFILE)
+    {
+      static long long hp[16 * 1024];
+      if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(hp, d_prof, sizeof hp, hipMemcpyDeviceToHost) == hipSuccess) {
+        static const char* names[6] = {"B_AL", "C_AL (line search)", "A_AL", "S", "M (+tests)", "rest"};
+        const unsigned nw = waves < 1024 ? waves : 1024;
+        double sum[6] = {0}, tot = 0.0;
+        for (unsigned w = 0; w < nw; ++w) for (int i = 0; i < 6; ++i) sum[i] += (double)hp[16 * w + i];
+        for (int i = 0; i < 6; ++i) tot += sum[i];
+        std::fprintf(stderr, "lane ref profile: batch %d N %d waves %u, %.0f cycles per wavefront\n", batch, P.N, waves, tot / nw);
+        for (int i = 0; i < 6; ++i) std::fprintf(stderr, "  %-20s %10.0f cycles  %5.1f %%\n", names[i], sum[i] / nw, 100.0 * sum[i] / tot);
+      }
+    }
+#endif
+    return hipGetLastError();
+  }
+}
+#else
+__attribute__((visibility("hidden"))) hipError_t qmpc_lane_ref_upload_params(int pslot, hipStream_t s, const void* dev_params);
+__attribute__((visibility("hidden"))) hipError_t qmpc_lane_ref_launch(int nl, int pslot, int batch, hipStream_t s, const void* dev_params, const double* rec, double* forces,
+                                qmpc_info* info, double* ws, unsigned waves, unsigned used, int lanes, const int* perm, double* traj_u, double* traj_x,
+                                size_t lds, long long* prof);
+#endif
+#if QL_UNIT != 2
 // called from qmpc_hip.hip (declared there); hidden: not part of the C ABI
 __attribute__((visibility("hidden"))) size_t qmpc_lane_ws_bytes(int N, int nl, unsigned slots, int wide) {
   return sizeof(double) * lane_ws_elements(N, nl, wide != 0) * (size_t)slots;      // wide: handles in the reference's solver mode
@@ -590,6 +663,8 @@ __attribute__((visibility("hidden"))) int qmpc_lane_param_slots() { return kPara
 __attribute__((visibility("hidden"))) hipError_t qmpc_lane_upload_params(int pslot, hipStream_t s, const void* dev_params,
                                                                           size_t dev_params_size) {
   if (dev_params_size != sizeof(DevParams) || pslot < 0 || pslot >= kParamSlots) return hipErrorInvalidValue;
+  const hipError_t e = qmpc_lane_ref_upload_params(pslot, s, dev_params);      // (the reference mode's unit has its own table)
+  if (e != hipSuccess) return e;
   return hipMemcpyToSymbolAsync(HIP_SYMBOL(ql_params), dev_params, sizeof(DevParams), sizeof(DevParams) * (size_t)pslot,
                                 hipMemcpyHostToDevice, s);
 }
@@ -650,32 +725,8 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
 #endif
   if (P.mode == QMPC_MODE_REFERENCE) {      // the reference's own solver mode (QuatMpc with four or eight contact points, ConvexMpc): qmpc_lane_ref_kernel
     if (u_init) return hipErrorInvalidValue;
-    if (nl == 8)
-      hipLaunchKernelGGL(qmpc_lane_ref_kernel<8>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm,
-                         traj_u, traj_x, prof);
-    else if (convex)
-      hipLaunchKernelGGL((qmpc_lane_ref_kernel<4, MD_CONVEX>), dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used,
-                         lanes, perm, traj_u, traj_x, prof);
-    else {
-      static const int pair_ref_env = std::getenv("QMPC_LANE_PAIR") ? std::atoi(std::getenv("QMPC_LANE_PAIR")) : 1;
-      hipLaunchKernelGGL(qmpc_lane_ref_kernel<4>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used,
-                         (lanes == 32 && pair_ref_env) ? -34 : lanes, perm, traj_u, traj_x, prof);
-    }
-#if defined(QL_PROFILE)
-    {
-      static long long hp[16 * 1024];
-      if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(hp, d_prof, sizeof hp, hipMemcpyDeviceToHost) == hipSuccess) {
-        static const char* names[6] = {"B_AL", "C_AL (line search)", "A_AL", "S", "M (+tests)", "rest"};
-        const unsigned nw = waves < 1024 ? waves : 1024;
-        double sum[6] = {0}, tot = 0.0;
-        for (unsigned w = 0; w < nw; ++w) for (int i = 0; i < 6; ++i) sum[i] += (double)hp[16 * w + i];
-        for (int i = 0; i < 6; ++i) tot += sum[i];
-        std::fprintf(stderr, "lane ref profile: batch %d N %d waves %u, %.0f cycles per wavefront\n", batch, P.N, waves, tot / nw);
-        for (int i = 0; i < 6; ++i) std::fprintf(stderr, "  %-20s %10.0f cycles  %5.1f %%\n", names[i], sum[i] / nw, 100.0 * sum[i] / tot);
-      }
-    }
-#endif
-    return hipGetLastError();
+    return qmpc_lane_ref_launch(convex ? -4 : nl, pslot, batch, s, upload_params ? dev_params : nullptr, rec, forces, info, ws, waves, used, lanes, perm,
+                                traj_u, traj_x, lds, prof);
   }
   if (nl == 8)
     hipLaunchKernelGGL(qmpc_lane_kernel<8>, dim3(waves), dim3(kLaneWave), lds, s, pslot, rec, forces, info, batch, ws, used, lanes, perm, prof,
@@ -713,3 +764,4 @@ __attribute__((visibility("hidden"))) hipError_t qmpc_lane_launch(int nl, int ps
 #endif
   return hipGetLastError();
 }
+#endif      // QL_UNIT != 2

@@ -13,13 +13,14 @@ print("ISA metadata of the final build (hipcc --offload-arch=gfx950 -O2 <per-uni
 print("columns: kernel | vgpr_count | agpr_count | sgpr_count | vgpr_spill_count | sgpr_spill_count | private_segment_fixed_size (scratch bytes) | group_segment_fixed_size (static LDS)")
 WAVE = ["-mllvm", "-disable-machine-licm", "-mllvm", "-disable-machine-sink"]
 for tu, extra in (("qmpc_hip.hip", WAVE), ("qmpc_loop_fused.hip", WAVE), ("qmpc_wform.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
-                  ("qmpc_lane.hip", ["-mllvm", "-disable-lsr"])):
+                  ("qmpc_lane.hip", ["-mllvm", "-disable-lsr", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-DQL_UNIT=1"]),
+                  ("qmpc_lane_ref.hip", ["-mllvm", "-disable-lsr", "-DQL_UNIT=2"])):
     with tempfile.TemporaryDirectory() as d:
         asm = Path(d) / "tu.s"
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", *extra, "-std=c++17", "-S", "--cuda-device-only", "-o", str(asm),
                         str(CSRC / tu)], check=True, stderr=subprocess.DEVNULL)
         txt = asm.read_text()
-    print(f"---- translation unit {tu} (extra flags: {' '.join(extra)})" + (" (flags: -O2 -mllvm -disable-lsr; the kernel calls its passes as functions: the per-function figures follow the kernel rows)" if "lane" in tu else ""))
+    print(f"---- translation unit {tu} (extra flags: {' '.join(extra)})" + (" (the kernel calls its passes as functions: the per-function figures follow the kernel rows)" if "lane" in tu else ""))
     for m in re.finditer(r"- \.agpr_count:.*?\.wavefront_size:\s+\d+", txt, re.S):
         blk = m.group(0)
         g = lambda k: re.search(r"\." + k + r":\s+(\S+)", blk).group(1)
