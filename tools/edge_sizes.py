@@ -5,9 +5,7 @@ partly filled: every instance converged, forces and iteration words equal to tho
 import sys, numpy as np
 sys.path.insert(0, '.')
 import __graft_entry__ as g
-from oracle import pyoracle
 pkg = g._load_pkg(); lib = pkg.load_library()
-orc = pyoracle.Oracle() if hasattr(pyoracle, 'Oracle') else None
 for N, sizes in ((10, (14336, 14337, 20011, 32767, 32768, 32769)), (20, (14848, 14849, 32767))):
     p = pkg.default_params(N, 0, lib)
     rec = pkg.random_go1_trot_states(40000, config_id=4 if N == 10 else 3)
