@@ -15,6 +15,6 @@ if [ "$1" = "run" ]; then
 fi
 for o in $B/wf_*.o; do
   n=$(basename $o .o)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o tools/.prof/$n.so $B/qmpc_hip.o $B/qmpc_loop_fused.o $o $B/qmpc_lane.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o tools/.prof/$n.so $B/qmpc_hip.o $B/qmpc_loop_fused.o $o $B/qmpc_lane.o $B/qmpc_lane_ref.o
 done
 ls tools/.prof/wf_*.so
